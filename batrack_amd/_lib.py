@@ -1,0 +1,97 @@
+"""ctypes binding of include/batrack_ba.h (libbatrack_ba.so, built in-tree by
+`batrack_amd.build()` / `__graft_entry__.build()`).  No fallback: if the HIP
+library is missing every entry point raises."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "lib", "libbatrack_ba.so")
+SOURCES = ["ba_kernels.hip", "ba_plan.cpp", "ba_api.cpp"]
+HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", os.path.join("..", "..", "include", "batrack_ba.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+
+BT_OK, BT_EINVAL, BT_ENOMEM, BT_EHIP, BT_EUNSUPPORTED = 0, -1, -2, -3, -4
+ERRORS = {BT_EINVAL: "invalid argument", BT_ENOMEM: "out of memory", BT_EHIP: "HIP runtime error",
+          BT_EUNSUPPORTED: "unsupported graph (n > 255 free poses or a track seen by > 64 free cameras)"}
+LOSS = {"trivial": 0, "huber": 1, "cauchy": 2}
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in (
+        "E", "n_buf", "p_tot", "fixedp", "n_all", "n", "m", "pairs", "tiles", "slots", "erows",
+        "max_tile_cams", "nnz_blocks", "updates", "workspace_bytes", "sorted_input")]
+
+
+class BaArgs(ctypes.Structure):
+    _fields_ = [("poses", ctypes.c_void_p), ("patches", ctypes.c_void_p), ("mono_disp", ctypes.c_void_p),
+                ("intrinsics", ctypes.c_void_p), ("targets", ctypes.c_void_p), ("target_stride", ctypes.c_int64),
+                ("weights", ctypes.c_void_p), ("poses_out", ctypes.c_void_p), ("patches_out", ctypes.c_void_p),
+                ("bounds", ctypes.c_float * 4), ("lmbda", ctypes.c_float), ("ep", ctypes.c_float),
+                ("alpha", ctypes.c_float), ("loss", ctypes.c_int32), ("structure_only", ctypes.c_int32)]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU present."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    cmd = ["hipcc"] + HIPCC_FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"batrack_amd: HIP library {LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    L.bt_version.restype = i32
+    L.bt_target_arch.restype = ctypes.c_char_p
+    L.bt_plan_create.restype = i32
+    L.bt_plan_create.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, ctypes.POINTER(vp)]
+    L.bt_plan_destroy.restype = None
+    L.bt_plan_destroy.argtypes = [vp]
+    L.bt_plan_get_info.restype = i32
+    L.bt_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
+    L.bt_plan_workspace_bytes.restype = ctypes.c_size_t
+    L.bt_plan_workspace_bytes.argtypes = [vp]
+    L.bt_plan_array.restype = i64
+    L.bt_plan_array.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp)]
+    for name in ("bt_ba_step", "bt_ba_reduce", "bt_ba_solve_update"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, ctypes.POINTER(BaArgs), vp, vp]
+    L.bt_ba_step_timed.restype = i32
+    L.bt_ba_step_timed.argtypes = [vp, ctypes.POINTER(BaArgs), vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.bt_ba_system.restype = vp
+    L.bt_ba_system.argtypes = [vp, vp, ctypes.POINTER(i64)]
+    L.bt_ba_dx.restype = vp
+    L.bt_ba_dx.argtypes = [vp, vp]
+    L.bt_ba_status.restype = i32
+    L.bt_ba_status.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_int32)]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != BT_OK:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")

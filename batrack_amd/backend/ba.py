@@ -1,0 +1,107 @@
+"""`BA_rgbd_droid` — the reference's bundle-adjustment entry point
+(/root/reference/main/backend/ba.py:217-339), same signature and argument
+meaning, executed by the gfx950 kernels behind include/batrack_ba.h.
+
+Called exactly as BATRACK.update() does (/root/reference/main/batrack.py:869-875):
+
+    Gs, patches = BA_rgbd_droid(Gs, patches, patches_monodisp, intrinsics,
+                                targets_3d[..., :2], targets_3d[..., 2:], weights, lmbda,
+                                ii, jj, kk, bounds, ep=ep, fixedp=t0,
+                                structure_only=..., loss=..., alpha=0.05)
+
+Behaviour kept from the reference: returns NEW tensors (inputs untouched); with
+structure_only (or no free pose) the input SE3 object itself is returned
+(ba.py:336-339); `targets_disp` is accepted and never read; the whole disparity
+buffer is clamped to [1e-3, 10] (ba.py:333); a failed Cholesky leaves the poses
+re-normalised but unmoved (ba.py:9-13), nothing raises.
+
+There is no CPU path: tensors must live on a ROCm device and the HIP library
+must be built, otherwise this raises.
+"""
+import weakref
+
+import torch
+
+from .. import _lib
+from ..plan import Plan, Stepper
+from .lietorch import SE3
+
+_CACHE = {}          # key -> (stepper, (weakref ii, jj, kk))
+_CACHE_MAX = 8
+
+
+def _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, device):
+    """One plan per (edge list, fixedp): the caller keeps self.ii/jj/kk alive and
+    unmodified across the 2*ITER calls of an update() (batrack.py:869-875) and
+    replaces the tensors when edges are appended/removed (batrack.py:189-204)."""
+    key = (id(ii), id(jj), id(kk), ii._version, jj._version, kk._version,
+           ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii.numel(), int(fixedp), int(n_buf), int(p_tot), str(device))
+    hit = _CACHE.get(key)
+    if hit is not None:
+        stepper, refs = hit
+        if all(r() is t for r, t in zip(refs, (ii, jj, kk))):
+            return stepper
+        del _CACHE[key]
+    if len(_CACHE) >= _CACHE_MAX:
+        _CACHE.pop(next(iter(_CACHE)))
+    stepper = Stepper(Plan(ii, jj, kk, n_buf, p_tot, fixedp), device)
+    _CACHE[key] = (stepper, tuple(weakref.ref(t) for t in (ii, jj, kk)))
+    return stepper
+
+
+def clear_plan_cache():
+    _CACHE.clear()
+
+
+def _f32c(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"BA_rgbd_droid: `{what}` must be on the GPU (no CPU fallback in batrack_amd)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"BA_rgbd_droid: `{what}` must be float32 (batrack.py:74-91), got {t.dtype}")
+    return t
+
+
+def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda,
+                  ii, jj, kk, bounds, ep=100.0, PRINT=False, fixedp=1, structure_only=False,
+                  loss='trivial', alpha=0.5):
+    _lib.lib()                                   # raises if the HIP library is missing
+    P = _f32c(poses.data, "poses")
+    if P.dim() != 3 or P.shape[0] != 1 or P.shape[-1] != 7:
+        raise ValueError("poses must wrap a [1, N, 7] tensor (batch b = 1, ba.py:218)")
+    if patches.shape[0] != 1 or patches.shape[2] != 3 or patches[0, 0, 0].numel() != 1:
+        raise ValueError("patches must be [1, P_tot, 3, 1, 1] (patch size 1, batrack.py:45)")
+    if loss not in _lib.LOSS:
+        raise NotImplementedError(loss)              # ba.py:98-99
+    n_buf, p_tot, E = P.shape[1], patches.shape[1], ii.numel()
+    if E == 0:
+        raise ValueError("empty edge list")
+    dev = P.device
+    Pc = P.contiguous()
+    pat = _f32c(patches, "patches").reshape(p_tot, 3).contiguous()
+    mono = _f32c(patches_monodisp, "patches_monodisp").reshape(-1).contiguous()
+    intr = _f32c(intrinsics, "intrinsics").reshape(-1, 4).contiguous()
+    if mono.numel() != p_tot or intr.shape[0] != n_buf:
+        raise ValueError("patches_monodisp / intrinsics do not match the patch / pose buffers")
+    tg = _f32c(targets_2d, "targets_2d")
+    if tg.shape[-1] != 2 or tg.numel() != 2 * E:
+        raise ValueError("targets_2d must be [1, E, 2]")
+    tg = tg.reshape(E, 2) if tg.is_contiguous() else tg[0]
+    if tg.stride(1) != 1:                          # the caller's view has strides (3, 1): used in place
+        tg = tg.contiguous()
+    w = _f32c(weights, "weights").reshape(E, 2).contiguous()
+    if isinstance(lmbda, torch.Tensor):
+        if lmbda.numel() != 1:
+            raise NotImplementedError("per-track lmbda tensors are not supported")
+        lmbda = float(lmbda)
+    stepper = _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, dev)
+    so = bool(structure_only) or stepper.plan.n == 0
+    patches_out = torch.empty_like(pat)
+    poses_out = Pc if so else torch.empty_like(Pc)
+    stepper.step(Pc, pat, mono, intr, tg, tg.stride(0), w, poses_out, patches_out,
+                 bounds, lmbda, ep, alpha, loss, so)
+    if PRINT:
+        print("BA_rgbd_droid: PRINT is not implemented in batrack_amd (debug only, ba.py:244-245)")
+    out_patches = patches_out.view(1, p_tot, 3, 1, 1)
+    if so:
+        return poses, out_patches
+    return SE3(poses_out.view(1, n_buf, 7)), out_patches

@@ -1,0 +1,210 @@
+// ba_api.cpp — the C ABI declared in include/batrack_ba.h.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <new>
+
+#include "ba_kernels.hpp"
+
+#define BT_VERSION 100
+
+namespace bt {
+
+template <class T>
+static size_t put(std::vector<char> &buf, const std::vector<T> &v) {
+    size_t off = (buf.size() + 255) / 256 * 256;
+    buf.resize(off + v.size() * sizeof(T) + 1);
+    if (!v.empty()) std::memcpy(buf.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+}
+
+int upload_plan(bt_plan *pl) {
+    std::vector<char> buf;
+    const size_t o_kx = put(buf, pl->kx), o_top = put(buf, pl->trk_of_patch), o_loc = put(buf, pl->trk_loc);
+    const size_t o_pi = put(buf, pl->pair_i), o_pj = put(buf, pl->pair_j);
+    const size_t o_t0 = put(buf, pl->tile_trk0), o_tn = put(buf, pl->tile_ntrk), o_tc = put(buf, pl->tile_ncam);
+    const size_t o_c0 = put(buf, pl->tile_cam0), o_s0 = put(buf, pl->tile_slot0), o_sn = put(buf, pl->tile_nslot);
+    const size_t o_e0 = put(buf, pl->tile_erow0), o_cams = put(buf, pl->tile_cams);
+    const size_t o_se = put(buf, pl->slot_edge), o_sp = put(buf, pl->slot_pair), o_sl = put(buf, pl->slot_lab);
+    const size_t o_cp = put(buf, pl->col_ptr), o_ri = put(buf, pl->row_idx), o_up = put(buf, pl->upd_ptr), o_u = put(buf, pl->upd);
+    void *d = nullptr;
+    if (hipMalloc(&d, buf.size() + 256) != hipSuccess) return BT_ENOMEM;
+    if (hipMemcpy(d, buf.data(), buf.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return BT_EHIP; }
+    pl->dev_base = d;
+    const char *b = static_cast<const char *>(d);
+    const bt_plan_info &I = pl->info;
+    PlanDev &P = pl->dev;
+    P.E = (int)I.E; P.n_buf = (int)I.n_buf; P.p_tot = (int)I.p_tot; P.fixedp = (int)I.fixedp;
+    P.n_all = (int)I.n_all; P.n = (int)I.n; P.D = (int)(6 * I.n); P.m = (int)I.m; P.P = (int)I.pairs;
+    P.T = (int)I.tiles; P.slots = (int)I.slots; P.erows = (int)I.erows; P.nnzb = (int)I.nnz_blocks;
+    P.nupd = (int)I.updates; P.max_rows16 = pl->max_rows16;
+#define BT_I32(off) reinterpret_cast<const int32_t *>(b + (off))
+    P.kx = BT_I32(o_kx); P.trk_of_patch = BT_I32(o_top); P.trk_loc = BT_I32(o_loc);
+    P.pair_i = BT_I32(o_pi); P.pair_j = BT_I32(o_pj);
+    P.tile_trk0 = BT_I32(o_t0); P.tile_ntrk = BT_I32(o_tn); P.tile_ncam = BT_I32(o_tc); P.tile_cam0 = BT_I32(o_c0);
+    P.tile_slot0 = BT_I32(o_s0); P.tile_nslot = BT_I32(o_sn); P.tile_erow0 = BT_I32(o_e0); P.tile_cams = BT_I32(o_cams);
+    P.slot_edge = BT_I32(o_se); P.slot_pair = BT_I32(o_sp);
+    P.slot_lab = reinterpret_cast<const uint16_t *>(b + o_sl);
+    P.col_ptr = BT_I32(o_cp); P.row_idx = BT_I32(o_ri); P.upd_ptr = BT_I32(o_up); P.upd = BT_I32(o_u);
+#undef BT_I32
+    return configure_kernels(P);
+}
+
+static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
+    char *w = static_cast<char *>(ws);
+    const WsLayout &L = pl->ws;
+    StepArgs s{};
+    s.poses = a->poses; s.patches = a->patches; s.mono = a->mono_disp; s.intr = a->intrinsics;
+    s.targets = a->targets; s.weights = a->weights; s.tstride = (int)a->target_stride;
+    s.poses_out = a->poses_out; s.patches_out = a->patches_out;
+    s.b0 = a->bounds[0]; s.b1 = a->bounds[1]; s.b2 = a->bounds[2]; s.b3 = a->bounds[3];
+    s.lmbda = a->lmbda; s.ep = a->ep; s.alpha = a->alpha; s.loss = a->loss;
+    const size_t D = (size_t)(6 * pl->info.n);
+    s.S = reinterpret_cast<double *>(w + L.sys); s.y = s.S + D * D;
+    s.pairacc = reinterpret_cast<double *>(w + L.pairacc);
+    s.ptab = reinterpret_cast<float *>(w + L.ptab); s.qw = reinterpret_cast<float2 *>(w + L.qw);
+    s.esave = reinterpret_cast<float *>(w + L.esave); s.lfac = reinterpret_cast<float *>(w + L.lfac);
+    s.linv = reinterpret_cast<float *>(w + L.linv); s.zvec = reinterpret_cast<float *>(w + L.zvec);
+    s.dx = reinterpret_cast<float *>(w + L.dx); s.status = reinterpret_cast<int *>(w + L.status);
+    return s;
+}
+
+static int check(const bt_plan *pl, const bt_ba_args *a, const void *ws) {
+    if (!pl || !a || !ws || !pl->dev_base) return BT_EINVAL;
+    if (!a->poses || !a->patches || !a->mono_disp || !a->intrinsics || !a->patches_out) return BT_EINVAL;
+    if (pl->info.E > 0 && (!a->targets || !a->weights || a->target_stride < 2)) return BT_EINVAL;
+    if (a->loss < BT_LOSS_TRIVIAL || a->loss > BT_LOSS_CAUCHY) return BT_EINVAL;
+    return BT_OK;
+}
+
+// ba.py:316: "structure_only or n == 0" take the same branch
+static bool is_so(const bt_plan *pl, const bt_ba_args *a) { return a->structure_only != 0 || pl->info.n == 0; }
+
+}  // namespace bt
+
+using namespace bt;
+
+extern "C" {
+
+int bt_version(void) { return BT_VERSION; }
+const char *bt_target_arch(void) { return "gfx950"; }
+
+int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf,
+                   int64_t p_tot, int64_t fixedp, int64_t n_all_min, int on_device, int upload, bt_plan **out) {
+    if (!out || E < 0 || (E > 0 && (!ii || !jj || !kk))) return BT_EINVAL;
+    *out = nullptr;
+    std::vector<int64_t> host;
+    const int64_t *hi = ii, *hj = jj, *hk = kk;
+    if (on_device && E > 0) {
+        host.resize((size_t)(3 * E));
+        if (hipMemcpy(host.data(), ii, (size_t)E * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(host.data() + E, jj, (size_t)E * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(host.data() + 2 * E, kk, (size_t)E * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            return BT_EHIP;
+        hi = host.data(); hj = host.data() + E; hk = host.data() + 2 * E;
+    }
+    bt_plan *pl = new (std::nothrow) bt_plan();
+    if (!pl) return BT_ENOMEM;
+    int rc = BT_OK;
+    try {
+        rc = build_plan_host(hi, hj, hk, E, n_buf, p_tot, fixedp, n_all_min, pl);
+        if (rc == BT_OK && upload) rc = upload_plan(pl);
+    } catch (const std::bad_alloc &) {
+        rc = BT_ENOMEM;
+    }
+    if (rc != BT_OK) { bt_plan_destroy(pl); return rc; }
+    *out = pl;
+    return BT_OK;
+}
+
+void bt_plan_destroy(bt_plan *pl) {
+    if (!pl) return;
+    if (pl->dev_base) (void)hipFree(pl->dev_base);
+    delete pl;
+}
+
+int bt_plan_get_info(const bt_plan *pl, bt_plan_info *info) {
+    if (!pl || !info) return BT_EINVAL;
+    *info = pl->info;
+    return BT_OK;
+}
+
+size_t bt_plan_workspace_bytes(const bt_plan *pl) { return pl ? pl->ws.total : 0; }
+
+int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
+    if (!pl || !name || !data) return -1;
+#define BT_ARR(n)                                                        \
+    if (std::strcmp(name, #n) == 0) { *data = pl->n.data(); return (int64_t)pl->n.size(); }
+    BT_ARR(kx) BT_ARR(trk_of_patch) BT_ARR(trk_loc) BT_ARR(pair_i) BT_ARR(pair_j)
+    BT_ARR(tile_trk0) BT_ARR(tile_ntrk) BT_ARR(tile_ncam) BT_ARR(tile_cam0) BT_ARR(tile_slot0)
+    BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
+    BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd)
+#undef BT_ARR
+    return -1;
+}
+
+int bt_ba_reduce(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
+    const int rc = check(pl, a, ws);
+    if (rc != BT_OK) return rc;
+    const StepArgs s = make_args(pl, a, ws);
+    return launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), is_so(pl, a), static_cast<hipStream_t>(stream));
+}
+
+int bt_ba_solve_update(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
+    const int rc = check(pl, a, ws);
+    if (rc != BT_OK) return rc;
+    const bool so = is_so(pl, a);
+    if (!so && !a->poses_out) return BT_EINVAL;
+    if (!so && a->poses_out == a->poses) return BT_EINVAL;
+    const StepArgs s = make_args(pl, a, ws);
+    const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
+    return launch_solve_update(pl->dev, s, so, copy_poses, static_cast<hipStream_t>(stream));
+}
+
+int bt_ba_step(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
+    const int rc = bt_ba_reduce(pl, a, ws, stream);
+    return rc != BT_OK ? rc : bt_ba_solve_update(pl, a, ws, stream);
+}
+
+int bt_ba_step_timed(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream, float *ms) {
+    const int rc = check(pl, a, ws);
+    if (rc != BT_OK || !ms) return rc != BT_OK ? rc : BT_EINVAL;
+    const bool so = is_so(pl, a);
+    if (!so && (!a->poses_out || a->poses_out == a->poses)) return BT_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t ev[10];
+    for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return BT_EHIP;
+    const StepArgs s = make_args(pl, a, ws);
+    const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
+    int r = launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), so, st, ev);
+    if (r == BT_OK) r = launch_solve_update(pl->dev, s, so, copy_poses, st, ev);
+    if (r == BT_OK && hipStreamSynchronize(st) != hipSuccess) r = BT_EHIP;
+    const bool ran[5] = { true, pl->dev.T > 0, !so && pl->dev.P > 0, !so, true };
+    for (int k = 0; k < 5; ++k) {
+        ms[k] = 0.0f;
+        if (r == BT_OK && ran[k] && hipEventElapsedTime(&ms[k], ev[2 * k], ev[2 * k + 1]) != hipSuccess) ms[k] = -1.0f;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return r;
+}
+
+double *bt_ba_system(const bt_plan *pl, void *ws, int64_t *count) {
+    if (!pl || !ws) return nullptr;
+    const int64_t D = 6 * pl->info.n;
+    if (count) *count = D * D + D;
+    return reinterpret_cast<double *>(static_cast<char *>(ws) + pl->ws.sys);
+}
+
+float *bt_ba_dx(const bt_plan *pl, void *ws) {
+    return (pl && ws) ? reinterpret_cast<float *>(static_cast<char *>(ws) + pl->ws.dx) : nullptr;
+}
+
+int bt_ba_status(const bt_plan *pl, void *ws, void *stream, int32_t *status) {
+    if (!pl || !ws || !status) return BT_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(status, static_cast<char *>(ws) + pl->ws.status, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return BT_EHIP;
+    return hipStreamSynchronize(st) == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+}  // extern "C"

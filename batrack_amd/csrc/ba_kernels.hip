@@ -1,0 +1,658 @@
+// ba_kernels.hip — gfx950 (CDNA4, wave64) kernels of the BA step.
+//
+// One BA_rgbd_droid call (/root/reference/main/backend/ba.py:217-339) becomes
+//   k_prep           relative pose of every camera pair (Gij is per PAIR, not per
+//                    edge: projective_ops.py:61) + clearing of the accumulators
+//   k_tile           per-edge reprojection, Jacobians, robust weights
+//                    (projective_ops.py:54-100, ba.py:228-266), per-track C/w/E,
+//                    per-pair J^T W J, and the tile's Schur product E Q E^T
+//                    (ba.py:284-323) — one workgroup of 4 waves per 64-track tile
+//   k_pair_finalize  B and v of ba.py:279-290 from the per-pair sums
+//   k_solve          damped block-sparse Cholesky of the reduced camera system,
+//                    forward/back substitution (ba.py:60-70,323-325)
+//   k_update         back-substitution of the depths, clamp, pose retraction
+//                    (ba.py:328-337, groups.py:153-156)
+//
+// Algebra used throughout: Ji = -Jj * Ad(Gij), so with
+// per-pair sums  Bjj = sum Jj^T W Jj,  gj = sum Jj^T W r  the blocks are
+//   B[a,a] += Ad^T Bjj Ad   B[b,a] += -Bjj Ad   B[b,b] += Bjj
+//   v[a]   += -Ad^T gj      v[b]   += gj        E[a,k] += -Ad^T Ej   E[b,k] += Ej
+// and Ji is never formed per edge.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "ba_kernels.hpp"
+
+namespace bt {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ k_prep
+__device__ inline void quat_to_rot(const double *q, double R[9]) {
+    const double n = 1.0 / sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+    const double x = q[0]*n, y = q[1]*n, z = q[2]*n, w = q[3]*n;
+    R[0] = 1 - 2*(y*y + z*z); R[1] = 2*(x*y - z*w);     R[2] = 2*(x*z + y*w);
+    R[3] = 2*(x*y + z*w);     R[4] = 1 - 2*(x*x + z*z); R[5] = 2*(y*z - x*w);
+    R[6] = 2*(x*z - y*w);     R[7] = 2*(y*z + x*w);     R[8] = 1 - 2*(x*x + y*y);
+}
+
+__global__ __launch_bounds__(256) void k_prep(PlanDev pd, StepArgs a, size_t zero_count, int do_zero) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nth = (size_t)gridDim.x * blockDim.x;
+    if (do_zero)
+        for (size_t i = gid; i < zero_count; i += nth) a.S[i] = 0.0;
+    if (gid >= (size_t)pd.P) return;
+    const int i = pd.pair_i[gid], j = pd.pair_j[gid];
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+    if (i != j) {                       // Gij = Gj * Gi^-1 ; a self edge is exactly the identity
+        double qi[4], qj[4], Ri[9], Rj[9], ti[3], tj[3];
+        for (int c = 0; c < 3; ++c) { ti[c] = a.poses[7*i + c]; tj[c] = a.poses[7*j + c]; }
+        for (int c = 0; c < 4; ++c) { qi[c] = a.poses[7*i + 3 + c]; qj[c] = a.poses[7*j + 3 + c]; }
+        quat_to_rot(qi, Ri); quat_to_rot(qj, Rj);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                R[3*r + c] = Rj[3*r]*Ri[3*c] + Rj[3*r + 1]*Ri[3*c + 1] + Rj[3*r + 2]*Ri[3*c + 2];
+        for (int r = 0; r < 3; ++r)
+            t[r] = tj[r] - (R[3*r]*ti[0] + R[3*r + 1]*ti[1] + R[3*r + 2]*ti[2]);
+    }
+    float *g = a.ptab + gid * kPairGeomFloats;
+    for (int c = 0; c < 9; ++c) g[c] = (float)R[c];
+    for (int c = 0; c < 3; ++c) g[9 + c] = (float)t[c];
+    // source intrinsics as (1/fx, 1/fy, cx, cy): iproj divides (projective_ops.py:25-26)
+    g[12] = 1.0f / a.intr[4*i]; g[13] = 1.0f / a.intr[4*i + 1]; g[14] = a.intr[4*i + 2]; g[15] = a.intr[4*i + 3];
+    for (int c = 0; c < 4; ++c) g[16 + c] = a.intr[4*j + c];
+}
+
+// ------------------------------------------------------------------ per-edge math
+struct EdgeQ {
+    float a0, a2, a3, a4, a5;      // Jj row 0 = (a0, 0, a2, a3, a4, a5)
+    float b1, b2, b3, b4, b5;      // Jj row 1 = (0, b1, b2, b3, b4, b5)
+    float jz0, jz1, r0, r1, W0, W1;
+};
+
+__device__ __forceinline__ float robust_weight(float r, int loss) {          // ba.py:81-100
+    const float s = r * r;
+    if (loss == BT_LOSS_HUBER) return s > 1.0f ? 1.0f / sqrtf(s) : 1.0f;
+    if (loss == BT_LOSS_CAUCHY) return 1.0f / (1.0f + s);
+    return 1.0f;
+}
+
+__device__ __forceinline__ void edge_eval(const float *g, float x, float y, float d, float tu, float tv,
+                                          float w0, float w1, const StepArgs &a, EdgeQ &o) {
+    // projective_ops.py:19-29 (iproj), :61-66 (act4), :43-45 (proj)
+    const float X0 = (x - g[14]) * g[12], Y0 = (y - g[15]) * g[13];
+    const float X = fmaf(g[0], X0, fmaf(g[1], Y0, g[2])) + g[9] * d;
+    const float Y = fmaf(g[3], X0, fmaf(g[4], Y0, g[5])) + g[10] * d;
+    const float Z = fmaf(g[6], X0, fmaf(g[7], Y0, g[8])) + g[11] * d;
+    const float fx = g[16], fy = g[17];
+    const float iz = 1.0f / fmaxf(Z, 1e-2f);
+    const float u = fmaf(fx, iz * X, g[18]), v = fmaf(fy, iz * Y, g[19]);
+    // projective_ops.py:80-98
+    const float dj = fabsf(Z) > 0.2f ? 1.0f / Z : 0.0f;
+    const float A = fx * dj, B = -fx * X * dj * dj, C = fy * dj, Dd = -fy * Y * dj * dj;
+    o.a0 = d * A;  o.a2 = d * B;  o.a3 = B * Y;            o.a4 = A * Z - B * X;  o.a5 = -A * Y;
+    o.b1 = d * C;  o.b2 = d * Dd; o.b3 = Dd * Y - C * Z;   o.b4 = -Dd * X;        o.b5 = C * X;
+    o.jz0 = fmaf(A, g[9], B * g[11]);
+    o.jz1 = fmaf(C, g[10], Dd * g[11]);
+    // ba.py:230-251
+    const float r0 = tu - u, r1 = tv - v;
+    float vld = Z > 0.2f ? 1.0f : 0.0f;
+    vld *= sqrtf(r0 * r0 + r1 * r1) < 250.0f ? 1.0f : 0.0f;
+    vld *= (u > a.b0 && v > a.b1 && u < a.b2 && v < a.b3) ? 1.0f : 0.0f;
+    o.W0 = vld * (w0 * robust_weight(r0, a.loss));
+    o.W1 = vld * (w1 * robust_weight(r1, a.loss));
+    o.r0 = vld * r0; o.r1 = vld * r1;
+}
+
+// Sum v[0..31] over the lanes of a wave; afterwards every lane holds, in v[0],
+// the total of element ((lane >> 1) & 31).  32 shuffles instead of 32 * 6.
+__device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) {
+#define BT_RS_STEP(M, H)                                            \
+    {                                                               \
+        const bool up = (lane & (M)) != 0;                          \
+        _Pragma("unroll") for (int i = 0; i < (H); ++i) {           \
+            const float send = up ? v[i] : v[i + (H)];              \
+            const float keep = up ? v[i + (H)] : v[i];              \
+            v[i] = keep + __shfl_xor(send, (M));                    \
+        }                                                           \
+    }
+    BT_RS_STEP(32, 16) BT_RS_STEP(16, 8) BT_RS_STEP(8, 4) BT_RS_STEP(4, 2) BT_RS_STEP(2, 1)
+#undef BT_RS_STEP
+    v[0] += __shfl_xor(v[0], 1);
+}
+
+// ------------------------------------------------------------------ k_tile
+// LDS: Eh[R16][66] local E (row = 6*local_cam + comp, column = lane = track),
+// row R = 6*ncam holds w' (the augmented column that yields the Schur RHS),
+// then Cw[2][64] and Qs[64].
+template <bool SO>
+__global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
+    const int R = 6 * ncam, R16 = SO ? 0 : ((R + 1 + 15) >> 4) << 4;
+    float *Eh = lds, *Cw = lds + R16 * kLdsRowStride, *Qs = Cw + 128;
+    for (int i = tid; i < R16 * kLdsRowStride + 192; i += 256) lds[i] = 0.0f;
+
+    const int trk = pd.tile_trk0[tile] + lane;
+    const bool has_trk = lane < ntrk;
+    int patch = 0;
+    float px = 0.0f, py = 0.0f, pdisp = 0.0f;
+    if (has_trk) {
+        patch = pd.kx[trk];
+        px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2];
+    }
+    __syncthreads();
+
+    float Cacc = 0.0f, wacc = 0.0f;
+    const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
+    for (int s = wave; s < nslot; s += 4) {
+        const size_t idx = (size_t)(slot0 + s) * kLanes + lane;
+        const int e = pd.slot_edge[idx];
+        const bool act = e >= 0;
+        const int pair = pd.slot_pair[idx];
+        const unsigned lab = pd.slot_lab[idx];
+        float tu = 0.0f, tv = 0.0f, w0 = 0.0f, w1 = 0.0f;
+        if (act) {
+            const float *tp = a.targets + (size_t)e * a.tstride;
+            tu = tp[0]; tv = tp[1];
+            const float2 w = reinterpret_cast<const float2 *>(a.weights)[e];
+            w0 = w.x; w1 = w.y;
+        }
+        float g[kPairGeomFloats];
+        {
+            const float4 *g4 = reinterpret_cast<const float4 *>(a.ptab + (size_t)pair * kPairGeomFloats);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const float4 t4 = g4[c];
+                g[4*c] = t4.x; g[4*c + 1] = t4.y; g[4*c + 2] = t4.z; g[4*c + 3] = t4.w;
+            }
+        }
+        EdgeQ q;
+        edge_eval(g, px, py, pdisp, tu, tv, w0, w1, a, q);
+        if (!act) { q.W0 = 0.0f; q.W1 = 0.0f; q.r0 = 0.0f; q.r1 = 0.0f; }
+
+        // C, w of the track (ba.py:287,292)
+        Cacc += q.W0 * q.jz0 * q.jz0 + q.W1 * q.jz1 * q.jz1;
+        wacc += q.W0 * q.jz0 * q.r0 + q.W1 * q.jz1 * q.r1;
+        if (SO) continue;
+
+        const float wa0 = q.W0 * q.a0, wa2 = q.W0 * q.a2, wa3 = q.W0 * q.a3, wa4 = q.W0 * q.a4, wa5 = q.W0 * q.a5;
+        const float wb1 = q.W1 * q.b1, wb2 = q.W1 * q.b2, wb3 = q.W1 * q.b3, wb4 = q.W1 * q.b4, wb5 = q.W1 * q.b5;
+        // Ej = Jj^T W Jz (ba.py:263) and Ei = -Ad^T Ej
+        float Ej[6] = { wa0 * q.jz0, wb1 * q.jz1, fmaf(wa2, q.jz0, wb2 * q.jz1), fmaf(wa3, q.jz0, wb3 * q.jz1),
+                        fmaf(wa4, q.jz0, wb4 * q.jz1), fmaf(wa5, q.jz0, wb5 * q.jz1) };
+        const unsigned la = lab & 0xffu, lb = lab >> 8;
+        if (act && lb != 0xffu) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) atomicAdd(&Eh[(lb * 6 + c) * kLdsRowStride + lane], Ej[c]);
+        }
+        if (act && la != 0xffu) {
+            // o_tau = R^T e_tau ; o_phi = R^T (e_tau x t + e_phi)      (se3.h:58-67)
+            const float cx = Ej[1]*g[11] - Ej[2]*g[10] + Ej[3];
+            const float cy = Ej[2]*g[9]  - Ej[0]*g[11] + Ej[4];
+            const float cz = Ej[0]*g[10] - Ej[1]*g[9]  + Ej[5];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float ot = g[c]*Ej[0] + g[3 + c]*Ej[1] + g[6 + c]*Ej[2];
+                const float op = g[c]*cx + g[3 + c]*cy + g[6 + c]*cz;
+                atomicAdd(&Eh[(la * 6 + c) * kLdsRowStride + lane], -ot);
+                atomicAdd(&Eh[(la * 6 + 3 + c) * kLdsRowStride + lane], -op);
+            }
+        }
+
+        // per-pair sums: Bjj (21, row-major upper triangle) and gj (6)   (ba.py:260,266)
+        float vals[32];
+        vals[0] = wa0 * q.a0;  vals[1] = 0.0f;        vals[2] = wa0 * q.a2;  vals[3] = wa0 * q.a3;
+        vals[4] = wa0 * q.a4;  vals[5] = wa0 * q.a5;
+        vals[6] = wb1 * q.b1;  vals[7] = wb1 * q.b2;  vals[8] = wb1 * q.b3;  vals[9] = wb1 * q.b4;  vals[10] = wb1 * q.b5;
+        vals[11] = fmaf(wa2, q.a2, wb2 * q.b2); vals[12] = fmaf(wa2, q.a3, wb2 * q.b3);
+        vals[13] = fmaf(wa2, q.a4, wb2 * q.b4); vals[14] = fmaf(wa2, q.a5, wb2 * q.b5);
+        vals[15] = fmaf(wa3, q.a3, wb3 * q.b3); vals[16] = fmaf(wa3, q.a4, wb3 * q.b4); vals[17] = fmaf(wa3, q.a5, wb3 * q.b5);
+        vals[18] = fmaf(wa4, q.a4, wb4 * q.b4); vals[19] = fmaf(wa4, q.a5, wb4 * q.b5);
+        vals[20] = fmaf(wa5, q.a5, wb5 * q.b5);
+        vals[21] = wa0 * q.r0; vals[22] = wb1 * q.r1;
+        vals[23] = fmaf(wa2, q.r0, wb2 * q.r1); vals[24] = fmaf(wa3, q.r0, wb3 * q.r1);
+        vals[25] = fmaf(wa4, q.r0, wb4 * q.r1); vals[26] = fmaf(wa5, q.r0, wb5 * q.r1);
+        vals[27] = vals[28] = vals[29] = vals[30] = vals[31] = 0.0f;
+
+        unsigned long long todo = __ballot(act);
+        while (todo) {                              // one pass per distinct pair in this slot
+            const int leader = __ffsll((long long)todo) - 1;
+            const int p0 = __shfl(pair, leader);
+            const bool mine = act && pair == p0;
+            float v[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) v[c] = mine ? vals[c] : 0.0f;
+            wave_reduce_scatter32(v, lane);
+            const int vi = (lane >> 1) & 31;
+            if ((lane & 1) == 0 && vi < 27)
+                atomicAdd(&a.pairacc[(size_t)p0 * kPairAccStride + vi], (double)v[0]);
+            todo &= ~__ballot(mine);
+        }
+    }
+
+    atomicAdd(&Cw[lane], Cacc);
+    atomicAdd(&Cw[64 + lane], wacc);
+    __syncthreads();
+    if (wave == 0) {                                                   // ba.py:296-311
+        float Q = 0.0f, wp = 0.0f;
+        if (has_trk) {
+            const float mono = a.mono[patch];
+            const float pm = mono > 1e-2f ? 1.0f : 0.0f;
+            float Ca = Cw[lane] + pm * a.alpha;
+            Ca = Ca + a.lmbda;
+            wp = Cw[64 + lane] - pm * a.alpha * (pdisp - mono);
+            Q = 1.0f / Ca;
+            a.qw[trk] = make_float2(Q, wp);
+        }
+        if (!SO) { Qs[lane] = Q; Eh[R * kLdsRowStride + lane] = wp; }
+    }
+    if (SO) return;
+    __syncthreads();
+
+    // keep E for the depth back-substitution (ba.py:328)
+    for (int row = wave; row < R; row += 4)
+        a.esave[((size_t)pd.tile_erow0[tile] + row) * kLanes + lane] = Eh[row * kLdsRowStride + lane];
+
+    // Schur product of the tile on the matrix cores: out[i][j] = sum_k Q_k Eh[i][k] Eh[j][k]
+    // over the 64 tracks; row R gives -(E Q w').  f64 MFMA so that the 64-term sums
+    // are exact products accumulated in double (DESIGN.md "precision").
+    const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
+    const int *cams = pd.tile_cams + pd.tile_cam0[tile];
+    for (int t = wave; t < ntl; t += 4) {
+        int ti = 0, base = 0;
+        while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
+        const int tj = t - base;
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        const float *ar = Eh + (16 * ti + (lane & 15)) * kLdsRowStride + (lane >> 4);
+        const float *br = Eh + (16 * tj + (lane & 15)) * kLdsRowStride + (lane >> 4);
+        const float *qr = Qs + (lane >> 4);
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const double av = (double)ar[4 * ks] * (double)qr[4 * ks];
+            const double bv = (double)br[4 * ks];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+        const int col = 16 * tj + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + (lane >> 4) + 4 * r;
+            if (col < R && row <= R) {
+                const int gc = 6 * cams[col / 6] + col % 6;
+                if (row == R) {
+                    atomicAdd(&a.y[gc], -acc[r]);
+                } else {
+                    const int gr = 6 * cams[row / 6] + row % 6;
+                    if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ k_pair_finalize
+// One wave per camera pair, in double.  sym index of (p<=q) in the 21-vector:
+__device__ __forceinline__ int sym21(int p, int q) {
+    if (p > q) { const int t = p; p = q; q = t; }
+    return p * 6 - p * (p - 1) / 2 + (q - p);
+}
+
+__global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
+    __shared__ double sB[4][36], sAd[4][36], sM[4][36], sg[4][6];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + w;
+    const bool live = p < pd.P;
+    int ia = -1, ib = -1;
+    if (live) {
+        ia = pd.pair_i[p] - pd.fixedp; ib = pd.pair_j[p] - pd.fixedp;
+        const double *acc = a.pairacc + (size_t)p * kPairAccStride;
+        const float *g = a.ptab + (size_t)p * kPairGeomFloats;
+        if (lane < 36) {
+            const int r = lane / 6, c = lane % 6;
+            sB[w][lane] = acc[sym21(r, c)];
+            // Ad = [[R, [t]x R], [0, R]]                                   (se3.h:58-67)
+            double v = 0.0;
+            if (r < 3 && c < 3) v = g[3*r + c];
+            else if (r >= 3 && c >= 3) v = g[3*(r - 3) + (c - 3)];
+            else if (r < 3 && c >= 3) {
+                const int cc = c - 3;
+                const double t0 = g[9], t1 = g[10], t2 = g[11];
+                const double R0 = g[cc], R1 = g[3 + cc], R2 = g[6 + cc];
+                v = r == 0 ? (-t2 * R1 + t1 * R2) : r == 1 ? (t2 * R0 - t0 * R2) : (-t1 * R0 + t0 * R1);
+            }
+            sAd[w][lane] = v;
+        } else if (lane < 42) {
+            sg[w][lane - 36] = acc[21 + lane - 36];
+        }
+    }
+    __syncthreads();
+    if (live && lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        double m = 0.0;
+        for (int s = 0; s < 6; ++s) m += sB[w][6*r + s] * sAd[w][6*s + c];
+        sM[w][lane] = m;                                          // M = Bjj Ad
+    }
+    __syncthreads();
+    if (!live) return;
+    const int D = pd.D;
+    if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        if (ia >= 0) {                                            // B[a,a] += Ad^T M
+            double v = 0.0;
+            for (int s = 0; s < 6; ++s) v += sAd[w][6*s + r] * sM[w][6*s + c];
+            if (r >= c) atomicAdd(&a.S[(size_t)(6*ia + r) * D + 6*ia + c], v);
+        }
+        if (ib >= 0 && r >= c) atomicAdd(&a.S[(size_t)(6*ib + r) * D + 6*ib + c], sB[w][lane]);
+        if (ia >= 0 && ib >= 0) {
+            if (ia > ib)      atomicAdd(&a.S[(size_t)(6*ia + r) * D + 6*ib + c], -sM[w][6*c + r]);   // B[a,b] = -M^T
+            else if (ib > ia) atomicAdd(&a.S[(size_t)(6*ib + r) * D + 6*ia + c], -sM[w][6*r + c]);   // B[b,a] = -M
+            else if (r >= c)  atomicAdd(&a.S[(size_t)(6*ia + r) * D + 6*ia + c], -(sM[w][6*r + c] + sM[w][6*c + r]));
+        }
+    } else if (lane < 42) {
+        const int c = lane - 36;
+        if (ia >= 0) {
+            double v = 0.0;
+            for (int s = 0; s < 6; ++s) v += sAd[w][6*s + c] * sg[w][s];
+            atomicAdd(&a.y[6*ia + c], -v);
+        }
+        if (ib >= 0) atomicAdd(&a.y[6*ib + c], sg[w][c]);
+    }
+}
+
+// ------------------------------------------------------------------ k_solve
+// Damped, block-sparse (6x6 blocks) right-looking Cholesky of the reduced camera
+// system, with y carried as an extra block row so the forward substitution is
+// part of the factorisation.  A <- S + (ep + lm * diag S) I  (ba.py:67); a
+// non-positive pivot gives dX = 0 (ba.py:9-13); a NaN in dX retries once with
+// lm = 1e-3 (ba.py:324-325).  One workgroup; the factor lives in the workspace.
+__device__ inline bool chol6_inv(float *Ablk, float *Linv) {
+    // in: lower triangle of a 6x6 block (row-major).  out: L in place, L^-1 in Linv.
+    float L[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) L[r][c] = c <= r ? Ablk[6*r + c] : 0.0f;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        float s = L[c][c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) s -= L[c][k] * L[c][k];
+        if (!(s > 0.0f)) ok = false;
+        const float l = sqrtf(s), il = 1.0f / l;
+        L[c][c] = l;
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+            float t = L[r][c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) t -= L[r][k] * L[c][k];
+            L[r][c] = t * il;
+        }
+    }
+    float Li[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (r < c) { Li[r][c] = 0.0f; continue; }
+            float t = r == c ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = c; k < r; ++k) t -= L[r][k] * Li[k][c];
+            Li[r][c] = t / L[r][r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { Ablk[6*r + c] = L[r][c]; Linv[6*r + c] = Li[r][c]; }
+    return ok;
+}
+
+__global__ __launch_bounds__(1024) void k_solve(PlanDev pd, StepArgs a) {
+    __shared__ float part[kMaxFree * 6 + 6];
+    __shared__ float tq[6];
+    __shared__ int flags[2];          // [0] cholesky failed, [1] NaN in dX
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int n = pd.n, D = pd.D;
+    float *Lw = a.lfac, *Li = a.linv, *z = a.zvec;
+    int status = BT_SOLVE_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const float lm = attempt == 0 ? 1e-4f : 1e-3f;
+        if (tid < 2) flags[tid] = 0;
+        // load the structurally non-zero blocks of S (+ damping) and y
+        for (int idx = tid; idx < pd.nnzb * 36; idx += nth) {
+            const int b = idx / 36, e = idx % 36, r = e / 6, c = e % 6;
+            const int row = pd.row_idx[b];
+            int lo = 0, hi = n;                       // column of block b: last j with col_ptr[j] <= b
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pd.col_ptr[mid] <= b) lo = mid; else hi = mid; }
+            const int col = lo;
+            double v = (row > col || r >= c) ? a.S[(size_t)(6*row + r) * D + 6*col + c] : 0.0;
+            if (row == col && r == c) v = v + ((double)a.ep + (double)lm * v);
+            Lw[idx] = (float)v;
+        }
+        for (int i = tid; i < D; i += nth) z[i] = (float)a.y[i];
+        __syncthreads();
+
+        for (int j = 0; j < n; ++j) {
+            const int dpos = pd.col_ptr[j], cnt = pd.col_ptr[j + 1] - dpos - 1;
+            if (tid == 0) {
+                if (!chol6_inv(Lw + (size_t)dpos * 36, Li + (size_t)j * 36)) flags[0] = 1;
+                float zz[6];
+                for (int r = 0; r < 6; ++r) {                       // z_j <- L_jj^-1 z_j
+                    float t = 0.0f;
+                    for (int c = 0; c <= r; ++c) t += Li[j*36 + 6*r + c] * z[6*j + c];
+                    zz[r] = t;
+                }
+                for (int r = 0; r < 6; ++r) z[6*j + r] = zz[r];
+            }
+            __syncthreads();
+            // L_ij = A_ij L_jj^-T, one thread per block row; then y_i -= L_ij z_j
+            for (int idx = tid; idx < cnt * 6; idx += nth) {
+                const int s = idx / 6, r = idx % 6;
+                float *blk = Lw + (size_t)(dpos + 1 + s) * 36 + 6*r;
+                float in[6], out[6];
+                for (int c = 0; c < 6; ++c) in[c] = blk[c];
+                float dot = 0.0f;
+                for (int c = 0; c < 6; ++c) {
+                    float t = 0.0f;
+                    for (int k = 0; k <= c; ++k) t += in[k] * Li[j*36 + 6*c + k];
+                    out[c] = t;
+                    dot += t * z[6*j + c];
+                }
+                for (int c = 0; c < 6; ++c) blk[c] = out[c];
+                z[6 * pd.row_idx[dpos + 1 + s] + r] -= dot;
+            }
+            __syncthreads();
+            const int u0 = pd.upd_ptr[j], nu = pd.upd_ptr[j + 1] - u0;
+            for (int idx = tid; idx < nu * 36; idx += nth) {
+                const int t = idx / 36, e = idx % 36, r = e / 6, c = e % 6;
+                const int *tr = pd.upd + (size_t)(u0 + t) * 3;
+                const float *L1 = Lw + (size_t)tr[0] * 36 + 6*r, *L2 = Lw + (size_t)tr[1] * 36 + 6*c;
+                float acc = 0.0f;
+                for (int k = 0; k < 6; ++k) acc += L1[k] * L2[k];
+                Lw[(size_t)tr[2] * 36 + e] -= acc;
+            }
+            __syncthreads();
+        }
+
+        // back substitution x = L^-T z, in place in z
+        for (int j = n - 1; j >= 0; --j) {
+            const int dpos = pd.col_ptr[j], cnt = pd.col_ptr[j + 1] - dpos - 1;
+            for (int idx = tid; idx < cnt * 6; idx += nth) {
+                const int s = idx / 6, c = idx % 6;
+                const float *blk = Lw + (size_t)(dpos + 1 + s) * 36;
+                const float *xr = z + 6 * pd.row_idx[dpos + 1 + s];
+                float t = 0.0f;
+                for (int r = 0; r < 6; ++r) t += blk[6*r + c] * xr[r];
+                part[idx] = t;
+            }
+            __syncthreads();
+            if (tid < 6) {
+                float t = z[6*j + tid];
+                for (int s = 0; s < cnt; ++s) t -= part[6*s + tid];
+                tq[tid] = t;
+            }
+            __syncthreads();
+            if (tid < 6) {
+                float x = 0.0f;
+                for (int r = tid; r < 6; ++r) x += Li[j*36 + 6*r + tid] * tq[r];
+                z[6*j + tid] = x;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < D; i += nth) if (z[i] != z[i]) flags[1] = 1;
+        __syncthreads();
+        const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
+        __syncthreads();
+        if (failed) {                                   // zeros, and zeros hold no NaN: done
+            for (int i = tid; i < D; i += nth) z[i] = 0.0f;
+            status = BT_SOLVE_CHOL_FAILED;
+            break;
+        }
+        if (!has_nan) break;
+        status = BT_SOLVE_RETRIED;
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += nth) a.dx[i] = z[i];
+    if (tid == 0) a.status[0] = status;
+}
+
+// ------------------------------------------------------------------ k_update
+__device__ inline void retract_pose(const float *pin, const float *xi, float *pout) {
+    // poses' = Exp(xi) * G  (groups.py:153-156; so3.h:153-190; se3.h:134-142), in double
+    const double tau[3] = {xi[0], xi[1], xi[2]}, phi[3] = {xi[3], xi[4], xi[5]};
+    const double th2 = phi[0]*phi[0] + phi[1]*phi[1] + phi[2]*phi[2], th = sqrt(th2);
+    double imag, real, c1, c2;
+    if (th < 1e-6) {
+        const double th4 = th2 * th2;
+        imag = 0.5 - th2 / 48.0 + th4 / 3840.0;
+        real = 1.0 - th2 / 8.0 + th4 / 384.0;
+        c1 = 0.5 - th2 / 24.0;
+        c2 = 1.0 / 6.0 - th2 / 120.0;
+    } else {
+        imag = sin(0.5 * th) / th;
+        real = cos(0.5 * th);
+        c1 = (1.0 - cos(th)) / th2;
+        c2 = (th - sin(th)) / (th2 * th);
+    }
+    double qe[4] = {imag * phi[0], imag * phi[1], imag * phi[2], real};
+    double nq = 1.0 / sqrt(qe[0]*qe[0] + qe[1]*qe[1] + qe[2]*qe[2] + qe[3]*qe[3]);
+    for (int c = 0; c < 4; ++c) qe[c] *= nq;
+    const double pxt[3] = {phi[1]*tau[2] - phi[2]*tau[1], phi[2]*tau[0] - phi[0]*tau[2], phi[0]*tau[1] - phi[1]*tau[0]};
+    const double ppt[3] = {phi[1]*pxt[2] - phi[2]*pxt[1], phi[2]*pxt[0] - phi[0]*pxt[2], phi[0]*pxt[1] - phi[1]*pxt[0]};
+    double te[3];
+    for (int c = 0; c < 3; ++c) te[c] = tau[c] + c1 * pxt[c] + c2 * ppt[c];
+    double q[4] = {pin[3], pin[4], pin[5], pin[6]};
+    nq = 1.0 / sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+    for (int c = 0; c < 4; ++c) q[c] *= nq;
+    const double t[3] = {pin[0], pin[1], pin[2]};
+    double qo[4] = { qe[3]*q[0] + qe[0]*q[3] + qe[1]*q[2] - qe[2]*q[1],
+                     qe[3]*q[1] - qe[0]*q[2] + qe[1]*q[3] + qe[2]*q[0],
+                     qe[3]*q[2] + qe[0]*q[1] - qe[1]*q[0] + qe[2]*q[3],
+                     qe[3]*q[3] - qe[0]*q[0] - qe[1]*q[1] - qe[2]*q[2] };
+    nq = 1.0 / sqrt(qo[0]*qo[0] + qo[1]*qo[1] + qo[2]*qo[2] + qo[3]*qo[3]);
+    double ux = qe[1]*t[2] - qe[2]*t[1], uy = qe[2]*t[0] - qe[0]*t[2], uz = qe[0]*t[1] - qe[1]*t[0];
+    ux += ux; uy += uy; uz += uz;
+    pout[0] = (float)(te[0] + t[0] + qe[3]*ux + (qe[1]*uz - qe[2]*uy));
+    pout[1] = (float)(te[1] + t[1] + qe[3]*uy + (qe[2]*ux - qe[0]*uz));
+    pout[2] = (float)(te[2] + t[2] + qe[3]*uz + (qe[0]*uy - qe[1]*ux));
+    for (int c = 0; c < 4; ++c) pout[3 + c] = (float)(qo[c] * nq);
+}
+
+template <bool SO>
+__global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_poses) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < pd.p_tot) {
+        const float x = a.patches[3*gid], y = a.patches[3*gid + 1], d = a.patches[3*gid + 2];
+        const int k = pd.trk_of_patch[gid];
+        float dz = 0.0f;
+        if (k >= 0) {
+            const float2 qw = a.qw[k];
+            if (SO) {
+                dz = qw.x * qw.y;                                        // ba.py:316-317
+            } else {
+                const int loc = pd.trk_loc[k], tile = loc >> 6, ln = loc & 63;
+                const int R = 6 * pd.tile_ncam[tile];
+                const float *base = a.esave + (size_t)pd.tile_erow0[tile] * kLanes + ln;
+                const int *cams = pd.tile_cams + pd.tile_cam0[tile];
+                float acc = 0.0f;
+                for (int c = 0; c < R; c += 6) {
+                    const float *dxc = a.dx + 6 * cams[c / 6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) acc = fmaf(base[(size_t)(c + r) * kLanes], dxc[r], acc);
+                }
+                dz = qw.x * (qw.y - acc);                               // ba.py:328
+            }
+        }
+        float dd = d + dz;                                              // ba.py:333 (whole buffer)
+        dd = dd < 1e-3f ? 1e-3f : dd;
+        dd = dd > 10.0f ? 10.0f : dd;
+        a.patches_out[3*gid] = x; a.patches_out[3*gid + 1] = y; a.patches_out[3*gid + 2] = dd;
+    } else if (do_poses && gid < pd.p_tot + pd.n_buf) {
+        const int p = gid - pd.p_tot;
+        if (SO) {
+            for (int c = 0; c < 7; ++c) a.poses_out[7*p + c] = a.poses[7*p + c];
+        } else {
+            float xi[6] = {0, 0, 0, 0, 0, 0};
+            if (p >= pd.fixedp && p < pd.fixedp + pd.n)
+                for (int c = 0; c < 6; ++c) xi[c] = a.dx[6 * (p - pd.fixedp) + c];
+            retract_pose(a.poses + 7*p, xi, a.poses_out + 7*p);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
+    return (size_t)((so ? 0 : pd.max_rows16) * kLdsRowStride + 192) * sizeof(float);
+}
+
+int configure_kernels(const PlanDev &pd) {
+    const size_t need = tile_lds_bytes(pd, false);
+    if (need > 160 * 1024) return BT_EUNSUPPORTED;
+    if (need > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)
+            return BT_EHIP;
+    }
+    return BT_OK;
+}
+
+// ev == nullptr: plain launches.  ev != nullptr: hipExtLaunchKernelGGL with a
+// (start, stop) event pair per kernel — ev[2*k], ev[2*k+1], k = 0 prep, 1 tile,
+// 2 pair_finalize, 3 solve, 4 update — so bench.py can read each kernel's own
+// duration on the stream it ran on.
+#define BT_LAUNCH(K, kern, grid, block, lds, ...)                                                        \
+    do {                                                                                                 \
+        if (ev) hipExtLaunchKernelGGL(kern, grid, block, lds, st, ev[2 * (K)], ev[2 * (K) + 1], 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                \
+    } while (0)
+
+int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev) {
+    const int zero = so ? 0 : 1;
+    size_t nb = (size_t)(pd.P + 255) / 256;
+    if (zero) nb = nb > (zero_doubles + 2047) / 2048 ? nb : (zero_doubles + 2047) / 2048;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    BT_LAUNCH(0, k_prep, dim3((unsigned)nb), dim3(256), 0, pd, a, zero_doubles, zero);
+    if (pd.T > 0) {
+        if (so) BT_LAUNCH(1, k_tile<true>, dim3(pd.T), dim3(256), tile_lds_bytes(pd, true), pd, a);
+        else    BT_LAUNCH(1, k_tile<false>, dim3(pd.T), dim3(256), tile_lds_bytes(pd, false), pd, a);
+    }
+    if (!so && pd.P > 0)
+        BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev) {
+    if (!so) BT_LAUNCH(3, k_solve, dim3(1), dim3(1024), 0, pd, a);
+    const int do_poses = so ? (copy_poses ? 1 : 0) : 1;
+    const int total = pd.p_tot + (do_poses ? pd.n_buf : 0);
+    if (so) BT_LAUNCH(4, k_update<true>, dim3((total + 255) / 256), dim3(256), 0, pd, a, do_poses);
+    else    BT_LAUNCH(4, k_update<false>, dim3((total + 255) / 256), dim3(256), 0, pd, a, do_poses);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+#undef BT_LAUNCH
+
+}  // namespace bt

@@ -1,0 +1,27 @@
+// ba_kernels.hpp — argument block and launchers shared by ba_kernels.hip / ba_api.cpp.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "ba_plan.hpp"
+
+namespace bt {
+
+// bt_ba_args plus the workspace regions, passed by value to every kernel.
+struct StepArgs {
+    const float *poses, *patches, *mono, *intr, *targets, *weights;
+    int tstride;
+    float *poses_out, *patches_out;
+    float b0, b1, b2, b3, lmbda, ep, alpha;
+    int loss;
+    double *S, *y, *pairacc;      // S, y, pairacc are contiguous (cleared together)
+    float *ptab;
+    float2 *qw;
+    float *esave, *lfac, *linv, *zvec, *dx;
+    int *status;
+};
+
+int configure_kernels(const PlanDev &pd);
+int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev = nullptr);
+int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev = nullptr);
+
+}  // namespace bt

@@ -1,0 +1,236 @@
+// ba_plan.cpp — host analysis of one BA edge list (no HIP calls in this file).
+//
+// What the reference recomputes inside every BA_rgbd_droid call
+//   n = max(ii, jj) + 1                      /root/reference/main/backend/ba.py:219
+//   kx, kk' = torch.unique(kk, sorted=True)  /root/reference/main/backend/ba.py:276
+//   dense E [n, m, 6] scatter targets        /root/reference/main/backend/ba.py:284-285
+// is done here once per edge list, and laid out for the tile kernel:
+//   * tracks sorted by patch slot; a TILE is up to 64 consecutive tracks whose
+//     union of free cameras stays small; lane l of the tile's wave owns track l;
+//   * SLOT s of a tile holds the s-th edge of each of its tracks (edges of a track
+//     ordered by camera pair, so tracks with the same observation pattern put
+//     the same pair in the same slot and the per-pair reductions are wave-uniform);
+//   * the distinct (ii, jj) camera pairs (their relative pose is per pair, not per edge);
+//   * the block-sparsity of the reduced camera system and of its Cholesky factor.
+#include "ba_plan.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace bt {
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void layout_workspace(bt_plan *pl) {
+    const bt_plan_info &I = pl->info;
+    const size_t D = (size_t)(6 * I.n);
+    WsLayout w{};
+    size_t off = 0;
+    w.sys = off;      off += (D * D + D) * sizeof(double);
+    off = align_up(off, 256);
+    w.pairacc = off;  off += (size_t)I.pairs * kPairAccStride * sizeof(double);
+    off = align_up(off, 256);
+    w.zero_bytes = off - w.sys;
+    w.ptab = off;     off = align_up(off + (size_t)I.pairs * kPairGeomFloats * sizeof(float), 256);
+    w.qw = off;       off = align_up(off + (size_t)I.m * 2 * sizeof(float), 256);
+    w.esave = off;    off = align_up(off + (size_t)I.erows * kLanes * sizeof(float), 256);
+    w.lfac = off;     off = align_up(off + (size_t)I.nnz_blocks * 36 * sizeof(float), 256);
+    w.linv = off;     off = align_up(off + (size_t)I.n * 36 * sizeof(float), 256);
+    w.zvec = off;     off = align_up(off + D * sizeof(float), 256);
+    w.dx = off;       off = align_up(off + D * sizeof(float) + 64, 256);
+    w.status = off;   off = align_up(off + 64, 256);
+    w.total = off;
+    pl->ws = w;
+    pl->info.workspace_bytes = (int64_t)w.total;
+}
+
+int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                    int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min, bt_plan *pl) {
+    if (E < 0 || n_buf <= 0 || p_tot <= 0 || fixedp < 0 || n_all_min < 0 || n_all_min > n_buf) return BT_EINVAL;
+    if (E > (int64_t)0x7fffffff / 2 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;
+    bt_plan_info &I = pl->info;
+    I = bt_plan_info{};
+    I.E = E; I.n_buf = n_buf; I.p_tot = p_tot; I.fixedp = fixedp;
+
+    // ---- n_all, validation (ba.py:219) ------------------------------------
+    int64_t n_all = n_all_min;
+    bool sorted = true;
+    for (int64_t e = 0; e < E; ++e) {
+        if (ii[e] < 0 || jj[e] < 0 || ii[e] >= n_buf || jj[e] >= n_buf) return BT_EINVAL;
+        if (kk[e] < 0 || kk[e] >= p_tot) return BT_EINVAL;
+        n_all = std::max(n_all, std::max(ii[e], jj[e]) + 1);
+        if (e && kk[e] < kk[e - 1]) sorted = false;
+    }
+    I.n_all = n_all;
+    I.sorted_input = sorted ? 1 : 0;
+    const int64_t n = std::max<int64_t>(n_all - fixedp, 0);
+    I.n = n;
+    if (n > kMaxFree) return BT_EUNSUPPORTED;
+
+    // ---- unique tracks, ascending (ba.py:276) ------------------------------
+    pl->trk_of_patch.assign((size_t)p_tot, -1);
+    for (int64_t e = 0; e < E; ++e) pl->trk_of_patch[(size_t)kk[e]] = 0;
+    int32_t m = 0;
+    pl->kx.clear();
+    for (int64_t p = 0; p < p_tot; ++p)
+        if (pl->trk_of_patch[(size_t)p] == 0) { pl->trk_of_patch[(size_t)p] = m++; pl->kx.push_back((int32_t)p); }
+    I.m = m;
+
+    // ---- distinct camera pairs, ascending (i, j) ---------------------------
+    std::vector<int32_t> pair_of((size_t)(n_all * n_all), -1);
+    for (int64_t e = 0; e < E; ++e) pair_of[(size_t)(ii[e] * n_all + jj[e])] = 0;
+    pl->pair_i.clear(); pl->pair_j.clear();
+    for (int64_t key = 0; key < n_all * n_all; ++key)
+        if (pair_of[(size_t)key] == 0) {
+            pair_of[(size_t)key] = (int32_t)pl->pair_i.size();
+            pl->pair_i.push_back((int32_t)(key / n_all));
+            pl->pair_j.push_back((int32_t)(key % n_all));
+        }
+    I.pairs = (int64_t)pl->pair_i.size();
+
+    // ---- edges grouped by track, ordered by (pair, original index) ---------
+    std::vector<int32_t> off((size_t)m + 1, 0);
+    for (int64_t e = 0; e < E; ++e) off[(size_t)pl->trk_of_patch[(size_t)kk[e]] + 1]++;
+    for (int32_t k = 0; k < m; ++k) off[(size_t)k + 1] += off[(size_t)k];
+    std::vector<int32_t> ord((size_t)E), cur(off.begin(), off.end() - 1);
+    for (int64_t e = 0; e < E; ++e) ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = (int32_t)e;
+    auto pair_id = [&](int32_t e) { return pair_of[(size_t)(ii[e] * n_all + jj[e])]; };
+    for (int32_t k = 0; k < m; ++k)
+        std::sort(ord.begin() + off[(size_t)k], ord.begin() + off[(size_t)k + 1], [&](int32_t a, int32_t b) {
+            const int32_t pa = pair_id(a), pb = pair_id(b);
+            return pa != pb ? pa < pb : a < b;
+        });
+
+    // ---- tiles: greedy over sorted tracks ----------------------------------
+    pl->tile_trk0.clear(); pl->tile_ntrk.clear(); pl->tile_ncam.clear(); pl->tile_cam0.clear();
+    pl->tile_slot0.clear(); pl->tile_nslot.clear(); pl->tile_erow0.clear(); pl->tile_cams.clear();
+    pl->trk_loc.assign((size_t)m, 0);
+    std::vector<int32_t> stamp((size_t)n + 1, -1);      // last tile-epoch that contains camera c
+    std::vector<int32_t> tstamp((size_t)n + 1, -1);     // last track that contains camera c
+    std::vector<int32_t> tile_set, trk_set;
+    int32_t epoch = 0, trk0 = 0;
+    int64_t slots = 0, erows = 0;
+    int max_cams = 0;
+    auto close_tile = [&](int32_t trk_end) {
+        if (trk_end == trk0) return;
+        std::sort(tile_set.begin(), tile_set.end());
+        const int32_t T = (int32_t)pl->tile_trk0.size();
+        int32_t nslot = 0;
+        for (int32_t k = trk0; k < trk_end; ++k) {
+            nslot = std::max(nslot, off[(size_t)k + 1] - off[(size_t)k]);
+            pl->trk_loc[(size_t)k] = (T << 6) | (k - trk0);
+        }
+        pl->tile_trk0.push_back(trk0); pl->tile_ntrk.push_back(trk_end - trk0);
+        pl->tile_ncam.push_back((int32_t)tile_set.size());
+        pl->tile_cam0.push_back((int32_t)pl->tile_cams.size());
+        pl->tile_cams.insert(pl->tile_cams.end(), tile_set.begin(), tile_set.end());
+        pl->tile_slot0.push_back((int32_t)slots); pl->tile_nslot.push_back(nslot);
+        pl->tile_erow0.push_back((int32_t)erows);
+        slots += nslot; erows += 6 * (int64_t)tile_set.size();
+        max_cams = std::max(max_cams, (int)tile_set.size());
+        tile_set.clear(); ++epoch; trk0 = trk_end;
+    };
+    for (int32_t k = 0; k < m; ++k) {
+        trk_set.clear();
+        for (int32_t s = off[(size_t)k]; s < off[(size_t)k + 1]; ++s) {
+            const int32_t e = ord[(size_t)s];
+            const int64_t cams[2] = { ii[e] - fixedp, jj[e] - fixedp };
+            for (int64_t c : cams)
+                if (c >= 0 && tstamp[(size_t)c] != k) { tstamp[(size_t)c] = k; trk_set.push_back((int32_t)c); }
+        }
+        if ((int)trk_set.size() > kTileCamHard) return BT_EUNSUPPORTED;
+        int add = 0;
+        for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) ++add;
+        const int limit = std::max<int>(kTileCamSoft, (int)trk_set.size());
+        if (k - trk0 >= kLanes || (k > trk0 && (int)tile_set.size() + add > limit)) close_tile(k);
+        for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) { stamp[(size_t)c] = epoch; tile_set.push_back(c); }
+    }
+    close_tile(m);
+    const int32_t T = (int32_t)pl->tile_trk0.size();
+    I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
+    pl->max_rows16 = (int)((6 * max_cams + 1 + 15) / 16 * 16);
+
+    // ---- slot arrays [slots][64] -------------------------------------------
+    pl->slot_edge.assign((size_t)slots * kLanes, -1);
+    pl->slot_pair.assign((size_t)slots * kLanes, 0);
+    pl->slot_lab.assign((size_t)slots * kLanes, 0xffff);
+    std::vector<int32_t> local((size_t)n + 1, -1);
+    for (int32_t t = 0; t < T; ++t) {
+        const int32_t c0 = pl->tile_cam0[(size_t)t], nc = pl->tile_ncam[(size_t)t];
+        for (int32_t c = 0; c < nc; ++c) local[(size_t)pl->tile_cams[(size_t)(c0 + c)]] = c;
+        for (int32_t l = 0; l < pl->tile_ntrk[(size_t)t]; ++l) {
+            const int32_t k = pl->tile_trk0[(size_t)t] + l;
+            for (int32_t s = off[(size_t)k]; s < off[(size_t)k + 1]; ++s) {
+                const int32_t e = ord[(size_t)s];
+                const size_t idx = ((size_t)pl->tile_slot0[(size_t)t] + (size_t)(s - off[(size_t)k])) * kLanes + (size_t)l;
+                const int64_t a = ii[e] - fixedp, b = jj[e] - fixedp;
+                const uint16_t la = a >= 0 ? (uint16_t)local[(size_t)a] : 0xff;
+                const uint16_t lb = b >= 0 ? (uint16_t)local[(size_t)b] : 0xff;
+                pl->slot_edge[idx] = e;
+                pl->slot_pair[idx] = pair_id(e);
+                pl->slot_lab[idx] = (uint16_t)(la | (lb << 8));
+            }
+        }
+    }
+
+    // ---- block structure of S (lower) and symbolic Cholesky ----------------
+    // S[u][v] (u >= v) may be non-zero if u and v share a tile (Schur term,
+    // ba.py:321) or form a camera pair with both ends free (B, ba.py:279-282).
+    std::vector<std::vector<uint8_t>> nz((size_t)n, std::vector<uint8_t>((size_t)n, 0));
+    for (int64_t c = 0; c < n; ++c) nz[(size_t)c][(size_t)c] = 1;
+    for (int32_t t = 0; t < T; ++t) {
+        const int32_t c0 = pl->tile_cam0[(size_t)t], nc = pl->tile_ncam[(size_t)t];
+        for (int32_t u = 0; u < nc; ++u)
+            for (int32_t v = 0; v <= u; ++v)
+                nz[(size_t)pl->tile_cams[(size_t)(c0 + u)]][(size_t)pl->tile_cams[(size_t)(c0 + v)]] = 1;
+    }
+    for (size_t p = 0; p < pl->pair_i.size(); ++p) {
+        const int64_t a = pl->pair_i[p] - fixedp, b = pl->pair_j[p] - fixedp;
+        if (a >= 0 && b >= 0) nz[(size_t)std::max(a, b)][(size_t)std::min(a, b)] = 1;
+    }
+    // column structures (rows > j), then fill: struct(parent(j)) |= struct(j) \ {parent(j)}
+    std::vector<std::vector<int32_t>> cs((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        for (int64_t r = j + 1; r < n; ++r) if (nz[(size_t)r][(size_t)j]) cs[(size_t)j].push_back((int32_t)r);
+    }
+    for (int64_t j = 0; j < n; ++j) {
+        auto &sj = cs[(size_t)j];
+        std::sort(sj.begin(), sj.end());
+        sj.erase(std::unique(sj.begin(), sj.end()), sj.end());
+        if (sj.empty()) continue;
+        auto &sp = cs[(size_t)sj[0]];
+        sp.insert(sp.end(), sj.begin() + 1, sj.end());
+    }
+    pl->col_ptr.assign((size_t)n + 1, 0);
+    pl->row_idx.clear();
+    for (int64_t j = 0; j < n; ++j) {
+        pl->col_ptr[(size_t)j] = (int32_t)pl->row_idx.size();
+        pl->row_idx.push_back((int32_t)j);
+        pl->row_idx.insert(pl->row_idx.end(), cs[(size_t)j].begin(), cs[(size_t)j].end());
+    }
+    pl->col_ptr[(size_t)n] = (int32_t)pl->row_idx.size();
+    I.nnz_blocks = (int64_t)pl->row_idx.size();
+    // update triples of the right-looking factorisation
+    auto find_pos = [&](int32_t col, int32_t row) {
+        const auto b = pl->row_idx.begin() + pl->col_ptr[(size_t)col], e = pl->row_idx.begin() + pl->col_ptr[(size_t)col + 1];
+        return (int32_t)(std::lower_bound(b, e, row) - pl->row_idx.begin());
+    };
+    pl->upd_ptr.assign((size_t)n + 1, 0);
+    pl->upd.clear();
+    for (int64_t j = 0; j < n; ++j) {
+        pl->upd_ptr[(size_t)j] = (int32_t)(pl->upd.size() / 3);
+        const int32_t b = pl->col_ptr[(size_t)j] + 1, e = pl->col_ptr[(size_t)j + 1];
+        for (int32_t s = b; s < e; ++s)
+            for (int32_t t2 = b; t2 <= s; ++t2) {
+                pl->upd.push_back(s); pl->upd.push_back(t2);
+                pl->upd.push_back(find_pos(pl->row_idx[(size_t)t2], pl->row_idx[(size_t)s]));
+            }
+    }
+    pl->upd_ptr[(size_t)n] = (int32_t)(pl->upd.size() / 3);
+    I.updates = (int64_t)(pl->upd.size() / 3);
+
+    layout_workspace(pl);
+    return BT_OK;
+}
+
+}  // namespace bt

@@ -1,0 +1,62 @@
+// ba_plan.hpp — structure of one BA edge list, shared by the host planner
+// (ba_plan.cpp), the kernels (ba_kernels.hip) and the C ABI (ba_api.cpp).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/batrack_ba.h"
+
+namespace bt {
+
+constexpr int kLanes = 64;          // tracks per wave tile (one lane = one track)
+constexpr int kTileCamSoft = 16;    // close a tile when its camera union would exceed this
+constexpr int kTileCamHard = 64;    // a single track may not see more free cameras than this
+constexpr int kMaxFree = 255;       // free poses supported by the reduced solver
+constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj + 6 gj)
+constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
+constexpr int kLdsRowStride = 66;   // floats per local E row (bank-conflict-free)
+
+// Device-side view: raw pointers into one device allocation + sizes.
+struct PlanDev {
+    int E, n_buf, p_tot, fixedp, n_all, n, D, m, P, T, slots, erows, nnzb, nupd, max_rows16;
+    const int32_t *kx, *trk_of_patch, *trk_loc;
+    const int32_t *pair_i, *pair_j;
+    const int32_t *tile_trk0, *tile_ntrk, *tile_ncam, *tile_cam0, *tile_slot0, *tile_nslot, *tile_erow0;
+    const int32_t *tile_cams;
+    const int32_t *slot_edge, *slot_pair;
+    const uint16_t *slot_lab;
+    const int32_t *col_ptr, *row_idx, *upd_ptr, *upd;
+};
+
+// Byte offsets of the regions inside the caller's workspace.
+struct WsLayout {
+    size_t sys, pairacc, zero_bytes;   // [sys, sys+zero_bytes) is cleared every reduce
+    size_t ptab, qw, esave, lfac, linv, zvec, dx, status, total;
+};
+
+}  // namespace bt
+
+struct bt_plan {
+    bt_plan_info info{};
+    std::vector<int32_t> kx, trk_of_patch, trk_loc;
+    std::vector<int32_t> pair_i, pair_j;
+    std::vector<int32_t> tile_trk0, tile_ntrk, tile_ncam, tile_cam0, tile_slot0, tile_nslot, tile_erow0;
+    std::vector<int32_t> tile_cams;
+    std::vector<int32_t> slot_edge, slot_pair;
+    std::vector<uint16_t> slot_lab;
+    std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd;
+    int max_rows16 = 16;
+    bt::WsLayout ws{};
+    void *dev_base = nullptr;   // one device allocation holding every array above
+    bt::PlanDev dev{};
+};
+
+namespace bt {
+// Pure host analysis (no HIP).  Returns BT_OK or an error code.
+int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                    int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min, bt_plan *plan);
+// Copies the arrays to the device and fills plan->dev (ba_api.cpp).
+int upload_plan(bt_plan *plan);
+}  // namespace bt

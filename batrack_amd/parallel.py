@@ -1,0 +1,104 @@
+"""Track-sharded multi-GPU BA step (new functionality — the
+reference is single-GPU, main/batrack.py:73-104).
+
+One process per GPU.  Tracks are split into `world` contiguous ranges of the
+sorted track list, balanced by edge count; a rank owns the edges, disparities
+and priors of its tracks; poses and intrinsics are replicated.  Per step:
+
+    bt_ba_reduce        partial reduced system [S | y] of the rank's tracks
+    all_reduce(SUM)     the ONE exchange: (6n)^2 + 6n float64 (RCCL over xGMI)
+    bt_ba_solve_update  identical solve on every rank, own depths, all poses
+
+No second exchange inside the iteration; `gather_patches` merges the ranks'
+disparities when the caller wants the full buffer back.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition_tracks(kk, world):
+    """Split the sorted distinct tracks of `kk` into `world` contiguous ranges with
+    near-equal edge counts.  Returns the list of (lo, hi) patch-id bounds, hi exclusive."""
+    kk = np.asarray(kk.cpu() if isinstance(kk, torch.Tensor) else kk)
+    if kk.size == 0:
+        return [(0, 0)] * world
+    ids, counts = np.unique(kk, return_counts=True)
+    csum = np.cumsum(counts)
+    total = csum[-1]
+    bounds, lo_idx = [], 0
+    for r in range(world):
+        target = total * (r + 1) / world
+        hi_idx = int(np.searchsorted(csum, target - 1e-9, side="left")) + 1 if r < world - 1 else len(ids)
+        hi_idx = max(hi_idx, lo_idx)
+        hi_idx = min(hi_idx, len(ids))
+        lo = int(ids[lo_idx]) if lo_idx < len(ids) else int(ids[-1]) + 1
+        hi = int(ids[hi_idx]) if hi_idx < len(ids) else int(ids[-1]) + 1
+        bounds.append((lo, hi))
+        lo_idx = hi_idx
+    return bounds
+
+
+def shard_edges(kk, world, rank):
+    """Indices (ascending, int64 tensor on kk's device) of the edges rank `rank` owns."""
+    lo, hi = partition_tracks(kk, world)[rank]
+    kt = kk if isinstance(kk, torch.Tensor) else torch.as_tensor(kk)
+    return torch.nonzero((kt >= lo) & (kt < hi), as_tuple=False).reshape(-1)
+
+
+def allreduce_system(system, group=None):
+    """Sum the partial reduced systems in place.  `system` is Stepper.system (float64
+    [S | y]); backend nccl (= RCCL) on GPUs, gloo in CPU tests."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(system, op=dist.ReduceOp.SUM, group=group)
+    return system
+
+
+class ShardedBA:
+    """BA_rgbd_droid over a track shard.  Construct on every rank with the FULL edge
+    list and inputs; each rank keeps only its own edges."""
+
+    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, device, world=None, rank=None, group=None):
+        from .plan import Plan, Stepper
+        self.group = group
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        self.device = torch.device(device)
+        self.idx = shard_edges(kk, self.world, self.rank).to(ii.device)
+        n_all = int(max(int(ii.max()), int(jj.max()))) + 1
+        self.ii, self.jj, self.kk = ii[self.idx].contiguous(), jj[self.idx].contiguous(), kk[self.idx].contiguous()
+        self.plan = Plan(self.ii, self.jj, self.kk, n_buf, p_tot, fixedp, n_all_min=n_all)
+        self.stepper = Stepper(self.plan, self.device)
+        lo, hi = partition_tracks(kk, self.world)[self.rank]
+        self.owned = (lo, hi)
+
+    def local(self, per_edge):
+        """Select this rank's rows of a per-edge tensor ([E, ...])."""
+        return per_edge[self.idx.to(per_edge.device)].contiguous()
+
+    def step(self, poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
+             bounds, lmbda, ep, alpha, loss, structure_only):
+        """targets / weights are already local (see `local`).  Same argument order as Stepper.step."""
+        args = (poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
+                bounds, lmbda, ep, alpha, loss, structure_only)
+        so = bool(structure_only) or self.plan.n == 0
+        self.stepper.step(*args, phase="reduce")
+        if not so:
+            allreduce_system(self.stepper.system, self.group)
+        self.stepper.step(*args, phase="solve_update")
+
+    def gather_patches(self, patches_out):
+        """Merge disparities: every patch slot is owned by exactly one rank (its track
+        range); slots outside every range are identical on all ranks."""
+        if self.world == 1:
+            return patches_out
+        ranges = [None] * self.world
+        dist.all_gather_object(ranges, self.owned, group=self.group)
+        lo, hi = self.owned
+        mine = torch.zeros_like(patches_out)
+        mine[lo:hi] = patches_out[lo:hi]
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM, group=self.group)
+        covered = torch.zeros(patches_out.shape[0], dtype=torch.bool, device=patches_out.device)
+        for a, b in ranges:
+            covered[a:b] = True
+        return torch.where(covered[:, None], mine, patches_out)

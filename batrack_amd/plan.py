@@ -1,0 +1,144 @@
+"""Plan and step objects over the C ABI (include/batrack_ba.h).
+
+`Plan` owns one bt_plan (the structure of an edge list: what the reference
+recomputes per call at ba.py:219,276).  `Stepper` binds a plan to device buffers
+and runs BA_rgbd_droid-equivalent steps with no allocation on the call path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_NP_TYPES = {"slot_lab": np.uint16}
+PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0", "tile_ntrk", "tile_ncam",
+               "tile_cam0", "tile_slot0", "tile_nslot", "tile_erow0", "tile_cams", "slot_edge", "slot_pair",
+               "slot_lab", "col_ptr", "row_idx", "upd_ptr", "upd")
+
+
+class Plan:
+    """bt_plan handle.  ii/jj/kk: int64 torch tensors (CPU or GPU) or numpy arrays."""
+
+    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, upload=True, n_all_min=0):
+        L = _lib.lib()
+        self._lib = L
+        self._h = ctypes.c_void_p()
+        self._keep = None
+        on_device = 0
+        if isinstance(ii, np.ndarray):
+            arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (ii, jj, kk)]
+            ptrs = [a.ctypes.data for a in arrs]
+            E = arrs[0].shape[0]
+        else:
+            import torch
+            arrs = [a.contiguous() for a in (ii, jj, kk)]
+            for a in arrs:
+                if a.dtype != torch.int64:
+                    raise TypeError("edge indices must be int64 (batrack.py:100-102)")
+            on_device = 1 if arrs[0].is_cuda else 0
+            ptrs = [a.data_ptr() for a in arrs]
+            E = arrs[0].numel()
+        self._keep = arrs
+        rc = L.bt_plan_create(ptrs[0], ptrs[1], ptrs[2], E, int(n_buf), int(p_tot), int(fixedp),
+                              int(n_all_min), on_device, 1 if upload else 0, ctypes.byref(self._h))
+        _lib.check(rc, "bt_plan_create")
+        self._keep = None
+        info = _lib.PlanInfo()
+        _lib.check(L.bt_plan_get_info(self._h, ctypes.byref(info)), "bt_plan_get_info")
+        self.info = {n: int(getattr(info, n)) for n, _ in _lib.PlanInfo._fields_}
+        self.uploaded = bool(upload)
+
+    def __getattr__(self, name):
+        info = self.__dict__.get("info")
+        if info is not None and name in info:
+            return info[name]
+        raise AttributeError(name)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def array(self, name):
+        """Host copy of a plan array (tests / tooling)."""
+        p = ctypes.c_void_p()
+        n = self._lib.bt_plan_array(self._h, name.encode(), ctypes.byref(p))
+        if n < 0:
+            raise KeyError(name)
+        dt = np.dtype(_NP_TYPES.get(name, np.int32))
+        if n == 0:
+            return np.zeros(0, dt)
+        buf = (ctypes.c_char * (n * dt.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    def arrays(self):
+        return {k: self.array(k) for k in PLAN_ARRAYS}
+
+    def close(self):
+        if self._h:
+            self._lib.bt_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stepper:
+    """A plan bound to a device: owns the workspace, fills bt_ba_args, launches."""
+
+    def __init__(self, plan, device):
+        import torch
+        if not plan.uploaded:
+            raise RuntimeError("plan was built host-only")
+        self.plan = plan
+        self.device = torch.device(device)
+        self.ws = torch.empty(max(plan.workspace_bytes, 256), dtype=torch.uint8, device=self.device)
+        self._args = _lib.BaArgs()
+        self._lib = _lib.lib()
+        cnt = ctypes.c_int64()
+        sys_ptr = self._lib.bt_ba_system(plan.handle, self.ws.data_ptr(), ctypes.byref(cnt))
+        off = sys_ptr - self.ws.data_ptr()
+        self.system = self.ws[off:off + 8 * cnt.value].view(torch.float64)      # [S | y], for all-reduce
+        D = 6 * plan.n
+        dx_off = self._lib.bt_ba_dx(plan.handle, self.ws.data_ptr()) - self.ws.data_ptr()
+        self.dx = self.ws[dx_off:dx_off + 4 * D].view(torch.float32).view(plan.n, 6)
+
+    def _fill(self, poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
+              bounds, lmbda, ep, alpha, loss, structure_only):
+        a = self._args
+        a.poses, a.patches, a.mono_disp = poses.data_ptr(), patches.data_ptr(), mono.data_ptr()
+        a.intrinsics, a.targets, a.weights = intrinsics.data_ptr(), targets.data_ptr(), weights.data_ptr()
+        a.target_stride = int(tstride)
+        a.poses_out, a.patches_out = poses_out.data_ptr(), patches_out.data_ptr()
+        a.bounds[0], a.bounds[1], a.bounds[2], a.bounds[3] = (float(b) for b in bounds)
+        a.lmbda, a.ep, a.alpha = float(lmbda), float(ep), float(alpha)
+        a.loss = _lib.LOSS[loss] if isinstance(loss, str) else int(loss)
+        a.structure_only = 1 if structure_only else 0
+        return a
+
+    def step(self, *args, stream=None, phase="all"):
+        import torch
+        a = self._fill(*args)
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        fn = {"all": self._lib.bt_ba_step, "reduce": self._lib.bt_ba_reduce,
+              "solve_update": self._lib.bt_ba_solve_update}[phase]
+        _lib.check(fn(self.plan.handle, ctypes.byref(a), self.ws.data_ptr(), st), f"bt_ba_{phase}")
+
+    def step_timed(self, *args, stream=None):
+        """One step with per-kernel HIP-event timing -> dict of milliseconds."""
+        import torch
+        a = self._fill(*args)
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        ms = (ctypes.c_float * 5)()
+        _lib.check(self._lib.bt_ba_step_timed(self.plan.handle, ctypes.byref(a), self.ws.data_ptr(), st, ms),
+                   "bt_ba_step_timed")
+        return dict(zip(("prep", "tile", "pair_finalize", "solve", "update"), [float(v) for v in ms]))
+
+    def status(self):
+        import torch
+        s = ctypes.c_int32(-1)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.bt_ba_status(self.plan.handle, self.ws.data_ptr(), st, ctypes.byref(s)), "bt_ba_status")
+        return s.value

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — BA iterations/s on the 64-KF / 131,072-edge factor graph (BASELINE.json
+`metric`; workload C3 of SURVEY.md §8d), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one BA iteration = one pose+structure `BA_rgbd_droid` call (ba.py:217)
+executed through the C ABI (bt_ba_step) with inputs resident in HBM; state is
+ping-ponged so the K timed steps are K real Gauss-Newton iterations.  The plan of
+the (fixed) edge list is built before the timed region (its cost is reported as
+`plan_build_ms`), exactly as the reference's caller reuses one edge list for
+2*ITER calls (batrack.py:869-875).  N > 1: tracks are sharded over the ranks, one
+RCCL all-reduce of the reduced system per step (batrack_amd/parallel.py); the
+graph is the same, so scaling is "strong".
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel named in
+BASELINE.json (the Jacobian kernel, k_tile): algorithmic bytes (SURVEY.md §8d:
+40 B/edge + 20 B/track + 72 B/pose) over the kernel's own duration measured with
+HIP events recorded by the launch on its stream (bt_ba_step_timed).
+`cpu_baseline` = the C oracle (a scalar port of the reference algorithm) timed on
+this host, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C3", choices=["C1", "C3"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--sweep", action="store_true", help="also print an edge-count sweep of k_tile (stderr)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from batrack_amd import graphgen
+    from batrack_amd.plan import Plan, Stepper
+    from batrack_amd.parallel import ShardedBA
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    g = graphgen.make_config(args.workload, seed=args.seed)
+    f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
+    poses, patches, mono, intr = f32(g.poses), f32(g.patches), f32(g.mono_disp), f32(g.intrinsics)
+    t3, w_pose, w_all = f32(g.targets3), f32(g.weights_pose), f32(g.weights)
+    ii, jj, kk = (torch.as_tensor(a, device=dev) for a in (g.ii, g.jj, g.kk))
+    n_buf, p_tot, fixedp = poses.shape[0], patches.shape[0], 1
+    scal = (list(g.bounds), 1e-4, 10.0, 0.05, "huber")        # bounds, lmbda, ep, alpha, loss (batrack.py:861-875)
+
+    t0 = time.perf_counter()
+    if world > 1:
+        eng = ShardedBA(ii, jj, kk, n_buf, p_tot, fixedp, dev)
+        plan, stepper = eng.plan, eng.stepper
+        tg, wp_l, wa_l = eng.local(t3), eng.local(w_pose), eng.local(w_all)
+        step = eng.step
+    else:
+        plan = Plan(ii, jj, kk, n_buf, p_tot, fixedp)
+        stepper = Stepper(plan, dev)
+        tg, wp_l, wa_l = t3, w_pose, w_all
+        step = stepper.step
+    torch.cuda.synchronize()
+    plan_ms = (time.perf_counter() - t0) * 1e3
+
+    P = [poses.clone(), torch.empty_like(poses)]
+    X = [patches.clone(), torch.empty_like(patches)]
+
+    def ba_iter(k):
+        a, b = k & 1, (k + 1) & 1
+        step(P[a], X[a], mono, intr, tg, tg.stride(0), wp_l, P[b], X[b], *scal, False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        ba_iter(k)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        ba_iter(k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    status = stepper.status()
+
+    extra = {}
+    roofline = None
+    cpu_baseline = None
+    if world == 1:
+        # dual iteration (what BATRACK.update really runs): pose+structure then structure-only
+        P2 = [poses.clone(), torch.empty_like(poses)]
+        X2 = [patches.clone(), torch.empty_like(patches), torch.empty_like(patches)]
+        nd = max(args.steps // 2, 10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(nd):
+            a, b = k & 1, (k + 1) & 1
+            stepper.step(P2[a], X2[a], mono, intr, tg, tg.stride(0), wp_l, P2[b], X2[2], *scal, False)
+            stepper.step(P2[b], X2[2], mono, intr, tg, tg.stride(0), wa_l, P2[b], X2[b], *scal, True)
+        torch.cuda.synchronize()
+        extra["dual_iterations_per_s"] = nd / (time.perf_counter() - t0)
+
+        # drop-in Python entry point (allocation + plan-cache lookup per call included)
+        from batrack_amd.backend.ba import BA_rgbd_droid
+        from batrack_amd.backend.lietorch import SE3
+        Gs, pat = SE3(poses[None]), patches[None, :, :, None, None]
+        t3b = t3[None]
+        na = max(args.steps // 2, 10)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(na):
+                Gs, pat = BA_rgbd_droid(Gs, pat, mono[None, :, None], intr[None], t3b[..., :2], t3b[..., 2:],
+                                        w_pose[None], 1e-4, ii, jj, kk, list(g.bounds), ep=10, fixedp=1,
+                                        structure_only=False, loss="huber", alpha=0.05)
+            torch.cuda.synchronize()
+            extra["python_api_iterations_per_s"] = na / (time.perf_counter() - t0)
+
+        # per-kernel durations from HIP events recorded by the launches themselves
+        acc = {}
+        nt = min(args.steps, 100)
+        for k in range(nt):
+            a, b = k & 1, (k + 1) & 1
+            ms = stepper.step_timed(P[a], X[a], mono, intr, tg, tg.stride(0), wp_l, P[b], X[b], *scal, False)
+            for name, v in ms.items():
+                acc.setdefault(name, []).append(v)
+        kern_us = {k: 1e3 * float(np.mean(v)) for k, v in acc.items()}
+        extra["kernel_us"] = {k: round(v, 3) for k, v in kern_us.items()}
+        alg_bytes = 40 * plan.E + 20 * plan.m + 72 * plan.n_all        # SURVEY.md §8d, Jacobian kernel only
+        tile_s = kern_us["tile"] * 1e-6
+        achieved = alg_bytes / tile_s / 1e9 if tile_s > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes": alg_bytes, "kernel_us": round(kern_us["tile"], 3)}
+
+        if not args.no_cpu_baseline:
+            import oracle
+            f64 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+            cin = (f64(g.poses), f64(g.patches), f64(g.mono_disp), f64(g.intrinsics), f64(g.targets3),
+                   f64(g.weights_pose), g.ii, g.jj, g.kk, g.bounds)
+            oracle.ba_step(*cin, fixedp=1, dtype=np.float32)
+            t0 = time.perf_counter()
+            nc = 0
+            while time.perf_counter() - t0 < args.cpu_seconds:
+                oracle.ba_step(*cin, fixedp=1, dtype=np.float32)
+                nc += 1
+            cpu_rate = nc / (time.perf_counter() - t0)
+            cpu_baseline = {"value": round(cpu_rate, 3), "unit": "BA iterations/s", "cores": 1, "kind": "port",
+                            "host_cores": os.cpu_count(),
+                            "sample": f"{nc} pose+structure steps of the same {args.workload} graph, float32, "
+                                      "scalar C port of the reference algorithm (oracle/ba_oracle_impl.h)"}
+
+    if rank == 0:
+        out = {
+            "metric": "BA iterations/s on 64-KF/128k-edge graph",
+            "value": round(args.steps / elapsed, 2), "unit": "BA iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {g.n_frames} keyframes, {plan.E if world == 1 else len(g.ii)} edges, "
+                                   f"{len(np.unique(g.kk))} tracks, {plan.n} free poses, pose+structure GN step, huber, "
+                                   f"make_graph seed {args.seed}",
+                       "parallelism": "single GPU" if world == 1 else f"track-sharded x{world}, 1 all-reduce of [S|y] per step",
+                       "plan_build_ms": round(plan_ms, 2), "solver_status": status, **extra},
+        }
+        if roofline is not None:
+            out["roofline"] = roofline
+        if cpu_baseline is not None:
+            out["cpu_baseline"] = cpu_baseline
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+/* batrack_ba.h — C ABI of the MI355X-native bundle-adjustment backend.
+ *
+ * Drop-in boundary for the reference's BA hot path.  The reference exposes a
+ * Python function, not an FFI:
+ *
+ *   BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d,
+ *                 targets_disp, weights, lmbda, ii, jj, kk, bounds, ep, PRINT,
+ *                 fixedp, structure_only, loss, alpha) -> (poses, patches)
+ *                                   /root/reference/main/backend/ba.py:217
+ *   called from BATRACK.update()    /root/reference/main/batrack.py:869-875
+ *
+ * This header is what a binding for that function binds (batrack_amd/backend/ba.py
+ * does so through ctypes; INTEGRATION.md shows the stub).  Plain pointers and
+ * sizes only; every pointer in bt_ba_args is a DEVICE pointer; `stream` is a
+ * hipStream_t passed as void*.  Nothing here allocates in the step functions,
+ * synchronises the device, or throws: integer status codes only.
+ *
+ * Two objects:
+ *   bt_plan   the structure of one edge list (ii, jj, kk, fixedp): unique tracks
+ *             (replaces torch.unique at ba.py:276), camera pairs, wave tiles, the
+ *             block-sparsity of the reduced camera system.  Built once per edge
+ *             list (the reference's caller keeps one list for 2*ITER calls,
+ *             batrack.py:869-875), reused by every step on it.
+ *   workspace caller-owned device scratch of bt_plan_workspace_bytes() bytes.
+ */
+#ifndef BATRACK_BA_H
+#define BATRACK_BA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bt_plan bt_plan;
+
+enum { BT_OK = 0, BT_EINVAL = -1, BT_ENOMEM = -2, BT_EHIP = -3, BT_EUNSUPPORTED = -4 };
+enum { BT_LOSS_TRIVIAL = 0, BT_LOSS_HUBER = 1, BT_LOSS_CAUCHY = 2 };   /* ba.py:81-100 */
+
+/* status word written by the solver (bt_ba_status): */
+enum { BT_SOLVE_OK = 0, BT_SOLVE_CHOL_FAILED = 1,   /* dX = 0, ba.py:9-13            */
+       BT_SOLVE_RETRIED = 2 };                      /* NaN -> lm = 1e-3, ba.py:324-325 */
+
+typedef struct {
+    int64_t E;            /* edges                                             */
+    int64_t n_buf;        /* pose / intrinsics buffer length                   */
+    int64_t p_tot;        /* patch slots                                       */
+    int64_t fixedp;       /* poses [0, fixedp) are held fixed                  */
+    int64_t n_all;        /* max(ii, jj) + 1               (ba.py:219)         */
+    int64_t n;            /* free poses = n_all - fixedp   (ba.py:272)         */
+    int64_t m;            /* distinct tracks in kk         (ba.py:276-277)     */
+    int64_t pairs;        /* distinct (ii, jj) camera pairs                    */
+    int64_t tiles;        /* wave tiles (<= 64 tracks each)                    */
+    int64_t slots;        /* sum over tiles of edge slots (each 64 lanes wide) */
+    int64_t erows;        /* sum over tiles of 6 * (free cameras of the tile)  */
+    int64_t max_tile_cams;
+    int64_t nnz_blocks;   /* 6x6 blocks of the Cholesky factor incl. fill      */
+    int64_t updates;      /* block-update triples of the factorisation         */
+    int64_t workspace_bytes;
+    int64_t sorted_input; /* 1 if kk was already non-decreasing                */
+} bt_plan_info;
+
+/* Build the plan.  ii/jj/kk are int64[E] (the dtype the reference's caller
+ * holds, batrack.py:100-102), on the device (on_device=1; copied back once,
+ * synchronously) or on the host (on_device=0).  upload=0 keeps the plan
+ * host-only (no HIP call is made: CPU tests).  Errors: BT_EINVAL for indices
+ * out of range, BT_EUNSUPPORTED if a single track is seen by more than 64 free
+ * cameras or n > 255.
+ * n_all_min: lower bound for n_all (0 = derive from the edges).  A rank that holds
+ * only a shard of the edges passes the global n_all so that every rank builds a
+ * reduced system of the same size. */
+int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                   int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
+                   int on_device, int upload, bt_plan **out);
+void bt_plan_destroy(bt_plan *plan);
+int bt_plan_get_info(const bt_plan *plan, bt_plan_info *info);
+size_t bt_plan_workspace_bytes(const bt_plan *plan);
+
+/* Host view of a plan array by name (for tests / tooling); returns the element
+ * count, or -1 for an unknown name.  Element type is int32 unless noted in
+ * DESIGN.md ("slot_lab" is uint16). */
+int64_t bt_plan_array(const bt_plan *plan, const char *name, const void **data);
+
+typedef struct {
+    const float *poses;        /* [n_buf,7] tx ty tz qx qy qz qw                      */
+    const float *patches;      /* [p_tot,3] x y inverse-depth (patch size P = 1)      */
+    const float *mono_disp;    /* [p_tot]   depth prior (patches_monodisp)            */
+    const float *intrinsics;   /* [n_buf,4] fx fy cx cy                               */
+    const float *targets;      /* (u, v) of edge e at targets[e*target_stride + {0,1}] */
+    int64_t target_stride;     /* in floats: 3 for the caller's targets_3d[..., :2] view */
+    const float *weights;      /* [E,2]                                               */
+    float *poses_out;          /* [n_buf,7]  (may alias poses only if structure_only) */
+    float *patches_out;        /* [p_tot,3]                                           */
+    float bounds[4];           /* x0 y0 x1 y1, strict                                 */
+    float lmbda, ep, alpha;    /* ba.py:217 (lm = 1e-4 inside block_solve is fixed)   */
+    int32_t loss;              /* BT_LOSS_*                                           */
+    int32_t structure_only;    /* ba.py:316                                           */
+} bt_ba_args;
+
+/* One BA_rgbd_droid call, all phases, enqueued on `stream`. */
+int bt_ba_step(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
+
+/* bt_ba_step with a (start, stop) HIP event pair around every kernel, recorded on
+ * `stream` by the launch itself; synchronises, then ms[k] = duration of kernel k:
+ * 0 k_prep, 1 k_tile (residual + Jacobian + assembly + Schur), 2 k_pair_finalize,
+ * 3 k_solve, 4 k_update; 0 for a kernel the call did not launch.  Measurement only. */
+int bt_ba_step_timed(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream, float *ms);
+
+/* The same call split at the multi-GPU exchange point:
+ *   bt_ba_reduce        residuals, Jacobians, block assembly, Schur complement of
+ *                       THIS rank's tracks -> partial reduced system [S | y]
+ *   (all-reduce the bt_ba_system() buffer across ranks: sum, float64)
+ *   bt_ba_solve_update  damped Cholesky solve, back-substitution, retraction  */
+int bt_ba_reduce(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
+int bt_ba_solve_update(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
+
+/* Device pointer to the reduced system inside `workspace`: (6n)^2 doubles of S
+ * (row-major, lower triangle populated) followed by 6n doubles of y. */
+double *bt_ba_system(const bt_plan *plan, void *workspace, int64_t *count);
+/* Device pointer to dX [n,6] floats inside `workspace`. */
+float *bt_ba_dx(const bt_plan *plan, void *workspace);
+/* Synchronous read-back of the solver status word (BT_SOLVE_*). */
+int bt_ba_status(const bt_plan *plan, void *workspace, void *stream, int32_t *status);
+
+/* Library/ABI version and the gfx target the kernels were compiled for. */
+int bt_version(void);
+const char *bt_target_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BATRACK_BA_H */

@@ -1,0 +1,63 @@
+"""Helpers for the -m gpu tests: run the HIP path (through the C ABI) on numpy inputs."""
+import numpy as np
+import torch
+
+from batrack_amd.backend.ba import BA_rgbd_droid
+from batrack_amd.backend.lietorch import SE3
+from batrack_amd.plan import Plan, Stepper
+
+DEV = "cuda:0"
+
+
+def t32(a):
+    return torch.as_tensor(np.asarray(a, np.float32), device=DEV)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+class HipProblem:
+    """Device copies of a golden/generated input dict, laid out as the caller holds them."""
+
+    def __init__(self, d):
+        self.poses = t32(d["poses"])[None]                       # [1,N,7]
+        self.patches = t32(d["patches"])[None, :, :, None, None]  # [1,P,3,1,1]
+        self.mono = t32(d["mono"])[None, :, None]                 # [1,P,1]
+        self.intr = t32(d["intrinsics"])[None]
+        self.t3 = t32(d["targets3"])[None]                        # [1,E,3]: 2-D target is a stride-3 view
+        self.w = {k: t32(d[k])[None] for k in ("weights", "weights_pose")}
+        self.ii, self.jj, self.kk = (torch.as_tensor(d[k], device=DEV) for k in ("ii", "jj", "kk"))
+        self.bounds = [float(v) for v in d["bounds"]]
+
+    def api_step(self, wkey, fixedp, so, loss="huber", poses=None, patches=None, lmbda=1e-4, ep=10.0, alpha=0.05):
+        """Through BA_rgbd_droid exactly as batrack.py:871-875 calls it."""
+        Gs = SE3(self.poses) if poses is None else poses
+        pat = self.patches if patches is None else patches
+        return BA_rgbd_droid(Gs, pat, self.mono, self.intr, self.t3[..., :2], self.t3[..., 2:], self.w[wkey],
+                             lmbda, self.ii, self.jj, self.kk, self.bounds, ep=ep, fixedp=fixedp,
+                             structure_only=so, loss=loss, alpha=alpha)
+
+    def raw_step(self, wkey, fixedp, so=False, loss="huber", lmbda=1e-4, ep=10.0, alpha=0.05):
+        """Through Plan/Stepper, returning the reduced system as well."""
+        plan = Plan(self.ii, self.jj, self.kk, self.poses.shape[1], self.patches.shape[1], fixedp)
+        st = Stepper(plan, DEV)
+        P = self.poses[0].contiguous()
+        pat = self.patches.reshape(-1, 3).contiguous()
+        so = so or plan.n == 0
+        pout = torch.empty_like(pat)
+        Pout = P if so else torch.empty_like(P)
+        tg = self.t3[0]
+        st.step(P, pat, self.mono.reshape(-1), self.intr[0], tg, tg.stride(0), self.w[wkey][0].contiguous(),
+                Pout, pout, self.bounds, lmbda, ep, alpha, loss, so)
+        torch.cuda.synchronize()
+        out = dict(poses_out=Pout.cpu().numpy(), patches_out=pout.cpu().numpy(), plan=plan, stepper=st)
+        if not so:
+            D = 6 * plan.n
+            sysv = st.system.cpu().numpy()
+            out["S_lower"] = sysv[:D * D].reshape(D, D)
+            out["y"] = sysv[D * D:]
+            out["dX"] = st.dx.cpu().numpy()
+            out["status"] = st.status()
+        return out

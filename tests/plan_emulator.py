@@ -1,0 +1,205 @@
+"""Test helper: executes a bt_plan on the CPU in float64 numpy, mirroring what the
+HIP kernels do with the plan arrays (ba_kernels.hip: k_prep, k_tile,
+k_pair_finalize, k_solve, k_update), with the per-edge Jacobians taken from the
+oracle.  It validates the plan layout, the Ji = -Jj Ad algebra and the
+block-sparse factorisation structure without a GPU.  Test infrastructure only.
+"""
+import numpy as np
+
+import oracle
+
+
+def quat_rot_matrix(q):
+    q = q / np.linalg.norm(q)
+    x, y, z, w = q
+    return np.array([[1 - 2*(y*y + z*z), 2*(x*y - z*w), 2*(x*z + y*w)],
+                     [2*(x*y + z*w), 1 - 2*(x*x + z*z), 2*(y*z - x*w)],
+                     [2*(x*z - y*w), 2*(y*z + x*w), 1 - 2*(x*x + y*y)]])
+
+
+def hat(t):
+    return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0.0]])
+
+
+def pair_geometry(poses, i, j):
+    if i == j:
+        return np.eye(3), np.zeros(3)
+    Ri, Rj = quat_rot_matrix(poses[i, 3:]), quat_rot_matrix(poses[j, 3:])
+    R = Rj @ Ri.T
+    return R, poses[j, :3] - R @ poses[i, :3]
+
+
+def adjoint(R, t):
+    Ad = np.zeros((6, 6))
+    Ad[:3, :3] = R
+    Ad[:3, 3:] = hat(t) @ R
+    Ad[3:, 3:] = R
+    return Ad
+
+
+def run(plan, A, inp, wkey, lmbda=1e-4, ep=10.0, alpha=0.05, structure_only=False, loss="huber"):
+    """plan: batrack_amd.plan.Plan (host-only is fine); A = plan.arrays(); inp: dict of
+    float64 inputs (poses, patches, mono, intrinsics, targets3, weights.., ii, jj, kk, bounds)."""
+    info = plan.info
+    n, fixedp, D = info["n"], info["fixedp"], 6 * info["n"]
+    ed = oracle.edges(inp["poses"], inp["patches"], inp["intrinsics"], inp["targets3"], inp[wkey],
+                      inp["ii"], inp["jj"], inp["kk"], inp["bounds"], loss=loss)
+    Jj, Jz, r, W = ed["Jj"], ed["Jz"], ed["r"], ed["W"]
+    P = info["pairs"]
+    Ads = [adjoint(*pair_geometry(inp["poses"], int(A["pair_i"][p]), int(A["pair_j"][p]))) for p in range(P)]
+    S = np.zeros((D, D))
+    y = np.zeros(D)
+    Bjj = np.zeros((P, 6, 6))
+    gj = np.zeros((P, 6))
+    m = info["m"]
+    Q = np.zeros(m)
+    wp = np.zeros(m)
+    Esave = {}
+    so = structure_only or n == 0
+    for t in range(info["tiles"]):
+        nt, nc = int(A["tile_ntrk"][t]), int(A["tile_ncam"][t])
+        cams = A["tile_cams"][A["tile_cam0"][t]:A["tile_cam0"][t] + nc]
+        Eh = np.zeros((6 * nc + 1, 64))
+        C = np.zeros(64)
+        wv = np.zeros(64)
+        for s in range(int(A["tile_nslot"][t])):
+            base = (int(A["tile_slot0"][t]) + s) * 64
+            for lane in range(64):
+                e = int(A["slot_edge"][base + lane])
+                if e < 0:
+                    continue
+                assert lane < nt
+                p = int(A["slot_pair"][base + lane])
+                lab = int(A["slot_lab"][base + lane])
+                la, lb = lab & 0xff, lab >> 8
+                assert A["pair_i"][p] == inp["ii"][e] and A["pair_j"][p] == inp["jj"][e]
+                assert A["kx"][A["tile_trk0"][t] + lane] == inp["kk"][e]
+                Wd = np.diag(W[e])
+                C[lane] += Jz[e] @ Wd @ Jz[e]
+                wv[lane] += Jz[e] @ Wd @ r[e]
+                Ej = Jj[e].T @ Wd @ Jz[e]
+                if lb != 0xff:
+                    assert cams[lb] == inp["jj"][e] - fixedp
+                    Eh[6*lb:6*lb + 6, lane] += Ej
+                else:
+                    assert inp["jj"][e] < fixedp
+                if la != 0xff:
+                    assert cams[la] == inp["ii"][e] - fixedp
+                    Eh[6*la:6*la + 6, lane] += -Ads[p].T @ Ej
+                else:
+                    assert inp["ii"][e] < fixedp
+                Bjj[p] += Jj[e].T @ Wd @ Jj[e]
+                gj[p] += Jj[e].T @ Wd @ r[e]
+        for lane in range(nt):
+            trk = int(A["tile_trk0"][t]) + lane
+            patch = int(A["kx"][trk])
+            mono = inp["mono"][patch]
+            pm = 1.0 if mono > 1e-2 else 0.0
+            Q[trk] = 1.0 / (C[lane] + pm * alpha + lmbda)
+            wp[trk] = wv[lane] - pm * alpha * (inp["patches"][patch, 2] - mono)
+            Eh[6 * nc, lane] = wp[trk]
+        if so:
+            continue
+        Esave[t] = Eh[:6 * nc].copy()
+        Ql = np.zeros(64)
+        Ql[:nt] = Q[A["tile_trk0"][t]:A["tile_trk0"][t] + nt]
+        out = (Eh * Ql) @ Eh.T
+        gidx = np.array([6 * cams[c // 6] + c % 6 for c in range(6 * nc)], dtype=np.int64)
+        for rr in range(6 * nc):
+            for cc in range(6 * nc):
+                if gidx[rr] >= gidx[cc]:
+                    S[gidx[rr], gidx[cc]] -= out[rr, cc]
+        y[gidx] -= out[6 * nc, :6 * nc]
+    if not so:
+        for p in range(P):
+            a, b = int(A["pair_i"][p]) - fixedp, int(A["pair_j"][p]) - fixedp
+            Ad = Ads[p]
+            M = Bjj[p] @ Ad
+            low = np.tril(np.ones((6, 6), bool))
+            if a >= 0:
+                blk = Ad.T @ M
+                S[6*a:6*a + 6, 6*a:6*a + 6] += np.where(low, blk, 0)
+                y[6*a:6*a + 6] += -Ad.T @ gj[p]
+            if b >= 0:
+                S[6*b:6*b + 6, 6*b:6*b + 6] += np.where(low, Bjj[p], 0)
+                y[6*b:6*b + 6] += gj[p]
+            if a >= 0 and b >= 0:
+                if a > b:
+                    S[6*a:6*a + 6, 6*b:6*b + 6] += -M.T
+                elif b > a:
+                    S[6*b:6*b + 6, 6*a:6*a + 6] += -M
+                else:
+                    S[6*a:6*a + 6, 6*a:6*a + 6] += np.where(low, -(M + M.T), 0)
+    out = dict(S_lower=S, y=y, Q=Q, wp=wp)
+    dX = np.zeros((n, 6))
+    if not so:
+        dX = sparse_chol_solve(A, S, y, n, ep, 1e-4)
+        out["dX"] = dX
+    # update
+    patches_out = inp["patches"].copy()
+    dz_all = np.zeros(inp["patches"].shape[0])
+    for t in range(info["tiles"]):
+        nt, nc = int(A["tile_ntrk"][t]), int(A["tile_ncam"][t])
+        cams = A["tile_cams"][A["tile_cam0"][t]:A["tile_cam0"][t] + nc]
+        for lane in range(nt):
+            trk = int(A["tile_trk0"][t]) + lane
+            assert A["trk_loc"][trk] == (t << 6 | lane)
+            assert A["trk_of_patch"][A["kx"][trk]] == trk
+            if so:
+                dz = Q[trk] * wp[trk]
+            else:
+                acc = sum(Esave[t][6*c:6*c + 6, lane] @ dX[cams[c]] for c in range(nc))
+                dz = Q[trk] * (wp[trk] - acc)
+            dz_all[A["kx"][trk]] = dz
+    patches_out[:, 2] = np.clip(inp["patches"][:, 2] + dz_all, 1e-3, 10.0)
+    out["patches_out"] = patches_out
+    return out
+
+
+def sparse_chol_solve(A, S_lower, y, n, ep, lm):
+    """k_solve: block-sparse right-looking Cholesky driven by col_ptr/row_idx/upd."""
+    col_ptr, row_idx, upd_ptr, upd = A["col_ptr"], A["row_idx"], A["upd_ptr"], A["upd"].reshape(-1, 3)
+    nnzb = len(row_idx)
+    L = np.zeros((nnzb, 6, 6))
+    col_of = np.zeros(nnzb, np.int64)
+    for j in range(n):
+        col_of[col_ptr[j]:col_ptr[j + 1]] = j
+    # every structurally non-zero block of S must be inside the symbolic pattern
+    Sb = np.abs(S_lower).reshape(n, 6, n, 6).max(axis=(1, 3))
+    pat = np.zeros((n, n), bool)
+    pat[row_idx, col_of] = True
+    assert not np.any((Sb > 0) & ~pat), "S has a block outside the plan's sparsity pattern"
+    for b in range(nnzb):
+        i, j = int(row_idx[b]), int(col_of[b])
+        blk = S_lower[6*i:6*i + 6, 6*j:6*j + 6].copy()
+        if i == j:
+            blk = np.tril(blk)
+            blk[np.diag_indices(6)] += ep + lm * np.diag(blk)
+        L[b] = blk
+    z = y.copy()
+    Linv = np.zeros((n, 6, 6))
+    for j in range(n):
+        d = col_ptr[j]
+        full = L[d] + np.tril(L[d], -1).T
+        Lj = np.linalg.cholesky(full)
+        L[d] = Lj
+        Linv[j] = np.linalg.inv(Lj)
+        z[6*j:6*j + 6] = Linv[j] @ z[6*j:6*j + 6]
+        for s in range(d + 1, col_ptr[j + 1]):
+            L[s] = L[s] @ Linv[j].T
+            i = int(row_idx[s])
+            z[6*i:6*i + 6] -= L[s] @ z[6*j:6*j + 6]
+        for t in range(upd_ptr[j], upd_ptr[j + 1]):
+            s1, s2, dst = upd[t]
+            assert col_of[s1] == j and col_of[s2] == j
+            assert row_idx[dst] == row_idx[s1] and col_of[dst] == row_idx[s2]
+            L[dst] -= L[s1] @ L[s2].T
+    x = z.copy()
+    for j in range(n - 1, -1, -1):
+        d = col_ptr[j]
+        tq = x[6*j:6*j + 6].copy()
+        for s in range(d + 1, col_ptr[j + 1]):
+            i = int(row_idx[s])
+            tq -= L[s].T @ x[6*i:6*i + 6]
+        x[6*j:6*j + 6] = Linv[j].T @ tq
+    return x.reshape(n, 6)

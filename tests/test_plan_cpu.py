@@ -1,0 +1,99 @@
+"""Host-side plan (batrack_amd/csrc/ba_plan.cpp) without a GPU: structure checks and a
+float64 numpy execution of the plan (tests/plan_emulator.py) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from batrack_amd import graphgen
+from batrack_amd.plan import Plan
+from plan_emulator import run as emulate
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def load(name):
+    d = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    return d
+
+
+def host_plan(d, fixedp):
+    return Plan(d["ii"], d["jj"], d["kk"], d["poses"].shape[0], d["patches"].shape[0], fixedp, upload=False)
+
+
+@pytest.mark.parametrize("name,fixedp", [("c1", 1), ("c1", 3), ("c1_rough", 1), ("c1_rough", 2),
+                                         ("window_small", None)])
+def test_plan_structure(name, fixedp):
+    d = load(name)
+    fixedp = int(d["fixedp"]) if fixedp is None else fixedp
+    pl = host_plan(d, fixedp)
+    A = pl.arrays()
+    E = len(d["ii"])
+    n_all = int(max(d["ii"].max(), d["jj"].max())) + 1
+    assert pl.n_all == n_all and pl.n == n_all - fixedp and pl.E == E
+    kx = np.unique(d["kk"])                                   # torch.unique(sorted=True), ba.py:276
+    assert np.array_equal(A["kx"], kx) and pl.m == len(kx)
+    pairs = np.unique(np.stack([d["ii"], d["jj"]], 1), axis=0)
+    assert np.array_equal(np.stack([A["pair_i"], A["pair_j"]], 1), pairs)
+    used = A["slot_edge"][A["slot_edge"] >= 0]
+    assert len(used) == E and np.array_equal(np.sort(used), np.arange(E))   # each edge exactly once
+    assert A["tile_ntrk"].sum() == pl.m and A["tile_ntrk"].max() <= 64
+    assert A["tile_ncam"].max() == pl.max_tile_cams <= 64
+    for t in range(pl.tiles):
+        cams = A["tile_cams"][A["tile_cam0"][t]:A["tile_cam0"][t] + A["tile_ncam"][t]]
+        assert np.all(np.diff(cams) > 0) and cams.min() >= 0 and cams.max() < pl.n
+    assert A["col_ptr"][0] == 0 and A["col_ptr"][-1] == pl.nnz_blocks == len(A["row_idx"])
+    for j in range(pl.n):
+        rows = A["row_idx"][A["col_ptr"][j]:A["col_ptr"][j + 1]]
+        assert rows[0] == j and np.all(np.diff(rows) > 0)
+
+
+CASES = [("c1", "weights_pose", 1, False, "huber", {}), ("c1", "weights_pose", 3, False, "huber", {}),
+         ("c1", "weights", 1, True, "huber", {}), ("c1", "weights_pose", 1, False, "cauchy", {}),
+         ("c1_rough", "weights_pose", 1, False, "huber", {}),
+         ("c1_rough", "weights_pose", 2, False, "huber", dict(alpha=0.5, ep=100.0)),
+         ("c1_rough", "weights", 1, True, "huber", {}),
+         ("window_small", "weights_pose", None, False, "huber", {}),
+         ("c1", "weights_pose", 8, False, "huber", {})]
+
+
+@pytest.mark.parametrize("name,wkey,fixedp,so,loss,kw", CASES)
+def test_plan_execution_matches_oracle(name, wkey, fixedp, so, loss, kw):
+    d = load(name)
+    fixedp = int(d["fixedp"]) if fixedp is None else fixedp
+    pl = host_plan(d, fixedp)
+    em = emulate(pl, pl.arrays(), d, wkey, structure_only=so, loss=loss, **kw)
+    o = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey],
+                       d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=fixedp, structure_only=so,
+                       loss=loss, want_system=True, **kw)
+    if "S" in o:
+        assert rel(np.tril(em["S_lower"]), np.tril(o["S"])) < 1e-10
+        assert rel(em["y"], o["y"]) < 1e-10
+        assert rel(em["dX"], o["dX"]) < 1e-7
+    assert rel(em["patches_out"], o["patches_out"]) < 1e-10
+
+
+def test_plan_rejects_bad_indices():
+    ii = np.array([0, 1], np.int64); jj = np.array([1, 5], np.int64); kk = np.array([0, 1], np.int64)
+    with pytest.raises(RuntimeError):
+        Plan(ii, jj, kk, 4, 8, 1, upload=False)          # jj >= n_buf
+    with pytest.raises(RuntimeError):
+        Plan(ii, np.array([1, 2], np.int64), np.array([0, 9], np.int64), 4, 8, 1, upload=False)  # kk >= p_tot
+
+
+def test_plan_c3_shape():
+    g = graphgen.make_config("C3", seed=0)
+    pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
+    assert (pl.E, pl.n, pl.m) == (131072, 63, 16384)
+    assert pl.tiles == 256 and pl.max_tile_cams <= 10 and pl.sorted_input == 1
+    A = pl.arrays()
+    # observation pattern is regular: every slot of every tile holds a single camera pair
+    sp = A["slot_pair"].reshape(-1, 64)
+    assert np.all(sp == sp[:, :1])
+    # banded reduced system: no fill outside the 7-block band
+    assert pl.nnz_blocks == sum(min(8, 63 - j) for j in range(63))
