@@ -62,6 +62,9 @@ def lib():
         raise RuntimeError(
             f"batrack_amd: HIP library {LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)")
+    # torch bundles its own libamdhip64; it must be in the process BEFORE our library
+    # resolves the same SONAME, or the two would talk to different HIP runtimes.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     L.bt_version.restype = i32

@@ -1,6 +1,7 @@
 // ba_api.cpp — the C ABI declared in include/batrack_ba.h.
 #include <hip/hip_runtime_api.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -27,6 +28,7 @@ int upload_plan(bt_plan *pl) {
     const size_t o_e0 = put(buf, pl->tile_erow0), o_cams = put(buf, pl->tile_cams);
     const size_t o_se = put(buf, pl->slot_edge), o_sp = put(buf, pl->slot_pair), o_sl = put(buf, pl->slot_lab);
     const size_t o_cp = put(buf, pl->col_ptr), o_ri = put(buf, pl->row_idx), o_up = put(buf, pl->upd_ptr), o_u = put(buf, pl->upd);
+    const size_t o_bc = put(buf, pl->blk_col), o_un = put(buf, pl->upd_next);
     void *d = nullptr;
     if (hipMalloc(&d, buf.size() + 256) != hipSuccess) return BT_ENOMEM;
     if (hipMemcpy(d, buf.data(), buf.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return BT_EHIP; }
@@ -45,7 +47,7 @@ int upload_plan(bt_plan *pl) {
     P.tile_slot0 = BT_I32(o_s0); P.tile_nslot = BT_I32(o_sn); P.tile_erow0 = BT_I32(o_e0); P.tile_cams = BT_I32(o_cams);
     P.slot_edge = BT_I32(o_se); P.slot_pair = BT_I32(o_sp);
     P.slot_lab = reinterpret_cast<const uint16_t *>(b + o_sl);
-    P.col_ptr = BT_I32(o_cp); P.row_idx = BT_I32(o_ri); P.upd_ptr = BT_I32(o_up); P.upd = BT_I32(o_u);
+    P.col_ptr = BT_I32(o_cp); P.row_idx = BT_I32(o_ri); P.upd_ptr = BT_I32(o_up); P.upd = BT_I32(o_u); P.blk_col = BT_I32(o_bc); P.upd_next = BT_I32(o_un);
 #undef BT_I32
     return configure_kernels(P);
 }
@@ -66,6 +68,8 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     s.esave = reinterpret_cast<float *>(w + L.esave); s.lfac = reinterpret_cast<float *>(w + L.lfac);
     s.linv = reinterpret_cast<float *>(w + L.linv); s.zvec = reinterpret_cast<float *>(w + L.zvec);
     s.dx = reinterpret_cast<float *>(w + L.dx); s.status = reinterpret_cast<int *>(w + L.status);
+    static const int dbg = std::getenv("BT_DEBUG_MODE") ? std::atoi(std::getenv("BT_DEBUG_MODE")) : 0;
+    s.dbg = dbg;
     return s;
 }
 
@@ -138,7 +142,7 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
     BT_ARR(kx) BT_ARR(trk_of_patch) BT_ARR(trk_loc) BT_ARR(pair_i) BT_ARR(pair_j)
     BT_ARR(tile_trk0) BT_ARR(tile_ntrk) BT_ARR(tile_ncam) BT_ARR(tile_cam0) BT_ARR(tile_slot0)
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
-    BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd)
+    BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next)
 #undef BT_ARR
     return -1;
 }

@@ -183,11 +183,11 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
         float Ej[6] = { wa0 * q.jz0, wb1 * q.jz1, fmaf(wa2, q.jz0, wb2 * q.jz1), fmaf(wa3, q.jz0, wb3 * q.jz1),
                         fmaf(wa4, q.jz0, wb4 * q.jz1), fmaf(wa5, q.jz0, wb5 * q.jz1) };
         const unsigned la = lab & 0xffu, lb = lab >> 8;
-        if (act && lb != 0xffu) {
+        if (act && lb != 0xffu && !(a.dbg & 8)) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) atomicAdd(&Eh[(lb * 6 + c) * kLdsRowStride + lane], Ej[c]);
         }
-        if (act && la != 0xffu) {
+        if (act && la != 0xffu && !(a.dbg & 8)) {
             // o_tau = R^T e_tau ; o_phi = R^T (e_tau x t + e_phi)      (se3.h:58-67)
             const float cx = Ej[1]*g[11] - Ej[2]*g[10] + Ej[3];
             const float cy = Ej[2]*g[9]  - Ej[0]*g[11] + Ej[4];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
             for (int c = 0; c < 32; ++c) v[c] = mine ? vals[c] : 0.0f;
             wave_reduce_scatter32(v, lane);
             const int vi = (lane >> 1) & 31;
-            if ((lane & 1) == 0 && vi < 27)
+            if ((lane & 1) == 0 && vi < 27 && !(a.dbg & 2))
                 atomicAdd(&a.pairacc[(size_t)p0 * kPairAccStride + vi], (double)v[0]);
             todo &= ~__ballot(mine);
         }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
     // are exact products accumulated in double (DESIGN.md "precision").
     const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
     const int *cams = pd.tile_cams + pd.tile_cam0[tile];
-    for (int t = wave; t < ntl; t += 4) {
+    for (int t = wave; t < ntl && !(a.dbg & 4); t += 4) {
         int ti = 0, base = 0;
         while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
         const int tj = t - base;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * ti + (lane >> 4) + 4 * r;
-            if (col < R && row <= R) {
+            if (col < R && row <= R && !(a.dbg & 1)) {
                 const int gc = 6 * cams[col / 6] + col % 6;
                 if (row == R) {
                     atomicAdd(&a.y[gc], -acc[r]);
@@ -410,7 +410,7 @@ __device__ inline bool chol6_inv(float *Ablk, float *Linv) {
     return ok;
 }
 
-__global__ __launch_bounds__(1024) void k_solve(PlanDev pd, StepArgs a) {
+__global__ __launch_bounds__(1024) void k_solve_global(PlanDev pd, StepArgs a) {
     __shared__ float part[kMaxFree * 6 + 6];
     __shared__ float tq[6];
     __shared__ int flags[2];          // [0] cholesky failed, [1] NaN in dX
@@ -424,10 +424,7 @@ __global__ __launch_bounds__(1024) void k_solve(PlanDev pd, StepArgs a) {
         // load the structurally non-zero blocks of S (+ damping) and y
         for (int idx = tid; idx < pd.nnzb * 36; idx += nth) {
             const int b = idx / 36, e = idx % 36, r = e / 6, c = e % 6;
-            const int row = pd.row_idx[b];
-            int lo = 0, hi = n;                       // column of block b: last j with col_ptr[j] <= b
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pd.col_ptr[mid] <= b) lo = mid; else hi = mid; }
-            const int col = lo;
+            const int row = pd.row_idx[b], col = pd.blk_col[b];
             double v = (row > col || r >= c) ? a.S[(size_t)(6*row + r) * D + 6*col + c] : 0.0;
             if (row == col && r == c) v = v + ((double)a.ep + (double)lm * v);
             Lw[idx] = (float)v;
@@ -519,6 +516,260 @@ __global__ __launch_bounds__(1024) void k_solve(PlanDev pd, StepArgs a) {
     if (tid == 0) a.status[0] = status;
 }
 
+// ------------------------------------------------------------------ k_solve_lds
+// The same factorisation with the factor resident in LDS and ONE workgroup barrier
+// per block column.  Wave 0 is the critical wave: for column j it applies the
+// updates of column j-1 that land in column j, factors the diagonal block (every
+// lane redundantly, in registers: no broadcast needed), forms L_ij = A_ij L_jj^-T
+// and carries y along (forward substitution).  The other waves apply the remaining
+// updates of column j-1, which only touch columns > j.  After the sweep all threads
+// turn the factor into back-substitution form M_ij = (L_ij L_jj^-1)^T, and wave 0
+// runs the sequential back substitution with DPP reductions.
+#define BT_LT(r, c) ((r) * ((r) + 1) / 2 + (c))
+
+template <typename T> __device__ __forceinline__ T rsqrt_t(T x);
+template <> __device__ __forceinline__ float rsqrt_t<float>(float x) { return rsqrtf(x); }
+template <> __device__ __forceinline__ double rsqrt_t<double>(double x) { return rsqrt(x); }
+
+template <typename T>
+__device__ __forceinline__ bool chol6_inv_packed(const T (&a)[21], T (&li)[21]) {
+    T L[21];
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        T s = a[BT_LT(c, c)];
+#pragma unroll
+        for (int k = 0; k < c; ++k) s -= L[BT_LT(c, k)] * L[BT_LT(c, k)];
+        ok = ok && (s > (T)0);
+        const T il = rsqrt_t<T>(s);
+        L[BT_LT(c, c)] = il;                       // diagonal kept as 1 / l_cc
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+            T t = a[BT_LT(r, c)];
+#pragma unroll
+            for (int k = 0; k < c; ++k) t -= L[BT_LT(r, k)] * L[BT_LT(c, k)];
+            L[BT_LT(r, c)] = t * il;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        li[BT_LT(c, c)] = L[BT_LT(c, c)];
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+            T t = (T)0;
+#pragma unroll
+            for (int k = c; k < r; ++k) t += L[BT_LT(r, k)] * li[BT_LT(k, c)];
+            li[BT_LT(r, c)] = -t * L[BT_LT(r, r)];
+        }
+    }
+    return ok;
+}
+
+__device__ __forceinline__ float dpp_add8(float v) {   // sum over aligned groups of 8 lanes, all lanes get it
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad xor 1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad xor 2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ double dpp_perm(double v, int ctrl_sel) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    if (ctrl_sel == 0) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); }
+    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); }
+    else { lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); }
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double dpp_add8(double v) {
+    v += dpp_perm(v, 0); v += dpp_perm(v, 1); v += dpp_perm(v, 2);
+    return v;
+}
+
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+template <typename T>
+__device__ __forceinline__ void apply_update(T *Lw, const unsigned short *tr, int e) {
+    const int r = e / 6, c = e - 6 * r;
+    const T *L1 = Lw + (size_t)tr[0] * 36 + 6 * r, *L2 = Lw + (size_t)tr[1] * 36 + 6 * c;
+    T acc = (T)0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc += L1[k] * L2[k];
+    Lw[(size_t)tr[2] * 36 + e] -= acc;
+}
+
+size_t solve_lds_bytes(const PlanDev &pd, size_t elem) {
+    size_t b = ((size_t)pd.nnzb * 36 + 2 * (size_t)pd.D) * elem;          // Lw, z, zt
+    b = (b + 15) / 16 * 16;
+    b += (size_t)pd.nupd * 3 * sizeof(unsigned short);                     // update triples
+    b = (b + 15) / 16 * 16;
+    b += ((size_t)pd.nnzb + 3 * ((size_t)pd.n + 1)) * sizeof(int);        // row_idx, col_ptr, upd_ptr, upd_next
+    return b + 64;
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int flags[2];
+    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nwaves = nth >> 6;
+    const int n = pd.n, D = pd.D, nnzb = pd.nnzb;
+    T *Lw = reinterpret_cast<T *>(smem);
+    T *z = Lw + (size_t)nnzb * 36, *zt = z + D;
+    size_t off = (((size_t)nnzb * 36 + 2 * (size_t)D) * sizeof(T) + 15) / 16 * 16;
+    unsigned short *upd = reinterpret_cast<unsigned short *>(smem + off);
+    off = (off + (size_t)pd.nupd * 3 * sizeof(unsigned short) + 15) / 16 * 16;
+    int *row_idx = reinterpret_cast<int *>(smem + off), *col_ptr = row_idx + nnzb, *upd_ptr = col_ptr + n + 1,
+        *upd_next = upd_ptr + n + 1;
+    for (int i = tid; i < pd.nupd * 3; i += nth) upd[i] = (unsigned short)pd.upd[i];
+    for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i];
+    for (int i = tid; i <= n; i += nth) { col_ptr[i] = pd.col_ptr[i]; upd_ptr[i] = pd.upd_ptr[i]; upd_next[i] = pd.upd_next[i]; }
+
+    int status = BT_SOLVE_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const double lm = attempt == 0 ? 1e-4 : 1e-3;
+        if (tid < 2) flags[tid] = 0;
+        for (int idx = tid; idx < nnzb * 36; idx += nth) {
+            const int b = idx / 36, e = idx - 36 * b, r = e / 6, c = e - 6 * r;
+            const int row = pd.row_idx[b], col = pd.blk_col[b];
+            double v = (row > col || r >= c) ? a.S[(size_t)(6 * row + r) * D + 6 * col + c] : 0.0;
+            if (row == col && r == c) v = v + ((double)a.ep + lm * v);            // ba.py:67
+            Lw[idx] = (T)v;
+        }
+        for (int i = tid; i < D; i += nth) z[i] = (T)a.y[i];
+        __syncthreads();
+
+        for (int j = 0; j <= n; ++j) {
+            // updates generated by column j-1
+            if (j > 0) {
+                const int u0 = upd_ptr[j - 1], nnext = upd_next[j - 1], nrest = upd_ptr[j] - u0 - nnext;
+                if (wave == 0) {
+                    for (int idx = lane; idx < nnext * 36; idx += 64) {
+                        const int t = idx / 36;
+                        apply_update(Lw, upd + 3 * (u0 + t), idx - 36 * t);
+                    }
+                    wave_fence();
+                } else {
+                    for (int idx = tid - 64; idx < nrest * 36; idx += nth - 64) {
+                        const int t = idx / 36;
+                        apply_update(Lw, upd + 3 * (u0 + nnext + t), idx - 36 * t);
+                    }
+                }
+            }
+            if (wave == 0 && j < n) {
+                const int dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
+                T ad[21], li[21];
+                const T *dblk = Lw + (size_t)dpos * 36;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) ad[BT_LT(r, c)] = dblk[6 * r + c];
+                const bool ok = chol6_inv_packed<T>(ad, li);
+                if (!ok && lane == 0) flags[0] = 1;
+                T zj[6], zz[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) zj[r] = z[6 * j + r];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {                      // z_j <- L_jj^-1 z_j
+                    T t = (T)0;
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) t += li[BT_LT(r, c)] * zj[c];
+                    zz[r] = t;
+                }
+                // L_ij = A_ij L_jj^-T (one lane per block row), y_i -= L_ij z_j
+                for (int idx = lane; idx < cnt * 6; idx += 64) {
+                    const int s = idx / 6, r = idx - 6 * s;
+                    T *blk = Lw + (size_t)(dpos + 1 + s) * 36 + 6 * r;
+                    T in[6], dot = (T)0;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) in[c] = blk[c];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        T t = (T)0;
+#pragma unroll
+                        for (int k = 0; k <= c; ++k) t += in[k] * li[BT_LT(c, k)];
+                        blk[c] = t;
+                        dot += t * zz[c];
+                    }
+                    z[6 * row_idx[dpos + 1 + s] + r] -= dot;
+                }
+                // keep L_jj^-1 (in place of A_jj) and z_j
+                T mine = li[0];
+#pragma unroll
+                for (int e = 1; e < 21; ++e) mine = lane == e ? li[e] : mine;
+                if (lane < 21) {
+                    const int r = lane >= 15 ? 5 : lane >= 10 ? 4 : lane >= 6 ? 3 : lane >= 3 ? 2 : lane >= 1 ? 1 : 0;
+                    Lw[(size_t)dpos * 36 + 6 * r + (lane - r * (r + 1) / 2)] = mine;
+                } else if (lane >= 32 && lane < 38) {
+                    T zm = zz[0];
+#pragma unroll
+                    for (int e = 1; e < 6; ++e) zm = (lane - 32) == e ? zz[e] : zm;
+                    z[6 * j + lane - 32] = zm;
+                }
+            }
+            __syncthreads();
+        }
+
+        // back-substitution form: block (i,j) <- rows r: Mt[r][c] = sum_k Linv_j[k][c] L_ij[r][k];  zt_j = Linv_j^T z_j
+        for (int idx = tid; idx < nnzb * 6; idx += nth) {
+            const int b = idx / 6, r = idx - 6 * b;
+            const int j = pd.blk_col[b];
+            if (row_idx[b] == j) continue;
+            const T *li = Lw + (size_t)col_ptr[j] * 36;
+            T *blk = Lw + (size_t)b * 36 + 6 * r;
+            T in[6], out[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) in[k] = blk[k];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                T t = (T)0;
+#pragma unroll
+                for (int k = c; k < 6; ++k) t += li[6 * k + c] * in[k];
+                out[c] = t;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) blk[c] = out[c];
+        }
+        for (int idx = tid; idx < D; idx += nth) {
+            const int j = idx / 6, c = idx - 6 * j;
+            const T *li = Lw + (size_t)col_ptr[j] * 36;
+            T t = (T)0;
+            for (int k = c; k < 6; ++k) t += li[6 * k + c] * z[6 * j + k];
+            zt[idx] = t;
+        }
+        __syncthreads();
+        // x_j = zt_j - sum_{i>j} M_ij x_i, descending; wave 0, lane = (component c) * 8 + g
+        if (wave == 0) {
+            const int c = lane >> 3, g = lane & 7;
+            for (int j = n - 1; j >= 0; --j) {
+                const int dpos = col_ptr[j], nterm = (col_ptr[j + 1] - dpos - 1) * 6;
+                T acc = (T)0;
+                if (c < 6)
+                    for (int t = g; t < nterm; t += 8) {
+                        const int s = t / 6, r = t - 6 * s;
+                        acc += Lw[(size_t)(dpos + 1 + s) * 36 + 6 * r + c] * zt[6 * row_idx[dpos + 1 + s] + r];
+                    }
+                acc = dpp_add8(acc);
+                if (c < 6 && g == 0) zt[6 * j + c] -= acc;
+                wave_fence();
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
+        __syncthreads();
+        const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
+        __syncthreads();
+        if (failed) {
+            for (int i = tid; i < D; i += nth) zt[i] = (T)0;
+            status = BT_SOLVE_CHOL_FAILED;
+            break;
+        }
+        if (!has_nan) break;
+        status = BT_SOLVE_RETRIED;
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += nth) a.dx[i] = (float)zt[i];
+    if (tid == 0) a.status[0] = status;
+    (void)nwaves;
+}
+
 // ------------------------------------------------------------------ k_update
 __device__ inline void retract_pose(const float *pin, const float *xi, float *pout) {
     // poses' = Exp(xi) * G  (groups.py:153-156; so3.h:153-190; se3.h:134-142), in double
@@ -608,14 +859,30 @@ static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     return (size_t)((so ? 0 : pd.max_rows16) * kLdsRowStride + 192) * sizeof(float);
 }
 
+constexpr size_t kLdsBudget = 160 * 1024 - 512;
+
+// 0: factor in LDS as double, 1: in LDS as float, 2: in the global workspace (float)
+int solver_mode(const PlanDev &pd) {
+    if (solve_lds_bytes(pd, sizeof(double)) <= kLdsBudget) return 0;
+    if (solve_lds_bytes(pd, sizeof(float)) <= kLdsBudget) return 1;
+    return 2;
+}
+
 int configure_kernels(const PlanDev &pd) {
     const size_t need = tile_lds_bytes(pd, false);
-    if (need > 160 * 1024) return BT_EUNSUPPORTED;
+    if (need > kLdsBudget) return BT_EUNSUPPORTED;
     if (need > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)
             return BT_EHIP;
     }
+    const int mode = solver_mode(pd);
+    if (mode == 0 && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_lds<double>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes(pd, 8)) != hipSuccess)
+        return BT_EHIP;
+    if (mode == 1 && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_lds<float>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes(pd, 4)) != hipSuccess)
+        return BT_EHIP;
     return BT_OK;
 }
 
@@ -646,7 +913,12 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
 }
 
 int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev) {
-    if (!so) BT_LAUNCH(3, k_solve, dim3(1), dim3(1024), 0, pd, a);
+    if (!so) {
+        const int mode = solver_mode(pd);
+        if (mode == 0)      BT_LAUNCH(3, k_solve_lds<double>, dim3(1), dim3(512), solve_lds_bytes(pd, 8), pd, a);
+        else if (mode == 1) BT_LAUNCH(3, k_solve_lds<float>, dim3(1), dim3(512), solve_lds_bytes(pd, 4), pd, a);
+        else                BT_LAUNCH(3, k_solve_global, dim3(1), dim3(1024), 0, pd, a);
+    }
     const int do_poses = so ? (copy_poses ? 1 : 0) : 1;
     const int total = pd.p_tot + (do_poses ? pd.n_buf : 0);
     if (so) BT_LAUNCH(4, k_update<true>, dim3((total + 255) / 256), dim3(256), 0, pd, a, do_poses);

@@ -18,6 +18,7 @@ struct StepArgs {
     float2 *qw;
     float *esave, *lfac, *linv, *zvec, *dx;
     int *status;
+    int dbg;                      // measurement-only switches (env BT_DEBUG_MODE), 0 in production
 };
 
 int configure_kernels(const PlanDev &pd);

@@ -215,16 +215,27 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         const auto b = pl->row_idx.begin() + pl->col_ptr[(size_t)col], e = pl->row_idx.begin() + pl->col_ptr[(size_t)col + 1];
         return (int32_t)(std::lower_bound(b, e, row) - pl->row_idx.begin());
     };
+    // block -> column map, and the update triples of every column: first those whose
+    // destination lies in column j+1 (the critical wave applies them itself before it
+    // factors that column), then the rest (helper waves)
+    pl->blk_col.assign(pl->row_idx.size(), 0);
+    for (int64_t j = 0; j < n; ++j)
+        for (int32_t b = pl->col_ptr[(size_t)j]; b < pl->col_ptr[(size_t)j + 1]; ++b) pl->blk_col[(size_t)b] = (int32_t)j;
     pl->upd_ptr.assign((size_t)n + 1, 0);
+    pl->upd_next.assign((size_t)n + 1, 0);
     pl->upd.clear();
     for (int64_t j = 0; j < n; ++j) {
         pl->upd_ptr[(size_t)j] = (int32_t)(pl->upd.size() / 3);
         const int32_t b = pl->col_ptr[(size_t)j] + 1, e = pl->col_ptr[(size_t)j + 1];
-        for (int32_t s = b; s < e; ++s)
-            for (int32_t t2 = b; t2 <= s; ++t2) {
-                pl->upd.push_back(s); pl->upd.push_back(t2);
-                pl->upd.push_back(find_pos(pl->row_idx[(size_t)t2], pl->row_idx[(size_t)s]));
-            }
+        for (int pass = 0; pass < 2; ++pass)
+            for (int32_t s = b; s < e; ++s)
+                for (int32_t t2 = b; t2 <= s; ++t2) {
+                    const bool next = pl->row_idx[(size_t)t2] == (int32_t)j + 1;
+                    if (next != (pass == 0)) continue;
+                    pl->upd.push_back(s); pl->upd.push_back(t2);
+                    pl->upd.push_back(find_pos(pl->row_idx[(size_t)t2], pl->row_idx[(size_t)s]));
+                    if (next) pl->upd_next[(size_t)j]++;
+                }
     }
     pl->upd_ptr[(size_t)n] = (int32_t)(pl->upd.size() / 3);
     I.updates = (int64_t)(pl->upd.size() / 3);

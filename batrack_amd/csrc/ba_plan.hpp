@@ -27,7 +27,7 @@ struct PlanDev {
     const int32_t *tile_cams;
     const int32_t *slot_edge, *slot_pair;
     const uint16_t *slot_lab;
-    const int32_t *col_ptr, *row_idx, *upd_ptr, *upd;
+    const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
 };
 
 // Byte offsets of the regions inside the caller's workspace.
@@ -46,7 +46,7 @@ struct bt_plan {
     std::vector<int32_t> tile_cams;
     std::vector<int32_t> slot_edge, slot_pair;
     std::vector<uint16_t> slot_lab;
-    std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd;
+    std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
     int max_rows16 = 16;
     bt::WsLayout ws{};
     void *dev_base = nullptr;   // one device allocation holding every array above

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-kernel HIP-event timings of one BA step for a workload (GPU box)."""
+import os, sys, argparse
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from batrack_amd import graphgen
+from batrack_amd.plan import Plan, Stepper
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="C3")
+ap.add_argument("--reps", type=int, default=50)
+args = ap.parse_args()
+dev = "cuda:0"
+if args.workload == "window":
+    g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
+else:
+    g, fixedp = graphgen.make_config(args.workload, seed=0), 1
+f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
+poses, patches, mono, intr, t3, w = f32(g.poses), f32(g.patches), f32(g.mono_disp), f32(g.intrinsics), f32(g.targets3), f32(g.weights_pose)
+ii, jj, kk = (torch.as_tensor(a, device=dev) for a in (g.ii, g.jj, g.kk))
+plan = Plan(ii, jj, kk, poses.shape[0], patches.shape[0], fixedp)
+st = Stepper(plan, dev)
+Po, Xo = torch.empty_like(poses), torch.empty_like(patches)
+scal = (list(g.bounds), 1e-4, 10.0, 0.05, "huber")
+acc = {}
+for k in range(args.reps + 5):
+    ms = st.step_timed(poses, patches, mono, intr, t3, 3, w, Po, Xo, *scal, False)
+    if k >= 5:
+        for n, v in ms.items():
+            acc.setdefault(n, []).append(v * 1e3)
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for k in range(200):
+    st.step(poses, patches, mono, intr, t3, 3, w, Po, Xo, *scal, False)
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / 200 * 1e6
+print(f"mode={os.environ.get('BT_DEBUG_MODE','0')} {args.workload} E={plan.E} n={plan.n} tiles={plan.tiles} nnzb={plan.nnz_blocks}: " +
+      " ".join(f"{n}={np.median(v):.2f}us" for n, v in acc.items()) + f" | wall/step={wall:.1f}us status={st.status()}", flush=True)
