@@ -623,6 +623,8 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
     for (int i = tid; i <= n; i += nth) { col_ptr[i] = pd.col_ptr[i]; upd_ptr[i] = pd.upd_ptr[i]; upd_next[i] = pd.upd_next[i]; }
 
     int status = BT_SOLVE_OK;
+    long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = clock64(), tn;
+#define BT_PF(i) do { tn = clock64(); pf[i] += tn - tc; tc = tn; } while (0)
     for (int attempt = 0; attempt < 2; ++attempt) {
         const double lm = attempt == 0 ? 1e-4 : 1e-3;
         if (tid < 2) flags[tid] = 0;
@@ -635,6 +637,7 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
         }
         for (int i = tid; i < D; i += nth) z[i] = (T)a.y[i];
         __syncthreads();
+        BT_PF(0);
 
         for (int j = 0; j <= n; ++j) {
             // updates generated by column j-1
@@ -653,6 +656,7 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
                     }
                 }
             }
+            BT_PF(1);
             if (wave == 0 && j < n) {
                 const int dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
                 T ad[21], li[21];
@@ -663,6 +667,7 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
                     for (int c = 0; c <= r; ++c) ad[BT_LT(r, c)] = dblk[6 * r + c];
                 const bool ok = chol6_inv_packed<T>(ad, li);
                 if (!ok && lane == 0) flags[0] = 1;
+                BT_PF(2);
                 T zj[6], zz[6];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) zj[r] = z[6 * j + r];
@@ -690,6 +695,7 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
                     }
                     z[6 * row_idx[dpos + 1 + s] + r] -= dot;
                 }
+                BT_PF(3);
                 // keep L_jj^-1 (in place of A_jj) and z_j
                 T mine = li[0];
 #pragma unroll
@@ -703,8 +709,10 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
                     for (int e = 1; e < 6; ++e) zm = (lane - 32) == e ? zz[e] : zm;
                     z[6 * j + lane - 32] = zm;
                 }
+                BT_PF(4);
             }
             __syncthreads();
+            BT_PF(5);
         }
 
         // back-substitution form: block (i,j) <- rows r: Mt[r][c] = sum_k Linv_j[k][c] L_ij[r][k];  zt_j = Linv_j^T z_j
@@ -735,6 +743,7 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
             zt[idx] = t;
         }
         __syncthreads();
+        BT_PF(6);
         // x_j = zt_j - sum_{i>j} M_ij x_i, descending; wave 0, lane = (component c) * 8 + g
         if (wave == 0) {
             const int c = lane >> 3, g = lane & 7;
@@ -752,6 +761,7 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
             }
         }
         __syncthreads();
+        BT_PF(7);
         for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
         __syncthreads();
         const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
@@ -767,6 +777,12 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
     __syncthreads();
     for (int i = tid; i < D; i += nth) a.dx[i] = (float)zt[i];
     if (tid == 0) a.status[0] = status;
+    BT_PF(8);
+    if ((a.dbg & 16) && lane == 0 && wave < 2) {        // measurement only: phase cycle counts of waves 0 and 1
+        long long *o = reinterpret_cast<long long *>(a.status + 4) + wave * 10;
+        for (int i = 0; i < 10; ++i) o[i] = pf[i];
+    }
+#undef BT_PF
     (void)nwaves;
 }
 

@@ -37,5 +37,15 @@ for k in range(200):
     st.step(poses, patches, mono, intr, t3, 3, w, Po, Xo, *scal, False)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / 200 * 1e6
+if int(os.environ.get("BT_DEBUG_MODE", "0")) & 16:
+    import ctypes
+    off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
+    raw = st.ws.cpu().numpy()
+    # status region follows dx region: find by scanning from plan layout is not exposed; use the status call offset
+    stat_off = off + ((6 * plan.n * 4 + 64 + 255) // 256) * 256
+    pf = np.frombuffer(raw[stat_off + 16: stat_off + 16 + 160].tobytes(), dtype=np.int64).reshape(2, 10)
+    names = ["load", "updates", "chol", "trsm", "store", "barrier", "Mprep", "backsub", "tail", "-"]
+    for w in range(2):
+        print(f"  solver wave{w} cycles: " + " ".join(f"{n}={v}" for n, v in zip(names, pf[w])) + f" total={pf[w].sum()}")
 print(f"mode={os.environ.get('BT_DEBUG_MODE','0')} {args.workload} E={plan.E} n={plan.n} tiles={plan.tiles} nnzb={plan.nnz_blocks}: " +
       " ".join(f"{n}={np.median(v):.2f}us" for n, v in acc.items()) + f" | wall/step={wall:.1f}us status={st.status()}", flush=True)
