@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "ba_kernels.hpp"
 
 namespace bt {
@@ -517,23 +519,46 @@ __global__ __launch_bounds__(1024) void k_solve_global(PlanDev pd, StepArgs a) {
 }
 
 // ------------------------------------------------------------------ k_solve_lds
-// The same factorisation with the factor resident in LDS and ONE workgroup barrier
-// per block column.  Wave 0 is the critical wave: for column j it applies the
-// updates of column j-1 that land in column j, factors the diagonal block (every
-// lane redundantly, in registers: no broadcast needed), forms L_ij = A_ij L_jj^-T
-// and carries y along (forward substitution).  The other waves apply the remaining
-// updates of column j-1, which only touch columns > j.  After the sweep all threads
-// turn the factor into back-substitution form M_ij = (L_ij L_jj^-1)^T, and wave 0
-// runs the sequential back substitution with DPP reductions.
+// The same factorisation with the factor resident in LDS.  A lone wave retires
+// roughly one instruction per 6-10 cycles on this part, so the sweep is written
+// for the fewest instructions on the critical path, two short phases per column:
+//   phase 1   wave 0: apply column j-1's update to the diagonal block of column j,
+//             factor it (every lane redundantly, in registers), store L_jj;
+//             all other waves: every other update of column j-1 (into column j's
+//             sub-diagonal blocks, into later columns, and into y)
+//   phase 2   all threads: one block row each of L_ij = A_ij L_jj^-T by forward
+//             substitution; the extra row is y_j (forward substitution of the RHS)
+// The diagonal block keeps L_jj with 1/l_cc on its diagonal.  After the sweep all
+// threads bring the factor into back-substitution form (L_jj^-1 in the strict upper
+// triangle of the diagonal block, M_ij = (L_ij L_jj^-1)^T), and wave 0 runs the
+// sequential back substitution with DPP reductions.
 #define BT_LT(r, c) ((r) * ((r) + 1) / 2 + (c))
 
 template <typename T> __device__ __forceinline__ T rsqrt_t(T x);
 template <> __device__ __forceinline__ float rsqrt_t<float>(float x) { return rsqrtf(x); }
 template <> __device__ __forceinline__ double rsqrt_t<double>(double x) { return rsqrt(x); }
 
+template <typename T> struct Vec2;
+template <> struct Vec2<float> { typedef float2 type; };
+template <> struct Vec2<double> { typedef double2 type; };
+
 template <typename T>
-__device__ __forceinline__ bool chol6_inv_packed(const T (&a)[21], T (&li)[21]) {
-    T L[21];
+__device__ __forceinline__ void load_row6(const T *p, T (&v)[6]) {
+    typedef typename Vec2<T>::type V;
+    const V a = reinterpret_cast<const V *>(p)[0], b = reinterpret_cast<const V *>(p)[1], c = reinterpret_cast<const V *>(p)[2];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+}
+template <typename T>
+__device__ __forceinline__ void store_row6(T *p, const T (&v)[6]) {
+    typedef typename Vec2<T>::type V;
+    V a, b, c;
+    a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3]; c.x = v[4]; c.y = v[5];
+    reinterpret_cast<V *>(p)[0] = a; reinterpret_cast<V *>(p)[1] = b; reinterpret_cast<V *>(p)[2] = c;
+}
+
+// in: lower triangle a (packed).  out: L packed, diagonal entries hold 1 / l_cc.
+template <typename T>
+__device__ __forceinline__ bool chol6_packed(const T (&a)[21], T (&L)[21]) {
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -542,24 +567,13 @@ __device__ __forceinline__ bool chol6_inv_packed(const T (&a)[21], T (&li)[21]) 
         for (int k = 0; k < c; ++k) s -= L[BT_LT(c, k)] * L[BT_LT(c, k)];
         ok = ok && (s > (T)0);
         const T il = rsqrt_t<T>(s);
-        L[BT_LT(c, c)] = il;                       // diagonal kept as 1 / l_cc
+        L[BT_LT(c, c)] = il;
 #pragma unroll
         for (int r = c + 1; r < 6; ++r) {
             T t = a[BT_LT(r, c)];
 #pragma unroll
             for (int k = 0; k < c; ++k) t -= L[BT_LT(r, k)] * L[BT_LT(c, k)];
             L[BT_LT(r, c)] = t * il;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        li[BT_LT(c, c)] = L[BT_LT(c, c)];
-#pragma unroll
-        for (int r = c + 1; r < 6; ++r) {
-            T t = (T)0;
-#pragma unroll
-            for (int k = c; k < r; ++k) t += L[BT_LT(r, k)] * li[BT_LT(k, c)];
-            li[BT_LT(r, c)] = -t * L[BT_LT(r, r)];
         }
     }
     return ok;
@@ -571,11 +585,11 @@ __device__ __forceinline__ float dpp_add8(float v) {   // sum over aligned group
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
     return v;
 }
-__device__ __forceinline__ double dpp_perm(double v, int ctrl_sel) {
+__device__ __forceinline__ double dpp_perm(double v, int sel) {
     const long long b = __double_as_longlong(v);
     int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    if (ctrl_sel == 0) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); }
-    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); }
+    if (sel == 0) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); }
+    else if (sel == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); }
     else { lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); }
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
@@ -586,13 +600,16 @@ __device__ __forceinline__ double dpp_add8(double v) {
 
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
+// dst[e] -= (row r of block tr[0]) . (row c of block tr[1])
 template <typename T>
 __device__ __forceinline__ void apply_update(T *Lw, const unsigned short *tr, int e) {
     const int r = e / 6, c = e - 6 * r;
-    const T *L1 = Lw + (size_t)tr[0] * 36 + 6 * r, *L2 = Lw + (size_t)tr[1] * 36 + 6 * c;
-    T acc = (T)0;
+    T a[6], b[6];
+    load_row6(Lw + (size_t)tr[0] * 36 + 6 * r, a);
+    load_row6(Lw + (size_t)tr[1] * 36 + 6 * c, b);
+    T acc = a[0] * b[0];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc += L1[k] * L2[k];
+    for (int k = 1; k < 6; ++k) acc += a[k] * b[k];
     Lw[(size_t)tr[2] * 36 + e] -= acc;
 }
 
@@ -609,7 +626,7 @@ template <typename T>
 __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[2];
-    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nwaves = nth >> 6;
+    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63;
     const int n = pd.n, D = pd.D, nnzb = pd.nnzb;
     T *Lw = reinterpret_cast<T *>(smem);
     T *z = Lw + (size_t)nnzb * 36, *zt = z + D;
@@ -618,142 +635,185 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
     off = (off + (size_t)pd.nupd * 3 * sizeof(unsigned short) + 15) / 16 * 16;
     int *row_idx = reinterpret_cast<int *>(smem + off), *col_ptr = row_idx + nnzb, *upd_ptr = col_ptr + n + 1,
         *upd_next = upd_ptr + n + 1;
+    long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = clock64(), tn;
+#define BT_PF(i) do { tn = clock64(); pf[i] += tn - tc; tc = tn; } while (0)
+    // structure -> LDS (coalesced), element -> (row, col) through zt as scratch is not possible for T=float
     for (int i = tid; i < pd.nupd * 3; i += nth) upd[i] = (unsigned short)pd.upd[i];
     for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i];
     for (int i = tid; i <= n; i += nth) { col_ptr[i] = pd.col_ptr[i]; upd_ptr[i] = pd.upd_ptr[i]; upd_next[i] = pd.upd_next[i]; }
+    __syncthreads();
 
     int status = BT_SOLVE_OK;
-    long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = clock64(), tn;
-#define BT_PF(i) do { tn = clock64(); pf[i] += tn - tc; tc = tn; } while (0)
     for (int attempt = 0; attempt < 2; ++attempt) {
         const double lm = attempt == 0 ? 1e-4 : 1e-3;
         if (tid < 2) flags[tid] = 0;
-        for (int idx = tid; idx < nnzb * 36; idx += nth) {
-            const int b = idx / 36, e = idx - 36 * b, r = e / 6, c = e - 6 * r;
-            const int row = pd.row_idx[b], col = pd.blk_col[b];
-            double v = (row > col || r >= c) ? a.S[(size_t)(6 * row + r) * D + 6 * col + c] : 0.0;
-            if (row == col && r == c) v = v + ((double)a.ep + lm * v);            // ba.py:67
-            Lw[idx] = (T)v;
+        // one thread per block row: 6 contiguous doubles of S
+        for (int idx = tid; idx < nnzb * 6; idx += nth) {
+            const int b = idx / 6, r = idx - 6 * b;
+            const int row = row_idx[b], col = pd.blk_col[b];
+            const double *src = a.S + (size_t)(6 * row + r) * D + 6 * col;
+            T v[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double x = (row > col || r >= c) ? src[c] : 0.0;
+                if (row == col && r == c) x = x + ((double)a.ep + lm * x);            // ba.py:67
+                v[c] = (T)x;
+            }
+            store_row6(Lw + (size_t)b * 36 + 6 * r, v);
         }
         for (int i = tid; i < D; i += nth) z[i] = (T)a.y[i];
         __syncthreads();
         BT_PF(0);
 
-        for (int j = 0; j <= n; ++j) {
-            // updates generated by column j-1
+        for (int j = 0; j < n; ++j) {
+            const int dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
+            // ---- phase 1
+            int u0 = 0, nup = 0, cntp = 0, dposp = 0;
+            bool has_diag = false;
             if (j > 0) {
-                const int u0 = upd_ptr[j - 1], nnext = upd_next[j - 1], nrest = upd_ptr[j] - u0 - nnext;
-                if (wave == 0) {
-                    for (int idx = lane; idx < nnext * 36; idx += 64) {
-                        const int t = idx / 36;
-                        apply_update(Lw, upd + 3 * (u0 + t), idx - 36 * t);
-                    }
-                    wave_fence();
-                } else {
-                    for (int idx = tid - 64; idx < nrest * 36; idx += nth - 64) {
-                        const int t = idx / 36;
-                        apply_update(Lw, upd + 3 * (u0 + nnext + t), idx - 36 * t);
-                    }
-                }
+                u0 = upd_ptr[j - 1]; nup = upd_ptr[j] - u0;
+                dposp = col_ptr[j - 1]; cntp = dpos - dposp - 1;
+                has_diag = upd_next[j - 1] > 0;             // first triple of column j-1 hits the diagonal of column j
             }
-            BT_PF(1);
-            if (wave == 0 && j < n) {
-                const int dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
-                T ad[21], li[21];
+            if (wave == 0) {
+                if (has_diag && lane < 36) apply_update(Lw, upd + 3 * u0, lane);
+                wave_fence();
+                T ad[21], L[21];
                 const T *dblk = Lw + (size_t)dpos * 36;
 #pragma unroll
-                for (int r = 0; r < 6; ++r)
+                for (int r = 0; r < 6; ++r) {
+                    T row[6];
+                    load_row6(dblk + 6 * r, row);
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) ad[BT_LT(r, c)] = dblk[6 * r + c];
-                const bool ok = chol6_inv_packed<T>(ad, li);
-                if (!ok && lane == 0) flags[0] = 1;
+                    for (int c = 0; c <= r; ++c) ad[BT_LT(r, c)] = row[c];
+                }
+                const bool ok = chol6_packed<T>(ad, L);
                 BT_PF(2);
-                T zj[6], zz[6];
+                if (lane == 0) {
+                    if (!ok) flags[0] = 1;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) zj[r] = z[6 * j + r];
+                    for (int r = 0; r < 6; ++r) {
+                        T row[6];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {                      // z_j <- L_jj^-1 z_j
-                    T t = (T)0;
-#pragma unroll
-                    for (int c = 0; c <= r; ++c) t += li[BT_LT(r, c)] * zj[c];
-                    zz[r] = t;
-                }
-                // L_ij = A_ij L_jj^-T (one lane per block row), y_i -= L_ij z_j
-                for (int idx = lane; idx < cnt * 6; idx += 64) {
-                    const int s = idx / 6, r = idx - 6 * s;
-                    T *blk = Lw + (size_t)(dpos + 1 + s) * 36 + 6 * r;
-                    T in[6], dot = (T)0;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) in[c] = blk[c];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        T t = (T)0;
-#pragma unroll
-                        for (int k = 0; k <= c; ++k) t += in[k] * li[BT_LT(c, k)];
-                        blk[c] = t;
-                        dot += t * zz[c];
+                        for (int c = 0; c < 6; ++c) row[c] = c <= r ? L[BT_LT(r, c)] : (T)0;
+                        store_row6(Lw + (size_t)dpos * 36 + 6 * r, row);
                     }
-                    z[6 * row_idx[dpos + 1 + s] + r] -= dot;
-                }
-                BT_PF(3);
-                // keep L_jj^-1 (in place of A_jj) and z_j
-                T mine = li[0];
-#pragma unroll
-                for (int e = 1; e < 21; ++e) mine = lane == e ? li[e] : mine;
-                if (lane < 21) {
-                    const int r = lane >= 15 ? 5 : lane >= 10 ? 4 : lane >= 6 ? 3 : lane >= 3 ? 2 : lane >= 1 ? 1 : 0;
-                    Lw[(size_t)dpos * 36 + 6 * r + (lane - r * (r + 1) / 2)] = mine;
-                } else if (lane >= 32 && lane < 38) {
-                    T zm = zz[0];
-#pragma unroll
-                    for (int e = 1; e < 6; ++e) zm = (lane - 32) == e ? zz[e] : zm;
-                    z[6 * j + lane - 32] = zm;
                 }
                 BT_PF(4);
+            } else if (j > 0) {
+                // remaining update triples of column j-1, then its contribution to y:  y_i -= L_i,j-1 z_j-1
+                const int first = has_diag ? 1 : 0, total = (nup - first) * 36 + cntp * 6;
+                for (int idx = tid - 64; idx < total; idx += nth - 64) {
+                    if (idx < (nup - first) * 36) {
+                        const int t = idx / 36;
+                        apply_update(Lw, upd + 3 * (u0 + first + t), idx - 36 * t);
+                    } else {
+                        const int q = idx - (nup - first) * 36, s = q / 6, r = q - 6 * s;
+                        T lr[6], zr[6];
+                        load_row6(Lw + (size_t)(dposp + 1 + s) * 36 + 6 * r, lr);
+                        load_row6(z + 6 * (j - 1), zr);
+                        T acc = lr[0] * zr[0];
+#pragma unroll
+                        for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
+                        z[6 * row_idx[dposp + 1 + s] + r] -= acc;
+                    }
+                }
+                BT_PF(1);
             }
+            __syncthreads();
+            BT_PF(5);
+            // ---- phase 2: block rows of column j (and y_j) by forward substitution against L_jj
+            for (int rw = tid; rw <= cnt * 6; rw += nth) {
+                T L[21];
+                const T *dblk = Lw + (size_t)dpos * 36;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    T row[6];
+                    load_row6(dblk + 6 * r, row);
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) L[BT_LT(r, c)] = row[c];
+                }
+                T *p = rw < cnt * 6 ? Lw + (size_t)(dpos + 1) * 36 + 6 * rw : z + 6 * j;
+                T in[6], out[6];
+                load_row6(p, in);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    T t = in[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
+                    out[c] = t * L[BT_LT(c, c)];
+                }
+                store_row6(p, out);
+            }
+            BT_PF(3);
             __syncthreads();
             BT_PF(5);
         }
 
-        // back-substitution form: block (i,j) <- rows r: Mt[r][c] = sum_k Linv_j[k][c] L_ij[r][k];  zt_j = Linv_j^T z_j
-        for (int idx = tid; idx < nnzb * 6; idx += nth) {
-            const int b = idx / 6, r = idx - 6 * b;
-            const int j = pd.blk_col[b];
-            if (row_idx[b] == j) continue;
-            const T *li = Lw + (size_t)col_ptr[j] * 36;
-            T *blk = Lw + (size_t)b * 36 + 6 * r;
-            T in[6], out[6];
+        // ---- back-substitution form
+        // (a) L_jj^-1 into the strict upper triangle of the diagonal block (one thread per column)
+        for (int j = tid; j < n; j += nth) {
+            T *dblk = Lw + (size_t)col_ptr[j] * 36;
+            T L[21], li[21];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) in[k] = blk[k];
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) L[BT_LT(r, c)] = dblk[6 * r + c];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                T t = (T)0;
+                li[BT_LT(c, c)] = L[BT_LT(c, c)];
 #pragma unroll
-                for (int k = c; k < 6; ++k) t += li[6 * k + c] * in[k];
-                out[c] = t;
+                for (int r = c + 1; r < 6; ++r) {
+                    T t = (T)0;
+#pragma unroll
+                    for (int k = c; k < r; ++k) t += L[BT_LT(r, k)] * li[BT_LT(k, c)];
+                    li[BT_LT(r, c)] = -t * L[BT_LT(r, r)];
+                }
             }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) blk[c] = out[c];
+            for (int r = 1; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < r; ++c) dblk[6 * c + r] = li[BT_LT(r, c)];      // Linv[r][c] at [c][r]
         }
-        for (int idx = tid; idx < D; idx += nth) {
-            const int j = idx / 6, c = idx - 6 * j;
-            const T *li = Lw + (size_t)col_ptr[j] * 36;
-            T t = (T)0;
-            for (int k = c; k < 6; ++k) t += li[6 * k + c] * z[6 * j + k];
-            zt[idx] = t;
+        __syncthreads();
+        // (b) block rows: Mt[r][c] = sum_{k>=c} Linv_j[k][c] L_ij[r][k];  zt_j[c] = sum_{k>=c} Linv_j[k][c] z_j[k]
+        for (int idx = tid; idx < nnzb * 6 + n; idx += nth) {
+            int j;
+            T *p, *q;
+            if (idx < nnzb * 6) {
+                const int b = idx / 6, r = idx - 6 * b;
+                j = pd.blk_col[b];
+                if (row_idx[b] == j) continue;
+                p = Lw + (size_t)b * 36 + 6 * r; q = p;
+            } else {
+                j = idx - nnzb * 6;
+                p = z + 6 * j; q = zt + 6 * j;
+            }
+            const T *dblk = Lw + (size_t)col_ptr[j] * 36;
+            T in[6], out[6];
+            load_row6(p, in);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                T t = dblk[7 * c] * in[c];
+#pragma unroll
+                for (int k = c + 1; k < 6; ++k) t += dblk[6 * c + k] * in[k];
+                out[c] = t;
+            }
+            store_row6(q, out);
         }
         __syncthreads();
         BT_PF(6);
-        // x_j = zt_j - sum_{i>j} M_ij x_i, descending; wave 0, lane = (component c) * 8 + g
+        // (c) x_j = zt_j - sum_{i>j} M_ij x_i, descending; wave 0, lane = (component c) * 8 + g
         if (wave == 0) {
             const int c = lane >> 3, g = lane & 7;
             for (int j = n - 1; j >= 0; --j) {
                 const int dpos = col_ptr[j], nterm = (col_ptr[j + 1] - dpos - 1) * 6;
+                const T *mb = Lw + (size_t)(dpos + 1) * 36 + c;
                 T acc = (T)0;
                 if (c < 6)
                     for (int t = g; t < nterm; t += 8) {
                         const int s = t / 6, r = t - 6 * s;
-                        acc += Lw[(size_t)(dpos + 1 + s) * 36 + 6 * r + c] * zt[6 * row_idx[dpos + 1 + s] + r];
+                        acc += mb[6 * t] * zt[6 * row_idx[dpos + 1 + s] + r];
                     }
                 acc = dpp_add8(acc);
                 if (c < 6 && g == 0) zt[6 * j + c] -= acc;
@@ -783,7 +843,6 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
         for (int i = 0; i < 10; ++i) o[i] = pf[i];
     }
 #undef BT_PF
-    (void)nwaves;
 }
 
 // ------------------------------------------------------------------ k_update
@@ -879,6 +938,9 @@ constexpr size_t kLdsBudget = 160 * 1024 - 512;
 
 // 0: factor in LDS as double, 1: in LDS as float, 2: in the global workspace (float)
 int solver_mode(const PlanDev &pd) {
+    static const int force = std::getenv("BT_SOLVER_MODE") ? std::atoi(std::getenv("BT_SOLVER_MODE")) : -1;   // measurement only
+    if (force == 2) return 2;
+    if (force == 1 && solve_lds_bytes(pd, sizeof(float)) <= kLdsBudget) return 1;
     if (solve_lds_bytes(pd, sizeof(double)) <= kLdsBudget) return 0;
     if (solve_lds_bytes(pd, sizeof(float)) <= kLdsBudget) return 1;
     return 2;
