@@ -622,8 +622,8 @@ size_t solve_lds_bytes(const PlanDev &pd, size_t elem) {
     return b + 64;
 }
 
-template <typename T>
-__global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
+template <typename T, bool PROF>
+__global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[2];
     const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63;
@@ -635,8 +635,8 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
     off = (off + (size_t)pd.nupd * 3 * sizeof(unsigned short) + 15) / 16 * 16;
     int *row_idx = reinterpret_cast<int *>(smem + off), *col_ptr = row_idx + nnzb, *upd_ptr = col_ptr + n + 1,
         *upd_next = upd_ptr + n + 1;
-    long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = clock64(), tn;
-#define BT_PF(i) do { tn = clock64(); pf[i] += tn - tc; tc = tn; } while (0)
+    long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
+#define BT_PF(i) do { if (PROF) { tn = clock64(); pf[i] += tn - tc; tc = tn; } } while (0)
     // structure -> LDS (coalesced), element -> (row, col) through zt as scratch is not possible for T=float
     for (int i = tid; i < pd.nupd * 3; i += nth) upd[i] = (unsigned short)pd.upd[i];
     for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i];
@@ -676,7 +676,17 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
                 has_diag = upd_next[j - 1] > 0;             // first triple of column j-1 hits the diagonal of column j
             }
             if (wave == 0) {
-                if (has_diag && lane < 36) apply_update(Lw, upd + 3 * u0, lane);
+                if (has_diag && lane < 36) {                       // block (j, j-1) is the first sub-block of column j-1
+                    const int r = lane / 6, c = lane - 6 * r;
+                    const T *src = Lw + (size_t)(dposp + 1) * 36;
+                    T x[6], y[6];
+                    load_row6(src + 6 * r, x);
+                    load_row6(src + 6 * c, y);
+                    T acc = x[0] * y[0];
+#pragma unroll
+                    for (int k = 1; k < 6; ++k) acc += x[k] * y[k];
+                    Lw[(size_t)dpos * 36 + lane] -= acc;
+                }
                 wave_fence();
                 T ad[21], L[21];
                 const T *dblk = Lw + (size_t)dpos * 36;
@@ -838,7 +848,7 @@ __global__ __launch_bounds__(512) void k_solve_lds(PlanDev pd, StepArgs a) {
     for (int i = tid; i < D; i += nth) a.dx[i] = (float)zt[i];
     if (tid == 0) a.status[0] = status;
     BT_PF(8);
-    if ((a.dbg & 16) && lane == 0 && wave < 2) {        // measurement only: phase cycle counts of waves 0 and 1
+    if (PROF && lane == 0 && wave < 2) {        // measurement only: phase cycle counts of waves 0 and 1
         long long *o = reinterpret_cast<long long *>(a.status + 4) + wave * 10;
         for (int i = 0; i < 10; ++i) o[i] = pf[i];
     }
@@ -946,6 +956,11 @@ int solver_mode(const PlanDev &pd) {
     return 2;
 }
 
+static int solver_threads() {
+    static const int t = std::getenv("BT_SOLVER_THREADS") ? std::atoi(std::getenv("BT_SOLVER_THREADS")) : 1024;   // measurement only
+    return t >= 128 && t <= 1024 ? (t / 64) * 64 : 1024;
+}
+
 int configure_kernels(const PlanDev &pd) {
     const size_t need = tile_lds_bytes(pd, false);
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
@@ -955,12 +970,15 @@ int configure_kernels(const PlanDev &pd) {
             return BT_EHIP;
     }
     const int mode = solver_mode(pd);
-    if (mode == 0 && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_lds<double>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes(pd, 8)) != hipSuccess)
-        return BT_EHIP;
-    if (mode == 1 && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_lds<float>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes(pd, 4)) != hipSuccess)
-        return BT_EHIP;
+    const void *fns[4] = { reinterpret_cast<const void *>(&k_solve_lds<double, false>),
+                           reinterpret_cast<const void *>(&k_solve_lds<double, true>),
+                           reinterpret_cast<const void *>(&k_solve_lds<float, false>),
+                           reinterpret_cast<const void *>(&k_solve_lds<float, true>) };
+    if (mode < 2)
+        for (int v = 0; v < 2; ++v)
+            if (hipFuncSetAttribute(fns[2 * mode + v], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)solve_lds_bytes(pd, mode == 0 ? 8 : 4)) != hipSuccess)
+                return BT_EHIP;
     return BT_OK;
 }
 
@@ -993,8 +1011,12 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
 int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev) {
     if (!so) {
         const int mode = solver_mode(pd);
-        if (mode == 0)      BT_LAUNCH(3, k_solve_lds<double>, dim3(1), dim3(512), solve_lds_bytes(pd, 8), pd, a);
-        else if (mode == 1) BT_LAUNCH(3, k_solve_lds<float>, dim3(1), dim3(512), solve_lds_bytes(pd, 4), pd, a);
+        const bool prof = (a.dbg & 16) != 0;
+        const int nthr = solver_threads();
+        if (mode == 0 && !prof)      BT_LAUNCH(3, (k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
+        else if (mode == 0)          BT_LAUNCH(3, (k_solve_lds<double, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
+        else if (mode == 1 && !prof) BT_LAUNCH(3, (k_solve_lds<float, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4), pd, a);
+        else if (mode == 1)          BT_LAUNCH(3, (k_solve_lds<float, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4), pd, a);
         else                BT_LAUNCH(3, k_solve_global, dim3(1), dim3(1024), 0, pd, a);
     }
     const int do_poses = so ? (copy_poses ? 1 : 0) : 1;
