@@ -28,9 +28,9 @@ def _qmul(a, b):
 
 
 def _qrot(q, p):
-    qv = q[..., :3]
-    uv = 2.0 * torch.linalg.cross(qv.expand_as(p), p)
-    return p + q[..., 3:] * uv + torch.linalg.cross(qv.expand_as(p), uv)
+    qv, p = torch.broadcast_tensors(q[..., :3], p)
+    uv = 2.0 * torch.linalg.cross(qv, p)
+    return p + q[..., 3:] * uv + torch.linalg.cross(qv, uv)
 
 
 class SE3:
@@ -114,7 +114,8 @@ class SE3:
         t, q = self._tq()
         if p.shape[-1] == 3:
             return _qrot(q, p) + t
-        return torch.cat([_qrot(q, p[..., :3]) + t * p[..., 3:], p[..., 3:]], -1)
+        xyz = _qrot(q, p[..., :3]) + t * p[..., 3:]
+        return torch.cat([xyz, p[..., 3:].expand(xyz.shape[:-1] + (1,))], -1)
 
     def __mul__(self, other):
         if isinstance(other, SE3):
@@ -135,7 +136,8 @@ class SE3:
         t, q = self._tq()
         qi = torch.cat([-q[..., :3], q[..., 3:]], -1)
         at, ap = a[..., :3], a[..., 3:]
-        return torch.cat([_qrot(qi, at), _qrot(qi, torch.linalg.cross(at, t.expand_as(at)) + ap)], -1)
+        at, tb = torch.broadcast_tensors(at, t)
+        return torch.cat([_qrot(qi, at), _qrot(qi, torch.linalg.cross(at, tb) + ap)], -1)
 
     @classmethod
     def exp(cls, x):

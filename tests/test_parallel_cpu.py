@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: two gloo ranks.  Each rank takes its track shard
+(batrack_amd.parallel.shard_edges), the reduced system of the shard is produced by the
+float64 plan emulator (test infrastructure standing in for the HIP kernels), the
+product's all-reduce helper sums them, and the result must equal the full system."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _worker(rank, world, port, name, fixedp, out):
+    sys.path[:0] = [os.path.dirname(HERE), HERE]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from batrack_amd.parallel import shard_edges, allreduce_system, partition_tracks
+        from batrack_amd.plan import Plan
+        from plan_emulator import run as emulate
+        d = dict(np.load(os.path.join(GOLD, name + ".npz")))
+        n_all = int(max(d["ii"].max(), d["jj"].max())) + 1
+        idx = shard_edges(torch.as_tensor(d["kk"]), world, rank).numpy()
+        loc = dict(d)
+        for k in ("ii", "jj", "kk", "targets3", "weights", "weights_pose"):
+            loc[k] = d[k][idx]
+        pl = Plan(loc["ii"], loc["jj"], loc["kk"], d["poses"].shape[0], d["patches"].shape[0], fixedp,
+                  upload=False, n_all_min=n_all)
+        assert pl.n == n_all - fixedp                       # every rank builds the same-size system
+        em = emulate(pl, pl.arrays(), loc, "weights_pose")
+        D = 6 * pl.n
+        system = torch.as_tensor(np.concatenate([np.tril(em["S_lower"]).reshape(-1), em["y"]]))
+        allreduce_system(system)
+        ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"],
+                             d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=fixedp, want_system=True)
+        S = system[:D * D].reshape(D, D).numpy()
+        y = system[D * D:].numpy()
+        eS = np.linalg.norm(S - np.tril(ref["S"])) / np.linalg.norm(np.tril(ref["S"]))
+        ey = np.linalg.norm(y - ref["y"]) / np.linalg.norm(ref["y"])
+        # shards are a partition of the edges, by track
+        cover = torch.zeros(len(d["kk"]), dtype=torch.int64)
+        cover[torch.as_tensor(idx)] = 1
+        dist.all_reduce(cover)
+        lo, hi = partition_tracks(d["kk"], world)[rank]
+        ok_part = bool((cover == 1).all()) and bool(((loc["kk"] >= lo) & (loc["kk"] < hi)).all())
+        out[rank] = (float(eS), float(ey), ok_part, len(idx))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,fixedp", [("c1", 1), ("c1_rough", 2)])
+def test_two_rank_sharded_reduce_equals_full(name, fixedp):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, name, fixedp, out), nprocs=world, join=True)
+    assert len(out) == world
+    sizes = []
+    for r in range(world):
+        eS, ey, ok_part, nloc = out[r]
+        assert ok_part
+        assert eS < 1e-10 and ey < 1e-10, (eS, ey)
+        sizes.append(nloc)
+    assert sum(sizes) == len(np.load(os.path.join(GOLD, name + ".npz"))["kk"])
+    assert min(sizes) > 0.3 * max(sizes)                 # balanced by edge count
+
+
+def test_partition_tracks_properties():
+    from batrack_amd.parallel import partition_tracks
+    rng = np.random.default_rng(0)
+    kk = np.sort(rng.integers(0, 500, 5000))
+    for world in (1, 2, 3, 8):
+        b = partition_tracks(kk, world)
+        assert len(b) == world and b[0][0] == kk.min() and b[-1][1] == kk.max() + 1
+        for (l0, h0), (l1, h1) in zip(b[:-1], b[1:]):
+            assert h0 == l1 and l0 <= h0
+        counts = [int(((kk >= lo) & (kk < hi)).sum()) for lo, hi in b]
+        assert sum(counts) == len(kk)
