@@ -536,7 +536,12 @@ __global__ __launch_bounds__(1024) void k_solve_global(PlanDev pd, StepArgs a) {
 
 template <typename T> __device__ __forceinline__ T rsqrt_t(T x);
 template <> __device__ __forceinline__ float rsqrt_t<float>(float x) { return rsqrtf(x); }
-template <> __device__ __forceinline__ double rsqrt_t<double>(double x) { return rsqrt(x); }
+template <> __device__ __forceinline__ double rsqrt_t<double>(double x) {
+    // fp32 hardware seed (1 ulp) + one Newton step in double: relative error ~1e-14.
+    // A non-positive or NaN pivot is caught by the caller's (s > 0) test.
+    const double y = (double)__builtin_amdgcn_rsqf((float)x);
+    return y * (1.5 - 0.5 * x * y * y);
+}
 
 template <typename T> struct Vec2;
 template <> struct Vec2<float> { typedef float2 type; };
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
 #define BT_PF(i) do { if (PROF) { tn = clock64(); pf[i] += tn - tc; tc = tn; } } while (0)
     // structure -> LDS (coalesced), element -> (row, col) through zt as scratch is not possible for T=float
     for (int i = tid; i < pd.nupd * 3; i += nth) upd[i] = (unsigned short)pd.upd[i];
-    for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i];
+    for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8);   // row | col << 8
     for (int i = tid; i <= n; i += nth) { col_ptr[i] = pd.col_ptr[i]; upd_ptr[i] = pd.upd_ptr[i]; upd_next[i] = pd.upd_next[i]; }
     __syncthreads();
 
@@ -647,19 +652,35 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         const double lm = attempt == 0 ? 1e-4 : 1e-3;
         if (tid < 2) flags[tid] = 0;
-        // one thread per block row: 6 contiguous doubles of S
-        for (int idx = tid; idx < nnzb * 6; idx += nth) {
-            const int b = idx / 6, r = idx - 6 * b;
-            const int row = row_idx[b], col = pd.blk_col[b];
-            const double *src = a.S + (size_t)(6 * row + r) * D + 6 * col;
-            T v[6];
+        // one thread per block row: 6 contiguous doubles of S; 4 rounds of loads in flight
+        for (int base = 0; base < nnzb * 6; base += 4 * nth) {
+            double v[4][6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double x = (row > col || r >= c) ? src[c] : 0.0;
-                if (row == col && r == c) x = x + ((double)a.ep + lm * x);            // ba.py:67
-                v[c] = (T)x;
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * nth + tid;
+                if (idx < nnzb * 6) {
+                    const int b = idx / 6, r = idx - 6 * b, rc = row_idx[b];
+                    const double *src = a.S + (size_t)(6 * (rc & 255) + r) * D + 6 * (rc >> 8);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) v[u][c] = src[c];
+                }
             }
-            store_row6(Lw + (size_t)b * 36 + 6 * r, v);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * nth + tid;
+                if (idx < nnzb * 6) {
+                    const int b = idx / 6, r = idx - 6 * b, rc = row_idx[b];
+                    const bool diag = (rc & 255) == (rc >> 8);
+                    T w[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double x = (!diag || r >= c) ? v[u][c] : 0.0;
+                        if (diag && r == c) x = x + ((double)a.ep + lm * x);          // ba.py:67
+                        w[c] = (T)x;
+                    }
+                    store_row6(Lw + (size_t)b * 36 + 6 * r, w);
+                }
+            }
         }
         for (int i = tid; i < D; i += nth) z[i] = (T)a.y[i];
         __syncthreads();
@@ -725,7 +746,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                         T acc = lr[0] * zr[0];
 #pragma unroll
                         for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
-                        z[6 * row_idx[dposp + 1 + s] + r] -= acc;
+                        z[6 * (row_idx[dposp + 1 + s] & 255) + r] -= acc;
                     }
                 }
                 BT_PF(1);
@@ -792,8 +813,8 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
             T *p, *q;
             if (idx < nnzb * 6) {
                 const int b = idx / 6, r = idx - 6 * b;
-                j = pd.blk_col[b];
-                if (row_idx[b] == j) continue;
+                j = row_idx[b] >> 8;
+                if ((row_idx[b] & 255) == j) continue;
                 p = Lw + (size_t)b * 36 + 6 * r; q = p;
             } else {
                 j = idx - nnzb * 6;
@@ -817,13 +838,15 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
         if (wave == 0) {
             const int c = lane >> 3, g = lane & 7;
             for (int j = n - 1; j >= 0; --j) {
-                const int dpos = col_ptr[j], nterm = (col_ptr[j + 1] - dpos - 1) * 6;
-                const T *mb = Lw + (size_t)(dpos + 1) * 36 + c;
+                const int dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
                 T acc = (T)0;
                 if (c < 6)
-                    for (int t = g; t < nterm; t += 8) {
-                        const int s = t / 6, r = t - 6 * s;
-                        acc += mb[6 * t] * zt[6 * row_idx[dpos + 1 + s] + r];
+                    for (int sb = g; sb < cnt; sb += 8) {           // one sub-block per lane group
+                        const int b = dpos + 1 + sb;
+                        T x[6];
+                        load_row6(zt + 6 * (row_idx[b] & 255), x);
+                        const T *mb = Lw + (size_t)b * 36 + c;     // Mt[r][c]
+                        acc += mb[0] * x[0] + mb[6] * x[1] + mb[12] * x[2] + mb[18] * x[3] + mb[24] * x[4] + mb[30] * x[5];
                     }
                 acc = dpp_add8(acc);
                 if (c < 6 && g == 0) zt[6 * j + c] -= acc;
