@@ -127,10 +127,12 @@ __device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) 
 // LDS: Eh[R16][66] local E (row = 6*local_cam + comp, column = lane = track),
 // row R = 6*ncam holds w' (the augmented column that yields the Schur RHS),
 // then Cw[2][64] and Qs[64].
-template <bool SO>
+template <bool SO, bool PROF>
 __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
+#define BT_PF(i) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); tn = clock64(); pf[i] += tn - tc; tc = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
     const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
     const int R = 6 * ncam, R16 = SO ? 0 : ((R + 1 + 15) >> 4) << 4;
     float *Eh = lds, *Cw = lds + R16 * kLdsRowStride, *Qs = Cw + 128;
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
         px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2];
     }
     __syncthreads();
+    BT_PF(0);
 
     float Cacc = 0.0f, wacc = 0.0f;
     const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
@@ -170,6 +173,8 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
                 g[4*c] = t4.x; g[4*c + 1] = t4.y; g[4*c + 2] = t4.z; g[4*c + 3] = t4.w;
             }
         }
+        if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        BT_PF(1);
         EdgeQ q;
         edge_eval(g, px, py, pdisp, tu, tv, w0, w1, a, q);
         if (!act) { q.W0 = 0.0f; q.W1 = 0.0f; q.r0 = 0.0f; q.r1 = 0.0f; }
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
             }
         }
 
+        BT_PF(2);
         // per-pair sums: Bjj (21, row-major upper triangle) and gj (6)   (ba.py:260,266)
         float vals[32];
         vals[0] = wa0 * q.a0;  vals[1] = 0.0f;        vals[2] = wa0 * q.a2;  vals[3] = wa0 * q.a3;
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
                 atomicAdd(&a.pairacc[(size_t)p0 * kPairAccStride + vi], (double)v[0]);
             todo &= ~__ballot(mine);
         }
+        BT_PF(3);
     }
 
     atomicAdd(&Cw[lane], Cacc);
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
     }
     if (SO) return;
     __syncthreads();
+    BT_PF(4);
 
     // keep E for the depth back-substitution (ba.py:328)
     for (int row = wave; row < R; row += 4)
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
     // Schur product of the tile on the matrix cores: out[i][j] = sum_k Q_k Eh[i][k] Eh[j][k]
     // over the 64 tracks; row R gives -(E Q w').  f64 MFMA so that the 64-term sums
     // are exact products accumulated in double (DESIGN.md "precision").
+    BT_PF(5);
     const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
     const int *cams = pd.tile_cams + pd.tile_cam0[tile];
     for (int t = wave; t < ntl && !(a.dbg & 4); t += 4) {
@@ -276,6 +285,7 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
             const double bv = (double)br[4 * ks];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
+        BT_PF(6);
         // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
         const int col = 16 * tj + (lane & 15);
 #pragma unroll
@@ -291,7 +301,15 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
                 }
             }
         }
+        BT_PF(7);
     }
+    if (PROF && lane == 0 && wave == 0 && (tile == 0 || tile == pd.T / 2)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BT_PF(8);
+        long long *o = reinterpret_cast<long long *>(a.status + 4) + (tile == 0 ? 20 : 30);
+        for (int i = 0; i < 10; ++i) o[i] = pf[i];
+    }
+#undef BT_PF
 }
 
 // ------------------------------------------------------------------ k_pair_finalize
@@ -988,7 +1006,9 @@ int configure_kernels(const PlanDev &pd) {
     const size_t need = tile_lds_bytes(pd, false);
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
     if (need > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)
             return BT_EHIP;
     }
@@ -1023,8 +1043,9 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
     if (nb < 1) nb = 1;
     BT_LAUNCH(0, k_prep, dim3((unsigned)nb), dim3(256), 0, pd, a, zero_doubles, zero);
     if (pd.T > 0) {
-        if (so) BT_LAUNCH(1, k_tile<true>, dim3(pd.T), dim3(256), tile_lds_bytes(pd, true), pd, a);
-        else    BT_LAUNCH(1, k_tile<false>, dim3(pd.T), dim3(256), tile_lds_bytes(pd, false), pd, a);
+        if (so)                BT_LAUNCH(1, (k_tile<true, false>), dim3(pd.T), dim3(256), tile_lds_bytes(pd, true), pd, a);
+        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), dim3(pd.T), dim3(256), tile_lds_bytes(pd, false), pd, a);
+        else                   BT_LAUNCH(1, (k_tile<false, false>), dim3(pd.T), dim3(256), tile_lds_bytes(pd, false), pd, a);
     }
     if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);

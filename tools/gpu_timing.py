@@ -37,6 +37,14 @@ for k in range(200):
     st.step(poses, patches, mono, intr, t3, 3, w, Po, Xo, *scal, False)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / 200 * 1e6
+if int(os.environ.get("BT_DEBUG_MODE", "0")) & 32:
+    off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
+    raw = st.ws.cpu().numpy()
+    stat_off = off + ((6 * plan.n * 4 + 64 + 255) // 256) * 256
+    pf = np.frombuffer(raw[stat_off + 16 + 160: stat_off + 16 + 320].tobytes(), dtype=np.int64).reshape(2, 10)
+    names = ["prologue", "loadwait", "math+E", "pairreduce", "CwQ", "Esave", "mfma", "epilogue", "drain", "-"]
+    for w, nm in enumerate(("tile0", "tileMid")):
+        print(f"  k_tile {nm} wave0 cycles: " + " ".join(f"{n}={v}" for n, v in zip(names, pf[w])) + f" total={pf[w].sum()}")
 if int(os.environ.get("BT_DEBUG_MODE", "0")) & 16:
     import ctypes
     off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
