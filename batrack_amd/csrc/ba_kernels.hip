@@ -106,9 +106,22 @@ __device__ __forceinline__ void edge_eval(const float *g, float x, float y, floa
     o.r0 = vld * r0; o.r1 = vld * r1;
 }
 
-// Sum v[0..31] over the lanes of a wave; afterwards every lane holds, in v[0],
-// the total of element ((lane >> 1) & 31).  32 shuffles instead of 32 * 6.
+// Sum v[0..31] over the 64 lanes of a wave; afterwards every lane holds, in v[0], the
+// total of element ((lane >> 1) & 31).  Halving exchange: 16 + 8 lane-swap instructions
+// (v_permlane32_swap / v_permlane16_swap move two registers at once) and 7 shuffles,
+// instead of 32 * 6 shuffles for a plain butterfly.
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {       // lanes < 32 keep v[i], lanes >= 32 keep v[i+16]
+        const uint2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+        v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {        // even 16-lane rows keep v[i], odd rows keep v[i+8]
+        const uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
+        v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
 #define BT_RS_STEP(M, H)                                            \
     {                                                               \
         const bool up = (lane & (M)) != 0;                          \
@@ -118,25 +131,42 @@ __device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) 
             v[i] = keep + __shfl_xor(send, (M));                    \
         }                                                           \
     }
-    BT_RS_STEP(32, 16) BT_RS_STEP(16, 8) BT_RS_STEP(8, 4) BT_RS_STEP(4, 2) BT_RS_STEP(2, 1)
+    BT_RS_STEP(8, 4) BT_RS_STEP(4, 2) BT_RS_STEP(2, 1)
 #undef BT_RS_STEP
     v[0] += __shfl_xor(v[0], 1);
 }
 
 // ------------------------------------------------------------------ k_tile
-// LDS: Eh[R16][66] local E (row = 6*local_cam + comp, column = lane = track),
-// row R = 6*ncam holds w' (the augmented column that yields the Schur RHS),
-// then Cw[2][64] and Qs[64].
+// One workgroup of 8 waves per tile of <= 64 tracks; lane l of every wave owns track l.
+// Wave w takes a contiguous chunk of the tile's edge slots (one slot each on the
+// regular 8-observation graphs), so a wave sees one camera pair per slot and the
+// per-pair sums are full-wave reductions.
+// LDS: Eh[R16][66]   local E: row = 6*local_cam + comp, column = lane = track; row R = w'
+//      stg[8][8][64] per-wave partials of (E at the source camera, C, w) per track
+//      las[8][64]    local source camera of those partials
+//      Qs[64], gidx[R16] (global row of a local row)
+// E accumulation never uses LDS atomics on the common path: a track's target-camera
+// rows are written by the wave that owns the slot (plain read-add-write), its
+// source-camera row is summed in registers and merged by an owner thread after the
+// barrier.  Only a duplicated (track, target camera) observation that straddles two
+// waves' chunks falls back to ds_add_f32.
+constexpr int kTileWaves = 8;
+
 template <bool SO, bool PROF>
-__global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
+__global__ __launch_bounds__(512) void k_tile(PlanDev pd, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); tn = clock64(); pf[i] += tn - tc; tc = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
     const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
     const int R = 6 * ncam, R16 = SO ? 0 : ((R + 1 + 15) >> 4) << 4;
-    float *Eh = lds, *Cw = lds + R16 * kLdsRowStride, *Qs = Cw + 128;
-    for (int i = tid; i < R16 * kLdsRowStride + 192; i += 256) lds[i] = 0.0f;
+    float *Eh = lds, *stg = Eh + R16 * kLdsRowStride;
+    int *las = reinterpret_cast<int *>(stg + kTileWaves * 8 * 64);
+    float *Qs = reinterpret_cast<float *>(las + kTileWaves * 64);
+    int *gidx = reinterpret_cast<int *>(Qs + 64);
+    const int *cams = pd.tile_cams + pd.tile_cam0[tile];
+    for (int i = tid; i < R16 * kLdsRowStride; i += 512) Eh[i] = 0.0f;
+    for (int i = tid; i < R16; i += 512) gidx[i] = i < R ? 6 * cams[i / 6] + i % 6 : -1;
 
     const int trk = pd.tile_trk0[tile] + lane;
     const bool has_trk = lane < ntrk;
@@ -146,17 +176,24 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
         patch = pd.kx[trk];
         px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2];
     }
+    const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
+    const int chunk = (nslot + kTileWaves - 1) / kTileWaves;
+    const int s0 = wave * chunk, s1 = min(nslot, s0 + chunk);
     __syncthreads();
     BT_PF(0);
 
-    float Cacc = 0.0f, wacc = 0.0f;
-    const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
-    for (int s = wave; s < nslot; s += 4) {
+    float Cacc = 0.0f, wacc = 0.0f, Ei[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned la_cur = 0xffu;
+    for (int s = s0; s < s1; ++s) {
         const size_t idx = (size_t)(slot0 + s) * kLanes + lane;
         const int e = pd.slot_edge[idx];
         const bool act = e >= 0;
         const int pair = pd.slot_pair[idx];
         const unsigned lab = pd.slot_lab[idx];
+        // a (track, target camera) observation duplicated into a neighbouring wave's chunk?
+        unsigned lab_nb = 0xffffu, lab_nb2 = 0xffffu;
+        if (!SO && s == s0 && s > 0) lab_nb = pd.slot_lab[idx - kLanes];
+        if (!SO && s == s1 - 1 && s + 1 < nslot) lab_nb2 = pd.slot_lab[idx + kLanes];
         float tu = 0.0f, tv = 0.0f, w0 = 0.0f, w1 = 0.0f;
         if (act) {
             const float *tp = a.targets + (size_t)e * a.tstride;
@@ -187,28 +224,41 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
         const float wa0 = q.W0 * q.a0, wa2 = q.W0 * q.a2, wa3 = q.W0 * q.a3, wa4 = q.W0 * q.a4, wa5 = q.W0 * q.a5;
         const float wb1 = q.W1 * q.b1, wb2 = q.W1 * q.b2, wb3 = q.W1 * q.b3, wb4 = q.W1 * q.b4, wb5 = q.W1 * q.b5;
         // Ej = Jj^T W Jz (ba.py:263) and Ei = -Ad^T Ej
-        float Ej[6] = { wa0 * q.jz0, wb1 * q.jz1, fmaf(wa2, q.jz0, wb2 * q.jz1), fmaf(wa3, q.jz0, wb3 * q.jz1),
-                        fmaf(wa4, q.jz0, wb4 * q.jz1), fmaf(wa5, q.jz0, wb5 * q.jz1) };
+        const float Ej[6] = { wa0 * q.jz0, wb1 * q.jz1, fmaf(wa2, q.jz0, wb2 * q.jz1), fmaf(wa3, q.jz0, wb3 * q.jz1),
+                              fmaf(wa4, q.jz0, wb4 * q.jz1), fmaf(wa5, q.jz0, wb5 * q.jz1) };
         const unsigned la = lab & 0xffu, lb = lab >> 8;
         if (act && lb != 0xffu && !(a.dbg & 8)) {
+            float *row = Eh + lb * 6 * kLdsRowStride + lane;
+            if (lb == (lab_nb >> 8) || lb == (lab_nb2 >> 8)) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) atomicAdd(&Eh[(lb * 6 + c) * kLdsRowStride + lane], Ej[c]);
+                for (int c = 0; c < 6; ++c) atomicAdd(row + c * kLdsRowStride, Ej[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) row[c * kLdsRowStride] += Ej[c];
+            }
         }
-        if (act && la != 0xffu && !(a.dbg & 8)) {
+        if (act && la != 0xffu) {
+            if (la != la_cur) {          // source camera changed within the chunk (not produced by the reference's caller)
+                if (la_cur != 0xffu) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) atomicAdd(&Eh[(la_cur * 6 + c) * kLdsRowStride + lane], Ei[c]);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) Ei[c] = 0.0f;
+                }
+                la_cur = la;
+            }
             // o_tau = R^T e_tau ; o_phi = R^T (e_tau x t + e_phi)      (se3.h:58-67)
             const float cx = Ej[1]*g[11] - Ej[2]*g[10] + Ej[3];
             const float cy = Ej[2]*g[9]  - Ej[0]*g[11] + Ej[4];
             const float cz = Ej[0]*g[10] - Ej[1]*g[9]  + Ej[5];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float ot = g[c]*Ej[0] + g[3 + c]*Ej[1] + g[6 + c]*Ej[2];
-                const float op = g[c]*cx + g[3 + c]*cy + g[6 + c]*cz;
-                atomicAdd(&Eh[(la * 6 + c) * kLdsRowStride + lane], -ot);
-                atomicAdd(&Eh[(la * 6 + 3 + c) * kLdsRowStride + lane], -op);
+                Ei[c]     -= g[c]*Ej[0] + g[3 + c]*Ej[1] + g[6 + c]*Ej[2];
+                Ei[3 + c] -= g[c]*cx + g[3 + c]*cy + g[6 + c]*cz;
             }
         }
-
         BT_PF(2);
+
         // per-pair sums: Bjj (21, row-major upper triangle) and gj (6)   (ba.py:260,266)
         float vals[32];
         vals[0] = wa0 * q.a0;  vals[1] = 0.0f;        vals[2] = wa0 * q.a2;  vals[3] = wa0 * q.a3;
@@ -241,17 +291,30 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
         BT_PF(3);
     }
 
-    atomicAdd(&Cw[lane], Cacc);
-    atomicAdd(&Cw[64 + lane], wacc);
+    // per-wave partials -> LDS
+#pragma unroll
+    for (int c = 0; c < 6; ++c) stg[(wave * 8 + c) * 64 + lane] = Ei[c];
+    stg[(wave * 8 + 6) * 64 + lane] = Cacc;
+    stg[(wave * 8 + 7) * 64 + lane] = wacc;
+    las[wave * 64 + lane] = (int)la_cur;
     __syncthreads();
-    if (wave == 0) {                                                   // ba.py:296-311
+    if (!SO && wave < 6) {                          // owner of component `wave` of every track's source-camera E
+        for (int w = 0; w < kTileWaves; ++w) {
+            const int lw = las[w * 64 + lane];
+            if (lw != 0xff) Eh[(lw * 6 + wave) * kLdsRowStride + lane] += stg[(w * 8 + wave) * 64 + lane];
+        }
+    }
+    if (wave == 6) {                                                   // ba.py:296-311
+        float C = 0.0f, wv = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kTileWaves; ++w) { C += stg[(w * 8 + 6) * 64 + lane]; wv += stg[(w * 8 + 7) * 64 + lane]; }
         float Q = 0.0f, wp = 0.0f;
         if (has_trk) {
             const float mono = a.mono[patch];
             const float pm = mono > 1e-2f ? 1.0f : 0.0f;
-            float Ca = Cw[lane] + pm * a.alpha;
+            float Ca = C + pm * a.alpha;
             Ca = Ca + a.lmbda;
-            wp = Cw[64 + lane] - pm * a.alpha * (pdisp - mono);
+            wp = wv - pm * a.alpha * (pdisp - mono);
             Q = 1.0f / Ca;
             a.qw[trk] = make_float2(Q, wp);
         }
@@ -262,41 +325,39 @@ __global__ __launch_bounds__(256) void k_tile(PlanDev pd, StepArgs a) {
     BT_PF(4);
 
     // keep E for the depth back-substitution (ba.py:328)
-    for (int row = wave; row < R; row += 4)
+    for (int row = wave; row < R; row += kTileWaves)
         a.esave[((size_t)pd.tile_erow0[tile] + row) * kLanes + lane] = Eh[row * kLdsRowStride + lane];
+    BT_PF(5);
 
     // Schur product of the tile on the matrix cores: out[i][j] = sum_k Q_k Eh[i][k] Eh[j][k]
-    // over the 64 tracks; row R gives -(E Q w').  f64 MFMA so that the 64-term sums
-    // are exact products accumulated in double (DESIGN.md "precision").
-    BT_PF(5);
+    // over the 64 tracks; row R gives E Q w'.  f64 MFMA: the fp32 products are exact in
+    // double, so the 64-term sums carry no fp32 accumulation error (DESIGN.md "precision").
     const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
-    const int *cams = pd.tile_cams + pd.tile_cam0[tile];
-    for (int t = wave; t < ntl && !(a.dbg & 4); t += 4) {
+    for (int t = wave; t < ntl && !(a.dbg & 4); t += kTileWaves) {
         int ti = 0, base = 0;
         while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
         const int tj = t - base;
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
         const float *ar = Eh + (16 * ti + (lane & 15)) * kLdsRowStride + (lane >> 4);
         const float *br = Eh + (16 * tj + (lane & 15)) * kLdsRowStride + (lane >> 4);
         const float *qr = Qs + (lane >> 4);
-#pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-            const double av = (double)ar[4 * ks] * (double)qr[4 * ks];
-            const double bv = (double)br[4 * ks];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        }
+        float av[16], bv[16], qv[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) { av[ks] = ar[4 * ks]; bv[ks] = br[4 * ks]; qv[ks] = qr[4 * ks]; }
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks] * (double)qv[ks], (double)bv[ks], acc, 0, 0, 0);
         BT_PF(6);
         // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-        const int col = 16 * tj + (lane & 15);
+        const int gc = gidx[16 * tj + (lane & 15)];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * ti + (lane >> 4) + 4 * r;
-            if (col < R && row <= R && !(a.dbg & 1)) {
-                const int gc = 6 * cams[col / 6] + col % 6;
+            if (gc >= 0 && row <= R && !(a.dbg & 1)) {
                 if (row == R) {
                     atomicAdd(&a.y[gc], -acc[r]);
                 } else {
-                    const int gr = 6 * cams[row / 6] + row % 6;
+                    const int gr = gidx[row];
                     if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]);
                 }
             }
@@ -982,7 +1043,8 @@ __global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_p
 
 // ------------------------------------------------------------------ launchers
 static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
-    return (size_t)((so ? 0 : pd.max_rows16) * kLdsRowStride + 192) * sizeof(float);
+    const size_t rows = so ? 0 : (size_t)pd.max_rows16;
+    return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 64 + rows) * sizeof(float) + 64;
 }
 
 constexpr size_t kLdsBudget = 160 * 1024 - 512;
@@ -1043,9 +1105,9 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
     if (nb < 1) nb = 1;
     BT_LAUNCH(0, k_prep, dim3((unsigned)nb), dim3(256), 0, pd, a, zero_doubles, zero);
     if (pd.T > 0) {
-        if (so)                BT_LAUNCH(1, (k_tile<true, false>), dim3(pd.T), dim3(256), tile_lds_bytes(pd, true), pd, a);
-        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), dim3(pd.T), dim3(256), tile_lds_bytes(pd, false), pd, a);
-        else                   BT_LAUNCH(1, (k_tile<false, false>), dim3(pd.T), dim3(256), tile_lds_bytes(pd, false), pd, a);
+        if (so)                BT_LAUNCH(1, (k_tile<true, false>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, true), pd, a);
+        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, false), pd, a);
+        else                   BT_LAUNCH(1, (k_tile<false, false>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, false), pd, a);
     }
     if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);
