@@ -14,7 +14,8 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 BT_OK, BT_EINVAL, BT_ENOMEM, BT_EHIP, BT_EUNSUPPORTED = 0, -1, -2, -3, -4
 ERRORS = {BT_EINVAL: "invalid argument", BT_ENOMEM: "out of memory", BT_EHIP: "HIP runtime error",
-          BT_EUNSUPPORTED: "unsupported graph (n > 255 free poses or a track seen by > 64 free cameras)"}
+          BT_EUNSUPPORTED: "unsupported graph (n > 255 free poses, a track seen by > 64 free cameras, or a track "
+                           "whose edges name more than one source frame: ii must equal ix[kk])"}
 LOSS = {"trivial": 0, "huber": 1, "cauchy": 2}
 
 

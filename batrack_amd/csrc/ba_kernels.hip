@@ -238,15 +238,7 @@ __global__ __launch_bounds__(512) void k_tile(PlanDev pd, StepArgs a) {
             }
         }
         if (act && la != 0xffu) {
-            if (la != la_cur) {          // source camera changed within the chunk (not produced by the reference's caller)
-                if (la_cur != 0xffu) {
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) atomicAdd(&Eh[(la_cur * 6 + c) * kLdsRowStride + lane], Ei[c]);
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) Ei[c] = 0.0f;
-                }
-                la_cur = la;
-            }
+            la_cur = la;                 // one source camera per track: enforced by the plan (ii = ix[kk], batrack.py:199)
             // o_tau = R^T e_tau ; o_phi = R^T (e_tau x t + e_phi)      (se3.h:58-67)
             const float cx = Ej[1]*g[11] - Ej[2]*g[10] + Ej[3];
             const float cy = Ej[2]*g[9]  - Ej[0]*g[11] + Ej[4];

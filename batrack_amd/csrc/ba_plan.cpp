@@ -101,6 +101,11 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             return pa != pb ? pa < pb : a < b;
         });
 
+    // ---- one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)
+    for (int32_t k = 0; k < m; ++k)
+        for (int32_t sidx = off[(size_t)k] + 1; sidx < off[(size_t)k + 1]; ++sidx)
+            if (ii[ord[(size_t)sidx]] != ii[ord[(size_t)off[(size_t)k]]]) return BT_EUNSUPPORTED;
+
     // ---- tiles: greedy over sorted tracks ----------------------------------
     pl->tile_trk0.clear(); pl->tile_ntrk.clear(); pl->tile_ncam.clear(); pl->tile_cam0.clear();
     pl->tile_slot0.clear(); pl->tile_nslot.clear(); pl->tile_erow0.clear(); pl->tile_cams.clear();

@@ -66,7 +66,8 @@ typedef struct {
  * synchronously) or on the host (on_device=0).  upload=0 keeps the plan
  * host-only (no HIP call is made: CPU tests).  Errors: BT_EINVAL for indices
  * out of range, BT_EUNSUPPORTED if a single track is seen by more than 64 free
- * cameras or n > 255.
+ * cameras, n > 255, or the edges of one track name different source frames (the
+ * caller's invariant ii = ix[kk], batrack.py:199, is relied upon).
  * n_all_min: lower bound for n_all (0 = derive from the edges).  A rank that holds
  * only a shard of the edges passes the global n_all so that every rank builds a
  * reduced system of the same size. */

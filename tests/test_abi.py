@@ -79,6 +79,13 @@ def test_unsupported_graphs_are_reported():
     assert L.bt_plan_create(ii.ctypes.data, jj.ctypes.data, kk.ctypes.data, n, n, 4, 1, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EUNSUPPORTED
 
 
+def test_track_with_two_source_frames_is_rejected():
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    ii = np.array([0, 1], np.int64); jj = np.array([1, 2], np.int64); kk = np.array([3, 3], np.int64)
+    assert L.bt_plan_create(ii.ctypes.data, jj.ctypes.data, kk.ctypes.data, 2, 4, 8, 1, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EUNSUPPORTED
+
+
 def test_product_path_has_no_cpu_fallback():
     """BA_rgbd_droid must refuse CPU tensors instead of silently computing elsewhere."""
     import torch
