@@ -29,6 +29,8 @@ int upload_plan(bt_plan *pl) {
     const size_t o_se = put(buf, pl->slot_edge), o_sp = put(buf, pl->slot_pair), o_sl = put(buf, pl->slot_lab);
     const size_t o_cp = put(buf, pl->col_ptr), o_ri = put(buf, pl->row_idx), o_up = put(buf, pl->upd_ptr), o_u = put(buf, pl->upd);
     const size_t o_bc = put(buf, pl->blk_col), o_un = put(buf, pl->upd_next);
+    const size_t o_pm = put(buf, pl->perm), o_bs = put(buf, pl->blk_src), o_lp = put(buf, pl->lvl_ptr), o_lc = put(buf, pl->lvl_cols);
+    const size_t o_cl = put(buf, pl->col_lvl), o_dpp = put(buf, pl->dp_ptr), o_dp = put(buf, pl->dp);
     void *d = nullptr;
     if (hipMalloc(&d, buf.size() + 256) != hipSuccess) return BT_ENOMEM;
     if (hipMemcpy(d, buf.data(), buf.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return BT_EHIP; }
@@ -48,6 +50,9 @@ int upload_plan(bt_plan *pl) {
     P.slot_edge = BT_I32(o_se); P.slot_pair = BT_I32(o_sp);
     P.slot_lab = reinterpret_cast<const uint16_t *>(b + o_sl);
     P.col_ptr = BT_I32(o_cp); P.row_idx = BT_I32(o_ri); P.upd_ptr = BT_I32(o_up); P.upd = BT_I32(o_u); P.blk_col = BT_I32(o_bc); P.upd_next = BT_I32(o_un);
+    P.perm = BT_I32(o_pm); P.blk_src = BT_I32(o_bs); P.lvl_ptr = BT_I32(o_lp); P.lvl_cols = BT_I32(o_lc);
+    P.col_lvl = BT_I32(o_cl); P.dp_ptr = BT_I32(o_dpp); P.dp = BT_I32(o_dp);
+    P.nlev = (int)pl->lvl_ptr.size() - 1; P.ndp = (int)pl->dp.size();
 #undef BT_I32
     return configure_kernels(P);
 }
@@ -142,7 +147,8 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
     BT_ARR(kx) BT_ARR(trk_of_patch) BT_ARR(trk_loc) BT_ARR(pair_i) BT_ARR(pair_j)
     BT_ARR(tile_trk0) BT_ARR(tile_ntrk) BT_ARR(tile_ncam) BT_ARR(tile_cam0) BT_ARR(tile_slot0)
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
-    BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next)
+    BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next) BT_ARR(perm) BT_ARR(blk_src) BT_ARR(lvl_ptr) BT_ARR(lvl_cols)
+    BT_ARR(col_lvl) BT_ARR(dp_ptr) BT_ARR(dp)
 #undef BT_ARR
     return -1;
 }

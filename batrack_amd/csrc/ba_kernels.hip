@@ -497,12 +497,14 @@ __global__ __launch_bounds__(1024) void k_solve_global(PlanDev pd, StepArgs a) {
         // load the structurally non-zero blocks of S (+ damping) and y
         for (int idx = tid; idx < pd.nnzb * 36; idx += nth) {
             const int b = idx / 36, e = idx % 36, r = e / 6, c = e % 6;
-            const int row = pd.row_idx[b], col = pd.blk_col[b];
-            double v = (row > col || r >= c) ? a.S[(size_t)(6*row + r) * D + 6*col + c] : 0.0;
+            const int row = pd.row_idx[b], col = pd.blk_col[b], src = pd.blk_src[b];
+            const int rn = src >> 9, cn = (src >> 1) & 255;
+            const int rr = (src & 1) ? c : r, cc = (src & 1) ? r : c;       // transposed source block
+            double v = (row > col || r >= c) ? a.S[(size_t)(6*rn + rr) * D + 6*cn + cc] : 0.0;
             if (row == col && r == c) v = v + ((double)a.ep + (double)lm * v);
             Lw[idx] = (float)v;
         }
-        for (int i = tid; i < D; i += nth) z[i] = (float)a.y[i];
+        for (int i = tid; i < D; i += nth) z[i] = (float)a.y[6 * pd.perm[i / 6] + i % 6];
         __syncthreads();
 
         for (int j = 0; j < n; ++j) {
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(1024) void k_solve_global(PlanDev pd, StepArgs a) {
                 const float *L1 = Lw + (size_t)tr[0] * 36 + 6*r, *L2 = Lw + (size_t)tr[1] * 36 + 6*c;
                 float acc = 0.0f;
                 for (int k = 0; k < 6; ++k) acc += L1[k] * L2[k];
-                Lw[(size_t)tr[2] * 36 + e] -= acc;
+                Lw[(size_t)(tr[2] & 0x7fff) * 36 + e] -= acc;
             }
             __syncthreads();
         }
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(1024) void k_solve_global(PlanDev pd, StepArgs a) {
         status = BT_SOLVE_RETRIED;
     }
     __syncthreads();
-    for (int i = tid; i < D; i += nth) a.dx[i] = z[i];
+    for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = z[i];
     if (tid == 0) a.status[0] = status;
 }
 
@@ -632,13 +634,13 @@ __device__ __forceinline__ void store_row6(T *p, const T (&v)[6]) {
     reinterpret_cast<V *>(p)[0] = a; reinterpret_cast<V *>(p)[1] = b; reinterpret_cast<V *>(p)[2] = c;
 }
 
-// in: lower triangle a (packed).  out: L packed, diagonal entries hold 1 / l_cc.
+// in place: lower triangle (packed) -> its Cholesky factor, diagonal entries hold 1 / l_cc.
 template <typename T>
-__device__ __forceinline__ bool chol6_packed(const T (&a)[21], T (&L)[21]) {
+__device__ __forceinline__ bool chol6_packed(T (&L)[21]) {
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        T s = a[BT_LT(c, c)];
+        T s = L[BT_LT(c, c)];
 #pragma unroll
         for (int k = 0; k < c; ++k) s -= L[BT_LT(c, k)] * L[BT_LT(c, k)];
         ok = ok && (s > (T)0);
@@ -646,7 +648,7 @@ __device__ __forceinline__ bool chol6_packed(const T (&a)[21], T (&L)[21]) {
         L[BT_LT(c, c)] = il;
 #pragma unroll
         for (int r = c + 1; r < 6; ++r) {
-            T t = a[BT_LT(r, c)];
+            T t = L[BT_LT(r, c)];
 #pragma unroll
             for (int k = 0; k < c; ++k) t -= L[BT_LT(r, k)] * L[BT_LT(c, k)];
             L[BT_LT(r, c)] = t * il;
@@ -676,7 +678,22 @@ __device__ __forceinline__ double dpp_add8(double v) {
 
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
-// dst[e] -= (row r of block tr[0]) . (row c of block tr[1])
+size_t solve_lds_bytes(const PlanDev &pd, size_t elem) {
+    size_t b = ((size_t)pd.nnzb * 36 + 2 * (size_t)pd.D) * elem;          // Lw, z, zt
+    b = (b + 15) / 16 * 16;
+    b += (size_t)pd.nupd * 3 * sizeof(unsigned short);                     // update triples
+    b = (b + 15) / 16 * 16;
+    // row_idx, col_ptr, upd_ptr, upd_next, dp_ptr, lvl_ptr, lvl_cols, dp
+    b += ((size_t)pd.nnzb + 4 * ((size_t)pd.n + 1) + (size_t)pd.nlev + 1 + (size_t)pd.n + (size_t)pd.ndp) * sizeof(int);
+    return b + 64;
+}
+
+template <typename T> __device__ __forceinline__ void lds_sub(T *p, T v, bool atomic) {
+    if (atomic) atomicAdd(p, -v); else *p -= v;
+}
+
+// dst[e] -= (row r of block tr[0]) . (row c of block tr[1]);  bit 15 of tr[2]: destination shared
+// with another column of the level -> LDS atomic
 template <typename T>
 __device__ __forceinline__ void apply_update(T *Lw, const unsigned short *tr, int e) {
     const int r = e / 6, c = e - 6 * r;
@@ -686,16 +703,8 @@ __device__ __forceinline__ void apply_update(T *Lw, const unsigned short *tr, in
     T acc = a[0] * b[0];
 #pragma unroll
     for (int k = 1; k < 6; ++k) acc += a[k] * b[k];
-    Lw[(size_t)tr[2] * 36 + e] -= acc;
-}
-
-size_t solve_lds_bytes(const PlanDev &pd, size_t elem) {
-    size_t b = ((size_t)pd.nnzb * 36 + 2 * (size_t)pd.D) * elem;          // Lw, z, zt
-    b = (b + 15) / 16 * 16;
-    b += (size_t)pd.nupd * 3 * sizeof(unsigned short);                     // update triples
-    b = (b + 15) / 16 * 16;
-    b += ((size_t)pd.nnzb + 3 * ((size_t)pd.n + 1)) * sizeof(int);        // row_idx, col_ptr, upd_ptr, upd_next
-    return b + 64;
+    const unsigned d = tr[2];
+    lds_sub(Lw + (size_t)(d & 0x7fffu) * 36 + e, acc, (d & 0x8000u) != 0);
 }
 
 template <typename T, bool PROF>
@@ -703,41 +712,53 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[2];
     const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63;
-    const int n = pd.n, D = pd.D, nnzb = pd.nnzb;
+    const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
     T *Lw = reinterpret_cast<T *>(smem);
     T *z = Lw + (size_t)nnzb * 36, *zt = z + D;
     size_t off = (((size_t)nnzb * 36 + 2 * (size_t)D) * sizeof(T) + 15) / 16 * 16;
     unsigned short *upd = reinterpret_cast<unsigned short *>(smem + off);
     off = (off + (size_t)pd.nupd * 3 * sizeof(unsigned short) + 15) / 16 * 16;
     int *row_idx = reinterpret_cast<int *>(smem + off), *col_ptr = row_idx + nnzb, *upd_ptr = col_ptr + n + 1,
-        *upd_next = upd_ptr + n + 1;
+        *upd_next = upd_ptr + n + 1, *dp_ptr = upd_next + n + 1, *lvl_ptr = dp_ptr + n + 1,
+        *lvl_cols = lvl_ptr + nlev + 1, *dp = lvl_cols + n;
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { tn = clock64(); pf[i] += tn - tc; tc = tn; } } while (0)
-    // structure -> LDS (coalesced), element -> (row, col) through zt as scratch is not possible for T=float
     for (int i = tid; i < pd.nupd * 3; i += nth) upd[i] = (unsigned short)pd.upd[i];
     for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8);   // row | col << 8
-    for (int i = tid; i <= n; i += nth) { col_ptr[i] = pd.col_ptr[i]; upd_ptr[i] = pd.upd_ptr[i]; upd_next[i] = pd.upd_next[i]; }
+    for (int i = tid; i <= n; i += nth) {
+        col_ptr[i] = pd.col_ptr[i]; upd_ptr[i] = pd.upd_ptr[i]; upd_next[i] = pd.upd_next[i]; dp_ptr[i] = pd.dp_ptr[i];
+    }
+    for (int i = tid; i <= nlev; i += nth) lvl_ptr[i] = pd.lvl_ptr[i];
+    for (int i = tid; i < n; i += nth) lvl_cols[i] = pd.lvl_cols[i];
+    for (int i = tid; i < pd.ndp; i += nth) dp[i] = pd.dp[i];
     __syncthreads();
 
     int status = BT_SOLVE_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const double lm = attempt == 0 ? 1e-4 : 1e-3;
         if (tid < 2) flags[tid] = 0;
-        // one thread per block row: 6 contiguous doubles of S; 4 rounds of loads in flight
-        for (int base = 0; base < nnzb * 6; base += 4 * nth) {
-            double v[4][6];
+        // one thread per block row: 6 doubles of S (caller order, lower triangle; blk_src says where
+        // and whether transposed); 4 rounds of loads in flight
+        for (int base = 0; base < nnzb * 6; base += 2 * nth) {
+            double v[2][6];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 const int idx = base + u * nth + tid;
                 if (idx < nnzb * 6) {
-                    const int b = idx / 6, r = idx - 6 * b, rc = row_idx[b];
-                    const double *src = a.S + (size_t)(6 * (rc & 255) + r) * D + 6 * (rc >> 8);
+                    const int b = idx / 6, r = idx - 6 * b, src = pd.blk_src[b];
+                    const int rn = src >> 9, cn = (src >> 1) & 255;
+                    if (src & 1) {
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) v[u][c] = src[c];
+                        for (int c = 0; c < 6; ++c) v[u][c] = a.S[(size_t)(6 * rn + c) * D + 6 * cn + r];
+                    } else {
+                        const double *p = a.S + (size_t)(6 * rn + r) * D + 6 * cn;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) v[u][c] = p[c];
+                    }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 const int idx = base + u * nth + tid;
                 if (idx < nnzb * 6) {
                     const int b = idx / 6, r = idx - 6 * b, rc = row_idx[b];
@@ -753,43 +774,41 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                 }
             }
         }
-        for (int i = tid; i < D; i += nth) z[i] = (T)a.y[i];
+        for (int i = tid; i < D; i += nth) z[i] = (T)a.y[6 * pd.perm[i / 6] + i % 6];
         __syncthreads();
         BT_PF(0);
 
-        for (int j = 0; j < n; ++j) {
-            const int dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
+        for (int l = 0; l < nlev; ++l) {
+            const int c0 = lvl_ptr[l], nc = lvl_ptr[l + 1] - c0;
+            const int p0 = l > 0 ? lvl_ptr[l - 1] : 0, np = l > 0 ? c0 - p0 : 0;
             // ---- phase 1
-            int u0 = 0, nup = 0, cntp = 0, dposp = 0;
-            bool has_diag = false;
-            if (j > 0) {
-                u0 = upd_ptr[j - 1]; nup = upd_ptr[j] - u0;
-                dposp = col_ptr[j - 1]; cntp = dpos - dposp - 1;
-                has_diag = upd_next[j - 1] > 0;             // first triple of column j-1 hits the diagonal of column j
-            }
-            if (wave == 0) {
-                if (has_diag && lane < 36) {                       // block (j, j-1) is the first sub-block of column j-1
-                    const int r = lane / 6, c = lane - 6 * r;
-                    const T *src = Lw + (size_t)(dposp + 1) * 36;
-                    T x[6], y[6];
-                    load_row6(src + 6 * r, x);
-                    load_row6(src + 6 * c, y);
-                    T acc = x[0] * y[0];
+            if (wave < nc) {
+                const int j = lvl_cols[c0 + wave], dpos = col_ptr[j];
+                for (int k = dp_ptr[j]; k < dp_ptr[j + 1]; ++k) {        // pending updates of this column's diagonal block
+                    if (lane < 36) {
+                        const unsigned short *tr = upd + 3 * dp[k];
+                        const int r = lane / 6, c = lane - 6 * r;
+                        const T *src = Lw + (size_t)tr[0] * 36;
+                        T x[6], y[6];
+                        load_row6(src + 6 * r, x);
+                        load_row6(src + 6 * c, y);
+                        T acc = x[0] * y[0];
 #pragma unroll
-                    for (int k = 1; k < 6; ++k) acc += x[k] * y[k];
-                    Lw[(size_t)dpos * 36 + lane] -= acc;
+                        for (int q = 1; q < 6; ++q) acc += x[q] * y[q];
+                        Lw[(size_t)dpos * 36 + lane] -= acc;
+                    }
+                    wave_fence();
                 }
-                wave_fence();
-                T ad[21], L[21];
+                T L[21];
                 const T *dblk = Lw + (size_t)dpos * 36;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     T row[6];
                     load_row6(dblk + 6 * r, row);
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) ad[BT_LT(r, c)] = row[c];
+                    for (int c = 0; c <= r; ++c) L[BT_LT(r, c)] = row[c];
                 }
-                const bool ok = chol6_packed<T>(ad, L);
+                const bool ok = chol6_packed<T>(L);
                 BT_PF(2);
                 if (lane == 0) {
                     if (!ok) flags[0] = 1;
@@ -802,50 +821,61 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                     }
                 }
                 BT_PF(4);
-            } else if (j > 0) {
-                // remaining update triples of column j-1, then its contribution to y:  y_i -= L_i,j-1 z_j-1
-                const int first = has_diag ? 1 : 0, total = (nup - first) * 36 + cntp * 6;
-                for (int idx = tid - 64; idx < total; idx += nth - 64) {
-                    if (idx < (nup - first) * 36) {
-                        const int t = idx / 36;
-                        apply_update(Lw, upd + 3 * (u0 + first + t), idx - 36 * t);
-                    } else {
-                        const int q = idx - (nup - first) * 36, s = q / 6, r = q - 6 * s;
-                        T lr[6], zr[6];
-                        load_row6(Lw + (size_t)(dposp + 1 + s) * 36 + 6 * r, lr);
-                        load_row6(z + 6 * (j - 1), zr);
-                        T acc = lr[0] * zr[0];
+            } else {
+                // the other update triples of the previous level's columns, and their contribution to y
+                const int h = tid - 64 * nc, hs = nth - 64 * nc;
+                for (int q = 0; q < np; ++q) {
+                    const int pj = lvl_cols[p0 + q];
+                    const int u0 = upd_ptr[pj] + upd_next[pj], nu = upd_ptr[pj + 1] - u0;
+                    const int dposp = col_ptr[pj], cntp = col_ptr[pj + 1] - dposp - 1;
+                    const int total = nu * 36 + cntp * 6;
+                    for (int idx = h; idx < total; idx += hs) {
+                        if (idx < nu * 36) {
+                            const int t = idx / 36;
+                            apply_update(Lw, upd + 3 * (u0 + t), idx - 36 * t);
+                        } else {
+                            const int qq = idx - nu * 36, sb = qq / 6, r = qq - 6 * sb;
+                            T lr[6], zr[6];
+                            load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
+                            load_row6(z + 6 * pj, zr);
+                            T acc = lr[0] * zr[0];
 #pragma unroll
-                        for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
-                        z[6 * (row_idx[dposp + 1 + s] & 255) + r] -= acc;
+                            for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
+                            lds_sub(z + 6 * (row_idx[dposp + 1 + sb] & 255) + r, acc, np > 1);
+                        }
                     }
                 }
                 BT_PF(1);
             }
             __syncthreads();
             BT_PF(5);
-            // ---- phase 2: block rows of column j (and y_j) by forward substitution against L_jj
-            for (int rw = tid; rw <= cnt * 6; rw += nth) {
-                T L[21];
-                const T *dblk = Lw + (size_t)dpos * 36;
+            // ---- phase 2: block rows of the level's columns (and their y) by forward substitution
+            for (int q = 0; q < nc; ++q) {
+                const int j = lvl_cols[c0 + q], dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
+                // spread the columns of the level over the workgroup: column q starts at thread q * (nth / nc)
+                const int t0 = q * (nth / nc), span = nth / nc;
+                for (int rw = tid - t0; rw >= 0 && rw <= cnt * 6 && tid < t0 + span; rw += span) {
+                    T L[21];
+                    const T *dblk = Lw + (size_t)dpos * 36;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    T row[6];
-                    load_row6(dblk + 6 * r, row);
+                    for (int r = 0; r < 6; ++r) {
+                        T row[6];
+                        load_row6(dblk + 6 * r, row);
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) L[BT_LT(r, c)] = row[c];
+                        for (int c = 0; c <= r; ++c) L[BT_LT(r, c)] = row[c];
+                    }
+                    T *p = rw < cnt * 6 ? Lw + (size_t)(dpos + 1) * 36 + 6 * rw : z + 6 * j;
+                    T in[6], out[6];
+                    load_row6(p, in);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        T t = in[c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
+                        out[c] = t * L[BT_LT(c, c)];
+                    }
+                    store_row6(p, out);
                 }
-                T *p = rw < cnt * 6 ? Lw + (size_t)(dpos + 1) * 36 + 6 * rw : z + 6 * j;
-                T in[6], out[6];
-                load_row6(p, in);
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    T t = in[c];
-#pragma unroll
-                    for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
-                    out[c] = t * L[BT_LT(c, c)];
-                }
-                store_row6(p, out);
             }
             BT_PF(3);
             __syncthreads();
@@ -905,11 +935,13 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
         }
         __syncthreads();
         BT_PF(6);
-        // (c) x_j = zt_j - sum_{i>j} M_ij x_i, descending; wave 0, lane = (component c) * 8 + g
-        if (wave == 0) {
-            const int c = lane >> 3, g = lane & 7;
-            for (int j = n - 1; j >= 0; --j) {
-                const int dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
+        // (c) x_j = zt_j - sum_{i>j} M_ij x_i, levels descending; one wave per column of the level,
+        //     lane = (component c) * 8 + g
+        for (int l = nlev - 1; l >= 0; --l) {
+            const int c0 = lvl_ptr[l], nc = lvl_ptr[l + 1] - c0;
+            if (wave < nc) {
+                const int c = lane >> 3, g = lane & 7;
+                const int j = lvl_cols[c0 + wave], dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
                 T acc = (T)0;
                 if (c < 6)
                     for (int sb = g; sb < cnt; sb += 8) {           // one sub-block per lane group
@@ -921,10 +953,9 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                     }
                 acc = dpp_add8(acc);
                 if (c < 6 && g == 0) zt[6 * j + c] -= acc;
-                wave_fence();
             }
+            __syncthreads();
         }
-        __syncthreads();
         BT_PF(7);
         for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
         __syncthreads();
@@ -939,7 +970,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
         status = BT_SOLVE_RETRIED;
     }
     __syncthreads();
-    for (int i = tid; i < D; i += nth) a.dx[i] = (float)zt[i];
+    for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
     if (tid == 0) a.status[0] = status;
     BT_PF(8);
     if (PROF && lane == 0 && wave < 2) {        // measurement only: phase cycle counts of waves 0 and 1

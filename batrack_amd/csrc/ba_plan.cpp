@@ -15,6 +15,7 @@
 #include "ba_plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace bt {
@@ -193,16 +194,58 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         const int64_t a = pl->pair_i[p] - fixedp, b = pl->pair_j[p] - fixedp;
         if (a >= 0 && b >= 0) nz[(size_t)std::max(a, b)][(size_t)std::min(a, b)] = 1;
     }
+    // ---- elimination order: two-ended ("twisted") when an index cut gives a small separator
+    // Cameras are time-ordered and co-visibility is local in time, so a vertex separator is
+    // looked for as S_k = { j >= k : some i < k is coupled to j }.  Order = [A = {<k} ascending |
+    // B = {>= k} \ S_k DESCENDING | S_k ascending]: both parts are eliminated from their far end
+    // towards the separator (no fill beyond their band), their columns are pairwise independent
+    // and are factored two per level.  Without a useful cut the natural order is kept.
+    std::vector<int32_t> perm((size_t)n);
+    std::iota(perm.begin(), perm.end(), 0);
+    {
+        static const int nd = std::getenv("BT_SOLVER_ORDER") ? std::atoi(std::getenv("BT_SOLVER_ORDER")) : 1;   // 0 = natural
+        int best_k = -1, best_score = (int)n;        // natural chain length = n
+        std::vector<uint8_t> in_s((size_t)n);
+        for (int64_t k = 1; k < n && nd; ++k) {
+            int ns = 0;
+            for (int64_t j = k; j < n; ++j) {
+                bool coupled = false;
+                for (int64_t i = 0; i < k && !coupled; ++i) coupled = nz[(size_t)j][(size_t)i] != 0;
+                ns += coupled ? 1 : 0;
+            }
+            const int na = (int)k, nb = (int)(n - k) - ns;
+            if (nb < 1 || ns * 3 > (int)n) continue;
+            const int score = std::max(na, nb) + ns;
+            if (score < best_score) { best_score = score; best_k = (int)k; }
+        }
+        if (best_k > 0 && best_score + 2 < (int)n) {
+            std::fill(in_s.begin(), in_s.end(), 0);
+            for (int64_t j = best_k; j < n; ++j)
+                for (int64_t i = 0; i < best_k; ++i) if (nz[(size_t)j][(size_t)i]) { in_s[(size_t)j] = 1; break; }
+            size_t o = 0;
+            for (int64_t i = 0; i < best_k; ++i) perm[o++] = (int32_t)i;
+            for (int64_t j = n - 1; j >= best_k; --j) if (!in_s[(size_t)j]) perm[o++] = (int32_t)j;
+            for (int64_t j = best_k; j < n; ++j) if (in_s[(size_t)j]) perm[o++] = (int32_t)j;
+        }
+    }
+    pl->perm = perm;
+    auto nzp = [&](int64_t a, int64_t b) {            // pattern in the permuted numbering
+        const int64_t x = perm[(size_t)a], y = perm[(size_t)b];
+        return nz[(size_t)std::max(x, y)][(size_t)std::min(x, y)] != 0;
+    };
+
     // column structures (rows > j), then fill: struct(parent(j)) |= struct(j) \ {parent(j)}
     std::vector<std::vector<int32_t>> cs((size_t)n);
     for (int64_t j = 0; j < n; ++j) {
-        for (int64_t r = j + 1; r < n; ++r) if (nz[(size_t)r][(size_t)j]) cs[(size_t)j].push_back((int32_t)r);
+        for (int64_t r = j + 1; r < n; ++r) if (nzp(r, j)) cs[(size_t)j].push_back((int32_t)r);
     }
+    std::vector<int32_t> parent((size_t)n, -1);
     for (int64_t j = 0; j < n; ++j) {
         auto &sj = cs[(size_t)j];
         std::sort(sj.begin(), sj.end());
         sj.erase(std::unique(sj.begin(), sj.end()), sj.end());
         if (sj.empty()) continue;
+        parent[(size_t)j] = sj[0];
         auto &sp = cs[(size_t)sj[0]];
         sp.insert(sp.end(), sj.begin() + 1, sj.end());
     }
@@ -215,35 +258,116 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     }
     pl->col_ptr[(size_t)n] = (int32_t)pl->row_idx.size();
     I.nnz_blocks = (int64_t)pl->row_idx.size();
-    // update triples of the right-looking factorisation
+    if (I.nnz_blocks >= 32768) return BT_EUNSUPPORTED;
     auto find_pos = [&](int32_t col, int32_t row) {
         const auto b = pl->row_idx.begin() + pl->col_ptr[(size_t)col], e = pl->row_idx.begin() + pl->col_ptr[(size_t)col + 1];
         return (int32_t)(std::lower_bound(b, e, row) - pl->row_idx.begin());
     };
-    // block -> column map, and the update triples of every column: first those whose
-    // destination lies in column j+1 (the critical wave applies them itself before it
-    // factors that column), then the rest (helper waves)
+
+    // block -> column map and where each block comes from in the caller-order lower triangle of S:
+    // blk_src = (row_nat << 9) | (col_nat << 1) | transposed
     pl->blk_col.assign(pl->row_idx.size(), 0);
+    pl->blk_src.assign(pl->row_idx.size(), 0);
     for (int64_t j = 0; j < n; ++j)
-        for (int32_t b = pl->col_ptr[(size_t)j]; b < pl->col_ptr[(size_t)j + 1]; ++b) pl->blk_col[(size_t)b] = (int32_t)j;
+        for (int32_t b = pl->col_ptr[(size_t)j]; b < pl->col_ptr[(size_t)j + 1]; ++b) {
+            pl->blk_col[(size_t)b] = (int32_t)j;
+            const int32_t x = perm[(size_t)pl->row_idx[(size_t)b]], y = perm[(size_t)j];
+            pl->blk_src[(size_t)b] = x >= y ? ((x << 9) | (y << 1)) : ((y << 9) | (x << 1) | 1);
+        }
+
+    // ---- level schedule: level(j) = 1 + max level of its children in the elimination tree;
+    // columns of one level are independent.  At most kMaxLevelCols per level (extra ones move up).
+    std::vector<int32_t> lvl((size_t)n, 0);
+    for (int64_t j = 0; j < n; ++j)
+        if (parent[(size_t)j] >= 0) lvl[(size_t)parent[(size_t)j]] = std::max(lvl[(size_t)parent[(size_t)j]], lvl[(size_t)j] + 1);
+    {
+        // enforce the per-level cap, keeping level(parent) > level(child)
+        std::vector<int32_t> cnt;
+        for (int64_t j = 0; j < n; ++j) {
+            int32_t l = lvl[(size_t)j];
+            for (;;) {
+                if ((size_t)l >= cnt.size()) cnt.resize((size_t)l + 1, 0);
+                if (cnt[(size_t)l] < kMaxLevelCols) break;
+                ++l;
+            }
+            cnt[(size_t)l]++;
+            lvl[(size_t)j] = l;
+            if (parent[(size_t)j] >= 0) lvl[(size_t)parent[(size_t)j]] = std::max(lvl[(size_t)parent[(size_t)j]], l + 1);
+        }
+    }
+    // every column a column updates must sit at a strictly higher level
+    for (int64_t j = 0; j < n; ++j)
+        for (int32_t b = pl->col_ptr[(size_t)j] + 1; b < pl->col_ptr[(size_t)j + 1]; ++b)
+            if (lvl[(size_t)pl->row_idx[(size_t)b]] <= lvl[(size_t)j]) return BT_EINVAL;   // cannot happen: rows are ancestors
+    int32_t nlev = 0;
+    for (int64_t j = 0; j < n; ++j) nlev = std::max(nlev, lvl[(size_t)j] + 1);
+    pl->col_lvl = lvl;
+    pl->lvl_ptr.assign((size_t)nlev + 1, 0);
+    for (int64_t j = 0; j < n; ++j) pl->lvl_ptr[(size_t)lvl[(size_t)j] + 1]++;
+    for (int32_t l = 0; l < nlev; ++l) pl->lvl_ptr[(size_t)l + 1] += pl->lvl_ptr[(size_t)l];
+    pl->lvl_cols.assign((size_t)n, 0);
+    {
+        std::vector<int32_t> cur(pl->lvl_ptr.begin(), pl->lvl_ptr.end() - 1);
+        for (int64_t j = 0; j < n; ++j) pl->lvl_cols[(size_t)cur[(size_t)lvl[(size_t)j]]++] = (int32_t)j;
+    }
+
+    // ---- update triples of every column (src1, src2, dst | atomic << 15).  First those whose
+    // destination is the DIAGONAL block of a column of the next level (that column's critical wave
+    // applies them itself before factoring: listed per target column in dp), then the rest.
+    // `atomic` marks a destination that another column of the same level also updates.
     pl->upd_ptr.assign((size_t)n + 1, 0);
     pl->upd_next.assign((size_t)n + 1, 0);
     pl->upd.clear();
+    std::vector<std::vector<int32_t>> dplist((size_t)n);
     for (int64_t j = 0; j < n; ++j) {
         pl->upd_ptr[(size_t)j] = (int32_t)(pl->upd.size() / 3);
         const int32_t b = pl->col_ptr[(size_t)j] + 1, e = pl->col_ptr[(size_t)j + 1];
-        for (int pass = 0; pass < 2; ++pass)
+        for (int sub = 0; sub < 2; ++sub)
             for (int32_t s = b; s < e; ++s)
                 for (int32_t t2 = b; t2 <= s; ++t2) {
-                    const bool next = pl->row_idx[(size_t)t2] == (int32_t)j + 1;
-                    if (next != (pass == 0)) continue;
+                    const int32_t dcol = pl->row_idx[(size_t)t2];
+                    const bool diag_next = s == t2 && lvl[(size_t)dcol] == lvl[(size_t)j] + 1;
+                    if (diag_next != (sub == 0)) continue;
+                    if (diag_next) { dplist[(size_t)dcol].push_back((int32_t)(pl->upd.size() / 3)); pl->upd_next[(size_t)j]++; }
                     pl->upd.push_back(s); pl->upd.push_back(t2);
-                    pl->upd.push_back(find_pos(pl->row_idx[(size_t)t2], pl->row_idx[(size_t)s]));
-                    if (next) pl->upd_next[(size_t)j]++;
+                    pl->upd.push_back(find_pos(dcol, pl->row_idx[(size_t)s]));
                 }
     }
     pl->upd_ptr[(size_t)n] = (int32_t)(pl->upd.size() / 3);
     I.updates = (int64_t)(pl->upd.size() / 3);
+    {
+        // shared destinations: scan each level's non-diagonal-next triples
+        std::vector<int32_t> seen(pl->row_idx.size(), -1), seen_col(pl->row_idx.size(), -1);
+        std::vector<uint8_t> shared(pl->row_idx.size(), 0);
+        for (int32_t l = 0; l < nlev; ++l) {
+            for (int32_t q = pl->lvl_ptr[(size_t)l]; q < pl->lvl_ptr[(size_t)l + 1]; ++q) {
+                const int32_t j = pl->lvl_cols[(size_t)q];
+                for (int32_t t = pl->upd_ptr[(size_t)j]; t < pl->upd_ptr[(size_t)j + 1]; ++t) {
+                    const int32_t dst = pl->upd[(size_t)t * 3 + 2];
+                    if (seen[(size_t)dst] == l && seen_col[(size_t)dst] != j) shared[(size_t)dst] = 1;
+                    seen[(size_t)dst] = l; seen_col[(size_t)dst] = j;
+                }
+            }
+            for (int32_t q = pl->lvl_ptr[(size_t)l]; q < pl->lvl_ptr[(size_t)l + 1]; ++q) {
+                const int32_t j = pl->lvl_cols[(size_t)q];
+                for (int32_t t = pl->upd_ptr[(size_t)j]; t < pl->upd_ptr[(size_t)j + 1]; ++t) {
+                    int32_t &dst = pl->upd[(size_t)t * 3 + 2];
+                    if (shared[(size_t)(dst & 0x7fff)]) dst |= 0x8000;
+                }
+            }
+            for (int32_t q = pl->lvl_ptr[(size_t)l]; q < pl->lvl_ptr[(size_t)l + 1]; ++q) {
+                const int32_t j = pl->lvl_cols[(size_t)q];
+                for (int32_t t = pl->upd_ptr[(size_t)j]; t < pl->upd_ptr[(size_t)j + 1]; ++t) shared[(size_t)(pl->upd[(size_t)t * 3 + 2] & 0x7fff)] = 0;
+            }
+        }
+    }
+    pl->dp_ptr.assign((size_t)n + 1, 0);
+    pl->dp.clear();
+    for (int64_t j = 0; j < n; ++j) {
+        pl->dp_ptr[(size_t)j] = (int32_t)pl->dp.size();
+        pl->dp.insert(pl->dp.end(), dplist[(size_t)j].begin(), dplist[(size_t)j].end());
+    }
+    pl->dp_ptr[(size_t)n] = (int32_t)pl->dp.size();
 
     layout_workspace(pl);
     return BT_OK;

@@ -16,7 +16,8 @@ constexpr int kTileCamHard = 64;    // a single track may not see more free came
 constexpr int kMaxFree = 255;       // free poses supported by the reduced solver
 constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj + 6 gj)
 constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
-constexpr int kLdsRowStride = 66;   // floats per local E row (bank-conflict-free)
+constexpr int kLdsRowStride = 66;
+constexpr int kMaxLevelCols = 4;    // columns of the reduced system factored concurrently (one critical wave each)   // floats per local E row (bank-conflict-free)
 
 // Device-side view: raw pointers into one device allocation + sizes.
 struct PlanDev {
@@ -28,6 +29,9 @@ struct PlanDev {
     const int32_t *slot_edge, *slot_pair;
     const uint16_t *slot_lab;
     const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
+    // elimination order and level schedule of the reduced solver
+    int nlev, ndp;
+    const int32_t *perm, *blk_src, *lvl_ptr, *lvl_cols, *col_lvl, *dp_ptr, *dp;
 };
 
 // Byte offsets of the regions inside the caller's workspace.
@@ -47,6 +51,7 @@ struct bt_plan {
     std::vector<int32_t> slot_edge, slot_pair;
     std::vector<uint16_t> slot_lab;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
+    std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp;
     int max_rows16 = 16;
     bt::WsLayout ws{};
     void *dev_base = nullptr;   // one device allocation holding every array above

@@ -157,49 +157,87 @@ def run(plan, A, inp, wkey, lmbda=1e-4, ep=10.0, alpha=0.05, structure_only=Fals
 
 
 def sparse_chol_solve(A, S_lower, y, n, ep, lm):
-    """k_solve: block-sparse right-looking Cholesky driven by col_ptr/row_idx/upd."""
-    col_ptr, row_idx, upd_ptr, upd = A["col_ptr"], A["row_idx"], A["upd_ptr"], A["upd"].reshape(-1, 3)
-    nnzb = len(row_idx)
-    L = np.zeros((nnzb, 6, 6))
-    col_of = np.zeros(nnzb, np.int64)
-    for j in range(n):
-        col_of[col_ptr[j]:col_ptr[j + 1]] = j
-    # every structurally non-zero block of S must be inside the symbolic pattern
-    Sb = np.abs(S_lower).reshape(n, 6, n, 6).max(axis=(1, 3))
+    """k_solve_lds: level-scheduled block-sparse right-looking Cholesky driven by the plan
+    arrays (perm, blk_src, col_ptr/row_idx, upd/upd_next, lvl_ptr/lvl_cols, dp)."""
+    col_ptr, row_idx, upd_ptr, upd_next = A["col_ptr"], A["row_idx"], A["upd_ptr"], A["upd_next"]
+    upd = A["upd"].reshape(-1, 3)
+    perm, blk_src, blk_col = A["perm"], A["blk_src"], A["blk_col"]
+    lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp = A["lvl_ptr"], A["lvl_cols"], A["col_lvl"], A["dp_ptr"], A["dp"]
+    nnzb, nlev = len(row_idx), len(lvl_ptr) - 1
+    assert sorted(perm.tolist()) == list(range(n)) and sorted(lvl_cols.tolist()) == list(range(n))
+    # every structurally non-zero block of S must be inside the symbolic pattern (in permuted numbering)
+    Sfull = S_lower + np.tril(S_lower, -1).T
+    Sp = Sfull.reshape(n, 6, n, 6)[perm][:, :, perm]            # [n,6,n,6] permuted
+    Sb = np.abs(Sp).max(axis=(1, 3))
     pat = np.zeros((n, n), bool)
-    pat[row_idx, col_of] = True
-    assert not np.any((Sb > 0) & ~pat), "S has a block outside the plan's sparsity pattern"
+    pat[row_idx, blk_col] = True
+    assert not np.any(np.tril(Sb > 0) & ~pat), "S has a block outside the plan's sparsity pattern"
+    L = np.zeros((nnzb, 6, 6))
     for b in range(nnzb):
-        i, j = int(row_idx[b]), int(col_of[b])
-        blk = S_lower[6*i:6*i + 6, 6*j:6*j + 6].copy()
+        src = int(blk_src[b]); rn, cn, tr = src >> 9, (src >> 1) & 255, src & 1
+        i, j = int(row_idx[b]), int(blk_col[b])
+        assert {rn, cn} == {int(perm[i]), int(perm[j])} and rn >= cn
+        blk = S_lower[6*rn:6*rn + 6, 6*cn:6*cn + 6].copy()
         if i == j:
             blk = np.tril(blk)
             blk[np.diag_indices(6)] += ep + lm * np.diag(blk)
+        elif tr:
+            blk = blk.T.copy()
+        assert np.allclose(blk if i != j else blk + np.tril(blk, -1).T, Sp[i, :, j, :] + (np.eye(6) * (ep + lm * np.diag(Sp[i, :, j, :])) if i == j else 0))
         L[b] = blk
-    z = y.copy()
+    z = y.reshape(n, 6)[perm].reshape(-1).copy()
     Linv = np.zeros((n, 6, 6))
-    for j in range(n):
-        d = col_ptr[j]
-        full = L[d] + np.tril(L[d], -1).T
-        Lj = np.linalg.cholesky(full)
-        L[d] = Lj
-        Linv[j] = np.linalg.inv(Lj)
-        z[6*j:6*j + 6] = Linv[j] @ z[6*j:6*j + 6]
-        for s in range(d + 1, col_ptr[j + 1]):
-            L[s] = L[s] @ Linv[j].T
-            i = int(row_idx[s])
-            z[6*i:6*i + 6] -= L[s] @ z[6*j:6*j + 6]
-        for t in range(upd_ptr[j], upd_ptr[j + 1]):
-            s1, s2, dst = upd[t]
-            assert col_of[s1] == j and col_of[s2] == j
-            assert row_idx[dst] == row_idx[s1] and col_of[dst] == row_idx[s2]
-            L[dst] -= L[s1] @ L[s2].T
+    applied = np.zeros(len(upd), int)
+    for l in range(nlev):
+        cols = lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]
+        assert 1 <= len(cols) <= 4 and all(col_lvl[c] == l for c in cols)
+        prev = lvl_cols[lvl_ptr[l - 1]:lvl_ptr[l]] if l > 0 else []
+        # phase 1, helper side: all but the leading `upd_next` triples of the previous level's columns
+        targets = {}
+        for p in prev:
+            for t in range(upd_ptr[p] + upd_next[p], upd_ptr[p + 1]):
+                s1, s2, dstf = upd[t]
+                dst, flag = int(dstf) & 0x7fff, int(dstf) >> 15
+                assert blk_col[s1] == p and blk_col[s2] == p
+                assert row_idx[dst] == row_idx[s1] and blk_col[dst] == row_idx[s2]
+                targets.setdefault(dst, set()).add(int(p))
+                L[dst] -= L[s1] @ L[s2].T
+                applied[t] += 1
+        for p in prev:
+            for t in range(upd_ptr[p] + upd_next[p], upd_ptr[p + 1]):
+                dstf = int(upd[t][2])
+                assert (dstf >> 15) == (1 if len(targets[dstf & 0x7fff]) > 1 else 0), "shared-destination flag wrong"
+            for s in range(col_ptr[p] + 1, col_ptr[p + 1]):
+                i = int(row_idx[s])
+                z[6*i:6*i + 6] -= L[s] @ z[6*p:6*p + 6]
+        # phase 1, critical side: pending diagonal updates, then the 6x6 factorisation
+        for c in cols:
+            for t in dp[dp_ptr[c]:dp_ptr[c + 1]]:
+                s1, s2, dstf = upd[t]
+                assert s1 == s2 and (int(dstf) & 0x7fff) == col_ptr[c] and col_lvl[blk_col[s1]] == l - 1
+                assert upd_ptr[blk_col[s1]] <= t < upd_ptr[blk_col[s1]] + upd_next[blk_col[s1]]
+                L[col_ptr[c]] -= L[s1] @ L[s2].T
+                applied[t] += 1
+            d = col_ptr[c]
+            full = L[d] + np.tril(L[d], -1).T
+            Lj = np.linalg.cholesky(full)
+            L[d] = Lj
+            Linv[c] = np.linalg.inv(Lj)
+        # phase 2: block rows and the RHS row
+        for c in cols:
+            z[6*c:6*c + 6] = Linv[c] @ z[6*c:6*c + 6]
+            for s in range(col_ptr[c] + 1, col_ptr[c + 1]):
+                assert col_lvl[row_idx[s]] > l
+                L[s] = L[s] @ Linv[c].T
+    assert np.all(applied == 1), "every update triple must be applied exactly once"
     x = z.copy()
-    for j in range(n - 1, -1, -1):
-        d = col_ptr[j]
-        tq = x[6*j:6*j + 6].copy()
-        for s in range(d + 1, col_ptr[j + 1]):
-            i = int(row_idx[s])
-            tq -= L[s].T @ x[6*i:6*i + 6]
-        x[6*j:6*j + 6] = Linv[j].T @ tq
-    return x.reshape(n, 6)
+    for l in range(nlev - 1, -1, -1):
+        for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]:
+            tq = x[6*c:6*c + 6].copy()
+            for s in range(col_ptr[c] + 1, col_ptr[c + 1]):
+                i = int(row_idx[s])
+                tq -= L[s].T @ x[6*i:6*i + 6]
+            x[6*c:6*c + 6] = Linv[c].T @ tq
+    out = np.zeros((n, 6))
+    out[perm] = x.reshape(n, 6)
+    return out

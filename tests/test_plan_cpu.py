@@ -95,5 +95,10 @@ def test_plan_c3_shape():
     # observation pattern is regular: every slot of every tile holds a single camera pair
     sp = A["slot_pair"].reshape(-1, 64)
     assert np.all(sp == sp[:, :1])
-    # banded reduced system: no fill outside the 7-block band
-    assert pl.nnz_blocks == sum(min(8, 63 - j) for j in range(63))
+    # banded reduced system, two-ended elimination: two chains meet at a 7-camera separator, so the
+    # sequential depth drops from 63 to 35 block columns with (almost) no fill beyond the band
+    lv = A["lvl_ptr"]
+    assert len(lv) - 1 == 35 and np.diff(lv).max() == 2
+    assert pl.nnz_blocks <= sum(min(8, 63 - j) for j in range(63)) + 28
+    perm = A["perm"]
+    assert perm[:28].tolist() == list(range(28)) and perm[28:56].tolist() == list(range(62, 34, -1))
