@@ -692,19 +692,35 @@ template <typename T> __device__ __forceinline__ void lds_sub(T *p, T v, bool at
     if (atomic) atomicAdd(p, -v); else *p -= v;
 }
 
-// dst[e] -= (row r of block tr[0]) . (row c of block tr[1]);  bit 15 of tr[2]: destination shared
-// with another column of the level -> LDS atomic
+// One ROW of an update triple: dst[r][:] -= (row r of block tr[0]) . (rows of block tr[1])^T.
+// 21 vector LDS loads and 36 FMAs for 6 outputs.  Bit 15 of tr[2]: the destination is also
+// updated by another column of the same level -> LDS atomics.
 template <typename T>
-__device__ __forceinline__ void apply_update(T *Lw, const unsigned short *tr, int e) {
-    const int r = e / 6, c = e - 6 * r;
-    T a[6], b[6];
+__device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr, int r) {
+    T a[6], o[6];
     load_row6(Lw + (size_t)tr[0] * 36 + 6 * r, a);
-    load_row6(Lw + (size_t)tr[1] * 36 + 6 * c, b);
-    T acc = a[0] * b[0];
+    const T *bb = Lw + (size_t)tr[1] * 36;
 #pragma unroll
-    for (int k = 1; k < 6; ++k) acc += a[k] * b[k];
+    for (int c = 0; c < 6; ++c) {
+        T b[6];
+        load_row6(bb + 6 * c, b);
+        T acc = a[0] * b[0];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += a[k] * b[k];
+        o[c] = acc;
+    }
     const unsigned d = tr[2];
-    lds_sub(Lw + (size_t)(d & 0x7fffu) * 36 + e, acc, (d & 0x8000u) != 0);
+    T *dst = Lw + (size_t)(d & 0x7fffu) * 36 + 6 * r;
+    if (d & 0x8000u) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) atomicAdd(dst + c, -o[c]);
+    } else {
+        T v[6];
+        load_row6(dst, v);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] -= o[c];
+        store_row6(dst, v);
+    }
 }
 
 template <typename T, bool PROF>
@@ -828,13 +844,13 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                     const int pj = lvl_cols[p0 + q];
                     const int u0 = upd_ptr[pj] + upd_next[pj], nu = upd_ptr[pj + 1] - u0;
                     const int dposp = col_ptr[pj], cntp = col_ptr[pj + 1] - dposp - 1;
-                    const int total = nu * 36 + cntp * 6;
+                    const int total = nu * 6 + cntp * 6;
                     for (int idx = h; idx < total; idx += hs) {
-                        if (idx < nu * 36) {
-                            const int t = idx / 36;
-                            apply_update(Lw, upd + 3 * (u0 + t), idx - 36 * t);
+                        if (idx < nu * 6) {
+                            const int t = idx / 6;
+                            apply_update_row(Lw, upd + 3 * (u0 + t), idx - 6 * t);
                         } else {
-                            const int qq = idx - nu * 36, sb = qq / 6, r = qq - 6 * sb;
+                            const int qq = idx - nu * 6, sb = qq / 6, r = qq - 6 * sb;
                             T lr[6], zr[6];
                             load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
                             load_row6(z + 6 * pj, zr);
@@ -850,11 +866,21 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
             __syncthreads();
             BT_PF(5);
             // ---- phase 2: block rows of the level's columns (and their y) by forward substitution
-            for (int q = 0; q < nc; ++q) {
-                const int j = lvl_cols[c0 + q], dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
-                // spread the columns of the level over the workgroup: column q starts at thread q * (nth / nc)
-                const int t0 = q * (nth / nc), span = nth / nc;
-                for (int rw = tid - t0; rw >= 0 && rw <= cnt * 6 && tid < t0 + span; rw += span) {
+            {
+                int rows_before[kMaxLevelCols + 1];
+                rows_before[0] = 0;
+#pragma unroll
+                for (int q = 0; q < kMaxLevelCols; ++q) {
+                    int cntq = 0;
+                    if (q < nc) { const int jq = lvl_cols[c0 + q]; cntq = (col_ptr[jq + 1] - col_ptr[jq] - 1) * 6 + 1; }
+                    rows_before[q + 1] = rows_before[q] + cntq;
+                }
+                for (int item = tid; item < rows_before[kMaxLevelCols]; item += nth) {
+                    int q = 0;
+#pragma unroll
+                    for (int k = 1; k < kMaxLevelCols; ++k) q += item >= rows_before[k] ? 1 : 0;
+                    const int rw = item - (q == 0 ? 0 : q == 1 ? rows_before[1] : q == 2 ? rows_before[2] : rows_before[3]);
+                    const int j = lvl_cols[c0 + q], dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
                     T L[21];
                     const T *dblk = Lw + (size_t)dpos * 36;
 #pragma unroll
