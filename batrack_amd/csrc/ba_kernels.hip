@@ -497,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_solve_global(PlanDev pd, StepArgs a) {
         // load the structurally non-zero blocks of S (+ damping) and y
         for (int idx = tid; idx < pd.nnzb * 36; idx += nth) {
             const int b = idx / 36, e = idx % 36, r = e / 6, c = e % 6;
-            const int row = pd.row_idx[b], col = pd.blk_col[b], src = pd.blk_src[b];
+            const int row = pd.row_idx[b], col = pd.blk_col[b] & 255, src = pd.blk_src[b];
             const int rn = src >> 9, cn = (src >> 1) & 255;
             const int rr = (src & 1) ? c : r, cc = (src & 1) ? r : c;       // transposed source block
             double v = (row > col || r >= c) ? a.S[(size_t)(6*rn + rr) * D + 6*cn + cc] : 0.0;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { tn = clock64(); pf[i] += tn - tc; tc = tn; } } while (0)
     for (int i = tid; i < pd.nupd * 3; i += nth) upd[i] = (unsigned short)pd.upd[i];
-    for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8);   // row | col << 8
+    for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8);   // row | col << 8 | shared-y << 24
     for (int i = tid; i <= n; i += nth) {
         col_ptr[i] = pd.col_ptr[i]; upd_ptr[i] = pd.upd_ptr[i]; upd_next[i] = pd.upd_next[i]; dp_ptr[i] = pd.dp_ptr[i];
     }
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                 const int idx = base + u * nth + tid;
                 if (idx < nnzb * 6) {
                     const int b = idx / 6, r = idx - 6 * b, rc = row_idx[b];
-                    const bool diag = (rc & 255) == (rc >> 8);
+                    const bool diag = (rc & 255) == ((rc >> 8) & 255);
                     T w[6];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) {
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                             T acc = lr[0] * zr[0];
 #pragma unroll
                             for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
-                            lds_sub(z + 6 * (row_idx[dposp + 1 + sb] & 255) + r, acc, np > 1);
+                            { const int rcv = row_idx[dposp + 1 + sb]; lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv >> 24) != 0); }
                         }
                     }
                 }
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
             T *p, *q;
             if (idx < nnzb * 6) {
                 const int b = idx / 6, r = idx - 6 * b;
-                j = row_idx[b] >> 8;
+                j = (row_idx[b] >> 8) & 255;
                 if ((row_idx[b] & 255) == j) continue;
                 p = Lw + (size_t)b * 36 + 6 * r; q = p;
             } else {
@@ -999,8 +999,8 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
     if (tid == 0) a.status[0] = status;
     BT_PF(8);
-    if (PROF && lane == 0 && wave < 2) {        // measurement only: phase cycle counts of waves 0 and 1
-        long long *o = reinterpret_cast<long long *>(a.status + 4) + wave * 10;
+    if (PROF && lane == 0 && (wave == 0 || wave == 5)) {        // measurement only: phase cycle counts of a critical and a helper wave
+        long long *o = reinterpret_cast<long long *>(a.status + 4) + (wave ? 1 : 0) * 10;
         for (int i = 0; i < 10; ++i) o[i] = pf[i];
     }
 #undef BT_PF

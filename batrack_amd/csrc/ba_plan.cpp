@@ -361,6 +361,21 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             }
         }
     }
+    // y rows updated by more than one column of a level: bit 16 of blk_col marks those blocks
+    {
+        std::vector<int32_t> seen((size_t)n, -1), cnt((size_t)n, 0);
+        for (int32_t l = 0; l < nlev; ++l) {
+            for (int pass = 0; pass < 2; ++pass)
+                for (int32_t q = pl->lvl_ptr[(size_t)l]; q < pl->lvl_ptr[(size_t)l + 1]; ++q) {
+                    const int32_t j = pl->lvl_cols[(size_t)q];
+                    for (int32_t b = pl->col_ptr[(size_t)j] + 1; b < pl->col_ptr[(size_t)j + 1]; ++b) {
+                        const int32_t r = pl->row_idx[(size_t)b];
+                        if (pass == 0) { if (seen[(size_t)r] != l) { seen[(size_t)r] = l; cnt[(size_t)r] = 0; } cnt[(size_t)r]++; }
+                        else if (cnt[(size_t)r] > 1) pl->blk_col[(size_t)b] |= 1 << 16;
+                    }
+                }
+        }
+    }
     pl->dp_ptr.assign((size_t)n + 1, 0);
     pl->dp.clear();
     for (int64_t j = 0; j < n; ++j) {

@@ -161,7 +161,7 @@ def sparse_chol_solve(A, S_lower, y, n, ep, lm):
     arrays (perm, blk_src, col_ptr/row_idx, upd/upd_next, lvl_ptr/lvl_cols, dp)."""
     col_ptr, row_idx, upd_ptr, upd_next = A["col_ptr"], A["row_idx"], A["upd_ptr"], A["upd_next"]
     upd = A["upd"].reshape(-1, 3)
-    perm, blk_src, blk_col = A["perm"], A["blk_src"], A["blk_col"]
+    perm, blk_src, blk_col, yshared = A["perm"], A["blk_src"], A["blk_col"] & 255, A["blk_col"] >> 16
     lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp = A["lvl_ptr"], A["lvl_cols"], A["col_lvl"], A["dp_ptr"], A["dp"]
     nnzb, nlev = len(row_idx), len(lvl_ptr) - 1
     assert sorted(perm.tolist()) == list(range(n)) and sorted(lvl_cols.tolist()) == list(range(n))
@@ -209,6 +209,8 @@ def sparse_chol_solve(A, S_lower, y, n, ep, lm):
                 assert (dstf >> 15) == (1 if len(targets[dstf & 0x7fff]) > 1 else 0), "shared-destination flag wrong"
             for s in range(col_ptr[p] + 1, col_ptr[p + 1]):
                 i = int(row_idx[s])
+                n_writers = sum(1 for p2 in prev if i in row_idx[col_ptr[p2] + 1:col_ptr[p2 + 1]])
+                assert yshared[s] == (1 if n_writers > 1 else 0), "shared-y flag wrong"
                 z[6*i:6*i + 6] -= L[s] @ z[6*p:6*p + 6]
         # phase 1, critical side: pending diagonal updates, then the 6x6 factorisation
         for c in cols:
