@@ -826,39 +826,53 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                 }
                 const bool ok = chol6_packed<T>(L);
                 BT_PF(2);
-                if (lane == 0) {
+                if (lane == 0) {                 // entries above the diagonal are don't-care until Linv is put there
                     if (!ok) flags[0] = 1;
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
                         T row[6];
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) row[c] = c <= r ? L[BT_LT(r, c)] : (T)0;
+                        for (int c = 0; c < 6; ++c) row[c] = L[BT_LT(r, c <= r ? c : r)];
                         store_row6(Lw + (size_t)dpos * 36 + 6 * r, row);
                     }
                 }
                 BT_PF(4);
             } else {
-                // the other update triples of the previous level's columns, and their contribution to y
+                // the other update triples of the previous level's columns (one ROW of a triple per
+                // thread) and their contribution to y, all columns flattened over the helper threads
                 const int h = tid - 64 * nc, hs = nth - 64 * nc;
-                for (int q = 0; q < np; ++q) {
+                int items_before[kMaxLevelCols + 1];
+                items_before[0] = 0;
+#pragma unroll
+                for (int q = 0; q < kMaxLevelCols; ++q) {
+                    int cntq = 0;
+                    if (q < np) {
+                        const int pj = lvl_cols[p0 + q];
+                        cntq = (upd_ptr[pj + 1] - upd_ptr[pj] - upd_next[pj]) * 6 + (col_ptr[pj + 1] - col_ptr[pj] - 1) * 6;
+                    }
+                    items_before[q + 1] = items_before[q] + cntq;
+                }
+                for (int item = h; item < items_before[kMaxLevelCols]; item += hs) {
+                    int q = 0;
+#pragma unroll
+                    for (int k = 1; k < kMaxLevelCols; ++k) q += item >= items_before[k] ? 1 : 0;
+                    const int idx = item - (q == 0 ? 0 : q == 1 ? items_before[1] : q == 2 ? items_before[2] : items_before[3]);
                     const int pj = lvl_cols[p0 + q];
                     const int u0 = upd_ptr[pj] + upd_next[pj], nu = upd_ptr[pj + 1] - u0;
-                    const int dposp = col_ptr[pj], cntp = col_ptr[pj + 1] - dposp - 1;
-                    const int total = nu * 6 + cntp * 6;
-                    for (int idx = h; idx < total; idx += hs) {
-                        if (idx < nu * 6) {
-                            const int t = idx / 6;
-                            apply_update_row(Lw, upd + 3 * (u0 + t), idx - 6 * t);
-                        } else {
-                            const int qq = idx - nu * 6, sb = qq / 6, r = qq - 6 * sb;
-                            T lr[6], zr[6];
-                            load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
-                            load_row6(z + 6 * pj, zr);
-                            T acc = lr[0] * zr[0];
+                    const int dposp = col_ptr[pj];
+                    if (idx < nu * 6) {
+                        const int t = idx / 6;
+                        apply_update_row(Lw, upd + 3 * (u0 + t), idx - 6 * t);
+                    } else {
+                        const int qq = idx - nu * 6, sb = qq / 6, r = qq - 6 * sb;
+                        T lr[6], zr[6];
+                        load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
+                        load_row6(z + 6 * pj, zr);
+                        T acc = lr[0] * zr[0];
 #pragma unroll
-                            for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
-                            { const int rcv = row_idx[dposp + 1 + sb]; lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv >> 24) != 0); }
-                        }
+                        for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
+                        const int rcv = row_idx[dposp + 1 + sb];
+                        lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv >> 24) != 0);
                     }
                 }
                 BT_PF(1);
