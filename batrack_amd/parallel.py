@@ -48,9 +48,15 @@ def shard_edges(kk, world, rank):
 
 def allreduce_system(system, group=None):
     """Sum the partial reduced systems in place.  `system` is Stepper.system (float64
-    [S | y]); backend nccl (= RCCL) on GPUs, gloo in CPU tests."""
+    [S | y]); backend nccl (= RCCL) on GPUs, gloo in CPU tests.  With a gloo group and a
+    device tensor (two test ranks sharing one GPU) the sum is staged through the host."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(system, op=dist.ReduceOp.SUM, group=group)
+        if system.is_cuda and dist.get_backend(group) == "gloo":
+            host = system.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            system.copy_(host)
+        else:
+            dist.all_reduce(system, op=dist.ReduceOp.SUM, group=group)
     return system
 
 
@@ -97,7 +103,7 @@ class ShardedBA:
         lo, hi = self.owned
         mine = torch.zeros_like(patches_out)
         mine[lo:hi] = patches_out[lo:hi]
-        dist.all_reduce(mine, op=dist.ReduceOp.SUM, group=self.group)
+        allreduce_system(mine, self.group)
         covered = torch.zeros(patches_out.shape[0], dtype=torch.bool, device=patches_out.device)
         for a, b in ranges:
             covered[a:b] = True
