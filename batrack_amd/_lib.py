@@ -71,7 +71,7 @@ def lib():
     L.bt_version.restype = i32
     L.bt_target_arch.restype = ctypes.c_char_p
     L.bt_plan_create.restype = i32
-    L.bt_plan_create.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i32, i32, ctypes.POINTER(vp)]
+    L.bt_plan_create.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, ctypes.POINTER(vp)]
     L.bt_plan_destroy.restype = None
     L.bt_plan_destroy.argtypes = [vp]
     L.bt_plan_get_info.restype = i32

@@ -99,7 +99,8 @@ int bt_version(void) { return BT_VERSION; }
 const char *bt_target_arch(void) { return "gfx950"; }
 
 int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf,
-                   int64_t p_tot, int64_t fixedp, int64_t n_all_min, int on_device, int upload, bt_plan **out) {
+                   int64_t p_tot, int64_t fixedp, int64_t n_all_min, int64_t own_lo, int64_t own_hi,
+                   int on_device, int upload, bt_plan **out) {
     if (!out || E < 0 || (E > 0 && (!ii || !jj || !kk))) return BT_EINVAL;
     *out = nullptr;
     std::vector<int64_t> host;
@@ -116,7 +117,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
     if (!pl) return BT_ENOMEM;
     int rc = BT_OK;
     try {
-        rc = build_plan_host(hi, hj, hk, E, n_buf, p_tot, fixedp, n_all_min, pl);
+        rc = build_plan_host(hi, hj, hk, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl);
         if (rc == BT_OK && upload) rc = upload_plan(pl);
     } catch (const std::bad_alloc &) {
         rc = BT_ENOMEM;

@@ -46,12 +46,16 @@ static void layout_workspace(bt_plan *pl) {
 }
 
 int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
-                    int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min, bt_plan *pl) {
+                    int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
+                    int64_t own_lo, int64_t own_hi, bt_plan *pl) {
     if (E < 0 || n_buf <= 0 || p_tot <= 0 || fixedp < 0 || n_all_min < 0 || n_all_min > n_buf) return BT_EINVAL;
     if (E > (int64_t)0x7fffffff / 2 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;
     bt_plan_info &I = pl->info;
     I = bt_plan_info{};
-    I.E = E; I.n_buf = n_buf; I.p_tot = p_tot; I.fixedp = fixedp;
+    I.n_buf = n_buf; I.p_tot = p_tot; I.fixedp = fixedp;
+    if (own_hi <= 0) { own_lo = 0; own_hi = p_tot; }
+    if (own_lo < 0 || own_hi > p_tot || own_lo > own_hi) return BT_EINVAL;
+    auto owned = [&](int64_t e) { return kk[e] >= own_lo && kk[e] < own_hi; };
 
     // ---- n_all, validation (ba.py:219) ------------------------------------
     int64_t n_all = n_all_min;
@@ -70,7 +74,9 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
     // ---- unique tracks, ascending (ba.py:276) ------------------------------
     pl->trk_of_patch.assign((size_t)p_tot, -1);
-    for (int64_t e = 0; e < E; ++e) pl->trk_of_patch[(size_t)kk[e]] = 0;
+    int64_t E_own = 0;
+    for (int64_t e = 0; e < E; ++e) if (owned(e)) { pl->trk_of_patch[(size_t)kk[e]] = 0; ++E_own; }
+    I.E = E_own;
     int32_t m = 0;
     pl->kx.clear();
     for (int64_t p = 0; p < p_tot; ++p)
@@ -79,7 +85,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
     // ---- distinct camera pairs, ascending (i, j) ---------------------------
     std::vector<int32_t> pair_of((size_t)(n_all * n_all), -1);
-    for (int64_t e = 0; e < E; ++e) pair_of[(size_t)(ii[e] * n_all + jj[e])] = 0;
+    for (int64_t e = 0; e < E; ++e) if (owned(e)) pair_of[(size_t)(ii[e] * n_all + jj[e])] = 0;
     pl->pair_i.clear(); pl->pair_j.clear();
     for (int64_t key = 0; key < n_all * n_all; ++key)
         if (pair_of[(size_t)key] == 0) {
@@ -91,10 +97,10 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
     // ---- edges grouped by track, ordered by (pair, original index) ---------
     std::vector<int32_t> off((size_t)m + 1, 0);
-    for (int64_t e = 0; e < E; ++e) off[(size_t)pl->trk_of_patch[(size_t)kk[e]] + 1]++;
+    for (int64_t e = 0; e < E; ++e) if (owned(e)) off[(size_t)pl->trk_of_patch[(size_t)kk[e]] + 1]++;
     for (int32_t k = 0; k < m; ++k) off[(size_t)k + 1] += off[(size_t)k];
-    std::vector<int32_t> ord((size_t)E), cur(off.begin(), off.end() - 1);
-    for (int64_t e = 0; e < E; ++e) ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = (int32_t)e;
+    std::vector<int32_t> ord((size_t)E_own + 1), cur(off.begin(), off.end() - 1);
+    for (int64_t e = 0; e < E; ++e) if (owned(e)) ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = (int32_t)e;
     auto pair_id = [&](int32_t e) { return pair_of[(size_t)(ii[e] * n_all + jj[e])]; };
     for (int32_t k = 0; k < m; ++k)
         std::sort(ord.begin() + off[(size_t)k], ord.begin() + off[(size_t)k + 1], [&](int32_t a, int32_t b) {
@@ -193,6 +199,29 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     for (size_t p = 0; p < pl->pair_i.size(); ++p) {
         const int64_t a = pl->pair_i[p] - fixedp, b = pl->pair_j[p] - fixedp;
         if (a >= 0 && b >= 0) nz[(size_t)std::max(a, b)][(size_t)std::min(a, b)] = 1;
+    }
+    if (E_own != E) {
+        // sharded: tracks owned by other ranks contribute blocks to the all-reduced system too.
+        // Their pattern: every camera pair of an edge, and all pairs among the free cameras of a track.
+        std::vector<int32_t> toff((size_t)p_tot + 1, 0);
+        for (int64_t e = 0; e < E; ++e) if (!owned(e)) toff[(size_t)kk[e] + 1]++;
+        for (int64_t p = 0; p < p_tot; ++p) toff[(size_t)p + 1] += toff[(size_t)p];
+        std::vector<int32_t> tord((size_t)(E - E_own) + 1), tcur(toff.begin(), toff.end() - 1);
+        for (int64_t e = 0; e < E; ++e) if (!owned(e)) tord[(size_t)tcur[(size_t)kk[e]]++] = (int32_t)e;
+        std::vector<int32_t> cset;
+        for (int64_t p = 0; p < p_tot; ++p) {
+            if (toff[(size_t)p] == toff[(size_t)p + 1]) continue;
+            cset.clear();
+            for (int32_t q = toff[(size_t)p]; q < toff[(size_t)p + 1]; ++q) {
+                const int32_t e = tord[(size_t)q];
+                if (ii[e] >= fixedp) cset.push_back((int32_t)(ii[e] - fixedp));
+                if (jj[e] >= fixedp) cset.push_back((int32_t)(jj[e] - fixedp));
+            }
+            std::sort(cset.begin(), cset.end());
+            cset.erase(std::unique(cset.begin(), cset.end()), cset.end());
+            for (size_t u = 0; u < cset.size(); ++u)
+                for (size_t v = 0; v <= u; ++v) nz[(size_t)cset[u]][(size_t)cset[v]] = 1;
+        }
     }
     // ---- elimination order: two-ended ("twisted") when an index cut gives a small separator
     // Cameras are time-ordered and co-visibility is local in time, so a vertex separator is

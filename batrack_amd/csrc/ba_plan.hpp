@@ -61,7 +61,8 @@ struct bt_plan {
 namespace bt {
 // Pure host analysis (no HIP).  Returns BT_OK or an error code.
 int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
-                    int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min, bt_plan *plan);
+                    int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
+                    int64_t own_lo, int64_t own_hi, bt_plan *plan);
 // Copies the arrays to the device and fills plan->dev (ba_api.cpp).
 int upload_plan(bt_plan *plan);
 }  // namespace bt

@@ -61,8 +61,9 @@ def allreduce_system(system, group=None):
 
 
 class ShardedBA:
-    """BA_rgbd_droid over a track shard.  Construct on every rank with the FULL edge
-    list and inputs; each rank keeps only its own edges."""
+    """BA_rgbd_droid over a track shard.  Construct on every rank with the FULL edge list;
+    per-edge inputs (targets, weights) stay the full tensors on every rank — a rank's plan
+    only touches the edges of its own track range."""
 
     def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, device, world=None, rank=None, group=None):
         from .plan import Plan, Stepper
@@ -70,17 +71,13 @@ class ShardedBA:
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
         self.device = torch.device(device)
-        self.idx = shard_edges(kk, self.world, self.rank).to(ii.device)
-        n_all = int(max(int(ii.max()), int(jj.max()))) + 1
-        self.ii, self.jj, self.kk = ii[self.idx].contiguous(), jj[self.idx].contiguous(), kk[self.idx].contiguous()
-        self.plan = Plan(self.ii, self.jj, self.kk, n_buf, p_tot, fixedp, n_all_min=n_all)
+        self.owned = partition_tracks(kk, self.world)[self.rank]
+        self.plan = Plan(ii, jj, kk, n_buf, p_tot, fixedp, own=self.owned if self.world > 1 else (0, 0))
         self.stepper = Stepper(self.plan, self.device)
-        lo, hi = partition_tracks(kk, self.world)[self.rank]
-        self.owned = (lo, hi)
 
     def local(self, per_edge):
-        """Select this rank's rows of a per-edge tensor ([E, ...])."""
-        return per_edge[self.idx.to(per_edge.device)].contiguous()
+        """Kept for callers written against the first version: per-edge tensors are used whole."""
+        return per_edge
 
     def step(self, poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
              bounds, lmbda, ep, alpha, loss, structure_only):

@@ -20,7 +20,7 @@ PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0",
 class Plan:
     """bt_plan handle.  ii/jj/kk: int64 torch tensors (CPU or GPU) or numpy arrays."""
 
-    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, upload=True, n_all_min=0):
+    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, upload=True, n_all_min=0, own=(0, 0)):
         L = _lib.lib()
         self._lib = L
         self._h = ctypes.c_void_p()
@@ -41,7 +41,7 @@ class Plan:
             E = arrs[0].numel()
         self._keep = arrs
         rc = L.bt_plan_create(ptrs[0], ptrs[1], ptrs[2], E, int(n_buf), int(p_tot), int(fixedp),
-                              int(n_all_min), on_device, 1 if upload else 0, ctypes.byref(self._h))
+                              int(n_all_min), int(own[0]), int(own[1]), on_device, 1 if upload else 0, ctypes.byref(self._h))
         _lib.check(rc, "bt_plan_create")
         self._keep = None
         info = _lib.PlanInfo()

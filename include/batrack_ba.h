@@ -43,7 +43,7 @@ enum { BT_SOLVE_OK = 0, BT_SOLVE_CHOL_FAILED = 1,   /* dX = 0, ba.py:9-13       
        BT_SOLVE_RETRIED = 2 };                      /* NaN -> lm = 1e-3, ba.py:324-325 */
 
 typedef struct {
-    int64_t E;            /* edges                                             */
+    int64_t E;            /* edges assembled by this plan (owned tracks)          */
     int64_t n_buf;        /* pose / intrinsics buffer length                   */
     int64_t p_tot;        /* patch slots                                       */
     int64_t fixedp;       /* poses [0, fixedp) are held fixed                  */
@@ -68,12 +68,15 @@ typedef struct {
  * out of range, BT_EUNSUPPORTED if a single track is seen by more than 64 free
  * cameras, n > 255, or the edges of one track name different source frames (the
  * caller's invariant ii = ix[kk], batrack.py:199, is relied upon).
- * n_all_min: lower bound for n_all (0 = derive from the edges).  A rank that holds
- * only a shard of the edges passes the global n_all so that every rank builds a
- * reduced system of the same size. */
+ * n_all_min: lower bound for n_all (0 = derive from the edges).
+ * own_lo, own_hi: multi-GPU sharding.  Every rank passes the FULL edge
+ * list; the plan assembles only the tracks with own_lo <= kk < own_hi (own_hi = 0: all),
+ * while the size and block-sparsity of the reduced system come from all edges, so the
+ * all-reduced [S | y] has the same layout and pattern on every rank.  Per-edge inputs
+ * (targets, weights) stay indexed by the full edge list. */
 int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
                    int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
-                   int on_device, int upload, bt_plan **out);
+                   int64_t own_lo, int64_t own_hi, int on_device, int upload, bt_plan **out);
 void bt_plan_destroy(bt_plan *plan);
 int bt_plan_get_info(const bt_plan *plan, bt_plan_info *info);
 size_t bt_plan_workspace_bytes(const bt_plan *plan);

@@ -54,11 +54,11 @@ def test_error_codes_not_crashes():
     h = ctypes.c_void_p()
     ii = np.array([0, 1], np.int64)
     # null output pointer / negative sizes / out-of-range indices
-    assert L.bt_plan_create(ii.ctypes.data, ii.ctypes.data, ii.ctypes.data, 2, 4, 8, 1, 0, 0, 0, None) == _lib.BT_EINVAL
-    assert L.bt_plan_create(ii.ctypes.data, ii.ctypes.data, ii.ctypes.data, -1, 4, 8, 1, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EINVAL
+    assert L.bt_plan_create(ii.ctypes.data, ii.ctypes.data, ii.ctypes.data, 2, 4, 8, 1, 0, 0, 0, 0, 0, None) == _lib.BT_EINVAL
+    assert L.bt_plan_create(ii.ctypes.data, ii.ctypes.data, ii.ctypes.data, -1, 4, 8, 1, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EINVAL
     bad = np.array([0, 9], np.int64)
-    assert L.bt_plan_create(ii.ctypes.data, bad.ctypes.data, ii.ctypes.data, 2, 4, 8, 1, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EINVAL
-    assert L.bt_plan_create(ii.ctypes.data, ii.ctypes.data, ii.ctypes.data, 2, 4, 8, 1, 0, 0, 0, ctypes.byref(h)) == _lib.BT_OK
+    assert L.bt_plan_create(ii.ctypes.data, bad.ctypes.data, ii.ctypes.data, 2, 4, 8, 1, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EINVAL
+    assert L.bt_plan_create(ii.ctypes.data, ii.ctypes.data, ii.ctypes.data, 2, 4, 8, 1, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.BT_OK
     # a host-only plan refuses to launch (no device arrays): code, not a crash
     args = _lib.BaArgs()
     assert L.bt_ba_step(h, ctypes.byref(args), ctypes.c_void_p(1), None) == _lib.BT_EINVAL
@@ -73,17 +73,17 @@ def test_unsupported_graphs_are_reported():
     h = ctypes.c_void_p()
     n = 300                                           # 299 free poses > 255
     ii = np.zeros(n, np.int64); jj = np.arange(n, dtype=np.int64); kk = np.zeros(n, np.int64)
-    assert L.bt_plan_create(ii.ctypes.data, jj.ctypes.data, kk.ctypes.data, n, n, 4, 1, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EUNSUPPORTED
+    assert L.bt_plan_create(ii.ctypes.data, jj.ctypes.data, kk.ctypes.data, n, n, 4, 1, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EUNSUPPORTED
     n = 80                                            # one track seen by 79 free cameras > 64
     ii = np.zeros(n, np.int64); jj = np.arange(n, dtype=np.int64); kk = np.zeros(n, np.int64)
-    assert L.bt_plan_create(ii.ctypes.data, jj.ctypes.data, kk.ctypes.data, n, n, 4, 1, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EUNSUPPORTED
+    assert L.bt_plan_create(ii.ctypes.data, jj.ctypes.data, kk.ctypes.data, n, n, 4, 1, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EUNSUPPORTED
 
 
 def test_track_with_two_source_frames_is_rejected():
     L = _lib.lib()
     h = ctypes.c_void_p()
     ii = np.array([0, 1], np.int64); jj = np.array([1, 2], np.int64); kk = np.array([3, 3], np.int64)
-    assert L.bt_plan_create(ii.ctypes.data, jj.ctypes.data, kk.ctypes.data, 2, 4, 8, 1, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EUNSUPPORTED
+    assert L.bt_plan_create(ii.ctypes.data, jj.ctypes.data, kk.ctypes.data, 2, 4, 8, 1, 0, 0, 0, 0, 0, ctypes.byref(h)) == _lib.BT_EUNSUPPORTED
 
 
 def test_product_path_has_no_cpu_fallback():

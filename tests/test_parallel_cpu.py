@@ -28,12 +28,12 @@ def _worker(rank, world, port, name, fixedp, out):
         d = dict(np.load(os.path.join(GOLD, name + ".npz")))
         n_all = int(max(d["ii"].max(), d["jj"].max())) + 1
         idx = shard_edges(torch.as_tensor(d["kk"]), world, rank).numpy()
-        loc = dict(d)
-        for k in ("ii", "jj", "kk", "targets3", "weights", "weights_pose"):
-            loc[k] = d[k][idx]
-        pl = Plan(loc["ii"], loc["jj"], loc["kk"], d["poses"].shape[0], d["patches"].shape[0], fixedp,
-                  upload=False, n_all_min=n_all)
-        assert pl.n == n_all - fixedp                       # every rank builds the same-size system
+        own = partition_tracks(d["kk"], world)[rank]
+        # every rank plans from the FULL edge list and assembles only its own track range
+        pl = Plan(d["ii"], d["jj"], d["kk"], d["poses"].shape[0], d["patches"].shape[0], fixedp,
+                  upload=False, own=own)
+        assert pl.n == n_all - fixedp and pl.E == len(idx)   # same-size system on every rank
+        loc = d
         em = emulate(pl, pl.arrays(), loc, "weights_pose")
         D = 6 * pl.n
         system = torch.as_tensor(np.concatenate([np.tril(em["S_lower"]).reshape(-1), em["y"]]))
@@ -42,6 +42,10 @@ def _worker(rank, world, port, name, fixedp, out):
                              d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=fixedp, want_system=True)
         S = system[:D * D].reshape(D, D).numpy()
         y = system[D * D:].numpy()
+        # the all-reduced system must be solvable with THIS rank's symbolic structure (pattern from all tracks)
+        from plan_emulator import sparse_chol_solve
+        dX = sparse_chol_solve(pl.arrays(), S, y, pl.n, 10.0, 1e-4)
+        assert np.linalg.norm(dX - ref["dX"]) / np.linalg.norm(ref["dX"]) < 1e-7
         eS = np.linalg.norm(S - np.tril(ref["S"])) / np.linalg.norm(np.tril(ref["S"]))
         ey = np.linalg.norm(y - ref["y"]) / np.linalg.norm(ref["y"])
         # shards are a partition of the edges, by track
@@ -49,7 +53,7 @@ def _worker(rank, world, port, name, fixedp, out):
         cover[torch.as_tensor(idx)] = 1
         dist.all_reduce(cover)
         lo, hi = partition_tracks(d["kk"], world)[rank]
-        ok_part = bool((cover == 1).all()) and bool(((loc["kk"] >= lo) & (loc["kk"] < hi)).all())
+        ok_part = bool((cover == 1).all()) and bool(((d["kk"][idx] >= lo) & (d["kk"][idx] < hi)).all())
         out[rank] = (float(eS), float(ey), ok_part, len(idx))
     finally:
         dist.destroy_process_group()
