@@ -84,6 +84,8 @@ def lib():
         f = getattr(L, name)
         f.restype = i32
         f.argtypes = [vp, ctypes.POINTER(BaArgs), vp, vp]
+    L.bt_ba_workspace_init.restype = i32
+    L.bt_ba_workspace_init.argtypes = [vp, vp, vp]
     L.bt_ba_step_timed.restype = i32
     L.bt_ba_step_timed.argtypes = [vp, ctypes.POINTER(BaArgs), vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.bt_ba_system.restype = vp

@@ -29,7 +29,7 @@ namespace bt {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// ------------------------------------------------------------------ k_prep
+// ------------------------------------------------------------------ pair geometry
 __device__ inline void quat_to_rot(const double *q, double R[9]) {
     const double n = 1.0 / sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
     const double x = q[0]*n, y = q[1]*n, z = q[2]*n, w = q[3]*n;
@@ -38,18 +38,15 @@ __device__ inline void quat_to_rot(const double *q, double R[9]) {
     R[6] = 2*(x*z - y*w);     R[7] = 2*(y*z + x*w);     R[8] = 1 - 2*(x*x + y*y);
 }
 
-__global__ __launch_bounds__(256) void k_prep(PlanDev pd, StepArgs a, size_t zero_count, int do_zero) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nth = (size_t)gridDim.x * blockDim.x;
-    if (do_zero)
-        for (size_t i = gid; i < zero_count; i += nth) a.S[i] = 0.0;
-    if (gid >= (size_t)pd.P) return;
-    const int i = pd.pair_i[gid], j = pd.pair_j[gid];
+// Relative pose of camera pair (i, j) and the intrinsics the edge maths needs, 20 floats:
+// R_ij (9, row-major), t_ij (3), (1/fx_i, 1/fy_i, cx_i, cy_i), (fx_j, fy_j, cx_j, cy_j).
+// Gij = Gj * Gi^-1 (projective_ops.py:61) in double; a self edge is exactly the identity.
+__device__ inline void pair_geometry(const float *poses, const float *intr, int i, int j, float *g) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
-    if (i != j) {                       // Gij = Gj * Gi^-1 ; a self edge is exactly the identity
+    if (i != j) {
         double qi[4], qj[4], Ri[9], Rj[9], ti[3], tj[3];
-        for (int c = 0; c < 3; ++c) { ti[c] = a.poses[7*i + c]; tj[c] = a.poses[7*j + c]; }
-        for (int c = 0; c < 4; ++c) { qi[c] = a.poses[7*i + 3 + c]; qj[c] = a.poses[7*j + 3 + c]; }
+        for (int c = 0; c < 3; ++c) { ti[c] = poses[7*i + c]; tj[c] = poses[7*j + c]; }
+        for (int c = 0; c < 4; ++c) { qi[c] = poses[7*i + 3 + c]; qj[c] = poses[7*j + 3 + c]; }
         quat_to_rot(qi, Ri); quat_to_rot(qj, Rj);
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c)
@@ -57,12 +54,11 @@ __global__ __launch_bounds__(256) void k_prep(PlanDev pd, StepArgs a, size_t zer
         for (int r = 0; r < 3; ++r)
             t[r] = tj[r] - (R[3*r]*ti[0] + R[3*r + 1]*ti[1] + R[3*r + 2]*ti[2]);
     }
-    float *g = a.ptab + gid * kPairGeomFloats;
     for (int c = 0; c < 9; ++c) g[c] = (float)R[c];
     for (int c = 0; c < 3; ++c) g[9 + c] = (float)t[c];
     // source intrinsics as (1/fx, 1/fy, cx, cy): iproj divides (projective_ops.py:25-26)
-    g[12] = 1.0f / a.intr[4*i]; g[13] = 1.0f / a.intr[4*i + 1]; g[14] = a.intr[4*i + 2]; g[15] = a.intr[4*i + 3];
-    for (int c = 0; c < 4; ++c) g[16 + c] = a.intr[4*j + c];
+    g[12] = 1.0f / intr[4*i]; g[13] = 1.0f / intr[4*i + 1]; g[14] = intr[4*i + 2]; g[15] = intr[4*i + 3];
+    for (int c = 0; c < 4; ++c) g[16 + c] = intr[4*j + c];
 }
 
 // ------------------------------------------------------------------ per-edge math
@@ -164,7 +160,16 @@ __global__ __launch_bounds__(512) void k_tile(PlanDev pd, StepArgs a) {
     int *las = reinterpret_cast<int *>(stg + kTileWaves * 8 * 64);
     float *Qs = reinterpret_cast<float *>(las + kTileWaves * 64);
     int *gidx = reinterpret_cast<int *>(Qs + 64);
+    float *geo = reinterpret_cast<float *>(gidx + R16);           // [npair][20], 16-byte aligned (R16 % 16 == 0)
     const int *cams = pd.tile_cams + pd.tile_cam0[tile];
+    {                                                              // relative pose of the tile's camera pairs
+        const int np = pd.tile_npair[tile];
+        const int *pl = pd.tile_pairs + pd.tile_pair0[tile];
+        for (int p = tid; p < np; p += 512) {
+            const int gp = pl[p];
+            pair_geometry(a.poses, a.intr, pd.pair_i[gp], pd.pair_j[gp], geo + p * kPairGeomFloats);
+        }
+    }
     for (int i = tid; i < R16 * kLdsRowStride; i += 512) Eh[i] = 0.0f;
     for (int i = tid; i < R16; i += 512) gidx[i] = i < R ? 6 * cams[i / 6] + i % 6 : -1;
 
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(512) void k_tile(PlanDev pd, StepArgs a) {
         }
         float g[kPairGeomFloats];
         {
-            const float4 *g4 = reinterpret_cast<const float4 *>(a.ptab + (size_t)pair * kPairGeomFloats);
+            const float4 *g4 = reinterpret_cast<const float4 *>(geo + (size_t)pd.slot_lp[idx] * kPairGeomFloats);
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
                 const float4 t4 = g4[c];
@@ -374,14 +379,17 @@ __device__ __forceinline__ int sym21(int p, int q) {
 
 __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
     __shared__ double sB[4][36], sAd[4][36], sM[4][36], sg[4][6];
+    __shared__ float sgeo[4][kPairGeomFloats];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + w;
     const bool live = p < pd.P;
     int ia = -1, ib = -1;
     if (live) {
         ia = pd.pair_i[p] - pd.fixedp; ib = pd.pair_j[p] - pd.fixedp;
-        const double *acc = a.pairacc + (size_t)p * kPairAccStride;
-        const float *g = a.ptab + (size_t)p * kPairGeomFloats;
+        double *acc = a.pairacc + (size_t)p * kPairAccStride;
+        float *g = sgeo[w];
+        if (lane == 0) pair_geometry(a.poses, a.intr, pd.pair_i[p], pd.pair_j[p], g);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (lane < 36) {
             const int r = lane / 6, c = lane % 6;
             sB[w][lane] = acc[sym21(r, c)];
@@ -399,6 +407,8 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
         } else if (lane < 42) {
             sg[w][lane - 36] = acc[21 + lane - 36];
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane < 27) acc[lane] = 0.0;                 // leave the per-pair sums clear for the next step
     }
     __syncthreads();
     if (live && lane < 36) {
@@ -589,6 +599,13 @@ __global__ __launch_bounds__(1024) void k_solve_global(PlanDev pd, StepArgs a) {
     __syncthreads();
     for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = z[i];
     if (tid == 0) a.status[0] = status;
+    // leave [S | y] clear for the next step's accumulation
+    for (int idx = tid; idx < pd.nnzb * 36; idx += nth) {
+        const int b = idx / 36, e = idx % 36, r = e / 6, c = e % 6, src = pd.blk_src[b];
+        const int rr = (src & 1) ? c : r, cc = (src & 1) ? r : c;
+        a.S[(size_t)(6*(src >> 9) + rr) * D + 6*((src >> 1) & 255) + cc] = 0.0;
+    }
+    for (int i = tid; i < D; i += nth) a.y[i] = 0.0;
 }
 
 // ------------------------------------------------------------------ k_solve_lds
@@ -1012,6 +1029,20 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     __syncthreads();
     for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
     if (tid == 0) a.status[0] = status;
+    // leave [S | y] clear for the next step's accumulation (this kernel is their only reader)
+    for (int idx = tid; idx < nnzb * 6; idx += nth) {
+        const int b = idx / 6, r = idx - 6 * b, src = pd.blk_src[b];
+        const int rn = src >> 9, cn = (src >> 1) & 255;
+        if (src & 1) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) a.S[(size_t)(6 * rn + c) * D + 6 * cn + r] = 0.0;
+        } else {
+            double *p = a.S + (size_t)(6 * rn + r) * D + 6 * cn;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) p[c] = 0.0;
+        }
+    }
+    for (int i = tid; i < D; i += nth) a.y[i] = 0.0;
     BT_PF(8);
     if (PROF && lane == 0 && (wave == 0 || wave == 5)) {        // measurement only: phase cycle counts of a critical and a helper wave
         long long *o = reinterpret_cast<long long *>(a.status + 4) + (wave ? 1 : 0) * 10;
@@ -1107,7 +1138,8 @@ __global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_p
 // ------------------------------------------------------------------ launchers
 static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     const size_t rows = so ? 0 : (size_t)pd.max_rows16;
-    return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 64 + rows) * sizeof(float) + 64;
+    return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 64 + rows +
+            (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) + 64;
 }
 
 constexpr size_t kLdsBudget = 160 * 1024 - 512;
@@ -1161,12 +1193,7 @@ int configure_kernels(const PlanDev &pd) {
     } while (0)
 
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev) {
-    const int zero = so ? 0 : 1;
-    size_t nb = (size_t)(pd.P + 255) / 256;
-    if (zero) nb = nb > (zero_doubles + 2047) / 2048 ? nb : (zero_doubles + 2047) / 2048;
-    if (nb > 2048) nb = 2048;
-    if (nb < 1) nb = 1;
-    BT_LAUNCH(0, k_prep, dim3((unsigned)nb), dim3(256), 0, pd, a, zero_doubles, zero);
+    (void)zero_doubles;   // the accumulators are cleared by their consumers (k_pair_finalize, k_solve_*)
     if (pd.T > 0) {
         if (so)                BT_LAUNCH(1, (k_tile<true, false>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, true), pd, a);
         else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, false), pd, a);

@@ -185,6 +185,30 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     }
 
+    // ---- distinct camera pairs of every tile (their relative pose is computed once per tile)
+    pl->tile_pair0.assign((size_t)T, 0); pl->tile_npair.assign((size_t)T, 0);
+    pl->tile_pairs.clear();
+    pl->slot_lp.assign((size_t)slots * kLanes, 0);
+    pl->max_tile_pairs = 0;
+    {
+        std::vector<int32_t> lp_of(pl->pair_i.size(), -1), mine;
+        for (int32_t t = 0; t < T; ++t) {
+            mine.clear();
+            const size_t b0 = (size_t)pl->tile_slot0[(size_t)t] * kLanes, b1 = b0 + (size_t)pl->tile_nslot[(size_t)t] * kLanes;
+            for (size_t i = b0; i < b1; ++i)
+                if (pl->slot_edge[i] >= 0 && lp_of[(size_t)pl->slot_pair[i]] < 0) { lp_of[(size_t)pl->slot_pair[i]] = 0; mine.push_back(pl->slot_pair[i]); }
+            std::sort(mine.begin(), mine.end());
+            if ((int)mine.size() > kMaxTilePairs) return BT_EUNSUPPORTED;
+            for (size_t q = 0; q < mine.size(); ++q) lp_of[(size_t)mine[q]] = (int32_t)q;
+            for (size_t i = b0; i < b1; ++i) if (pl->slot_edge[i] >= 0) pl->slot_lp[i] = (uint8_t)lp_of[(size_t)pl->slot_pair[i]];
+            pl->tile_pair0[(size_t)t] = (int32_t)pl->tile_pairs.size();
+            pl->tile_npair[(size_t)t] = (int32_t)mine.size();
+            pl->tile_pairs.insert(pl->tile_pairs.end(), mine.begin(), mine.end());
+            pl->max_tile_pairs = std::max(pl->max_tile_pairs, (int)mine.size());
+            for (int32_t q : mine) lp_of[(size_t)q] = -1;
+        }
+    }
+
     // ---- block structure of S (lower) and symbolic Cholesky ----------------
     // S[u][v] (u >= v) may be non-zero if u and v share a tile (Schur term,
     // ba.py:321) or form a camera pair with both ends free (B, ba.py:279-282).

@@ -17,7 +17,8 @@ constexpr int kMaxFree = 255;       // free poses supported by the reduced solve
 constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj + 6 gj)
 constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
 constexpr int kLdsRowStride = 66;
-constexpr int kMaxLevelCols = 4;    // columns of the reduced system factored concurrently (one critical wave each)   // floats per local E row (bank-conflict-free)
+constexpr int kMaxLevelCols = 4;
+constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geometry is kept in LDS    // columns of the reduced system factored concurrently (one critical wave each)   // floats per local E row (bank-conflict-free)
 
 // Device-side view: raw pointers into one device allocation + sizes.
 struct PlanDev {
@@ -28,6 +29,9 @@ struct PlanDev {
     const int32_t *tile_cams;
     const int32_t *slot_edge, *slot_pair;
     const uint16_t *slot_lab;
+    const int32_t *tile_pair0, *tile_npair, *tile_pairs;     // distinct camera pairs of a tile (global pair ids)
+    const uint8_t *slot_lp;                                  // local pair index of a (slot, lane) within its tile
+    int max_tile_pairs;
     const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
     // elimination order and level schedule of the reduced solver
     int nlev, ndp;
@@ -50,6 +54,9 @@ struct bt_plan {
     std::vector<int32_t> tile_cams;
     std::vector<int32_t> slot_edge, slot_pair;
     std::vector<uint16_t> slot_lab;
+    std::vector<int32_t> tile_pair0, tile_npair, tile_pairs;
+    std::vector<uint8_t> slot_lp;
+    int max_tile_pairs = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
     std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp;
     int max_rows16 = 16;

@@ -10,11 +10,11 @@ import numpy as np
 
 from . import _lib
 
-_NP_TYPES = {"slot_lab": np.uint16}
+_NP_TYPES = {"slot_lab": np.uint16, "slot_lp": np.uint8}
 PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0", "tile_ntrk", "tile_ncam",
                "tile_cam0", "tile_slot0", "tile_nslot", "tile_erow0", "tile_cams", "slot_edge", "slot_pair",
                "slot_lab", "col_ptr", "row_idx", "upd_ptr", "upd", "blk_col", "upd_next", "perm", "blk_src",
-               "lvl_ptr", "lvl_cols", "col_lvl", "dp_ptr", "dp")
+               "lvl_ptr", "lvl_cols", "col_lvl", "dp_ptr", "dp", "tile_pair0", "tile_npair", "tile_pairs", "slot_lp")
 
 
 class Plan:
@@ -95,7 +95,8 @@ class Stepper:
             raise RuntimeError("plan was built host-only")
         self.plan = plan
         self.device = torch.device(device)
-        self.ws = torch.empty(max(plan.workspace_bytes, 256), dtype=torch.uint8, device=self.device)
+        # zero-filled: the accumulators must start clear (bt_ba_workspace_init); every step leaves them clear
+        self.ws = torch.zeros(max(plan.workspace_bytes, 256), dtype=torch.uint8, device=self.device)
         self._args = _lib.BaArgs()
         self._lib = _lib.lib()
         cnt = ctypes.c_int64()

@@ -102,12 +102,18 @@ typedef struct {
     int32_t structure_only;    /* ba.py:316                                           */
 } bt_ba_args;
 
+/* Clears the accumulators ([S | y] and the per-pair sums) inside `workspace`.  Call once
+ * after allocating a workspace (or pass zero-filled memory), and again only if a
+ * bt_ba_reduce was not followed by its bt_ba_solve_update: every completed step leaves the
+ * accumulators clear for the next one (the kernels that consume them reset them). */
+int bt_ba_workspace_init(const bt_plan *plan, void *workspace, void *stream);
+
 /* One BA_rgbd_droid call, all phases, enqueued on `stream`. */
 int bt_ba_step(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
 
 /* bt_ba_step with a (start, stop) HIP event pair around every kernel, recorded on
  * `stream` by the launch itself; synchronises, then ms[k] = duration of kernel k:
- * 0 k_prep, 1 k_tile (residual + Jacobian + assembly + Schur), 2 k_pair_finalize,
+ * 0 (unused, 0), 1 k_tile (residual + Jacobian + assembly + Schur), 2 k_pair_finalize,
  * 3 k_solve, 4 k_update; 0 for a kernel the call did not launch.  Measurement only. */
 int bt_ba_step_timed(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream, float *ms);
 
