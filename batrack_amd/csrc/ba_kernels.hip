@@ -599,13 +599,6 @@ __global__ __launch_bounds__(1024) void k_solve_global(PlanDev pd, StepArgs a) {
     __syncthreads();
     for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = z[i];
     if (tid == 0) a.status[0] = status;
-    // leave [S | y] clear for the next step's accumulation
-    for (int idx = tid; idx < pd.nnzb * 36; idx += nth) {
-        const int b = idx / 36, e = idx % 36, r = e / 6, c = e % 6, src = pd.blk_src[b];
-        const int rr = (src & 1) ? c : r, cc = (src & 1) ? r : c;
-        a.S[(size_t)(6*(src >> 9) + rr) * D + 6*((src >> 1) & 255) + cc] = 0.0;
-    }
-    for (int i = tid; i < D; i += nth) a.y[i] = 0.0;
 }
 
 // ------------------------------------------------------------------ k_solve_lds
@@ -1029,20 +1022,6 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     __syncthreads();
     for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
     if (tid == 0) a.status[0] = status;
-    // leave [S | y] clear for the next step's accumulation (this kernel is their only reader)
-    for (int idx = tid; idx < nnzb * 6; idx += nth) {
-        const int b = idx / 6, r = idx - 6 * b, src = pd.blk_src[b];
-        const int rn = src >> 9, cn = (src >> 1) & 255;
-        if (src & 1) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) a.S[(size_t)(6 * rn + c) * D + 6 * cn + r] = 0.0;
-        } else {
-            double *p = a.S + (size_t)(6 * rn + r) * D + 6 * cn;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) p[c] = 0.0;
-        }
-    }
-    for (int i = tid; i < D; i += nth) a.y[i] = 0.0;
     BT_PF(8);
     if (PROF && lane == 0 && (wave == 0 || wave == 5)) {        // measurement only: phase cycle counts of a critical and a helper wave
         long long *o = reinterpret_cast<long long *>(a.status + 4) + (wave ? 1 : 0) * 10;
@@ -1094,7 +1073,15 @@ __device__ inline void retract_pose(const float *pin, const float *xi, float *po
 }
 
 template <bool SO>
-__global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_poses) {
+__global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_poses, int first_zero_block) {
+    if (!SO && (int)blockIdx.x >= first_zero_block) {
+        // [S | y] has been consumed by the solver: leave it clear for the next step's accumulation
+        const size_t nz = (size_t)pd.D * pd.D + pd.D;
+        const size_t i0 = ((size_t)(blockIdx.x - first_zero_block) * blockDim.x + threadIdx.x) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i0 + k < nz) a.S[i0 + k] = 0.0;
+        return;
+    }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < pd.p_tot) {
         const float x = a.patches[3*gid], y = a.patches[3*gid + 1], d = a.patches[3*gid + 2];
@@ -1217,8 +1204,11 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
     }
     const int do_poses = so ? (copy_poses ? 1 : 0) : 1;
     const int total = pd.p_tot + (do_poses ? pd.n_buf : 0);
-    if (so) BT_LAUNCH(4, k_update<true>, dim3((total + 255) / 256), dim3(256), 0, pd, a, do_poses);
-    else    BT_LAUNCH(4, k_update<false>, dim3((total + 255) / 256), dim3(256), 0, pd, a, do_poses);
+    const int nb = (total + 255) / 256;
+    const size_t nz = (size_t)pd.D * pd.D + pd.D;
+    const int zb = (int)((nz + 1023) / 1024);
+    if (so) BT_LAUNCH(4, k_update<true>, dim3(nb), dim3(256), 0, pd, a, do_poses, nb);
+    else    BT_LAUNCH(4, k_update<false>, dim3(nb + zb), dim3(256), 0, pd, a, do_poses, nb);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 #undef BT_LAUNCH

@@ -49,13 +49,17 @@ class HipProblem:
         pout = torch.empty_like(pat)
         Pout = P if so else torch.empty_like(P)
         tg = self.t3[0]
-        st.step(P, pat, self.mono.reshape(-1), self.intr[0], tg, tg.stride(0), self.w[wkey][0].contiguous(),
+        args = (P, pat, self.mono.reshape(-1), self.intr[0], tg, tg.stride(0), self.w[wkey][0].contiguous(),
                 Pout, pout, self.bounds, lmbda, ep, alpha, loss, so)
+        st.step(*args, phase="reduce")                 # the step, split where multi-GPU all-reduces,
+        torch.cuda.synchronize()                       # so the reduced system can be inspected
+        sysv = st.system.cpu().numpy().copy()
+        st.step(*args, phase="solve_update")
         torch.cuda.synchronize()
+        assert not so and float(st.system.abs().max()) == 0.0 or so   # accumulators left clear
         out = dict(poses_out=Pout.cpu().numpy(), patches_out=pout.cpu().numpy(), plan=plan, stepper=st)
         if not so:
             D = 6 * plan.n
-            sysv = st.system.cpu().numpy()
             out["S_lower"] = sysv[:D * D].reshape(D, D)
             out["y"] = sysv[D * D:]
             out["dX"] = st.dx.cpu().numpy()
