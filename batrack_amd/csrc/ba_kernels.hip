@@ -702,16 +702,17 @@ template <typename T> __device__ __forceinline__ void lds_sub(T *p, T v, bool at
     if (atomic) atomicAdd(p, -v); else *p -= v;
 }
 
-// One ROW of an update triple: dst[r][:] -= (row r of block tr[0]) . (rows of block tr[1])^T.
-// 21 vector LDS loads and 36 FMAs for 6 outputs.  Bit 15 of tr[2]: the destination is also
-// updated by another column of the same level -> LDS atomics.
+// Half a ROW of an update triple: dst[r][3h..3h+2] -= (row r of block tr[0]) . (rows 3h..3h+2 of
+// block tr[1]).  12 vector LDS loads and 18 FMAs for 3 outputs; two such tasks per row keep every
+// helper thread of a banded column busy for one short round.  Bit 15 of tr[2]: the destination is
+// also updated by another column of the same level -> LDS atomics.
 template <typename T>
-__device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr, int r) {
-    T a[6], o[6];
+__device__ __forceinline__ void apply_update_half_row(T *Lw, const unsigned short *tr, int r, int h) {
+    T a[6], o[3];
     load_row6(Lw + (size_t)tr[0] * 36 + 6 * r, a);
-    const T *bb = Lw + (size_t)tr[1] * 36;
+    const T *bb = Lw + (size_t)tr[1] * 36 + 18 * h;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < 3; ++c) {
         T b[6];
         load_row6(bb + 6 * c, b);
         T acc = a[0] * b[0];
@@ -720,16 +721,13 @@ __device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr
         o[c] = acc;
     }
     const unsigned d = tr[2];
-    T *dst = Lw + (size_t)(d & 0x7fffu) * 36 + 6 * r;
+    T *dst = Lw + (size_t)(d & 0x7fffu) * 36 + 6 * r + 3 * h;
     if (d & 0x8000u) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) atomicAdd(dst + c, -o[c]);
+        for (int c = 0; c < 3; ++c) atomicAdd(dst + c, -o[c]);
     } else {
-        T v[6];
-        load_row6(dst, v);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) v[c] -= o[c];
-        store_row6(dst, v);
+        for (int c = 0; c < 3; ++c) dst[c] -= o[c];
     }
 }
 
@@ -858,7 +856,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                     int cntq = 0;
                     if (q < np) {
                         const int pj = lvl_cols[p0 + q];
-                        cntq = (upd_ptr[pj + 1] - upd_ptr[pj] - upd_next[pj]) * 6 + (col_ptr[pj + 1] - col_ptr[pj] - 1) * 6;
+                        cntq = (upd_ptr[pj + 1] - upd_ptr[pj] - upd_next[pj]) * 12 + (col_ptr[pj + 1] - col_ptr[pj] - 1) * 6;
                     }
                     items_before[q + 1] = items_before[q] + cntq;
                 }
@@ -870,11 +868,11 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                     const int pj = lvl_cols[p0 + q];
                     const int u0 = upd_ptr[pj] + upd_next[pj], nu = upd_ptr[pj + 1] - u0;
                     const int dposp = col_ptr[pj];
-                    if (idx < nu * 6) {
-                        const int t = idx / 6;
-                        apply_update_row(Lw, upd + 3 * (u0 + t), idx - 6 * t);
+                    if (idx < nu * 12) {
+                        const int t = idx / 12, rh = idx - 12 * t;
+                        apply_update_half_row(Lw, upd + 3 * (u0 + t), rh >> 1, rh & 1);
                     } else {
-                        const int qq = idx - nu * 6, sb = qq / 6, r = qq - 6 * sb;
+                        const int qq = idx - nu * 12, sb = qq / 6, r = qq - 6 * sb;
                         T lr[6], zr[6];
                         load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
                         load_row6(z + 6 * pj, zr);
