@@ -695,6 +695,7 @@ size_t solve_lds_bytes(const PlanDev &pd, size_t elem) {
     b = (b + 15) / 16 * 16;
     // row_idx, col_ptr, upd_ptr, upd_next, dp_ptr, lvl_ptr, lvl_cols, dp
     b += ((size_t)pd.nnzb + 4 * ((size_t)pd.n + 1) + (size_t)pd.nlev + 1 + (size_t)pd.n + (size_t)pd.ndp) * sizeof(int);
+    b = (b + 15) / 16 * 16 + (size_t)pd.nlev * kMaxLevelCols * 8 * sizeof(int);   // lvl_meta
     return b + 64;
 }
 
@@ -702,17 +703,16 @@ template <typename T> __device__ __forceinline__ void lds_sub(T *p, T v, bool at
     if (atomic) atomicAdd(p, -v); else *p -= v;
 }
 
-// Half a ROW of an update triple: dst[r][3h..3h+2] -= (row r of block tr[0]) . (rows 3h..3h+2 of
-// block tr[1]).  12 vector LDS loads and 18 FMAs for 3 outputs; two such tasks per row keep every
-// helper thread of a banded column busy for one short round.  Bit 15 of tr[2]: the destination is
-// also updated by another column of the same level -> LDS atomics.
+// One ROW of an update triple: dst[r][:] -= (row r of block tr[0]) . (rows of block tr[1])^T.
+// 21 vector LDS loads and 36 FMAs for 6 outputs.  Bit 15 of tr[2]: the destination is also
+// updated by another column of the same level -> LDS atomics.
 template <typename T>
-__device__ __forceinline__ void apply_update_half_row(T *Lw, const unsigned short *tr, int r, int h) {
-    T a[6], o[3];
+__device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr, int r) {
+    T a[6], o[6];
     load_row6(Lw + (size_t)tr[0] * 36 + 6 * r, a);
-    const T *bb = Lw + (size_t)tr[1] * 36 + 18 * h;
+    const T *bb = Lw + (size_t)tr[1] * 36;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 6; ++c) {
         T b[6];
         load_row6(bb + 6 * c, b);
         T acc = a[0] * b[0];
@@ -721,13 +721,16 @@ __device__ __forceinline__ void apply_update_half_row(T *Lw, const unsigned shor
         o[c] = acc;
     }
     const unsigned d = tr[2];
-    T *dst = Lw + (size_t)(d & 0x7fffu) * 36 + 6 * r + 3 * h;
+    T *dst = Lw + (size_t)(d & 0x7fffu) * 36 + 6 * r;
     if (d & 0x8000u) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(dst + c, -o[c]);
+        for (int c = 0; c < 6; ++c) atomicAdd(dst + c, -o[c]);
     } else {
+        T v[6];
+        load_row6(dst, v);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dst[c] -= o[c];
+        for (int c = 0; c < 6; ++c) v[c] -= o[c];
+        store_row6(dst, v);
     }
 }
 
@@ -745,6 +748,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     int *row_idx = reinterpret_cast<int *>(smem + off), *col_ptr = row_idx + nnzb, *upd_ptr = col_ptr + n + 1,
         *upd_next = upd_ptr + n + 1, *dp_ptr = upd_next + n + 1, *lvl_ptr = dp_ptr + n + 1,
         *lvl_cols = lvl_ptr + nlev + 1, *dp = lvl_cols + n;
+    int4 *lvl_meta = reinterpret_cast<int4 *>(smem + ((reinterpret_cast<unsigned char *>(dp + pd.ndp) - smem + 15) / 16 * 16));
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { tn = clock64(); pf[i] += tn - tc; tc = tn; } } while (0)
     for (int i = tid; i < pd.nupd * 3; i += nth) upd[i] = (unsigned short)pd.upd[i];
@@ -755,6 +759,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     for (int i = tid; i <= nlev; i += nth) lvl_ptr[i] = pd.lvl_ptr[i];
     for (int i = tid; i < n; i += nth) lvl_cols[i] = pd.lvl_cols[i];
     for (int i = tid; i < pd.ndp; i += nth) dp[i] = pd.dp[i];
+    for (int i = tid; i < nlev * kMaxLevelCols * 2; i += nth) lvl_meta[i] = reinterpret_cast<const int4 *>(pd.lvl_meta)[i];
     __syncthreads();
 
     int status = BT_SOLVE_OK;
@@ -803,12 +808,19 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
         BT_PF(0);
 
         for (int l = 0; l < nlev; ++l) {
-            const int c0 = lvl_ptr[l], nc = lvl_ptr[l + 1] - c0;
-            const int p0 = l > 0 ? lvl_ptr[l - 1] : 0, np = l > 0 ? c0 - p0 : 0;
+            // per-level metadata: one LDS round trip instead of chains of index lookups
+            int4 mA[kMaxLevelCols], mB[kMaxLevelCols];
+#pragma unroll
+            for (int q = 0; q < kMaxLevelCols; ++q) { mA[q] = lvl_meta[(l * kMaxLevelCols + q) * 2]; mB[q] = lvl_meta[(l * kMaxLevelCols + q) * 2 + 1]; }
+            int nc = 0;
+#pragma unroll
+            for (int q = 0; q < kMaxLevelCols; ++q) nc += mA[q].x >= 0 ? 1 : 0;
             // ---- phase 1
             if (wave < nc) {
-                const int j = lvl_cols[c0 + wave], dpos = col_ptr[j];
-                for (int k = dp_ptr[j]; k < dp_ptr[j + 1]; ++k) {        // pending updates of this column's diagonal block
+                const int4 ma = wave == 0 ? mA[0] : wave == 1 ? mA[1] : wave == 2 ? mA[2] : mA[3];
+                const int4 mb = wave == 0 ? mB[0] : wave == 1 ? mB[1] : wave == 2 ? mB[2] : mB[3];
+                const int dpos = ma.y;
+                for (int k = mb.y; k < mb.y + mb.z; ++k) {        // pending updates of this column's diagonal block
                     if (lane < 36) {
                         const unsigned short *tr = upd + 3 * dp[k];
                         const int r = lane / 6, c = lane - 6 * r;
@@ -845,34 +857,31 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                     }
                 }
                 BT_PF(4);
-            } else {
+            } else if (l > 0) {
                 // the other update triples of the previous level's columns (one ROW of a triple per
                 // thread) and their contribution to y, all columns flattened over the helper threads
                 const int h = tid - 64 * nc, hs = nth - 64 * nc;
+                int4 pA[kMaxLevelCols], pB[kMaxLevelCols];
+#pragma unroll
+                for (int q = 0; q < kMaxLevelCols; ++q) { pA[q] = lvl_meta[((l - 1) * kMaxLevelCols + q) * 2]; pB[q] = lvl_meta[((l - 1) * kMaxLevelCols + q) * 2 + 1]; }
                 int items_before[kMaxLevelCols + 1];
                 items_before[0] = 0;
 #pragma unroll
-                for (int q = 0; q < kMaxLevelCols; ++q) {
-                    int cntq = 0;
-                    if (q < np) {
-                        const int pj = lvl_cols[p0 + q];
-                        cntq = (upd_ptr[pj + 1] - upd_ptr[pj] - upd_next[pj]) * 12 + (col_ptr[pj + 1] - col_ptr[pj] - 1) * 6;
-                    }
-                    items_before[q + 1] = items_before[q] + cntq;
-                }
+                for (int q = 0; q < kMaxLevelCols; ++q)
+                    items_before[q + 1] = items_before[q] + (pA[q].x >= 0 ? pB[q].x * 6 + pA[q].z * 6 : 0);
                 for (int item = h; item < items_before[kMaxLevelCols]; item += hs) {
                     int q = 0;
 #pragma unroll
                     for (int k = 1; k < kMaxLevelCols; ++k) q += item >= items_before[k] ? 1 : 0;
                     const int idx = item - (q == 0 ? 0 : q == 1 ? items_before[1] : q == 2 ? items_before[2] : items_before[3]);
-                    const int pj = lvl_cols[p0 + q];
-                    const int u0 = upd_ptr[pj] + upd_next[pj], nu = upd_ptr[pj + 1] - u0;
-                    const int dposp = col_ptr[pj];
-                    if (idx < nu * 12) {
-                        const int t = idx / 12, rh = idx - 12 * t;
-                        apply_update_half_row(Lw, upd + 3 * (u0 + t), rh >> 1, rh & 1);
+                    const int4 pa = q == 0 ? pA[0] : q == 1 ? pA[1] : q == 2 ? pA[2] : pA[3];
+                    const int4 pb = q == 0 ? pB[0] : q == 1 ? pB[1] : q == 2 ? pB[2] : pB[3];
+                    const int pj = pa.x, u0 = pa.w, nu = pb.x, dposp = pa.y;
+                    if (idx < nu * 6) {
+                        const int t = idx / 6;
+                        apply_update_row(Lw, upd + 3 * (u0 + t), idx - 6 * t);
                     } else {
-                        const int qq = idx - nu * 12, sb = qq / 6, r = qq - 6 * sb;
+                        const int qq = idx - nu * 6, sb = qq / 6, r = qq - 6 * sb;
                         T lr[6], zr[6];
                         load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
                         load_row6(z + 6 * pj, zr);
@@ -892,17 +901,14 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                 int rows_before[kMaxLevelCols + 1];
                 rows_before[0] = 0;
 #pragma unroll
-                for (int q = 0; q < kMaxLevelCols; ++q) {
-                    int cntq = 0;
-                    if (q < nc) { const int jq = lvl_cols[c0 + q]; cntq = (col_ptr[jq + 1] - col_ptr[jq] - 1) * 6 + 1; }
-                    rows_before[q + 1] = rows_before[q] + cntq;
-                }
+                for (int q = 0; q < kMaxLevelCols; ++q) rows_before[q + 1] = rows_before[q] + (mA[q].x >= 0 ? mA[q].z * 6 + 1 : 0);
                 for (int item = tid; item < rows_before[kMaxLevelCols]; item += nth) {
                     int q = 0;
 #pragma unroll
                     for (int k = 1; k < kMaxLevelCols; ++k) q += item >= rows_before[k] ? 1 : 0;
                     const int rw = item - (q == 0 ? 0 : q == 1 ? rows_before[1] : q == 2 ? rows_before[2] : rows_before[3]);
-                    const int j = lvl_cols[c0 + q], dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
+                    const int4 ma = q == 0 ? mA[0] : q == 1 ? mA[1] : q == 2 ? mA[2] : mA[3];
+                    const int j = ma.x, dpos = ma.y, cnt = ma.z;
                     T L[21];
                     const T *dblk = Lw + (size_t)dpos * 36;
 #pragma unroll
@@ -986,10 +992,10 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
         // (c) x_j = zt_j - sum_{i>j} M_ij x_i, levels descending; one wave per column of the level,
         //     lane = (component c) * 8 + g
         for (int l = nlev - 1; l >= 0; --l) {
-            const int c0 = lvl_ptr[l], nc = lvl_ptr[l + 1] - c0;
-            if (wave < nc) {
+            const int4 ma = lvl_meta[(l * kMaxLevelCols + (wave < kMaxLevelCols ? wave : 0)) * 2];
+            if (wave < kMaxLevelCols && ma.x >= 0) {
                 const int c = lane >> 3, g = lane & 7;
-                const int j = lvl_cols[c0 + wave], dpos = col_ptr[j], cnt = col_ptr[j + 1] - dpos - 1;
+                const int j = ma.x, dpos = ma.y, cnt = ma.z;
                 T acc = (T)0;
                 if (c < 6)
                     for (int sb = g; sb < cnt; sb += 8) {           // one sub-block per lane group

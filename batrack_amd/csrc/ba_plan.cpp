@@ -437,6 +437,18 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     }
     pl->dp_ptr[(size_t)n] = (int32_t)pl->dp.size();
 
+    pl->lvl_meta.assign((size_t)nlev * kMaxLevelCols * 8, 0);
+    for (int32_t l = 0; l < nlev; ++l)
+        for (int q = 0; q < kMaxLevelCols; ++q) {
+            int32_t *mrow = pl->lvl_meta.data() + ((size_t)l * kMaxLevelCols + q) * 8;
+            if (pl->lvl_ptr[(size_t)l] + q >= pl->lvl_ptr[(size_t)l + 1]) { mrow[0] = -1; continue; }
+            const int32_t j = pl->lvl_cols[(size_t)pl->lvl_ptr[(size_t)l] + q];
+            mrow[0] = j; mrow[1] = pl->col_ptr[(size_t)j]; mrow[2] = pl->col_ptr[(size_t)j + 1] - pl->col_ptr[(size_t)j] - 1;
+            mrow[3] = pl->upd_ptr[(size_t)j] + pl->upd_next[(size_t)j];
+            mrow[4] = pl->upd_ptr[(size_t)j + 1] - mrow[3];
+            mrow[5] = pl->dp_ptr[(size_t)j]; mrow[6] = pl->dp_ptr[(size_t)j + 1] - pl->dp_ptr[(size_t)j];
+        }
+
     layout_workspace(pl);
     return BT_OK;
 }

@@ -36,6 +36,7 @@ struct PlanDev {
     // elimination order and level schedule of the reduced solver
     int nlev, ndp;
     const int32_t *perm, *blk_src, *lvl_ptr, *lvl_cols, *col_lvl, *dp_ptr, *dp;
+    const int32_t *lvl_meta;   // [nlev][kMaxLevelCols][8]: col, diag pos, #sub-blocks, first rest triple, #rest triples, dp first, #dp, 0  (col = -1: unused)
 };
 
 // Byte offsets of the regions inside the caller's workspace.
@@ -58,7 +59,7 @@ struct bt_plan {
     std::vector<uint8_t> slot_lp;
     int max_tile_pairs = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
-    std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp;
+    std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp, lvl_meta;
     int max_rows16 = 16;
     bt::WsLayout ws{};
     void *dev_base = nullptr;   // one device allocation holding every array above
