@@ -734,6 +734,12 @@ __device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr
     }
 }
 
+// wave-uniform metadata: LDS -> SGPRs
+__device__ __forceinline__ int4 uniform4(const int4 v) {
+    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                     __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+}
+
 template <typename T, bool PROF>
 __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -808,17 +814,13 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
         BT_PF(0);
 
         for (int l = 0; l < nlev; ++l) {
-            // per-level metadata: one LDS round trip instead of chains of index lookups
-            int4 mA[kMaxLevelCols], mB[kMaxLevelCols];
-#pragma unroll
-            for (int q = 0; q < kMaxLevelCols; ++q) { mA[q] = lvl_meta[(l * kMaxLevelCols + q) * 2]; mB[q] = lvl_meta[(l * kMaxLevelCols + q) * 2 + 1]; }
-            int nc = 0;
-#pragma unroll
-            for (int q = 0; q < kMaxLevelCols; ++q) nc += mA[q].x >= 0 ? 1 : 0;
+            // per-level metadata (wave-uniform, kept in SGPRs): one LDS round trip instead of chains
+            // of index lookups
+            const int4 *ml = lvl_meta + (size_t)l * kMaxLevelCols * 2;
+            const int nc = __builtin_amdgcn_readfirstlane(ml[1].w);
             // ---- phase 1
             if (wave < nc) {
-                const int4 ma = wave == 0 ? mA[0] : wave == 1 ? mA[1] : wave == 2 ? mA[2] : mA[3];
-                const int4 mb = wave == 0 ? mB[0] : wave == 1 ? mB[1] : wave == 2 ? mB[2] : mB[3];
+                const int4 ma = uniform4(ml[2 * wave]), mb = uniform4(ml[2 * wave + 1]);
                 const int dpos = ma.y;
                 for (int k = mb.y; k < mb.y + mb.z; ++k) {        // pending updates of this column's diagonal block
                     if (lane < 36) {
@@ -861,22 +863,24 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                 // the other update triples of the previous level's columns (one ROW of a triple per
                 // thread) and their contribution to y, all columns flattened over the helper threads
                 const int h = tid - 64 * nc, hs = nth - 64 * nc;
-                int4 pA[kMaxLevelCols], pB[kMaxLevelCols];
-#pragma unroll
-                for (int q = 0; q < kMaxLevelCols; ++q) { pA[q] = lvl_meta[((l - 1) * kMaxLevelCols + q) * 2]; pB[q] = lvl_meta[((l - 1) * kMaxLevelCols + q) * 2 + 1]; }
+                const int4 *mp = lvl_meta + (size_t)(l - 1) * kMaxLevelCols * 2;
+                const int4 pA0 = uniform4(mp[0]), pA1 = uniform4(mp[2]), pA2 = uniform4(mp[4]), pA3 = uniform4(mp[6]);
+                const int nu0 = __builtin_amdgcn_readfirstlane(mp[1].x), nu1 = __builtin_amdgcn_readfirstlane(mp[3].x),
+                          nu2 = __builtin_amdgcn_readfirstlane(mp[5].x), nu3 = __builtin_amdgcn_readfirstlane(mp[7].x);
                 int items_before[kMaxLevelCols + 1];
                 items_before[0] = 0;
-#pragma unroll
-                for (int q = 0; q < kMaxLevelCols; ++q)
-                    items_before[q + 1] = items_before[q] + (pA[q].x >= 0 ? pB[q].x * 6 + pA[q].z * 6 : 0);
+                items_before[1] = pA0.x >= 0 ? nu0 * 6 + pA0.z * 6 : 0;
+                items_before[2] = items_before[1] + (pA1.x >= 0 ? nu1 * 6 + pA1.z * 6 : 0);
+                items_before[3] = items_before[2] + (pA2.x >= 0 ? nu2 * 6 + pA2.z * 6 : 0);
+                items_before[4] = items_before[3] + (pA3.x >= 0 ? nu3 * 6 + pA3.z * 6 : 0);
                 for (int item = h; item < items_before[kMaxLevelCols]; item += hs) {
                     int q = 0;
 #pragma unroll
                     for (int k = 1; k < kMaxLevelCols; ++k) q += item >= items_before[k] ? 1 : 0;
                     const int idx = item - (q == 0 ? 0 : q == 1 ? items_before[1] : q == 2 ? items_before[2] : items_before[3]);
-                    const int4 pa = q == 0 ? pA[0] : q == 1 ? pA[1] : q == 2 ? pA[2] : pA[3];
-                    const int4 pb = q == 0 ? pB[0] : q == 1 ? pB[1] : q == 2 ? pB[2] : pB[3];
-                    const int pj = pa.x, u0 = pa.w, nu = pb.x, dposp = pa.y;
+                    const int4 pa = q == 0 ? pA0 : q == 1 ? pA1 : q == 2 ? pA2 : pA3;
+                    const int nu = q == 0 ? nu0 : q == 1 ? nu1 : q == 2 ? nu2 : nu3;
+                    const int pj = pa.x, u0 = pa.w, dposp = pa.y;
                     if (idx < nu * 6) {
                         const int t = idx / 6;
                         apply_update_row(Lw, upd + 3 * (u0 + t), idx - 6 * t);
@@ -898,16 +902,19 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
             BT_PF(5);
             // ---- phase 2: block rows of the level's columns (and their y) by forward substitution
             {
+                const int4 mA0 = uniform4(ml[0]), mA1 = uniform4(ml[2]), mA2 = uniform4(ml[4]), mA3 = uniform4(ml[6]);
                 int rows_before[kMaxLevelCols + 1];
                 rows_before[0] = 0;
-#pragma unroll
-                for (int q = 0; q < kMaxLevelCols; ++q) rows_before[q + 1] = rows_before[q] + (mA[q].x >= 0 ? mA[q].z * 6 + 1 : 0);
+                rows_before[1] = mA0.x >= 0 ? mA0.z * 6 + 1 : 0;
+                rows_before[2] = rows_before[1] + (mA1.x >= 0 ? mA1.z * 6 + 1 : 0);
+                rows_before[3] = rows_before[2] + (mA2.x >= 0 ? mA2.z * 6 + 1 : 0);
+                rows_before[4] = rows_before[3] + (mA3.x >= 0 ? mA3.z * 6 + 1 : 0);
                 for (int item = tid; item < rows_before[kMaxLevelCols]; item += nth) {
                     int q = 0;
 #pragma unroll
                     for (int k = 1; k < kMaxLevelCols; ++k) q += item >= rows_before[k] ? 1 : 0;
                     const int rw = item - (q == 0 ? 0 : q == 1 ? rows_before[1] : q == 2 ? rows_before[2] : rows_before[3]);
-                    const int4 ma = q == 0 ? mA[0] : q == 1 ? mA[1] : q == 2 ? mA[2] : mA[3];
+                    const int4 ma = q == 0 ? mA0 : q == 1 ? mA1 : q == 2 ? mA2 : mA3;
                     const int j = ma.x, dpos = ma.y, cnt = ma.z;
                     T L[21];
                     const T *dblk = Lw + (size_t)dpos * 36;
@@ -992,7 +999,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
         // (c) x_j = zt_j - sum_{i>j} M_ij x_i, levels descending; one wave per column of the level,
         //     lane = (component c) * 8 + g
         for (int l = nlev - 1; l >= 0; --l) {
-            const int4 ma = lvl_meta[(l * kMaxLevelCols + (wave < kMaxLevelCols ? wave : 0)) * 2];
+            const int4 ma = uniform4(lvl_meta[(l * kMaxLevelCols + (wave < kMaxLevelCols ? wave : 0)) * 2]);
             if (wave < kMaxLevelCols && ma.x >= 0) {
                 const int c = lane >> 3, g = lane & 7;
                 const int j = ma.x, dpos = ma.y, cnt = ma.z;

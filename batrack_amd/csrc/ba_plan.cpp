@@ -447,6 +447,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             mrow[3] = pl->upd_ptr[(size_t)j] + pl->upd_next[(size_t)j];
             mrow[4] = pl->upd_ptr[(size_t)j + 1] - mrow[3];
             mrow[5] = pl->dp_ptr[(size_t)j]; mrow[6] = pl->dp_ptr[(size_t)j + 1] - pl->dp_ptr[(size_t)j];
+            mrow[7] = pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l];     // columns in this level
         }
 
     layout_workspace(pl);
