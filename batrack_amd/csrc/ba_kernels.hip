@@ -146,12 +146,13 @@ __device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) 
 // source-camera row is summed in registers and merged by an owner thread after the
 // barrier.  Only a duplicated (track, target camera) observation that straddles two
 // waves' chunks falls back to ds_add_f32.
-constexpr int kTileWaves = 8;
+constexpr int kTileWavesMax = 16;
 
 template <bool SO, bool PROF>
-__global__ __launch_bounds__(512) void k_tile(PlanDev pd, StepArgs a) {
+__global__ __launch_bounds__(1024) void k_tile(PlanDev pd, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nthr = blockDim.x, kTileWaves = nthr >> 6;          // 8 or 16 waves per tile (launch parameter)
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); tn = clock64(); pf[i] += tn - tc; tc = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
     const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
@@ -165,13 +166,13 @@ __global__ __launch_bounds__(512) void k_tile(PlanDev pd, StepArgs a) {
     {                                                              // relative pose of the tile's camera pairs
         const int np = pd.tile_npair[tile];
         const int *pl = pd.tile_pairs + pd.tile_pair0[tile];
-        for (int p = tid; p < np; p += 512) {
+        for (int p = tid; p < np; p += nthr) {
             const int gp = pl[p];
             pair_geometry(a.poses, a.intr, pd.pair_i[gp], pd.pair_j[gp], geo + p * kPairGeomFloats);
         }
     }
-    for (int i = tid; i < R16 * kLdsRowStride; i += 512) Eh[i] = 0.0f;
-    for (int i = tid; i < R16; i += 512) gidx[i] = i < R ? 6 * cams[i / 6] + i % 6 : -1;
+    for (int i = tid; i < R16 * kLdsRowStride; i += nthr) Eh[i] = 0.0f;
+    for (int i = tid; i < R16; i += nthr) gidx[i] = i < R ? 6 * cams[i / 6] + i % 6 : -1;
 
     const int trk = pd.tile_trk0[tile] + lane;
     const bool has_trk = lane < ntrk;
@@ -303,7 +304,6 @@ __global__ __launch_bounds__(512) void k_tile(PlanDev pd, StepArgs a) {
     }
     if (wave == 6) {                                                   // ba.py:296-311
         float C = 0.0f, wv = 0.0f;
-#pragma unroll
         for (int w = 0; w < kTileWaves; ++w) { C += stg[(w * 8 + 6) * 64 + lane]; wv += stg[(w * 8 + 7) * 64 + lane]; }
         float Q = 0.0f, wp = 0.0f;
         if (has_trk) {
@@ -1134,8 +1134,14 @@ __global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_p
 }
 
 // ------------------------------------------------------------------ launchers
+static int tile_threads() {
+    static const int t = std::getenv("BT_TILE_THREADS") ? std::atoi(std::getenv("BT_TILE_THREADS")) : 1024;   // measurement only
+    return t == 512 ? 512 : 1024;
+}
+
 static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     const size_t rows = so ? 0 : (size_t)pd.max_rows16;
+    const size_t kTileWaves = (size_t)tile_threads() / 64;
     return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 64 + rows +
             (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) + 64;
 }
@@ -1193,9 +1199,9 @@ int configure_kernels(const PlanDev &pd) {
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev) {
     (void)zero_doubles;   // the accumulators are cleared by their consumers (k_pair_finalize, k_solve_*)
     if (pd.T > 0) {
-        if (so)                BT_LAUNCH(1, (k_tile<true, false>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, true), pd, a);
-        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, false), pd, a);
-        else                   BT_LAUNCH(1, (k_tile<false, false>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, false), pd, a);
+        if (so)                BT_LAUNCH(1, (k_tile<true, false>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a);
+        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a);
+        else                   BT_LAUNCH(1, (k_tile<false, false>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a);
     }
     if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);
