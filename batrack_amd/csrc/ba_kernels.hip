@@ -190,16 +190,21 @@ __global__ __launch_bounds__(1024) void k_tile(PlanDev pd, StepArgs a) {
 
     float Cacc = 0.0f, wacc = 0.0f, Ei[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     unsigned la_cur = 0xffu;
+    // Target cameras this track also observes in the neighbouring waves' chunks right across the
+    // chunk boundary.  Observations of one (track, camera) are contiguous in slot order, so a run
+    // that continues into a neighbour's chunk is recognised by these two values; every slot of
+    // such a run must use LDS atomics (the neighbour updates the same element concurrently).
+    unsigned lb_prev = 0xffu, lb_next = 0xffu;
+    if (!SO && s0 < s1) {
+        if (s0 > 0) lb_prev = pd.slot_lab[(size_t)(slot0 + s0 - 1) * kLanes + lane] >> 8;
+        if (s1 < nslot) lb_next = pd.slot_lab[(size_t)(slot0 + s1) * kLanes + lane] >> 8;
+    }
     for (int s = s0; s < s1; ++s) {
         const size_t idx = (size_t)(slot0 + s) * kLanes + lane;
         const int e = pd.slot_edge[idx];
         const bool act = e >= 0;
         const int pair = pd.slot_pair[idx];
         const unsigned lab = pd.slot_lab[idx];
-        // a (track, target camera) observation duplicated into a neighbouring wave's chunk?
-        unsigned lab_nb = 0xffffu, lab_nb2 = 0xffffu;
-        if (!SO && s == s0 && s > 0) lab_nb = pd.slot_lab[idx - kLanes];
-        if (!SO && s == s1 - 1 && s + 1 < nslot) lab_nb2 = pd.slot_lab[idx + kLanes];
         float tu = 0.0f, tv = 0.0f, w0 = 0.0f, w1 = 0.0f;
         if (act) {
             const float *tp = a.targets + (size_t)e * a.tstride;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(1024) void k_tile(PlanDev pd, StepArgs a) {
         const unsigned la = lab & 0xffu, lb = lab >> 8;
         if (act && lb != 0xffu && !(a.dbg & 8)) {
             float *row = Eh + lb * 6 * kLdsRowStride + lane;
-            if (lb == (lab_nb >> 8) || lb == (lab_nb2 >> 8)) {
+            if (lb == lb_prev || lb == lb_next) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) atomicAdd(row + c * kLdsRowStride, Ej[c]);
             } else {
@@ -1135,8 +1140,10 @@ __global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_p
 
 // ------------------------------------------------------------------ launchers
 static int tile_threads() {
-    static const int t = std::getenv("BT_TILE_THREADS") ? std::atoi(std::getenv("BT_TILE_THREADS")) : 1024;   // measurement only
-    return t == 512 ? 512 : 1024;
+    // 8 waves per tile; 16 only on request (measurement): it shortens deep slot loops a little but
+    // halves the tiles resident per CU, which costs more on large graphs
+    static const int t = std::getenv("BT_TILE_THREADS") ? std::atoi(std::getenv("BT_TILE_THREADS")) : 512;
+    return t == 1024 ? 1024 : 512;
 }
 
 static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
