@@ -199,6 +199,22 @@ __global__ __launch_bounds__(1024) void k_tile(PlanDev pd, StepArgs a) {
         if (s0 > 0) lb_prev = pd.slot_lab[(size_t)(slot0 + s0 - 1) * kLanes + lane] >> 8;
         if (s1 < nslot) lb_next = pd.slot_lab[(size_t)(slot0 + s1) * kLanes + lane] >> 8;
     }
+    float Ejacc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned lb_acc = 0xffu;
+    auto flush_ej = [&](unsigned lbf) {
+        if (lbf != 0xffu && !(a.dbg & 8)) {
+            float *row = Eh + lbf * 6 * kLdsRowStride + lane;
+            if (lbf == lb_prev || lbf == lb_next) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) atomicAdd(row + c * kLdsRowStride, Ejacc[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) row[c * kLdsRowStride] += Ejacc[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Ejacc[c] = 0.0f;
+    };
     for (int s = s0; s < s1; ++s) {
         const size_t idx = (size_t)(slot0 + s) * kLanes + lane;
         const int e = pd.slot_edge[idx];
@@ -238,15 +254,15 @@ __global__ __launch_bounds__(1024) void k_tile(PlanDev pd, StepArgs a) {
         const float Ej[6] = { wa0 * q.jz0, wb1 * q.jz1, fmaf(wa2, q.jz0, wb2 * q.jz1), fmaf(wa3, q.jz0, wb3 * q.jz1),
                               fmaf(wa4, q.jz0, wb4 * q.jz1), fmaf(wa5, q.jz0, wb5 * q.jz1) };
         const unsigned la = lab & 0xffu, lb = lab >> 8;
-        if (act && lb != 0xffu && !(a.dbg & 8)) {
-            float *row = Eh + lb * 6 * kLdsRowStride + lane;
-            if (lb == lb_prev || lb == lb_next) {
+        // target-camera E: repeated observations of one (track, camera) are consecutive slots, so they
+        // are summed in registers and written once when the camera changes (or the chunk ends)
+        if (act && lb != lb_acc) {
+            flush_ej(lb_acc);
+            lb_acc = lb;
+        }
+        if (act && lb != 0xffu) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) atomicAdd(row + c * kLdsRowStride, Ej[c]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) row[c * kLdsRowStride] += Ej[c];
-            }
+            for (int c = 0; c < 6; ++c) Ejacc[c] += Ej[c];
         }
         if (act && la != 0xffu) {
             la_cur = la;                 // one source camera per track: enforced by the plan (ii = ix[kk], batrack.py:199)
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(1024) void k_tile(PlanDev pd, StepArgs a) {
         BT_PF(3);
     }
 
+    if (!SO) flush_ej(lb_acc);
     // per-wave partials -> LDS
 #pragma unroll
     for (int c = 0; c < 6; ++c) stg[(wave * 8 + c) * 64 + lane] = Ei[c];
