@@ -64,11 +64,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback)")
+    # BT_BENCH_BACKEND=gloo: test hook to run several ranks on ONE GPU (RCCL refuses duplicate devices)
+    backend = os.environ.get("BT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     g = graphgen.make_config(args.workload, seed=args.seed)
     f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
@@ -114,7 +121,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     status = stepper.status()
@@ -161,7 +168,7 @@ def main():
             for name, v in ms.items():
                 acc.setdefault(name, []).append(v)
         kern_us = {k: 1e3 * float(np.mean(v)) for k, v in acc.items()}
-        extra["kernel_us"] = {k: round(v, 3) for k, v in kern_us.items()}
+        extra["kernel_us"] = {k: round(v, 3) for k, v in kern_us.items() if v > 0}
         alg_bytes = 40 * plan.E + 20 * plan.m + 72 * plan.n_all        # SURVEY.md §8d, Jacobian kernel only
         tile_s = kern_us["tile"] * 1e-6
         achieved = alg_bytes / tile_s / 1e9 if tile_s > 0 else 0.0
