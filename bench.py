@@ -172,8 +172,16 @@ def main():
         alg_bytes = 40 * plan.E + 20 * plan.m + 72 * plan.n_all        # SURVEY.md §8d, Jacobian kernel only
         tile_s = kern_us["tile"] * 1e-6
         achieved = alg_bytes / tile_s / 1e9 if tile_s > 0 else 0.0
+        # HBM bytes per launch from the PMC passes (their own rocprofv3 runs, committed under profiles/)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_tile.json")))
+            if pmc.get(args.workload, {}).get("edges") == plan.E:
+                traffic = pmc[args.workload]["traffic_bytes"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes": alg_bytes, "kernel_us": round(kern_us["tile"], 3)}
 
         if not args.no_cpu_baseline:
