@@ -148,245 +148,312 @@ __device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) 
 // waves' chunks falls back to ds_add_f32.
 constexpr int kTileWavesMax = 16;
 
+constexpr int kTileAccMax = 16;  // Schur output tiles (16x16) a workgroup accumulates across tiles, in LDS (up to 13 cameras)
+
 template <bool SO, bool PROF>
-__global__ __launch_bounds__(1024) void k_tile(PlanDev pd, StepArgs a) {
+__global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthr = blockDim.x, kTileWaves = nthr >> 6;          // 8 or 16 waves per tile (launch parameter)
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); tn = clock64(); pf[i] += tn - tc; tc = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
-    const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
-    const int R = 6 * ncam, R16 = SO ? 0 : ((R + 1 + 15) >> 4) << 4;
-    float *Eh = lds, *stg = Eh + R16 * kLdsRowStride;
+    // LDS carve-up for the largest tile of the plan (fixed offsets: tiles of one workgroup differ in size)
+    const int R16max = SO ? 0 : pd.max_rows16;
+    float *Eh = lds, *stg = Eh + R16max * kLdsRowStride;
     int *las = reinterpret_cast<int *>(stg + kTileWaves * 8 * 64);
     float *Qs = reinterpret_cast<float *>(las + kTileWaves * 64);
     int *gidx = reinterpret_cast<int *>(Qs + 64);
-    float *geo = reinterpret_cast<float *>(gidx + R16);           // [npair][20], 16-byte aligned (R16 % 16 == 0)
-    const int *cams = pd.tile_cams + pd.tile_cam0[tile];
-    {                                                              // relative pose of the tile's camera pairs
-        const int np = pd.tile_npair[tile];
-        const int *pl = pd.tile_pairs + pd.tile_pair0[tile];
-        for (int p = tid; p < np; p += nthr) {
-            const int gp = pl[p];
-            pair_geometry(a.poses, a.intr, pd.pair_i[gp], pd.pair_j[gp], geo + p * kPairGeomFloats);
-        }
-    }
-    for (int i = tid; i < R16 * kLdsRowStride; i += nthr) Eh[i] = 0.0f;
-    for (int i = tid; i < R16; i += nthr) gidx[i] = i < R ? 6 * cams[i / 6] + i % 6 : -1;
-
-    const int trk = pd.tile_trk0[tile] + lane;
-    const bool has_trk = lane < ntrk;
-    int patch = 0;
-    float px = 0.0f, py = 0.0f, pdisp = 0.0f;
-    if (has_trk) {
-        patch = pd.kx[trk];
-        px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2];
-    }
-    const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
-    const int chunk = (nslot + kTileWaves - 1) / kTileWaves;
-    const int s0 = wave * chunk, s1 = min(nslot, s0 + chunk);
-    __syncthreads();
-    BT_PF(0);
-
-    float Cacc = 0.0f, wacc = 0.0f, Ei[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    unsigned la_cur = 0xffu;
-    // Target cameras this track also observes in the neighbouring waves' chunks right across the
-    // chunk boundary.  Observations of one (track, camera) are contiguous in slot order, so a run
-    // that continues into a neighbour's chunk is recognised by these two values; every slot of
-    // such a run must use LDS atomics (the neighbour updates the same element concurrently).
-    unsigned lb_prev = 0xffu, lb_next = 0xffu;
-    if (!SO && s0 < s1) {
-        if (s0 > 0) lb_prev = pd.slot_lab[(size_t)(slot0 + s0 - 1) * kLanes + lane] >> 8;
-        if (s1 < nslot) lb_next = pd.slot_lab[(size_t)(slot0 + s1) * kLanes + lane] >> 8;
-    }
-    float Ejacc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    unsigned lb_acc = 0xffu;
-    auto flush_ej = [&](unsigned lbf) {
-        if (lbf != 0xffu && !(a.dbg & 8)) {
-            float *row = Eh + lbf * 6 * kLdsRowStride + lane;
-            if (lbf == lb_prev || lbf == lb_next) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) atomicAdd(row + c * kLdsRowStride, Ejacc[c]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) row[c * kLdsRowStride] += Ejacc[c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) Ejacc[c] = 0.0f;
+    float *geo = reinterpret_cast<float *>(gidx + R16max);        // [npair][20], 16-byte aligned
+    // persistent accumulators: the Schur output tiles of the workgroup in LDS ([tile][reg][lane] doubles,
+    // each tile owned by one wave), and one per-pair sum per wave in registers
+    double *lacc = reinterpret_cast<double *>(geo + (size_t)pd.max_tile_pairs * kPairGeomFloats);
+    const int ntl_max = SO ? 0 : min(kTileAccMax, (R16max >> 4) * ((R16max >> 4) + 1) / 2);
+    for (int i = tid; i < ntl_max * 256; i += nthr) lacc[i] = 0.0;
+    bool sacc_live = false;
+    int Racc = 0;                      // 6 * cameras of the tiles accumulated in sacc
+    double pacc = 0.0;
+    int p_cur = -1;
+    auto flush_pair = [&]() {
+        const int vi = (lane >> 1) & 31;
+        if (p_cur >= 0 && (lane & 1) == 0 && vi < 27 && !(a.dbg & 2))
+            atomicAdd(&a.pairacc[(size_t)p_cur * kPairAccStride + vi], pacc);
+        pacc = 0.0; p_cur = -1;
     };
-    for (int s = s0; s < s1; ++s) {
-        const size_t idx = (size_t)(slot0 + s) * kLanes + lane;
-        const int e = pd.slot_edge[idx];
-        const bool act = e >= 0;
-        const int pair = pd.slot_pair[idx];
-        const unsigned lab = pd.slot_lab[idx];
-        float tu = 0.0f, tv = 0.0f, w0 = 0.0f, w1 = 0.0f;
-        if (act) {
-            const float *tp = a.targets + (size_t)e * a.tstride;
-            tu = tp[0]; tv = tp[1];
-            const float2 w = reinterpret_cast<const float2 *>(a.weights)[e];
-            w0 = w.x; w1 = w.y;
-        }
-        float g[kPairGeomFloats];
-        {
-            const float4 *g4 = reinterpret_cast<const float4 *>(geo + (size_t)pd.slot_lp[idx] * kPairGeomFloats);
+    auto flush_schur = [&]() {         // uses gidx of the tiles the accumulators belong to (still in LDS)
+        if (!sacc_live) return;
+        const int nt = ((Racc + 1 + 15) >> 4), ntl = nt * (nt + 1) / 2;
+        for (int t = wave; t < ntl; t += kTileWaves) {
+            int ti = 0, base = 0;
+            while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
+            const int tj = t - base;
+            // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+            const int gc = gidx[16 * tj + (lane & 15)];
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                const float4 t4 = g4[c];
-                g[4*c] = t4.x; g[4*c + 1] = t4.y; g[4*c + 2] = t4.z; g[4*c + 3] = t4.w;
-            }
-        }
-        if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        BT_PF(1);
-        EdgeQ q;
-        edge_eval(g, px, py, pdisp, tu, tv, w0, w1, a, q);
-        if (!act) { q.W0 = 0.0f; q.W1 = 0.0f; q.r0 = 0.0f; q.r1 = 0.0f; }
-
-        // C, w of the track (ba.py:287,292)
-        Cacc += q.W0 * q.jz0 * q.jz0 + q.W1 * q.jz1 * q.jz1;
-        wacc += q.W0 * q.jz0 * q.r0 + q.W1 * q.jz1 * q.r1;
-        if (SO) continue;
-
-        const float wa0 = q.W0 * q.a0, wa2 = q.W0 * q.a2, wa3 = q.W0 * q.a3, wa4 = q.W0 * q.a4, wa5 = q.W0 * q.a5;
-        const float wb1 = q.W1 * q.b1, wb2 = q.W1 * q.b2, wb3 = q.W1 * q.b3, wb4 = q.W1 * q.b4, wb5 = q.W1 * q.b5;
-        // Ej = Jj^T W Jz (ba.py:263) and Ei = -Ad^T Ej
-        const float Ej[6] = { wa0 * q.jz0, wb1 * q.jz1, fmaf(wa2, q.jz0, wb2 * q.jz1), fmaf(wa3, q.jz0, wb3 * q.jz1),
-                              fmaf(wa4, q.jz0, wb4 * q.jz1), fmaf(wa5, q.jz0, wb5 * q.jz1) };
-        const unsigned la = lab & 0xffu, lb = lab >> 8;
-        // target-camera E: repeated observations of one (track, camera) are consecutive slots, so they
-        // are summed in registers and written once when the camera changes (or the chunk ends)
-        if (act && lb != lb_acc) {
-            flush_ej(lb_acc);
-            lb_acc = lb;
-        }
-        if (act && lb != 0xffu) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) Ejacc[c] += Ej[c];
-        }
-        if (act && la != 0xffu) {
-            la_cur = la;                 // one source camera per track: enforced by the plan (ii = ix[kk], batrack.py:199)
-            // o_tau = R^T e_tau ; o_phi = R^T (e_tau x t + e_phi)      (se3.h:58-67)
-            const float cx = Ej[1]*g[11] - Ej[2]*g[10] + Ej[3];
-            const float cy = Ej[2]*g[9]  - Ej[0]*g[11] + Ej[4];
-            const float cz = Ej[0]*g[10] - Ej[1]*g[9]  + Ej[5];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                Ei[c]     -= g[c]*Ej[0] + g[3 + c]*Ej[1] + g[6 + c]*Ej[2];
-                Ei[3 + c] -= g[c]*cx + g[3 + c]*cy + g[6 + c]*cz;
-            }
-        }
-        BT_PF(2);
-
-        // per-pair sums: Bjj (21, row-major upper triangle) and gj (6)   (ba.py:260,266)
-        float vals[32];
-        vals[0] = wa0 * q.a0;  vals[1] = 0.0f;        vals[2] = wa0 * q.a2;  vals[3] = wa0 * q.a3;
-        vals[4] = wa0 * q.a4;  vals[5] = wa0 * q.a5;
-        vals[6] = wb1 * q.b1;  vals[7] = wb1 * q.b2;  vals[8] = wb1 * q.b3;  vals[9] = wb1 * q.b4;  vals[10] = wb1 * q.b5;
-        vals[11] = fmaf(wa2, q.a2, wb2 * q.b2); vals[12] = fmaf(wa2, q.a3, wb2 * q.b3);
-        vals[13] = fmaf(wa2, q.a4, wb2 * q.b4); vals[14] = fmaf(wa2, q.a5, wb2 * q.b5);
-        vals[15] = fmaf(wa3, q.a3, wb3 * q.b3); vals[16] = fmaf(wa3, q.a4, wb3 * q.b4); vals[17] = fmaf(wa3, q.a5, wb3 * q.b5);
-        vals[18] = fmaf(wa4, q.a4, wb4 * q.b4); vals[19] = fmaf(wa4, q.a5, wb4 * q.b5);
-        vals[20] = fmaf(wa5, q.a5, wb5 * q.b5);
-        vals[21] = wa0 * q.r0; vals[22] = wb1 * q.r1;
-        vals[23] = fmaf(wa2, q.r0, wb2 * q.r1); vals[24] = fmaf(wa3, q.r0, wb3 * q.r1);
-        vals[25] = fmaf(wa4, q.r0, wb4 * q.r1); vals[26] = fmaf(wa5, q.r0, wb5 * q.r1);
-        vals[27] = vals[28] = vals[29] = vals[30] = vals[31] = 0.0f;
-
-        unsigned long long todo = __ballot(act);
-        while (todo) {                              // one pass per distinct pair in this slot
-            const int leader = __ffsll((long long)todo) - 1;
-            const int p0 = __shfl(pair, leader);
-            const bool mine = act && pair == p0;
-            float v[32];
-#pragma unroll
-            for (int c = 0; c < 32; ++c) v[c] = mine ? vals[c] : 0.0f;
-            wave_reduce_scatter32(v, lane);
-            const int vi = (lane >> 1) & 31;
-            if ((lane & 1) == 0 && vi < 27 && !(a.dbg & 2))
-                atomicAdd(&a.pairacc[(size_t)p0 * kPairAccStride + vi], (double)v[0]);
-            todo &= ~__ballot(mine);
-        }
-        BT_PF(3);
-    }
-
-    if (!SO) flush_ej(lb_acc);
-    // per-wave partials -> LDS
-#pragma unroll
-    for (int c = 0; c < 6; ++c) stg[(wave * 8 + c) * 64 + lane] = Ei[c];
-    stg[(wave * 8 + 6) * 64 + lane] = Cacc;
-    stg[(wave * 8 + 7) * 64 + lane] = wacc;
-    las[wave * 64 + lane] = (int)la_cur;
-    __syncthreads();
-    if (!SO && wave < 6) {                          // owner of component `wave` of every track's source-camera E
-        for (int w = 0; w < kTileWaves; ++w) {
-            const int lw = las[w * 64 + lane];
-            if (lw != 0xff) Eh[(lw * 6 + wave) * kLdsRowStride + lane] += stg[(w * 8 + wave) * 64 + lane];
-        }
-    }
-    if (wave == 6) {                                                   // ba.py:296-311
-        float C = 0.0f, wv = 0.0f;
-        for (int w = 0; w < kTileWaves; ++w) { C += stg[(w * 8 + 6) * 64 + lane]; wv += stg[(w * 8 + 7) * 64 + lane]; }
-        float Q = 0.0f, wp = 0.0f;
-        if (has_trk) {
-            const float mono = a.mono[patch];
-            const float pm = mono > 1e-2f ? 1.0f : 0.0f;
-            float Ca = C + pm * a.alpha;
-            Ca = Ca + a.lmbda;
-            wp = wv - pm * a.alpha * (pdisp - mono);
-            Q = 1.0f / Ca;
-            a.qw[trk] = make_float2(Q, wp);
-        }
-        if (!SO) { Qs[lane] = Q; Eh[R * kLdsRowStride + lane] = wp; }
-    }
-    if (SO) return;
-    __syncthreads();
-    BT_PF(4);
-
-    // keep E for the depth back-substitution (ba.py:328)
-    for (int row = wave; row < R; row += kTileWaves)
-        a.esave[((size_t)pd.tile_erow0[tile] + row) * kLanes + lane] = Eh[row * kLdsRowStride + lane];
-    BT_PF(5);
-
-    // Schur product of the tile on the matrix cores: out[i][j] = sum_k Q_k Eh[i][k] Eh[j][k]
-    // over the 64 tracks; row R gives E Q w'.  f64 MFMA: the fp32 products are exact in
-    // double, so the 64-term sums carry no fp32 accumulation error (DESIGN.md "precision").
-    const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
-    for (int t = wave; t < ntl && !(a.dbg & 4); t += kTileWaves) {
-        int ti = 0, base = 0;
-        while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
-        const int tj = t - base;
-        const float *ar = Eh + (16 * ti + (lane & 15)) * kLdsRowStride + (lane >> 4);
-        const float *br = Eh + (16 * tj + (lane & 15)) * kLdsRowStride + (lane >> 4);
-        const float *qr = Qs + (lane >> 4);
-        float av[16], bv[16], qv[16];
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) { av[ks] = ar[4 * ks]; bv[ks] = br[4 * ks]; qv[ks] = qr[4 * ks]; }
-        double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks] * (double)qv[ks], (double)bv[ks], acc, 0, 0, 0);
-        BT_PF(6);
-        // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-        const int gc = gidx[16 * tj + (lane & 15)];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * ti + (lane >> 4) + 4 * r;
-            if (gc >= 0 && row <= R && !(a.dbg & 1)) {
-                if (row == R) {
-                    atomicAdd(&a.y[gc], -acc[r]);
-                } else {
-                    const int gr = gidx[row];
-                    if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]);
+            for (int r = 0; r < 4; ++r) {
+                double *slot = lacc + (size_t)(t * 4 + r) * 64 + lane;
+                const double val = *slot;
+                *slot = 0.0;
+                const int row = 16 * ti + (lane >> 4) + 4 * r;
+                if (gc >= 0 && row <= Racc && !(a.dbg & 1)) {
+                    if (row == Racc) {
+                        atomicAdd(&a.y[gc], -val);
+                    } else {
+                        const int gr = gidx[row];
+                        if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -val);
+                    }
                 }
             }
         }
+        sacc_live = false;
+    };
+
+    const int tile_begin = blockIdx.x * tiles_per_wg, tile_end = min(pd.T, tile_begin + tiles_per_wg);
+#pragma unroll 1
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int flags = tile == tile_begin ? 0 : pd.tile_flags[tile];
+        const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
+        const int R = 6 * ncam, R16 = SO ? 0 : ((R + 1 + 15) >> 4) << 4;
+        const int *cams = pd.tile_cams + pd.tile_cam0[tile];
+        if (!SO && !(flags & 1)) {                                 // other cameras: emit what was accumulated, new row map
+            flush_schur();
+            __syncthreads();
+            for (int i = tid; i < R16max; i += nthr) gidx[i] = i < R ? 6 * cams[i / 6] + i % 6 : -1;
+        }
+        if (!(flags & 2)) {                                        // relative pose of the tile's camera pairs
+            const int np = pd.tile_npair[tile];
+            const int *pl = pd.tile_pairs + pd.tile_pair0[tile];
+            for (int p = tid; p < np; p += nthr) {
+                const int gp = pl[p];
+                pair_geometry(a.poses, a.intr, pd.pair_i[gp], pd.pair_j[gp], geo + p * kPairGeomFloats);
+            }
+        }
+        for (int i = tid; i < R16 * kLdsRowStride; i += nthr) Eh[i] = 0.0f;
+
+        const int trk = pd.tile_trk0[tile] + lane;
+        const bool has_trk = lane < ntrk;
+        int patch = 0;
+        float px = 0.0f, py = 0.0f, pdisp = 0.0f;
+        if (has_trk) {
+            patch = pd.kx[trk];
+            px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2];
+        }
+        const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
+        const int chunk = (nslot + kTileWaves - 1) / kTileWaves;
+        const int s0 = wave * chunk, s1 = min(nslot, s0 + chunk);
+        __syncthreads();
+        BT_PF(0);
+
+        float Cacc = 0.0f, wacc = 0.0f, Ei[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        unsigned la_cur = 0xffu;
+        // Target cameras this track also observes in the neighbouring waves' chunks right across the
+        // chunk boundary.  Observations of one (track, camera) are contiguous in slot order, so a run
+        // that continues into a neighbour's chunk is recognised by these two values; every slot of
+        // such a run must use LDS atomics (the neighbour updates the same element concurrently).
+        unsigned lb_prev = 0xffu, lb_next = 0xffu;
+        if (!SO && s0 < s1) {
+            if (s0 > 0) lb_prev = pd.slot_lab[(size_t)(slot0 + s0 - 1) * kLanes + lane] >> 8;
+            if (s1 < nslot) lb_next = pd.slot_lab[(size_t)(slot0 + s1) * kLanes + lane] >> 8;
+        }
+        float Ejacc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        unsigned lb_acc = 0xffu;
+        auto flush_ej = [&](unsigned lbf) {
+            if (lbf != 0xffu && !(a.dbg & 8)) {
+                float *row = Eh + lbf * 6 * kLdsRowStride + lane;
+                if (lbf == lb_prev || lbf == lb_next) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) atomicAdd(row + c * kLdsRowStride, Ejacc[c]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) row[c * kLdsRowStride] += Ejacc[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Ejacc[c] = 0.0f;
+        };
+#pragma unroll 1
+        for (int s = s0; s < s1; ++s) {
+            const size_t idx = (size_t)(slot0 + s) * kLanes + lane;
+            const int e = pd.slot_edge[idx];
+            const bool act = e >= 0;
+            const int pair = pd.slot_pair[idx];
+            const unsigned lab = pd.slot_lab[idx];
+            float tu = 0.0f, tv = 0.0f, w0 = 0.0f, w1 = 0.0f;
+            if (act) {
+                const float *tp = a.targets + (size_t)e * a.tstride;
+                tu = tp[0]; tv = tp[1];
+                const float2 w = reinterpret_cast<const float2 *>(a.weights)[e];
+                w0 = w.x; w1 = w.y;
+            }
+            float g[kPairGeomFloats];
+            {
+                const float4 *g4 = reinterpret_cast<const float4 *>(geo + (size_t)pd.slot_lp[idx] * kPairGeomFloats);
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const float4 t4 = g4[c];
+                    g[4*c] = t4.x; g[4*c + 1] = t4.y; g[4*c + 2] = t4.z; g[4*c + 3] = t4.w;
+                }
+            }
+            if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            BT_PF(1);
+            EdgeQ q;
+            edge_eval(g, px, py, pdisp, tu, tv, w0, w1, a, q);
+            if (!act) { q.W0 = 0.0f; q.W1 = 0.0f; q.r0 = 0.0f; q.r1 = 0.0f; }
+
+            // C, w of the track (ba.py:287,292)
+            Cacc += q.W0 * q.jz0 * q.jz0 + q.W1 * q.jz1 * q.jz1;
+            wacc += q.W0 * q.jz0 * q.r0 + q.W1 * q.jz1 * q.r1;
+            if (SO) continue;
+
+            const float wa0 = q.W0 * q.a0, wa2 = q.W0 * q.a2, wa3 = q.W0 * q.a3, wa4 = q.W0 * q.a4, wa5 = q.W0 * q.a5;
+            const float wb1 = q.W1 * q.b1, wb2 = q.W1 * q.b2, wb3 = q.W1 * q.b3, wb4 = q.W1 * q.b4, wb5 = q.W1 * q.b5;
+            // Ej = Jj^T W Jz (ba.py:263) and Ei = -Ad^T Ej
+            const float Ej[6] = { wa0 * q.jz0, wb1 * q.jz1, fmaf(wa2, q.jz0, wb2 * q.jz1), fmaf(wa3, q.jz0, wb3 * q.jz1),
+                                  fmaf(wa4, q.jz0, wb4 * q.jz1), fmaf(wa5, q.jz0, wb5 * q.jz1) };
+            const unsigned la = lab & 0xffu, lb = lab >> 8;
+            // target-camera E: repeated observations of one (track, camera) are consecutive slots, so they
+            // are summed in registers and written once when the camera changes (or the chunk ends)
+            if (act && lb != lb_acc) {
+                flush_ej(lb_acc);
+                lb_acc = lb;
+            }
+            if (act && lb != 0xffu) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Ejacc[c] += Ej[c];
+            }
+            if (act && la != 0xffu) {
+                la_cur = la;                 // one source camera per track: enforced by the plan (ii = ix[kk], batrack.py:199)
+                // o_tau = R^T e_tau ; o_phi = R^T (e_tau x t + e_phi)      (se3.h:58-67)
+                const float cx = Ej[1]*g[11] - Ej[2]*g[10] + Ej[3];
+                const float cy = Ej[2]*g[9]  - Ej[0]*g[11] + Ej[4];
+                const float cz = Ej[0]*g[10] - Ej[1]*g[9]  + Ej[5];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    Ei[c]     -= g[c]*Ej[0] + g[3 + c]*Ej[1] + g[6 + c]*Ej[2];
+                    Ei[3 + c] -= g[c]*cx + g[3 + c]*cy + g[6 + c]*cz;
+                }
+            }
+            BT_PF(2);
+
+            // per-pair sums: Bjj (21, row-major upper triangle) and gj (6)   (ba.py:260,266).  The 27
+            // products are formed inside the loop (one pass per distinct pair of the slot, a single
+            // pass on regular graphs) so that no second copy of them stays live.
+            unsigned long long todo = __ballot(act);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int p0 = __shfl(pair, leader);
+                const float m = (act && pair == p0) ? 1.0f : 0.0f;
+                const float ma0 = m * wa0, mb1 = m * wb1, ma2 = m * wa2, mb2 = m * wb2, ma3 = m * wa3, mb3 = m * wb3,
+                            ma4 = m * wa4, mb4 = m * wb4, ma5 = m * wa5, mb5 = m * wb5;
+                float v[32];
+                v[0] = ma0 * q.a0;  v[1] = 0.0f;        v[2] = ma0 * q.a2;  v[3] = ma0 * q.a3;
+                v[4] = ma0 * q.a4;  v[5] = ma0 * q.a5;
+                v[6] = mb1 * q.b1;  v[7] = mb1 * q.b2;  v[8] = mb1 * q.b3;  v[9] = mb1 * q.b4;  v[10] = mb1 * q.b5;
+                v[11] = fmaf(ma2, q.a2, mb2 * q.b2); v[12] = fmaf(ma2, q.a3, mb2 * q.b3);
+                v[13] = fmaf(ma2, q.a4, mb2 * q.b4); v[14] = fmaf(ma2, q.a5, mb2 * q.b5);
+                v[15] = fmaf(ma3, q.a3, mb3 * q.b3); v[16] = fmaf(ma3, q.a4, mb3 * q.b4); v[17] = fmaf(ma3, q.a5, mb3 * q.b5);
+                v[18] = fmaf(ma4, q.a4, mb4 * q.b4); v[19] = fmaf(ma4, q.a5, mb4 * q.b5);
+                v[20] = fmaf(ma5, q.a5, mb5 * q.b5);
+                v[21] = ma0 * q.r0; v[22] = mb1 * q.r1;
+                v[23] = fmaf(ma2, q.r0, mb2 * q.r1); v[24] = fmaf(ma3, q.r0, mb3 * q.r1);
+                v[25] = fmaf(ma4, q.r0, mb4 * q.r1); v[26] = fmaf(ma5, q.r0, mb5 * q.r1);
+                v[27] = v[28] = v[29] = v[30] = v[31] = 0.0f;
+                wave_reduce_scatter32(v, lane);
+                if (p0 != p_cur) { flush_pair(); p_cur = p0; }   // same pair as this wave's previous slot / tile: keep summing
+                pacc += (double)v[0];
+                todo &= ~__ballot(act && pair == p0);
+            }
+            BT_PF(3);
+        }
+        if (!SO) flush_ej(lb_acc);
+
+        // per-wave partials -> LDS
+#pragma unroll
+        for (int c = 0; c < 6; ++c) stg[(wave * 8 + c) * 64 + lane] = Ei[c];
+        stg[(wave * 8 + 6) * 64 + lane] = Cacc;
+        stg[(wave * 8 + 7) * 64 + lane] = wacc;
+        las[wave * 64 + lane] = (int)la_cur;
+        __syncthreads();
+        if (!SO && wave < 6) {                          // owner of component `wave` of every track's source-camera E
+            for (int w = 0; w < kTileWaves; ++w) {
+                const int lw = las[w * 64 + lane];
+                if (lw != 0xff) Eh[(lw * 6 + wave) * kLdsRowStride + lane] += stg[(w * 8 + wave) * 64 + lane];
+            }
+        }
+        if (wave == 6) {                                                   // ba.py:296-311
+            float C = 0.0f, wv = 0.0f;
+            for (int w = 0; w < kTileWaves; ++w) { C += stg[(w * 8 + 6) * 64 + lane]; wv += stg[(w * 8 + 7) * 64 + lane]; }
+            float Q = 0.0f, wp = 0.0f;
+            if (has_trk) {
+                const float mono = a.mono[patch];
+                const float pm = mono > 1e-2f ? 1.0f : 0.0f;
+                float Ca = C + pm * a.alpha;
+                Ca = Ca + a.lmbda;
+                wp = wv - pm * a.alpha * (pdisp - mono);
+                Q = 1.0f / Ca;
+                a.qw[trk] = make_float2(Q, wp);
+            }
+            if (!SO) { Qs[lane] = Q; Eh[R * kLdsRowStride + lane] = wp; }
+        }
+        __syncthreads();
+        BT_PF(4);
+        if (SO) continue;
+
+        // keep E for the depth back-substitution (ba.py:328)
+        for (int row = wave; row < R; row += kTileWaves)
+            a.esave[((size_t)pd.tile_erow0[tile] + row) * kLanes + lane] = Eh[row * kLdsRowStride + lane];
+        BT_PF(5);
+
+        // Schur product of the tile on the matrix cores: out[i][j] += sum_k Q_k Eh[i][k] Eh[j][k]
+        // over the 64 tracks; row R gives E Q w'.  f64 MFMA: the fp32 products are exact in
+        // double, so the sums carry no fp32 accumulation error (DESIGN.md "precision").  The
+        // accumulators stay in registers across consecutive tiles with the same cameras.
+        const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
+        const bool keep = ntl <= ntl_max;           // else: more output tiles than LDS accumulators, emit per tile
+        for (int t = wave; t < ntl && !(a.dbg & 4); t += kTileWaves) {
+            int ti = 0, base = 0;
+            while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
+            const int tj = t - base;
+            const float *ar = Eh + (16 * ti + (lane & 15)) * kLdsRowStride + (lane >> 4);
+            const float *br = Eh + (16 * tj + (lane & 15)) * kLdsRowStride + (lane >> 4);
+            const float *qr = Qs + (lane >> 4);
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int quarter = 0; quarter < 4; ++quarter) {
+                float av[4], bv[4], qv[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) { av[ks] = ar[4 * (4 * quarter + ks)]; bv[ks] = br[4 * (4 * quarter + ks)]; qv[ks] = qr[4 * (4 * quarter + ks)]; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks] * (double)qv[ks], (double)bv[ks], acc, 0, 0, 0);
+            }
+            if (keep) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lacc[(size_t)(t * 4 + r) * 64 + lane] += acc[r];
+            } else {
+                const int gc = gidx[16 * tj + (lane & 15)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + (lane >> 4) + 4 * r;
+                    if (gc >= 0 && row <= R && !(a.dbg & 1)) {
+                        if (row == R) atomicAdd(&a.y[gc], -acc[r]);
+                        else { const int gr = gidx[row]; if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]); }
+                    }
+                }
+            }
+        }
+        if (keep) { sacc_live = true; Racc = R; }
+        BT_PF(6);
+        __syncthreads();            // the next tile of this workgroup reuses Eh / stg
+    }
+    if (!SO) {
+        flush_pair();
+        flush_schur();
         BT_PF(7);
     }
-    if (PROF && lane == 0 && wave == 0 && (tile == 0 || tile == pd.T / 2)) {
+    if (PROF && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BT_PF(8);
-        long long *o = reinterpret_cast<long long *>(a.status + 4) + (tile == 0 ? 20 : 30);
+        long long *o = reinterpret_cast<long long *>(a.status + 4) + (blockIdx.x == 0 ? 20 : 30);
         for (int i = 0; i < 10; ++i) o[i] = pf[i];
     }
 #undef BT_PF
@@ -1159,15 +1226,15 @@ __global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_p
 static int tile_threads() {
     // 8 waves per tile; 16 only on request (measurement): it shortens deep slot loops a little but
     // halves the tiles resident per CU, which costs more on large graphs
-    static const int t = std::getenv("BT_TILE_THREADS") ? std::atoi(std::getenv("BT_TILE_THREADS")) : 512;
-    return t == 1024 ? 1024 : 512;
+    return 512;
 }
 
 static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     const size_t rows = so ? 0 : (size_t)pd.max_rows16;
     const size_t kTileWaves = (size_t)tile_threads() / 64;
+    const size_t nt = rows / 16, ntl = nt * (nt + 1) / 2;
     return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 64 + rows +
-            (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) + 64;
+            (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) + (ntl < 16 ? ntl : 16) * 2048 + 64;
 }
 
 constexpr size_t kLdsBudget = 160 * 1024 - 512;
@@ -1223,9 +1290,13 @@ int configure_kernels(const PlanDev &pd) {
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev) {
     (void)zero_doubles;   // the accumulators are cleared by their consumers (k_pair_finalize, k_solve_*)
     if (pd.T > 0) {
-        if (so)                BT_LAUNCH(1, (k_tile<true, false>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a);
-        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a);
-        else                   BT_LAUNCH(1, (k_tile<false, false>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a);
+        // persistent workgroups once there are more tiles than ~4 per CU: a workgroup then walks a
+        // contiguous range of tiles and keeps its accumulators across tiles with the same cameras
+        static const int max_wgs = std::getenv("BT_TILE_MAX_WGS") ? std::atoi(std::getenv("BT_TILE_MAX_WGS")) : 1024;   // measurement only
+        const int tpw = (pd.T + max_wgs - 1) / max_wgs, nwg = (pd.T + tpw - 1) / tpw;
+        if (so)                BT_LAUNCH(1, (k_tile<true, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
+        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
+        else                   BT_LAUNCH(1, (k_tile<false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
     }
     if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);

@@ -209,6 +209,21 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     }
 
+    // consecutive tiles with identical camera / pair lists: a persistent workgroup keeps its
+    // accumulators across them
+    pl->tile_flags.assign((size_t)T, 0);
+    for (int32_t t = 1; t < T; ++t) {
+        const int32_t nc = pl->tile_ncam[(size_t)t], np2 = pl->tile_npair[(size_t)t];
+        if (nc == pl->tile_ncam[(size_t)t - 1] &&
+            std::equal(pl->tile_cams.begin() + pl->tile_cam0[(size_t)t], pl->tile_cams.begin() + pl->tile_cam0[(size_t)t] + nc,
+                       pl->tile_cams.begin() + pl->tile_cam0[(size_t)t - 1]))
+            pl->tile_flags[(size_t)t] |= 1;
+        if (np2 == pl->tile_npair[(size_t)t - 1] &&
+            std::equal(pl->tile_pairs.begin() + pl->tile_pair0[(size_t)t], pl->tile_pairs.begin() + pl->tile_pair0[(size_t)t] + np2,
+                       pl->tile_pairs.begin() + pl->tile_pair0[(size_t)t - 1]))
+            pl->tile_flags[(size_t)t] |= 2;
+    }
+
     // ---- block structure of S (lower) and symbolic Cholesky ----------------
     // S[u][v] (u >= v) may be non-zero if u and v share a tile (Schur term,
     // ba.py:321) or form a camera pair with both ends free (B, ba.py:279-282).
