@@ -150,7 +150,10 @@ constexpr int kTileWavesMax = 16;
 
 constexpr int kTileAccMax = 16;  // Schur output tiles (16x16) a workgroup accumulates across tiles, in LDS (up to 13 cameras)
 
-template <bool SO, bool PROF>
+// PERSIST = false: one tile per workgroup (graphs with up to ~1024 tiles, e.g. the 64-KF / 131k-edge
+// benchmark): no cross-tile state, Schur tiles go straight from the MFMA registers to the atomics.
+// PERSIST = true: a workgroup walks tiles_per_wg consecutive tiles and keeps its accumulators.
+template <bool SO, bool PROF, bool PERSIST>
 __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
     // persistent accumulators: the Schur output tiles of the workgroup in LDS ([tile][reg][lane] doubles,
     // each tile owned by one wave), and one per-pair sum per wave in registers
     double *lacc = reinterpret_cast<double *>(geo + (size_t)pd.max_tile_pairs * kPairGeomFloats);
-    const int ntl_max = SO ? 0 : min(kTileAccMax, (R16max >> 4) * ((R16max >> 4) + 1) / 2);
+    const int ntl_max = (SO || !PERSIST) ? 0 : min(kTileAccMax, (R16max >> 4) * ((R16max >> 4) + 1) / 2);
     for (int i = tid; i < ntl_max * 256; i += nthr) lacc[i] = 0.0;
     bool sacc_live = false;
     int Racc = 0;                      // 6 * cameras of the tiles accumulated in sacc
@@ -207,7 +210,8 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
         sacc_live = false;
     };
 
-    const int tile_begin = blockIdx.x * tiles_per_wg, tile_end = min(pd.T, tile_begin + tiles_per_wg);
+    const int tile_begin = PERSIST ? blockIdx.x * tiles_per_wg : blockIdx.x;
+    const int tile_end = PERSIST ? min(pd.T, tile_begin + tiles_per_wg) : tile_begin + 1;
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int flags = tile == tile_begin ? 0 : pd.tile_flags[tile];
@@ -417,13 +421,22 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
             const float *br = Eh + (16 * tj + (lane & 15)) * kLdsRowStride + (lane >> 4);
             const float *qr = Qs + (lane >> 4);
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (PERSIST) {
 #pragma unroll 1
-            for (int quarter = 0; quarter < 4; ++quarter) {
-                float av[4], bv[4], qv[4];
+                for (int quarter = 0; quarter < 4; ++quarter) {
+                    float av[4], bv[4], qv[4];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) { av[ks] = ar[4 * (4 * quarter + ks)]; bv[ks] = br[4 * (4 * quarter + ks)]; qv[ks] = qr[4 * (4 * quarter + ks)]; }
+                    for (int ks = 0; ks < 4; ++ks) { av[ks] = ar[4 * (4 * quarter + ks)]; bv[ks] = br[4 * (4 * quarter + ks)]; qv[ks] = qr[4 * (4 * quarter + ks)]; }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                    for (int ks = 0; ks < 4; ++ks)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks] * (double)qv[ks], (double)bv[ks], acc, 0, 0, 0);
+                }
+            } else {
+                float av[16], bv[16], qv[16];
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) { av[ks] = ar[4 * ks]; bv[ks] = br[4 * ks]; qv[ks] = qr[4 * ks]; }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks] * (double)qv[ks], (double)bv[ks], acc, 0, 0, 0);
             }
             if (keep) {
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
         }
         if (keep) { sacc_live = true; Racc = R; }
         BT_PF(6);
-        __syncthreads();            // the next tile of this workgroup reuses Eh / stg
+        if (PERSIST) __syncthreads();            // the next tile of this workgroup reuses Eh / stg
     }
     if (!SO) {
         flush_pair();
@@ -1258,9 +1271,11 @@ int configure_kernels(const PlanDev &pd) {
     const size_t need = tile_lds_bytes(pd, false);
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
     if (need > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, true>),
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)
             return BT_EHIP;
     }
@@ -1294,9 +1309,11 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         // contiguous range of tiles and keeps its accumulators across tiles with the same cameras
         static const int max_wgs = std::getenv("BT_TILE_MAX_WGS") ? std::atoi(std::getenv("BT_TILE_MAX_WGS")) : 1024;   // measurement only
         const int tpw = (pd.T + max_wgs - 1) / max_wgs, nwg = (pd.T + tpw - 1) / tpw;
-        if (so)                BT_LAUNCH(1, (k_tile<true, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
-        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
-        else                   BT_LAUNCH(1, (k_tile<false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
+        if (so && tpw == 1)    BT_LAUNCH(1, (k_tile<true, false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
+        else if (so)           BT_LAUNCH(1, (k_tile<true, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
+        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true, false>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, 1);
+        else if (tpw == 1)     BT_LAUNCH(1, (k_tile<false, false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
+        else                   BT_LAUNCH(1, (k_tile<false, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
     }
     if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);
