@@ -922,6 +922,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
             const int nc = __builtin_amdgcn_readfirstlane(ml[1].w);
             // ---- phase 1
             if (wave < nc) {
+                __builtin_amdgcn_s_setprio(3);            // the critical path of the level: win issue arbitration on this SIMD
                 const int4 ma = uniform4(ml[2 * wave]), mb = uniform4(ml[2 * wave + 1]);
                 const int dpos = ma.y;
                 for (int k = mb.y; k < mb.y + mb.z; ++k) {        // pending updates of this column's diagonal block
@@ -961,6 +962,7 @@ __global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
                     }
                 }
                 BT_PF(4);
+                __builtin_amdgcn_s_setprio(0);
             } else if (l > 0) {
                 // the other update triples of the previous level's columns (one ROW of a triple per
                 // thread) and their contribution to y, all columns flattened over the helper threads
