@@ -810,26 +810,27 @@ template <typename T> __device__ __forceinline__ void lds_sub(T *p, T v, bool at
 // updated by another column of the same level -> LDS atomics.
 template <typename T>
 __device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr, int r) {
-    T a[6], o[6];
-    load_row6(Lw + (size_t)tr[0] * 36 + 6 * r, a);
-    const T *bb = Lw + (size_t)tr[1] * 36;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        T b[6];
-        load_row6(bb + 6 * c, b);
-        T acc = a[0] * b[0];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) acc += a[k] * b[k];
-        o[c] = acc;
-    }
+    T a[6], b[36], o[6], v[6];
     const unsigned d = tr[2];
     T *dst = Lw + (size_t)(d & 0x7fffu) * 36 + 6 * r;
+    const T *bb = Lw + (size_t)tr[1] * 36;
+    // all 24 vector loads are issued before any arithmetic: one LDS latency instead of one per row
+    load_row6(Lw + (size_t)tr[0] * 36 + 6 * r, a);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) load_row6(bb + 6 * c, reinterpret_cast<T (&)[6]>(b[6 * c]));
+    load_row6(dst, v);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        T acc = a[0] * b[6 * c];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += a[k] * b[6 * c + k];
+        o[c] = acc;
+    }
     if (d & 0x8000u) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) atomicAdd(dst + c, -o[c]);
     } else {
-        T v[6];
-        load_row6(dst, v);
 #pragma unroll
         for (int c = 0; c < 6; ++c) v[c] -= o[c];
         store_row6(dst, v);
