@@ -844,7 +844,7 @@ __device__ __forceinline__ int4 uniform4(const int4 v) {
 }
 
 template <typename T, bool PROF>
-__global__ __launch_bounds__(1024) void k_solve_lds(PlanDev pd, StepArgs a) {
+__global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[2];
     const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63;
@@ -1266,8 +1266,10 @@ int solver_mode(const PlanDev &pd) {
 }
 
 static int solver_threads() {
-    static const int t = std::getenv("BT_SOLVER_THREADS") ? std::atoi(std::getenv("BT_SOLVER_THREADS")) : 1024;   // measurement only
-    return t >= 128 && t <= 1024 ? (t / 64) * 64 : 1024;
+    // 12 waves: enough helper threads for one round of update rows on banded systems, and a
+    // 170-register budget per thread so that a whole 6x6 operand block can be in flight from LDS
+    static const int t = std::getenv("BT_SOLVER_THREADS") ? std::atoi(std::getenv("BT_SOLVER_THREADS")) : 768;   // measurement only
+    return t >= 256 && t <= 768 ? (t / 64) * 64 : 768;
 }
 
 int configure_kernels(const PlanDev &pd) {
