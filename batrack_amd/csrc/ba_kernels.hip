@@ -808,10 +808,11 @@ template <typename T> __device__ __forceinline__ void lds_sub(T *p, T v, bool at
 // One ROW of an update triple: dst[r][:] -= (row r of block tr[0]) . (rows of block tr[1])^T.
 // 21 vector LDS loads and 36 FMAs for 6 outputs.  Bit 15 of tr[2]: the destination is also
 // updated by another column of the same level -> LDS atomics.
-template <typename T>
-__device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr, int r) {
+template <typename T, bool PROF = false>
+__device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr, int r, long long *pf = nullptr, long long *tcp = nullptr) {
     T a[6], b[36], o[6], v[6];
     const unsigned d = tr[2];
+    if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); pf[2] += tn - *tcp; *tcp = tn; }
     T *dst = Lw + (size_t)(d & 0x7fffu) * 36 + 6 * r;
     const T *bb = Lw + (size_t)tr[1] * 36;
     // all 24 vector loads are issued before any arithmetic: one LDS latency instead of one per row
@@ -820,6 +821,7 @@ __device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr
     for (int c = 0; c < 6; ++c) load_row6(bb + 6 * c, reinterpret_cast<T (&)[6]>(b[6 * c]));
     load_row6(dst, v);
     __builtin_amdgcn_sched_barrier(0);
+    if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); pf[4] += tn - *tcp; *tcp = tn; }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         T acc = a[0] * b[6 * c];
@@ -835,6 +837,7 @@ __device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr
         for (int c = 0; c < 6; ++c) v[c] -= o[c];
         store_row6(dst, v);
     }
+    if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); pf[9] += tn - *tcp; *tcp = tn; }
 }
 
 // wave-uniform metadata: LDS -> SGPRs
@@ -978,6 +981,7 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
                 items_before[2] = items_before[1] + (pA1.x >= 0 ? nu1 * 6 + pA1.z * 6 : 0);
                 items_before[3] = items_before[2] + (pA2.x >= 0 ? nu2 * 6 + pA2.z * 6 : 0);
                 items_before[4] = items_before[3] + (pA3.x >= 0 ? nu3 * 6 + pA3.z * 6 : 0);
+                BT_PF(0);                 // (helper waves: slot 0 = time from the barrier to the first item)
                 for (int item = h; item < items_before[kMaxLevelCols]; item += hs) {
                     int q = 0;
 #pragma unroll
@@ -988,7 +992,7 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
                     const int pj = pa.x, u0 = pa.w, dposp = pa.y;
                     if (idx < nu * 6) {
                         const int t = idx / 6;
-                        apply_update_row(Lw, upd + 3 * (u0 + t), idx - 6 * t);
+                        apply_update_row<T, PROF>(Lw, upd + 3 * (u0 + t), idx - 6 * t, pf, &tc);
                     } else {
                         const int qq = idx - nu * 6, sb = qq / 6, r = qq - 6 * sb;
                         T lr[6], zr[6];
