@@ -919,15 +919,27 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
         __syncthreads();
         BT_PF(0);
 
-        for (int l = 0; l < nlev; ++l) {
-            // per-level metadata (wave-uniform, kept in SGPRs): one LDS round trip instead of chains
-            // of index lookups
+        // Per-level metadata (wave-uniform, kept in SGPRs).  The entry of level l+1 is fetched from LDS
+        // before the barrier that ends level l, so its latency hides behind the barrier.
+        int4 cA0, cA1, cA2, cA3, pA0, pA1, pA2, pA3, cW, cWb;     // current / previous level, and this wave's own column
+        int cn0, cn1, cn2, cn3, pn0 = 0, pn1 = 0, pn2 = 0, pn3 = 0, nc;
+        pA0 = pA1 = pA2 = pA3 = make_int4(-1, 0, 0, 0);
+        auto fetch_level = [&](int l) {
             const int4 *ml = lvl_meta + (size_t)l * kMaxLevelCols * 2;
-            const int nc = __builtin_amdgcn_readfirstlane(ml[1].w);
+            cA0 = uniform4(ml[0]); cA1 = uniform4(ml[2]); cA2 = uniform4(ml[4]); cA3 = uniform4(ml[6]);
+            const int4 b0 = uniform4(ml[1]);
+            cn0 = b0.x; nc = b0.w;
+            cn1 = __builtin_amdgcn_readfirstlane(ml[3].x); cn2 = __builtin_amdgcn_readfirstlane(ml[5].x);
+            cn3 = __builtin_amdgcn_readfirstlane(ml[7].x);
+            const int wq = wave < kMaxLevelCols ? wave : 0;
+            cW = uniform4(ml[2 * wq]); cWb = uniform4(ml[2 * wq + 1]);
+        };
+        fetch_level(0);
+        for (int l = 0; l < nlev; ++l) {
             // ---- phase 1
             if (wave < nc) {
                 __builtin_amdgcn_s_setprio(3);            // the critical path of the level: win issue arbitration on this SIMD
-                const int4 ma = uniform4(ml[2 * wave]), mb = uniform4(ml[2 * wave + 1]);
+                const int4 ma = cW, mb = cWb;
                 const int dpos = ma.y;
                 for (int k = mb.y; k < mb.y + mb.z; ++k) {        // pending updates of this column's diagonal block
                     if (lane < 36) {
@@ -971,10 +983,7 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
                 // the other update triples of the previous level's columns (one ROW of a triple per
                 // thread) and their contribution to y, all columns flattened over the helper threads
                 const int h = tid - 64 * nc, hs = nth - 64 * nc;
-                const int4 *mp = lvl_meta + (size_t)(l - 1) * kMaxLevelCols * 2;
-                const int4 pA0 = uniform4(mp[0]), pA1 = uniform4(mp[2]), pA2 = uniform4(mp[4]), pA3 = uniform4(mp[6]);
-                const int nu0 = __builtin_amdgcn_readfirstlane(mp[1].x), nu1 = __builtin_amdgcn_readfirstlane(mp[3].x),
-                          nu2 = __builtin_amdgcn_readfirstlane(mp[5].x), nu3 = __builtin_amdgcn_readfirstlane(mp[7].x);
+                const int nu0 = pn0, nu1 = pn1, nu2 = pn2, nu3 = pn3;
                 int items_before[kMaxLevelCols + 1];
                 items_before[0] = 0;
                 items_before[1] = pA0.x >= 0 ? nu0 * 6 + pA0.z * 6 : 0;
@@ -1011,7 +1020,7 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
             BT_PF(5);
             // ---- phase 2: block rows of the level's columns (and their y) by forward substitution
             {
-                const int4 mA0 = uniform4(ml[0]), mA1 = uniform4(ml[2]), mA2 = uniform4(ml[4]), mA3 = uniform4(ml[6]);
+                const int4 mA0 = cA0, mA1 = cA1, mA2 = cA2, mA3 = cA3;
                 int rows_before[kMaxLevelCols + 1];
                 rows_before[0] = 0;
                 rows_before[1] = mA0.x >= 0 ? mA0.z * 6 + 1 : 0;
@@ -1048,6 +1057,8 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
                 }
             }
             BT_PF(3);
+            pA0 = cA0; pA1 = cA1; pA2 = cA2; pA3 = cA3; pn0 = cn0; pn1 = cn1; pn2 = cn2; pn3 = cn3;
+            if (l + 1 < nlev) fetch_level(l + 1);
             __syncthreads();
             BT_PF(5);
         }
