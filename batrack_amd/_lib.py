@@ -8,8 +8,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "lib", "libbatrack_ba.so")
-SOURCES = ["ba_kernels.hip", "ba_plan.cpp", "ba_api.cpp"]
-HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", os.path.join("..", "..", "include", "batrack_ba.h")]
+SOURCES = ["ba_kernels.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip"]
+HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
+           os.path.join("..", "..", "include", "batrack_se3.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 
 BT_OK, BT_EINVAL, BT_ENOMEM, BT_EHIP, BT_EUNSUPPORTED = 0, -1, -2, -3, -4
@@ -94,6 +95,11 @@ def lib():
     L.bt_ba_dx.argtypes = [vp, vp]
     L.bt_ba_status.restype = i32
     L.bt_ba_status.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_int32)]
+    for name, nptr in (("bt_se3_exp", 2), ("bt_se3_log", 2), ("bt_se3_inv", 2), ("bt_se3_mul", 3), ("bt_se3_act", 3),
+                       ("bt_se3_act4", 3), ("bt_se3_adj", 3), ("bt_se3_adjT", 3), ("bt_se3_matrix", 2)):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp] * nptr + [i64, i32, vp]
     _lib = L
     return L
 

@@ -3,9 +3,10 @@
 /root/reference/main/batrack.py:864,883): `.data` [...,7] = (tx ty tz qx qy qz qw),
 `.vec()`, indexing, `inv`, `*`, `exp`, `retr`, `matrix`, `act`, `adjT`, `log`.
 
-The group maths here is plain torch on whatever device `.data` lives on; it is
-host-side convenience for callers, not the BA hot path (the hot path consumes
-`.data` directly inside the HIP kernels).  Conventions follow the reference's
+On the GPU the group operations run the HIP kernels of batrack_amd/csrc/se3_kernels.hip
+(through `lietorch_backends`, the counterpart of the reference's compiled module); on
+CPU tensors they fall back to the plain-torch formulas below (used by CPU tests and
+tooling only — the BA hot path consumes `.data` directly inside its own kernels).  Conventions follow the reference's
 headers: unit quaternion renormalised on use, tangent = (tau, phi), EPS = 1e-6
 (lietorch/include/so3.h:31-65,153-190, se3.h:36-67,124-142, common.h:7).
 """
@@ -31,6 +32,19 @@ def _qrot(q, p):
     qv, p = torch.broadcast_tensors(q[..., :3], p)
     uv = 2.0 * torch.linalg.cross(qv, p)
     return p + q[..., 3:] * uv + torch.linalg.cross(qv, uv)
+
+
+def _hip(x):
+    """HIP element-wise kernels apply to GPU float32/float64 data."""
+    return x.is_cuda and x.dtype in (torch.float32, torch.float64)
+
+
+def _flat_pair(x, y):
+    """Broadcast two [..., d] tensors over their batch dims and flatten (broadcasting.py:9-31)."""
+    shape = torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    xf = x.expand(shape + x.shape[-1:]).reshape(-1, x.shape[-1]).contiguous()
+    yf = y.expand(shape + y.shape[-1:]).reshape(-1, y.shape[-1]).contiguous()
+    return xf, yf, shape
 
 
 class SE3:
@@ -99,11 +113,18 @@ class SE3:
         return self.data[..., :3], _unit(self.data[..., 3:7])
 
     def inv(self):
+        if _hip(self.data):
+            from . import lietorch_backends as lb
+            return SE3(lb.inv(3, self.data.reshape(-1, 7).contiguous()).view(self.data.shape))
         t, q = self._tq()
         qi = torch.cat([-q[..., :3], q[..., 3:]], -1)
         return SE3(torch.cat([-_qrot(qi, t), qi], -1))
 
     def mul(self, other):
+        if _hip(self.data) and _hip(other.data):
+            from . import lietorch_backends as lb
+            xf, yf, shape = _flat_pair(self.data, other.data)
+            return SE3(lb.mul(3, xf, yf).view(shape + (7,)))
         t1, q1 = self._tq()
         t2, q2 = other._tq()
         t1, t2 = torch.broadcast_tensors(t1, t2)
@@ -111,6 +132,11 @@ class SE3:
         return SE3(torch.cat([t1 + _qrot(q1, t2), _unit(_qmul(q1, q2))], -1))
 
     def act(self, p):
+        if _hip(self.data) and _hip(p) and p.dtype == self.data.dtype:
+            from . import lietorch_backends as lb
+            xf, pf, shape = _flat_pair(self.data, p)
+            out = lb.act(3, xf, pf) if p.shape[-1] == 3 else lb.act4(3, xf, pf)
+            return out.view(shape + (p.shape[-1],))
         t, q = self._tq()
         if p.shape[-1] == 3:
             return _qrot(q, p) + t
@@ -133,6 +159,10 @@ class SE3:
         return self.act(p)
 
     def adjT(self, a):
+        if _hip(self.data) and _hip(a) and a.dtype == self.data.dtype:
+            from . import lietorch_backends as lb
+            xf, af, shape = _flat_pair(self.data, a)
+            return lb.adjT(3, xf, af).view(shape + (6,))
         t, q = self._tq()
         qi = torch.cat([-q[..., :3], q[..., 3:]], -1)
         at, ap = a[..., :3], a[..., 3:]
@@ -141,6 +171,9 @@ class SE3:
 
     @classmethod
     def exp(cls, x):
+        if _hip(x):
+            from . import lietorch_backends as lb
+            return cls(lb.expm(3, x.reshape(-1, 6).contiguous()).view(x.shape[:-1] + (7,)))
         tau, phi = x[..., :3], x[..., 3:]
         th2 = (phi * phi).sum(-1, keepdim=True)
         th = th2.sqrt()
@@ -155,6 +188,9 @@ class SE3:
         return cls(torch.cat([tau + c1 * pxt + c2 * torch.linalg.cross(phi, pxt), q], -1))
 
     def log(self):
+        if _hip(self.data):
+            from . import lietorch_backends as lb
+            return lb.logm(3, self.data.reshape(-1, 7).contiguous()).view(self.data.shape[:-1] + (6,))
         t, q = self._tq()
         qv, w = q[..., :3], q[..., 3:]
         n2 = (qv * qv).sum(-1, keepdim=True)
