@@ -13,15 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "batrack_ba.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(bt_[a-z_0-9]+)\s*\(", src)))
+    names = set()
+    for h in ("batrack_ba.h", "batrack_se3.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(bt_[A-Za-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_symbols_are_exported():
     L = ctypes.CDLL(_lib.LIB_PATH)
     names = declared_symbols()
-    assert len(names) >= 14
+    assert len(names) >= 24 and "bt_se3_adjT" in names
     for n in names:
         assert hasattr(L, n), f"{n} declared in batrack_ba.h but not exported"
 
