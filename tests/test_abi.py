@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("batrack_ba.h", "batrack_se3.h"):
+    for h in ("batrack_ba.h", "batrack_se3.h", "batrack_patchify.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(bt_[A-Za-z_0-9]+)\s*\(", src))
