@@ -155,3 +155,31 @@ def test_convergence_full_ba_c3():
     e0 = np.linalg.norm(d["poses"][:, :3] - g.poses_gt[:, :3])
     e1 = np.linalg.norm(hip_pose[:, :3] - g.poses_gt[:, :3])
     assert e1 < 0.5 * e0
+
+
+def test_cholesky_failure_gives_zero_pose_update():
+    """ba.py:9-13: a failed factorisation returns dX = 0 — the depths still move, the poses are only
+    re-normalised.  Forced with a negative damping that makes the reduced system indefinite."""
+    d = load("c1")
+    kw = dict(ep=-1e9)
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"],
+                         d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, want_system=True, **kw)
+    assert ref["failed"] and np.all(ref["dX"] == 0)
+    o = HipProblem(d).raw_step("weights_pose", 1, **kw)
+    assert o["status"] == 1                                   # BT_SOLVE_CHOL_FAILED
+    assert np.all(o["dX"] == 0)
+    assert rel(o["poses_out"], ref["poses_out"]) < 1e-6       # Exp(0) * G: quaternions re-normalised only
+    assert rel(o["patches_out"], ref["patches_out"]) < 1e-5   # dZ = Q w' (ba.py:328 with dX = 0)
+
+
+def test_status_word_after_structure_only_and_plan_reuse():
+    """Plans are reused across the 2*ITER calls of an update(); alternating call kinds must not leak state."""
+    d = load("c1_rough")
+    hp = HipProblem(d)
+    a1 = hp.api_step("weights_pose", 2, False)
+    b1 = hp.api_step("weights", 2, True, poses=a1[0], patches=a1[1])
+    a2 = hp.api_step("weights_pose", 2, False)                # same inputs as a1, after an SO step on the same plan
+    torch.cuda.synchronize()
+    assert rel(a2[0].data.cpu().numpy(), a1[0].data.cpu().numpy()) < 1e-6
+    assert rel(a2[1].cpu().numpy(), a1[1].cpu().numpy()) < 1e-6
+    assert b1[0] is a1[0]
