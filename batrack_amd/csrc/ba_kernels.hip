@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
     for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
     if (tid == 0) a.status[0] = status;
     BT_PF(8);
-    if (PROF && lane == 0 && (wave == 0 || wave == 5)) {        // measurement only: phase cycle counts of a critical and a helper wave
+    if (PROF && lane == 0 && (wave == 0 || wave == 2)) {        // measurement only: phase cycle counts of a critical and a helper wave
         long long *o = reinterpret_cast<long long *>(a.status + 4) + (wave ? 1 : 0) * 10;
         for (int i = 0; i < 10; ++i) o[i] = pf[i];
     }
