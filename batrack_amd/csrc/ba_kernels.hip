@@ -935,7 +935,9 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
             cW = uniform4(ml[2 * wq]); cWb = uniform4(ml[2 * wq + 1]);
         };
         fetch_level(0);
+        long long ph1 = 0, ph2 = 0, tph = PROF ? clock64() : 0;
         for (int l = 0; l < nlev; ++l) {
+            if (PROF) tph = clock64();
             // ---- phase 1
             if (wave < nc) {
                 __builtin_amdgcn_s_setprio(3);            // the critical path of the level: win issue arbitration on this SIMD
@@ -1016,7 +1018,9 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
                 }
                 BT_PF(1);
             }
+            if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ph1 += clock64() - tph; }
             __syncthreads();
+            if (PROF) tph = clock64();
             BT_PF(5);
             // ---- phase 2: block rows of the level's columns (and their y) by forward substitution
             {
@@ -1057,12 +1061,17 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
                 }
             }
             BT_PF(3);
+            if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ph2 += clock64() - tph; }
             pA0 = cA0; pA1 = cA1; pA2 = cA2; pA3 = cA3; pn0 = cn0; pn1 = cn1; pn2 = cn2; pn3 = cn3;
             if (l + 1 < nlev) fetch_level(l + 1);
             __syncthreads();
             BT_PF(5);
         }
 
+        if (PROF && lane == 0) {
+            long long *o = reinterpret_cast<long long *>(a.status + 4) + 40 + wave * 2;
+            o[0] = ph1; o[1] = ph2;
+        }
         // ---- back-substitution form
         // (a) L_jj^-1 into the strict upper triangle of the diagonal block (one thread per column)
         for (int j = tid; j < n; j += nth) {

@@ -39,7 +39,7 @@ static void layout_workspace(bt_plan *pl) {
     w.linv = off;     off = align_up(off + (size_t)I.n * 36 * sizeof(float), 256);
     w.zvec = off;     off = align_up(off + D * sizeof(float), 256);
     w.dx = off;       off = align_up(off + D * sizeof(float) + 64, 256);
-    w.status = off;   off = align_up(off + 512, 256);
+    w.status = off;   off = align_up(off + 1024, 256);
     w.total = off;
     pl->ws = w;
     pl->info.workspace_bytes = (int64_t)w.total;

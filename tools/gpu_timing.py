@@ -53,6 +53,8 @@ if int(os.environ.get("BT_DEBUG_MODE", "0")) & 16:
     stat_off = off + ((6 * plan.n * 4 + 64 + 255) // 256) * 256
     pf = np.frombuffer(raw[stat_off + 16: stat_off + 16 + 160].tobytes(), dtype=np.int64).reshape(2, 10)
     names = ["load", "updates", "chol", "trsm", "store", "barrier", "Mprep", "backsub", "tail", "-"]
+    ph = np.frombuffer(raw[stat_off + 16 + 320: stat_off + 16 + 320 + 16 * 12].tobytes(), dtype=np.int64).reshape(12, 2)
+    print("  solver per-wave busy cycles (phase1, phase2): " + " ".join(f"w{w}:{a}/{b}" for w, (a, b) in enumerate(ph)))
     for w in range(2):
         print(f"  solver wave{w} cycles: " + " ".join(f"{n}={v}" for n, v in zip(names, pf[w])) + f" total={pf[w].sum()}")
 print(f"mode={os.environ.get('BT_DEBUG_MODE','0')} {args.workload} E={plan.E} n={plan.n} tiles={plan.tiles} nnzb={plan.nnz_blocks}: " +
