@@ -986,35 +986,47 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
                 // thread) and their contribution to y, all columns flattened over the helper threads
                 const int h = tid - 64 * nc, hs = nth - 64 * nc;
                 const int nu0 = pn0, nu1 = pn1, nu2 = pn2, nu3 = pn3;
-                int items_before[kMaxLevelCols + 1];
-                items_before[0] = 0;
-                items_before[1] = pA0.x >= 0 ? nu0 * 6 + pA0.z * 6 : 0;
-                items_before[2] = items_before[1] + (pA1.x >= 0 ? nu1 * 6 + pA1.z * 6 : 0);
-                items_before[3] = items_before[2] + (pA2.x >= 0 ? nu2 * 6 + pA2.z * 6 : 0);
-                items_before[4] = items_before[3] + (pA3.x >= 0 ? nu3 * 6 + pA3.z * 6 : 0);
+                // (a) update rows of all columns of the previous level, flattened over the helper threads
+                int rows_b[kMaxLevelCols + 1];
+                rows_b[0] = 0;
+                rows_b[1] = pA0.x >= 0 ? nu0 * 6 : 0;
+                rows_b[2] = rows_b[1] + (pA1.x >= 0 ? nu1 * 6 : 0);
+                rows_b[3] = rows_b[2] + (pA2.x >= 0 ? nu2 * 6 : 0);
+                rows_b[4] = rows_b[3] + (pA3.x >= 0 ? nu3 * 6 : 0);
                 BT_PF(0);                 // (helper waves: slot 0 = time from the barrier to the first item)
-                for (int item = h; item < items_before[kMaxLevelCols]; item += hs) {
+                for (int item = h; item < rows_b[kMaxLevelCols]; item += hs) {
                     int q = 0;
 #pragma unroll
-                    for (int k = 1; k < kMaxLevelCols; ++k) q += item >= items_before[k] ? 1 : 0;
-                    const int idx = item - (q == 0 ? 0 : q == 1 ? items_before[1] : q == 2 ? items_before[2] : items_before[3]);
+                    for (int k = 1; k < kMaxLevelCols; ++k) q += item >= rows_b[k] ? 1 : 0;
+                    const int idx = item - (q == 0 ? 0 : q == 1 ? rows_b[1] : q == 2 ? rows_b[2] : rows_b[3]);
                     const int4 pa = q == 0 ? pA0 : q == 1 ? pA1 : q == 2 ? pA2 : pA3;
-                    const int nu = q == 0 ? nu0 : q == 1 ? nu1 : q == 2 ? nu2 : nu3;
-                    const int pj = pa.x, u0 = pa.w, dposp = pa.y;
-                    if (idx < nu * 6) {
-                        const int t = idx / 6;
-                        apply_update_row<T, PROF>(Lw, upd + 3 * (u0 + t), idx - 6 * t, pf, &tc);
-                    } else {
-                        const int qq = idx - nu * 6, sb = qq / 6, r = qq - 6 * sb;
-                        T lr[6], zr[6];
-                        load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
-                        load_row6(z + 6 * pj, zr);
-                        T acc = lr[0] * zr[0];
+                    const int t = idx / 6;
+                    apply_update_row<T, PROF>(Lw, upd + 3 * (pa.w + t), idx - 6 * t, pf, &tc);
+                }
+                // (b) their contribution to y, on the waves after those that had update rows (no wave
+                //     runs both kinds of item in the common one-round case)
+                int ys_b[kMaxLevelCols + 1];
+                ys_b[0] = 0;
+                ys_b[1] = pA0.x >= 0 ? pA0.z * 6 : 0;
+                ys_b[2] = ys_b[1] + (pA1.x >= 0 ? pA1.z * 6 : 0);
+                ys_b[3] = ys_b[2] + (pA2.x >= 0 ? pA2.z * 6 : 0);
+                ys_b[4] = ys_b[3] + (pA3.x >= 0 ? pA3.z * 6 : 0);
+                const int shift = ((rows_b[kMaxLevelCols] + 63) >> 6) << 6;
+                for (int item = (h - shift % hs + hs) % hs; item < ys_b[kMaxLevelCols]; item += hs) {
+                    int q = 0;
 #pragma unroll
-                        for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
-                        const int rcv = row_idx[dposp + 1 + sb];
-                        lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv >> 24) != 0);
-                    }
+                    for (int k = 1; k < kMaxLevelCols; ++k) q += item >= ys_b[k] ? 1 : 0;
+                    const int qq = item - (q == 0 ? 0 : q == 1 ? ys_b[1] : q == 2 ? ys_b[2] : ys_b[3]);
+                    const int4 pa = q == 0 ? pA0 : q == 1 ? pA1 : q == 2 ? pA2 : pA3;
+                    const int pj = pa.x, dposp = pa.y, sb = qq / 6, r = qq - 6 * sb;
+                    T lr[6], zr[6];
+                    load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
+                    load_row6(z + 6 * pj, zr);
+                    T acc = lr[0] * zr[0];
+#pragma unroll
+                    for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
+                    const int rcv = row_idx[dposp + 1 + sb];
+                    lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv >> 24) != 0);
                 }
                 BT_PF(1);
             }
