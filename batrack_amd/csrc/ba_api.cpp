@@ -33,7 +33,6 @@ int upload_plan(bt_plan *pl) {
     const size_t o_tp0 = put(buf, pl->tile_pair0), o_tnp = put(buf, pl->tile_npair), o_tps = put(buf, pl->tile_pairs), o_slp = put(buf, pl->slot_lp);
     const size_t o_pm = put(buf, pl->perm), o_bs = put(buf, pl->blk_src), o_lp = put(buf, pl->lvl_ptr), o_lc = put(buf, pl->lvl_cols);
     const size_t o_cl = put(buf, pl->col_lvl), o_dpp = put(buf, pl->dp_ptr), o_dp = put(buf, pl->dp);
-    const size_t o_syp = put(buf, pl->sy_ptr), o_syt = put(buf, pl->sy_tiles), o_syd = put(buf, pl->sy_dst);
     void *d = nullptr;
     if (hipMalloc(&d, buf.size() + 256) != hipSuccess) return BT_ENOMEM;
     if (hipMemcpy(d, buf.data(), buf.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return BT_EHIP; }
@@ -57,8 +56,6 @@ int upload_plan(bt_plan *pl) {
     P.col_lvl = BT_I32(o_cl); P.dp_ptr = BT_I32(o_dpp); P.dp = BT_I32(o_dp);
     P.nlev = (int)pl->lvl_ptr.size() - 1; P.ndp = (int)pl->dp.size();
     P.lvl_meta = BT_I32(o_lm); P.tile_flags = BT_I32(o_tf);
-    P.sy_ptr = BT_I32(o_syp); P.sy_tiles = BT_I32(o_syt); P.sy_dst = reinterpret_cast<const uint16_t *>(b + o_syd);
-    P.sy_ok = pl->sy_ok; P.sy_ntiles = (int)pl->sy_tiles.size();
     P.tile_pair0 = BT_I32(o_tp0); P.tile_npair = BT_I32(o_tnp); P.tile_pairs = BT_I32(o_tps);
     P.slot_lp = reinterpret_cast<const uint8_t *>(b + o_slp); P.max_tile_pairs = pl->max_tile_pairs;
 #undef BT_I32
@@ -157,7 +154,7 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
     BT_ARR(tile_trk0) BT_ARR(tile_ntrk) BT_ARR(tile_ncam) BT_ARR(tile_cam0) BT_ARR(tile_slot0)
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
     BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next) BT_ARR(perm) BT_ARR(blk_src) BT_ARR(lvl_ptr) BT_ARR(lvl_cols)
-    BT_ARR(col_lvl) BT_ARR(dp_ptr) BT_ARR(dp) BT_ARR(tile_pair0) BT_ARR(tile_npair) BT_ARR(tile_pairs) BT_ARR(slot_lp) BT_ARR(tile_flags) BT_ARR(sy_ptr) BT_ARR(sy_tiles) BT_ARR(sy_dst)
+    BT_ARR(col_lvl) BT_ARR(dp_ptr) BT_ARR(dp) BT_ARR(tile_pair0) BT_ARR(tile_npair) BT_ARR(tile_pairs) BT_ARR(slot_lp) BT_ARR(tile_flags)
 #undef BT_ARR
     return -1;
 }

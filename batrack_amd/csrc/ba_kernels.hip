@@ -1182,329 +1182,6 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
 #undef BT_PF
 }
 
-// ------------------------------------------------------------------ k_solve_mfma
-// The LDS-resident factorisation with every column's updates on the matrix cores.
-// Column j's updates are the lower triangle of P P^T with the panel P = [rows of its
-// sub-diagonal blocks L_ij ; y_j]: 16x16 output tiles, two v_mfma_f64_16x16x4 each
-// (K = 6), scattered through the plan's per-tile destination table (sy_dst).  Per level:
-//   phase A   one thread per panel row (and one for y_j): factor the column's diagonal
-//             block redundantly in registers, forward-substitute the own row
-//   phase B   all waves: the level's panel-product tiles; the factored diagonal blocks
-//             (staged by the y_j threads) are put in place
-// A lone wave retires one instruction per 6-10 cycles, so phase A costs what the
-// critical wave of k_solve_lds paid for the 6x6 factorisation alone; the pending
-// diagonal updates, the store/reload of L_jj and the LDS-bandwidth-bound update rows
-// (48 doubles read per 36 FMAs) are gone.
-typedef double double4_mf __attribute__((ext_vector_type(4)));
-
-template <typename T>
-__device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArgs &a, T *Lw, T *z, const int *row_idx,
-                                                double lm, int tid, int nth) {
-    const int nnzb = pd.nnzb, D = pd.D;
-    for (int base = 0; base < nnzb * 6; base += 2 * nth) {
-        double v[2][6];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = base + u * nth + tid;
-            if (idx < nnzb * 6) {
-                const int b = idx / 6, r = idx - 6 * b, src = pd.blk_src[b];
-                const int rn = src >> 9, cn = (src >> 1) & 255;
-                if (src & 1) {
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) v[u][c] = a.S[(size_t)(6 * rn + c) * D + 6 * cn + r];
-                } else {
-                    const double *p = a.S + (size_t)(6 * rn + r) * D + 6 * cn;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) v[u][c] = p[c];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = base + u * nth + tid;
-            if (idx < nnzb * 6) {
-                const int b = idx / 6, r = idx - 6 * b, rc = row_idx[b];
-                const bool diag = (rc & 255) == ((rc >> 8) & 255);
-                T w[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    double x = (!diag || r >= c) ? v[u][c] : 0.0;
-                    if (diag && r == c) x = x + ((double)a.ep + lm * x);          // ba.py:67
-                    w[c] = (T)x;
-                }
-                store_row6(Lw + (size_t)b * 36 + 6 * r, w);
-            }
-        }
-    }
-    for (int i = tid; i < D; i += nth) z[i] = (T)a.y[6 * pd.perm[i / 6] + i % 6];
-}
-
-// Back substitution of the LDS-resident factor (diagonal blocks hold L_jj with 1/l_cc on the
-// diagonal): brings it into M form, then x_j = zt_j - sum_{i>j} M_ij x_i by levels, descending.
-template <typename T>
-__device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T *z, T *zt, const int *row_idx,
-                                                    const int *col_ptr, const int4 *lvl_meta, int tid, int nth) {
-    const int n = pd.n, nnzb = pd.nnzb, nlev = pd.nlev, wave = tid >> 6, lane = tid & 63;
-    for (int j = tid; j < n; j += nth) {
-        T *dblk = Lw + (size_t)col_ptr[j] * 36;
-        T L[21], li[21];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c <= r; ++c) L[BT_LT(r, c)] = dblk[6 * r + c];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            li[BT_LT(c, c)] = L[BT_LT(c, c)];
-#pragma unroll
-            for (int r = c + 1; r < 6; ++r) {
-                T t = (T)0;
-#pragma unroll
-                for (int k = c; k < r; ++k) t += L[BT_LT(r, k)] * li[BT_LT(k, c)];
-                li[BT_LT(r, c)] = -t * L[BT_LT(r, r)];
-            }
-        }
-#pragma unroll
-        for (int r = 1; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < r; ++c) dblk[6 * c + r] = li[BT_LT(r, c)];      // Linv[r][c] at [c][r]
-    }
-    __syncthreads();
-    for (int idx = tid; idx < nnzb * 6 + n; idx += nth) {
-        int j;
-        T *p, *q;
-        if (idx < nnzb * 6) {
-            const int b = idx / 6, r = idx - 6 * b;
-            j = (row_idx[b] >> 8) & 255;
-            if ((row_idx[b] & 255) == j) continue;
-            p = Lw + (size_t)b * 36 + 6 * r; q = p;
-        } else {
-            j = idx - nnzb * 6;
-            p = z + 6 * j; q = zt + 6 * j;
-        }
-        const T *dblk = Lw + (size_t)col_ptr[j] * 36;
-        T in[6], out[6];
-        load_row6(p, in);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            T t = dblk[7 * c] * in[c];
-#pragma unroll
-            for (int k = c + 1; k < 6; ++k) t += dblk[6 * c + k] * in[k];
-            out[c] = t;
-        }
-        store_row6(q, out);
-    }
-    __syncthreads();
-    for (int l = nlev - 1; l >= 0; --l) {
-        const int4 ma = uniform4(lvl_meta[(l * kMaxLevelCols + (wave < kMaxLevelCols ? wave : 0)) * 2]);
-        if (wave < kMaxLevelCols && ma.x >= 0) {
-            const int c = lane >> 3, g = lane & 7;
-            const int j = ma.x, dpos = ma.y, cnt = ma.z;
-            T acc = (T)0;
-            if (c < 6)
-                for (int sb = g; sb < cnt; sb += 8) {           // one sub-block per lane group
-                    const int b = dpos + 1 + sb;
-                    T x[6];
-                    load_row6(zt + 6 * (row_idx[b] & 255), x);
-                    const T *mb = Lw + (size_t)b * 36 + c;     // Mt[r][c]
-                    acc += mb[0] * x[0] + mb[6] * x[1] + mb[12] * x[2] + mb[18] * x[3] + mb[24] * x[4] + mb[30] * x[5];
-                }
-            acc = dpp_add8(acc);
-            if (c < 6 && g == 0) zt[6 * j + c] -= acc;
-        }
-        __syncthreads();
-    }
-}
-
-size_t solve_mfma_lds_bytes(const PlanDev &pd) {
-    size_t b = ((size_t)pd.nnzb * 36 + 2 * (size_t)pd.D + kMaxLevelCols * 36) * sizeof(double);     // Lw, z, zt, staged L_jj
-    b += ((size_t)pd.nnzb + (size_t)pd.n + 1 + (size_t)pd.nlev + 1 + (size_t)pd.sy_ntiles) * sizeof(int);   // row_idx, col_ptr, sy_ptr, sy_tiles
-    b = (b + 15) / 16 * 16 + (size_t)pd.nlev * kMaxLevelCols * 8 * sizeof(int);   // lvl_meta
-    return b + 64;
-}
-
-constexpr int kSyBatch = 4;      // tiles a wave keeps in flight
-
-template <bool PROF>
-__global__ __launch_bounds__(768) void k_solve_mfma(PlanDev pd, StepArgs a) {
-    typedef double T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int flags[2];
-    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
-    const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
-    T *Lw = reinterpret_cast<T *>(smem);
-    T *z = Lw + (size_t)nnzb * 36, *zt = z + D, *dstage = zt + D;
-    int *row_idx = reinterpret_cast<int *>(dstage + kMaxLevelCols * 36), *col_ptr = row_idx + nnzb, *sy_ptr = col_ptr + n + 1,
-        *sy_tiles = sy_ptr + nlev + 1;
-    int4 *lvl_meta = reinterpret_cast<int4 *>(smem + ((reinterpret_cast<unsigned char *>(sy_tiles + pd.sy_ntiles) - smem + 15) / 16 * 16));
-    for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8);
-    for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
-    for (int i = tid; i <= nlev; i += nth) sy_ptr[i] = pd.sy_ptr[i];
-    for (int i = tid; i < pd.sy_ntiles; i += nth) sy_tiles[i] = pd.sy_tiles[i];
-    for (int i = tid; i < nlev * kMaxLevelCols * 2; i += nth) lvl_meta[i] = reinterpret_cast<const int4 *>(pd.lvl_meta)[i];
-    const uint2 *dst_tab = reinterpret_cast<const uint2 *>(pd.sy_dst);
-    long long phA = 0, phB = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0;
-    __syncthreads();
-
-    int status = BT_SOLVE_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const double lm = attempt == 0 ? 1e-4 : 1e-3;
-        if (tid < 2) flags[tid] = 0;
-        lds_load_system<T>(pd, a, Lw, z, row_idx, lm, tid, nth);
-        __syncthreads();
-        if (PROF) tload = clock64() - tall;
-
-        int4 cA0, cA1, cA2, cA3;
-        auto fetch_level = [&](int l) {
-            const int4 *ml = lvl_meta + (size_t)l * kMaxLevelCols * 2;
-            cA0 = uniform4(ml[0]); cA1 = uniform4(ml[2]); cA2 = uniform4(ml[4]); cA3 = uniform4(ml[6]);
-        };
-        fetch_level(0);
-        for (int l = 0; l < nlev; ++l) {
-            if (PROF) tph = clock64();
-            const int4 mA0 = cA0, mA1 = cA1, mA2 = cA2, mA3 = cA3;
-            // this wave's first batch of tiles: destination offsets from global memory, in flight during phase A
-            const int t0 = __builtin_amdgcn_readfirstlane(sy_ptr[l]), ntl = __builtin_amdgcn_readfirstlane(sy_ptr[l + 1]) - t0;
-            uint2 dtab[kSyBatch];
-#pragma unroll
-            for (int u = 0; u < kSyBatch; ++u) {
-                const int t = wave + u * nw;
-                dtab[u] = t < ntl ? dst_tab[(size_t)(t0 + t) * 64 + lane] : make_uint2(0xffffffffu, 0xffffffffu);
-            }
-            // ---- phase A
-            {
-                int rows_before[kMaxLevelCols + 1];
-                rows_before[0] = 0;
-                rows_before[1] = mA0.x >= 0 ? mA0.z * 6 + 1 : 0;
-                rows_before[2] = rows_before[1] + (mA1.x >= 0 ? mA1.z * 6 + 1 : 0);
-                rows_before[3] = rows_before[2] + (mA2.x >= 0 ? mA2.z * 6 + 1 : 0);
-                rows_before[4] = rows_before[3] + (mA3.x >= 0 ? mA3.z * 6 + 1 : 0);
-                for (int item = tid; item < rows_before[kMaxLevelCols]; item += nth) {
-                    int q = 0;
-#pragma unroll
-                    for (int k = 1; k < kMaxLevelCols; ++k) q += item >= rows_before[k] ? 1 : 0;
-                    const int rw = item - (q == 0 ? 0 : q == 1 ? rows_before[1] : q == 2 ? rows_before[2] : rows_before[3]);
-                    const int4 ma = q == 0 ? mA0 : q == 1 ? mA1 : q == 2 ? mA2 : mA3;
-                    const int j = ma.x, dpos = ma.y, cnt = ma.z;
-                    T L[21];
-                    const T *dblk = Lw + (size_t)dpos * 36;
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        T row[6];
-                        load_row6(dblk + 6 * r, row);
-#pragma unroll
-                        for (int c = 0; c <= r; ++c) L[BT_LT(r, c)] = row[c];
-                    }
-                    T *p = rw < cnt * 6 ? Lw + (size_t)(dpos + 1) * 36 + 6 * rw : z + 6 * j;
-                    T in[6], out[6];
-                    load_row6(p, in);
-                    const bool ok = chol6_packed<T>(L);
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        T t = in[c];
-#pragma unroll
-                        for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
-                        out[c] = t * L[BT_LT(c, c)];
-                    }
-                    store_row6(p, out);
-                    if (rw == cnt * 6) {          // the y_j thread stages L_jj; it is put in place in phase B
-                        if (!ok) flags[0] = 1;
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) {
-                            T row[6];
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) row[c] = L[BT_LT(r, c <= r ? c : r)];
-                            store_row6(dstage + 36 * q + 6 * r, row);
-                        }
-                    }
-                }
-            }
-            if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); phA += clock64() - tph; }
-            __syncthreads();
-            if (PROF) tph = clock64();
-            // ---- phase B
-            {
-                const int nc = (mA0.x >= 0) + (mA1.x >= 0) + (mA2.x >= 0) + (mA3.x >= 0);
-                const int back = nth - 1 - tid;               // staged L_jj -> diagonal blocks, on the last threads
-                if (back < nc * 18) {
-                    const int q = back / 18, e = back - 18 * q;
-                    const int dpos = q == 0 ? mA0.y : q == 1 ? mA1.y : q == 2 ? mA2.y : mA3.y;
-                    reinterpret_cast<double2 *>(Lw + (size_t)dpos * 36)[e] = reinterpret_cast<const double2 *>(dstage + 36 * q)[e];
-                }
-                const int m16 = lane & 15, k0 = lane >> 4;
-                for (int base = wave; base < ntl; base += kSyBatch * nw) {
-                    double av[kSyBatch][2], bv[kSyBatch][2];
-#pragma unroll
-                    for (int u = 0; u < kSyBatch; ++u) {
-                        const int t = base + u * nw;
-                        av[u][0] = av[u][1] = bv[u][0] = bv[u][1] = 0.0;
-                        if (t < ntl) {
-                            const int desc = __builtin_amdgcn_readfirstlane(sy_tiles[t0 + t]);
-                            const int q = desc & 255, I = (desc >> 8) & 255, J = desc >> 16;
-                            const int4 ma = q == 0 ? mA0 : q == 1 ? mA1 : q == 2 ? mA2 : mA3;
-                            const int pbase = (ma.y + 1) * 36, rows = 6 * ma.z;
-                            const int pa = 16 * I + m16, pb = 16 * J + m16;
-                            const T *ap = pa == rows ? z + 6 * ma.x : Lw + pbase + 6 * pa;
-                            const T *bp = Lw + pbase + 6 * pb;
-                            av[u][0] = ap[k0]; bv[u][0] = bp[k0];
-                            if (k0 < 2) { av[u][1] = ap[4 + k0]; bv[u][1] = bp[4 + k0]; }
-                            if (base != wave) dtab[u] = dst_tab[(size_t)(t0 + t) * 64 + lane];
-                        } else if (base != wave) dtab[u] = make_uint2(0xffffffffu, 0xffffffffu);
-                    }
-                    double4_mf acc[kSyBatch];
-#pragma unroll
-                    for (int u = 0; u < kSyBatch; ++u) {
-                        acc[u] = double4_mf{0.0, 0.0, 0.0, 0.0};
-                        if (base + u * nw < ntl) {
-                            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], bv[u][0], acc[u], 0, 0, 0);
-                            acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], bv[u][1], acc[u], 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < kSyBatch; ++u) {
-                        const unsigned offs[4] = {dtab[u].x & 0xffffu, dtab[u].x >> 16, dtab[u].y & 0xffffu, dtab[u].y >> 16};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (offs[r] != 0xffffu) {
-                                T *dp = Lw + (offs[r] & 0x7fffu);
-                                if (offs[r] & 0x8000u) atomicAdd(dp, -acc[u][r]);
-                                else *dp -= acc[u][r];
-                            }
-                        }
-                    }
-                }
-            }
-            if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); phB += clock64() - tph; }
-            if (l + 1 < nlev) fetch_level(l + 1);
-            __syncthreads();
-        }
-        if (PROF) tsweep = clock64() - tall;
-
-        lds_back_substitute<T>(pd, Lw, z, zt, row_idx, col_ptr, lvl_meta, tid, nth);
-        for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
-        __syncthreads();
-        const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
-        __syncthreads();
-        if (failed) {
-            for (int i = tid; i < D; i += nth) zt[i] = (T)0;
-            status = BT_SOLVE_CHOL_FAILED;
-            break;
-        }
-        if (!has_nan) break;
-        status = BT_SOLVE_RETRIED;
-    }
-    __syncthreads();
-    for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
-    if (tid == 0) a.status[0] = status;
-    if (PROF && lane == 0) {        // measurement only: per-wave busy cycles of the two phases, and the stage boundaries
-        long long *o = reinterpret_cast<long long *>(a.status + 4) + 40 + wave * 2;
-        o[0] = phA; o[1] = phB;
-        if (wave == 0) {
-            long long *g = reinterpret_cast<long long *>(a.status + 4);
-            g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
-        }
-    }
-}
-
 // ------------------------------------------------------------------ k_update
 __device__ inline void retract_pose(const float *pin, const float *xi, float *pout) {
     // poses' = Exp(xi) * G  (groups.py:153-156; so3.h:153-190; se3.h:134-142), in double
@@ -1624,12 +1301,6 @@ int solver_mode(const PlanDev &pd) {
     return 2;
 }
 
-// the panel-product (matrix core) variant of the double LDS solver; BT_SOLVER_MFMA=0: update rows on the vector ALUs
-static bool use_mfma_solver(const PlanDev &pd) {
-    static const int on = std::getenv("BT_SOLVER_MFMA") ? std::atoi(std::getenv("BT_SOLVER_MFMA")) : 1;   // measurement only
-    return on != 0 && pd.sy_ok != 0;
-}
-
 static int solver_threads() {
     // 12 waves: enough helper threads for one round of update rows on banded systems, and a
     // 170-register budget per thread so that a whole 6x6 operand block can be in flight from LDS
@@ -1659,12 +1330,6 @@ int configure_kernels(const PlanDev &pd) {
             if (hipFuncSetAttribute(fns[2 * mode + v], hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)solve_lds_bytes(pd, mode == 0 ? 8 : 4)) != hipSuccess)
                 return BT_EHIP;
-    if (mode == 0 && pd.sy_ok)
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_mfma<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_mfma_lds_bytes(pd)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_mfma<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_mfma_lds_bytes(pd)) != hipSuccess)
-            return BT_EHIP;
     return BT_OK;
 }
 
@@ -1701,9 +1366,7 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int mode = solver_mode(pd);
         const bool prof = (a.dbg & 16) != 0;
         const int nthr = solver_threads();
-        if (mode == 0 && use_mfma_solver(pd) && !prof) BT_LAUNCH(3, k_solve_mfma<false>, dim3(1), dim3(nthr), solve_mfma_lds_bytes(pd), pd, a);
-        else if (mode == 0 && use_mfma_solver(pd))     BT_LAUNCH(3, k_solve_mfma<true>, dim3(1), dim3(nthr), solve_mfma_lds_bytes(pd), pd, a);
-        else if (mode == 0 && !prof) BT_LAUNCH(3, (k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
+        if (mode == 0 && !prof)      BT_LAUNCH(3, (k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
         else if (mode == 0)          BT_LAUNCH(3, (k_solve_lds<double, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
         else if (mode == 1 && !prof) BT_LAUNCH(3, (k_solve_lds<float, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4), pd, a);
         else if (mode == 1)          BT_LAUNCH(3, (k_solve_lds<float, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4), pd, a);

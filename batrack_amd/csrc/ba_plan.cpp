@@ -465,52 +465,6 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             mrow[7] = pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l];     // columns in this level
         }
 
-    // ---- panel-product tiles (k_solve_mfma).  Column j's updates are the lower triangle of P P^T,
-    // P = [rows of its sub-diagonal blocks ; y_j] (6 cnt + 1 rows of 6), computed in 16x16 output
-    // tiles on the matrix cores.  Per level: the list of tiles (column slot | tile row << 8 |
-    // tile col << 16) and, per tile, where each of its 256 outputs is subtracted: an offset in
-    // elements from the factor's base (y sits right behind the factor), bit 15 = destination shared
-    // with another column of the level (LDS atomic), 0xffff = output not used.  Entry order is
-    // [tile][lane][reg] in the 16x16x4 f64 MFMA accumulator layout (row = (lane >> 4) + 4 reg, col = lane & 15).
-    pl->sy_ptr.assign((size_t)nlev + 1, 0);
-    pl->sy_tiles.clear();
-    pl->sy_dst.clear();
-    pl->sy_ok = (int64_t)pl->row_idx.size() * 36 + 6 * n <= 0x7fff ? 1 : 0;
-    if (pl->sy_ok) {
-        const int32_t zoff = (int32_t)pl->row_idx.size() * 36;
-        std::vector<int32_t> tri;
-        for (int32_t l = 0; l < nlev; ++l) {
-            pl->sy_ptr[(size_t)l] = (int32_t)pl->sy_tiles.size();
-            for (int32_t qi = pl->lvl_ptr[(size_t)l]; qi < pl->lvl_ptr[(size_t)l + 1]; ++qi) {
-                const int32_t j = pl->lvl_cols[(size_t)qi], q = qi - pl->lvl_ptr[(size_t)l];
-                const int32_t b = pl->col_ptr[(size_t)j] + 1, cnt = pl->col_ptr[(size_t)j + 1] - b;
-                if (cnt == 0) continue;
-                tri.assign((size_t)cnt * cnt, -1);
-                for (int32_t t = pl->upd_ptr[(size_t)j]; t < pl->upd_ptr[(size_t)j + 1]; ++t)
-                    tri[(size_t)(pl->upd[(size_t)t * 3] - b) * cnt + (pl->upd[(size_t)t * 3 + 1] - b)] = pl->upd[(size_t)t * 3 + 2];
-                const int32_t rows = 6 * cnt + 1, ntr = (rows + 15) / 16;
-                for (int32_t I = 0; I < ntr; ++I)
-                    for (int32_t J = 0; J <= I; ++J) {
-                        pl->sy_tiles.push_back(q | (I << 8) | (J << 16));
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int reg = 0; reg < 4; ++reg) {
-                                const int32_t pr = 16 * I + (lane >> 4) + 4 * reg, qc = 16 * J + (lane & 15);
-                                uint16_t off = 0xffff;
-                                if (qc < 6 * cnt && pr < 6 * cnt && pr / 6 >= qc / 6) {
-                                    const int32_t d = tri[(size_t)(pr / 6) * cnt + qc / 6];
-                                    off = (uint16_t)(((d & 0x7fff) * 36 + (pr % 6) * 6 + qc % 6) | (d & 0x8000));
-                                } else if (qc < 6 * cnt && pr == 6 * cnt) {
-                                    const int32_t blk = b + qc / 6;
-                                    off = (uint16_t)((zoff + 6 * pl->row_idx[(size_t)blk] + qc % 6) | ((pl->blk_col[(size_t)blk] >> 16) ? 0x8000 : 0));
-                                }
-                                pl->sy_dst.push_back(off);
-                            }
-                    }
-            }
-        }
-        pl->sy_ptr[(size_t)nlev] = (int32_t)pl->sy_tiles.size();
-    }
-
     layout_workspace(pl);
     return BT_OK;
 }

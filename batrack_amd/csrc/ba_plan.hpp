@@ -37,9 +37,6 @@ struct PlanDev {
     // elimination order and level schedule of the reduced solver
     int nlev, ndp;
     const int32_t *perm, *blk_src, *lvl_ptr, *lvl_cols, *col_lvl, *dp_ptr, *dp;
-    const int32_t *sy_ptr, *sy_tiles;   // panel-product tiles per level (k_solve_mfma); sy_ok = 0: not available
-    const uint16_t *sy_dst;
-    int sy_ok, sy_ntiles;
     const int32_t *lvl_meta;   // [nlev][kMaxLevelCols][8]: col, diag pos, #sub-blocks, first rest triple, #rest triples, dp first, #dp, 0  (col = -1: unused)
 };
 
@@ -64,9 +61,6 @@ struct bt_plan {
     int max_tile_pairs = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
     std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp, lvl_meta;
-    std::vector<int32_t> sy_ptr, sy_tiles;      // panel-product tiles of the MFMA solver, per level
-    std::vector<uint16_t> sy_dst;               // [tile][lane][reg] destination offsets
-    int sy_ok = 0;
     int max_rows16 = 16;
     bt::WsLayout ws{};
     void *dev_base = nullptr;   // one device allocation holding every array above

@@ -10,12 +10,11 @@ import numpy as np
 
 from . import _lib
 
-_NP_TYPES = {"slot_lab": np.uint16, "slot_lp": np.uint8, "sy_dst": np.uint16}
+_NP_TYPES = {"slot_lab": np.uint16, "slot_lp": np.uint8}
 PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0", "tile_ntrk", "tile_ncam",
                "tile_cam0", "tile_slot0", "tile_nslot", "tile_erow0", "tile_cams", "slot_edge", "slot_pair",
                "slot_lab", "col_ptr", "row_idx", "upd_ptr", "upd", "blk_col", "upd_next", "perm", "blk_src",
-               "lvl_ptr", "lvl_cols", "col_lvl", "dp_ptr", "dp", "tile_pair0", "tile_npair", "tile_pairs", "slot_lp", "tile_flags",
-               "sy_ptr", "sy_tiles", "sy_dst")
+               "lvl_ptr", "lvl_cols", "col_lvl", "dp_ptr", "dp", "tile_pair0", "tile_npair", "tile_pairs", "slot_lp", "tile_flags")
 
 
 class Plan:

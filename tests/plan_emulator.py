@@ -134,9 +134,6 @@ def run(plan, A, inp, wkey, lmbda=1e-4, ep=10.0, alpha=0.05, structure_only=Fals
     dX = np.zeros((n, 6))
     if not so:
         dX = sparse_chol_solve(A, S, y, n, ep, 1e-4)
-        if len(A["sy_tiles"]) or n <= 1:
-            dX2 = sparse_chol_solve_tiles(A, S, y, n, ep, 1e-4)
-            assert np.allclose(dX, dX2, rtol=1e-9, atol=1e-12 * max(1.0, np.abs(dX).max())), "tile solver differs from the triple solver"
         out["dX"] = dX
     # update
     patches_out = inp["patches"].copy()
@@ -236,87 +233,6 @@ def sparse_chol_solve(A, S_lower, y, n, ep, lm):
                 L[s] = L[s] @ Linv[c].T
     assert np.all(applied == 1), "every update triple must be applied exactly once"
     x = z.copy()
-    for l in range(nlev - 1, -1, -1):
-        for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]:
-            tq = x[6*c:6*c + 6].copy()
-            for s in range(col_ptr[c] + 1, col_ptr[c + 1]):
-                i = int(row_idx[s])
-                tq -= L[s].T @ x[6*i:6*i + 6]
-            x[6*c:6*c + 6] = Linv[c].T @ tq
-    out = np.zeros((n, 6))
-    out[perm] = x.reshape(n, 6)
-    return out
-
-
-def sparse_chol_solve_tiles(A, S_lower, y, n, ep, lm):
-    """k_solve_mfma: the same factorisation with every column's updates done as 16x16 tiles of the
-    panel product P P^T (P = [sub-diagonal block rows ; y_j]) scattered through sy_dst.  Checks
-    that no destination is written twice without the shared flag."""
-    col_ptr, row_idx = A["col_ptr"], A["row_idx"]
-    perm, blk_src, blk_col = A["perm"], A["blk_src"], A["blk_col"] & 255
-    lvl_ptr, lvl_cols = A["lvl_ptr"], A["lvl_cols"]
-    sy_ptr, sy_tiles, sy_dst = A["sy_ptr"], A["sy_tiles"], A["sy_dst"].reshape(-1, 64, 4)
-    nnzb, nlev = len(row_idx), len(lvl_ptr) - 1
-    assert len(sy_ptr) == nlev + 1 and sy_ptr[-1] == len(sy_tiles) == len(sy_dst)
-    mem = np.zeros(nnzb * 36 + 6 * n)                     # factor blocks (row-major 6x6), then y
-    zoff = nnzb * 36
-    for b in range(nnzb):
-        src = int(blk_src[b]); rn, cn, tr = src >> 9, (src >> 1) & 255, src & 1
-        blk = S_lower[6*rn:6*rn + 6, 6*cn:6*cn + 6].copy()
-        if row_idx[b] == blk_col[b]:
-            blk = np.tril(blk)
-            blk[np.diag_indices(6)] += ep + lm * np.diag(blk)
-        elif tr:
-            blk = blk.T.copy()
-        mem[36*b:36*b + 36] = blk.reshape(-1)
-    mem[zoff:] = y.reshape(n, 6)[perm].reshape(-1)
-    Linv = np.zeros((n, 6, 6))
-    lane = np.arange(64)
-    for l in range(nlev):
-        cols = lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]
-        # phase A: factor the diagonal block, forward-substitute the panel rows and y_j
-        for c in cols:
-            d = int(col_ptr[c])
-            blk = mem[36*d:36*d + 36].reshape(6, 6)
-            Lj = np.linalg.cholesky(np.tril(blk) + np.tril(blk, -1).T)
-            Linv[c] = np.linalg.inv(Lj)
-            mem[36*d:36*d + 36] = Lj.reshape(-1)
-            for s in range(d + 1, col_ptr[c + 1]):
-                mem[36*s:36*s + 36] = (mem[36*s:36*s + 36].reshape(6, 6) @ Linv[c].T).reshape(-1)
-            mem[zoff + 6*c:zoff + 6*c + 6] = Linv[c] @ mem[zoff + 6*c:zoff + 6*c + 6]
-        # phase B: the tiles of this level (reads first, then all writes: sources and destinations are disjoint)
-        writes = {}
-        deltas = []
-        covered = {int(c): set() for c in cols}
-        for t in range(sy_ptr[l], sy_ptr[l + 1]):
-            desc = int(sy_tiles[t]); q, I, J = desc & 255, (desc >> 8) & 255, desc >> 16
-            c = int(cols[q]); d = int(col_ptr[c]); cnt = int(col_ptr[c + 1]) - d - 1
-            assert cnt > 0 and J <= I and 16 * I < 6 * cnt + 1
-            P = np.zeros((max(6 * cnt + 1, 16 * (I + 1)) + 16, 6))
-            P[:6 * cnt] = mem[36*(d + 1):36*(d + 1 + cnt)].reshape(-1, 6)
-            P[6 * cnt] = mem[zoff + 6*c:zoff + 6*c + 6]
-            out = P[16*I:16*I + 16] @ P[16*J:16*J + 16].T
-            for reg in range(4):
-                rows, cs = (lane >> 4) + 4 * reg, lane & 15
-                offs = sy_dst[t, :, reg]
-                for ln in np.nonzero(offs != 0xffff)[0]:
-                    off, fl = int(offs[ln]) & 0x7fff, int(offs[ln]) >> 15
-                    deltas.append((off, out[rows[ln], cs[ln]]))
-                    writes.setdefault(off, []).append((c, fl))
-                    covered[c].add((16*I + int(rows[ln]), 16*J + int(cs[ln])))
-        for off, ws in writes.items():
-            writers = {w[0] for w in ws}
-            assert len(ws) == len(writers), "one column writes a destination twice"
-            assert all(w[1] == (1 if len(writers) > 1 else 0) for w in ws), "shared flag wrong"
-        for c in cols:                                   # every needed output is produced
-            c = int(c); cnt = int(col_ptr[c + 1]) - int(col_ptr[c]) - 1
-            need = {(p, q) for p in range(6 * cnt) for q in range(6 * cnt) if p // 6 > q // 6 or (p // 6 == q // 6 and p % 6 >= q % 6)}
-            need |= {(6 * cnt, q) for q in range(6 * cnt)}
-            assert need <= covered[c]
-        for off, v in deltas:
-            mem[off] -= v
-    L = mem[:zoff].reshape(nnzb, 6, 6)
-    x = mem[zoff:].copy()
     for l in range(nlev - 1, -1, -1):
         for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]:
             tq = x[6*c:6*c + 6].copy()
