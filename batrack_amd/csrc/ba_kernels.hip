@@ -1182,6 +1182,389 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
 #undef BT_PF
 }
 
+// ------------------------------------------------------------------ k_solve_fused
+// The LDS-resident factorisation with ONE phase and one barrier per level.
+//   column waves   (64 panel rows each, rows of one column per wave so its metadata is scalar):
+//                  lanes 0..35 bring the column's diagonal block up to date with the "pending"
+//                  updates (sources: the level right below) into a per-wave scratch; every
+//                  lane then applies the pending updates of its own panel row (or of y_j) in
+//                  registers, factors the 6x6 block redundantly and forward-substitutes its row
+//   helper waves   the "lazy" updates of the level below (destinations two or more levels up)
+//                  and its lazy y contributions, concurrently
+// Against k_solve_lds (two phases: factor | substitute) this removes a barrier, the
+// store/reload of L_jj between the phases and the wait of the substitution for the slowest
+// helper; the chain per level is the 6x6 factorisation plus one update row.
+template <typename T>
+__device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArgs &a, T *Lw, T *z, const int *row_idx,
+                                                double lm, int tid, int nth) {
+    const int nnzb = pd.nnzb, D = pd.D;
+    for (int base = 0; base < nnzb * 6; base += 2 * nth) {
+        double v[2][6];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = base + u * nth + tid;
+            if (idx < nnzb * 6) {
+                const int b = idx / 6, r = idx - 6 * b, src = pd.blk_src[b];
+                const int rn = src >> 9, cn = (src >> 1) & 255;
+                if (src & 1) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) v[u][c] = a.S[(size_t)(6 * rn + c) * D + 6 * cn + r];
+                } else {
+                    const double *p = a.S + (size_t)(6 * rn + r) * D + 6 * cn;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) v[u][c] = p[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = base + u * nth + tid;
+            if (idx < nnzb * 6) {
+                const int b = idx / 6, r = idx - 6 * b, rc = row_idx[b];
+                const bool diag = (rc & 255) == ((rc >> 8) & 255);
+                T w[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double x = (!diag || r >= c) ? v[u][c] : 0.0;
+                    if (diag && r == c) x = x + ((double)a.ep + lm * x);          // ba.py:67
+                    w[c] = (T)x;
+                }
+                store_row6(Lw + (size_t)b * 36 + 6 * r, w);
+            }
+        }
+    }
+    for (int i = tid; i < D; i += nth) z[i] = (T)a.y[6 * pd.perm[i / 6] + i % 6];
+}
+
+// Back substitution of the LDS-resident factor (diagonal blocks hold L_jj with 1/l_cc on the
+// diagonal): brings it into M form, then x_j = zt_j - sum_{i>j} M_ij x_i by levels, descending.
+template <typename T>
+__device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T *z, T *zt, const int *row_idx,
+                                                    const int *col_ptr, const int4 *lvl_meta, int mstride, int tid, int nth) {
+    const int n = pd.n, nnzb = pd.nnzb, nlev = pd.nlev, wave = tid >> 6, lane = tid & 63;
+    for (int j = tid; j < n; j += nth) {
+        T *dblk = Lw + (size_t)col_ptr[j] * 36;
+        T L[21], li[21];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) L[BT_LT(r, c)] = dblk[6 * r + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            li[BT_LT(c, c)] = L[BT_LT(c, c)];
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) {
+                T t = (T)0;
+#pragma unroll
+                for (int k = c; k < r; ++k) t += L[BT_LT(r, k)] * li[BT_LT(k, c)];
+                li[BT_LT(r, c)] = -t * L[BT_LT(r, r)];
+            }
+        }
+#pragma unroll
+        for (int r = 1; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < r; ++c) dblk[6 * c + r] = li[BT_LT(r, c)];      // Linv[r][c] at [c][r]
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nnzb * 6 + n; idx += nth) {
+        int j;
+        T *p, *q;
+        if (idx < nnzb * 6) {
+            const int b = idx / 6, r = idx - 6 * b;
+            j = (row_idx[b] >> 8) & 255;
+            if ((row_idx[b] & 255) == j) continue;
+            p = Lw + (size_t)b * 36 + 6 * r; q = p;
+        } else {
+            j = idx - nnzb * 6;
+            p = z + 6 * j; q = zt + 6 * j;
+        }
+        const T *dblk = Lw + (size_t)col_ptr[j] * 36;
+        T in[6], out[6];
+        load_row6(p, in);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            T t = dblk[7 * c] * in[c];
+#pragma unroll
+            for (int k = c + 1; k < 6; ++k) t += dblk[6 * c + k] * in[k];
+            out[c] = t;
+        }
+        store_row6(q, out);
+    }
+    __syncthreads();
+    for (int l = nlev - 1; l >= 0; --l) {
+        const int4 ma = uniform4(lvl_meta[(l * kMaxLevelCols + (wave < kMaxLevelCols ? wave : 0)) * mstride]);
+        if (wave < kMaxLevelCols && ma.x >= 0) {
+            const int c = lane >> 3, g = lane & 7;
+            const int j = ma.x, dpos = ma.y, cnt = ma.z;
+            T acc = (T)0;
+            if (c < 6)
+                for (int sb = g; sb < cnt; sb += 8) {           // one sub-block per lane group
+                    const int b = dpos + 1 + sb;
+                    T x[6];
+                    load_row6(zt + 6 * (row_idx[b] & 255), x);
+                    const T *mb = Lw + (size_t)b * 36 + c;     // Mt[r][c]
+                    acc += mb[0] * x[0] + mb[6] * x[1] + mb[12] * x[2] + mb[18] * x[3] + mb[24] * x[4] + mb[30] * x[5];
+                }
+            acc = dpp_add8(acc);
+            if (c < 6 && g == 0) zt[6 * j + c] -= acc;
+        }
+        __syncthreads();
+    }
+}
+
+
+// LDS of k_solve_fused: Lw | z | work | row_idx | col_ptr, where `work` holds the sweep's tables (per-wave
+// scratch, staged L_jj, lazy triples, pending pairs and their pointers) and is reused for zt afterwards.
+// The per-level metadata stays in global memory (prefetched a level ahead).
+__host__ __device__ inline size_t fused_work_bytes(const PlanDev &pd, int nthreads) {
+    const size_t nw = (size_t)nthreads / 64;
+    const size_t b = (nw * 36 + 2 * kMaxLevelCols * 36) * sizeof(double) +
+                     ((size_t)pd.fz_nlazy * 3 + (size_t)pd.fz_npend * 2 + (size_t)pd.nnzb + 1) * sizeof(unsigned short);
+    const size_t zt = (size_t)pd.D * sizeof(double) + (size_t)pd.nlev * kMaxLevelCols * sizeof(int4);   // zt + compact level table
+    return ((b > zt ? b : zt) + 15) / 16 * 16;
+}
+size_t solve_fused_lds_bytes(const PlanDev &pd, int nthreads) {
+    return ((size_t)pd.nnzb * 36 + (size_t)pd.D) * sizeof(double) + fused_work_bytes(pd, nthreads) +
+           ((size_t)pd.nnzb + (size_t)pd.n + 1) * sizeof(int) + 64;
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
+    typedef double T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int flags[2];
+    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
+    const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
+    T *Lw = reinterpret_cast<T *>(smem);
+    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr, *dstage = scr + (size_t)nw * 36;
+    unsigned short *lazy = reinterpret_cast<unsigned short *>(dstage + 2 * kMaxLevelCols * 36), *pend = lazy + (size_t)pd.fz_nlazy * 3,
+                   *pend_ptr = pend + (size_t)pd.fz_npend * 2;
+    int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + fused_work_bytes(pd, nth)), *col_ptr = row_idx + nnzb;
+    const int4 *meta = reinterpret_cast<const int4 *>(pd.fz_meta);
+    // row | col << 8 | shared-y << 24 | pending-y << 25
+    for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8) | (pd.fz_yurg[i] << 25);
+    for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
+    long long phA = 0, phL = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0;
+    __syncthreads();
+
+    int status = BT_SOLVE_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const double lm = attempt == 0 ? 1e-4 : 1e-3;
+        if (tid < 2) flags[tid] = 0;
+        // the sweep's tables (their LDS is reused for zt by the back substitution, so a retry reloads them)
+        for (int i = tid; i < pd.fz_nlazy * 3; i += nth) lazy[i] = (unsigned short)pd.fz_lazy[i];
+        for (int i = tid; i < pd.fz_npend * 2; i += nth) pend[i] = (unsigned short)pd.fz_pend[i];
+        for (int i = tid; i <= nnzb; i += nth) pend_ptr[i] = (unsigned short)pd.fz_pend_ptr[i];
+        lds_load_system<T>(pd, a, Lw, z, row_idx, lm, tid, nth);
+        __syncthreads();
+        if (PROF) tload = clock64() - tall;
+
+        // wave-uniform level metadata, read from global memory one level ahead
+        int4 cA0, cA1, cA2, cA3, cB0, cB1, cB2, cB3, pA0, pA1, pA2, pA3, nx[2 * kMaxLevelCols];
+        int pn0 = 0, pn1 = 0, pn2 = 0, pn3 = 0, pnc = 0;
+        pA0 = pA1 = pA2 = pA3 = make_int4(-1, 0, 0, 0);
+        auto prefetch_level = [&](int l) {
+#pragma unroll
+            for (int i = 0; i < 2 * kMaxLevelCols; ++i) nx[i] = meta[(size_t)l * kMaxLevelCols * 2 + i];
+        };
+        auto take_level = [&]() {
+            cA0 = uniform4(nx[0]); cA1 = uniform4(nx[2]); cA2 = uniform4(nx[4]); cA3 = uniform4(nx[6]);
+            cB0 = uniform4(nx[1]); cB1 = uniform4(nx[3]); cB2 = uniform4(nx[5]); cB3 = uniform4(nx[7]);
+        };
+        prefetch_level(0);
+        take_level();
+        for (int l = 0; l < nlev; ++l) {
+            if (PROF) tph = clock64();
+            if (l + 1 < nlev) prefetch_level(l + 1);
+            const int nA = cB3.y + cB3.z;                   // waves of panel rows in this level
+            // ---- the level's columns
+            for (int aw = wave; aw < nA; aw += nw) {
+                __builtin_amdgcn_s_setprio(3);
+                const int q = (aw >= cB1.y ? 1 : 0) + (aw >= cB2.y ? 1 : 0) + (aw >= cB3.y ? 1 : 0);
+                const int4 ma = q == 0 ? cA0 : q == 1 ? cA1 : q == 2 ? cA2 : cA3;
+                const int w0 = q == 0 ? cB0.y : q == 1 ? cB1.y : q == 2 ? cB2.y : cB3.y;
+                const int j = ma.x, dpos = ma.y, cnt = ma.z, part = aw - w0;
+                const int dp0 = __builtin_amdgcn_readfirstlane(pend_ptr[dpos]), dp1 = __builtin_amdgcn_readfirstlane(pend_ptr[dpos + 1]);
+                const int rw = part * 64 + lane;
+                const bool valid = rw <= cnt * 6, isy = rw == cnt * 6;
+                // own row: where it lives and its pending updates
+                const int sb = rw / 6, r = rw - 6 * sb, bown = dpos + 1 + sb;
+                T *p = isy ? z + 6 * j : Lw + (size_t)bown * 36 + 6 * r;
+                int k0 = dp0, k1 = dp1;
+                if (valid && !isy) { k0 = pend_ptr[bown]; k1 = pend_ptr[bown + 1]; }
+                if (!valid) k1 = k0;
+                T in[6];
+                if (valid) load_row6(p, in);
+                // (1) diagonal block + pending updates -> per-wave scratch (lanes 0..35, one element each)
+                if (lane < 36) {
+                    const int dr = lane / 6, dc = lane - 6 * dr;
+                    T v = Lw[(size_t)dpos * 36 + lane];
+                    for (int k = dp0; k < dp1; ++k) {
+                        const T *src = Lw + (size_t)pend[2 * k] * 36;
+                        T x[6], yv[6];
+                        load_row6(src + 6 * dr, x);
+                        load_row6(src + 6 * dc, yv);
+                        T acc = x[0] * yv[0];
+#pragma unroll
+                        for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
+                        v -= acc;
+                    }
+                    scr[wave * 36 + lane] = v;
+                }
+                // (2) pending updates of the own row: in[c] -= sum_e avec[e] M[c][e]
+                for (int k = k0; k < k1; ++k) {
+                    const int s1 = pend[2 * k], s2 = pend[2 * k + 1];
+                    const T *av = isy ? z + 6 * ((row_idx[s1] >> 8) & 255) : Lw + (size_t)s1 * 36 + 6 * r;
+                    const T *M = Lw + (size_t)(isy ? s1 : s2) * 36;
+                    T avec[6], m[36];
+                    load_row6(av, avec);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) load_row6(M + 6 * c, reinterpret_cast<T (&)[6]>(m[6 * c]));
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        T acc = avec[0] * m[6 * c];
+#pragma unroll
+                        for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
+                        in[c] -= acc;
+                    }
+                }
+                wave_fence();
+                // (3) factor the updated diagonal block (every lane, in registers) and substitute the own row
+                T L[21];
+                const T *dblk = scr + wave * 36;
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) {
+                    T row[6];
+                    load_row6(dblk + 6 * rr, row);
+#pragma unroll
+                    for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
+                }
+                const bool ok = chol6_packed<T>(L);
+                if (valid) {
+                    T out[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        T t = in[c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
+                        out[c] = t * L[BT_LT(c, c)];
+                    }
+                    store_row6(p, out);
+                }
+                if (part == 0 && lane == 0) {          // L_jj is put in place one level later (its readers run after the sweep)
+                    if (!ok) flags[0] = 1;
+                    T *ds = dstage + (size_t)((l & 1) * kMaxLevelCols + q) * 36;
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) {
+                        T row[6];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) row[c] = L[BT_LT(rr, c <= rr ? c : rr)];
+                        store_row6(ds + 6 * rr, row);
+                    }
+                }
+                wave_fence();                              // scratch is reused by this wave's next column
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); phA += tn - tph; tph = tn; }
+            // ---- lazy work of the level below
+            if (l > 0) {
+                int h, hs;
+                if (nA < nw) { h = tid - 64 * nA; hs = nth - 64 * nA; }
+                else { hs = nth; h = (tid + nth - (64 * nA) % nth) % nth; }
+                if (h >= 0) {
+                    {   // staged L_jj of the previous level -> their diagonal blocks
+                        const int back = hs - 1 - h;
+                        if (back < pnc * 18) {
+                            const int q = back / 18, e = back - 18 * q;
+                            const int dpos = q == 0 ? pA0.y : q == 1 ? pA1.y : q == 2 ? pA2.y : pA3.y;
+                            reinterpret_cast<double2 *>(Lw + (size_t)dpos * 36)[e] =
+                                reinterpret_cast<const double2 *>(dstage + (size_t)(((l - 1) & 1) * kMaxLevelCols + q) * 36)[e];
+                        }
+                    }
+                    int rows_b[kMaxLevelCols + 1];
+                    rows_b[0] = 0;
+                    rows_b[1] = pA0.x >= 0 ? pn0 * 6 : 0;
+                    rows_b[2] = rows_b[1] + (pA1.x >= 0 ? pn1 * 6 : 0);
+                    rows_b[3] = rows_b[2] + (pA2.x >= 0 ? pn2 * 6 : 0);
+                    rows_b[4] = rows_b[3] + (pA3.x >= 0 ? pn3 * 6 : 0);
+                    for (int item = h; item < rows_b[kMaxLevelCols]; item += hs) {
+                        int q = 0;
+#pragma unroll
+                        for (int k = 1; k < kMaxLevelCols; ++k) q += item >= rows_b[k] ? 1 : 0;
+                        const int idx = item - (q == 0 ? 0 : q == 1 ? rows_b[1] : q == 2 ? rows_b[2] : rows_b[3]);
+                        const int4 pa = q == 0 ? pA0 : q == 1 ? pA1 : q == 2 ? pA2 : pA3;
+                        const int t = idx / 6;
+                        apply_update_row<T, false>(Lw, lazy + 3 * (pa.w + t), idx - 6 * t);
+                    }
+                    int ys_b[kMaxLevelCols + 1];
+                    ys_b[0] = 0;
+                    ys_b[1] = pA0.x >= 0 ? pA0.z * 6 : 0;
+                    ys_b[2] = ys_b[1] + (pA1.x >= 0 ? pA1.z * 6 : 0);
+                    ys_b[3] = ys_b[2] + (pA2.x >= 0 ? pA2.z * 6 : 0);
+                    ys_b[4] = ys_b[3] + (pA3.x >= 0 ? pA3.z * 6 : 0);
+                    const int shift = ((rows_b[kMaxLevelCols] + 63) >> 6) << 6;
+                    for (int item = (h - shift % hs + hs) % hs; item < ys_b[kMaxLevelCols]; item += hs) {
+                        int q = 0;
+#pragma unroll
+                        for (int k = 1; k < kMaxLevelCols; ++k) q += item >= ys_b[k] ? 1 : 0;
+                        const int qq = item - (q == 0 ? 0 : q == 1 ? ys_b[1] : q == 2 ? ys_b[2] : ys_b[3]);
+                        const int4 pa = q == 0 ? pA0 : q == 1 ? pA1 : q == 2 ? pA2 : pA3;
+                        const int pj = pa.x, dposp = pa.y, sb = qq / 6, r = qq - 6 * sb;
+                        const int rcv = row_idx[dposp + 1 + sb];
+                        if (rcv & (1 << 25)) continue;            // pending: the destination column's y thread takes it
+                        T lr[6], zr[6];
+                        load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
+                        load_row6(z + 6 * pj, zr);
+                        T acc = lr[0] * zr[0];
+#pragma unroll
+                        for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
+                        lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv & (1 << 24)) != 0);
+                    }
+                }
+            }
+            if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); phL += clock64() - tph; }
+            pA0 = cA0; pA1 = cA1; pA2 = cA2; pA3 = cA3; pn0 = cB0.x; pn1 = cB1.x; pn2 = cB2.x; pn3 = cB3.x; pnc = cB0.w;
+            if (l + 1 < nlev) take_level();
+            __syncthreads();
+        }
+        // the last level's staged diagonal blocks (its columns have no lazy work: nothing lies above them)
+        if (tid < pnc * 18) {
+            const int q = tid / 18, e = tid - 18 * q;
+            const int dpos = q == 0 ? pA0.y : q == 1 ? pA1.y : q == 2 ? pA2.y : pA3.y;
+            reinterpret_cast<double2 *>(Lw + (size_t)dpos * 36)[e] =
+                reinterpret_cast<const double2 *>(dstage + (size_t)(((nlev - 1) & 1) * kMaxLevelCols + q) * 36)[e];
+        }
+        __syncthreads();
+        if (PROF) tsweep = clock64() - tall;
+
+        int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
+        for (int i = tid; i < nlev * kMaxLevelCols; i += nth) bmeta[i] = meta[2 * i];
+        lds_back_substitute<T>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth);
+        for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
+        __syncthreads();
+        const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
+        __syncthreads();
+        if (failed) {
+            for (int i = tid; i < D; i += nth) zt[i] = (T)0;
+            status = BT_SOLVE_CHOL_FAILED;
+            break;
+        }
+        if (!has_nan) break;
+        status = BT_SOLVE_RETRIED;
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
+    if (tid == 0) a.status[0] = status;
+    if (PROF && lane == 0) {        // measurement only: per-wave busy cycles (columns, lazy work) and the stage boundaries
+        long long *o = reinterpret_cast<long long *>(a.status + 4) + 40 + wave * 2;
+        o[0] = phA; o[1] = phL;
+        if (wave == 0) {
+            long long *g = reinterpret_cast<long long *>(a.status + 4);
+            g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ k_update
 __device__ inline void retract_pose(const float *pin, const float *xi, float *pout) {
     // poses' = Exp(xi) * G  (groups.py:153-156; so3.h:153-190; se3.h:134-142), in double
@@ -1301,6 +1684,13 @@ int solver_mode(const PlanDev &pd) {
     return 2;
 }
 
+static int solver_threads();
+// one-phase-per-level variant of the double LDS solver; BT_SOLVER_FUSED=0: the two-phase k_solve_lds
+static bool use_fused_solver(const PlanDev &pd) {
+    static const int on = std::getenv("BT_SOLVER_FUSED") ? std::atoi(std::getenv("BT_SOLVER_FUSED")) : 1;   // measurement only
+    return on != 0 && solve_fused_lds_bytes(pd, solver_threads()) <= kLdsBudget;
+}
+
 static int solver_threads() {
     // 12 waves: enough helper threads for one round of update rows on banded systems, and a
     // 170-register budget per thread so that a whole 6x6 operand block can be in flight from LDS
@@ -1330,6 +1720,12 @@ int configure_kernels(const PlanDev &pd) {
             if (hipFuncSetAttribute(fns[2 * mode + v], hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)solve_lds_bytes(pd, mode == 0 ? 8 : 4)) != hipSuccess)
                 return BT_EHIP;
+    if (mode == 0 && use_fused_solver(pd))
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_fused_lds_bytes(pd, solver_threads())) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_fused_lds_bytes(pd, solver_threads())) != hipSuccess)
+            return BT_EHIP;
     return BT_OK;
 }
 
@@ -1366,7 +1762,9 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int mode = solver_mode(pd);
         const bool prof = (a.dbg & 16) != 0;
         const int nthr = solver_threads();
-        if (mode == 0 && !prof)      BT_LAUNCH(3, (k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
+        if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH(3, k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
+        else if (mode == 0 && use_fused_solver(pd))     BT_LAUNCH(3, k_solve_fused<true>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
+        else if (mode == 0 && !prof) BT_LAUNCH(3, (k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
         else if (mode == 0)          BT_LAUNCH(3, (k_solve_lds<double, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
         else if (mode == 1 && !prof) BT_LAUNCH(3, (k_solve_lds<float, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4), pd, a);
         else if (mode == 1)          BT_LAUNCH(3, (k_solve_lds<float, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4), pd, a);

@@ -465,6 +465,57 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             mrow[7] = pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l];     // columns in this level
         }
 
+    // ---- fused schedule (k_solve_fused): ONE phase and one barrier per level.  A column's wave
+    // applies the updates coming from the level right below to its own diagonal block and panel
+    // rows itself ("pending": listed per destination block), factors and substitutes; every other
+    // update ("lazy": destination two or more levels up) runs on the helper waves one level later,
+    // concurrently with the next level's columns.
+    //   fz_pend_ptr[nnzb+1], fz_pend[2 k]      (src1, src2) of the pending triples of a block
+    //   fz_lazy_ptr[n+1],  fz_lazy[3 k]        lazy triples of a column (src1, src2, dst | shared << 15)
+    //   fz_yurg[nnzb]                          1: the y contribution of this block is pending, not lazy
+    //   fz_meta[nlev][kMaxLevelCols][8]        col, diag pos, #sub-blocks, first lazy triple, #lazy,
+    //                                          first wave of the column, #waves (64 panel rows each), #cols
+    {
+        const size_t nb = pl->row_idx.size();
+        std::vector<std::vector<int32_t>> pend(nb);
+        pl->fz_lazy_ptr.assign((size_t)n + 1, 0);
+        pl->fz_lazy.clear();
+        pl->fz_yurg.assign(nb, 0);
+        for (int64_t j = 0; j < n; ++j) {
+            pl->fz_lazy_ptr[(size_t)j] = (int32_t)(pl->fz_lazy.size() / 3);
+            for (int32_t t = pl->upd_ptr[(size_t)j]; t < pl->upd_ptr[(size_t)j + 1]; ++t) {
+                const int32_t s1 = pl->upd[(size_t)t * 3], s2 = pl->upd[(size_t)t * 3 + 1], d = pl->upd[(size_t)t * 3 + 2];
+                const int32_t dcol = pl->row_idx[(size_t)s2];
+                if (lvl[(size_t)dcol] == lvl[(size_t)j] + 1) { pend[(size_t)(d & 0x7fff)].push_back(s1); pend[(size_t)(d & 0x7fff)].push_back(s2); }
+                else { pl->fz_lazy.push_back(s1); pl->fz_lazy.push_back(s2); pl->fz_lazy.push_back(d); }
+            }
+            for (int32_t b = pl->col_ptr[(size_t)j] + 1; b < pl->col_ptr[(size_t)j + 1]; ++b)
+                if (lvl[(size_t)pl->row_idx[(size_t)b]] == lvl[(size_t)j] + 1) pl->fz_yurg[(size_t)b] = 1;
+        }
+        pl->fz_lazy_ptr[(size_t)n] = (int32_t)(pl->fz_lazy.size() / 3);
+        pl->fz_pend_ptr.assign(nb + 1, 0);
+        pl->fz_pend.clear();
+        for (size_t b = 0; b < nb; ++b) {
+            pl->fz_pend_ptr[b] = (int32_t)(pl->fz_pend.size() / 2);
+            pl->fz_pend.insert(pl->fz_pend.end(), pend[b].begin(), pend[b].end());
+        }
+        pl->fz_pend_ptr[nb] = (int32_t)(pl->fz_pend.size() / 2);
+        pl->fz_meta.assign((size_t)nlev * kMaxLevelCols * 8, 0);
+        for (int32_t l = 0; l < nlev; ++l) {
+            int32_t w0 = 0;
+            for (int q = 0; q < kMaxLevelCols; ++q) {
+                int32_t *mrow = pl->fz_meta.data() + ((size_t)l * kMaxLevelCols + q) * 8;
+                if (pl->lvl_ptr[(size_t)l] + q >= pl->lvl_ptr[(size_t)l + 1]) { mrow[0] = -1; mrow[5] = w0; continue; }
+                const int32_t j = pl->lvl_cols[(size_t)pl->lvl_ptr[(size_t)l] + q];
+                mrow[0] = j; mrow[1] = pl->col_ptr[(size_t)j]; mrow[2] = pl->col_ptr[(size_t)j + 1] - pl->col_ptr[(size_t)j] - 1;
+                mrow[3] = pl->fz_lazy_ptr[(size_t)j]; mrow[4] = pl->fz_lazy_ptr[(size_t)j + 1] - mrow[3];
+                mrow[5] = w0; mrow[6] = (6 * mrow[2] + 1 + 63) / 64;
+                mrow[7] = pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l];
+                w0 += mrow[6];
+            }
+        }
+    }
+
     layout_workspace(pl);
     return BT_OK;
 }

@@ -134,6 +134,8 @@ def run(plan, A, inp, wkey, lmbda=1e-4, ep=10.0, alpha=0.05, structure_only=Fals
     dX = np.zeros((n, 6))
     if not so:
         dX = sparse_chol_solve(A, S, y, n, ep, 1e-4)
+        dX2 = sparse_chol_solve_fused(A, S, y, n, ep, 1e-4)
+        assert np.allclose(dX, dX2, rtol=1e-9, atol=1e-12 * max(1.0, np.abs(dX).max())), "fused schedule differs from the two-phase schedule"
         out["dX"] = dX
     # update
     patches_out = inp["patches"].copy()
@@ -232,6 +234,108 @@ def sparse_chol_solve(A, S_lower, y, n, ep, lm):
                 assert col_lvl[row_idx[s]] > l
                 L[s] = L[s] @ Linv[c].T
     assert np.all(applied == 1), "every update triple must be applied exactly once"
+    x = z.copy()
+    for l in range(nlev - 1, -1, -1):
+        for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]:
+            tq = x[6*c:6*c + 6].copy()
+            for s in range(col_ptr[c] + 1, col_ptr[c + 1]):
+                i = int(row_idx[s])
+                tq -= L[s].T @ x[6*i:6*i + 6]
+            x[6*c:6*c + 6] = Linv[c].T @ tq
+    out = np.zeros((n, 6))
+    out[perm] = x.reshape(n, 6)
+    return out
+
+
+def sparse_chol_solve_fused(A, S_lower, y, n, ep, lm):
+    """k_solve_fused: one phase per level.  The waves of a column apply the pending updates (sources
+    one level below) to the column's own blocks, factor and substitute; the lazy updates of the level
+    below run concurrently on the helper waves.  Checks that the two groups touch disjoint data."""
+    col_ptr, row_idx = A["col_ptr"], A["row_idx"]
+    perm, blk_src, blk_col, yshared = A["perm"], A["blk_src"], A["blk_col"] & 255, A["blk_col"] >> 16
+    lvl_ptr, lvl_cols, col_lvl = A["lvl_ptr"], A["lvl_cols"], A["col_lvl"]
+    pend_ptr, pend = A["fz_pend_ptr"], A["fz_pend"].reshape(-1, 2)
+    lazy_ptr, lazy, yurg = A["fz_lazy_ptr"], A["fz_lazy"].reshape(-1, 3), A["fz_yurg"]
+    meta = A["fz_meta"].reshape(-1, 4, 8)
+    nnzb, nlev = len(row_idx), len(lvl_ptr) - 1
+    assert len(pend) + len(lazy) == len(A["upd"]) // 3, "every update triple is either pending or lazy"
+    L = np.zeros((nnzb, 6, 6))
+    for b in range(nnzb):
+        src = int(blk_src[b]); rn, cn, tr = src >> 9, (src >> 1) & 255, src & 1
+        blk = S_lower[6*rn:6*rn + 6, 6*cn:6*cn + 6].copy()
+        if row_idx[b] == blk_col[b]:
+            blk = np.tril(blk)
+            blk[np.diag_indices(6)] += ep + lm * np.diag(blk)
+        elif tr:
+            blk = blk.T.copy()
+        L[b] = blk
+    z = y.reshape(n, 6)[perm].reshape(-1).copy()
+    Linv = np.zeros((n, 6, 6))
+    for l in range(nlev):
+        cols = [int(c) for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]]
+        prev = [int(c) for c in lvl_cols[lvl_ptr[l - 1]:lvl_ptr[l]]] if l > 0 else []
+        w0 = 0
+        for q in range(4):
+            m = meta[l, q]
+            if q < len(cols):
+                c = cols[q]
+                assert m[0] == c and m[1] == col_ptr[c] and m[2] == col_ptr[c + 1] - col_ptr[c] - 1 and m[7] == len(cols)
+                assert m[3] == lazy_ptr[c] and m[4] == lazy_ptr[c + 1] - lazy_ptr[c]
+                assert m[5] == w0 and m[6] == (6 * m[2] + 1 + 63) // 64
+                w0 += int(m[6])
+            else:
+                assert m[0] == -1
+        a_reads, a_writes = set(), set()              # blocks; ("z", col) for y segments
+        for c in cols:
+            d = int(col_ptr[c])
+            for b in range(d, int(col_ptr[c + 1])):
+                for s1, s2 in pend[pend_ptr[b]:pend_ptr[b + 1]]:
+                    src_col = int(blk_col[s1])
+                    assert blk_col[s2] == src_col and col_lvl[src_col] == l - 1
+                    assert row_idx[s1] == row_idx[b] and row_idx[s2] == c
+                    L[b] -= L[s1] @ L[s2].T
+                    a_reads |= {int(s1), int(s2)}
+                a_writes.add(b)
+            for s1, s2 in pend[pend_ptr[d]:pend_ptr[d + 1]]:          # pending y contributions ride on the diagonal list
+                assert s1 == s2 and yurg[s1] == 1
+                src_col = int(blk_col[s1])
+                z[6*c:6*c + 6] -= L[s1] @ z[6*src_col:6*src_col + 6]
+                a_reads.add(("z", src_col))
+            n_yurg = sum(int(yurg[b]) for p in prev for b in range(col_ptr[p] + 1, col_ptr[p + 1]) if row_idx[b] == c)
+            assert n_yurg == pend_ptr[d + 1] - pend_ptr[d]
+            a_writes.add(("z", c))
+            full = np.tril(L[d]) + np.tril(L[d], -1).T
+            Lj = np.linalg.cholesky(full)
+            L[d] = Lj
+            Linv[c] = np.linalg.inv(Lj)
+            z[6*c:6*c + 6] = Linv[c] @ z[6*c:6*c + 6]
+            for s in range(d + 1, col_ptr[c + 1]):
+                assert col_lvl[row_idx[s]] > l
+                L[s] = L[s] @ Linv[c].T
+        # lazy updates of the level below, on the helper waves during the same phase
+        targets, ytargets = {}, {}
+        for p in prev:
+            for s1, s2, dstf in lazy[lazy_ptr[p]:lazy_ptr[p + 1]]:
+                dst = int(dstf) & 0x7fff
+                assert blk_col[s1] == p and blk_col[s2] == p and row_idx[dst] == row_idx[s1] and blk_col[dst] == row_idx[s2]
+                assert col_lvl[blk_col[dst]] > l, "a lazy destination must lie above the level being factored"
+                assert dst not in a_reads and dst not in a_writes and int(s1) not in a_writes and int(s2) not in a_writes
+                targets.setdefault(dst, []).append((p, int(dstf) >> 15))
+                L[dst] -= L[s1] @ L[s2].T
+            for b in range(col_ptr[p] + 1, col_ptr[p + 1]):
+                if yurg[b]:
+                    assert col_lvl[row_idx[b]] == l
+                    continue
+                i = int(row_idx[b])
+                assert col_lvl[i] > l and ("z", i) not in a_reads and ("z", i) not in a_writes and ("z", p) not in a_writes
+                ytargets.setdefault(i, []).append(int(yshared[b]))
+                z[6*i:6*i + 6] -= L[b] @ z[6*p:6*p + 6]
+        for dst, ws in targets.items():
+            if len(ws) > 1:
+                assert all(f == 1 for _, f in ws), "two columns update a block without the shared flag"
+        for i, fl in ytargets.items():
+            if len(fl) > 1:
+                assert all(f == 1 for f in fl), "two columns update a y segment without the shared flag"
     x = z.copy()
     for l in range(nlev - 1, -1, -1):
         for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]:

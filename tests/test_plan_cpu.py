@@ -102,3 +102,39 @@ def test_plan_c3_shape():
     assert pl.nnz_blocks <= sum(min(8, 63 - j) for j in range(63)) + 28
     perm = A["perm"]
     assert perm[:28].tolist() == list(range(28)) and perm[28:56].tolist() == list(range(62, 34, -1))
+
+
+def test_c3_solver_schedules_solve_the_system():
+    """Both level schedules (two-phase and fused) of the 63-pose plan, run by the emulator on a
+    random SPD system with the plan's sparsity pattern, reproduce the dense solve."""
+    from plan_emulator import sparse_chol_solve, sparse_chol_solve_fused
+    g = graphgen.make_config("C3", seed=0)
+    pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
+    A = pl.arrays()
+    n = pl.n
+    rng = np.random.default_rng(5)
+    cams = np.unique(np.stack([g.ii, g.jj], 1), axis=0) - 1
+    pat = np.eye(n, dtype=bool)
+    ix = g.ii[np.argsort(g.kk, kind="stable")]
+    seen = {}
+    for i, j, k in zip(g.ii, g.jj, g.kk):
+        seen.setdefault(int(k), set()).update((int(i) - 1, int(j) - 1))
+    for s in seen.values():
+        s = [c for c in s if c >= 0]
+        for a in s:
+            for b in s:
+                pat[a, b] = True
+    S = np.zeros((6 * n, 6 * n))
+    for a in range(n):
+        for b in range(a + 1):
+            if pat[a, b]:
+                S[6*a:6*a + 6, 6*b:6*b + 6] = rng.normal(size=(6, 6))
+    S = np.tril(S) + np.tril(S, -1).T
+    S += np.eye(6 * n) * (np.abs(S).sum(1).max() + 1.0)
+    y = rng.normal(size=6 * n)
+    Sd = S.copy()
+    Sd[np.diag_indices(6 * n)] += 10.0 + 1e-4 * np.diag(S)
+    want = np.linalg.solve(Sd, y).reshape(n, 6)
+    for fn in (sparse_chol_solve, sparse_chol_solve_fused):
+        got = fn(A, np.tril(S), y, n, 10.0, 1e-4)
+        assert rel(got, want) < 1e-10
