@@ -1328,11 +1328,14 @@ size_t solve_fused_lds_bytes(const PlanDev &pd, int nthreads) {
            ((size_t)pd.nnzb + (size_t)pd.n + 1) * sizeof(int) + 64;
 }
 
+constexpr int kFusedCols = 2;     // columns per level k_solve_fused handles (two-ended chains); wider levels use k_solve_lds
+
 template <bool PROF>
 __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     typedef double T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[2];
+    __shared__ int4 mbuf[3][2 * kFusedCols];          // level metadata, rolling: levels l, l+1, l+2
     const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
     const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
     T *Lw = reinterpret_cast<T *>(smem);
@@ -1340,7 +1343,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     unsigned short *lazy = reinterpret_cast<unsigned short *>(dstage + 2 * kMaxLevelCols * 36), *pend = lazy + (size_t)pd.fz_nlazy * 3,
                    *pend_ptr = pend + (size_t)pd.fz_npend * 2;
     int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + fused_work_bytes(pd, nth)), *col_ptr = row_idx + nnzb;
-    const int4 *meta = reinterpret_cast<const int4 *>(pd.fz_meta);
+    const int4 *meta = reinterpret_cast<const int4 *>(pd.fz_meta);     // [nlev][kMaxLevelCols][2]
     // row | col << 8 | shared-y << 24 | pending-y << 25
     for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8) | (pd.fz_yurg[i] << 25);
     for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
@@ -1355,35 +1358,35 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         for (int i = tid; i < pd.fz_nlazy * 3; i += nth) lazy[i] = (unsigned short)pd.fz_lazy[i];
         for (int i = tid; i < pd.fz_npend * 2; i += nth) pend[i] = (unsigned short)pd.fz_pend[i];
         for (int i = tid; i <= nnzb; i += nth) pend_ptr[i] = (unsigned short)pd.fz_pend_ptr[i];
+        if (tid < 2 * 2 * kFusedCols) {                 // metadata of levels 0 and 1
+            const int lv = tid / (2 * kFusedCols), e = tid - lv * 2 * kFusedCols;
+            if (lv < nlev) mbuf[lv][e] = meta[(size_t)lv * kMaxLevelCols * 2 + e];
+        }
         lds_load_system<T>(pd, a, Lw, z, row_idx, lm, tid, nth);
         __syncthreads();
         if (PROF) tload = clock64() - tall;
 
-        // wave-uniform level metadata, read from global memory one level ahead
-        int4 cA0, cA1, cA2, cA3, cB0, cB1, cB2, cB3, pA0, pA1, pA2, pA3, nx[2 * kMaxLevelCols];
-        int pn0 = 0, pn1 = 0, pn2 = 0, pn3 = 0, pnc = 0;
-        pA0 = pA1 = pA2 = pA3 = make_int4(-1, 0, 0, 0);
-        auto prefetch_level = [&](int l) {
-#pragma unroll
-            for (int i = 0; i < 2 * kMaxLevelCols; ++i) nx[i] = meta[(size_t)l * kMaxLevelCols * 2 + i];
+        // wave-uniform level metadata in SGPRs: (col, diag pos, #sub-blocks, first lazy triple), (#lazy, first wave, #waves, #cols)
+        int4 cA0, cA1, cB0, cB1, pA0, pA1;
+        int pn0 = 0, pn1 = 0, pnc = 0;
+        pA0 = pA1 = make_int4(-1, 0, 0, 0);
+        auto take_level = [&](int l) {
+            const int4 *ml = mbuf[l % 3];
+            cA0 = uniform4(ml[0]); cB0 = uniform4(ml[1]); cA1 = uniform4(ml[2]); cB1 = uniform4(ml[3]);
         };
-        auto take_level = [&]() {
-            cA0 = uniform4(nx[0]); cA1 = uniform4(nx[2]); cA2 = uniform4(nx[4]); cA3 = uniform4(nx[6]);
-            cB0 = uniform4(nx[1]); cB1 = uniform4(nx[3]); cB2 = uniform4(nx[5]); cB3 = uniform4(nx[7]);
-        };
-        prefetch_level(0);
-        take_level();
+        take_level(0);
+        const bool feeder = tid >= nth - 2 * kFusedCols;           // the last threads bring in level l + 2's metadata
         for (int l = 0; l < nlev; ++l) {
             if (PROF) tph = clock64();
-            if (l + 1 < nlev) prefetch_level(l + 1);
-            const int nA = cB3.y + cB3.z;                   // waves of panel rows in this level
+            int4 mnext = make_int4(0, 0, 0, 0);
+            if (feeder && l + 2 < nlev) mnext = meta[(size_t)(l + 2) * kMaxLevelCols * 2 + (tid - (nth - 2 * kFusedCols))];
+            const int nA = cB1.y + cB1.z;                   // waves of panel rows in this level
             // ---- the level's columns
             for (int aw = wave; aw < nA; aw += nw) {
                 __builtin_amdgcn_s_setprio(3);
-                const int q = (aw >= cB1.y ? 1 : 0) + (aw >= cB2.y ? 1 : 0) + (aw >= cB3.y ? 1 : 0);
-                const int4 ma = q == 0 ? cA0 : q == 1 ? cA1 : q == 2 ? cA2 : cA3;
-                const int w0 = q == 0 ? cB0.y : q == 1 ? cB1.y : q == 2 ? cB2.y : cB3.y;
-                const int j = ma.x, dpos = ma.y, cnt = ma.z, part = aw - w0;
+                const bool second = aw >= cB1.y;
+                const int4 ma = second ? cA1 : cA0;
+                const int j = ma.x, dpos = ma.y, cnt = ma.z, part = aw - (second ? cB1.y : 0), q = second ? 1 : 0;
                 const int dp0 = __builtin_amdgcn_readfirstlane(pend_ptr[dpos]), dp1 = __builtin_amdgcn_readfirstlane(pend_ptr[dpos + 1]);
                 const int rw = part * 64 + lane;
                 const bool valid = rw <= cnt * 6, isy = rw == cnt * 6;
@@ -1416,16 +1419,20 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     const int s1 = pend[2 * k], s2 = pend[2 * k + 1];
                     const T *av = isy ? z + 6 * ((row_idx[s1] >> 8) & 255) : Lw + (size_t)s1 * 36 + 6 * r;
                     const T *M = Lw + (size_t)(isy ? s1 : s2) * 36;
-                    T avec[6], m[36];
+                    T avec[6];
                     load_row6(av, avec);
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) load_row6(M + 6 * c, reinterpret_cast<T (&)[6]>(m[6 * c]));
+                    for (int half = 0; half < 2; ++half) {
+                        T m[18];
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        T acc = avec[0] * m[6 * c];
+                        for (int c = 0; c < 3; ++c) load_row6(M + 6 * (3 * half + c), reinterpret_cast<T (&)[6]>(m[6 * c]));
 #pragma unroll
-                        for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
-                        in[c] -= acc;
+                        for (int c = 0; c < 3; ++c) {
+                            T acc = avec[0] * m[6 * c];
+#pragma unroll
+                            for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
+                            in[3 * half + c] -= acc;
+                        }
                     }
                 }
                 wave_fence();
@@ -1476,40 +1483,23 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         const int back = hs - 1 - h;
                         if (back < pnc * 18) {
                             const int q = back / 18, e = back - 18 * q;
-                            const int dpos = q == 0 ? pA0.y : q == 1 ? pA1.y : q == 2 ? pA2.y : pA3.y;
+                            const int dpos = q == 0 ? pA0.y : pA1.y;
                             reinterpret_cast<double2 *>(Lw + (size_t)dpos * 36)[e] =
                                 reinterpret_cast<const double2 *>(dstage + (size_t)(((l - 1) & 1) * kMaxLevelCols + q) * 36)[e];
                         }
                     }
-                    int rows_b[kMaxLevelCols + 1];
-                    rows_b[0] = 0;
-                    rows_b[1] = pA0.x >= 0 ? pn0 * 6 : 0;
-                    rows_b[2] = rows_b[1] + (pA1.x >= 0 ? pn1 * 6 : 0);
-                    rows_b[3] = rows_b[2] + (pA2.x >= 0 ? pn2 * 6 : 0);
-                    rows_b[4] = rows_b[3] + (pA3.x >= 0 ? pn3 * 6 : 0);
-                    for (int item = h; item < rows_b[kMaxLevelCols]; item += hs) {
-                        int q = 0;
-#pragma unroll
-                        for (int k = 1; k < kMaxLevelCols; ++k) q += item >= rows_b[k] ? 1 : 0;
-                        const int idx = item - (q == 0 ? 0 : q == 1 ? rows_b[1] : q == 2 ? rows_b[2] : rows_b[3]);
-                        const int4 pa = q == 0 ? pA0 : q == 1 ? pA1 : q == 2 ? pA2 : pA3;
-                        const int t = idx / 6;
-                        apply_update_row<T, false>(Lw, lazy + 3 * (pa.w + t), idx - 6 * t);
+                    const int rows0 = pA0.x >= 0 ? pn0 * 6 : 0, rows1 = rows0 + (pA1.x >= 0 ? pn1 * 6 : 0);
+                    for (int item = h; item < rows1; item += hs) {
+                        const bool sec = item >= rows0;
+                        const int idx = item - (sec ? rows0 : 0), t = idx / 6;
+                        apply_update_row<T, false>(Lw, lazy + 3 * ((sec ? pA1.w : pA0.w) + t), idx - 6 * t);
                     }
-                    int ys_b[kMaxLevelCols + 1];
-                    ys_b[0] = 0;
-                    ys_b[1] = pA0.x >= 0 ? pA0.z * 6 : 0;
-                    ys_b[2] = ys_b[1] + (pA1.x >= 0 ? pA1.z * 6 : 0);
-                    ys_b[3] = ys_b[2] + (pA2.x >= 0 ? pA2.z * 6 : 0);
-                    ys_b[4] = ys_b[3] + (pA3.x >= 0 ? pA3.z * 6 : 0);
-                    const int shift = ((rows_b[kMaxLevelCols] + 63) >> 6) << 6;
-                    for (int item = (h - shift % hs + hs) % hs; item < ys_b[kMaxLevelCols]; item += hs) {
-                        int q = 0;
-#pragma unroll
-                        for (int k = 1; k < kMaxLevelCols; ++k) q += item >= ys_b[k] ? 1 : 0;
-                        const int qq = item - (q == 0 ? 0 : q == 1 ? ys_b[1] : q == 2 ? ys_b[2] : ys_b[3]);
-                        const int4 pa = q == 0 ? pA0 : q == 1 ? pA1 : q == 2 ? pA2 : pA3;
-                        const int pj = pa.x, dposp = pa.y, sb = qq / 6, r = qq - 6 * sb;
+                    const int ys0 = pA0.x >= 0 ? pA0.z * 6 : 0, ys1 = ys0 + (pA1.x >= 0 ? pA1.z * 6 : 0);
+                    const int shift = ((rows1 + 63) >> 6) << 6;
+                    for (int item = (h - shift % hs + hs) % hs; item < ys1; item += hs) {
+                        const bool sec = item >= ys0;
+                        const int qq = item - (sec ? ys0 : 0);
+                        const int pj = sec ? pA1.x : pA0.x, dposp = sec ? pA1.y : pA0.y, sb = qq / 6, r = qq - 6 * sb;
                         const int rcv = row_idx[dposp + 1 + sb];
                         if (rcv & (1 << 25)) continue;            // pending: the destination column's y thread takes it
                         T lr[6], zr[6];
@@ -1522,15 +1512,16 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     }
                 }
             }
+            if (feeder && l + 2 < nlev) mbuf[(l + 2) % 3][tid - (nth - 2 * kFusedCols)] = mnext;
             if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); phL += clock64() - tph; }
-            pA0 = cA0; pA1 = cA1; pA2 = cA2; pA3 = cA3; pn0 = cB0.x; pn1 = cB1.x; pn2 = cB2.x; pn3 = cB3.x; pnc = cB0.w;
-            if (l + 1 < nlev) take_level();
+            pA0 = cA0; pA1 = cA1; pn0 = cB0.x; pn1 = cB1.x; pnc = cB0.w;
+            if (l + 1 < nlev) take_level(l + 1);
             __syncthreads();
         }
         // the last level's staged diagonal blocks (its columns have no lazy work: nothing lies above them)
         if (tid < pnc * 18) {
             const int q = tid / 18, e = tid - 18 * q;
-            const int dpos = q == 0 ? pA0.y : q == 1 ? pA1.y : q == 2 ? pA2.y : pA3.y;
+            const int dpos = q == 0 ? pA0.y : pA1.y;
             reinterpret_cast<double2 *>(Lw + (size_t)dpos * 36)[e] =
                 reinterpret_cast<const double2 *>(dstage + (size_t)(((nlev - 1) & 1) * kMaxLevelCols + q) * 36)[e];
         }
@@ -1688,7 +1679,7 @@ static int solver_threads();
 // one-phase-per-level variant of the double LDS solver; BT_SOLVER_FUSED=0: the two-phase k_solve_lds
 static bool use_fused_solver(const PlanDev &pd) {
     static const int on = std::getenv("BT_SOLVER_FUSED") ? std::atoi(std::getenv("BT_SOLVER_FUSED")) : 1;   // measurement only
-    return on != 0 && solve_fused_lds_bytes(pd, solver_threads()) <= kLdsBudget;
+    return on != 0 && pd.fz_ok != 0 && solve_fused_lds_bytes(pd, solver_threads()) <= kLdsBudget;
 }
 
 static int solver_threads() {

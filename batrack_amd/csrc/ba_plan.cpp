@@ -501,7 +501,9 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
         pl->fz_pend_ptr[nb] = (int32_t)(pl->fz_pend.size() / 2);
         pl->fz_meta.assign((size_t)nlev * kMaxLevelCols * 8, 0);
+        pl->fz_ok = 1;
         for (int32_t l = 0; l < nlev; ++l) {
+            if (pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l] > 2) pl->fz_ok = 0;
             int32_t w0 = 0;
             for (int q = 0; q < kMaxLevelCols; ++q) {
                 int32_t *mrow = pl->fz_meta.data() + ((size_t)l * kMaxLevelCols + q) * 8;
