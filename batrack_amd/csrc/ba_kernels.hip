@@ -1347,7 +1347,8 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     // row | col << 8 | shared-y << 24 | pending-y << 25
     for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8) | (pd.fz_yurg[i] << 25);
     for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
-    long long phA = 0, phL = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0;
+    long long phA = 0, phL = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, sub[6] = {0, 0, 0, 0, 0, 0}, tsub = 0;
+#define BT_SUB(i) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tq = clock64(); sub[i] += tq - tsub; tsub = tq; } } while (0)
     __syncthreads();
 
     int status = BT_SOLVE_OK;
@@ -1384,6 +1385,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
             // ---- the level's columns
             for (int aw = wave; aw < nA; aw += nw) {
                 __builtin_amdgcn_s_setprio(3);
+                if (PROF) tsub = clock64();
                 const bool second = aw >= cB1.y;
                 const int4 ma = second ? cA1 : cA0;
                 const int j = ma.x, dpos = ma.y, cnt = ma.z, part = aw - (second ? cB1.y : 0), q = second ? 1 : 0;
@@ -1414,6 +1416,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     }
                     scr[wave * 36 + lane] = v;
                 }
+                BT_SUB(0);
                 // (2) pending updates of the own row: in[c] -= sum_e avec[e] M[c][e]
                 for (int k = k0; k < k1; ++k) {
                     const int s1 = pend[2 * k], s2 = pend[2 * k + 1];
@@ -1435,6 +1438,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         }
                     }
                 }
+                BT_SUB(1);
                 wave_fence();
                 // (3) factor the updated diagonal block (every lane, in registers) and substitute the own row
                 T L[21];
@@ -1447,6 +1451,8 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
                 }
                 const bool ok = chol6_packed<T>(L);
+                if (PROF) { asm volatile("" :: "v"(L[20])); }
+                BT_SUB(2);
                 if (valid) {
                     T out[6];
 #pragma unroll
@@ -1458,6 +1464,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     }
                     store_row6(p, out);
                 }
+                BT_SUB(3);
                 if (part == 0 && lane == 0) {          // L_jj is put in place one level later (its readers run after the sweep)
                     if (!ok) flags[0] = 1;
                     T *ds = dstage + (size_t)((l & 1) * kMaxLevelCols + q) * 36;
@@ -1469,6 +1476,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         store_row6(ds + 6 * rr, row);
                     }
                 }
+                BT_SUB(4);
                 wave_fence();                              // scratch is reused by this wave's next column
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -1552,8 +1560,10 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         if (wave == 0) {
             long long *g = reinterpret_cast<long long *>(a.status + 4);
             g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
+            for (int i = 0; i < 5; ++i) g[3 + i] = sub[i];
         }
     }
+#undef BT_SUB
 }
 
 // ------------------------------------------------------------------ k_update
