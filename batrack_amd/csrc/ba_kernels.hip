@@ -1238,7 +1238,7 @@ __device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArg
 
 // Back substitution of the LDS-resident factor (diagonal blocks hold L_jj with 1/l_cc on the
 // diagonal): brings it into M form, then x_j = zt_j - sum_{i>j} M_ij x_i by levels, descending.
-template <typename T>
+template <typename T, bool RAW_DIAG = false>
 __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T *z, T *zt, const int *row_idx,
                                                     const int *col_ptr, const int4 *lvl_meta, int mstride, int tid, int nth) {
     const int n = pd.n, nnzb = pd.nnzb, nlev = pd.nlev, wave = tid >> 6, lane = tid & 63;
@@ -1249,6 +1249,11 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
         for (int r = 0; r < 6; ++r)
 #pragma unroll
             for (int c = 0; c <= r; ++c) L[BT_LT(r, c)] = dblk[6 * r + c];
+        if (RAW_DIAG) {                   // the block still holds the (fully updated) A_jj: factor it here
+            (void)chol6_packed<T>(L);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) dblk[7 * c] = L[BT_LT(c, c)];
+        }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             li[BT_LT(c, c)] = L[BT_LT(c, c)];
@@ -1313,19 +1318,19 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
 }
 
 
-// LDS of k_solve_fused: Lw | z | work | row_idx | col_ptr, where `work` holds the sweep's tables (per-wave
-// scratch, staged L_jj, lazy triples, pending pairs and their pointers) and is reused for zt afterwards.
+// LDS of k_solve_fused: Lw | z | work | row_idx | pfirst | col_ptr, where `work` holds the sweep's tables
+// (per-wave scratch, staged diagonal blocks, lazy triples) and is reused for zt afterwards.
 // The per-level metadata stays in global memory (prefetched a level ahead).
 __host__ __device__ inline size_t fused_work_bytes(const PlanDev &pd, int nthreads) {
     const size_t nw = (size_t)nthreads / 64;
     const size_t b = (nw * 36 + 2 * kMaxLevelCols * 36) * sizeof(double) +
-                     ((size_t)pd.fz_nlazy * 3 + (size_t)pd.fz_npend * 2 + (size_t)pd.nnzb + 1) * sizeof(unsigned short);
+                     (size_t)pd.fz_nlazy * 3 * sizeof(unsigned short) + 16;
     const size_t zt = (size_t)pd.D * sizeof(double) + (size_t)pd.nlev * kMaxLevelCols * sizeof(int4);   // zt + compact level table
     return ((b > zt ? b : zt) + 15) / 16 * 16;
 }
 size_t solve_fused_lds_bytes(const PlanDev &pd, int nthreads) {
     return ((size_t)pd.nnzb * 36 + (size_t)pd.D) * sizeof(double) + fused_work_bytes(pd, nthreads) +
-           ((size_t)pd.nnzb + (size_t)pd.n + 1) * sizeof(int) + 64;
+           (2 * (size_t)pd.nnzb + (size_t)pd.n + 1) * sizeof(int) + 64;       // row_idx, pfirst, col_ptr
 }
 
 constexpr int kFusedCols = 2;     // columns per level k_solve_fused handles (two-ended chains); wider levels use k_solve_lds
@@ -1340,12 +1345,18 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
     T *Lw = reinterpret_cast<T *>(smem);
     T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr, *dstage = scr + (size_t)nw * 36;
-    unsigned short *lazy = reinterpret_cast<unsigned short *>(dstage + 2 * kMaxLevelCols * 36), *pend = lazy + (size_t)pd.fz_nlazy * 3,
-                   *pend_ptr = pend + (size_t)pd.fz_npend * 2;
-    int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + fused_work_bytes(pd, nth)), *col_ptr = row_idx + nnzb;
+    unsigned short *lazy = reinterpret_cast<unsigned short *>(dstage + 2 * kMaxLevelCols * 36);
+    int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + fused_work_bytes(pd, nth)), *pfirst = row_idx + nnzb,
+        *col_ptr = pfirst + nnzb;
     const int4 *meta = reinterpret_cast<const int4 *>(pd.fz_meta);     // [nlev][kMaxLevelCols][2]
     // row | col << 8 | shared-y << 24 | pending-y << 25
     for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8) | (pd.fz_yurg[i] << 25);
+    // first pending pair of a block and how many it has: src1 | src2 << 15 | min(count, 3) << 30; further pairs
+    // (a block updated by two columns of the level below: where chains merge) are read from global memory
+    for (int i = tid; i < nnzb; i += nth) {
+        const int k0 = pd.fz_pend_ptr[i], c = pd.fz_pend_ptr[i + 1] - k0;
+        pfirst[i] = c > 0 ? (pd.fz_pend[2 * k0] | (pd.fz_pend[2 * k0 + 1] << 15) | ((c < 3 ? c : 3) << 30)) : 0;
+    }
     for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
     long long phA = 0, phL = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, sub[6] = {0, 0, 0, 0, 0, 0}, tsub = 0;
 #define BT_SUB(i) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tq = clock64(); sub[i] += tq - tsub; tsub = tq; } } while (0)
@@ -1357,8 +1368,6 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         if (tid < 2) flags[tid] = 0;
         // the sweep's tables (their LDS is reused for zt by the back substitution, so a retry reloads them)
         for (int i = tid; i < pd.fz_nlazy * 3; i += nth) lazy[i] = (unsigned short)pd.fz_lazy[i];
-        for (int i = tid; i < pd.fz_npend * 2; i += nth) pend[i] = (unsigned short)pd.fz_pend[i];
-        for (int i = tid; i <= nnzb; i += nth) pend_ptr[i] = (unsigned short)pd.fz_pend_ptr[i];
         if (tid < 2 * 2 * kFusedCols) {                 // metadata of levels 0 and 1
             const int lv = tid / (2 * kFusedCols), e = tid - lv * 2 * kFusedCols;
             if (lv < nlev) mbuf[lv][e] = meta[(size_t)lv * kMaxLevelCols * 2 + e];
@@ -1389,55 +1398,70 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                 const bool second = aw >= cB1.y;
                 const int4 ma = second ? cA1 : cA0;
                 const int j = ma.x, dpos = ma.y, cnt = ma.z, part = aw - (second ? cB1.y : 0), q = second ? 1 : 0;
-                const int dp0 = __builtin_amdgcn_readfirstlane(pend_ptr[dpos]), dp1 = __builtin_amdgcn_readfirstlane(pend_ptr[dpos + 1]);
                 const int rw = part * 64 + lane;
                 const bool valid = rw <= cnt * 6, isy = rw == cnt * 6;
-                // own row: where it lives and its pending updates
                 const int sb = rw / 6, r = rw - 6 * sb, bown = dpos + 1 + sb;
                 T *p = isy ? z + 6 * j : Lw + (size_t)bown * 36 + 6 * r;
-                int k0 = dp0, k1 = dp1;
-                if (valid && !isy) { k0 = pend_ptr[bown]; k1 = pend_ptr[bown + 1]; }
-                if (!valid) k1 = k0;
-                T in[6];
-                if (valid) load_row6(p, in);
-                // (1) diagonal block + pending updates -> per-wave scratch (lanes 0..35, one element each)
-                if (lane < 36) {
-                    const int dr = lane / 6, dc = lane - 6 * dr;
-                    T v = Lw[(size_t)dpos * 36 + lane];
-                    for (int k = dp0; k < dp1; ++k) {
-                        const T *src = Lw + (size_t)pend[2 * k] * 36;
-                        T x[6], yv[6];
-                        load_row6(src + 6 * dr, x);
-                        load_row6(src + 6 * dc, yv);
-                        T acc = x[0] * yv[0];
-#pragma unroll
-                        for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
-                        v -= acc;
-                    }
-                    scr[wave * 36 + lane] = v;
-                }
-                BT_SUB(0);
-                // (2) pending updates of the own row: in[c] -= sum_e avec[e] M[c][e]
-                for (int k = k0; k < k1; ++k) {
-                    const int s1 = pend[2 * k], s2 = pend[2 * k + 1];
-                    const T *av = isy ? z + 6 * ((row_idx[s1] >> 8) & 255) : Lw + (size_t)s1 * 36 + 6 * r;
+                // First pending update of the diagonal block (lanes 0..35 keep one element each; the other
+                // lanes run along) and of the own row, straight-line: every load is in flight before the
+                // first FMA.  in[c] -= sum_e avec[e] M[c][e] with avec = row r of src1 and M = src2, or for
+                // the y row avec = y of the source column and M = src1.
+                const unsigned pfd = (unsigned)pfirst[dpos], pfo = valid && !isy ? (unsigned)pfirst[bown] : pfd;
+                const int el = lane < 36 ? lane : lane - 36, dr = el / 6, dc = el - 6 * dr;
+                const int sd = pfd & 0x7fff, s1 = pfo & 0x7fff, s2 = (pfo >> 15) & 0x7fff;
+                const int nd = pfd >> 30, no = valid ? (int)(pfo >> 30) : 0;
+                T in[6], x[6], yv[6], avec[6], m[36];
+                T v = Lw[(size_t)dpos * 36 + el];
+                load_row6(p, in);
+                load_row6(Lw + (size_t)sd * 36 + 6 * dr, x);
+                load_row6(Lw + (size_t)sd * 36 + 6 * dc, yv);
+                load_row6(isy ? z + 6 * ((row_idx[s1] >> 8) & 255) : Lw + (size_t)s1 * 36 + 6 * r, avec);
+                {
                     const T *M = Lw + (size_t)(isy ? s1 : s2) * 36;
-                    T avec[6];
-                    load_row6(av, avec);
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        T m[18];
+                    for (int c = 0; c < 6; ++c) load_row6(M + 6 * c, reinterpret_cast<T (&)[6]>(m[6 * c]));
+                }
+                {
+                    T acc = x[0] * yv[0];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) load_row6(M + 6 * (3 * half + c), reinterpret_cast<T (&)[6]>(m[6 * c]));
+                    for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
+                    v -= nd > 0 ? acc : (T)0;
+                }
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            T acc = avec[0] * m[6 * c];
+                for (int c = 0; c < 6; ++c) {
+                    T acc = avec[0] * m[6 * c];
 #pragma unroll
-                            for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
-                            in[3 * half + c] -= acc;
+                    for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
+                    in[c] -= no > 0 ? acc : (T)0;
+                }
+                if (__builtin_amdgcn_ballot_w64(nd > 1 || no > 1)) {       // rare: further pending pairs, lists in global memory
+                    if (lane < 36 && nd > 1)
+                        for (int k = pd.fz_pend_ptr[dpos] + 1; k < pd.fz_pend_ptr[dpos + 1]; ++k) {
+                            const T *src = Lw + (size_t)pd.fz_pend[2 * k] * 36;
+                            T acc = (T)0;
+                            for (int e = 0; e < 6; ++e) acc += src[6 * dr + e] * src[6 * dc + e];
+                            v -= acc;
+                        }
+                    if (no > 1) {
+                        const int bsel = isy ? dpos : bown;
+                        for (int k = pd.fz_pend_ptr[bsel] + 1; k < pd.fz_pend_ptr[bsel + 1]; ++k) {
+                            const int t1 = pd.fz_pend[2 * k], t2 = pd.fz_pend[2 * k + 1];
+                            const T *av = isy ? z + 6 * ((row_idx[t1] >> 8) & 255) : Lw + (size_t)t1 * 36 + 6 * r;
+                            const T *M = Lw + (size_t)(isy ? t1 : t2) * 36;
+                            for (int c = 0; c < 6; ++c) {
+                                T acc = (T)0;
+                                for (int e = 0; e < 6; ++e) acc += av[e] * M[6 * c + e];
+                                in[c] -= acc;
+                            }
                         }
                     }
                 }
+                if (lane < 36) {
+                    scr[wave * 36 + lane] = v;
+                    // the updated block goes in place one level later (its next reader is the back substitution)
+                    if (part == 0) dstage[(size_t)((l & 1) * kMaxLevelCols + q) * 36 + lane] = v;
+                }
+                BT_SUB(0);
                 BT_SUB(1);
                 wave_fence();
                 // (3) factor the updated diagonal block (every lane, in registers) and substitute the own row
@@ -1465,17 +1489,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     store_row6(p, out);
                 }
                 BT_SUB(3);
-                if (part == 0 && lane == 0) {          // L_jj is put in place one level later (its readers run after the sweep)
-                    if (!ok) flags[0] = 1;
-                    T *ds = dstage + (size_t)((l & 1) * kMaxLevelCols + q) * 36;
-#pragma unroll
-                    for (int rr = 0; rr < 6; ++rr) {
-                        T row[6];
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) row[c] = L[BT_LT(rr, c <= rr ? c : rr)];
-                        store_row6(ds + 6 * rr, row);
-                    }
-                }
+                if (!ok && lane == 0) flags[0] = 1;
                 BT_SUB(4);
                 wave_fence();                              // scratch is reused by this wave's next column
                 __builtin_amdgcn_s_setprio(0);
@@ -1487,7 +1501,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                 if (nA < nw) { h = tid - 64 * nA; hs = nth - 64 * nA; }
                 else { hs = nth; h = (tid + nth - (64 * nA) % nth) % nth; }
                 if (h >= 0) {
-                    {   // staged L_jj of the previous level -> their diagonal blocks
+                    {   // staged diagonal blocks of the previous level -> in place
                         const int back = hs - 1 - h;
                         if (back < pnc * 18) {
                             const int q = back / 18, e = back - 18 * q;
@@ -1538,7 +1552,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
 
         int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
         for (int i = tid; i < nlev * kMaxLevelCols; i += nth) bmeta[i] = meta[2 * i];
-        lds_back_substitute<T>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth);
+        lds_back_substitute<T, true>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth);
         for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
         __syncthreads();
         const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
