@@ -1335,20 +1335,38 @@ size_t solve_fused_lds_bytes(const PlanDev &pd, int nthreads) {
 
 constexpr int kFusedCols = 2;     // columns per level k_solve_fused handles (two-ended chains); wider levels use k_solve_lds
 
+// packed 6x6 lower triangle (BT_LT order, 21 values) <-> LDS, vector accesses
+template <typename T>
+__device__ __forceinline__ void store_packed21(T *p, const T (&L)[21]) {
+    typedef typename Vec2<T>::type V;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { V v; v.x = L[2 * i]; v.y = L[2 * i + 1]; reinterpret_cast<V *>(p)[i] = v; }
+    p[20] = L[20];
+}
+template <typename T>
+__device__ __forceinline__ void load_packed21(const T *p, T (&L)[21]) {
+    typedef typename Vec2<T>::type V;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { const V v = reinterpret_cast<const V *>(p)[i]; L[2 * i] = v.x; L[2 * i + 1] = v.y; }
+    L[20] = p[20];
+}
+
 template <bool PROF>
 __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     typedef double T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[2];
-    __shared__ int4 mbuf[3][2 * kFusedCols];          // level metadata, rolling: levels l, l+1, l+2
+    __shared__ int lready[kFusedCols];                 // level + 1 whose L_jj (packed) is ready in lpk
+    __shared__ int4 mbuf[3][2];                        // packed level metadata, rolling: levels l, l+1, l+2
     const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
     const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
     T *Lw = reinterpret_cast<T *>(smem);
-    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr, *dstage = scr + (size_t)nw * 36;
+    // work region: per-column scratch (updated diagonal block, 36) and packed factor (24), staged diagonal blocks, lazy triples
+    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr, *lpk = scr + kFusedCols * 36, *dstage = scr + (size_t)nw * 36;
     unsigned short *lazy = reinterpret_cast<unsigned short *>(dstage + 2 * kMaxLevelCols * 36);
     int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + fused_work_bytes(pd, nth)), *pfirst = row_idx + nnzb,
         *col_ptr = pfirst + nnzb;
-    const int4 *meta = reinterpret_cast<const int4 *>(pd.fz_meta);     // [nlev][kMaxLevelCols][2]
+    const int4 *pmeta = reinterpret_cast<const int4 *>(pd.fz_pmeta);     // [nlev][2]
     // row | col << 8 | shared-y << 24 | pending-y << 25
     for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8) | (pd.fz_yurg[i] << 25);
     // first pending pair of a block and how many it has: src1 | src2 << 15 | min(count, 3) << 30; further pairs
@@ -1366,132 +1384,147 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         const double lm = attempt == 0 ? 1e-4 : 1e-3;
         if (tid < 2) flags[tid] = 0;
+        if (tid < kFusedCols) lready[tid] = 0;
         // the sweep's tables (their LDS is reused for zt by the back substitution, so a retry reloads them)
         for (int i = tid; i < pd.fz_nlazy * 3; i += nth) lazy[i] = (unsigned short)pd.fz_lazy[i];
-        if (tid < 2 * 2 * kFusedCols) {                 // metadata of levels 0 and 1
-            const int lv = tid / (2 * kFusedCols), e = tid - lv * 2 * kFusedCols;
-            if (lv < nlev) mbuf[lv][e] = meta[(size_t)lv * kMaxLevelCols * 2 + e];
-        }
+        if (tid < 4 && (tid >> 1) < nlev) mbuf[tid >> 1][tid & 1] = pmeta[tid];       // metadata of levels 0 and 1
         lds_load_system<T>(pd, a, Lw, z, row_idx, lm, tid, nth);
         __syncthreads();
         if (PROF) tload = clock64() - tall;
 
-        // wave-uniform level metadata in SGPRs: (col, diag pos, #sub-blocks, first lazy triple), (#lazy, first wave, #waves, #cols)
-        int4 cA0, cA1, cB0, cB1, pA0, pA1;
-        int pn0 = 0, pn1 = 0, pnc = 0;
-        pA0 = pA1 = make_int4(-1, 0, 0, 0);
+        // wave-uniform packed level metadata in SGPRs (ba_plan.cpp: fz_pmeta)
+        int c0a, c0b, c0c, c1a, c1b, c1c, cnc;             // current level: columns 0 and 1, #columns
+        int p0a = 0, p0b = 0, p0c = 0, p1a = 0, p1b = 0, p1c = 0, pnc = 0;   // previous level
         auto take_level = [&](int l) {
-            const int4 *ml = mbuf[l % 3];
-            cA0 = uniform4(ml[0]); cB0 = uniform4(ml[1]); cA1 = uniform4(ml[2]); cB1 = uniform4(ml[3]);
+            const int4 m0 = mbuf[l % 3][0], m1 = mbuf[l % 3][1];
+            c0a = __builtin_amdgcn_readfirstlane(m0.x); c0b = __builtin_amdgcn_readfirstlane(m0.y); c0c = __builtin_amdgcn_readfirstlane(m0.z);
+            c1a = __builtin_amdgcn_readfirstlane(m0.w); c1b = __builtin_amdgcn_readfirstlane(m1.x); c1c = __builtin_amdgcn_readfirstlane(m1.y);
+            cnc = __builtin_amdgcn_readfirstlane(m1.z);
         };
         take_level(0);
-        const bool feeder = tid >= nth - 2 * kFusedCols;           // the last threads bring in level l + 2's metadata
+        const bool feeder = tid >= nth - 2;           // the last two threads bring in level l + 2's metadata
         for (int l = 0; l < nlev; ++l) {
             if (PROF) tph = clock64();
             int4 mnext = make_int4(0, 0, 0, 0);
-            if (feeder && l + 2 < nlev) mnext = meta[(size_t)(l + 2) * kMaxLevelCols * 2 + (tid - (nth - 2 * kFusedCols))];
-            const int nA = cB1.y + cB1.z;                   // waves of panel rows in this level
-            // ---- the level's columns
+            if (feeder && l + 2 < nlev) mnext = pmeta[(size_t)(l + 2) * 2 + (tid - (nth - 2))];
+            const int nr0 = c0b >> 16, nr1 = cnc > 1 ? c1b >> 16 : 0;     // row waves of the two columns
+            const int nA = cnc + nr0 + nr1;                               // factor waves, then row waves
             for (int aw = wave; aw < nA; aw += nw) {
                 __builtin_amdgcn_s_setprio(3);
                 if (PROF) tsub = clock64();
-                const bool second = aw >= cB1.y;
-                const int4 ma = second ? cA1 : cA0;
-                const int j = ma.x, dpos = ma.y, cnt = ma.z, part = aw - (second ? cB1.y : 0), q = second ? 1 : 0;
-                const int rw = part * 64 + lane;
-                const bool valid = rw <= cnt * 6, isy = rw == cnt * 6;
-                const int sb = rw / 6, r = rw - 6 * sb, bown = dpos + 1 + sb;
-                T *p = isy ? z + 6 * j : Lw + (size_t)bown * 36 + 6 * r;
-                // First pending update of the diagonal block (lanes 0..35 keep one element each; the other
-                // lanes run along) and of the own row, straight-line: every load is in flight before the
-                // first FMA.  in[c] -= sum_e avec[e] M[c][e] with avec = row r of src1 and M = src2, or for
-                // the y row avec = y of the source column and M = src1.
-                const unsigned pfd = (unsigned)pfirst[dpos], pfo = valid && !isy ? (unsigned)pfirst[bown] : pfd;
-                const int el = lane < 36 ? lane : lane - 36, dr = el / 6, dc = el - 6 * dr;
-                const int sd = pfd & 0x7fff, s1 = pfo & 0x7fff, s2 = (pfo >> 15) & 0x7fff;
-                const int nd = pfd >> 30, no = valid ? (int)(pfo >> 30) : 0;
-                T in[6], x[6], yv[6], avec[6], m[36];
-                T v = Lw[(size_t)dpos * 36 + el];
-                load_row6(p, in);
-                load_row6(Lw + (size_t)sd * 36 + 6 * dr, x);
-                load_row6(Lw + (size_t)sd * 36 + 6 * dc, yv);
-                load_row6(isy ? z + 6 * ((row_idx[s1] >> 8) & 255) : Lw + (size_t)s1 * 36 + 6 * r, avec);
-                {
-                    const T *M = Lw + (size_t)(isy ? s1 : s2) * 36;
+                if (aw < cnc) {
+                    // ---- factor wave of column q = aw: bring the diagonal block up to date (lanes 0..35, one
+                    // element each), factor it (every lane, in registers), publish the packed factor
+                    const int q = aw, ma = q ? c1a : c0a, dpos = (q ? c1b : c0b) & 0xffff;
+                    (void)ma;
+                    const unsigned pfd = (unsigned)pfirst[dpos];
+                    const int el = lane < 36 ? lane : lane - 36, dr = el / 6, dc = el - 6 * dr;
+                    const int sd = pfd & 0x7fff, nd = pfd >> 30;
+                    T x[6], yv[6];
+                    T v = Lw[(size_t)dpos * 36 + el];
+                    load_row6(Lw + (size_t)sd * 36 + 6 * dr, x);
+                    load_row6(Lw + (size_t)sd * 36 + 6 * dc, yv);
+                    {
+                        T acc = x[0] * yv[0];
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) load_row6(M + 6 * c, reinterpret_cast<T (&)[6]>(m[6 * c]));
-                }
-                {
-                    T acc = x[0] * yv[0];
-#pragma unroll
-                    for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
-                    v -= nd > 0 ? acc : (T)0;
-                }
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    T acc = avec[0] * m[6 * c];
-#pragma unroll
-                    for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
-                    in[c] -= no > 0 ? acc : (T)0;
-                }
-                if (__builtin_amdgcn_ballot_w64(nd > 1 || no > 1)) {       // rare: further pending pairs, lists in global memory
-                    if (lane < 36 && nd > 1)
+                        for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
+                        v -= nd > 0 ? acc : (T)0;
+                    }
+                    if (nd > 1 && lane < 36)              // rare: further pending pairs, lists in global memory
                         for (int k = pd.fz_pend_ptr[dpos] + 1; k < pd.fz_pend_ptr[dpos + 1]; ++k) {
                             const T *src = Lw + (size_t)pd.fz_pend[2 * k] * 36;
                             T acc = (T)0;
                             for (int e = 0; e < 6; ++e) acc += src[6 * dr + e] * src[6 * dc + e];
                             v -= acc;
                         }
-                    if (no > 1) {
-                        const int bsel = isy ? dpos : bown;
-                        for (int k = pd.fz_pend_ptr[bsel] + 1; k < pd.fz_pend_ptr[bsel + 1]; ++k) {
-                            const int t1 = pd.fz_pend[2 * k], t2 = pd.fz_pend[2 * k + 1];
-                            const T *av = isy ? z + 6 * ((row_idx[t1] >> 8) & 255) : Lw + (size_t)t1 * 36 + 6 * r;
-                            const T *M = Lw + (size_t)(isy ? t1 : t2) * 36;
-                            for (int c = 0; c < 6; ++c) {
-                                T acc = (T)0;
-                                for (int e = 0; e < 6; ++e) acc += av[e] * M[6 * c + e];
-                                in[c] -= acc;
+                    if (lane < 36) {
+                        scr[q * 36 + lane] = v;
+                        // the updated block goes in place one level later (its next reader is the back substitution)
+                        dstage[(size_t)((l & 1) * kMaxLevelCols + q) * 36 + lane] = v;
+                    }
+                    wave_fence();
+                    BT_SUB(0);
+                    T L[21];
+                    const T *dblk = scr + q * 36;
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) {
+                        T row[6];
+                        load_row6(dblk + 6 * rr, row);
+#pragma unroll
+                        for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
+                    }
+                    const bool ok = chol6_packed<T>(L);
+                    BT_SUB(1);
+                    if (lane == 0) {
+                        store_packed21(lpk + q * 24, L);
+                        if (!ok) flags[0] = 1;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __hip_atomic_store(&lready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    BT_SUB(2);
+                } else {
+                    // ---- row wave: one panel row (or y_j) per lane: its pending update, then, once the factor
+                    // wave has published L_jj, the forward substitution
+                    const int ra = aw - cnc, q = ra >= nr0 ? 1 : 0, part = ra - (q ? nr0 : 0);
+                    const int ma = q ? c1a : c0a, dpos = (q ? c1b : c0b) & 0xffff;
+                    const int j = ma & 255, cnt = (ma >> 8) & 255, ysrc = (ma >> 16) & 255;
+                    const int rw = part * 64 + lane;
+                    const bool valid = rw <= cnt * 6, isy = rw == cnt * 6;
+                    const int sb = rw / 6, r = rw - 6 * sb, bown = dpos + 1 + sb;
+                    T *p = isy ? z + 6 * j : Lw + (size_t)bown * 36 + 6 * r;
+                    // in[c] -= sum_e avec[e] M[c][e] with avec = row r of src1 and M = src2, or for the y row
+                    // avec = y of the source column and M = src1; every load is in flight before the first FMA
+                    const unsigned pfo = (unsigned)pfirst[valid && !isy ? bown : dpos];
+                    const int s1 = pfo & 0x7fff, s2 = (pfo >> 15) & 0x7fff, no = valid ? (int)(pfo >> 30) : 0;
+                    T in[6], avec[6], m[36];
+                    load_row6(p, in);
+                    load_row6(isy ? z + 6 * ysrc : Lw + (size_t)s1 * 36 + 6 * r, avec);
+                    {
+                        const T *M = Lw + (size_t)(isy ? s1 : s2) * 36;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) load_row6(M + 6 * c, reinterpret_cast<T (&)[6]>(m[6 * c]));
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        T acc = avec[0] * m[6 * c];
+#pragma unroll
+                        for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
+                        in[c] -= no > 0 ? acc : (T)0;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(no > 1)) {       // rare: further pending pairs, lists in global memory
+                        if (no > 1) {
+                            const int bsel = isy ? dpos : bown;
+                            for (int k = pd.fz_pend_ptr[bsel] + 1; k < pd.fz_pend_ptr[bsel + 1]; ++k) {
+                                const int t1 = pd.fz_pend[2 * k], t2 = pd.fz_pend[2 * k + 1];
+                                const T *av = isy ? z + 6 * ((row_idx[t1] >> 8) & 255) : Lw + (size_t)t1 * 36 + 6 * r;
+                                const T *M = Lw + (size_t)(isy ? t1 : t2) * 36;
+                                for (int c = 0; c < 6; ++c) {
+                                    T acc = (T)0;
+                                    for (int e = 0; e < 6; ++e) acc += av[e] * M[6 * c + e];
+                                    in[c] -= acc;
+                                }
                             }
                         }
                     }
-                }
-                if (lane < 36) {
-                    scr[wave * 36 + lane] = v;
-                    // the updated block goes in place one level later (its next reader is the back substitution)
-                    if (part == 0) dstage[(size_t)((l & 1) * kMaxLevelCols + q) * 36 + lane] = v;
-                }
-                BT_SUB(0);
-                BT_SUB(1);
-                wave_fence();
-                // (3) factor the updated diagonal block (every lane, in registers) and substitute the own row
-                T L[21];
-                const T *dblk = scr + wave * 36;
+                    BT_SUB(3);
+                    while (__hip_atomic_load(&lready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= l) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    T L[21];
+                    load_packed21(lpk + q * 24, L);
+                    BT_SUB(4);
+                    if (valid) {
+                        T out[6];
 #pragma unroll
-                for (int rr = 0; rr < 6; ++rr) {
-                    T row[6];
-                    load_row6(dblk + 6 * rr, row);
+                        for (int c = 0; c < 6; ++c) {
+                            T t = in[c];
 #pragma unroll
-                    for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
-                }
-                const bool ok = chol6_packed<T>(L);
-                if (PROF) { asm volatile("" :: "v"(L[20])); }
-                BT_SUB(2);
-                if (valid) {
-                    T out[6];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        T t = in[c];
-#pragma unroll
-                        for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
-                        out[c] = t * L[BT_LT(c, c)];
+                            for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
+                            out[c] = t * L[BT_LT(c, c)];
+                        }
+                        store_row6(p, out);
                     }
-                    store_row6(p, out);
+                    BT_SUB(5);
                 }
-                BT_SUB(3);
-                if (!ok && lane == 0) flags[0] = 1;
-                BT_SUB(4);
-                wave_fence();                              // scratch is reused by this wave's next column
                 __builtin_amdgcn_s_setprio(0);
             }
             if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); phA += tn - tph; tph = tn; }
@@ -1505,23 +1538,23 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         const int back = hs - 1 - h;
                         if (back < pnc * 18) {
                             const int q = back / 18, e = back - 18 * q;
-                            const int dpos = q == 0 ? pA0.y : pA1.y;
+                            const int dpos = (q == 0 ? p0b : p1b) & 0xffff;
                             reinterpret_cast<double2 *>(Lw + (size_t)dpos * 36)[e] =
                                 reinterpret_cast<const double2 *>(dstage + (size_t)(((l - 1) & 1) * kMaxLevelCols + q) * 36)[e];
                         }
                     }
-                    const int rows0 = pA0.x >= 0 ? pn0 * 6 : 0, rows1 = rows0 + (pA1.x >= 0 ? pn1 * 6 : 0);
+                    const int rows0 = (p0c >> 16) * 6, rows1 = rows0 + (pnc > 1 ? (p1c >> 16) * 6 : 0);
                     for (int item = h; item < rows1; item += hs) {
                         const bool sec = item >= rows0;
                         const int idx = item - (sec ? rows0 : 0), t = idx / 6;
-                        apply_update_row<T, false>(Lw, lazy + 3 * ((sec ? pA1.w : pA0.w) + t), idx - 6 * t);
+                        apply_update_row<T, false>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t);
                     }
-                    const int ys0 = pA0.x >= 0 ? pA0.z * 6 : 0, ys1 = ys0 + (pA1.x >= 0 ? pA1.z * 6 : 0);
+                    const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
                     const int shift = ((rows1 + 63) >> 6) << 6;
                     for (int item = (h - shift % hs + hs) % hs; item < ys1; item += hs) {
                         const bool sec = item >= ys0;
                         const int qq = item - (sec ? ys0 : 0);
-                        const int pj = sec ? pA1.x : pA0.x, dposp = sec ? pA1.y : pA0.y, sb = qq / 6, r = qq - 6 * sb;
+                        const int pj = (sec ? p1a : p0a) & 255, dposp = (sec ? p1b : p0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
                         const int rcv = row_idx[dposp + 1 + sb];
                         if (rcv & (1 << 25)) continue;            // pending: the destination column's y thread takes it
                         T lr[6], zr[6];
@@ -1534,16 +1567,16 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     }
                 }
             }
-            if (feeder && l + 2 < nlev) mbuf[(l + 2) % 3][tid - (nth - 2 * kFusedCols)] = mnext;
+            if (feeder && l + 2 < nlev) mbuf[(l + 2) % 3][tid - (nth - 2)] = mnext;
             if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); phL += clock64() - tph; }
-            pA0 = cA0; pA1 = cA1; pn0 = cB0.x; pn1 = cB1.x; pnc = cB0.w;
+            p0a = c0a; p0b = c0b; p0c = c0c; p1a = c1a; p1b = c1b; p1c = c1c; pnc = cnc;
             if (l + 1 < nlev) take_level(l + 1);
             __syncthreads();
         }
         // the last level's staged diagonal blocks (its columns have no lazy work: nothing lies above them)
         if (tid < pnc * 18) {
             const int q = tid / 18, e = tid - 18 * q;
-            const int dpos = q == 0 ? pA0.y : pA1.y;
+            const int dpos = (q == 0 ? p0b : p1b) & 0xffff;
             reinterpret_cast<double2 *>(Lw + (size_t)dpos * 36)[e] =
                 reinterpret_cast<const double2 *>(dstage + (size_t)(((nlev - 1) & 1) * kMaxLevelCols + q) * 36)[e];
         }
@@ -1551,7 +1584,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         if (PROF) tsweep = clock64() - tall;
 
         int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
-        for (int i = tid; i < nlev * kMaxLevelCols; i += nth) bmeta[i] = meta[2 * i];
+        for (int i = tid; i < nlev * kMaxLevelCols; i += nth) bmeta[i] = reinterpret_cast<const int4 *>(pd.fz_meta)[2 * i];
         lds_back_substitute<T, true>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth);
         for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
         __syncthreads();
@@ -1571,10 +1604,10 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     if (PROF && lane == 0) {        // measurement only: per-wave busy cycles (columns, lazy work) and the stage boundaries
         long long *o = reinterpret_cast<long long *>(a.status + 4) + 40 + wave * 2;
         o[0] = phA; o[1] = phL;
-        if (wave == 0) {
-            long long *g = reinterpret_cast<long long *>(a.status + 4);
+        if (wave == 0 || wave == 2) {
+            long long *g = reinterpret_cast<long long *>(a.status + 4) + (wave ? 10 : 0);
             g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
-            for (int i = 0; i < 5; ++i) g[3 + i] = sub[i];
+            for (int i = 0; i < 6; ++i) g[3 + i] = sub[i];
         }
     }
 #undef BT_SUB
