@@ -57,6 +57,32 @@ __global__ void k_f64_chain(double *out, long long *cyc, int iters) {
     if (threadIdx.x == 0) { out[0] = a + r; cyc[0] = t1 - t0; cyc[1] = t3 - t2; }
 }
 
+// reciprocal square root variants for the 6x6 pivots: accuracy against 1/sqrt in double, and the
+// cycles of a dependent chain
+__device__ __forceinline__ double rs_seed32(double x) { const double y = (double)__builtin_amdgcn_rsqf((float)x); return y * (1.5 - 0.5 * x * y * y); }
+__device__ __forceinline__ double rs_hw64(double x) { return __builtin_amdgcn_rsq(x); }
+__device__ __forceinline__ double rs_hw64n(double x) { const double y = __builtin_amdgcn_rsq(x); return y * (1.5 - 0.5 * x * y * y); }
+__global__ void k_rsq(double *out, long long *cyc, int iters) {
+    double e0 = 0, e1 = 0, e2 = 0;
+    for (int i = threadIdx.x; i < 200000; i += blockDim.x) {
+        const double x = exp2((double)(i % 97) - 40.0) * (1.0 + (double)i * 4.7e-6);
+        const double ref = 1.0 / sqrt(x);
+        e0 = fmax(e0, fabs(rs_seed32(x) - ref) / ref);
+        e1 = fmax(e1, fabs(rs_hw64(x) - ref) / ref);
+        e2 = fmax(e2, fabs(rs_hw64n(x) - ref) / ref);
+    }
+    for (int o = 32; o; o >>= 1) { e0 = fmax(e0, __shfl_xor(e0, o)); e1 = fmax(e1, __shfl_xor(e1, o)); e2 = fmax(e2, __shfl_xor(e2, o)); }
+    double r = 2.0 + threadIdx.x;
+    long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) r = rs_seed32(r) + 2.0;
+    long long t1 = clock64();
+    for (int i = 0; i < iters; ++i) r = rs_hw64(r) + 2.0;
+    long long t2 = clock64();
+    for (int i = 0; i < iters; ++i) r = rs_hw64n(r) + 2.0;
+    long long t3 = clock64();
+    if (threadIdx.x == 0) { out[0] = e0; out[1] = e1; out[2] = e2; out[3] = r; cyc[0] = t1 - t0; cyc[1] = t2 - t1; cyc[2] = t3 - t2; }
+}
+
 __global__ void k_atomic(double *dst, int n_addr, int per_thread) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     for (int i = 0; i < per_thread; ++i) {
@@ -93,6 +119,15 @@ int main() {
         for (int i = 0; i < N; ++i) hipLaunchKernelGGL(k_empty, dim3(grid), dim3(256), 0, 0, (int *)nullptr);
         CK(hipDeviceSynchronize());
         printf("empty kernel grid=%d: %.2f us per launch (back-to-back, one stream)\n", grid, (now() - t0) / N * 1e6);
+    }
+    {
+        const int iters = 20000;
+        hipLaunchKernelGGL(k_rsq, dim3(1), dim3(64), 0, 0, dd, dcyc, iters);
+        CK(hipDeviceSynchronize());
+        double he[4];
+        CK(hipMemcpy(he, dd, sizeof(he), hipMemcpyDeviceToHost)); CK(hipMemcpy(hc, dcyc, sizeof(hc), hipMemcpyDeviceToHost));
+        printf("rsqrt(double): f32 seed + Newton: max rel err %.2e, %.1f cycles/op (+1 add) | v_rsq_f64: %.2e, %.1f | v_rsq_f64 + Newton: %.2e, %.1f\n",
+               he[0], (double)hc[0] / iters, he[1], (double)hc[1] / iters, he[2], (double)hc[2] / iters);
     }
     // effective clock of a single wave / single WG
     for (int rep = 0; rep < 3; ++rep) {
