@@ -840,6 +840,34 @@ __device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr
     if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); pf[9] += tn - *tcp; *tcp = tn; }
 }
 
+// Half a row of an update triple (outputs 3 hh .. 3 hh + 2): 12 vector loads and 18 FMAs.
+template <typename T>
+__device__ __forceinline__ void apply_update_half(T *Lw, const unsigned short *tr, int r, int hh) {
+    T a[6], b[18], v[3], o[3];
+    const unsigned d = tr[2];
+    T *dst = Lw + (size_t)(d & 0x7fffu) * 36 + 6 * r + 3 * hh;
+    const T *bb = Lw + (size_t)tr[1] * 36 + 18 * hh;
+    load_row6(Lw + (size_t)tr[0] * 36 + 6 * r, a);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) load_row6(bb + 6 * c, reinterpret_cast<T (&)[6]>(b[6 * c]));
+    v[0] = dst[0]; v[1] = dst[1]; v[2] = dst[2];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        T acc = a[0] * b[6 * c];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += a[k] * b[6 * c + k];
+        o[c] = acc;
+    }
+    if (d & 0x8000u) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(dst + c, -o[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[c] = v[c] - o[c];
+    }
+}
+
 // wave-uniform metadata: LDS -> SGPRs
 __device__ __forceinline__ int4 uniform4(const int4 v) {
     return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
@@ -1392,43 +1420,47 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         __syncthreads();
         if (PROF) tload = clock64() - tall;
 
-        // wave-uniform packed level metadata in SGPRs (ba_plan.cpp: fz_pmeta)
-        int c0a, c0b, c0c, c1a, c1b, c1c, cnc;             // current level: columns 0 and 1, #columns
-        int p0a = 0, p0b = 0, p0c = 0, p1a = 0, p1b = 0, p1c = 0, pnc = 0;   // previous level
-        auto take_level = [&](int l) {
+        // wave-uniform packed level metadata in SGPRs (ba_plan.cpp: fz_pmeta): current, next and previous level
+        int c0a, c0b, c0c, c0d, c1a, c1b, c1c, c1d, n0a = 0, n0b = 0, n0c = 0, n0d = 0, n1a = 0, n1b = 0, n1c = 0, n1d = 0;
+        int p0a = 0, p0b = 0, p0c = 0, p1a = 0, p1b = 0, p1c = 0, pnc = 0;
+        auto take_next = [&](int l) {
             const int4 m0 = mbuf[l % 3][0], m1 = mbuf[l % 3][1];
-            c0a = __builtin_amdgcn_readfirstlane(m0.x); c0b = __builtin_amdgcn_readfirstlane(m0.y); c0c = __builtin_amdgcn_readfirstlane(m0.z);
-            c1a = __builtin_amdgcn_readfirstlane(m0.w); c1b = __builtin_amdgcn_readfirstlane(m1.x); c1c = __builtin_amdgcn_readfirstlane(m1.y);
-            cnc = __builtin_amdgcn_readfirstlane(m1.z);
+            n0a = __builtin_amdgcn_readfirstlane(m0.x); n0b = __builtin_amdgcn_readfirstlane(m0.y);
+            n0c = __builtin_amdgcn_readfirstlane(m0.z); n0d = __builtin_amdgcn_readfirstlane(m0.w);
+            n1a = __builtin_amdgcn_readfirstlane(m1.x); n1b = __builtin_amdgcn_readfirstlane(m1.y);
+            n1c = __builtin_amdgcn_readfirstlane(m1.z); n1d = __builtin_amdgcn_readfirstlane(m1.w);
         };
-        take_level(0);
+        take_next(0);
         const bool feeder = tid >= nth - 2;           // the last two threads bring in level l + 2's metadata
+        unsigned pf_next = 0;                         // a row wave's pfirst entry of the next level, read ahead
+        int pf_level = -1;
         for (int l = 0; l < nlev; ++l) {
+            c0a = n0a; c0b = n0b; c0c = n0c; c0d = n0d; c1a = n1a; c1b = n1b; c1c = n1c; c1d = n1d;
             if (PROF) tph = clock64();
             int4 mnext = make_int4(0, 0, 0, 0);
             if (feeder && l + 2 < nlev) mnext = pmeta[(size_t)(l + 2) * 2 + (tid - (nth - 2))];
-            const int nr0 = c0b >> 16, nr1 = cnc > 1 ? c1b >> 16 : 0;     // row waves of the two columns
-            const int nA = cnc + nr0 + nr1;                               // factor waves, then row waves
+            const int cnc = (c0b >> 24) & 3;
+            const int nr0 = (c0b >> 16) & 255, nr1 = cnc > 1 ? (c1b >> 16) & 255 : 0;     // row waves of the two columns
+            const int nA = cnc + nr0 + nr1;                                               // factor waves, then row waves
+            bool got_next = false;
             for (int aw = wave; aw < nA; aw += nw) {
                 __builtin_amdgcn_s_setprio(3);
                 if (PROF) tsub = clock64();
                 if (aw < cnc) {
                     // ---- factor wave of column q = aw: bring the diagonal block up to date (lanes 0..35, one
                     // element each), factor it (every lane, in registers), publish the packed factor
-                    const int q = aw, ma = q ? c1a : c0a, dpos = (q ? c1b : c0b) & 0xffff;
-                    (void)ma;
-                    const unsigned pfd = (unsigned)pfirst[dpos];
+                    const int q = aw, dpos = (q ? c1b : c0b) & 0xffff, md = q ? c1d : c0d;
                     const int el = lane < 36 ? lane : lane - 36, dr = el / 6, dc = el - 6 * dr;
-                    const int sd = pfd & 0x7fff, nd = pfd >> 30;
+                    const int sd = md & 0x7fff, nd = md >> 15;
                     T x[6], yv[6];
                     T v = Lw[(size_t)dpos * 36 + el];
                     load_row6(Lw + (size_t)sd * 36 + 6 * dr, x);
                     load_row6(Lw + (size_t)sd * 36 + 6 * dc, yv);
-                    {
+                    if (nd > 0) {
                         T acc = x[0] * yv[0];
 #pragma unroll
                         for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
-                        v -= nd > 0 ? acc : (T)0;
+                        v -= acc;
                     }
                     if (nd > 1 && lane < 36)              // rare: further pending pairs, lists in global memory
                         for (int k = pd.fz_pend_ptr[dpos] + 1; k < pd.fz_pend_ptr[dpos + 1]; ++k) {
@@ -1462,6 +1494,26 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         __hip_atomic_store(&lready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     BT_SUB(2);
+                    __builtin_amdgcn_s_setprio(0);
+                    if (!got_next && l + 1 < nlev) { take_next(l + 1); got_next = true; }
+                    // lazy y contributions of the level below, spread over the factor waves
+                    if (l > 0) {
+                        const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
+                        for (int item = aw * 64 + lane; item < ys1; item += cnc * 64) {
+                            const bool sec = item >= ys0;
+                            const int qq = item - (sec ? ys0 : 0);
+                            const int pj = (sec ? p1a : p0a) & 255, dposp = (sec ? p1b : p0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
+                            const int rcv = row_idx[dposp + 1 + sb];
+                            if (rcv & (1 << 25)) continue;            // pending: the destination column's y thread takes it
+                            T lr[6], zr[6];
+                            load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
+                            load_row6(z + 6 * pj, zr);
+                            T acc = lr[0] * zr[0];
+#pragma unroll
+                            for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
+                            lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv & (1 << 24)) != 0);
+                        }
+                    }
                 } else {
                     // ---- row wave: one panel row (or y_j) per lane: its pending update, then, once the factor
                     // wave has published L_jj, the forward substitution
@@ -1474,7 +1526,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     T *p = isy ? z + 6 * j : Lw + (size_t)bown * 36 + 6 * r;
                     // in[c] -= sum_e avec[e] M[c][e] with avec = row r of src1 and M = src2, or for the y row
                     // avec = y of the source column and M = src1; every load is in flight before the first FMA
-                    const unsigned pfo = (unsigned)pfirst[valid && !isy ? bown : dpos];
+                    const unsigned pfo = (pf_level == l && aw == wave) ? pf_next : (unsigned)pfirst[valid && !isy ? bown : dpos];
                     const int s1 = pfo & 0x7fff, s2 = (pfo >> 15) & 0x7fff, no = valid ? (int)(pfo >> 30) : 0;
                     T in[6], avec[6], m[36];
                     load_row6(p, in);
@@ -1507,6 +1559,20 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         }
                     }
                     BT_SUB(3);
+                    // while the factor wave works: the next level's metadata and this wave's pfirst entry there
+                    if (!got_next && l + 1 < nlev) {
+                        take_next(l + 1);
+                        got_next = true;
+                        const int ncn = (n0b >> 24) & 3, mr0 = (n0b >> 16) & 255;
+                        const int ran = wave - ncn;
+                        if (ran >= 0) {
+                            const int qn = ran >= mr0 ? 1 : 0, partn = ran - (qn ? mr0 : 0);
+                            const int cntn = ((qn ? n1a : n0a) >> 8) & 255, dposn = (qn ? n1b : n0b) & 0xffff;
+                            const int rwn = partn * 64 + lane;
+                            pf_next = (unsigned)pfirst[rwn < cntn * 6 ? dposn + 1 + rwn / 6 : dposn];
+                            pf_level = l + 1;
+                        }
+                    }
                     while (__hip_atomic_load(&lready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= l) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     T L[21];
@@ -1524,11 +1590,11 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         store_row6(p, out);
                     }
                     BT_SUB(5);
+                    __builtin_amdgcn_s_setprio(0);
                 }
-                __builtin_amdgcn_s_setprio(0);
             }
             if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); phA += tn - tph; tph = tn; }
-            // ---- lazy work of the level below
+            // ---- lazy updates of the level below: helper waves (all waves once there are more column waves than waves)
             if (l > 0) {
                 int h, hs;
                 if (nA < nw) { h = tid - 64 * nA; hs = nth - 64 * nA; }
@@ -1543,34 +1609,28 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                                 reinterpret_cast<const double2 *>(dstage + (size_t)(((l - 1) & 1) * kMaxLevelCols + q) * 36)[e];
                         }
                     }
-                    const int rows0 = (p0c >> 16) * 6, rows1 = rows0 + (pnc > 1 ? (p1c >> 16) * 6 : 0);
-                    for (int item = h; item < rows1; item += hs) {
-                        const bool sec = item >= rows0;
-                        const int idx = item - (sec ? rows0 : 0), t = idx / 6;
-                        apply_update_row<T, false>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t);
-                    }
-                    const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
-                    const int shift = ((rows1 + 63) >> 6) << 6;
-                    for (int item = (h - shift % hs + hs) % hs; item < ys1; item += hs) {
-                        const bool sec = item >= ys0;
-                        const int qq = item - (sec ? ys0 : 0);
-                        const int pj = (sec ? p1a : p0a) & 255, dposp = (sec ? p1b : p0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
-                        const int rcv = row_idx[dposp + 1 + sb];
-                        if (rcv & (1 << 25)) continue;            // pending: the destination column's y thread takes it
-                        T lr[6], zr[6];
-                        load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
-                        load_row6(z + 6 * pj, zr);
-                        T acc = lr[0] * zr[0];
-#pragma unroll
-                        for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
-                        lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv & (1 << 24)) != 0);
+                    const int rows0 = ((p0c >> 16) & 0xffff) * 6, rows1 = rows0 + (pnc > 1 ? ((p1c >> 16) & 0xffff) * 6 : 0);
+                    if (2 * rows1 <= hs) {
+                        // half rows: two threads per row of a triple, the shortest chain when the helpers are plenty
+                        if (h < 2 * rows1) {
+                            const int item = h >> 1, hh = h & 1;
+                            const bool sec = item >= rows0;
+                            const int idx = item - (sec ? rows0 : 0), t = idx / 6;
+                            apply_update_half<T>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t, hh);
+                        }
+                    } else {
+                        for (int item = h; item < rows1; item += hs) {
+                            const bool sec = item >= rows0;
+                            const int idx = item - (sec ? rows0 : 0), t = idx / 6;
+                            apply_update_row<T, false>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t);
+                        }
                     }
                 }
             }
             if (feeder && l + 2 < nlev) mbuf[(l + 2) % 3][tid - (nth - 2)] = mnext;
             if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); phL += clock64() - tph; }
             p0a = c0a; p0b = c0b; p0c = c0c; p1a = c1a; p1b = c1b; p1c = c1c; pnc = cnc;
-            if (l + 1 < nlev) take_level(l + 1);
+            if (!got_next && l + 1 < nlev) take_next(l + 1);
             __syncthreads();
         }
         // the last level's staged diagonal blocks (its columns have no lazy work: nothing lies above them)

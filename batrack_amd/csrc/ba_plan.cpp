@@ -500,24 +500,28 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             pl->fz_pend.insert(pl->fz_pend.end(), pend[b].begin(), pend[b].end());
         }
         pl->fz_pend_ptr[nb] = (int32_t)(pl->fz_pend.size() / 2);
-        // packed per-level record of the (at most two) columns k_solve_fused handles per level:
-        //   [3q]   col | #sub-blocks << 8 | source column of the diagonal block's first pending pair << 16
-        //   [3q+1] diag pos | #row waves << 16      [3q+2] first lazy triple | #lazy << 16      [6] #cols
+        // packed per-level record of the (at most two) columns k_solve_fused handles per level, 4 ints each:
+        //   [4q]   col | #sub-blocks << 8 | source column of the diagonal block's first pending pair << 16
+        //   [4q+1] diag pos | #row waves << 16 | (q = 0: #cols << 24)
+        //   [4q+2] first lazy triple | #lazy << 16
+        //   [4q+3] source block of the diagonal block's first pending pair | min(#pending, 3) << 15
         pl->fz_pmeta.assign((size_t)nlev * 8, 0);
         for (int32_t l = 0; l < nlev; ++l) {
             const int32_t nc = pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l];
             int32_t *m = pl->fz_pmeta.data() + (size_t)l * 8;
-            m[6] = nc;
             for (int32_t q = 0; q < nc && q < 2; ++q) {
                 const int32_t j = pl->lvl_cols[(size_t)pl->lvl_ptr[(size_t)l] + q];
                 const int32_t dpos = pl->col_ptr[(size_t)j], cnt = pl->col_ptr[(size_t)j + 1] - dpos - 1;
-                const int32_t k0 = pl->fz_pend_ptr[(size_t)dpos];
-                const int32_t ysrc = pl->fz_pend_ptr[(size_t)dpos + 1] > k0 ? (pl->blk_col[(size_t)pl->fz_pend[(size_t)k0 * 2]] & 255) : 0;
+                const int32_t k0 = pl->fz_pend_ptr[(size_t)dpos], np = pl->fz_pend_ptr[(size_t)dpos + 1] - k0;
+                const int32_t sd = np > 0 ? pl->fz_pend[(size_t)k0 * 2] : 0;
+                const int32_t ysrc = np > 0 ? (pl->blk_col[(size_t)sd] & 255) : 0;
                 const int32_t lz0 = pl->fz_lazy_ptr[(size_t)j], nlz = pl->fz_lazy_ptr[(size_t)j + 1] - lz0;
-                m[3 * q] = j | (cnt << 8) | (ysrc << 16);
-                m[3 * q + 1] = dpos | (((6 * cnt + 1 + 63) / 64) << 16);
-                m[3 * q + 2] = lz0 | (nlz << 16);
+                m[4 * q] = j | (cnt << 8) | (ysrc << 16);
+                m[4 * q + 1] = dpos | (((6 * cnt + 1 + 63) / 64) << 16);
+                m[4 * q + 2] = lz0 | (nlz << 16);
+                m[4 * q + 3] = sd | ((np < 3 ? np : 3) << 15);
             }
+            m[1] |= nc << 24;
         }
         pl->fz_meta.assign((size_t)nlev * kMaxLevelCols * 8, 0);
         pl->fz_ok = (pl->fz_lazy.size() / 3 < 65536 && pl->row_idx.size() < 32768) ? 1 : 0;

@@ -286,12 +286,15 @@ def sparse_chol_solve_fused(A, S_lower, y, n, ep, lm):
             else:
                 assert m[0] == -1
         pm = A["fz_pmeta"].reshape(-1, 8)[l]
-        assert pm[6] == len(cols)
+        assert pm[1] >> 24 == len(cols)
         for q, c in enumerate(cols[:2]):
             d = int(col_ptr[c]); cnt = int(col_ptr[c + 1]) - d - 1
-            ysrc = int(blk_col[pend[pend_ptr[d]][0]]) if pend_ptr[d + 1] > pend_ptr[d] else 0
-            assert pm[3*q] == (c | cnt << 8 | ysrc << 16) and pm[3*q + 1] == (d | ((6 * cnt + 1 + 63) // 64) << 16)
-            assert pm[3*q + 2] == (int(lazy_ptr[c]) | (int(lazy_ptr[c + 1] - lazy_ptr[c]) << 16))
+            npd = int(pend_ptr[d + 1] - pend_ptr[d])
+            sd = int(pend[pend_ptr[d]][0]) if npd else 0
+            ysrc = int(blk_col[sd]) if npd else 0
+            assert pm[4*q] == (c | cnt << 8 | ysrc << 16) and (pm[4*q + 1] & 0xffffff) == (d | ((6 * cnt + 1 + 63) // 64) << 16)
+            assert pm[4*q + 2] == (int(lazy_ptr[c]) | (int(lazy_ptr[c + 1] - lazy_ptr[c]) << 16))
+            assert pm[4*q + 3] == (sd | min(npd, 3) << 15)
         a_reads, a_writes = set(), set()              # blocks; ("z", col) for y segments
         for c in cols:
             d = int(col_ptr[c])
