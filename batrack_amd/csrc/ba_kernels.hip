@@ -1496,24 +1496,6 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     BT_SUB(2);
                     __builtin_amdgcn_s_setprio(0);
                     if (!got_next && l + 1 < nlev) { take_next(l + 1); got_next = true; }
-                    // lazy y contributions of the level below, spread over the factor waves
-                    if (l > 0) {
-                        const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
-                        for (int item = aw * 64 + lane; item < ys1; item += cnc * 64) {
-                            const bool sec = item >= ys0;
-                            const int qq = item - (sec ? ys0 : 0);
-                            const int pj = (sec ? p1a : p0a) & 255, dposp = (sec ? p1b : p0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
-                            const int rcv = row_idx[dposp + 1 + sb];
-                            if (rcv & (1 << 25)) continue;            // pending: the destination column's y thread takes it
-                            T lr[6], zr[6];
-                            load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
-                            load_row6(z + 6 * pj, zr);
-                            T acc = lr[0] * zr[0];
-#pragma unroll
-                            for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
-                            lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv & (1 << 24)) != 0);
-                        }
-                    }
                 } else {
                     // ---- row wave: one panel row (or y_j) per lane: its pending update, then, once the factor
                     // wave has published L_jj, the forward substitution
@@ -1623,6 +1605,26 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                             const bool sec = item >= rows0;
                             const int idx = item - (sec ? rows0 : 0), t = idx / 6;
                             apply_update_row<T, false>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t);
+                        }
+                    }
+                    // lazy y contributions of the level below, on the threads after those with update rows
+                    {
+                        const int used = 2 * rows1 <= hs ? 2 * rows1 : rows1;
+                        const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
+                        const int shift = ((used + 63) >> 6) << 6;
+                        for (int item = (h - shift % hs + hs) % hs; item < ys1; item += hs) {
+                            const bool sec = item >= ys0;
+                            const int qq = item - (sec ? ys0 : 0);
+                            const int pj = (sec ? p1a : p0a) & 255, dposp = (sec ? p1b : p0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
+                            const int rcv = row_idx[dposp + 1 + sb];
+                            if (rcv & (1 << 25)) continue;            // pending: the destination column's y thread takes it
+                            T lr[6], zr[6];
+                            load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
+                            load_row6(z + 6 * pj, zr);
+                            T acc = lr[0] * zr[0];
+#pragma unroll
+                            for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
+                            lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv & (1 << 24)) != 0);
                         }
                     }
                 }
