@@ -1432,6 +1432,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         };
         take_next(0);
         const bool feeder = tid >= nth - 2;           // the last two threads bring in level l + 2's metadata
+        const bool half_rows = (a.dbg & 64) != 0;     // measurement only: two threads per lazy update row
         unsigned pf_next = 0;                         // a row wave's pfirst entry of the next level, read ahead
         int pf_level = -1;
         for (int l = 0; l < nlev; ++l) {
@@ -1592,7 +1593,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         }
                     }
                     const int rows0 = ((p0c >> 16) & 0xffff) * 6, rows1 = rows0 + (pnc > 1 ? ((p1c >> 16) & 0xffff) * 6 : 0);
-                    if (2 * rows1 <= hs) {
+                    if (half_rows && 2 * rows1 <= hs) {
                         // half rows: two threads per row of a triple, the shortest chain when the helpers are plenty
                         if (h < 2 * rows1) {
                             const int item = h >> 1, hh = h & 1;
@@ -1609,7 +1610,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     }
                     // lazy y contributions of the level below, on the threads after those with update rows
                     {
-                        const int used = 2 * rows1 <= hs ? 2 * rows1 : rows1;
+                        const int used = half_rows && 2 * rows1 <= hs ? 2 * rows1 : rows1;
                         const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
                         const int shift = ((used + 63) >> 6) << 6;
                         for (int item = (h - shift % hs + hs) % hs; item < ys1; item += hs) {
