@@ -1496,7 +1496,6 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     }
                     BT_SUB(2);
                     __builtin_amdgcn_s_setprio(0);
-                    if (!got_next && l + 1 < nlev) { take_next(l + 1); got_next = true; }
                 } else {
                     // ---- row wave: one panel row (or y_j) per lane: its pending update, then, once the factor
                     // wave has published L_jj, the forward substitution
