@@ -1542,7 +1542,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     }
                     BT_SUB(3);
                     // while the factor wave works: the next level's metadata and this wave's pfirst entry there
-                    if (!got_next && l + 1 < nlev) {
+                    if ((a.dbg & 128) && !got_next && l + 1 < nlev) {        // measurement only
                         take_next(l + 1);
                         got_next = true;
                         const int ncn = (n0b >> 24) & 3, mr0 = (n0b >> 16) & 255;
