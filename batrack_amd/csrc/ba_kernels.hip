@@ -1324,27 +1324,59 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
         store_row6(q, out);
     }
     __syncthreads();
-    for (int l = nlev - 1; l >= 0; --l) {
-        const int4 ma = uniform4(lvl_meta[(l * kMaxLevelCols + (wave < kMaxLevelCols ? wave : 0)) * mstride]);
-        if (wave < kMaxLevelCols && ma.x >= 0) {
-            const int c = lane >> 3, g = lane & 7;
-            const int j = ma.x, dpos = ma.y, cnt = ma.z;
-            T acc = (T)0;
-            if (c < 6)
-                for (int sb = g; sb < cnt; sb += 8) {           // one sub-block per lane group
-                    const int b = dpos + 1 + sb;
+    // (c) x_j = zt_j - sum_{i>j} M_ij x_i, levels descending, ONE WAVE PER COLUMN SLOT and no barrier unless
+    // the level reads an x_i another slot's wave wrote since the last barrier (lvl_meta[..].w, ba_plan.cpp
+    // bs_sync): on a two-ended chain the two waves run down their chains independently.  The static
+    // operands of level l - 1 (block index, M entries) are loaded before level l's x are waited for.
+    // lane = (component c) * 8 + g, one sub-block per lane group g.
+    {
+        const bool bw = wave < kMaxLevelCols;
+        const int c = lane >> 3, g = lane & 7;
+        int4 nma = make_int4(-1, 0, 0, 0);
+        int nrc = 0;
+        T nm[6] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+        auto preload = [&](int l) {
+            nma = uniform4(lvl_meta[(l * kMaxLevelCols + (bw ? wave : 0)) * mstride]);
+            if (!bw) nma.x = -1;
+            if (nma.x >= 0 && c < 6 && g < nma.z) {
+                const int b = nma.y + 1 + g;
+                nrc = row_idx[b] & 255;
+                const T *mb = Lw + (size_t)b * 36 + c;     // Mt[r][c]
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nm[k] = mb[6 * k];
+            }
+        };
+        preload(nlev - 1);
+        for (int l = nlev - 1; l >= 0; --l) {
+            const int4 ma = nma;
+            const int rc = nrc;
+            T m[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[k] = nm[k];
+            if (l > 0) preload(l - 1);
+            if (ma.w) __syncthreads();
+            if (ma.x >= 0) {
+                const int j = ma.x, dpos = ma.y, cnt = ma.z;
+                T acc = (T)0;
+                if (c < 6 && g < cnt) {
                     T x[6];
-                    load_row6(zt + 6 * (row_idx[b] & 255), x);
-                    const T *mb = Lw + (size_t)b * 36 + c;     // Mt[r][c]
-                    acc += mb[0] * x[0] + mb[6] * x[1] + mb[12] * x[2] + mb[18] * x[3] + mb[24] * x[4] + mb[30] * x[5];
+                    load_row6(zt + 6 * rc, x);
+                    acc = m[0] * x[0] + m[1] * x[1] + m[2] * x[2] + m[3] * x[3] + m[4] * x[4] + m[5] * x[5];
+                    for (int sb = g + 8; sb < cnt; sb += 8) {       // wide columns: further sub-blocks of this lane group
+                        const int b = dpos + 1 + sb;
+                        load_row6(zt + 6 * (row_idx[b] & 255), x);
+                        const T *mb = Lw + (size_t)b * 36 + c;
+                        acc += mb[0] * x[0] + mb[6] * x[1] + mb[12] * x[2] + mb[18] * x[3] + mb[24] * x[4] + mb[30] * x[5];
+                    }
                 }
-            acc = dpp_add8(acc);
-            if (c < 6 && g == 0) zt[6 * j + c] -= acc;
+                acc = dpp_add8(acc);
+                if (c < 6 && g == 0) zt[6 * j + c] -= acc;
+                wave_fence();
+            }
         }
         __syncthreads();
     }
 }
-
 
 // LDS of k_solve_fused: Lw | z | work | row_idx | pfirst | col_ptr, where `work` holds the sweep's tables
 // (per-wave scratch, staged diagonal blocks, lazy triples) and is reused for zt afterwards.
@@ -1646,7 +1678,11 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         if (PROF) tsweep = clock64() - tall;
 
         int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
-        for (int i = tid; i < nlev * kMaxLevelCols; i += nth) bmeta[i] = reinterpret_cast<const int4 *>(pd.fz_meta)[2 * i];
+        for (int i = tid; i < nlev * kMaxLevelCols; i += nth) {          // (col, diag pos, #sub-blocks, barrier before this level)
+            int4 mm = reinterpret_cast<const int4 *>(pd.fz_meta)[2 * i];
+            mm.w = pd.bs_sync[i / kMaxLevelCols];
+            bmeta[i] = mm;
+        }
         lds_back_substitute<T, true>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth);
         for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
         __syncthreads();

@@ -523,6 +523,27 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             }
             m[1] |= nc << 24;
         }
+        // back substitution, levels descending, one wave per column slot: a barrier is needed before a level
+        // only if one of its columns reads an x_i written by another slot's wave since the last barrier
+        pl->bs_sync.assign((size_t)nlev, 0);
+        {
+            std::vector<int32_t> slot((size_t)n, 0);
+            for (int32_t l = 0; l < nlev; ++l)
+                for (int32_t qi = pl->lvl_ptr[(size_t)l]; qi < pl->lvl_ptr[(size_t)l + 1]; ++qi)
+                    slot[(size_t)pl->lvl_cols[(size_t)qi]] = qi - pl->lvl_ptr[(size_t)l];
+            int32_t last_barrier = nlev;          // no barrier yet
+            for (int32_t l = nlev - 1; l >= 0; --l) {
+                bool need = false;
+                for (int32_t qi = pl->lvl_ptr[(size_t)l]; qi < pl->lvl_ptr[(size_t)l + 1]; ++qi) {
+                    const int32_t j = pl->lvl_cols[(size_t)qi];
+                    for (int32_t b = pl->col_ptr[(size_t)j] + 1; b < pl->col_ptr[(size_t)j + 1]; ++b) {
+                        const int32_t i = pl->row_idx[(size_t)b];
+                        if (slot[(size_t)i] != slot[(size_t)j] && last_barrier > lvl[(size_t)i] - 1) need = true;
+                    }
+                }
+                if (need) { pl->bs_sync[(size_t)l] = 1; last_barrier = l; }
+            }
+        }
         pl->fz_meta.assign((size_t)nlev * kMaxLevelCols * 8, 0);
         pl->fz_ok = (pl->fz_lazy.size() / 3 < 65536 && pl->row_idx.size() < 32768) ? 1 : 0;
         for (int32_t l = 0; l < nlev; ++l) {

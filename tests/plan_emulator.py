@@ -346,14 +346,24 @@ def sparse_chol_solve_fused(A, S_lower, y, n, ep, lm):
         for i, fl in ytargets.items():
             if len(fl) > 1:
                 assert all(f == 1 for f in fl), "two columns update a y segment without the shared flag"
+    # back substitution: one wave per column slot, barriers only where bs_sync says so; a value written by
+    # another slot's wave may be read only if a barrier lies in between
     x = z.copy()
+    bs_sync = A["bs_sync"]
+    written_at = {}                          # column -> (slot, number of barriers passed when written)
+    barriers = 0
     for l in range(nlev - 1, -1, -1):
-        for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]:
+        if bs_sync[l]:
+            barriers += 1
+        for q, c in enumerate(lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]):
             tq = x[6*c:6*c + 6].copy()
             for s in range(col_ptr[c] + 1, col_ptr[c + 1]):
                 i = int(row_idx[s])
+                sl, nb = written_at[i]
+                assert sl == q or nb < barriers, "back substitution reads another wave's x without a barrier"
                 tq -= L[s].T @ x[6*i:6*i + 6]
             x[6*c:6*c + 6] = Linv[c].T @ tq
+            written_at[int(c)] = (q, barriers)
     out = np.zeros((n, 6))
     out[perm] = x.reshape(n, 6)
     return out
