@@ -1268,7 +1268,7 @@ __device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArg
 // diagonal): brings it into M form, then x_j = zt_j - sum_{i>j} M_ij x_i by levels, descending.
 template <typename T, bool RAW_DIAG = false>
 __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T *z, T *zt, const int *row_idx,
-                                                    const int *col_ptr, const int4 *lvl_meta, int mstride, int tid, int nth) {
+                                                    const int *col_ptr, const int4 *lvl_meta, int mstride, int tid, int nth, long long *tprof = nullptr) {
     const int n = pd.n, nnzb = pd.nnzb, nlev = pd.nlev, wave = tid >> 6, lane = tid & 63;
     for (int j = tid; j < n; j += nth) {
         T *dblk = Lw + (size_t)col_ptr[j] * 36;
@@ -1299,6 +1299,7 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
             for (int c = 0; c < r; ++c) dblk[6 * c + r] = li[BT_LT(r, c)];      // Linv[r][c] at [c][r]
     }
     __syncthreads();
+    if (tprof) tprof[0] = clock64();
     for (int idx = tid; idx < nnzb * 6 + n; idx += nth) {
         int j;
         T *p, *q;
@@ -1324,6 +1325,7 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
         store_row6(q, out);
     }
     __syncthreads();
+    if (tprof) tprof[1] = clock64();
     // (c) x_j = zt_j - sum_{i>j} M_ij x_i, levels descending, ONE WAVE PER COLUMN SLOT and no barrier unless
     // the level reads an x_i another slot's wave wrote since the last barrier (lvl_meta[..].w, ba_plan.cpp
     // bs_sync): on a two-ended chain the two waves run down their chains independently.  The static
@@ -1683,7 +1685,9 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
             mm.w = pd.bs_sync[i / kMaxLevelCols];
             bmeta[i] = mm;
         }
-        lds_back_substitute<T, true>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth);
+        long long tbs[2] = {0, 0};
+        lds_back_substitute<T, true>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth, PROF ? tbs : nullptr);
+        if (PROF) { sub[0] = tbs[0] - tall; sub[1] = tbs[1] - tall; sub[2] = clock64() - tall; }
         for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
         __syncthreads();
         const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
@@ -1705,7 +1709,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         if (wave == 0 || wave == 2) {
             long long *g = reinterpret_cast<long long *>(a.status + 4) + (wave ? 10 : 0);
             g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
-            for (int i = 0; i < 6; ++i) g[3 + i] = sub[i];
+            for (int i = 0; i < 6; ++i) g[3 + i] = sub[i];       // wave 0: ends of Linv / M form / back substitution; wave 2: row-wave stages
         }
     }
 #undef BT_SUB
