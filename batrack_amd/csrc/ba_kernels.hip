@@ -1222,14 +1222,16 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
 // Against k_solve_lds (two phases: factor | substitute) this removes a barrier, the
 // store/reload of L_jj between the phases and the wait of the substitution for the slowest
 // helper; the chain per level is the 6x6 factorisation plus one update row.
+constexpr int kLoadInFlight = 4;      // block rows of S a thread has in flight (6 doubles each)
+
 template <typename T>
 __device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArgs &a, T *Lw, T *z, const int *row_idx,
                                                 double lm, int tid, int nth) {
     const int nnzb = pd.nnzb, D = pd.D;
-    for (int base = 0; base < nnzb * 6; base += 2 * nth) {
-        double v[2][6];
+    for (int base = 0; base < nnzb * 6; base += kLoadInFlight * nth) {
+        double v[kLoadInFlight][6];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kLoadInFlight; ++u) {
             const int idx = base + u * nth + tid;
             if (idx < nnzb * 6) {
                 const int b = idx / 6, r = idx - 6 * b, src = pd.blk_src[b];
@@ -1245,7 +1247,7 @@ __device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArg
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kLoadInFlight; ++u) {
             const int idx = base + u * nth + tid;
             if (idx < nnzb * 6) {
                 const int b = idx / 6, r = idx - 6 * b, rc = row_idx[b];
@@ -1429,14 +1431,9 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + fused_work_bytes(pd, nth)), *pfirst = row_idx + nnzb,
         *col_ptr = pfirst + nnzb;
     const int4 *pmeta = reinterpret_cast<const int4 *>(pd.fz_pmeta);     // [nlev][2]
-    // row | col << 8 | shared-y << 24 | pending-y << 25
-    for (int i = tid; i < nnzb; i += nth) row_idx[i] = pd.row_idx[i] | (pd.blk_col[i] << 8) | (pd.fz_yurg[i] << 25);
-    // first pending pair of a block and how many it has: src1 | src2 << 15 | min(count, 3) << 30; further pairs
-    // (a block updated by two columns of the level below: where chains merge) are read from global memory
-    for (int i = tid; i < nnzb; i += nth) {
-        const int k0 = pd.fz_pend_ptr[i], c = pd.fz_pend_ptr[i + 1] - k0;
-        pfirst[i] = c > 0 ? (pd.fz_pend[2 * k0] | (pd.fz_pend[2 * k0 + 1] << 15) | ((c < 3 ? c : 3) << 30)) : 0;
-    }
+    // per block: row | col << 8 | shared-y << 24 | pending-y << 25, and its first pending pair
+    // src1 | src2 << 15 | min(count, 3) << 30 (further pairs, where chains merge, are read from global memory)
+    for (int i = tid; i < nnzb; i += nth) { row_idx[i] = pd.fz_rowinfo[i]; pfirst[i] = pd.fz_pfirst[i]; }
     for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
     long long phA = 0, phL = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, sub[6] = {0, 0, 0, 0, 0, 0}, tsub = 0;
 #define BT_SUB(i) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tq = clock64(); sub[i] += tq - tsub; tsub = tq; } } while (0)

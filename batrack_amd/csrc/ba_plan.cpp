@@ -523,6 +523,17 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             }
             m[1] |= nc << 24;
         }
+        // what the kernel keeps per block, ready-made: row | col << 8 | shared-y << 24 | pending-y << 25, and
+        // the first pending pair src1 | src2 << 15 | min(#pending, 3) << 30
+        pl->fz_rowinfo.assign(nb, 0);
+        pl->fz_pfirst.assign(nb, 0);
+        for (size_t b = 0; b < nb; ++b) {
+            pl->fz_rowinfo[b] = pl->row_idx[b] | ((pl->blk_col[b] & 255) << 8) | ((pl->blk_col[b] >> 16) << 24) | (pl->fz_yurg[b] << 25);
+            const int32_t k0 = pl->fz_pend_ptr[b], c = pl->fz_pend_ptr[b + 1] - k0;
+            if (c > 0 && nb < 32768)
+                pl->fz_pfirst[b] = (int32_t)((uint32_t)pl->fz_pend[(size_t)k0 * 2] | ((uint32_t)pl->fz_pend[(size_t)k0 * 2 + 1] << 15) |
+                                             ((uint32_t)(c < 3 ? c : 3) << 30));
+        }
         // back substitution, levels descending, one wave per column slot: a barrier is needed before a level
         // only if one of its columns reads an x_i written by another slot's wave since the last barrier
         pl->bs_sync.assign((size_t)nlev, 0);

@@ -258,6 +258,12 @@ def sparse_chol_solve_fused(A, S_lower, y, n, ep, lm):
     lazy_ptr, lazy, yurg = A["fz_lazy_ptr"], A["fz_lazy"].reshape(-1, 3), A["fz_yurg"]
     meta = A["fz_meta"].reshape(-1, 4, 8)
     nnzb, nlev = len(row_idx), len(lvl_ptr) - 1
+    ri, pf = A["fz_rowinfo"], A["fz_pfirst"].astype(np.int64) & 0xffffffff
+    for b in range(nnzb):
+        assert ri[b] == (int(row_idx[b]) | int(blk_col[b]) << 8 | int(yshared[b]) << 24 | int(yurg[b]) << 25)
+        c = int(pend_ptr[b + 1] - pend_ptr[b])
+        want = (int(pend[pend_ptr[b]][0]) | int(pend[pend_ptr[b]][1]) << 15 | min(c, 3) << 30) if c else 0
+        assert pf[b] == want
     assert len(pend) + len(lazy) == len(A["upd"]) // 3, "every update triple is either pending or lazy"
     L = np.zeros((nnzb, 6, 6))
     for b in range(nnzb):
