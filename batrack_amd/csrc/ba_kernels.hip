@@ -1765,24 +1765,51 @@ __global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_p
         return;
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float sdx[SO ? 1 : 6 * kMaxFree];
+    const bool patch_block = (int)(blockIdx.x * blockDim.x) < pd.p_tot;
+    if (!SO && patch_block) {                          // the pose update, once per workgroup
+        for (int i = threadIdx.x; i < pd.D; i += blockDim.x) sdx[i] = a.dx[i];
+        __syncthreads();
+    }
     if (gid < pd.p_tot) {
         const float x = a.patches[3*gid], y = a.patches[3*gid + 1], d = a.patches[3*gid + 2];
-        const int k = pd.trk_of_patch[gid];
         float dz = 0.0f;
-        if (k >= 0) {
-            const float2 qw = a.qw[k];
-            if (SO) {
-                dz = qw.x * qw.y;                                        // ba.py:316-317
-            } else {
-                const int loc = pd.trk_loc[k], tile = loc >> 6, ln = loc & 63;
-                const int R = 6 * pd.tile_ncam[tile];
-                const float *base = a.esave + (size_t)pd.tile_erow0[tile] * kLanes + ln;
-                const int *cams = pd.tile_cams + pd.tile_cam0[tile];
+        if (SO) {
+            const int k = pd.trk_of_patch[gid];
+            if (k >= 0) { const float2 qw = a.qw[k]; dz = qw.x * qw.y; }               // ba.py:316-317
+        } else {
+            // one record per patch (ba_plan.cpp: upd_rec): track, where its E rows start, its cameras
+            const int4 r0 = reinterpret_cast<const int4 *>(pd.upd_rec)[2 * gid], r1 = reinterpret_cast<const int4 *>(pd.upd_rec)[2 * gid + 1];
+            const int k = r0.x;
+            if (k >= 0) {
+                const float2 qw = a.qw[k];
+                const float *base = a.esave + (size_t)r0.y;
                 float acc = 0.0f;
-                for (int c = 0; c < R; c += 6) {
-                    const float *dxc = a.dx + 6 * cams[c / 6];
+                if (!(r0.z & (1 << 30))) {
+                    const int nc = r0.z;
+                    const int cw[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) acc = fmaf(base[(size_t)(c + r) * kLanes], dxc[r], acc);
+                    for (int w4 = 0; w4 < 4; ++w4) {
+                        if (4 * w4 >= nc) break;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int c = 4 * w4 + b;
+                            if (c < nc) {
+                                const float *dxc = sdx + 6 * ((cw[w4] >> (8 * b)) & 255);
+#pragma unroll
+                                for (int r = 0; r < 6; ++r) acc = fmaf(base[(size_t)(6 * c + r) * kLanes], dxc[r], acc);
+                            }
+                        }
+                    }
+                } else {                                   // a tile with more than 16 cameras: camera list in the tile arrays
+                    const int loc = pd.trk_loc[k], tile = loc >> 6;
+                    const int nc = pd.tile_ncam[tile];
+                    const int *cams = pd.tile_cams + pd.tile_cam0[tile];
+                    for (int c = 0; c < nc; ++c) {
+                        const float *dxc = sdx + 6 * cams[c];
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) acc = fmaf(base[(size_t)(6 * c + r) * kLanes], dxc[r], acc);
+                    }
                 }
                 dz = qw.x * (qw.y - acc);                               // ba.py:328
             }

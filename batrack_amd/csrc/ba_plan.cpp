@@ -573,6 +573,23 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     }
 
+    // ---- k_update: everything a patch's depth back-substitution needs in one 32-byte record,
+    // [track or -1, first E row * 64 + lane, #cameras (bit 30: more than 16, use the tile arrays), 0, 16 camera bytes]
+    pl->upd_rec.assign((size_t)p_tot * 8, 0);
+    for (int64_t p = 0; p < p_tot; ++p) {
+        int32_t *r = pl->upd_rec.data() + (size_t)p * 8;
+        const int32_t k = pl->trk_of_patch[(size_t)p];
+        r[0] = k;
+        if (k < 0) continue;
+        const int32_t loc = pl->trk_loc[(size_t)k], tile = loc >> 6, ln = loc & 63;
+        const int32_t nc = pl->tile_ncam[(size_t)tile], c0 = pl->tile_cam0[(size_t)tile];
+        r[1] = pl->tile_erow0[(size_t)tile] * kLanes + ln;
+        r[2] = nc > 16 ? (nc | (1 << 30)) : nc;
+        if (nc <= 16)
+            for (int32_t c = 0; c < nc; ++c)
+                r[4 + c / 4] |= (pl->tile_cams[(size_t)(c0 + c)] & 255) << (8 * (c % 4));
+    }
+
     layout_workspace(pl);
     return BT_OK;
 }
