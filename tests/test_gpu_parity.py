@@ -183,3 +183,31 @@ def test_status_word_after_structure_only_and_plan_reuse():
     assert rel(a2[0].data.cpu().numpy(), a1[0].data.cpu().numpy()) < 1e-6
     assert rel(a2[1].cpu().numpy(), a1[1].cpu().numpy()) < 1e-6
     assert b1[0] is a1[0]
+
+
+def test_reduced_system_is_reproducible_step_after_step():
+    """The pair sums are finalised inside k_tile by whichever wave contributes last and the
+    accumulators are cleared by their consumers: 40 consecutive reductions of the same inputs
+    must give the same [S | y] (up to the order of the fp64 atomics)."""
+    d = c3_inputs(0)
+    hp = HipProblem(d)
+    o = hp.raw_step("weights_pose", 1)
+    st, plan = o["stepper"], o["plan"]
+    P = hp.poses[0].contiguous(); pat = hp.patches.reshape(-1, 3).contiguous()
+    Pout, pout = torch.empty_like(P), torch.empty_like(pat)
+    tg = hp.t3[0]
+    args = (P, pat, hp.mono.reshape(-1), hp.intr[0], tg, tg.stride(0), hp.w["weights_pose"][0].contiguous(),
+            Pout, pout, hp.bounds, 1e-4, 10.0, 0.05, "huber", False)
+    ref = None
+    for it in range(40):
+        st.step(*args, phase="reduce")
+        torch.cuda.synchronize()
+        sysv = st.system.cpu().numpy().copy()
+        st.step(*args, phase="solve_update")
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = sysv
+            D = 6 * plan.n
+            assert rel(np.diag(sysv[:D * D].reshape(D, D)), load("c3")["ps.f64.S_diag"]) < 2e-6
+        else:
+            assert rel(sysv, ref) < 1e-12, it
