@@ -204,13 +204,13 @@ int bt_ba_step_timed(const bt_plan *pl, const bt_ba_args *a, void *ws, void *str
     for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return BT_EHIP;
     const StepArgs s = make_args(pl, a, ws);
     const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
-    int r = launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), so, st, ev);
-    if (r == BT_OK) r = launch_solve_update(pl->dev, s, so, copy_poses, st, ev);
+    unsigned ran = 0;
+    int r = launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), so, st, ev, &ran);
+    if (r == BT_OK) r = launch_solve_update(pl->dev, s, so, copy_poses, st, ev, &ran);
     if (r == BT_OK && hipStreamSynchronize(st) != hipSuccess) r = BT_EHIP;
-    const bool ran[5] = { false, pl->dev.T > 0, !so && pl->dev.P > 0, !so, true };
     for (int k = 0; k < 5; ++k) {
-        ms[k] = 0.0f;
-        if (r == BT_OK && ran[k] && hipEventElapsedTime(&ms[k], ev[2 * k], ev[2 * k + 1]) != hipSuccess) ms[k] = -1.0f;
+        ms[k] = 0.0f;                                  // a kernel that was not launched (e.g. pair finalisation fused into k_tile) reads 0
+        if (r == BT_OK && (ran >> k & 1u) && hipEventElapsedTime(&ms[k], ev[2 * k], ev[2 * k + 1]) != hipSuccess) ms[k] = -1.0f;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return r;

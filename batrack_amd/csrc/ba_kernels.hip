@@ -1935,11 +1935,12 @@ int configure_kernels(const PlanDev &pd) {
 // duration on the stream it ran on.
 #define BT_LAUNCH(K, kern, grid, block, lds, ...)                                                        \
     do {                                                                                                 \
+        if (ran) *ran |= 1u << (K);                                                                      \
         if (ev) hipExtLaunchKernelGGL(kern, grid, block, lds, st, ev[2 * (K)], ev[2 * (K) + 1], 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                \
     } while (0)
 
-int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev) {
+int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev, unsigned *ran) {
     (void)zero_doubles;   // the accumulators are cleared by their consumers (pair finalisation, k_update)
     // pair sums -> B, v inside k_tile (by the wave making a pair's last contribution) when every tile has its own
     // workgroup; BT_FUSE_PAIRS=0: always the separate k_pair_finalize
@@ -1964,7 +1965,7 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 
-int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev) {
+int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev, unsigned *ran) {
     if (!so) {
         const int mode = solver_mode(pd);
         const bool prof = (a.dbg & 16) != 0;

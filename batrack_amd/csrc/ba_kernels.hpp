@@ -22,7 +22,8 @@ struct StepArgs {
 };
 
 int configure_kernels(const PlanDev &pd);
-int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev = nullptr);
-int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev = nullptr);
+// ev != nullptr: a (start, stop) event pair per kernel; *ran gets bit k set for every kernel k that was launched
+int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
+int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
 
 }  // namespace bt
