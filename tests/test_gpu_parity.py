@@ -188,7 +188,9 @@ def test_status_word_after_structure_only_and_plan_reuse():
 def test_reduced_system_is_reproducible_step_after_step():
     """The pair sums are finalised inside k_tile by whichever wave contributes last and the
     accumulators are cleared by their consumers: 40 consecutive reductions of the same inputs
-    must give the same [S | y] (up to the order of the fp64 atomics)."""
+    must give the same [S | y] up to the order of the fp64 atomics (measured 2e-11..5e-11 relative, with
+    or without the fusion: S = B - E C^-1 E^T cancels two much larger sums); a lost or doubled pair
+    contribution would show at 1e-3."""
     d = c3_inputs(0)
     hp = HipProblem(d)
     o = hp.raw_step("weights_pose", 1)
@@ -210,4 +212,4 @@ def test_reduced_system_is_reproducible_step_after_step():
             D = 6 * plan.n
             assert rel(np.diag(sysv[:D * D].reshape(D, D)), load("c3")["ps.f64.S_diag"]) < 2e-6
         else:
-            assert rel(sysv, ref) < 1e-12, it
+            assert rel(sysv, ref) < 1e-9, it
