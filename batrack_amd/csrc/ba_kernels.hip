@@ -1,16 +1,17 @@
 // ba_kernels.hip — gfx950 (CDNA4, wave64) kernels of the BA step.
 //
-// One BA_rgbd_droid call (/root/reference/main/backend/ba.py:217-339) becomes three kernels:
-//   k_tile           per 64-track tile: relative pose of its camera pairs (Gij is per PAIR,
-//                    not per edge: projective_ops.py:61), per-edge reprojection, Jacobians,
-//                    robust weights (projective_ops.py:54-100, ba.py:228-266), per-track
-//                    C/w/E, per-pair J^T W J turned into B and v blocks by the wave that
-//                    summed them (ba.py:279-290), and the tile's Schur product E Q E^T on
-//                    the f64 matrix cores (ba.py:284-323)
-//   k_solve_*        damped block-sparse Cholesky of the reduced camera system in LDS,
+// One BA_rgbd_droid call (/root/reference/main/backend/ba.py:217-339) becomes
+//   k_prep           relative pose of every camera pair (Gij is per PAIR, not per
+//                    edge: projective_ops.py:61) + clearing of the accumulators
+//   k_tile           per-edge reprojection, Jacobians, robust weights
+//                    (projective_ops.py:54-100, ba.py:228-266), per-track C/w/E,
+//                    per-pair J^T W J, and the tile's Schur product E Q E^T
+//                    (ba.py:284-323) — one workgroup of 4 waves per 64-track tile
+//   k_pair_finalize  B and v of ba.py:279-290 from the per-pair sums
+//   k_solve          damped block-sparse Cholesky of the reduced camera system,
 //                    forward/back substitution (ba.py:60-70,323-325)
 //   k_update         back-substitution of the depths, clamp, pose retraction
-//                    (ba.py:328-337, groups.py:153-156); clears [S | y] for the next step
+//                    (ba.py:328-337, groups.py:153-156)
 //
 // Algebra used throughout: Ji = -Jj * Ad(Gij), so with
 // per-pair sums  Bjj = sum Jj^T W Jj,  gj = sum Jj^T W r  the blocks are
@@ -153,22 +154,20 @@ __device__ __forceinline__ int sym21(int p, int q) {
 }
 
 
-constexpr int kPairFinScratch = 36 * 3 + 6 + 28;     // doubles of LDS scratch per wave: B, Ad, M, g, the 27 sums
+constexpr int kPairFinScratch = 36 * 3 + 6;     // doubles of LDS scratch per finalising wave
 
-// B and v contributions (ba.py:279-290) of a wave's running sums of one camera pair, by that wave:
+// B and v contributions of one camera pair from its sums (ba.py:279-290), by ONE WAVE:
 //   B[a,a] += Ad^T Bjj Ad,  B[b,a] += -Bjj Ad,  B[b,b] += Bjj,  v[a] += -Ad^T gj,  v[b] += gj
-// They are linear in (Bjj, gj), so every wave turns its own partial sums into the reduced system's
-// blocks as soon as it leaves a pair: no per-pair accumulator in memory, no second kernel, no ordering
-// between workgroups.  pacc: element (lane >> 1) of the sums in the even lanes (21 Bjj, 6 gj);
-// g: the pair's geometry in LDS; scr: kPairFinScratch doubles of LDS owned by the wave.
-__device__ __forceinline__ void emit_pair_wave(const PlanDev &pd, const StepArgs &a, int p, const float *g, double *scr, int lane, double pacc) {
-    double *sB = scr, *sAd = scr + 36, *sM = scr + 72, *sg = scr + 108, *acc = scr + 114;
+// g: the pair's geometry (R, t, ...) in LDS; scr: kPairFinScratch doubles of LDS owned by the wave.
+// The sums are read with agent-scope loads (their last contributions may have come from another
+// XCD's atomics in this same kernel) and left clear, with their contribution counter, for the next step.
+__device__ __forceinline__ void finalize_pair_wave(const PlanDev &pd, const StepArgs &a, int p, const float *g, double *scr, int lane) {
+    double *sB = scr, *sAd = scr + 36, *sM = scr + 72, *sg = scr + 108;
     const int ia = pd.pair_i[p] - pd.fixedp, ib = pd.pair_j[p] - pd.fixedp;
-    if ((lane & 1) == 0 && (lane >> 1) < 27) acc[lane >> 1] = pacc;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    double *acc = a.pairacc + (size_t)p * kPairAccStride;
     if (lane < 36) {
         const int r = lane / 6, c = lane % 6;
-        sB[lane] = acc[sym21(r, c)];
+        sB[lane] = __hip_atomic_load(acc + sym21(r, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // Ad = [[R, [t]x R], [0, R]]                                   (se3.h:58-67)
         double v = 0.0;
         if (r < 3 && c < 3) v = g[3*r + c];
@@ -181,9 +180,11 @@ __device__ __forceinline__ void emit_pair_wave(const PlanDev &pd, const StepArgs
         }
         sAd[lane] = v;
     } else if (lane < 42) {
-        sg[lane - 36] = acc[21 + lane - 36];
+        sg[lane - 36] = __hip_atomic_load(acc + 21 + lane - 36, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < 27) acc[lane] = 0.0;                  // clear for the next step
+    if (lane == 31) reinterpret_cast<int *>(acc + 31)[0] = 0;
     if (lane < 36) {
         const int r = lane / 6, c = lane % 6;
         double m = 0.0;
@@ -214,7 +215,7 @@ __device__ __forceinline__ void emit_pair_wave(const PlanDev &pd, const StepArgs
         }
         if (ib >= 0) atomicAdd(&a.y[6*ib + c], sg[c]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the scratch is reused by the wave's next pair
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // scratch may be reused by the wave's next pair
 }
 
 constexpr int kTileAccMax = 16;  // Schur output tiles (16x16) a workgroup accumulates across tiles, in LDS (up to 13 cameras)
@@ -222,7 +223,7 @@ constexpr int kTileAccMax = 16;  // Schur output tiles (16x16) a workgroup accum
 // PERSIST = false: one tile per workgroup (graphs with up to ~1024 tiles, e.g. the 64-KF / 131k-edge
 // benchmark): no cross-tile state, Schur tiles go straight from the MFMA registers to the atomics.
 // PERSIST = true: a workgroup walks tiles_per_wg consecutive tiles and keeps its accumulators.
-template <bool SO, bool PROF, bool PERSIST>
+template <bool SO, bool PROF, bool PERSIST, bool FUSE = false>
 __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -245,9 +246,24 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
     int Racc = 0;                      // 6 * cameras of the tiles accumulated in sacc
     double pacc = 0.0;
     int p_cur = -1, lp_cur = 0;
-    double *pscr = reinterpret_cast<double *>(lacc + (size_t)ntl_max * 256) + (size_t)wave * kPairFinScratch;   // this wave's pair scratch
-    auto flush_pair = [&]() {            // the wave leaves a pair: its running sums go into the reduced system
-        if (p_cur >= 0 && !(a.dbg & 2)) emit_pair_wave(pd, a, p_cur, geo + (size_t)lp_cur * kPairGeomFloats, pscr, lane, pacc);
+    auto flush_pair = [&]() {
+        const int vi = (lane >> 1) & 31;
+        if (p_cur >= 0 && (lane & 1) == 0 && vi < 27 && !(a.dbg & 2))
+            atomicAdd(&a.pairacc[(size_t)p_cur * kPairAccStride + vi], pacc);
+        if (FUSE && p_cur >= 0) {
+            // The wave that brings a pair's contribution count to the plan's number (pair_nflush) turns
+            // the sums into their B and v blocks right here: no separate kernel between this one and the
+            // solver.  The count sits in the pair's spare accumulator slot; the atomics above are complete
+            // (vmcnt) before it is raised.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int old = 0;
+            if (lane == 0)
+                old = __hip_atomic_fetch_add(reinterpret_cast<int *>(a.pairacc + (size_t)p_cur * kPairAccStride + 31), 1,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old == pd.pair_nflush[p_cur] - 1)
+                finalize_pair_wave(pd, a, p_cur, geo + (size_t)lp_cur * kPairGeomFloats, lacc + (size_t)wave * kPairFinScratch, lane);
+        }
         pacc = 0.0; p_cur = -1;
     };
     auto flush_schur = [&]() {         // uses gidx of the tiles the accumulators belong to (still in LDS)
@@ -538,6 +554,19 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
         for (int i = 0; i < 10; ++i) o[i] = pf[i];
     }
 #undef BT_PF
+}
+
+// ------------------------------------------------------------------ k_pair_finalize
+// One wave per camera pair, in double.  sym index of (p<=q) in the 21-vector:
+__global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
+    __shared__ double scr[4][kPairFinScratch];
+    __shared__ float sgeo[4][kPairGeomFloats];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + w;
+    if (p >= pd.P) return;
+    if (lane == 0) pair_geometry(a.poses, a.intr, pd.pair_i[p], pd.pair_j[p], sgeo[w]);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    finalize_pair_wave(pd, a, p, sgeo[w], scr[w], lane);
 }
 
 // ------------------------------------------------------------------ k_solve
@@ -1838,7 +1867,7 @@ static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     const size_t nt = rows / 16, ntl = nt * (nt + 1) / 2;
     return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 64 + rows +
             (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) +
-           (ntl < 16 ? ntl : 16) * 2048 + (so ? 0 : kTileWaves * kPairFinScratch * sizeof(double)) + 64;   // Schur accumulators, pair scratch
+           std::max<size_t>((ntl < 16 ? ntl : 16) * 2048, so ? 0 : kTileWaves * kPairFinScratch * sizeof(double)) + 64;   // Schur accumulators / pair scratch
 }
 
 constexpr size_t kLdsBudget = 160 * 1024 - 512;
@@ -1872,6 +1901,8 @@ int configure_kernels(const PlanDev &pd) {
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
     if (need > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
@@ -1910,7 +1941,12 @@ int configure_kernels(const PlanDev &pd) {
     } while (0)
 
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev, unsigned *ran) {
-    (void)zero_doubles;   // [S | y] is cleared by its consumer's successor (k_update)
+    (void)zero_doubles;   // the accumulators are cleared by their consumers (pair finalisation, k_update)
+    // pair sums -> B, v inside k_tile (by the wave making a pair's last contribution) when every tile has its own
+    // workgroup; BT_FUSE_PAIRS=0: always the separate k_pair_finalize
+    static const int fuse_env = std::getenv("BT_FUSE_PAIRS") ? std::atoi(std::getenv("BT_FUSE_PAIRS")) : 1;   // measurement only
+    const bool fuse = fuse_env != 0 && !(a.dbg & 2);
+    bool fused = false;
     if (pd.T > 0) {
         // persistent workgroups once there are more tiles than ~4 per CU: a workgroup then walks a
         // contiguous range of tiles and keeps its accumulators across tiles with the same cameras
@@ -1919,9 +1955,13 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         if (so && tpw == 1)    BT_LAUNCH(1, (k_tile<true, false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
         else if (so)           BT_LAUNCH(1, (k_tile<true, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
         else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true, false>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, 1);
+        else if (tpw == 1 && fuse) BT_LAUNCH(1, (k_tile<false, false, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
         else if (tpw == 1)     BT_LAUNCH(1, (k_tile<false, false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
         else                   BT_LAUNCH(1, (k_tile<false, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
+        fused = !so && !(a.dbg & 32) && tpw == 1 && fuse;
     }
+    if (!so && pd.P > 0 && !fused)
+        BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 

@@ -13,7 +13,7 @@ struct StepArgs {
     float *poses_out, *patches_out;
     float b0, b1, b2, b3, lmbda, ep, alpha;
     int loss;
-    double *S, *y, *pairacc;      // [S | y] contiguous (cleared together); pairacc: unused
+    double *S, *y, *pairacc;      // S, y, pairacc are contiguous (cleared together)
     float *ptab;
     float2 *qw;
     float *esave, *lfac, *linv, *zvec, *dx;

@@ -29,7 +29,7 @@ static void layout_workspace(bt_plan *pl) {
     size_t off = 0;
     w.sys = off;      off += (D * D + D) * sizeof(double);
     off = align_up(off, 256);
-    w.pairacc = off;  // (no per-pair accumulators any more: every wave emits its pair sums into [S | y] itself)
+    w.pairacc = off;  off += (size_t)I.pairs * kPairAccStride * sizeof(double);
     off = align_up(off, 256);
     w.zero_bytes = off - w.sys;
     w.ptab = off;     off = align_up(off + (size_t)I.pairs * kPairGeomFloats * sizeof(float), 256);
@@ -569,6 +569,35 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
                 mrow[5] = w0; mrow[6] = (6 * mrow[2] + 1 + 63) / 64;
                 mrow[7] = pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l];
                 w0 += mrow[6];
+            }
+        }
+    }
+
+    // ---- how many times k_tile (one tile per workgroup, 8 waves) adds into each pair's sums: a wave walks its
+    // chunk of slots, takes the distinct pairs of a slot in order of their first active lane, and emits its
+    // running sum whenever the pair changes and at the end.  The wave that makes the last contribution
+    // finalises the pair (ba_kernels.hip: flush_pair), so the counts must mirror that loop exactly.
+    pl->pair_nflush.assign((size_t)I.pairs, 0);
+    {
+        const int kWaves = 8;
+        for (int64_t t = 0; t < I.tiles; ++t) {
+            const int32_t slot0 = pl->tile_slot0[(size_t)t], nslot = pl->tile_nslot[(size_t)t];
+            const int32_t chunk = (nslot + kWaves - 1) / kWaves;
+            for (int w = 0; w < kWaves; ++w) {
+                const int32_t s0 = w * chunk, s1 = std::min(nslot, s0 + chunk);
+                int32_t p_cur = -1;
+                for (int32_t sl = s0; sl < s1; ++sl) {
+                    const size_t b0 = (size_t)(slot0 + sl) * kLanes;
+                    bool done[kLanes];
+                    for (int ln = 0; ln < kLanes; ++ln) done[ln] = pl->slot_edge[b0 + ln] < 0;
+                    for (int ln = 0; ln < kLanes; ++ln) {
+                        if (done[ln]) continue;
+                        const int32_t p0 = pl->slot_pair[b0 + ln];
+                        for (int l2 = ln; l2 < kLanes; ++l2) if (!done[l2] && pl->slot_pair[b0 + l2] == p0) done[l2] = true;
+                        if (p0 != p_cur) { if (p_cur >= 0) pl->pair_nflush[(size_t)p_cur]++; p_cur = p0; }
+                    }
+                }
+                if (p_cur >= 0) pl->pair_nflush[(size_t)p_cur]++;
             }
         }
     }
