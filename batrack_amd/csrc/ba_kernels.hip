@@ -148,82 +148,12 @@ __device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) 
 // waves' chunks falls back to ds_add_f32.
 constexpr int kTileWavesMax = 16;
 
-__device__ __forceinline__ int sym21(int p, int q) {
-    if (p > q) { const int t = p; p = q; q = t; }
-    return p * 6 - p * (p - 1) / 2 + (q - p);
-}
-
-
-constexpr int kPairFinScratch = 36 * 3 + 6;     // doubles of LDS scratch per finalising wave
-
-// B and v contributions of one camera pair from its sums (ba.py:279-290), by ONE WAVE:
-//   B[a,a] += Ad^T Bjj Ad,  B[b,a] += -Bjj Ad,  B[b,b] += Bjj,  v[a] += -Ad^T gj,  v[b] += gj
-// g: the pair's geometry (R, t, ...) in LDS; scr: kPairFinScratch doubles of LDS owned by the wave.
-// The sums are read with agent-scope loads (their last contributions may have come from another
-// XCD's atomics in this same kernel) and left clear, with their contribution counter, for the next step.
-__device__ __forceinline__ void finalize_pair_wave(const PlanDev &pd, const StepArgs &a, int p, const float *g, double *scr, int lane) {
-    double *sB = scr, *sAd = scr + 36, *sM = scr + 72, *sg = scr + 108;
-    const int ia = pd.pair_i[p] - pd.fixedp, ib = pd.pair_j[p] - pd.fixedp;
-    double *acc = a.pairacc + (size_t)p * kPairAccStride;
-    if (lane < 36) {
-        const int r = lane / 6, c = lane % 6;
-        sB[lane] = __hip_atomic_load(acc + sym21(r, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // Ad = [[R, [t]x R], [0, R]]                                   (se3.h:58-67)
-        double v = 0.0;
-        if (r < 3 && c < 3) v = g[3*r + c];
-        else if (r >= 3 && c >= 3) v = g[3*(r - 3) + (c - 3)];
-        else if (r < 3 && c >= 3) {
-            const int cc = c - 3;
-            const double t0 = g[9], t1 = g[10], t2 = g[11];
-            const double R0 = g[cc], R1 = g[3 + cc], R2 = g[6 + cc];
-            v = r == 0 ? (-t2 * R1 + t1 * R2) : r == 1 ? (t2 * R0 - t0 * R2) : (-t1 * R0 + t0 * R1);
-        }
-        sAd[lane] = v;
-    } else if (lane < 42) {
-        sg[lane - 36] = __hip_atomic_load(acc + 21 + lane - 36, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if (lane < 27) acc[lane] = 0.0;                  // clear for the next step
-    if (lane == 31) reinterpret_cast<int *>(acc + 31)[0] = 0;
-    if (lane < 36) {
-        const int r = lane / 6, c = lane % 6;
-        double m = 0.0;
-        for (int s = 0; s < 6; ++s) m += sB[6*r + s] * sAd[6*s + c];
-        sM[lane] = m;                                          // M = Bjj Ad
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const int D = pd.D;
-    if (lane < 36) {
-        const int r = lane / 6, c = lane % 6;
-        if (ia >= 0) {                                            // B[a,a] += Ad^T M
-            double v = 0.0;
-            for (int s = 0; s < 6; ++s) v += sAd[6*s + r] * sM[6*s + c];
-            if (r >= c) atomicAdd(&a.S[(size_t)(6*ia + r) * D + 6*ia + c], v);
-        }
-        if (ib >= 0 && r >= c) atomicAdd(&a.S[(size_t)(6*ib + r) * D + 6*ib + c], sB[lane]);
-        if (ia >= 0 && ib >= 0) {
-            if (ia > ib)      atomicAdd(&a.S[(size_t)(6*ia + r) * D + 6*ib + c], -sM[6*c + r]);   // B[a,b] = -M^T
-            else if (ib > ia) atomicAdd(&a.S[(size_t)(6*ib + r) * D + 6*ia + c], -sM[6*r + c]);   // B[b,a] = -M
-            else if (r >= c)  atomicAdd(&a.S[(size_t)(6*ia + r) * D + 6*ia + c], -(sM[6*r + c] + sM[6*c + r]));
-        }
-    } else if (lane < 42) {
-        const int c = lane - 36;
-        if (ia >= 0) {
-            double v = 0.0;
-            for (int s = 0; s < 6; ++s) v += sAd[6*s + c] * sg[s];
-            atomicAdd(&a.y[6*ia + c], -v);
-        }
-        if (ib >= 0) atomicAdd(&a.y[6*ib + c], sg[c]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // scratch may be reused by the wave's next pair
-}
-
 constexpr int kTileAccMax = 16;  // Schur output tiles (16x16) a workgroup accumulates across tiles, in LDS (up to 13 cameras)
 
 // PERSIST = false: one tile per workgroup (graphs with up to ~1024 tiles, e.g. the 64-KF / 131k-edge
 // benchmark): no cross-tile state, Schur tiles go straight from the MFMA registers to the atomics.
 // PERSIST = true: a workgroup walks tiles_per_wg consecutive tiles and keeps its accumulators.
-template <bool SO, bool PROF, bool PERSIST, bool FUSE = false>
+template <bool SO, bool PROF, bool PERSIST>
 __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -245,25 +175,11 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
     bool sacc_live = false;
     int Racc = 0;                      // 6 * cameras of the tiles accumulated in sacc
     double pacc = 0.0;
-    int p_cur = -1, lp_cur = 0;
+    int p_cur = -1;
     auto flush_pair = [&]() {
         const int vi = (lane >> 1) & 31;
         if (p_cur >= 0 && (lane & 1) == 0 && vi < 27 && !(a.dbg & 2))
             atomicAdd(&a.pairacc[(size_t)p_cur * kPairAccStride + vi], pacc);
-        if (FUSE && p_cur >= 0) {
-            // The wave that brings a pair's contribution count to the plan's number (pair_nflush) turns
-            // the sums into their B and v blocks right here: no separate kernel between this one and the
-            // solver.  The count sits in the pair's spare accumulator slot; the atomics above are complete
-            // (vmcnt) before it is raised.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int old = 0;
-            if (lane == 0)
-                old = __hip_atomic_fetch_add(reinterpret_cast<int *>(a.pairacc + (size_t)p_cur * kPairAccStride + 31), 1,
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            old = __builtin_amdgcn_readfirstlane(old);
-            if (old == pd.pair_nflush[p_cur] - 1)
-                finalize_pair_wave(pd, a, p_cur, geo + (size_t)lp_cur * kPairGeomFloats, lacc + (size_t)wave * kPairFinScratch, lane);
-        }
         pacc = 0.0; p_cur = -1;
     };
     auto flush_schur = [&]() {         // uses gidx of the tiles the accumulators belong to (still in LDS)
@@ -446,7 +362,7 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
                 v[25] = fmaf(ma4, q.r0, mb4 * q.r1); v[26] = fmaf(ma5, q.r0, mb5 * q.r1);
                 v[27] = v[28] = v[29] = v[30] = v[31] = 0.0f;
                 wave_reduce_scatter32(v, lane);
-                if (p0 != p_cur) { flush_pair(); p_cur = p0; lp_cur = __shfl((int)pd.slot_lp[idx], leader); }   // same pair as this wave's previous slot / tile: keep summing
+                if (p0 != p_cur) { flush_pair(); p_cur = p0; }   // same pair as this wave's previous slot / tile: keep summing
                 pacc += (double)v[0];
                 todo &= ~__ballot(act && pair == p0);
             }
@@ -558,15 +474,76 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
 
 // ------------------------------------------------------------------ k_pair_finalize
 // One wave per camera pair, in double.  sym index of (p<=q) in the 21-vector:
+__device__ __forceinline__ int sym21(int p, int q) {
+    if (p > q) { const int t = p; p = q; q = t; }
+    return p * 6 - p * (p - 1) / 2 + (q - p);
+}
+
 __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
-    __shared__ double scr[4][kPairFinScratch];
+    __shared__ double sB[4][36], sAd[4][36], sM[4][36], sg[4][6];
     __shared__ float sgeo[4][kPairGeomFloats];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + w;
-    if (p >= pd.P) return;
-    if (lane == 0) pair_geometry(a.poses, a.intr, pd.pair_i[p], pd.pair_j[p], sgeo[w]);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    finalize_pair_wave(pd, a, p, sgeo[w], scr[w], lane);
+    const bool live = p < pd.P;
+    int ia = -1, ib = -1;
+    if (live) {
+        ia = pd.pair_i[p] - pd.fixedp; ib = pd.pair_j[p] - pd.fixedp;
+        double *acc = a.pairacc + (size_t)p * kPairAccStride;
+        float *g = sgeo[w];
+        if (lane == 0) pair_geometry(a.poses, a.intr, pd.pair_i[p], pd.pair_j[p], g);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane < 36) {
+            const int r = lane / 6, c = lane % 6;
+            sB[w][lane] = acc[sym21(r, c)];
+            // Ad = [[R, [t]x R], [0, R]]                                   (se3.h:58-67)
+            double v = 0.0;
+            if (r < 3 && c < 3) v = g[3*r + c];
+            else if (r >= 3 && c >= 3) v = g[3*(r - 3) + (c - 3)];
+            else if (r < 3 && c >= 3) {
+                const int cc = c - 3;
+                const double t0 = g[9], t1 = g[10], t2 = g[11];
+                const double R0 = g[cc], R1 = g[3 + cc], R2 = g[6 + cc];
+                v = r == 0 ? (-t2 * R1 + t1 * R2) : r == 1 ? (t2 * R0 - t0 * R2) : (-t1 * R0 + t0 * R1);
+            }
+            sAd[w][lane] = v;
+        } else if (lane < 42) {
+            sg[w][lane - 36] = acc[21 + lane - 36];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane < 27) acc[lane] = 0.0;                 // leave the per-pair sums clear for the next step
+    }
+    __syncthreads();
+    if (live && lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        double m = 0.0;
+        for (int s = 0; s < 6; ++s) m += sB[w][6*r + s] * sAd[w][6*s + c];
+        sM[w][lane] = m;                                          // M = Bjj Ad
+    }
+    __syncthreads();
+    if (!live) return;
+    const int D = pd.D;
+    if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        if (ia >= 0) {                                            // B[a,a] += Ad^T M
+            double v = 0.0;
+            for (int s = 0; s < 6; ++s) v += sAd[w][6*s + r] * sM[w][6*s + c];
+            if (r >= c) atomicAdd(&a.S[(size_t)(6*ia + r) * D + 6*ia + c], v);
+        }
+        if (ib >= 0 && r >= c) atomicAdd(&a.S[(size_t)(6*ib + r) * D + 6*ib + c], sB[w][lane]);
+        if (ia >= 0 && ib >= 0) {
+            if (ia > ib)      atomicAdd(&a.S[(size_t)(6*ia + r) * D + 6*ib + c], -sM[w][6*c + r]);   // B[a,b] = -M^T
+            else if (ib > ia) atomicAdd(&a.S[(size_t)(6*ib + r) * D + 6*ia + c], -sM[w][6*r + c]);   // B[b,a] = -M
+            else if (r >= c)  atomicAdd(&a.S[(size_t)(6*ia + r) * D + 6*ia + c], -(sM[w][6*r + c] + sM[w][6*c + r]));
+        }
+    } else if (lane < 42) {
+        const int c = lane - 36;
+        if (ia >= 0) {
+            double v = 0.0;
+            for (int s = 0; s < 6; ++s) v += sAd[w][6*s + c] * sg[w][s];
+            atomicAdd(&a.y[6*ia + c], -v);
+        }
+        if (ib >= 0) atomicAdd(&a.y[6*ib + c], sg[w][c]);
+    }
 }
 
 // ------------------------------------------------------------------ k_solve
@@ -1866,8 +1843,7 @@ static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     const size_t kTileWaves = (size_t)tile_threads() / 64;
     const size_t nt = rows / 16, ntl = nt * (nt + 1) / 2;
     return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 64 + rows +
-            (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) +
-           std::max<size_t>((ntl < 16 ? ntl : 16) * 2048, so ? 0 : kTileWaves * kPairFinScratch * sizeof(double)) + 64;   // Schur accumulators / pair scratch
+            (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) + (ntl < 16 ? ntl : 16) * 2048 + 64;
 }
 
 constexpr size_t kLdsBudget = 160 * 1024 - 512;
@@ -1901,8 +1877,6 @@ int configure_kernels(const PlanDev &pd) {
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
     if (need > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
@@ -1941,12 +1915,7 @@ int configure_kernels(const PlanDev &pd) {
     } while (0)
 
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev, unsigned *ran) {
-    (void)zero_doubles;   // the accumulators are cleared by their consumers (pair finalisation, k_update)
-    // pair sums -> B, v inside k_tile (by the wave making a pair's last contribution) when every tile has its own
-    // workgroup; BT_FUSE_PAIRS=0: always the separate k_pair_finalize
-    static const int fuse_env = std::getenv("BT_FUSE_PAIRS") ? std::atoi(std::getenv("BT_FUSE_PAIRS")) : 1;   // measurement only
-    const bool fuse = fuse_env != 0 && !(a.dbg & 2);
-    bool fused = false;
+    (void)zero_doubles;   // the accumulators are cleared by their consumers (k_pair_finalize, k_update)
     if (pd.T > 0) {
         // persistent workgroups once there are more tiles than ~4 per CU: a workgroup then walks a
         // contiguous range of tiles and keeps its accumulators across tiles with the same cameras
@@ -1955,12 +1924,10 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         if (so && tpw == 1)    BT_LAUNCH(1, (k_tile<true, false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
         else if (so)           BT_LAUNCH(1, (k_tile<true, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
         else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true, false>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, 1);
-        else if (tpw == 1 && fuse) BT_LAUNCH(1, (k_tile<false, false, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
         else if (tpw == 1)     BT_LAUNCH(1, (k_tile<false, false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
         else                   BT_LAUNCH(1, (k_tile<false, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
-        fused = !so && !(a.dbg & 32) && tpw == 1 && fuse;
     }
-    if (!so && pd.P > 0 && !fused)
+    if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }

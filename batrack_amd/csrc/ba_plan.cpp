@@ -573,35 +573,6 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     }
 
-    // ---- how many times k_tile (one tile per workgroup, 8 waves) adds into each pair's sums: a wave walks its
-    // chunk of slots, takes the distinct pairs of a slot in order of their first active lane, and emits its
-    // running sum whenever the pair changes and at the end.  The wave that makes the last contribution
-    // finalises the pair (ba_kernels.hip: flush_pair), so the counts must mirror that loop exactly.
-    pl->pair_nflush.assign((size_t)I.pairs, 0);
-    {
-        const int kWaves = 8;
-        for (int64_t t = 0; t < I.tiles; ++t) {
-            const int32_t slot0 = pl->tile_slot0[(size_t)t], nslot = pl->tile_nslot[(size_t)t];
-            const int32_t chunk = (nslot + kWaves - 1) / kWaves;
-            for (int w = 0; w < kWaves; ++w) {
-                const int32_t s0 = w * chunk, s1 = std::min(nslot, s0 + chunk);
-                int32_t p_cur = -1;
-                for (int32_t sl = s0; sl < s1; ++sl) {
-                    const size_t b0 = (size_t)(slot0 + sl) * kLanes;
-                    bool done[kLanes];
-                    for (int ln = 0; ln < kLanes; ++ln) done[ln] = pl->slot_edge[b0 + ln] < 0;
-                    for (int ln = 0; ln < kLanes; ++ln) {
-                        if (done[ln]) continue;
-                        const int32_t p0 = pl->slot_pair[b0 + ln];
-                        for (int l2 = ln; l2 < kLanes; ++l2) if (!done[l2] && pl->slot_pair[b0 + l2] == p0) done[l2] = true;
-                        if (p0 != p_cur) { if (p_cur >= 0) pl->pair_nflush[(size_t)p_cur]++; p_cur = p0; }
-                    }
-                }
-                if (p_cur >= 0) pl->pair_nflush[(size_t)p_cur]++;
-            }
-        }
-    }
-
     // ---- k_update: everything a patch's depth back-substitution needs in one 32-byte record,
     // [track or -1, first E row * 64 + lane, #cameras (bit 30: more than 16, use the tile arrays), 0, 16 camera bytes]
     pl->upd_rec.assign((size_t)p_tot * 8, 0);

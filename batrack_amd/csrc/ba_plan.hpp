@@ -24,7 +24,7 @@ constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geom
 struct PlanDev {
     int E, n_buf, p_tot, fixedp, n_all, n, D, m, P, T, slots, erows, nnzb, nupd, max_rows16;
     const int32_t *kx, *trk_of_patch, *trk_loc, *upd_rec;
-    const int32_t *pair_i, *pair_j, *pair_nflush;   // pair_nflush: contributions k_tile (one tile per workgroup) makes to a pair's sums
+    const int32_t *pair_i, *pair_j;
     const int32_t *tile_trk0, *tile_ntrk, *tile_ncam, *tile_cam0, *tile_slot0, *tile_nslot, *tile_erow0;
     const int32_t *tile_cams;
     const int32_t *slot_edge, *slot_pair;
@@ -54,7 +54,7 @@ struct WsLayout {
 struct bt_plan {
     bt_plan_info info{};
     std::vector<int32_t> kx, trk_of_patch, trk_loc, upd_rec;
-    std::vector<int32_t> pair_i, pair_j, pair_nflush;
+    std::vector<int32_t> pair_i, pair_j;
     std::vector<int32_t> tile_trk0, tile_ntrk, tile_ncam, tile_cam0, tile_slot0, tile_nslot, tile_erow0;
     std::vector<int32_t> tile_cams;
     std::vector<int32_t> slot_edge, slot_pair;

@@ -186,11 +186,10 @@ def test_status_word_after_structure_only_and_plan_reuse():
 
 
 def test_reduced_system_is_reproducible_step_after_step():
-    """The pair sums are finalised inside k_tile by whichever wave contributes last and the
-    accumulators are cleared by their consumers: 40 consecutive reductions of the same inputs
-    must give the same [S | y] up to the order of the fp64 atomics (measured 2e-11..5e-11 relative, with
-    or without the fusion: S = B - E C^-1 E^T cancels two much larger sums); a lost or doubled pair
-    contribution would show at 1e-3."""
+    """The accumulators ([S | y], the per-pair sums) are filled with fp64 atomics by all workgroups and
+    cleared by their consumers for the next step: 40 consecutive reductions of the same inputs must
+    give the same system up to the order of the atomics (measured 2e-11..5e-11 relative: S = B - E C^-1 E^T
+    cancels two much larger sums); a lost or doubled contribution, or a stale accumulator, would show at 1e-3."""
     d = c3_inputs(0)
     hp = HipProblem(d)
     o = hp.raw_step("weights_pose", 1)

@@ -46,7 +46,6 @@ VARIANTS = [
     ({}, 2e-3, 1e-5),
     ({"BT_SOLVER_FUSED": "0"}, 2e-3, 1e-5),
     ({"BT_SOLVER_FUSED": "0", "BT_SOLVER_ORDER": "0"}, 2e-3, 1e-5),
-    ({"BT_FUSE_PAIRS": "0"}, 2e-3, 1e-5),
     ({"BT_SOLVER_MODE": "1"}, 2e-2, 1e-4),
     ({"BT_SOLVER_MODE": "2"}, 2e-2, 1e-4),
 ]
