@@ -223,12 +223,26 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
             __syncthreads();
             for (int i = tid; i < R16max; i += nthr) gidx[i] = i < R ? 6 * cams[i / 6] + i % 6 : -1;
         }
+        // first loads that need nothing but the tile index: the cameras of its pairs and the patch of this lane's track
+        const int mtp = pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1;
+        const int ij0 = tid < mtp ? pd.tile_ij[(size_t)tile * mtp + tid] : 0;
+        const int patch_ld = pd.tile_kx[(size_t)tile * kLanes + lane];
+        const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
+        const int chunk = (nslot + kTileWaves - 1) / kTileWaves;
+        const int s0 = wave * chunk, s1 = min(nslot, s0 + chunk);
+        // this wave's first slot, in flight while the pair geometry is computed
+        int e_nx = -1, pair_nx = 0, lp_nx = 0;
+        unsigned lab_nx = 0xffffu;
+        if (s0 < s1) {
+            const size_t idx = (size_t)(slot0 + s0) * kLanes + lane;
+            e_nx = pd.slot_edge[idx]; pair_nx = pd.slot_pair[idx]; lab_nx = pd.slot_lab[idx]; lp_nx = pd.slot_lp[idx];
+        }
         if (!(flags & 2)) {                                        // relative pose of the tile's camera pairs
             const int np = pd.tile_npair[tile];
-            const int *pl = pd.tile_pairs + pd.tile_pair0[tile];
-            for (int p = tid; p < np; p += nthr) {
-                const int gp = pl[p];
-                pair_geometry(a.poses, a.intr, pd.pair_i[gp], pd.pair_j[gp], geo + p * kPairGeomFloats);
+            if (tid < np) pair_geometry(a.poses, a.intr, ij0 & 0xffff, ij0 >> 16, geo + tid * kPairGeomFloats);
+            for (int p = tid + nthr; p < np; p += nthr) {          // (more pairs than threads: never with kMaxTilePairs = 192)
+                const int ij = pd.tile_ij[(size_t)tile * mtp + p];
+                pair_geometry(a.poses, a.intr, ij & 0xffff, ij >> 16, geo + p * kPairGeomFloats);
             }
         }
         for (int i = tid; i < R16 * kLdsRowStride; i += nthr) Eh[i] = 0.0f;
@@ -238,12 +252,16 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
         int patch = 0;
         float px = 0.0f, py = 0.0f, pdisp = 0.0f;
         if (has_trk) {
-            patch = pd.kx[trk];
+            patch = patch_ld;
             px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2];
         }
-        const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
-        const int chunk = (nslot + kTileWaves - 1) / kTileWaves;
-        const int s0 = wave * chunk, s1 = min(nslot, s0 + chunk);
+        float tu_nx = 0.0f, tv_nx = 0.0f, w0_nx = 0.0f, w1_nx = 0.0f;
+        if (e_nx >= 0) {
+            const float *tp = a.targets + (size_t)e_nx * a.tstride;
+            tu_nx = tp[0]; tv_nx = tp[1];
+            const float2 w = reinterpret_cast<const float2 *>(a.weights)[e_nx];
+            w0_nx = w.x; w1_nx = w.y;
+        }
         __syncthreads();
         BT_PF(0);
 
@@ -277,20 +295,25 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
 #pragma unroll 1
         for (int s = s0; s < s1; ++s) {
             const size_t idx = (size_t)(slot0 + s) * kLanes + lane;
-            const int e = pd.slot_edge[idx];
+            // this slot's operands were loaded one iteration ahead (the first one before the barrier above)
+            const int e = e_nx, pair = pair_nx, lp = lp_nx;
             const bool act = e >= 0;
-            const int pair = pd.slot_pair[idx];
-            const unsigned lab = pd.slot_lab[idx];
-            float tu = 0.0f, tv = 0.0f, w0 = 0.0f, w1 = 0.0f;
-            if (act) {
-                const float *tp = a.targets + (size_t)e * a.tstride;
-                tu = tp[0]; tv = tp[1];
-                const float2 w = reinterpret_cast<const float2 *>(a.weights)[e];
-                w0 = w.x; w1 = w.y;
+            const unsigned lab = lab_nx;
+            const float tu = tu_nx, tv = tv_nx, w0 = w0_nx, w1 = w1_nx;
+            if (s + 1 < s1) {
+                const size_t idn = idx + kLanes;
+                e_nx = pd.slot_edge[idn]; pair_nx = pd.slot_pair[idn]; lab_nx = pd.slot_lab[idn]; lp_nx = pd.slot_lp[idn];
+                tu_nx = tv_nx = w0_nx = w1_nx = 0.0f;
+                if (e_nx >= 0) {
+                    const float *tp = a.targets + (size_t)e_nx * a.tstride;
+                    tu_nx = tp[0]; tv_nx = tp[1];
+                    const float2 w = reinterpret_cast<const float2 *>(a.weights)[e_nx];
+                    w0_nx = w.x; w1_nx = w.y;
+                }
             }
             float g[kPairGeomFloats];
             {
-                const float4 *g4 = reinterpret_cast<const float4 *>(geo + (size_t)pd.slot_lp[idx] * kPairGeomFloats);
+                const float4 *g4 = reinterpret_cast<const float4 *>(geo + (size_t)lp * kPairGeomFloats);
 #pragma unroll
                 for (int c = 0; c < 5; ++c) {
                     const float4 t4 = g4[c];

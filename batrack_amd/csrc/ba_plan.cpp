@@ -573,6 +573,24 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     }
 
+    // ---- k_tile's first loads, indexed by the tile alone (no dependent index chain in its prologue):
+    //   tile_ij[t][max_tile_pairs]   cameras (i | j << 16) of the tile's pairs, in local pair order
+    //   tile_kx[t][64]               patch of every track of the tile (-1: no track in this lane)
+    {
+        const size_t mtp = (size_t)std::max(pl->max_tile_pairs, 1);
+        pl->tile_ij.assign((size_t)I.tiles * mtp, 0);
+        pl->tile_kx.assign((size_t)I.tiles * kLanes, -1);
+        for (int64_t t = 0; t < I.tiles; ++t) {
+            for (int32_t q = 0; q < pl->tile_npair[(size_t)t]; ++q) {
+                const int32_t gp = pl->tile_pairs[(size_t)(pl->tile_pair0[(size_t)t] + q)];
+                pl->tile_ij[(size_t)t * mtp + (size_t)q] = pl->pair_i[(size_t)gp] | (pl->pair_j[(size_t)gp] << 16);
+            }
+            for (int32_t ln = 0; ln < pl->tile_ntrk[(size_t)t]; ++ln)
+                pl->tile_kx[(size_t)t * kLanes + (size_t)ln] = pl->kx[(size_t)(pl->tile_trk0[(size_t)t] + ln)];
+        }
+        if (n_buf >= 65536) return BT_EUNSUPPORTED;
+    }
+
     // ---- k_update: everything a patch's depth back-substitution needs in one 32-byte record,
     // [track or -1, first E row * 64 + lane, #cameras (bit 30: more than 16, use the tile arrays), 0, 16 camera bytes]
     pl->upd_rec.assign((size_t)p_tot * 8, 0);

@@ -30,6 +30,7 @@ struct PlanDev {
     const int32_t *slot_edge, *slot_pair;
     const uint16_t *slot_lab;
     const int32_t *tile_pair0, *tile_npair, *tile_pairs;     // distinct camera pairs of a tile (global pair ids)
+    const int32_t *tile_ij, *tile_kx;                        // per tile: cameras of its pairs [max_tile_pairs], patch of its tracks [64]
     const int32_t *tile_flags;                               // bit 0: same cameras as the previous tile, bit 1: same pair list
     const uint8_t *slot_lp;                                  // local pair index of a (slot, lane) within its tile
     int max_tile_pairs;
@@ -59,7 +60,7 @@ struct bt_plan {
     std::vector<int32_t> tile_cams;
     std::vector<int32_t> slot_edge, slot_pair;
     std::vector<uint16_t> slot_lab;
-    std::vector<int32_t> tile_pair0, tile_npair, tile_pairs, tile_flags;
+    std::vector<int32_t> tile_pair0, tile_npair, tile_pairs, tile_flags, tile_ij, tile_kx;
     std::vector<uint8_t> slot_lp;
     int max_tile_pairs = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
