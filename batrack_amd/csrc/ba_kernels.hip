@@ -401,10 +401,23 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
         las[wave * 64 + lane] = (int)la_cur;
         __syncthreads();
         if (!SO && wave < 6) {                          // owner of component `wave` of every track's source-camera E
-            for (int w = 0; w < kTileWaves; ++w) {
-                const int lw = las[w * 64 + lane];
-                if (lw != 0xff) Eh[(lw * 6 + wave) * kLdsRowStride + lane] += stg[(w * 8 + wave) * 64 + lane];
+            // a track has ONE source camera (plan-enforced), so the waves' partials of a lane all go to the same
+            // element: all loads first, one read-modify-write
+            float sum = 0.0f;
+            int la = 0xff;
+            for (int w0 = 0; w0 < kTileWaves; w0 += 8) {
+                int lw[8];
+                float pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = w0 + u < kTileWaves;
+                    lw[u] = in ? las[(w0 + u) * 64 + lane] : 0xff;
+                    pv[u] = in ? stg[((w0 + u) * 8 + wave) * 64 + lane] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (lw[u] != 0xff) { sum += pv[u]; la = lw[u]; }
             }
+            if (la != 0xff) Eh[(la * 6 + wave) * kLdsRowStride + lane] += sum;
         }
         if (wave == 6) {                                                   // ba.py:296-311
             float C = 0.0f, wv = 0.0f;
