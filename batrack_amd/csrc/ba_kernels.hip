@@ -251,9 +251,11 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
         const bool has_trk = lane < ntrk;
         int patch = 0;
         float px = 0.0f, py = 0.0f, pdisp = 0.0f;
+        float mono_v = 0.0f;
         if (has_trk) {
             patch = patch_ld;
             px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2];
+            mono_v = a.mono[patch];                 // needed only after the slot loop: no load latency there
         }
         float tu_nx = 0.0f, tv_nx = 0.0f, w0_nx = 0.0f, w1_nx = 0.0f;
         if (e_nx >= 0) {
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
             for (int w = 0; w < kTileWaves; ++w) { C += stg[(w * 8 + 6) * 64 + lane]; wv += stg[(w * 8 + 7) * 64 + lane]; }
             float Q = 0.0f, wp = 0.0f;
             if (has_trk) {
-                const float mono = a.mono[patch];
+                const float mono = mono_v;
                 const float pm = mono > 1e-2f ? 1.0f : 0.0f;
                 float Ca = C + pm * a.alpha;
                 Ca = Ca + a.lmbda;
