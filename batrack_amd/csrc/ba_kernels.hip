@@ -1249,17 +1249,22 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
 }
 
 // ------------------------------------------------------------------ k_solve_fused
-// The LDS-resident factorisation with ONE phase and one barrier per level.
-//   column waves   (64 panel rows each, rows of one column per wave so its metadata is scalar):
-//                  lanes 0..35 bring the column's diagonal block up to date with the "pending"
-//                  updates (sources: the level right below) into a per-wave scratch; every
-//                  lane then applies the pending updates of its own panel row (or of y_j) in
-//                  registers, factors the 6x6 block redundantly and forward-substitutes its row
-//   helper waves   the "lazy" updates of the level below (destinations two or more levels up)
-//                  and its lazy y contributions, concurrently
-// Against k_solve_lds (two phases: factor | substitute) this removes a barrier, the
-// store/reload of L_jj between the phases and the wait of the substitution for the slowest
-// helper; the chain per level is the 6x6 factorisation plus one update row.
+// The LDS-resident factorisation with ONE phase and one barrier per level (levels of at most
+// two columns: two-ended chains).  Updates are split by destination (ba_plan.cpp, fz_*):
+// "pending" = the destination column is factored in the very next level, "lazy" = later.
+//   factor wave    one per column: lanes 0..35 apply the pending updates to the column's diagonal
+//                  block (one element each), every lane factors it redundantly in registers,
+//                  lane 0 publishes the packed factor through LDS + a flag
+//   row waves      64 panel rows of one column each (metadata stays scalar): every lane applies
+//                  the pending update of its own row (or of y_j) in registers - all loads in
+//                  flight before the first FMA - while the factor wave works, then picks up the
+//                  factor and forward-substitutes its row
+//   helper waves   the lazy updates of the level below (one row of a triple per thread) and its
+//                  lazy y contributions
+// Against k_solve_lds (two phases: factor | substitute) this removes a barrier, the store and
+// reload of L_jj between the phases and the wait of the substitution for the slowest helper.
+// The sweep is bounded by LDS throughput (~175 KB of 16-byte reads per level, with bank conflicts
+// between the 288-byte blocks) about as much as by the 6x6 chain; see DESIGN.md section 6.
 constexpr int kLoadInFlight = 4;      // block rows of S a thread has in flight (6 doubles each)
 
 template <typename T>
