@@ -1379,36 +1379,33 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
     {
         const bool bw = wave < kMaxLevelCols;
         const int c = lane >> 3, g = lane & 7;
-        int4 nma = make_int4(-1, 0, 0, 0);
-        int nrc = 0;
-        T nm[6] = {(T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
-        auto preload = [&](int l) {
-            nma = uniform4(lvl_meta[(l * kMaxLevelCols + (bw ? wave : 0)) * mstride]);
-            if (!bw) nma.x = -1;
-            if (nma.x >= 0 && c < 6 && g < nma.z) {
-                const int b = nma.y + 1 + g;
-                nrc = row_idx[b] & 255;
-                const T *mb = Lw + (size_t)b * 36 + c;     // Mt[r][c]
+        struct Pre { int4 ma; int rc; T m[6]; T ztj; };
+        auto preload = [&](int l, Pre &P) {           // everything of level l that does not depend on the x computed so far
+            P.ma = uniform4(lvl_meta[(l * kMaxLevelCols + (bw ? wave : 0)) * mstride]);
+            if (!bw) P.ma.x = -1;
+            P.rc = 0; P.ztj = (T)0;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) nm[k] = mb[6 * k];
+            for (int k = 0; k < 6; ++k) P.m[k] = (T)0;
+            if (P.ma.x >= 0 && c < 6) {
+                P.ztj = zt[6 * P.ma.x + c];
+                if (g < P.ma.z) {
+                    const int b = P.ma.y + 1 + g;
+                    P.rc = row_idx[b] & 255;
+                    const T *mb = Lw + (size_t)b * 36 + c;     // Mt[r][c]
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) P.m[k] = mb[6 * k];
+                }
             }
         };
-        preload(nlev - 1);
-        for (int l = nlev - 1; l >= 0; --l) {
-            const int4 ma = nma;
-            const int rc = nrc;
-            T m[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) m[k] = nm[k];
-            if (l > 0) preload(l - 1);
-            if (ma.w) __syncthreads();
-            if (ma.x >= 0) {
-                const int j = ma.x, dpos = ma.y, cnt = ma.z;
+        auto step = [&](const Pre &P) {
+            if (P.ma.w) __syncthreads();
+            if (P.ma.x >= 0) {
+                const int j = P.ma.x, dpos = P.ma.y, cnt = P.ma.z;
                 T acc = (T)0;
                 if (c < 6 && g < cnt) {
                     T x[6];
-                    load_row6(zt + 6 * rc, x);
-                    acc = m[0] * x[0] + m[1] * x[1] + m[2] * x[2] + m[3] * x[3] + m[4] * x[4] + m[5] * x[5];
+                    load_row6(zt + 6 * P.rc, x);
+                    acc = P.m[0] * x[0] + P.m[1] * x[1] + P.m[2] * x[2] + P.m[3] * x[3] + P.m[4] * x[4] + P.m[5] * x[5];
                     for (int sb = g + 8; sb < cnt; sb += 8) {       // wide columns: further sub-blocks of this lane group
                         const int b = dpos + 1 + sb;
                         load_row6(zt + 6 * (row_idx[b] & 255), x);
@@ -1417,8 +1414,18 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
                     }
                 }
                 acc = dpp_add8(acc);
-                if (c < 6 && g == 0) zt[6 * j + c] -= acc;
+                if (c < 6 && g == 0) zt[6 * j + c] = P.ztj - acc;
                 wave_fence();
+            }
+        };
+        Pre A, B;                                      // two register sets, levels alternate between them
+        preload(nlev - 1, A);
+        for (int l = nlev - 1; l >= 0; l -= 2) {
+            if (l >= 1) preload(l - 1, B);
+            step(A);
+            if (l >= 1) {
+                if (l >= 2) preload(l - 2, A);
+                step(B);
             }
         }
         __syncthreads();
