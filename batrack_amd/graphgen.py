@@ -181,6 +181,48 @@ def make_graph(N, M, K, seed=0, cam=SINTEL, n_buf=None, shuffle=False,
                  n_frames=N, M=M)
 
 
+def make_random_graph(N, M, seed=0, deg=(2, 6), far_frac=0.3, groups=1, cam=SINTEL, n_buf=None, shuffle=True):
+    """Irregular co-visibility: every track of frame i is observed from a random number of frames, most of
+    them near i, a fraction anywhere in the trajectory (loop-closure-like), self edges and repeated
+    observations included.  Exercises elimination orders, fill and level schedules that the banded
+    ``make_graph`` never produces.  ``groups`` > 1 splits the frames into that many sub-sequences with no
+    edges between them (a forest of elimination trees).  Geometry, noise and weights as in ``make_graph``."""
+    g = make_graph(N, M, 1, seed=seed, cam=cam, n_buf=n_buf)
+    rng = np.random.default_rng(seed + 1000)
+    na = N * M
+    ii_l, jj_l, kk_l = [], [], []
+    for k in range(na):
+        i = k // M
+        gsz = -(-N // groups)
+        lo, hi = (i // gsz) * gsz, min(N, (i // gsz + 1) * gsz)
+        nd = int(rng.integers(deg[0], deg[1] + 1))
+        for _ in range(nd):
+            if rng.random() < far_frac:
+                j = int(rng.integers(lo, hi))
+            else:
+                j = int(np.clip(i + rng.integers(-3, 4), lo, hi - 1))
+            ii_l.append(i); jj_l.append(j); kk_l.append(k)
+    ii, jj, kk = (np.asarray(a, np.int64) for a in (ii_l, jj_l, kk_l))
+    gt_patches = g.patches.copy()
+    gt_patches[:, 2] = g.disp_gt
+    u, v, _ = reproject(g.poses_gt, gt_patches, g.intrinsics, ii, jj, kk)
+    E = kk.shape[0]
+    targets3 = np.zeros((E, 3))
+    targets3[:, 0] = u + rng.normal(0.0, 0.5, E)
+    targets3[:, 1] = v + rng.normal(0.0, 0.5, E)
+    targets3[:, 2] = g.disp_gt[kk]
+    weights = rng.uniform(0.2, 1.0, (E, 2))
+    dynamic = rng.random(na) < 0.3
+    weights_pose = weights * (~dynamic[kk])[:, None]
+    if shuffle:
+        p = rng.permutation(E)
+        ii, jj, kk, targets3, weights, weights_pose = ii[p], jj[p], kk[p], targets3[p], weights[p], weights_pose[p]
+    return Graph(poses=g.poses, poses_gt=g.poses_gt, patches=g.patches, disp_gt=g.disp_gt, mono_disp=g.mono_disp,
+                 intrinsics=g.intrinsics, targets3=targets3, weights=weights,
+                 weights_pose=np.ascontiguousarray(weights_pose), ii=ii, jj=jj, kk=kk, bounds=g.bounds,
+                 n_frames=N, M=M)
+
+
 def make_config(name, seed=0, **kw):
     N, M, K = CONFIGS[name]
     return make_graph(N, M, K, seed=seed, **kw)

@@ -212,3 +212,25 @@ def test_reduced_system_is_reproducible_step_after_step():
             assert rel(np.diag(sysv[:D * D].reshape(D, D)), load("c3")["ps.f64.S_diag"]) < 2e-6
         else:
             assert rel(sysv, ref) < 1e-9, it
+
+
+@pytest.mark.parametrize("seed,N,M,fixedp,far,groups", [(0, 10, 6, 1, 0.3, 1), (1, 17, 5, 2, 0.1, 1), (2, 24, 40, 1, 0.0, 1),
+                                                 (3, 30, 30, 3, 0.5, 1), (4, 12, 80, 1, 1.0, 1), (5, 40, 20, 1, 0.05, 1),
+                                                 (6, 64, 16, 1, 0.2, 1), (7, 33, 64, 0, 0.0, 4), (8, 25, 64, 1, 0.2, 3),
+                                                 (9, 36, 64, 0, 0.3, 6)])
+def test_random_covisibility_graphs_vs_oracle(seed, N, M, fixedp, far, groups):
+    """Irregular sparsity (loop-closure-like edges, self edges, repeats, shuffled order): whichever solver
+    variant and tile layout the plan picks, the step equals the float64 oracle's."""
+    g = graphgen.make_random_graph(N, M, seed=seed, far_frac=far, groups=groups)
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics),
+             targets3=f(g.targets3), weights=f(g.weights), weights_pose=f(g.weights_pose),
+             ii=g.ii, jj=g.jj, kk=g.kk, bounds=np.asarray(g.bounds))
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"],
+                         d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=fixedp, want_system=True)
+    o = HipProblem(d).raw_step("weights_pose", fixedp)
+    assert o["status"] == 0
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 4e-6
+    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 2e-3
+    assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL
+    assert rel(o["patches_out"], ref["patches_out"]) < STATE_TOL

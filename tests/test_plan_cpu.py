@@ -138,3 +138,28 @@ def test_c3_solver_schedules_solve_the_system():
     for fn in (sparse_chol_solve, sparse_chol_solve_fused):
         got = fn(A, np.tril(S), y, n, 10.0, 1e-4)
         assert rel(got, want) < 1e-10
+
+
+def as_inputs(g):
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    return dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics),
+                targets3=f(g.targets3), weights=f(g.weights), weights_pose=f(g.weights_pose),
+                ii=g.ii, jj=g.jj, kk=g.kk, bounds=np.asarray(g.bounds, np.float64))
+
+
+@pytest.mark.parametrize("seed,N,M,fixedp,far,groups", [(0, 10, 6, 1, 0.3, 1), (1, 17, 5, 2, 0.1, 1), (2, 24, 4, 1, 0.0, 1),
+                                                 (3, 30, 3, 3, 0.5, 1), (4, 12, 8, 1, 1.0, 1), (5, 40, 2, 1, 0.05, 1),
+                                                 (7, 33, 64, 0, 0.0, 4), (8, 25, 64, 1, 0.2, 3)])
+def test_random_covisibility_graphs(seed, N, M, fixedp, far, groups):
+    """Irregular sparsity (loop-closure-like edges, self edges, repeats): every plan table - tiles, pairs,
+    elimination order, both level schedules with their hazard flags - executed in numpy gives the oracle's step."""
+    g = graphgen.make_random_graph(N, M, seed=seed, far_frac=far, groups=groups)
+    d = as_inputs(g)
+    pl = host_plan(d, fixedp)
+    em = emulate(pl, pl.arrays(), d, "weights_pose")
+    o = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"],
+                       d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=fixedp, want_system=True)
+    assert rel(np.tril(em["S_lower"]), np.tril(o["S"])) < 1e-10
+    assert rel(em["y"], o["y"]) < 1e-10
+    assert rel(em["dX"], o["dX"]) < 1e-7
+    assert rel(em["patches_out"], o["patches_out"]) < 1e-10
