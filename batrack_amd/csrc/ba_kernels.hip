@@ -1381,11 +1381,10 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
         const int c = lane >> 3, g = lane & 7;
         struct Pre { int4 ma; int rc; T m[6]; T ztj; };
         auto preload = [&](int l, Pre &P) {           // everything of level l that does not depend on the x computed so far
-            P.ma = uniform4(lvl_meta[(l * kMaxLevelCols + (bw ? wave : 0)) * mstride]);
+            // (per-lane copies of the level record: no scalarisation needed; operands of lanes without a
+            //  sub-block are never used)
+            P.ma = lvl_meta[(l * kMaxLevelCols + (bw ? wave : 0)) * mstride];
             if (!bw) P.ma.x = -1;
-            P.rc = 0; P.ztj = (T)0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) P.m[k] = (T)0;
             if (P.ma.x >= 0 && c < 6) {
                 P.ztj = zt[6 * P.ma.x + c];
                 if (g < P.ma.z) {
@@ -1398,7 +1397,7 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
             }
         };
         auto step = [&](const Pre &P) {
-            if (P.ma.w) __syncthreads();
+            if (__builtin_amdgcn_readfirstlane(P.ma.w)) __syncthreads();
             if (P.ma.x >= 0) {
                 const int j = P.ma.x, dpos = P.ma.y, cnt = P.ma.z;
                 T acc = (T)0;
@@ -1418,7 +1417,7 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
                 wave_fence();
             }
         };
-        Pre A, B;                                      // two register sets, levels alternate between them
+        Pre A = {}, B = {};                            // two register sets, levels alternate between them
         preload(nlev - 1, A);
         for (int l = nlev - 1; l >= 0; l -= 2) {
             if (l >= 1) preload(l - 1, B);
@@ -1487,7 +1486,8 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
     long long phA = 0, phL = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, sub[6] = {0, 0, 0, 0, 0, 0}, tsub = 0;
 #define BT_SUB(i) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tq = clock64(); sub[i] += tq - tsub; tsub = tq; } } while (0)
-    __syncthreads();
+    // (no barrier here: the load of S below reads the per-block words from global memory, so it is in flight
+    //  together with these table copies; the barrier after it covers both)
 
     int status = BT_SOLVE_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1497,7 +1497,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         // the sweep's tables (their LDS is reused for zt by the back substitution, so a retry reloads them)
         for (int i = tid; i < pd.fz_nlazy * 3; i += nth) lazy[i] = (unsigned short)pd.fz_lazy[i];
         if (tid < 4 && (tid >> 1) < nlev) mbuf[tid >> 1][tid & 1] = pmeta[tid];       // metadata of levels 0 and 1
-        lds_load_system<T>(pd, a, Lw, z, row_idx, lm, tid, nth);
+        lds_load_system<T>(pd, a, Lw, z, pd.fz_rowinfo, lm, tid, nth);
         __syncthreads();
         if (PROF) tload = clock64() - tall;
 
