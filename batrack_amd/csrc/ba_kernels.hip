@@ -1486,8 +1486,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
     long long phA = 0, phL = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, sub[6] = {0, 0, 0, 0, 0, 0}, tsub = 0;
 #define BT_SUB(i) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tq = clock64(); sub[i] += tq - tsub; tsub = tq; } } while (0)
-    // (no barrier here: the load of S below reads the per-block words from global memory, so it is in flight
-    //  together with these table copies; the barrier after it covers both)
+    __syncthreads();
 
     int status = BT_SOLVE_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1497,7 +1496,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         // the sweep's tables (their LDS is reused for zt by the back substitution, so a retry reloads them)
         for (int i = tid; i < pd.fz_nlazy * 3; i += nth) lazy[i] = (unsigned short)pd.fz_lazy[i];
         if (tid < 4 && (tid >> 1) < nlev) mbuf[tid >> 1][tid & 1] = pmeta[tid];       // metadata of levels 0 and 1
-        lds_load_system<T>(pd, a, Lw, z, pd.fz_rowinfo, lm, tid, nth);
+        lds_load_system<T>(pd, a, Lw, z, row_idx, lm, tid, nth);
         __syncthreads();
         if (PROF) tload = clock64() - tall;
 
