@@ -1761,6 +1761,229 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
 #undef BT_SUB
 }
 
+// ------------------------------------------------------------------ k_solve_rr
+// Register-resident variant of the LDS solver: the part of the reduced system that is not factored
+// yet lives in the MFMA accumulators of the 8 waves, as 16x16 tiles of the permuted matrix (lower
+// triangle; ownership, tables: ba_plan.cpp "rr_"); LDS holds only the factored columns.  Per level:
+//   extract   the owners of the tiles holding a column's diagonal block and panel store those entries
+//             into the block storage (they have received every update by then: same registers)
+//   factor    one wave per 64 panel rows of a column: factor the diagonal block redundantly in
+//             registers, forward-substitute the own row (or y_j); nothing is pending
+//   update    tile (I, J) -= P_I P_J^T, P = rows of the column's panel from LDS: two
+//             v_mfma_f64_16x16x4 per touched tile (K = 6), and the column's contributions to y
+// Against k_solve_fused this removes the read-modify-write of every updated block through LDS (the
+// bulk of its LDS traffic) and the update work of the row waves ahead of the factorisation.
+constexpr int kRRSlots = kRRSlotsMax;      // accumulator tiles per wave (8 VGPRs each); 8 waves so that they fit beside the 6x6 factorisation
+
+__host__ __device__ inline size_t rr_work_bytes(const PlanDev &pd) {
+    const size_t zt = (size_t)pd.D * sizeof(double) + (size_t)pd.nlev * kMaxLevelCols * sizeof(int4);   // zt + compact level table (after the sweep)
+    return ((zt > 64 ? zt : 64) + 15) / 16 * 16;                                                         // 8 zeros during the sweep
+}
+size_t solve_rr_lds_bytes(const PlanDev &pd) {
+    return ((size_t)pd.nnzb * 36 + (size_t)pd.D) * sizeof(double) + rr_work_bytes(pd) +
+           (2 * (size_t)pd.nnzb + (size_t)pd.n + 1 + (size_t)pd.nlev * 8) * sizeof(int) +          // row_idx, pfirst, col_ptr, level records
+           (size_t)pd.rr_nmaps * 16 * sizeof(unsigned short) + 64;
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs a) {
+    typedef double T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int flags[2];
+    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
+    const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev, S = pd.rr_nslots;
+    T *Lw = reinterpret_cast<T *>(smem);
+    T *z = Lw + (size_t)nnzb * 36, *work = z + D, *zt = work;
+    int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(work) + rr_work_bytes(pd)), *pfirst = row_idx + nnzb,
+        *col_ptr = pfirst + nnzb, *lrec = col_ptr + n + 1;
+    unsigned short *maps = reinterpret_cast<unsigned short *>(lrec + (size_t)nlev * 8);
+    const int zero_off = (int)(work - Lw);                                   // 8 doubles of zeros (operand rows outside a panel)
+    for (int i = tid; i < nnzb; i += nth) { row_idx[i] = pd.fz_rowinfo[i]; pfirst[i] = pd.fz_pfirst[i]; }
+    for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
+    for (int i = tid; i < nlev * 8; i += nth) lrec[i] = pd.fz_pmeta[i];
+    for (int i = tid; i < pd.rr_nmaps * 16; i += nth) maps[i] = pd.rr_map[i];
+    long long tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, sub[6] = {0, 0, 0, 0, 0, 0}, tsub = 0;
+#define BT_SUB(i) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tq = clock64(); sub[i] += tq - tsub; tsub = tq; } } while (0)
+
+    int status = BT_SOLVE_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const double lm = attempt == 0 ? 1e-4 : 1e-3;
+        if (tid < 2) flags[tid] = 0;
+        if (tid < 8) work[tid] = (T)0;
+        // ---- the system into the accumulators: this wave's tiles, entry by entry from S (caller order, lower triangle)
+        double4_t acc[kRRSlots];
+        {
+            const int *it = pd.rr_init + (size_t)wave * S * 256 + lane;
+#pragma unroll
+            for (int s = 0; s < kRRSlots; ++s) {
+                int idx[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) idx[r] = s < S ? it[(s * 4 + r) * 64] : -1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = 0.0;
+                    if (idx[r] >= 0) {
+                        v = a.S[idx[r] & 0x3fffffff];
+                        if (idx[r] & (1 << 30)) v = v + ((double)a.ep + lm * v);          // ba.py:67
+                    }
+                    acc[s][r] = v;
+                }
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four tiles' loads in flight at a time (register budget)
+            }
+        }
+        for (int i = tid; i < D; i += nth) z[i] = (T)a.y[6 * pd.perm[i / 6] + i % 6];
+        __syncthreads();
+        if (PROF) tload = clock64() - tall;
+
+        // packed level records (ba_plan.cpp: fz_pmeta) of the current level, in SGPRs
+        int c0a = 0, c0b = 0, c1a = 0, c1b = 0;
+        auto take_level = [&](int l) {
+            const int4 m0 = reinterpret_cast<const int4 *>(lrec)[2 * l], m1 = reinterpret_cast<const int4 *>(lrec)[2 * l + 1];
+            c0a = __builtin_amdgcn_readfirstlane(m0.x); c0b = __builtin_amdgcn_readfirstlane(m0.y);
+            c1a = __builtin_amdgcn_readfirstlane(m1.x); c1b = __builtin_amdgcn_readfirstlane(m1.y);
+        };
+        auto load_desc = [&](const int32_t *base, int l) {
+            return lane < 2 * S ? base[((size_t)l * nw + wave) * S * 2 + lane] : -1;
+        };
+        // extraction: tiles -> block storage, for the columns of level l (descriptors in ve)
+        auto extract = [&](int ve) {
+#pragma unroll
+            for (int s = 0; s < kRRSlots; ++s)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int d = __builtin_amdgcn_readlane(ve, 2 * s + q);
+                    if (d >= 0) {
+                        const int mp = (d & 0xffff) * 16, cc = (lane & 15) - ((d >> 16) - 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned o = maps[mp + (lane >> 4) + 4 * r];
+                            if (o != 0xffffu && cc >= 0 && cc < 6) Lw[(o & 0x7fffu) + cc] = acc[s][r];
+                        }
+                    }
+                }
+        };
+        int ve = load_desc(pd.rr_edesc, 0), vu = -1;
+        extract(ve);
+        for (int l = 0; l < nlev; ++l) {
+            take_level(l);
+            vu = load_desc(pd.rr_udesc, l);
+            ve = l + 1 < nlev ? load_desc(pd.rr_edesc, l + 1) : -1;
+            __syncthreads();
+            if (PROF) tsub = clock64();
+            // ---- factor: one wave per 64 panel rows (and y_j) of a column
+            const int cnc = (c0b >> 24) & 3;
+            const int nr0 = (c0b >> 16) & 255, nr1 = cnc > 1 ? (c1b >> 16) & 255 : 0;
+            for (int aw = wave; aw < nr0 + nr1; aw += nw) {
+                const int q = aw >= nr0 ? 1 : 0, part = aw - (q ? nr0 : 0);
+                const int ma = q ? c1a : c0a, dpos = (q ? c1b : c0b) & 0xffff;
+                const int j = ma & 255, cnt = (ma >> 8) & 255;
+                const int rw = part * 64 + lane;
+                const bool valid = rw <= cnt * 6, isy = rw == cnt * 6;
+                const int sb = rw / 6, r = rw - 6 * sb;
+                T *p = isy ? z + 6 * j : Lw + (size_t)(dpos + 1 + sb) * 36 + 6 * r;
+                T in[6], L[21];
+                load_row6(p, in);
+                {
+                    const T *dblk = Lw + (size_t)dpos * 36;
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) {
+                        T row[6];
+                        load_row6(dblk + 6 * rr, row);
+#pragma unroll
+                        for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
+                    }
+                }
+                const bool ok = chol6_packed<T>(L);
+                if (!ok && part == 0 && lane == 0) flags[0] = 1;
+                if (valid) {
+                    T out[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        T t = in[c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
+                        out[c] = t * L[BT_LT(c, c)];
+                    }
+                    store_row6(p, out);
+                }
+            }
+            BT_SUB(0);
+            __syncthreads();
+            if (PROF) tsub = clock64();
+            // ---- update: this wave's touched tiles on the matrix cores
+            {
+                const int m16 = lane & 15, k0 = lane >> 4;
+#pragma unroll
+                for (int s = 0; s < kRRSlots; ++s)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int d = __builtin_amdgcn_readlane(vu, 2 * s + q);
+                        if (d >= 0) {
+                            const unsigned oa = maps[(d & 0xffff) * 16 + m16], ob = maps[(d >> 16) * 16 + m16];
+                            const bool za = (oa & 0x8000u) != 0, zb = (ob & 0x8000u) != 0;     // diagonal-block rows and rows outside the panel: zero
+                            const T a0 = Lw[za ? zero_off : (int)oa + k0], a1 = Lw[(za || k0 >= 2) ? zero_off : (int)oa + 4 + k0];
+                            const T b0 = Lw[zb ? zero_off : (int)ob + k0], b1 = Lw[(zb || k0 >= 2) ? zero_off : (int)ob + 4 + k0];
+                            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc[s], 0, 0, 0);
+                            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc[s], 0, 0, 0);
+                        }
+                    }
+            }
+            // ---- the level's contributions to y: y_i -= L_ij y_j, one row of a block per thread, from the last threads down
+            {
+                const int ys0 = ((c0a >> 8) & 255) * 6, ys1 = ys0 + (cnc > 1 ? ((c1a >> 8) & 255) * 6 : 0);
+                for (int item = nth - 1 - tid; item < ys1; item += nth) {
+                    const bool sec = item >= ys0;
+                    const int qq = item - (sec ? ys0 : 0);
+                    const int pj = (sec ? c1a : c0a) & 255, dposp = (sec ? c1b : c0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
+                    const int rcv = row_idx[dposp + 1 + sb];
+                    T lr[6], zr[6];
+                    load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
+                    load_row6(z + 6 * pj, zr);
+                    T sum = lr[0] * zr[0];
+#pragma unroll
+                    for (int k = 1; k < 6; ++k) sum += lr[k] * zr[k];
+                    lds_sub(z + 6 * (rcv & 255) + r, sum, (rcv & (1 << 24)) != 0);
+                }
+            }
+            BT_SUB(1);
+            // ---- extract the next level's columns
+            if (l + 1 < nlev) extract(ve);
+            BT_SUB(2);
+        }
+        __syncthreads();
+        if (PROF) tsweep = clock64() - tall;
+
+        int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
+        for (int i = tid; i < nlev * kMaxLevelCols; i += nth) {          // (col, diag pos, #sub-blocks, barrier before this level)
+            int4 mm = reinterpret_cast<const int4 *>(pd.fz_meta)[2 * i];
+            mm.w = pd.bs_sync[i / kMaxLevelCols];
+            bmeta[i] = mm;
+        }
+        long long tbs[2] = {0, 0};
+        lds_back_substitute<T, true>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth, PROF ? tbs : nullptr);
+        for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
+        __syncthreads();
+        const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
+        __syncthreads();
+        if (failed) {
+            for (int i = tid; i < D; i += nth) zt[i] = (T)0;
+            status = BT_SOLVE_CHOL_FAILED;
+            break;
+        }
+        if (!has_nan) break;
+        status = BT_SOLVE_RETRIED;
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
+    if (tid == 0) a.status[0] = status;
+    if (PROF && lane == 0 && wave == 0) {        // measurement only
+        long long *g = reinterpret_cast<long long *>(a.status + 4);
+        g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
+        for (int i = 0; i < 6; ++i) g[3 + i] = sub[i];
+    }
+#undef BT_SUB
+}
+
 // ------------------------------------------------------------------ k_update
 __device__ inline void retract_pose(const float *pin, const float *xi, float *pout) {
     // poses' = Exp(xi) * G  (groups.py:153-156; so3.h:153-190; se3.h:134-142), in double
@@ -1914,6 +2137,12 @@ static bool use_fused_solver(const PlanDev &pd) {
     return on != 0 && pd.fz_ok != 0 && solve_fused_lds_bytes(pd, solver_threads()) <= kLdsBudget;
 }
 
+// register-resident variant; BT_SOLVER_RR=0: the factor stays in LDS throughout (k_solve_fused)
+static bool use_rr_solver(const PlanDev &pd) {
+    static const int on = std::getenv("BT_SOLVER_RR") ? std::atoi(std::getenv("BT_SOLVER_RR")) : 1;   // measurement only
+    return on != 0 && pd.rr_ok != 0 && pd.rr_nslots <= kRRSlots && solve_rr_lds_bytes(pd) <= kLdsBudget;
+}
+
 static int solver_threads() {
     // 12 waves: enough helper threads for one round of update rows on banded systems, and a
     // 170-register budget per thread so that a whole 6x6 operand block can be in flight from LDS
@@ -1943,6 +2172,12 @@ int configure_kernels(const PlanDev &pd) {
             if (hipFuncSetAttribute(fns[2 * mode + v], hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)solve_lds_bytes(pd, mode == 0 ? 8 : 4)) != hipSuccess)
                 return BT_EHIP;
+    if (mode == 0 && use_rr_solver(pd))
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_rr<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_rr_lds_bytes(pd)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_rr<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_rr_lds_bytes(pd)) != hipSuccess)
+            return BT_EHIP;
     if (mode == 0 && use_fused_solver(pd))
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)solve_fused_lds_bytes(pd, solver_threads())) != hipSuccess ||
@@ -1986,7 +2221,9 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int mode = solver_mode(pd);
         const bool prof = (a.dbg & 16) != 0;
         const int nthr = solver_threads();
-        if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH(3, k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
+        if (mode == 0 && use_rr_solver(pd) && !prof)    BT_LAUNCH(3, k_solve_rr<false>, dim3(1), dim3(64 * kRRWaves), solve_rr_lds_bytes(pd), pd, a);
+        else if (mode == 0 && use_rr_solver(pd))        BT_LAUNCH(3, k_solve_rr<true>, dim3(1), dim3(64 * kRRWaves), solve_rr_lds_bytes(pd), pd, a);
+        else if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH(3, k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
         else if (mode == 0 && use_fused_solver(pd))     BT_LAUNCH(3, k_solve_fused<true>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
         else if (mode == 0 && !prof) BT_LAUNCH(3, (k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
         else if (mode == 0)          BT_LAUNCH(3, (k_solve_lds<double, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
