@@ -1812,23 +1812,36 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
         if (tid < 8) work[tid] = (T)0;
         // ---- the system into the accumulators: this wave's tiles, entry by entry from S (caller order, lower triangle)
         double4_t acc[kRRSlots];
+        // One case per accumulator slot: the slot index must be a compile-time constant for the tile to stay in
+        // registers, the lists of touched slots are data.
+#define BT_SLOT_SWITCH(slot, BODY)                                                                                  \
+        switch (slot) {                                                                                             \
+            case 0: BODY(0) break;   case 1: BODY(1) break;   case 2: BODY(2) break;   case 3: BODY(3) break;       \
+            case 4: BODY(4) break;   case 5: BODY(5) break;   case 6: BODY(6) break;   case 7: BODY(7) break;       \
+            case 8: BODY(8) break;   case 9: BODY(9) break;   case 10: BODY(10) break; case 11: BODY(11) break;     \
+            case 12: BODY(12) break; case 13: BODY(13) break; case 14: BODY(14) break; default: BODY(15) break;     \
+        }
+        static_assert(kRRSlots == 16, "BT_SLOT_SWITCH lists 16 slots");
         {
             const int *it = pd.rr_init + (size_t)wave * S * 256 + lane;
-#pragma unroll
-            for (int s = 0; s < kRRSlots; ++s) {
+#pragma unroll 1
+            for (int s = 0; s < S; ++s) {
                 int idx[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) idx[r] = s < S ? it[(s * 4 + r) * 64] : -1;
+                for (int r = 0; r < 4; ++r) idx[r] = it[(s * 4 + r) * 64];
+                double4_t v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    double v = 0.0;
+                    double x = 0.0;
                     if (idx[r] >= 0) {
-                        v = a.S[idx[r] & 0x3fffffff];
-                        if (idx[r] & (1 << 30)) v = v + ((double)a.ep + lm * v);          // ba.py:67
+                        x = a.S[idx[r] & 0x3fffffff];
+                        if (idx[r] & (1 << 30)) x = x + ((double)a.ep + lm * x);          // ba.py:67
                     }
-                    acc[s][r] = v;
+                    v[r] = x;
                 }
-                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four tiles' loads in flight at a time (register budget)
+#define BT_SET(k) acc[k] = v;
+                BT_SLOT_SWITCH(s, BT_SET)
+#undef BT_SET
             }
         }
         for (int i = tid; i < D; i += nth) z[i] = (T)a.y[6 * pd.perm[i / 6] + i % 6];
@@ -1842,25 +1855,26 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
             c0a = __builtin_amdgcn_readfirstlane(m0.x); c0b = __builtin_amdgcn_readfirstlane(m0.y);
             c1a = __builtin_amdgcn_readfirstlane(m1.x); c1b = __builtin_amdgcn_readfirstlane(m1.y);
         };
-        auto load_desc = [&](const int32_t *base, int l) {
-            return lane < 2 * S ? base[((size_t)l * nw + wave) * S * 2 + lane] : -1;
+        auto load_desc = [&](const int32_t *base, int l) {          // this wave's list of touched slots of level l, one entry per lane
+            return lane < kRRTouches ? base[((size_t)l * nw + wave) * kRRTouches + lane] : -1;
         };
-        // extraction: tiles -> block storage, for the columns of level l (descriptors in ve)
+        // extraction: tiles -> block storage, for the columns of a level (list in ve: slot | map << 4 | (6 j - 16 J + 16) << 18)
         auto extract = [&](int ve) {
+#pragma unroll 1
+            for (int t = 0; t < kRRTouches; ++t) {
+                const int d = __builtin_amdgcn_readlane(ve, t);
+                if (d < 0) break;
+                const int mp = ((d >> 4) & 0x3fff) * 16, cc = (lane & 15) - ((d >> 18) - 16);
+                unsigned o[4];
 #pragma unroll
-            for (int s = 0; s < kRRSlots; ++s)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int d = __builtin_amdgcn_readlane(ve, 2 * s + q);
-                    if (d >= 0) {
-                        const int mp = (d & 0xffff) * 16, cc = (lane & 15) - ((d >> 16) - 16);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const unsigned o = maps[mp + (lane >> 4) + 4 * r];
-                            if (o != 0xffffu && cc >= 0 && cc < 6) Lw[(o & 0x7fffu) + cc] = acc[s][r];
-                        }
-                    }
-                }
+                for (int r = 0; r < 4; ++r) o[r] = maps[mp + (lane >> 4) + 4 * r];
+                const bool col_ok = cc >= 0 && cc < 6;
+#define BT_EXT(k)                                                                                                   \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                       \
+                    if (o[r] != 0xffffu && col_ok) Lw[(o[r] & 0x7fffu) + cc] = acc[k][r];
+                BT_SLOT_SWITCH(d & 15, BT_EXT)
+#undef BT_EXT
+            }
         };
         int ve = load_desc(pd.rr_edesc, 0), vu = -1;
         extract(ve);
@@ -1910,23 +1924,23 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
             BT_SUB(0);
             __syncthreads();
             if (PROF) tsub = clock64();
-            // ---- update: this wave's touched tiles on the matrix cores
+            // ---- update: this wave's touched tiles on the matrix cores (list in vu: slot | mapA << 4 | mapB << 18)
             {
                 const int m16 = lane & 15, k0 = lane >> 4;
-#pragma unroll
-                for (int s = 0; s < kRRSlots; ++s)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int d = __builtin_amdgcn_readlane(vu, 2 * s + q);
-                        if (d >= 0) {
-                            const unsigned oa = maps[(d & 0xffff) * 16 + m16], ob = maps[(d >> 16) * 16 + m16];
-                            const bool za = (oa & 0x8000u) != 0, zb = (ob & 0x8000u) != 0;     // diagonal-block rows and rows outside the panel: zero
-                            const T a0 = Lw[za ? zero_off : (int)oa + k0], a1 = Lw[(za || k0 >= 2) ? zero_off : (int)oa + 4 + k0];
-                            const T b0 = Lw[zb ? zero_off : (int)ob + k0], b1 = Lw[(zb || k0 >= 2) ? zero_off : (int)ob + 4 + k0];
-                            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc[s], 0, 0, 0);
-                            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc[s], 0, 0, 0);
-                        }
-                    }
+#pragma unroll 1
+                for (int t = 0; t < kRRTouches; ++t) {
+                    const int d = __builtin_amdgcn_readlane(vu, t);
+                    if (d < 0) break;
+                    const unsigned oa = maps[((d >> 4) & 0x3fff) * 16 + m16], ob = maps[((d >> 18) & 0x3fff) * 16 + m16];
+                    const bool za = (oa & 0x8000u) != 0, zb = (ob & 0x8000u) != 0;     // diagonal-block rows and rows outside the panel: zero
+                    const T a0 = -Lw[za ? zero_off : (int)oa + k0], a1 = -Lw[(za || k0 >= 2) ? zero_off : (int)oa + 4 + k0];
+                    const T b0 = Lw[zb ? zero_off : (int)ob + k0], b1 = Lw[(zb || k0 >= 2) ? zero_off : (int)ob + 4 + k0];
+#define BT_UPD(k)                                                                                                   \
+                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[k], 0, 0, 0);                         \
+                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[k], 0, 0, 0);
+                    BT_SLOT_SWITCH(d & 15, BT_UPD)
+#undef BT_UPD
+                }
             }
             // ---- the level's contributions to y: y_i -= L_ij y_j, one row of a block per thread, from the last threads down
             {
@@ -1982,6 +1996,7 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
         for (int i = 0; i < 6; ++i) g[3 + i] = sub[i];
     }
 #undef BT_SUB
+#undef BT_SLOT_SWITCH
 }
 
 // ------------------------------------------------------------------ k_update

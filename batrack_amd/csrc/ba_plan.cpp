@@ -582,7 +582,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     //   update   tile (I, J) -= P_I P_J^T with P = rows of column j's panel, two v_mfma_f64_16x16x4 (rr_udesc)
     // Tables: rr_map[k][16]   LDS offset (in elements) of the 16 rows of a tile row within a column's blocks,
     //                         bit 15 = row of the diagonal block (extracted, but zero as an update operand), 0xffff = none
-    //         rr_edesc / rr_udesc [level][wave][slot][2]   extract: map | (6 j - 16 J + 16) << 16; update: mapA | mapB << 16; -1 none
+    //         rr_edesc / rr_udesc [level][wave][kRRTouches]  lists of touched accumulator slots (formats below), -1 terminated
     //         rr_init[wave][slot][reg][lane]               where the tile entry comes from in S (bit 30: diagonal), -1: zero
     {
         const int kW = kRRWaves, kSlotsMax = kRRSlotsMax;
@@ -652,13 +652,27 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             }
             int S = 0;
             for (int w = 0; w < kW; ++w) S = std::max(S, nslots[w]);
-            ok = ok && S <= kSlotsMax && pl->rr_map.size() / 16 < 32768;
+            ok = ok && S <= kSlotsMax && pl->rr_map.size() / 16 < 8192;
+            // per (level, wave) lists of at most kRRTouches entries, -1 terminated:
+            //   update   slot | mapA << 4 | mapB << 18          extract   slot | map << 4 | (6 j - 16 J + 16) << 18
+            std::vector<int> ne((size_t)nlev * kW, 0), nu((size_t)nlev * kW, 0);
+            if (ok) {
+                pl->rr_edesc.assign((size_t)nlev * kW * kRRTouches, -1);
+                pl->rr_udesc.assign((size_t)nlev * kW * kRRTouches, -1);
+                for (const Touch &t : et) {
+                    const size_t lw = (size_t)t.l * kW + owner[(size_t)t.tile];
+                    if (ne[lw] >= kRRTouches) { ok = false; break; }
+                    pl->rr_edesc[lw * kRRTouches + ne[lw]++] = slot[(size_t)t.tile] | (t.a << 4) | (t.b << 18);
+                }
+                for (const Touch &t : ut) {
+                    const size_t lw = (size_t)t.l * kW + owner[(size_t)t.tile];
+                    if (nu[lw] >= kRRTouches) { ok = false; break; }
+                    pl->rr_udesc[lw * kRRTouches + nu[lw]++] = slot[(size_t)t.tile] | (t.a << 4) | (t.b << 18);
+                }
+            }
+            if (!ok) { pl->rr_edesc.clear(); pl->rr_udesc.clear(); }
             if (ok) {
                 pl->rr_ok = 1; pl->rr_nslots = S; pl->rr_nmaps = (int)(pl->rr_map.size() / 16);
-                pl->rr_edesc.assign((size_t)nlev * kW * S * 2, -1);
-                pl->rr_udesc.assign((size_t)nlev * kW * S * 2, -1);
-                for (const Touch &t : et) pl->rr_edesc[(((size_t)t.l * kW + owner[(size_t)t.tile]) * S + slot[(size_t)t.tile]) * 2 + t.q] = t.a | (t.b << 16);
-                for (const Touch &t : ut) pl->rr_udesc[(((size_t)t.l * kW + owner[(size_t)t.tile]) * S + slot[(size_t)t.tile]) * 2 + t.q] = t.a | (t.b << 16);
                 pl->rr_init.assign((size_t)kW * S * 256, -1);
                 for (int w = 0; w < kW; ++w)
                     for (int sl = 0; sl < nslots[w]; ++sl) {

@@ -19,6 +19,7 @@ constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
 constexpr int kLdsRowStride = 66;
 constexpr int kRRWaves = 8;          // waves of the register-resident solver (512 threads: 256 registers each)
 constexpr int kRRSlotsMax = 16;      // accumulator tiles a wave may own (8 registers each)
+constexpr int kRRTouches = 8;        // tiles of one wave a level may extract from / update
 constexpr int kMaxLevelCols = 4;
 constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geometry is kept in LDS    // columns of the reduced system factored concurrently (one critical wave each)   // floats per local E row (bank-conflict-free)
 

@@ -387,10 +387,10 @@ def sparse_chol_solve_rr(A, S_lower, y, n, ep, lm):
     lvl_ptr, lvl_cols, col_lvl = A["lvl_ptr"], A["lvl_cols"], A["col_lvl"]
     pend_ptr, pend, yurg = A["fz_pend_ptr"], A["fz_pend"].reshape(-1, 2), A["fz_yurg"]
     nnzb, nlev, D = len(row_idx), len(lvl_ptr) - 1, 6 * n
-    W = 8
-    S = len(A["rr_edesc"]) // (nlev * W * 2)
-    assert S > 0 and len(A["rr_init"]) == W * S * 256
-    edesc, udesc = A["rr_edesc"].reshape(nlev, W, S, 2), A["rr_udesc"].reshape(nlev, W, S, 2)
+    W, K = 8, 8
+    S = len(A["rr_init"]) // (W * 256)
+    assert S > 0 and len(A["rr_edesc"]) == nlev * W * K == len(A["rr_udesc"])
+    edesc, udesc = A["rr_edesc"].reshape(nlev, W, K), A["rr_udesc"].reshape(nlev, W, K)
     rmap = A["rr_map"].reshape(-1, 16).astype(np.int64)
     init = A["rr_init"].reshape(W, S, 4, 64)
     lane = np.arange(64)
@@ -412,22 +412,21 @@ def sparse_chol_solve_rr(A, S_lower, y, n, ep, lm):
         assert len(cols) <= 2
         # extract
         for w in range(W):
-            for sl in range(S):
-                for q in range(2):
-                    d = int(edesc[l, w, sl, q])
-                    if d < 0:
-                        continue
-                    assert q < len(cols)
-                    m_id, c0 = d & 0xffff, (d >> 16) - 16
-                    for r in range(4):
-                        offs = rmap[m_id][(lane >> 4) + 4 * r]
-                        cc = (lane & 15) - c0
-                        sel = (offs != 0xffff) & (cc >= 0) & (cc < 6)
-                        dst = (offs[sel] & 0x7fff) + cc[sel]
-                        blk = dst // 36
-                        assert np.all(blk_col[blk] == cols[q])
-                        mem[dst] = tiles[w, sl, r][sel]
-                        written[dst] += 1
+            for t in range(K):
+                d = int(edesc[l, w, t])
+                if d < 0:
+                    assert np.all(edesc[l, w, t:] < 0)
+                    break
+                sl, m_id, c0 = d & 15, (d >> 4) & 0x3fff, (d >> 18) - 16
+                for r in range(4):
+                    offs = rmap[m_id][(lane >> 4) + 4 * r]
+                    cc = (lane & 15) - c0
+                    sel = (offs != 0xffff) & (cc >= 0) & (cc < 6)
+                    dst = (offs[sel] & 0x7fff) + cc[sel]
+                    blk = dst // 36
+                    assert np.all(np.isin(blk_col[blk], cols))
+                    mem[dst] = tiles[w, sl, r][sel]
+                    written[dst] += 1
         for c in cols:
             d = int(col_ptr[c])
             low = np.tril(np.ones((6, 6), bool)).reshape(-1)
@@ -452,23 +451,24 @@ def sparse_chol_solve_rr(A, S_lower, y, n, ep, lm):
                 z[6*i:6*i + 6] -= mem[36*b:36*b + 36].reshape(6, 6) @ z[6*p:6*p + 6]
         # update
         for w in range(W):
-            for sl in range(S):
-                for q in range(2):
-                    d = int(udesc[l, w, sl, q])
-                    if d < 0:
-                        continue
-                    ops = []
-                    for m_id in (d & 0xffff, d >> 16):
-                        offs = rmap[m_id]
-                        P = np.zeros((16, 6))
-                        for m in range(16):
-                            if offs[m] != 0xffff and not (offs[m] & 0x8000):
-                                P[m] = mem[offs[m]:offs[m] + 6]
-                                assert blk_col[offs[m] // 36] == cols[q]
-                        ops.append(P)
-                    prod = ops[0] @ ops[1].T
-                    for r in range(4):
-                        tiles[w, sl, r] -= prod[(lane >> 4) + 4 * r, lane & 15]
+            for t in range(K):
+                d = int(udesc[l, w, t])
+                if d < 0:
+                    assert np.all(udesc[l, w, t:] < 0)
+                    break
+                sl = d & 15
+                ops = []
+                for m_id in ((d >> 4) & 0x3fff, (d >> 18) & 0x3fff):
+                    offs = rmap[m_id]
+                    P = np.zeros((16, 6))
+                    for m in range(16):
+                        if offs[m] != 0xffff and not (offs[m] & 0x8000):
+                            P[m] = mem[offs[m]:offs[m] + 6]
+                            assert blk_col[offs[m] // 36] in cols
+                    ops.append(P)
+                prod = ops[0] @ ops[1].T
+                for r in range(4):
+                    tiles[w, sl, r] -= prod[(lane >> 4) + 4 * r, lane & 15]
     L = mem.reshape(nnzb, 6, 6)
     x = z.copy()
     bs_sync = A["bs_sync"]
