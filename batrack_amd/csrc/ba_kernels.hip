@@ -1825,23 +1825,21 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
         {
             const int *it = pd.rr_init + (size_t)wave * S * 256 + lane;
 #pragma unroll 1
-            for (int s = 0; s < S; ++s) {
-                int idx[4];
+            for (int g = 0; g < S; g += 4) {                  // four tiles at a time: 16 index loads, then 16 loads of S
+                int idx[16];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) idx[r] = it[(s * 4 + r) * 64];
-                double4_t v;
+                for (int u = 0; u < 16; ++u) idx[u] = g + (u >> 2) < S ? it[((g + (u >> 2)) * 4 + (u & 3)) * 64] : -1;
+                double x[16];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double x = 0.0;
-                    if (idx[r] >= 0) {
-                        x = a.S[idx[r] & 0x3fffffff];
-                        if (idx[r] & (1 << 30)) x = x + ((double)a.ep + lm * x);          // ba.py:67
-                    }
-                    v[r] = x;
-                }
-#define BT_SET(k) acc[k] = v;
-                BT_SLOT_SWITCH(s, BT_SET)
-#undef BT_SET
+                for (int u = 0; u < 16; ++u) x[u] = idx[u] >= 0 ? a.S[idx[u] & 0x3fffffff] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (idx[u] >= 0 && (idx[u] & (1 << 30))) x[u] = x[u] + ((double)a.ep + lm * x[u]);          // ba.py:67
+#define BT_SET4(b)                                                                                                  \
+                acc[b] = double4_t{x[0], x[1], x[2], x[3]};         acc[b + 1] = double4_t{x[4], x[5], x[6], x[7]};  \
+                acc[b + 2] = double4_t{x[8], x[9], x[10], x[11]};   acc[b + 3] = double4_t{x[12], x[13], x[14], x[15]};
+                switch (g) { case 0: BT_SET4(0) break; case 4: BT_SET4(4) break; case 8: BT_SET4(8) break; default: BT_SET4(12) break; }
+#undef BT_SET4
             }
         }
         for (int i = tid; i < D; i += nth) z[i] = (T)a.y[6 * pd.perm[i / 6] + i % 6];
@@ -1924,22 +1922,39 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
             BT_SUB(0);
             __syncthreads();
             if (PROF) tsub = clock64();
-            // ---- update: this wave's touched tiles on the matrix cores (list in vu: slot | mapA << 4 | mapB << 18)
+            // ---- update: this wave's touched tiles on the matrix cores (list in vu: slot | mapA << 4 | mapB << 18);
+            // row maps and operands of four touches in flight before the first MFMA
             {
                 const int m16 = lane & 15, k0 = lane >> 4;
 #pragma unroll 1
-                for (int t = 0; t < kRRTouches; ++t) {
-                    const int d = __builtin_amdgcn_readlane(vu, t);
-                    if (d < 0) break;
-                    const unsigned oa = maps[((d >> 4) & 0x3fff) * 16 + m16], ob = maps[((d >> 18) & 0x3fff) * 16 + m16];
-                    const bool za = (oa & 0x8000u) != 0, zb = (ob & 0x8000u) != 0;     // diagonal-block rows and rows outside the panel: zero
-                    const T a0 = -Lw[za ? zero_off : (int)oa + k0], a1 = -Lw[(za || k0 >= 2) ? zero_off : (int)oa + 4 + k0];
-                    const T b0 = Lw[zb ? zero_off : (int)ob + k0], b1 = Lw[(zb || k0 >= 2) ? zero_off : (int)ob + 4 + k0];
+                for (int tb = 0; tb < kRRTouches; tb += 4) {
+                    int d[4];
+                    unsigned oa[4], ob[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        d[u] = __builtin_amdgcn_readlane(vu, tb + u);
+                        const int dd = d[u] < 0 ? 0 : d[u];
+                        oa[u] = maps[((dd >> 4) & 0x3fff) * 16 + m16]; ob[u] = maps[((dd >> 18) & 0x3fff) * 16 + m16];
+                    }
+                    if (d[0] < 0) break;
+                    T a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool za = (oa[u] & 0x8000u) != 0, zb = (ob[u] & 0x8000u) != 0;     // diagonal-block rows, rows outside the panel: zero
+                        a0[u] = -Lw[za ? zero_off : (int)oa[u] + k0]; a1[u] = -Lw[(za || k0 >= 2) ? zero_off : (int)oa[u] + 4 + k0];
+                        b0[u] = Lw[zb ? zero_off : (int)ob[u] + k0];  b1[u] = Lw[(zb || k0 >= 2) ? zero_off : (int)ob[u] + 4 + k0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (d[u] >= 0) {
+                            const T x0 = a0[u], x1 = a1[u], y0 = b0[u], y1 = b1[u];
 #define BT_UPD(k)                                                                                                   \
-                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[k], 0, 0, 0);                         \
-                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[k], 0, 0, 0);
-                    BT_SLOT_SWITCH(d & 15, BT_UPD)
+                            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, acc[k], 0, 0, 0);                 \
+                            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, acc[k], 0, 0, 0);
+                            BT_SLOT_SWITCH(d[u] & 15, BT_UPD)
 #undef BT_UPD
+                        }
+                    }
                 }
             }
             // ---- the level's contributions to y: y_i -= L_ij y_j, one row of a block per thread, from the last threads down
