@@ -1937,6 +1937,7 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
                         oa[u] = maps[((dd >> 4) & 0x3fff) * 16 + m16]; ob[u] = maps[((dd >> 18) & 0x3fff) * 16 + m16];
                     }
                     if (d[0] < 0) break;
+                    BT_SUB(3);
                     T a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -1944,6 +1945,7 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
                         a0[u] = -Lw[za ? zero_off : (int)oa[u] + k0]; a1[u] = -Lw[(za || k0 >= 2) ? zero_off : (int)oa[u] + 4 + k0];
                         b0[u] = Lw[zb ? zero_off : (int)ob[u] + k0];  b1[u] = Lw[(zb || k0 >= 2) ? zero_off : (int)ob[u] + 4 + k0];
                     }
+                    BT_SUB(4);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (d[u] >= 0) {
@@ -1957,6 +1959,7 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
                     }
                 }
             }
+            BT_SUB(5);
             // ---- the level's contributions to y: y_i -= L_ij y_j, one row of a block per thread, from the last threads down
             {
                 const int ys0 = ((c0a >> 8) & 255) * 6, ys1 = ys0 + (cnc > 1 ? ((c1a >> 8) & 255) * 6 : 0);
