@@ -1773,6 +1773,108 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
 //             v_mfma_f64_16x16x4 per touched tile (K = 6), and the column's contributions to y
 // Against k_solve_fused this removes the read-modify-write of every updated block through LDS (the
 // bulk of its LDS traffic) and the update work of the row waves ahead of the factorisation.
+// The accumulator tiles live in AGPRs a[8 k .. 8 k + 7] (slot k), addressed by name from inline assembly: which
+// slot a level touches is data, and a C++ array of accumulators indexed through a switch makes the compiler
+// shuttle every tile through temporaries (measured: >1000 register copies per level).  The clobber lists make
+// the register allocator reserve the AGPRs; nothing else in the kernel uses them.  Wait states around the f64
+// MFMA and the AGPR moves are written out (the compiler does not see these instructions).
+__device__ __forceinline__ void rr_mfma(int slot, double x0, double y0, double x1, double y1) {
+    switch (slot) {
+        case 0: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[0:7], %0, %1, a[0:7]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[0:7], %2, %3, a[0:7]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7"); break;
+        case 1: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[8:15], %0, %1, a[8:15]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[8:15], %2, %3, a[8:15]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"); break;
+        case 2: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[16:23], %0, %1, a[16:23]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[16:23], %2, %3, a[16:23]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23"); break;
+        case 3: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[24:31], %0, %1, a[24:31]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[24:31], %2, %3, a[24:31]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"); break;
+        case 4: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[32:39], %0, %1, a[32:39]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[32:39], %2, %3, a[32:39]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39"); break;
+        case 5: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[40:47], %0, %1, a[40:47]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[40:47], %2, %3, a[40:47]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47"); break;
+        case 6: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[48:55], %0, %1, a[48:55]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[48:55], %2, %3, a[48:55]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55"); break;
+        case 7: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[56:63], %0, %1, a[56:63]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[56:63], %2, %3, a[56:63]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"); break;
+        case 8: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[64:71], %0, %1, a[64:71]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[64:71], %2, %3, a[64:71]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71"); break;
+        case 9: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[72:79], %0, %1, a[72:79]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[72:79], %2, %3, a[72:79]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79"); break;
+        case 10: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[80:87], %0, %1, a[80:87]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[80:87], %2, %3, a[80:87]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87"); break;
+        case 11: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[88:95], %0, %1, a[88:95]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[88:95], %2, %3, a[88:95]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"); break;
+        case 12: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[96:103], %0, %1, a[96:103]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[96:103], %2, %3, a[96:103]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103"); break;
+        case 13: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[104:111], %0, %1, a[104:111]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[104:111], %2, %3, a[104:111]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111"); break;
+        case 14: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[112:119], %0, %1, a[112:119]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[112:119], %2, %3, a[112:119]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119"); break;
+        default: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[120:127], %0, %1, a[120:127]\n\ts_nop 4\n\t"
+                          "v_mfma_f64_16x16x4_f64 a[120:127], %2, %3, a[120:127]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"); break;
+    }
+}
+__device__ __forceinline__ void rr_read(int slot, double (&v)[4]) {          // tile of a slot -> four doubles per lane
+    int w[8];
+    switch (slot) {
+        case 0: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 1: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\tv_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11\n\tv_accvgpr_read_b32 %4, a12\n\tv_accvgpr_read_b32 %5, a13\n\tv_accvgpr_read_b32 %6, a14\n\tv_accvgpr_read_b32 %7, a15\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 2: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\tv_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 3: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a24\n\tv_accvgpr_read_b32 %1, a25\n\tv_accvgpr_read_b32 %2, a26\n\tv_accvgpr_read_b32 %3, a27\n\tv_accvgpr_read_b32 %4, a28\n\tv_accvgpr_read_b32 %5, a29\n\tv_accvgpr_read_b32 %6, a30\n\tv_accvgpr_read_b32 %7, a31\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 4: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\tv_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 5: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a40\n\tv_accvgpr_read_b32 %1, a41\n\tv_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a43\n\tv_accvgpr_read_b32 %4, a44\n\tv_accvgpr_read_b32 %5, a45\n\tv_accvgpr_read_b32 %6, a46\n\tv_accvgpr_read_b32 %7, a47\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 6: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a52\n\tv_accvgpr_read_b32 %5, a53\n\tv_accvgpr_read_b32 %6, a54\n\tv_accvgpr_read_b32 %7, a55\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 7: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a56\n\tv_accvgpr_read_b32 %1, a57\n\tv_accvgpr_read_b32 %2, a58\n\tv_accvgpr_read_b32 %3, a59\n\tv_accvgpr_read_b32 %4, a60\n\tv_accvgpr_read_b32 %5, a61\n\tv_accvgpr_read_b32 %6, a62\n\tv_accvgpr_read_b32 %7, a63\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 8: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a69\n\tv_accvgpr_read_b32 %6, a70\n\tv_accvgpr_read_b32 %7, a71\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 9: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73\n\tv_accvgpr_read_b32 %2, a74\n\tv_accvgpr_read_b32 %3, a75\n\tv_accvgpr_read_b32 %4, a76\n\tv_accvgpr_read_b32 %5, a77\n\tv_accvgpr_read_b32 %6, a78\n\tv_accvgpr_read_b32 %7, a79\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 10: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83\n\tv_accvgpr_read_b32 %4, a84\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a86\n\tv_accvgpr_read_b32 %7, a87\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 11: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a88\n\tv_accvgpr_read_b32 %1, a89\n\tv_accvgpr_read_b32 %2, a90\n\tv_accvgpr_read_b32 %3, a91\n\tv_accvgpr_read_b32 %4, a92\n\tv_accvgpr_read_b32 %5, a93\n\tv_accvgpr_read_b32 %6, a94\n\tv_accvgpr_read_b32 %7, a95\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 12: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99\n\tv_accvgpr_read_b32 %4, a100\n\tv_accvgpr_read_b32 %5, a101\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a103\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 13: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a104\n\tv_accvgpr_read_b32 %1, a105\n\tv_accvgpr_read_b32 %2, a106\n\tv_accvgpr_read_b32 %3, a107\n\tv_accvgpr_read_b32 %4, a108\n\tv_accvgpr_read_b32 %5, a109\n\tv_accvgpr_read_b32 %6, a110\n\tv_accvgpr_read_b32 %7, a111\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        case 14: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115\n\tv_accvgpr_read_b32 %4, a116\n\tv_accvgpr_read_b32 %5, a117\n\tv_accvgpr_read_b32 %6, a118\n\tv_accvgpr_read_b32 %7, a119\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+        default: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a120\n\tv_accvgpr_read_b32 %1, a121\n\tv_accvgpr_read_b32 %2, a122\n\tv_accvgpr_read_b32 %3, a123\n\tv_accvgpr_read_b32 %4, a124\n\tv_accvgpr_read_b32 %5, a125\n\tv_accvgpr_read_b32 %6, a126\n\tv_accvgpr_read_b32 %7, a127\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
+    }
+    for (int r = 0; r < 4; ++r) v[r] = __hiloint2double(w[2 * r + 1], w[2 * r]);
+}
+__device__ __forceinline__ void rr_write(int slot, const double (&v)[4]) {   // four doubles per lane -> tile of a slot
+    int w[8];
+    for (int r = 0; r < 4; ++r) { w[2 * r] = __double2loint(v[r]); w[2 * r + 1] = __double2hiint(v[r]); }
+    switch (slot) {
+        case 0: asm volatile("v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %2\n\tv_accvgpr_write_b32 a3, %3\n\tv_accvgpr_write_b32 a4, %4\n\tv_accvgpr_write_b32 a5, %5\n\tv_accvgpr_write_b32 a6, %6\n\tv_accvgpr_write_b32 a7, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7"); break;
+        case 1: asm volatile("v_accvgpr_write_b32 a8, %0\n\tv_accvgpr_write_b32 a9, %1\n\tv_accvgpr_write_b32 a10, %2\n\tv_accvgpr_write_b32 a11, %3\n\tv_accvgpr_write_b32 a12, %4\n\tv_accvgpr_write_b32 a13, %5\n\tv_accvgpr_write_b32 a14, %6\n\tv_accvgpr_write_b32 a15, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"); break;
+        case 2: asm volatile("v_accvgpr_write_b32 a16, %0\n\tv_accvgpr_write_b32 a17, %1\n\tv_accvgpr_write_b32 a18, %2\n\tv_accvgpr_write_b32 a19, %3\n\tv_accvgpr_write_b32 a20, %4\n\tv_accvgpr_write_b32 a21, %5\n\tv_accvgpr_write_b32 a22, %6\n\tv_accvgpr_write_b32 a23, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23"); break;
+        case 3: asm volatile("v_accvgpr_write_b32 a24, %0\n\tv_accvgpr_write_b32 a25, %1\n\tv_accvgpr_write_b32 a26, %2\n\tv_accvgpr_write_b32 a27, %3\n\tv_accvgpr_write_b32 a28, %4\n\tv_accvgpr_write_b32 a29, %5\n\tv_accvgpr_write_b32 a30, %6\n\tv_accvgpr_write_b32 a31, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"); break;
+        case 4: asm volatile("v_accvgpr_write_b32 a32, %0\n\tv_accvgpr_write_b32 a33, %1\n\tv_accvgpr_write_b32 a34, %2\n\tv_accvgpr_write_b32 a35, %3\n\tv_accvgpr_write_b32 a36, %4\n\tv_accvgpr_write_b32 a37, %5\n\tv_accvgpr_write_b32 a38, %6\n\tv_accvgpr_write_b32 a39, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39"); break;
+        case 5: asm volatile("v_accvgpr_write_b32 a40, %0\n\tv_accvgpr_write_b32 a41, %1\n\tv_accvgpr_write_b32 a42, %2\n\tv_accvgpr_write_b32 a43, %3\n\tv_accvgpr_write_b32 a44, %4\n\tv_accvgpr_write_b32 a45, %5\n\tv_accvgpr_write_b32 a46, %6\n\tv_accvgpr_write_b32 a47, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47"); break;
+        case 6: asm volatile("v_accvgpr_write_b32 a48, %0\n\tv_accvgpr_write_b32 a49, %1\n\tv_accvgpr_write_b32 a50, %2\n\tv_accvgpr_write_b32 a51, %3\n\tv_accvgpr_write_b32 a52, %4\n\tv_accvgpr_write_b32 a53, %5\n\tv_accvgpr_write_b32 a54, %6\n\tv_accvgpr_write_b32 a55, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55"); break;
+        case 7: asm volatile("v_accvgpr_write_b32 a56, %0\n\tv_accvgpr_write_b32 a57, %1\n\tv_accvgpr_write_b32 a58, %2\n\tv_accvgpr_write_b32 a59, %3\n\tv_accvgpr_write_b32 a60, %4\n\tv_accvgpr_write_b32 a61, %5\n\tv_accvgpr_write_b32 a62, %6\n\tv_accvgpr_write_b32 a63, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"); break;
+        case 8: asm volatile("v_accvgpr_write_b32 a64, %0\n\tv_accvgpr_write_b32 a65, %1\n\tv_accvgpr_write_b32 a66, %2\n\tv_accvgpr_write_b32 a67, %3\n\tv_accvgpr_write_b32 a68, %4\n\tv_accvgpr_write_b32 a69, %5\n\tv_accvgpr_write_b32 a70, %6\n\tv_accvgpr_write_b32 a71, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71"); break;
+        case 9: asm volatile("v_accvgpr_write_b32 a72, %0\n\tv_accvgpr_write_b32 a73, %1\n\tv_accvgpr_write_b32 a74, %2\n\tv_accvgpr_write_b32 a75, %3\n\tv_accvgpr_write_b32 a76, %4\n\tv_accvgpr_write_b32 a77, %5\n\tv_accvgpr_write_b32 a78, %6\n\tv_accvgpr_write_b32 a79, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79"); break;
+        case 10: asm volatile("v_accvgpr_write_b32 a80, %0\n\tv_accvgpr_write_b32 a81, %1\n\tv_accvgpr_write_b32 a82, %2\n\tv_accvgpr_write_b32 a83, %3\n\tv_accvgpr_write_b32 a84, %4\n\tv_accvgpr_write_b32 a85, %5\n\tv_accvgpr_write_b32 a86, %6\n\tv_accvgpr_write_b32 a87, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87"); break;
+        case 11: asm volatile("v_accvgpr_write_b32 a88, %0\n\tv_accvgpr_write_b32 a89, %1\n\tv_accvgpr_write_b32 a90, %2\n\tv_accvgpr_write_b32 a91, %3\n\tv_accvgpr_write_b32 a92, %4\n\tv_accvgpr_write_b32 a93, %5\n\tv_accvgpr_write_b32 a94, %6\n\tv_accvgpr_write_b32 a95, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"); break;
+        case 12: asm volatile("v_accvgpr_write_b32 a96, %0\n\tv_accvgpr_write_b32 a97, %1\n\tv_accvgpr_write_b32 a98, %2\n\tv_accvgpr_write_b32 a99, %3\n\tv_accvgpr_write_b32 a100, %4\n\tv_accvgpr_write_b32 a101, %5\n\tv_accvgpr_write_b32 a102, %6\n\tv_accvgpr_write_b32 a103, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103"); break;
+        case 13: asm volatile("v_accvgpr_write_b32 a104, %0\n\tv_accvgpr_write_b32 a105, %1\n\tv_accvgpr_write_b32 a106, %2\n\tv_accvgpr_write_b32 a107, %3\n\tv_accvgpr_write_b32 a108, %4\n\tv_accvgpr_write_b32 a109, %5\n\tv_accvgpr_write_b32 a110, %6\n\tv_accvgpr_write_b32 a111, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111"); break;
+        case 14: asm volatile("v_accvgpr_write_b32 a112, %0\n\tv_accvgpr_write_b32 a113, %1\n\tv_accvgpr_write_b32 a114, %2\n\tv_accvgpr_write_b32 a115, %3\n\tv_accvgpr_write_b32 a116, %4\n\tv_accvgpr_write_b32 a117, %5\n\tv_accvgpr_write_b32 a118, %6\n\tv_accvgpr_write_b32 a119, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119"); break;
+        default: asm volatile("v_accvgpr_write_b32 a120, %0\n\tv_accvgpr_write_b32 a121, %1\n\tv_accvgpr_write_b32 a122, %2\n\tv_accvgpr_write_b32 a123, %3\n\tv_accvgpr_write_b32 a124, %4\n\tv_accvgpr_write_b32 a125, %5\n\tv_accvgpr_write_b32 a126, %6\n\tv_accvgpr_write_b32 a127, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"); break;
+    }
+}
+
 constexpr int kRRSlots = kRRSlotsMax;      // accumulator tiles per wave (8 VGPRs each); 8 waves so that they fit beside the 6x6 factorisation
 
 __host__ __device__ inline size_t rr_work_bytes(const PlanDev &pd) {
@@ -1811,21 +1913,10 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
         if (tid < 2) flags[tid] = 0;
         if (tid < 8) work[tid] = (T)0;
         // ---- the system into the accumulators: this wave's tiles, entry by entry from S (caller order, lower triangle)
-        double4_t acc[kRRSlots];
-        // One case per accumulator slot: the slot index must be a compile-time constant for the tile to stay in
-        // registers, the lists of touched slots are data.
-#define BT_SLOT_SWITCH(slot, BODY)                                                                                  \
-        switch (slot) {                                                                                             \
-            case 0: BODY(0) break;   case 1: BODY(1) break;   case 2: BODY(2) break;   case 3: BODY(3) break;       \
-            case 4: BODY(4) break;   case 5: BODY(5) break;   case 6: BODY(6) break;   case 7: BODY(7) break;       \
-            case 8: BODY(8) break;   case 9: BODY(9) break;   case 10: BODY(10) break; case 11: BODY(11) break;     \
-            case 12: BODY(12) break; case 13: BODY(13) break; case 14: BODY(14) break; default: BODY(15) break;     \
-        }
-        static_assert(kRRSlots == 16, "BT_SLOT_SWITCH lists 16 slots");
         {
             const int *it = pd.rr_init + (size_t)wave * S * 256 + lane;
 #pragma unroll 1
-            for (int g = 0; g < S; g += 4) {                  // four tiles at a time: 16 index loads, then 16 loads of S
+            for (int g = 0; g < kRRSlots; g += 4) {               // four tiles at a time: 16 index loads, then 16 loads of S
                 int idx[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) idx[u] = g + (u >> 2) < S ? it[((g + (u >> 2)) * 4 + (u & 3)) * 64] : -1;
@@ -1835,11 +1926,11 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
                     if (idx[u] >= 0 && (idx[u] & (1 << 30))) x[u] = x[u] + ((double)a.ep + lm * x[u]);          // ba.py:67
-#define BT_SET4(b)                                                                                                  \
-                acc[b] = double4_t{x[0], x[1], x[2], x[3]};         acc[b + 1] = double4_t{x[4], x[5], x[6], x[7]};  \
-                acc[b + 2] = double4_t{x[8], x[9], x[10], x[11]};   acc[b + 3] = double4_t{x[12], x[13], x[14], x[15]};
-                switch (g) { case 0: BT_SET4(0) break; case 4: BT_SET4(4) break; case 8: BT_SET4(8) break; default: BT_SET4(12) break; }
-#undef BT_SET4
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                    rr_write(g + q, v);
+                }
             }
         }
         for (int i = tid; i < D; i += nth) z[i] = (T)a.y[6 * pd.perm[i / 6] + i % 6];
@@ -1866,12 +1957,13 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
                 unsigned o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = maps[mp + (lane >> 4) + 4 * r];
-                const bool col_ok = cc >= 0 && cc < 6;
-#define BT_EXT(k)                                                                                                   \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                       \
-                    if (o[r] != 0xffffu && col_ok) Lw[(o[r] & 0x7fffu) + cc] = acc[k][r];
-                BT_SLOT_SWITCH(d & 15, BT_EXT)
-#undef BT_EXT
+                double v[4];
+                rr_read(d & 15, v);
+                if (cc >= 0 && cc < 6) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (o[r] != 0xffffu) Lw[(o[r] & 0x7fffu) + cc] = v[r];
+                }
             }
         };
         int ve = load_desc(pd.rr_edesc, 0), vu = -1;
@@ -1947,16 +2039,8 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
                     }
                     BT_SUB(4);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (d[u] >= 0) {
-                            const T x0 = a0[u], x1 = a1[u], y0 = b0[u], y1 = b1[u];
-#define BT_UPD(k)                                                                                                   \
-                            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, acc[k], 0, 0, 0);                 \
-                            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, acc[k], 0, 0, 0);
-                            BT_SLOT_SWITCH(d[u] & 15, BT_UPD)
-#undef BT_UPD
-                        }
-                    }
+                    for (int u = 0; u < 4; ++u)
+                        if (d[u] >= 0) rr_mfma(d[u] & 15, a0[u], b0[u], a1[u], b1[u]);
                 }
             }
             BT_SUB(5);
@@ -2014,7 +2098,6 @@ __global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs
         for (int i = 0; i < 6; ++i) g[3 + i] = sub[i];
     }
 #undef BT_SUB
-#undef BT_SLOT_SWITCH
 }
 
 // ------------------------------------------------------------------ k_update
