@@ -1761,345 +1761,6 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
 #undef BT_SUB
 }
 
-// ------------------------------------------------------------------ k_solve_rr
-// Register-resident variant of the LDS solver: the part of the reduced system that is not factored
-// yet lives in the MFMA accumulators of the 8 waves, as 16x16 tiles of the permuted matrix (lower
-// triangle; ownership, tables: ba_plan.cpp "rr_"); LDS holds only the factored columns.  Per level:
-//   extract   the owners of the tiles holding a column's diagonal block and panel store those entries
-//             into the block storage (they have received every update by then: same registers)
-//   factor    one wave per 64 panel rows of a column: factor the diagonal block redundantly in
-//             registers, forward-substitute the own row (or y_j); nothing is pending
-//   update    tile (I, J) -= P_I P_J^T, P = rows of the column's panel from LDS: two
-//             v_mfma_f64_16x16x4 per touched tile (K = 6), and the column's contributions to y
-// Against k_solve_fused this removes the read-modify-write of every updated block through LDS (the
-// bulk of its LDS traffic) and the update work of the row waves ahead of the factorisation.
-// The accumulator tiles live in AGPRs a[8 k .. 8 k + 7] (slot k), addressed by name from inline assembly: which
-// slot a level touches is data, and a C++ array of accumulators indexed through a switch makes the compiler
-// shuttle every tile through temporaries (measured: >1000 register copies per level).  The clobber lists make
-// the register allocator reserve the AGPRs; nothing else in the kernel uses them.  Wait states around the f64
-// MFMA and the AGPR moves are written out (the compiler does not see these instructions).
-__device__ __forceinline__ void rr_mfma(int slot, double x0, double y0, double x1, double y1) {
-    switch (slot) {
-        case 0: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[0:7], %0, %1, a[0:7]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[0:7], %2, %3, a[0:7]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7"); break;
-        case 1: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[8:15], %0, %1, a[8:15]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[8:15], %2, %3, a[8:15]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"); break;
-        case 2: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[16:23], %0, %1, a[16:23]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[16:23], %2, %3, a[16:23]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23"); break;
-        case 3: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[24:31], %0, %1, a[24:31]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[24:31], %2, %3, a[24:31]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"); break;
-        case 4: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[32:39], %0, %1, a[32:39]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[32:39], %2, %3, a[32:39]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39"); break;
-        case 5: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[40:47], %0, %1, a[40:47]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[40:47], %2, %3, a[40:47]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47"); break;
-        case 6: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[48:55], %0, %1, a[48:55]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[48:55], %2, %3, a[48:55]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55"); break;
-        case 7: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[56:63], %0, %1, a[56:63]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[56:63], %2, %3, a[56:63]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"); break;
-        case 8: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[64:71], %0, %1, a[64:71]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[64:71], %2, %3, a[64:71]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71"); break;
-        case 9: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[72:79], %0, %1, a[72:79]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[72:79], %2, %3, a[72:79]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79"); break;
-        case 10: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[80:87], %0, %1, a[80:87]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[80:87], %2, %3, a[80:87]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87"); break;
-        case 11: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[88:95], %0, %1, a[88:95]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[88:95], %2, %3, a[88:95]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"); break;
-        case 12: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[96:103], %0, %1, a[96:103]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[96:103], %2, %3, a[96:103]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103"); break;
-        case 13: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[104:111], %0, %1, a[104:111]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[104:111], %2, %3, a[104:111]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111"); break;
-        case 14: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[112:119], %0, %1, a[112:119]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[112:119], %2, %3, a[112:119]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119"); break;
-        default: asm volatile("s_nop 4\n\tv_mfma_f64_16x16x4_f64 a[120:127], %0, %1, a[120:127]\n\ts_nop 4\n\t"
-                          "v_mfma_f64_16x16x4_f64 a[120:127], %2, %3, a[120:127]\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-                          : : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"); break;
-    }
-}
-__device__ __forceinline__ void rr_read(int slot, double (&v)[4]) {          // tile of a slot -> four doubles per lane
-    int w[8];
-    switch (slot) {
-        case 0: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 1: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\tv_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11\n\tv_accvgpr_read_b32 %4, a12\n\tv_accvgpr_read_b32 %5, a13\n\tv_accvgpr_read_b32 %6, a14\n\tv_accvgpr_read_b32 %7, a15\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 2: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\tv_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 3: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a24\n\tv_accvgpr_read_b32 %1, a25\n\tv_accvgpr_read_b32 %2, a26\n\tv_accvgpr_read_b32 %3, a27\n\tv_accvgpr_read_b32 %4, a28\n\tv_accvgpr_read_b32 %5, a29\n\tv_accvgpr_read_b32 %6, a30\n\tv_accvgpr_read_b32 %7, a31\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 4: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\tv_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 5: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a40\n\tv_accvgpr_read_b32 %1, a41\n\tv_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a43\n\tv_accvgpr_read_b32 %4, a44\n\tv_accvgpr_read_b32 %5, a45\n\tv_accvgpr_read_b32 %6, a46\n\tv_accvgpr_read_b32 %7, a47\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 6: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a52\n\tv_accvgpr_read_b32 %5, a53\n\tv_accvgpr_read_b32 %6, a54\n\tv_accvgpr_read_b32 %7, a55\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 7: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a56\n\tv_accvgpr_read_b32 %1, a57\n\tv_accvgpr_read_b32 %2, a58\n\tv_accvgpr_read_b32 %3, a59\n\tv_accvgpr_read_b32 %4, a60\n\tv_accvgpr_read_b32 %5, a61\n\tv_accvgpr_read_b32 %6, a62\n\tv_accvgpr_read_b32 %7, a63\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 8: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a69\n\tv_accvgpr_read_b32 %6, a70\n\tv_accvgpr_read_b32 %7, a71\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 9: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73\n\tv_accvgpr_read_b32 %2, a74\n\tv_accvgpr_read_b32 %3, a75\n\tv_accvgpr_read_b32 %4, a76\n\tv_accvgpr_read_b32 %5, a77\n\tv_accvgpr_read_b32 %6, a78\n\tv_accvgpr_read_b32 %7, a79\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 10: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83\n\tv_accvgpr_read_b32 %4, a84\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a86\n\tv_accvgpr_read_b32 %7, a87\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 11: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a88\n\tv_accvgpr_read_b32 %1, a89\n\tv_accvgpr_read_b32 %2, a90\n\tv_accvgpr_read_b32 %3, a91\n\tv_accvgpr_read_b32 %4, a92\n\tv_accvgpr_read_b32 %5, a93\n\tv_accvgpr_read_b32 %6, a94\n\tv_accvgpr_read_b32 %7, a95\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 12: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99\n\tv_accvgpr_read_b32 %4, a100\n\tv_accvgpr_read_b32 %5, a101\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a103\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 13: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a104\n\tv_accvgpr_read_b32 %1, a105\n\tv_accvgpr_read_b32 %2, a106\n\tv_accvgpr_read_b32 %3, a107\n\tv_accvgpr_read_b32 %4, a108\n\tv_accvgpr_read_b32 %5, a109\n\tv_accvgpr_read_b32 %6, a110\n\tv_accvgpr_read_b32 %7, a111\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        case 14: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115\n\tv_accvgpr_read_b32 %4, a116\n\tv_accvgpr_read_b32 %5, a117\n\tv_accvgpr_read_b32 %6, a118\n\tv_accvgpr_read_b32 %7, a119\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-        default: asm volatile("s_nop 7\n\tv_accvgpr_read_b32 %0, a120\n\tv_accvgpr_read_b32 %1, a121\n\tv_accvgpr_read_b32 %2, a122\n\tv_accvgpr_read_b32 %3, a123\n\tv_accvgpr_read_b32 %4, a124\n\tv_accvgpr_read_b32 %5, a125\n\tv_accvgpr_read_b32 %6, a126\n\tv_accvgpr_read_b32 %7, a127\n\ts_nop 1" : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]), "=v"(w[4]), "=v"(w[5]), "=v"(w[6]), "=v"(w[7])); break;
-    }
-    for (int r = 0; r < 4; ++r) v[r] = __hiloint2double(w[2 * r + 1], w[2 * r]);
-}
-__device__ __forceinline__ void rr_write(int slot, const double (&v)[4]) {   // four doubles per lane -> tile of a slot
-    int w[8];
-    for (int r = 0; r < 4; ++r) { w[2 * r] = __double2loint(v[r]); w[2 * r + 1] = __double2hiint(v[r]); }
-    switch (slot) {
-        case 0: asm volatile("v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %2\n\tv_accvgpr_write_b32 a3, %3\n\tv_accvgpr_write_b32 a4, %4\n\tv_accvgpr_write_b32 a5, %5\n\tv_accvgpr_write_b32 a6, %6\n\tv_accvgpr_write_b32 a7, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7"); break;
-        case 1: asm volatile("v_accvgpr_write_b32 a8, %0\n\tv_accvgpr_write_b32 a9, %1\n\tv_accvgpr_write_b32 a10, %2\n\tv_accvgpr_write_b32 a11, %3\n\tv_accvgpr_write_b32 a12, %4\n\tv_accvgpr_write_b32 a13, %5\n\tv_accvgpr_write_b32 a14, %6\n\tv_accvgpr_write_b32 a15, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"); break;
-        case 2: asm volatile("v_accvgpr_write_b32 a16, %0\n\tv_accvgpr_write_b32 a17, %1\n\tv_accvgpr_write_b32 a18, %2\n\tv_accvgpr_write_b32 a19, %3\n\tv_accvgpr_write_b32 a20, %4\n\tv_accvgpr_write_b32 a21, %5\n\tv_accvgpr_write_b32 a22, %6\n\tv_accvgpr_write_b32 a23, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23"); break;
-        case 3: asm volatile("v_accvgpr_write_b32 a24, %0\n\tv_accvgpr_write_b32 a25, %1\n\tv_accvgpr_write_b32 a26, %2\n\tv_accvgpr_write_b32 a27, %3\n\tv_accvgpr_write_b32 a28, %4\n\tv_accvgpr_write_b32 a29, %5\n\tv_accvgpr_write_b32 a30, %6\n\tv_accvgpr_write_b32 a31, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"); break;
-        case 4: asm volatile("v_accvgpr_write_b32 a32, %0\n\tv_accvgpr_write_b32 a33, %1\n\tv_accvgpr_write_b32 a34, %2\n\tv_accvgpr_write_b32 a35, %3\n\tv_accvgpr_write_b32 a36, %4\n\tv_accvgpr_write_b32 a37, %5\n\tv_accvgpr_write_b32 a38, %6\n\tv_accvgpr_write_b32 a39, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39"); break;
-        case 5: asm volatile("v_accvgpr_write_b32 a40, %0\n\tv_accvgpr_write_b32 a41, %1\n\tv_accvgpr_write_b32 a42, %2\n\tv_accvgpr_write_b32 a43, %3\n\tv_accvgpr_write_b32 a44, %4\n\tv_accvgpr_write_b32 a45, %5\n\tv_accvgpr_write_b32 a46, %6\n\tv_accvgpr_write_b32 a47, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47"); break;
-        case 6: asm volatile("v_accvgpr_write_b32 a48, %0\n\tv_accvgpr_write_b32 a49, %1\n\tv_accvgpr_write_b32 a50, %2\n\tv_accvgpr_write_b32 a51, %3\n\tv_accvgpr_write_b32 a52, %4\n\tv_accvgpr_write_b32 a53, %5\n\tv_accvgpr_write_b32 a54, %6\n\tv_accvgpr_write_b32 a55, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55"); break;
-        case 7: asm volatile("v_accvgpr_write_b32 a56, %0\n\tv_accvgpr_write_b32 a57, %1\n\tv_accvgpr_write_b32 a58, %2\n\tv_accvgpr_write_b32 a59, %3\n\tv_accvgpr_write_b32 a60, %4\n\tv_accvgpr_write_b32 a61, %5\n\tv_accvgpr_write_b32 a62, %6\n\tv_accvgpr_write_b32 a63, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"); break;
-        case 8: asm volatile("v_accvgpr_write_b32 a64, %0\n\tv_accvgpr_write_b32 a65, %1\n\tv_accvgpr_write_b32 a66, %2\n\tv_accvgpr_write_b32 a67, %3\n\tv_accvgpr_write_b32 a68, %4\n\tv_accvgpr_write_b32 a69, %5\n\tv_accvgpr_write_b32 a70, %6\n\tv_accvgpr_write_b32 a71, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71"); break;
-        case 9: asm volatile("v_accvgpr_write_b32 a72, %0\n\tv_accvgpr_write_b32 a73, %1\n\tv_accvgpr_write_b32 a74, %2\n\tv_accvgpr_write_b32 a75, %3\n\tv_accvgpr_write_b32 a76, %4\n\tv_accvgpr_write_b32 a77, %5\n\tv_accvgpr_write_b32 a78, %6\n\tv_accvgpr_write_b32 a79, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79"); break;
-        case 10: asm volatile("v_accvgpr_write_b32 a80, %0\n\tv_accvgpr_write_b32 a81, %1\n\tv_accvgpr_write_b32 a82, %2\n\tv_accvgpr_write_b32 a83, %3\n\tv_accvgpr_write_b32 a84, %4\n\tv_accvgpr_write_b32 a85, %5\n\tv_accvgpr_write_b32 a86, %6\n\tv_accvgpr_write_b32 a87, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87"); break;
-        case 11: asm volatile("v_accvgpr_write_b32 a88, %0\n\tv_accvgpr_write_b32 a89, %1\n\tv_accvgpr_write_b32 a90, %2\n\tv_accvgpr_write_b32 a91, %3\n\tv_accvgpr_write_b32 a92, %4\n\tv_accvgpr_write_b32 a93, %5\n\tv_accvgpr_write_b32 a94, %6\n\tv_accvgpr_write_b32 a95, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"); break;
-        case 12: asm volatile("v_accvgpr_write_b32 a96, %0\n\tv_accvgpr_write_b32 a97, %1\n\tv_accvgpr_write_b32 a98, %2\n\tv_accvgpr_write_b32 a99, %3\n\tv_accvgpr_write_b32 a100, %4\n\tv_accvgpr_write_b32 a101, %5\n\tv_accvgpr_write_b32 a102, %6\n\tv_accvgpr_write_b32 a103, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103"); break;
-        case 13: asm volatile("v_accvgpr_write_b32 a104, %0\n\tv_accvgpr_write_b32 a105, %1\n\tv_accvgpr_write_b32 a106, %2\n\tv_accvgpr_write_b32 a107, %3\n\tv_accvgpr_write_b32 a108, %4\n\tv_accvgpr_write_b32 a109, %5\n\tv_accvgpr_write_b32 a110, %6\n\tv_accvgpr_write_b32 a111, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111"); break;
-        case 14: asm volatile("v_accvgpr_write_b32 a112, %0\n\tv_accvgpr_write_b32 a113, %1\n\tv_accvgpr_write_b32 a114, %2\n\tv_accvgpr_write_b32 a115, %3\n\tv_accvgpr_write_b32 a116, %4\n\tv_accvgpr_write_b32 a117, %5\n\tv_accvgpr_write_b32 a118, %6\n\tv_accvgpr_write_b32 a119, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119"); break;
-        default: asm volatile("v_accvgpr_write_b32 a120, %0\n\tv_accvgpr_write_b32 a121, %1\n\tv_accvgpr_write_b32 a122, %2\n\tv_accvgpr_write_b32 a123, %3\n\tv_accvgpr_write_b32 a124, %4\n\tv_accvgpr_write_b32 a125, %5\n\tv_accvgpr_write_b32 a126, %6\n\tv_accvgpr_write_b32 a127, %7\n\ts_nop 1" : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]) : "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"); break;
-    }
-}
-
-constexpr int kRRSlots = kRRSlotsMax;      // accumulator tiles per wave (8 VGPRs each); 8 waves so that they fit beside the 6x6 factorisation
-
-__host__ __device__ inline size_t rr_work_bytes(const PlanDev &pd) {
-    const size_t zt = (size_t)pd.D * sizeof(double) + (size_t)pd.nlev * kMaxLevelCols * sizeof(int4);   // zt + compact level table (after the sweep)
-    return ((zt > 64 ? zt : 64) + 15) / 16 * 16;                                                         // 8 zeros during the sweep
-}
-size_t solve_rr_lds_bytes(const PlanDev &pd) {
-    return ((size_t)pd.nnzb * 36 + (size_t)pd.D) * sizeof(double) + rr_work_bytes(pd) +
-           (2 * (size_t)pd.nnzb + (size_t)pd.n + 1 + (size_t)pd.nlev * 8) * sizeof(int) +          // row_idx, pfirst, col_ptr, level records
-           (size_t)pd.rr_nmaps * 16 * sizeof(unsigned short) + 64;
-}
-
-template <bool PROF>
-__global__ __launch_bounds__(64 * kRRWaves) void k_solve_rr(PlanDev pd, StepArgs a) {
-    typedef double T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int flags[2];
-    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
-    const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev, S = pd.rr_nslots;
-    T *Lw = reinterpret_cast<T *>(smem);
-    T *z = Lw + (size_t)nnzb * 36, *work = z + D, *zt = work;
-    int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(work) + rr_work_bytes(pd)), *pfirst = row_idx + nnzb,
-        *col_ptr = pfirst + nnzb, *lrec = col_ptr + n + 1;
-    unsigned short *maps = reinterpret_cast<unsigned short *>(lrec + (size_t)nlev * 8);
-    const int zero_off = (int)(work - Lw);                                   // 8 doubles of zeros (operand rows outside a panel)
-    for (int i = tid; i < nnzb; i += nth) { row_idx[i] = pd.fz_rowinfo[i]; pfirst[i] = pd.fz_pfirst[i]; }
-    for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
-    for (int i = tid; i < nlev * 8; i += nth) lrec[i] = pd.fz_pmeta[i];
-    for (int i = tid; i < pd.rr_nmaps * 16; i += nth) maps[i] = pd.rr_map[i];
-    long long tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, sub[6] = {0, 0, 0, 0, 0, 0}, tsub = 0;
-#define BT_SUB(i) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tq = clock64(); sub[i] += tq - tsub; tsub = tq; } } while (0)
-
-    int status = BT_SOLVE_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const double lm = attempt == 0 ? 1e-4 : 1e-3;
-        if (tid < 2) flags[tid] = 0;
-        if (tid < 8) work[tid] = (T)0;
-        // ---- the system into the accumulators: this wave's tiles, entry by entry from S (caller order, lower triangle)
-        {
-            const int *it = pd.rr_init + (size_t)wave * S * 256 + lane;
-#pragma unroll 1
-            for (int g = 0; g < kRRSlots; g += 4) {               // four tiles at a time: 16 index loads, then 16 loads of S
-                int idx[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) idx[u] = g + (u >> 2) < S ? it[((g + (u >> 2)) * 4 + (u & 3)) * 64] : -1;
-                double x[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) x[u] = idx[u] >= 0 ? a.S[idx[u] & 0x3fffffff] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (idx[u] >= 0 && (idx[u] & (1 << 30))) x[u] = x[u] + ((double)a.ep + lm * x[u]);          // ba.py:67
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-                    rr_write(g + q, v);
-                }
-            }
-        }
-        for (int i = tid; i < D; i += nth) z[i] = (T)a.y[6 * pd.perm[i / 6] + i % 6];
-        __syncthreads();
-        if (PROF) tload = clock64() - tall;
-
-        // packed level records (ba_plan.cpp: fz_pmeta) of the current level, in SGPRs
-        int c0a = 0, c0b = 0, c1a = 0, c1b = 0;
-        auto take_level = [&](int l) {
-            const int4 m0 = reinterpret_cast<const int4 *>(lrec)[2 * l], m1 = reinterpret_cast<const int4 *>(lrec)[2 * l + 1];
-            c0a = __builtin_amdgcn_readfirstlane(m0.x); c0b = __builtin_amdgcn_readfirstlane(m0.y);
-            c1a = __builtin_amdgcn_readfirstlane(m1.x); c1b = __builtin_amdgcn_readfirstlane(m1.y);
-        };
-        auto load_desc = [&](const int32_t *base, int l) {          // this wave's list of touched slots of level l, one entry per lane
-            return lane < kRRTouches ? base[((size_t)l * nw + wave) * kRRTouches + lane] : -1;
-        };
-        // extraction: tiles -> block storage, for the columns of a level (list in ve: slot | map << 4 | (6 j - 16 J + 16) << 18)
-        auto extract = [&](int ve) {
-#pragma unroll 1
-            for (int t = 0; t < kRRTouches; ++t) {
-                const int d = __builtin_amdgcn_readlane(ve, t);
-                if (d < 0) break;
-                const int mp = ((d >> 4) & 0x3fff) * 16, cc = (lane & 15) - ((d >> 18) - 16);
-                unsigned o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = maps[mp + (lane >> 4) + 4 * r];
-                double v[4];
-                rr_read(d & 15, v);
-                if (cc >= 0 && cc < 6) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (o[r] != 0xffffu) Lw[(o[r] & 0x7fffu) + cc] = v[r];
-                }
-            }
-        };
-        int ve = load_desc(pd.rr_edesc, 0), vu = -1;
-        extract(ve);
-        for (int l = 0; l < nlev; ++l) {
-            take_level(l);
-            vu = load_desc(pd.rr_udesc, l);
-            ve = l + 1 < nlev ? load_desc(pd.rr_edesc, l + 1) : -1;
-            __syncthreads();
-            if (PROF) tsub = clock64();
-            // ---- factor: one wave per 64 panel rows (and y_j) of a column
-            const int cnc = (c0b >> 24) & 3;
-            const int nr0 = (c0b >> 16) & 255, nr1 = cnc > 1 ? (c1b >> 16) & 255 : 0;
-            for (int aw = wave; aw < nr0 + nr1; aw += nw) {
-                const int q = aw >= nr0 ? 1 : 0, part = aw - (q ? nr0 : 0);
-                const int ma = q ? c1a : c0a, dpos = (q ? c1b : c0b) & 0xffff;
-                const int j = ma & 255, cnt = (ma >> 8) & 255;
-                const int rw = part * 64 + lane;
-                const bool valid = rw <= cnt * 6, isy = rw == cnt * 6;
-                const int sb = rw / 6, r = rw - 6 * sb;
-                T *p = isy ? z + 6 * j : Lw + (size_t)(dpos + 1 + sb) * 36 + 6 * r;
-                T in[6], L[21];
-                load_row6(p, in);
-                {
-                    const T *dblk = Lw + (size_t)dpos * 36;
-#pragma unroll
-                    for (int rr = 0; rr < 6; ++rr) {
-                        T row[6];
-                        load_row6(dblk + 6 * rr, row);
-#pragma unroll
-                        for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
-                    }
-                }
-                const bool ok = chol6_packed<T>(L);
-                if (!ok && part == 0 && lane == 0) flags[0] = 1;
-                if (valid) {
-                    T out[6];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        T t = in[c];
-#pragma unroll
-                        for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
-                        out[c] = t * L[BT_LT(c, c)];
-                    }
-                    store_row6(p, out);
-                }
-            }
-            BT_SUB(0);
-            __syncthreads();
-            if (PROF) tsub = clock64();
-            // ---- update: this wave's touched tiles on the matrix cores (list in vu: slot | mapA << 4 | mapB << 18);
-            // row maps and operands of four touches in flight before the first MFMA
-            {
-                const int m16 = lane & 15, k0 = lane >> 4;
-#pragma unroll 1
-                for (int tb = 0; tb < kRRTouches; tb += 4) {
-                    int d[4];
-                    unsigned oa[4], ob[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        d[u] = __builtin_amdgcn_readlane(vu, tb + u);
-                        const int dd = d[u] < 0 ? 0 : d[u];
-                        oa[u] = maps[((dd >> 4) & 0x3fff) * 16 + m16]; ob[u] = maps[((dd >> 18) & 0x3fff) * 16 + m16];
-                    }
-                    if (d[0] < 0) break;
-                    BT_SUB(3);
-                    T a0[4], a1[4], b0[4], b1[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool za = (oa[u] & 0x8000u) != 0, zb = (ob[u] & 0x8000u) != 0;     // diagonal-block rows, rows outside the panel: zero
-                        a0[u] = -Lw[za ? zero_off : (int)oa[u] + k0]; a1[u] = -Lw[(za || k0 >= 2) ? zero_off : (int)oa[u] + 4 + k0];
-                        b0[u] = Lw[zb ? zero_off : (int)ob[u] + k0];  b1[u] = Lw[(zb || k0 >= 2) ? zero_off : (int)ob[u] + 4 + k0];
-                    }
-                    BT_SUB(4);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (d[u] >= 0) rr_mfma(d[u] & 15, a0[u], b0[u], a1[u], b1[u]);
-                }
-            }
-            BT_SUB(5);
-            // ---- the level's contributions to y: y_i -= L_ij y_j, one row of a block per thread, from the last threads down
-            {
-                const int ys0 = ((c0a >> 8) & 255) * 6, ys1 = ys0 + (cnc > 1 ? ((c1a >> 8) & 255) * 6 : 0);
-                for (int item = nth - 1 - tid; item < ys1; item += nth) {
-                    const bool sec = item >= ys0;
-                    const int qq = item - (sec ? ys0 : 0);
-                    const int pj = (sec ? c1a : c0a) & 255, dposp = (sec ? c1b : c0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
-                    const int rcv = row_idx[dposp + 1 + sb];
-                    T lr[6], zr[6];
-                    load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
-                    load_row6(z + 6 * pj, zr);
-                    T sum = lr[0] * zr[0];
-#pragma unroll
-                    for (int k = 1; k < 6; ++k) sum += lr[k] * zr[k];
-                    lds_sub(z + 6 * (rcv & 255) + r, sum, (rcv & (1 << 24)) != 0);
-                }
-            }
-            BT_SUB(1);
-            // ---- extract the next level's columns
-            if (l + 1 < nlev) extract(ve);
-            BT_SUB(2);
-        }
-        __syncthreads();
-        if (PROF) tsweep = clock64() - tall;
-
-        int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
-        for (int i = tid; i < nlev * kMaxLevelCols; i += nth) {          // (col, diag pos, #sub-blocks, barrier before this level)
-            int4 mm = reinterpret_cast<const int4 *>(pd.fz_meta)[2 * i];
-            mm.w = pd.bs_sync[i / kMaxLevelCols];
-            bmeta[i] = mm;
-        }
-        long long tbs[2] = {0, 0};
-        lds_back_substitute<T, true>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth, PROF ? tbs : nullptr);
-        for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
-        __syncthreads();
-        const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
-        __syncthreads();
-        if (failed) {
-            for (int i = tid; i < D; i += nth) zt[i] = (T)0;
-            status = BT_SOLVE_CHOL_FAILED;
-            break;
-        }
-        if (!has_nan) break;
-        status = BT_SOLVE_RETRIED;
-    }
-    __syncthreads();
-    for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
-    if (tid == 0) a.status[0] = status;
-    if (PROF && lane == 0 && wave == 0) {        // measurement only
-        long long *g = reinterpret_cast<long long *>(a.status + 4);
-        g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
-        for (int i = 0; i < 6; ++i) g[3 + i] = sub[i];
-    }
-#undef BT_SUB
-}
-
 // ------------------------------------------------------------------ k_update
 __device__ inline void retract_pose(const float *pin, const float *xi, float *pout) {
     // poses' = Exp(xi) * G  (groups.py:153-156; so3.h:153-190; se3.h:134-142), in double
@@ -2253,12 +1914,6 @@ static bool use_fused_solver(const PlanDev &pd) {
     return on != 0 && pd.fz_ok != 0 && solve_fused_lds_bytes(pd, solver_threads()) <= kLdsBudget;
 }
 
-// register-resident variant; BT_SOLVER_RR=0: the factor stays in LDS throughout (k_solve_fused)
-static bool use_rr_solver(const PlanDev &pd) {
-    static const int on = std::getenv("BT_SOLVER_RR") ? std::atoi(std::getenv("BT_SOLVER_RR")) : 1;   // measurement only
-    return on != 0 && pd.rr_ok != 0 && pd.rr_nslots <= kRRSlots && solve_rr_lds_bytes(pd) <= kLdsBudget;
-}
-
 static int solver_threads() {
     // 12 waves: enough helper threads for one round of update rows on banded systems, and a
     // 170-register budget per thread so that a whole 6x6 operand block can be in flight from LDS
@@ -2288,12 +1943,6 @@ int configure_kernels(const PlanDev &pd) {
             if (hipFuncSetAttribute(fns[2 * mode + v], hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)solve_lds_bytes(pd, mode == 0 ? 8 : 4)) != hipSuccess)
                 return BT_EHIP;
-    if (mode == 0 && use_rr_solver(pd))
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_rr<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_rr_lds_bytes(pd)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_rr<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_rr_lds_bytes(pd)) != hipSuccess)
-            return BT_EHIP;
     if (mode == 0 && use_fused_solver(pd))
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)solve_fused_lds_bytes(pd, solver_threads())) != hipSuccess ||
@@ -2337,9 +1986,7 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int mode = solver_mode(pd);
         const bool prof = (a.dbg & 16) != 0;
         const int nthr = solver_threads();
-        if (mode == 0 && use_rr_solver(pd) && !prof)    BT_LAUNCH(3, k_solve_rr<false>, dim3(1), dim3(64 * kRRWaves), solve_rr_lds_bytes(pd), pd, a);
-        else if (mode == 0 && use_rr_solver(pd))        BT_LAUNCH(3, k_solve_rr<true>, dim3(1), dim3(64 * kRRWaves), solve_rr_lds_bytes(pd), pd, a);
-        else if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH(3, k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
+        if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH(3, k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
         else if (mode == 0 && use_fused_solver(pd))     BT_LAUNCH(3, k_solve_fused<true>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
         else if (mode == 0 && !prof) BT_LAUNCH(3, (k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
         else if (mode == 0)          BT_LAUNCH(3, (k_solve_lds<double, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);

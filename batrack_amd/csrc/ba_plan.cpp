@@ -573,123 +573,6 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     }
 
-    // ---- register-resident schedule (k_solve_rr).  The not-yet-factored part of the reduced system lives in
-    // the MFMA accumulators of the solver's kRRWaves waves as 16x16 tiles of the permuted matrix (lower triangle);
-    // only factored panels go to LDS.  Per level and column j:
-    //   extract  the owners of the tiles holding column j's diagonal block and panel write those entries to
-    //            the block storage in LDS                                   (rr_edesc, rr_map)
-    //   factor   as in the fused schedule, but with nothing pending: all updates are already in the registers
-    //   update   tile (I, J) -= P_I P_J^T with P = rows of column j's panel, two v_mfma_f64_16x16x4 (rr_udesc)
-    // Tables: rr_map[k][16]   LDS offset (in elements) of the 16 rows of a tile row within a column's blocks,
-    //                         bit 15 = row of the diagonal block (extracted, but zero as an update operand), 0xffff = none
-    //         rr_edesc / rr_udesc [level][wave][kRRTouches]  lists of touched accumulator slots (formats below), -1 terminated
-    //         rr_init[wave][slot][reg][lane]               where the tile entry comes from in S (bit 30: diagonal), -1: zero
-    {
-        const int kW = kRRWaves, kSlotsMax = kRRSlotsMax;
-        const int64_t Dd = 6 * n;
-        const int NT = (int)((Dd + 15) / 16);
-        pl->rr_ok = 0; pl->rr_nslots = 0; pl->rr_nmaps = 0;
-        pl->rr_map.clear(); pl->rr_edesc.clear(); pl->rr_udesc.clear(); pl->rr_init.clear();
-        const bool small = (int64_t)pl->row_idx.size() * 36 + 2 * Dd + 64 < 0x7fff && n > 0 && pl->fz_ok;
-        if (small) {
-            std::vector<int32_t> owner((size_t)NT * NT, -1), slot((size_t)NT * NT, -1), tile_of_slot;
-            std::vector<int> nslots(kW, 0);
-            std::vector<std::vector<int32_t>> wave_tiles(kW);
-            std::vector<int32_t> map_of((size_t)n * NT, -1);
-            auto get_map = [&](int32_t j, int32_t I) -> int32_t {
-                int32_t &id = map_of[(size_t)j * NT + I];
-                if (id >= 0) return id;
-                id = (int32_t)(pl->rr_map.size() / 16);
-                const int32_t b0 = pl->col_ptr[(size_t)j], b1 = pl->col_ptr[(size_t)j + 1];
-                for (int m = 0; m < 16; ++m) {
-                    const int64_t row = 16 * (int64_t)I + m;
-                    uint16_t v = 0xffff;
-                    if (row < Dd) {
-                        const int32_t br = (int32_t)(row / 6);
-                        const auto it = std::lower_bound(pl->row_idx.begin() + b0, pl->row_idx.begin() + b1, br);
-                        if (it != pl->row_idx.begin() + b1 && *it == br) {
-                            const int32_t b = (int32_t)(it - pl->row_idx.begin());
-                            v = (uint16_t)((b * 36 + (int32_t)(row % 6) * 6) | (b == b0 ? 0x8000 : 0));
-                        }
-                    }
-                    pl->rr_map.push_back(v);
-                }
-                return id;
-            };
-            struct Touch { int32_t l, q, tile, a, b; };
-            std::vector<Touch> et, ut;
-            bool ok = true;
-            for (int32_t l = 0; l < nlev && ok; ++l) {
-                std::vector<int> lvl_load(kW, 0);
-                for (int32_t qi = pl->lvl_ptr[(size_t)l]; qi < pl->lvl_ptr[(size_t)l + 1]; ++qi) {
-                    const int32_t j = pl->lvl_cols[(size_t)qi], q = qi - pl->lvl_ptr[(size_t)l];
-                    const int32_t b0 = pl->col_ptr[(size_t)j], b1 = pl->col_ptr[(size_t)j + 1];
-                    std::vector<int32_t> Ipan, Iext;
-                    for (int32_t b = b0; b < b1; ++b)
-                        for (int e = 0; e < 6; e += 5) {
-                            const int32_t I = (6 * pl->row_idx[(size_t)b] + e) / 16;
-                            if (b > b0) Ipan.push_back(I);
-                            Iext.push_back(I);
-                        }
-                    auto uniq = [](std::vector<int32_t> &v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
-                    uniq(Ipan); uniq(Iext);
-                    auto own = [&](int32_t I, int32_t J, bool heavy) {
-                        int32_t &o = owner[(size_t)I * NT + J];
-                        if (o < 0) {
-                            int best = 0;
-                            for (int w = 1; w < kW; ++w)
-                                if (lvl_load[w] < lvl_load[best] || (lvl_load[w] == lvl_load[best] && nslots[w] < nslots[best])) best = w;
-                            o = best;
-                            slot[(size_t)I * NT + J] = nslots[best]++;
-                            wave_tiles[(size_t)best].push_back(I * NT + J);
-                        }
-                        if (heavy) lvl_load[(size_t)o]++;
-                    };
-                    const int32_t J0 = (6 * j) / 16, J1 = (6 * j + 5) / 16;
-                    for (int32_t I : Ipan) for (int32_t J : Ipan) if (I >= J) { own(I, J, true); ut.push_back({l, q, I * NT + J, get_map(j, I), get_map(j, J)}); }
-                    for (int32_t I : Iext) for (int32_t J = J0; J <= J1; ++J) if (I >= J) { own(I, J, false); et.push_back({l, q, I * NT + J, get_map(j, I), 6 * j - 16 * J + 16}); }
-                }
-            }
-            int S = 0;
-            for (int w = 0; w < kW; ++w) S = std::max(S, nslots[w]);
-            ok = ok && S <= kSlotsMax && pl->rr_map.size() / 16 < 8192;
-            // per (level, wave) lists of at most kRRTouches entries, -1 terminated:
-            //   update   slot | mapA << 4 | mapB << 18          extract   slot | map << 4 | (6 j - 16 J + 16) << 18
-            std::vector<int> ne((size_t)nlev * kW, 0), nu((size_t)nlev * kW, 0);
-            if (ok) {
-                pl->rr_edesc.assign((size_t)nlev * kW * kRRTouches, -1);
-                pl->rr_udesc.assign((size_t)nlev * kW * kRRTouches, -1);
-                for (const Touch &t : et) {
-                    const size_t lw = (size_t)t.l * kW + owner[(size_t)t.tile];
-                    if (ne[lw] >= kRRTouches) { ok = false; break; }
-                    pl->rr_edesc[lw * kRRTouches + ne[lw]++] = slot[(size_t)t.tile] | (t.a << 4) | (t.b << 18);
-                }
-                for (const Touch &t : ut) {
-                    const size_t lw = (size_t)t.l * kW + owner[(size_t)t.tile];
-                    if (nu[lw] >= kRRTouches) { ok = false; break; }
-                    pl->rr_udesc[lw * kRRTouches + nu[lw]++] = slot[(size_t)t.tile] | (t.a << 4) | (t.b << 18);
-                }
-            }
-            if (!ok) { pl->rr_edesc.clear(); pl->rr_udesc.clear(); }
-            if (ok) {
-                pl->rr_ok = 1; pl->rr_nslots = S; pl->rr_nmaps = (int)(pl->rr_map.size() / 16);
-                pl->rr_init.assign((size_t)kW * S * 256, -1);
-                for (int w = 0; w < kW; ++w)
-                    for (int sl = 0; sl < nslots[w]; ++sl) {
-                        const int32_t tile = wave_tiles[(size_t)w][(size_t)sl], I = tile / NT, J = tile % NT;
-                        for (int r = 0; r < 4; ++r)
-                            for (int lane = 0; lane < 64; ++lane) {
-                                const int64_t row = 16 * (int64_t)I + (lane >> 4) + 4 * r, col = 16 * (int64_t)J + (lane & 15);
-                                if (row >= Dd || col >= Dd) continue;
-                                const int64_t R = 6 * (int64_t)perm[(size_t)(row / 6)] + row % 6, C = 6 * (int64_t)perm[(size_t)(col / 6)] + col % 6;
-                                const int64_t off = R >= C ? R * Dd + C : C * Dd + R;
-                                pl->rr_init[(((size_t)w * S + sl) * 4 + r) * 64 + lane] = (int32_t)(off | (R == C ? (1 << 30) : 0));
-                            }
-                    }
-            }
-        }
-    }
-
     // ---- k_tile's first loads, indexed by the tile alone (no dependent index chain in its prologue):
     //   tile_ij[t][max_tile_pairs]   cameras (i | j << 16) of the tile's pairs, in local pair order
     //   tile_kx[t][64]               patch of every track of the tile (-1: no track in this lane)

@@ -17,9 +17,6 @@ constexpr int kMaxFree = 255;       // free poses supported by the reduced solve
 constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj + 6 gj)
 constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
 constexpr int kLdsRowStride = 66;
-constexpr int kRRWaves = 8;          // waves of the register-resident solver (512 threads: 256 registers each)
-constexpr int kRRSlotsMax = 16;      // accumulator tiles a wave may own (8 registers each)
-constexpr int kRRTouches = 8;        // tiles of one wave a level may extract from / update
 constexpr int kMaxLevelCols = 4;
 constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geometry is kept in LDS    // columns of the reduced system factored concurrently (one critical wave each)   // floats per local E row (bank-conflict-free)
 
@@ -44,10 +41,6 @@ struct PlanDev {
     // fused schedule (k_solve_fused): pending updates per destination block, lazy triples per column
     const int32_t *fz_pend_ptr, *fz_pend, *fz_lazy_ptr, *fz_lazy, *fz_yurg, *fz_meta, *fz_pmeta, *bs_sync, *fz_rowinfo, *fz_pfirst;
     int fz_npend, fz_nlazy, fz_ok;      // fz_ok: no level has more than two columns
-    // register-resident schedule (k_solve_rr)
-    const uint16_t *rr_map;
-    const int32_t *rr_edesc, *rr_udesc, *rr_init;
-    int rr_ok, rr_nslots, rr_nmaps;
     const int32_t *lvl_meta;   // [nlev][kMaxLevelCols][8]: col, diag pos, #sub-blocks, first rest triple, #rest triples, dp first, #dp, 0  (col = -1: unused)
 };
 
@@ -74,9 +67,6 @@ struct bt_plan {
     std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp, lvl_meta;
     std::vector<int32_t> fz_pend_ptr, fz_pend, fz_lazy_ptr, fz_lazy, fz_yurg, fz_meta, fz_pmeta, bs_sync, fz_rowinfo, fz_pfirst;   // fused schedule (k_solve_fused)
     int fz_ok = 0;
-    std::vector<uint16_t> rr_map;                        // register-resident schedule (k_solve_rr)
-    std::vector<int32_t> rr_edesc, rr_udesc, rr_init;
-    int rr_ok = 0, rr_nslots = 0, rr_nmaps = 0;
     int max_rows16 = 16;
     bt::WsLayout ws{};
     void *dev_base = nullptr;   // one device allocation holding every array above

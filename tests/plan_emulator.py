@@ -136,9 +136,6 @@ def run(plan, A, inp, wkey, lmbda=1e-4, ep=10.0, alpha=0.05, structure_only=Fals
         dX = sparse_chol_solve(A, S, y, n, ep, 1e-4)
         dX2 = sparse_chol_solve_fused(A, S, y, n, ep, 1e-4)
         assert np.allclose(dX, dX2, rtol=1e-9, atol=1e-12 * max(1.0, np.abs(dX).max())), "fused schedule differs from the two-phase schedule"
-        if len(A["rr_init"]):
-            dX3 = sparse_chol_solve_rr(A, S, y, n, ep, 1e-4)
-            assert np.allclose(dX, dX3, rtol=1e-9, atol=1e-12 * max(1.0, np.abs(dX).max())), "register-resident schedule differs"
         out["dX"] = dX
     # update
     patches_out = inp["patches"].copy()
@@ -373,112 +370,6 @@ def sparse_chol_solve_fused(A, S_lower, y, n, ep, lm):
                 tq -= L[s].T @ x[6*i:6*i + 6]
             x[6*c:6*c + 6] = Linv[c].T @ tq
             written_at[int(c)] = (q, barriers)
-    out = np.zeros((n, 6))
-    out[perm] = x.reshape(n, 6)
-    return out
-
-
-def sparse_chol_solve_rr(A, S_lower, y, n, ep, lm):
-    """k_solve_rr: the trailing matrix lives in 16x16 accumulator tiles owned by the 12 waves; per level
-    extract (tiles -> block storage), factor / substitute, update (tile -= P_I P_J^T).  Checks that every
-    entry the factorisation reads was extracted exactly once, from a tile that had received all its updates."""
-    col_ptr, row_idx = A["col_ptr"], A["row_idx"]
-    perm, blk_col, yshared = A["perm"], A["blk_col"] & 255, A["blk_col"] >> 16
-    lvl_ptr, lvl_cols, col_lvl = A["lvl_ptr"], A["lvl_cols"], A["col_lvl"]
-    pend_ptr, pend, yurg = A["fz_pend_ptr"], A["fz_pend"].reshape(-1, 2), A["fz_yurg"]
-    nnzb, nlev, D = len(row_idx), len(lvl_ptr) - 1, 6 * n
-    W, K = 8, 8
-    S = len(A["rr_init"]) // (W * 256)
-    assert S > 0 and len(A["rr_edesc"]) == nlev * W * K == len(A["rr_udesc"])
-    edesc, udesc = A["rr_edesc"].reshape(nlev, W, K), A["rr_udesc"].reshape(nlev, W, K)
-    rmap = A["rr_map"].reshape(-1, 16).astype(np.int64)
-    init = A["rr_init"].reshape(W, S, 4, 64)
-    lane = np.arange(64)
-    Sflat = S_lower.reshape(-1)
-    tiles = np.zeros((W, S, 4, 64))
-    ok_init = init >= 0
-    off = init & ((1 << 30) - 1)
-    vals = Sflat[np.where(ok_init, off, 0)]
-    isdiag = ok_init & ((init >> 30) & 1 == 1)
-    vals = np.where(isdiag, vals + ep + lm * vals, vals)
-    tiles[...] = np.where(ok_init, vals, 0.0)
-    mem = np.full(nnzb * 36, np.nan)
-    written = np.zeros(nnzb * 36, int)
-    z = y.reshape(n, 6)[perm].reshape(-1).copy()
-    Linv = np.zeros((n, 6, 6))
-    for l in range(nlev):
-        cols = [int(c) for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]]
-        prev = [int(c) for c in lvl_cols[lvl_ptr[l - 1]:lvl_ptr[l]]] if l > 0 else []
-        assert len(cols) <= 2
-        # extract
-        for w in range(W):
-            for t in range(K):
-                d = int(edesc[l, w, t])
-                if d < 0:
-                    assert np.all(edesc[l, w, t:] < 0)
-                    break
-                sl, m_id, c0 = d & 15, (d >> 4) & 0x3fff, (d >> 18) - 16
-                for r in range(4):
-                    offs = rmap[m_id][(lane >> 4) + 4 * r]
-                    cc = (lane & 15) - c0
-                    sel = (offs != 0xffff) & (cc >= 0) & (cc < 6)
-                    dst = (offs[sel] & 0x7fff) + cc[sel]
-                    blk = dst // 36
-                    assert np.all(np.isin(blk_col[blk], cols))
-                    mem[dst] = tiles[w, sl, r][sel]
-                    written[dst] += 1
-        for c in cols:
-            d = int(col_ptr[c])
-            low = np.tril(np.ones((6, 6), bool)).reshape(-1)
-            assert np.all(written[36*d:36*d + 36][low] == 1), "diagonal block not (or twice) extracted"
-            assert np.all(written[36*(d + 1):36*int(col_ptr[c + 1])] == 1), "panel not (or twice) extracted"
-        # factor / substitute (y as in the fused schedule)
-        for c in cols:
-            d = int(col_ptr[c])
-            for s1, s2 in pend[pend_ptr[d]:pend_ptr[d + 1]]:
-                z[6*c:6*c + 6] -= mem[36*s1:36*s1 + 36].reshape(6, 6) @ z[6*int(blk_col[s1]):6*int(blk_col[s1]) + 6]
-            blk = mem[36*d:36*d + 36].reshape(6, 6)
-            Lj = np.linalg.cholesky(np.tril(blk) + np.tril(blk, -1).T)
-            Linv[c] = np.linalg.inv(Lj)
-            z[6*c:6*c + 6] = Linv[c] @ z[6*c:6*c + 6]
-            for b in range(d + 1, int(col_ptr[c + 1])):
-                mem[36*b:36*b + 36] = (mem[36*b:36*b + 36].reshape(6, 6) @ Linv[c].T).reshape(-1)
-        for p in prev:
-            for b in range(col_ptr[p] + 1, col_ptr[p + 1]):
-                if yurg[b]:
-                    continue
-                i = int(row_idx[b])
-                z[6*i:6*i + 6] -= mem[36*b:36*b + 36].reshape(6, 6) @ z[6*p:6*p + 6]
-        # update
-        for w in range(W):
-            for t in range(K):
-                d = int(udesc[l, w, t])
-                if d < 0:
-                    assert np.all(udesc[l, w, t:] < 0)
-                    break
-                sl = d & 15
-                ops = []
-                for m_id in ((d >> 4) & 0x3fff, (d >> 18) & 0x3fff):
-                    offs = rmap[m_id]
-                    P = np.zeros((16, 6))
-                    for m in range(16):
-                        if offs[m] != 0xffff and not (offs[m] & 0x8000):
-                            P[m] = mem[offs[m]:offs[m] + 6]
-                            assert blk_col[offs[m] // 36] in cols
-                    ops.append(P)
-                prod = ops[0] @ ops[1].T
-                for r in range(4):
-                    tiles[w, sl, r] -= prod[(lane >> 4) + 4 * r, lane & 15]
-    L = mem.reshape(nnzb, 6, 6)
-    x = z.copy()
-    bs_sync = A["bs_sync"]
-    for l in range(nlev - 1, -1, -1):
-        for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]:
-            tq = x[6*c:6*c + 6].copy()
-            for s in range(col_ptr[c] + 1, col_ptr[c + 1]):
-                i = int(row_idx[s])
-                tq -= L[s].T @ x[6*i:6*i + 6]
-            x[6*c:6*c + 6] = Linv[c].T @ tq
     out = np.zeros((n, 6))
     out[perm] = x.reshape(n, 6)
     return out

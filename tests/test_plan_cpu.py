@@ -107,7 +107,7 @@ def test_plan_c3_shape():
 def test_c3_solver_schedules_solve_the_system():
     """Both level schedules (two-phase and fused) of the 63-pose plan, run by the emulator on a
     random SPD system with the plan's sparsity pattern, reproduce the dense solve."""
-    from plan_emulator import sparse_chol_solve, sparse_chol_solve_fused, sparse_chol_solve_rr
+    from plan_emulator import sparse_chol_solve, sparse_chol_solve_fused
     g = graphgen.make_config("C3", seed=0)
     pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
     A = pl.arrays()
@@ -135,8 +135,7 @@ def test_c3_solver_schedules_solve_the_system():
     Sd = S.copy()
     Sd[np.diag_indices(6 * n)] += 10.0 + 1e-4 * np.diag(S)
     want = np.linalg.solve(Sd, y).reshape(n, 6)
-    assert len(A["rr_init"]) > 0
-    for fn in (sparse_chol_solve, sparse_chol_solve_fused, sparse_chol_solve_rr):
+    for fn in (sparse_chol_solve, sparse_chol_solve_fused):
         got = fn(A, np.tril(S), y, n, 10.0, 1e-4)
         assert rel(got, want) < 1e-10
 

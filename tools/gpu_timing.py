@@ -55,10 +55,7 @@ if int(os.environ.get("BT_DEBUG_MODE", "0")) & 16:
     names = ["load", "updates", "chol", "trsm", "store", "barrier", "Mprep", "backsub", "tail", "-"]
     ph = np.frombuffer(raw[stat_off + 16 + 320: stat_off + 16 + 320 + 16 * 12].tobytes(), dtype=np.int64).reshape(12, 2)
     print("  solver per-wave busy cycles (phase1, phase2): " + " ".join(f"w{w}:{a}/{b}" for w, (a, b) in enumerate(ph)))
-    if os.environ.get("BT_SOLVER_RR", "1") != "0":
-        g = pf.reshape(-1)
-        print(f"  rr solver wave0: load={g[0]} sweep_end={g[1]} total={g[2]} | factor={g[3]} y+rest={g[4]} extract={g[5]} | update: maps={g[6]} operands={g[7]} mfma={g[8]}")
-    elif os.environ.get("BT_SOLVER_FUSED", "1") != "0":
+    if os.environ.get("BT_SOLVER_FUSED", "1") != "0":
         g = pf.reshape(-1)
         print(f"  fused solver: load={g[0]} sweep_end={g[1]} total={g[2]} | tail: Linv_end={g[3]} Mform_end={g[4]} backsub_end={g[5]} | row wave: row_update={g[16]} wait+loadL={g[17]} trsm+store={g[18]}")
     for w in range(2):
