@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Where the time of a plan build goes: host analysis vs device upload (C3, repeated)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from batrack_amd import graphgen
+from batrack_amd.plan import Plan
+
+g = graphgen.make_config("C3", seed=0)
+n_buf, p_tot = g.poses.shape[0], g.patches.shape[0]
+dev = "cuda:0"
+ii, jj, kk = (torch.as_tensor(a, device=dev) for a in (g.ii, g.jj, g.kk))
+for name, args, kw in (("host arrays, no upload", (g.ii, g.jj, g.kk), dict(upload=False)),
+                       ("host arrays, upload", (g.ii, g.jj, g.kk), dict(upload=True)),
+                       ("device tensors, upload", (ii, jj, kk), dict(upload=True))):
+    ts = []
+    for _ in range(8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pl = Plan(*args, n_buf, p_tot, 1, **kw)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+        pl.close()
+    print(f"{name:26s}: first {ts[0]:.2f} ms, then median {np.median(ts[1:]):.2f} ms")
