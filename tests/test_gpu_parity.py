@@ -236,3 +236,21 @@ def test_random_covisibility_graphs_vs_oracle(seed, N, M, fixedp, far, groups):
     assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 2e-3
     assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL
     assert rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
+
+
+def test_largest_supported_system_vs_oracle():
+    """255 free poses (the ABI's limit): a 256-frame banded graph; the reduced system (1530 x 1530) is far too
+    large for LDS as double, so this also exercises the solver variant picked for big systems."""
+    g = graphgen.make_graph(256, 8, 4, seed=11)
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics),
+             targets3=f(g.targets3), weights=f(g.weights), weights_pose=f(g.weights_pose),
+             ii=g.ii, jj=g.jj, kk=g.kk, bounds=np.asarray(g.bounds))
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"],
+                         d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, want_system=True)
+    o = HipProblem(d).raw_step("weights_pose", 1)
+    assert o["plan"].n == 255 and o["status"] == 0
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
+    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 2e-2          # float32 factor for a system this size
+    assert rel(o["poses_out"], ref["poses_out"]) < 1e-4
+    assert rel(o["patches_out"], ref["patches_out"]) < 1e-4

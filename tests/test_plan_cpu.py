@@ -163,3 +163,35 @@ def test_random_covisibility_graphs(seed, N, M, fixedp, far, groups):
     assert rel(em["y"], o["y"]) < 1e-10
     assert rel(em["dX"], o["dX"]) < 1e-7
     assert rel(em["patches_out"], o["patches_out"]) < 1e-10
+
+
+def _chain_edges(N, K=3):
+    """One track per frame, observed from the K following frames (a banded system with N - fixedp free poses)."""
+    kk = np.repeat(np.arange(N, dtype=np.int64), K)
+    ii = kk.copy()
+    jj = np.clip(ii + np.tile(np.arange(1, K + 1, dtype=np.int64), N), 0, N - 1)
+    return ii, jj, kk
+
+
+def test_plan_limits():
+    """The documented limits (include/batrack_ba.h): 255 free poses, 64 free cameras per track, one source
+    frame per track.  At the limit the plan builds; one past it the call is refused (BT_EUNSUPPORTED), never
+    a silent wrong answer."""
+    ii, jj, kk = _chain_edges(256)
+    pl = Plan(ii, jj, kk, 256, 256, 1, upload=False)
+    assert pl.n == 255
+    ii, jj, kk = _chain_edges(257)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        Plan(ii, jj, kk, 257, 257, 1, upload=False)
+    # one track of frame 0 seen by 64 / 65 free cameras
+    for ncam, ok in ((64, True), (65, False)):
+        N = ncam + 1
+        jj = np.arange(1, N, dtype=np.int64); ii = np.zeros_like(jj); kk = np.zeros_like(jj)
+        if ok:
+            assert Plan(ii, jj, kk, N, 4, 1, upload=False).max_tile_cams == 64
+        else:
+            with pytest.raises(RuntimeError, match="unsupported"):
+                Plan(ii, jj, kk, N, 4, 1, upload=False)
+    # a track whose edges name two source frames (the caller's invariant ii = ix[kk], batrack.py:199)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        Plan(np.array([0, 1], np.int64), np.array([2, 3], np.int64), np.array([5, 5], np.int64), 4, 8, 1, upload=False)
