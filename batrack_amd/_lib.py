@@ -81,7 +81,7 @@ def lib():
     L.bt_plan_workspace_bytes.argtypes = [vp]
     L.bt_plan_array.restype = i64
     L.bt_plan_array.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp)]
-    for name in ("bt_ba_step", "bt_ba_reduce", "bt_ba_solve_update"):
+    for name in ("bt_ba_step", "bt_ba_reduce", "bt_ba_solve_update", "bt_ba_pack", "bt_ba_unpack"):
         f = getattr(L, name)
         f.restype = i32
         f.argtypes = [vp, ctypes.POINTER(BaArgs), vp, vp]
@@ -91,6 +91,8 @@ def lib():
     L.bt_ba_step_timed.argtypes = [vp, ctypes.POINTER(BaArgs), vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.bt_ba_system.restype = vp
     L.bt_ba_system.argtypes = [vp, vp, ctypes.POINTER(i64)]
+    L.bt_ba_packed.restype = vp
+    L.bt_ba_packed.argtypes = [vp, vp, ctypes.POINTER(i64)]
     L.bt_ba_dx.restype = vp
     L.bt_ba_dx.argtypes = [vp, vp]
     L.bt_ba_status.restype = i32

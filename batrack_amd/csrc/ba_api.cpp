@@ -79,7 +79,7 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     const size_t D = (size_t)(6 * pl->info.n);
     s.S = reinterpret_cast<double *>(w + L.sys); s.y = s.S + D * D;
     s.pairacc = reinterpret_cast<double *>(w + L.pairacc);
-    s.ptab = reinterpret_cast<float *>(w + L.ptab); s.qw = reinterpret_cast<float2 *>(w + L.qw);
+    s.packed = reinterpret_cast<double *>(w + L.packed); s.qw = reinterpret_cast<float2 *>(w + L.qw);
     s.esave = reinterpret_cast<float *>(w + L.esave); s.lfac = reinterpret_cast<float *>(w + L.lfac);
     s.linv = reinterpret_cast<float *>(w + L.linv); s.zvec = reinterpret_cast<float *>(w + L.zvec);
     s.dx = reinterpret_cast<float *>(w + L.dx); s.status = reinterpret_cast<int *>(w + L.status);
@@ -214,6 +214,26 @@ int bt_ba_step_timed(const bt_plan *pl, const bt_ba_args *a, void *ws, void *str
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return r;
+}
+
+int bt_ba_pack(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
+    const int rc = check(pl, a, ws);
+    if (rc != BT_OK) return rc;
+    if (is_so(pl, a)) return BT_OK;
+    return launch_pack(pl->dev, make_args(pl, a, ws), false, static_cast<hipStream_t>(stream));
+}
+
+int bt_ba_unpack(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
+    const int rc = check(pl, a, ws);
+    if (rc != BT_OK) return rc;
+    if (is_so(pl, a)) return BT_OK;
+    return launch_pack(pl->dev, make_args(pl, a, ws), true, static_cast<hipStream_t>(stream));
+}
+
+double *bt_ba_packed(const bt_plan *pl, void *ws, int64_t *count) {
+    if (!pl || !ws) return nullptr;
+    if (count) *count = pl->info.nnz_blocks * 36 + 6 * pl->info.n;
+    return reinterpret_cast<double *>(static_cast<char *>(ws) + pl->ws.packed);
 }
 
 double *bt_ba_system(const bt_plan *pl, void *ws, int64_t *count) {

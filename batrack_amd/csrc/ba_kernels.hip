@@ -1888,6 +1888,26 @@ __global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_p
     }
 }
 
+// ------------------------------------------------------------------ k_pack_system
+// Dense [S | y] (caller order, lower triangle) <-> the plan's non-zero blocks in factor order followed by
+// y in factor order: the multi-GPU exchange buffer (include/batrack_ba.h: bt_ba_pack).  One thread per element.
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void k_pack_system(PlanDev pd, StepArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, nb = pd.nnzb * 36;
+    if (i < nb) {
+        const int b = i / 36, e = i - 36 * b, r = e / 6, c = e - 6 * r, src = pd.blk_src[b];
+        const int rn = src >> 9, cn = (src >> 1) & 255;
+        const bool diag = rn == cn;
+        if (diag && c > r) { if (!UNPACK) a.packed[i] = 0.0; return; }       // S holds the lower triangle only
+        double *p = (src & 1) ? a.S + (size_t)(6 * rn + c) * pd.D + 6 * cn + r : a.S + (size_t)(6 * rn + r) * pd.D + 6 * cn + c;
+        if (UNPACK) *p = a.packed[i]; else a.packed[i] = *p;
+    } else if (i < nb + pd.D) {
+        const int k = i - nb;
+        double *p = a.y + 6 * pd.perm[k / 6] + k % 6;
+        if (UNPACK) *p = a.packed[i]; else a.packed[i] = *p;
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 static int tile_threads() {
     // 8 waves per tile; 16 only on request (measurement): it shortens deep slot loops a little but
@@ -1986,6 +2006,14 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
     }
     if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+int launch_pack(const PlanDev &pd, const StepArgs &a, bool unpack, hipStream_t st) {
+    const int total = pd.nnzb * 36 + pd.D;
+    if (total <= 0) return BT_OK;
+    if (unpack) hipLaunchKernelGGL(k_pack_system<true>, dim3((total + 255) / 256), dim3(256), 0, st, pd, a);
+    else        hipLaunchKernelGGL(k_pack_system<false>, dim3((total + 255) / 256), dim3(256), 0, st, pd, a);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 

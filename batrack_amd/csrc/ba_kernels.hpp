@@ -14,7 +14,7 @@ struct StepArgs {
     float b0, b1, b2, b3, lmbda, ep, alpha;
     int loss;
     double *S, *y, *pairacc;      // S, y, pairacc are contiguous (cleared together)
-    float *ptab;
+    double *packed;               // the non-zero blocks of [S | y] in factor order (multi-GPU exchange buffer)
     float2 *qw;
     float *esave, *lfac, *linv, *zvec, *dx;
     int *status;
@@ -24,6 +24,8 @@ struct StepArgs {
 int configure_kernels(const PlanDev &pd);
 // ev != nullptr: a (start, stop) event pair per kernel; *ran gets bit k set for every kernel k that was launched
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
+// dense [S | y] <-> its non-zero blocks in factor order (bt_ba_pack / bt_ba_unpack)
+int launch_pack(const PlanDev &pd, const StepArgs &a, bool unpack, hipStream_t st);
 int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
 
 }  // namespace bt

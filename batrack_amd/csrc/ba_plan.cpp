@@ -32,7 +32,7 @@ static void layout_workspace(bt_plan *pl) {
     w.pairacc = off;  off += (size_t)I.pairs * kPairAccStride * sizeof(double);
     off = align_up(off, 256);
     w.zero_bytes = off - w.sys;
-    w.ptab = off;     off = align_up(off + (size_t)I.pairs * kPairGeomFloats * sizeof(float), 256);
+    w.packed = off;   off = align_up(off + ((size_t)I.nnz_blocks * 36 + D) * sizeof(double), 256);   // exchange form of [S | y]
     w.qw = off;       off = align_up(off + (size_t)I.m * 2 * sizeof(float), 256);
     w.esave = off;    off = align_up(off + (size_t)I.erows * kLanes * sizeof(float), 256);
     w.lfac = off;     off = align_up(off + (size_t)I.nnz_blocks * 36 * sizeof(float), 256);

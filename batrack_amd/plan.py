@@ -103,7 +103,10 @@ class Stepper:
         cnt = ctypes.c_int64()
         sys_ptr = self._lib.bt_ba_system(plan.handle, self.ws.data_ptr(), ctypes.byref(cnt))
         off = sys_ptr - self.ws.data_ptr()
-        self.system = self.ws[off:off + 8 * cnt.value].view(torch.float64)      # [S | y], for all-reduce
+        self.system = self.ws[off:off + 8 * cnt.value].view(torch.float64)      # [S | y], dense
+        pk_ptr = self._lib.bt_ba_packed(plan.handle, self.ws.data_ptr(), ctypes.byref(cnt))
+        off = pk_ptr - self.ws.data_ptr()
+        self.packed = self.ws[off:off + 8 * cnt.value].view(torch.float64)      # its non-zero blocks, for the all-reduce
         D = 6 * plan.n
         dx_off = self._lib.bt_ba_dx(plan.handle, self.ws.data_ptr()) - self.ws.data_ptr()
         self.dx = self.ws[dx_off:dx_off + 4 * D].view(torch.float32).view(plan.n, 6)
@@ -125,8 +128,8 @@ class Stepper:
         import torch
         a = self._fill(*args)
         st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
-        fn = {"all": self._lib.bt_ba_step, "reduce": self._lib.bt_ba_reduce,
-              "solve_update": self._lib.bt_ba_solve_update}[phase]
+        fn = {"all": self._lib.bt_ba_step, "reduce": self._lib.bt_ba_reduce, "pack": self._lib.bt_ba_pack,
+              "unpack": self._lib.bt_ba_unpack, "solve_update": self._lib.bt_ba_solve_update}[phase]
         _lib.check(fn(self.plan.handle, ctypes.byref(a), self.ws.data_ptr(), st), f"bt_ba_{phase}")
 
     def step_timed(self, *args, stream=None):

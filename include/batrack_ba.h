@@ -128,6 +128,17 @@ int bt_ba_solve_update(const bt_plan *plan, const bt_ba_args *args, void *worksp
 /* Device pointer to the reduced system inside `workspace`: (6n)^2 doubles of S
  * (row-major, lower triangle populated) followed by 6n doubles of y. */
 double *bt_ba_system(const bt_plan *plan, void *workspace, int64_t *count);
+
+/* Compact exchange form of the same system: only the blocks of S that can be non-zero (the plan's
+ * sparsity pattern incl. fill, 36 doubles each, in the solver's block order) followed by y - about 8x
+ * fewer bytes than bt_ba_system() on a banded graph (140 KB instead of 1.15 MB at 64 keyframes), so
+ * the all-reduce between bt_ba_reduce and bt_ba_solve_update is latency- instead of size-bound:
+ *   bt_ba_reduce -> bt_ba_pack -> all-reduce bt_ba_packed() -> bt_ba_unpack -> bt_ba_solve_update
+ * No-ops for structure-only steps.  Every rank has the same pattern (the plan is built from the full
+ * edge list), so the packed buffers add element-wise. */
+int bt_ba_pack(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
+int bt_ba_unpack(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
+double *bt_ba_packed(const bt_plan *plan, void *workspace, int64_t *count);
 /* Device pointer to dX [n,6] floats inside `workspace`. */
 float *bt_ba_dx(const bt_plan *plan, void *workspace);
 /* Synchronous read-back of the solver status word (BT_SOLVE_*). */

@@ -254,3 +254,40 @@ def test_largest_supported_system_vs_oracle():
     assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 2e-2          # float32 factor for a system this size
     assert rel(o["poses_out"], ref["poses_out"]) < 1e-4
     assert rel(o["patches_out"], ref["patches_out"]) < 1e-4
+
+
+def test_packed_exchange_form_roundtrip():
+    """bt_ba_pack / bt_ba_unpack (the multi-GPU exchange form of [S | y]): packing, clearing the dense system and
+    unpacking restores it exactly; the packed buffer is the plan's non-zero blocks in factor order; the
+    step completed from the unpacked system equals the plain step."""
+    d = c3_inputs(0)
+    hp = HipProblem(d)
+    o = hp.raw_step("weights_pose", 1)
+    st, plan = o["stepper"], o["plan"]
+    P = hp.poses[0].contiguous(); pat = hp.patches.reshape(-1, 3).contiguous()
+    Pout, pout = torch.empty_like(P), torch.empty_like(pat)
+    tg = hp.t3[0]
+    args = (P, pat, hp.mono.reshape(-1), hp.intr[0], tg, tg.stride(0), hp.w["weights_pose"][0].contiguous(),
+            Pout, pout, hp.bounds, 1e-4, 10.0, 0.05, "huber", False)
+    st.step(*args, phase="reduce")
+    dense = st.system.clone()
+    st.step(*args, phase="pack")
+    packed = st.packed.clone()
+    st.system.zero_()
+    st.step(*args, phase="unpack")
+    torch.cuda.synchronize()
+    assert torch.equal(st.system, dense)
+    A = plan.arrays()
+    D = 6 * plan.n
+    Sd = dense[:D * D].reshape(D, D).cpu().numpy()
+    pk = packed.cpu().numpy()
+    assert pk.shape[0] == plan.nnz_blocks * 36 + D < dense.numel() // 6
+    for b in (0, 1, plan.nnz_blocks // 2, plan.nnz_blocks - 1):
+        src = int(A["blk_src"][b]); rn, cn, tr = src >> 9, (src >> 1) & 255, src & 1
+        blk = Sd[6*rn:6*rn + 6, 6*cn:6*cn + 6]
+        want = np.tril(blk) if rn == cn else (blk.T if tr else blk)
+        assert np.array_equal(pk[36*b:36*b + 36].reshape(6, 6), want)
+    assert np.array_equal(pk[plan.nnz_blocks * 36:].reshape(plan.n, 6), dense[D * D:].cpu().numpy().reshape(plan.n, 6)[A["perm"]])
+    st.step(*args, phase="solve_update")
+    torch.cuda.synchronize()
+    assert rel(Pout.cpu().numpy(), o["poses_out"]) < 1e-7 and rel(pout.cpu().numpy(), o["patches_out"]) < 1e-7
