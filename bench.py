@@ -12,7 +12,7 @@ ping-ponged so the K timed steps are K real Gauss-Newton iterations.  The plan o
 the (fixed) edge list is built before the timed region (its cost is reported as
 `plan_build_ms`), exactly as the reference's caller reuses one edge list for
 2*ITER calls (batrack.py:869-875).  N > 1: tracks are sharded over the ranks, one
-RCCL all-reduce of the reduced system per step (batrack_amd/parallel.py); the
+RCCL all-reduce of the reduced system's non-zero blocks per step (batrack_amd/parallel.py); the
 graph is the same, so scaling is "strong".
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel named in
@@ -212,7 +212,7 @@ def main():
             "config": {"workload": f"{args.workload}: {g.n_frames} keyframes, {plan.E if world == 1 else len(g.ii)} edges, "
                                    f"{len(np.unique(g.kk))} tracks, {plan.n} free poses, pose+structure GN step, huber, "
                                    f"make_graph seed {args.seed}",
-                       "parallelism": "single GPU" if world == 1 else f"track-sharded x{world}, 1 all-reduce of [S|y] per step",
+                       "parallelism": "single GPU" if world == 1 else f"track-sharded x{world}, 1 all-reduce of the non-zero blocks of [S|y] per step",
                        "plan_build_ms": round(plan_ms, 2), "solver_status": status, **extra},
         }
         if roofline is not None:
