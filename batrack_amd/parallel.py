@@ -87,12 +87,21 @@ class ShardedBA:
         args = (poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
                 bounds, lmbda, ep, alpha, loss, structure_only)
         so = bool(structure_only) or self.plan.n == 0
-        self.stepper.step(*args, phase="reduce")
-        if not so and self.world > 1:
-            self.stepper.step(*args, phase="pack")
-            allreduce_system(self.stepper.packed, self.group)
-            self.stepper.step(*args, phase="unpack")
-        self.stepper.step(*args, phase="solve_update")
+        st = self.stepper
+        if so or self.world == 1:
+            st.step(*args)
+            return
+        # one argument block, five enqueues on the current stream (the all-reduce is enqueued by torch on the same stream)
+        import ctypes
+        from . import _lib
+        a = st._fill(*args)
+        L, h, ws = st._lib, self.plan.handle, st.ws.data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+        _lib.check(L.bt_ba_reduce(h, ctypes.byref(a), ws, stream), "bt_ba_reduce")
+        _lib.check(L.bt_ba_pack(h, ctypes.byref(a), ws, stream), "bt_ba_pack")
+        allreduce_system(st.packed, self.group)
+        _lib.check(L.bt_ba_unpack(h, ctypes.byref(a), ws, stream), "bt_ba_unpack")
+        _lib.check(L.bt_ba_solve_update(h, ctypes.byref(a), ws, stream), "bt_ba_solve_update")
 
     def gather_patches(self, patches_out):
         """Merge disparities: every patch slot is owned by exactly one rank (its track
