@@ -1689,7 +1689,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                             apply_update_half<T>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t, hh);
                         }
                     } else {
-                        for (int item = h; item < rows1; item += hs) {
+                        for (int item = h; item < rows1 && !(a.dbg & 256); item += hs) {     // (dbg 256: measurement only, skips the lazy updates)
                             const bool sec = item >= rows0;
                             const int idx = item - (sec ? rows0 : 0), t = idx / 6;
                             apply_update_row<T, false>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t);
