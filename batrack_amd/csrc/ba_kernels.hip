@@ -1260,13 +1260,12 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
 // The LDS-resident factorisation with ONE phase and one barrier per level (levels of at most
 // two columns: two-ended chains).  Updates are split by destination (ba_plan.cpp, fz_*):
 // "pending" = the destination column is factored in the very next level, "lazy" = later.
-//   factor wave    one per column: lanes 0..35 apply the pending updates to the column's diagonal
-//                  block (one element each), every lane factors it redundantly in registers,
-//                  lane 0 publishes the packed factor through LDS + a flag
+//   diagonal wave  one per column: lanes 0..35 apply the pending updates to the column's diagonal
+//                  block (one element each) and publish it through LDS + a flag
 //   row waves      64 panel rows of one column each (metadata stays scalar): every lane applies
 //                  the pending update of its own row (or of y_j) in registers - all loads in
-//                  flight before the first FMA - while the factor wave works, then picks up the
-//                  factor and forward-substitutes its row
+//                  flight before the first FMA - while the diagonal wave works, then picks up the
+//                  block, factors it redundantly in registers and forward-substitutes its row
 //   helper waves   the lazy updates of the level below (one row of a triple per thread) and its
 //                  lazy y contributions
 // Against k_solve_lds (two phases: factor | substitute) this removes a barrier, the store and
@@ -1456,34 +1455,18 @@ size_t solve_fused_lds_bytes(const PlanDev &pd, int nthreads) {
 
 constexpr int kFusedCols = 2;     // columns per level k_solve_fused handles (two-ended chains); wider levels use k_solve_lds
 
-// packed 6x6 lower triangle (BT_LT order, 21 values) <-> LDS, vector accesses
-template <typename T>
-__device__ __forceinline__ void store_packed21(T *p, const T (&L)[21]) {
-    typedef typename Vec2<T>::type V;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { V v; v.x = L[2 * i]; v.y = L[2 * i + 1]; reinterpret_cast<V *>(p)[i] = v; }
-    p[20] = L[20];
-}
-template <typename T>
-__device__ __forceinline__ void load_packed21(const T *p, T (&L)[21]) {
-    typedef typename Vec2<T>::type V;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { const V v = reinterpret_cast<const V *>(p)[i]; L[2 * i] = v.x; L[2 * i + 1] = v.y; }
-    L[20] = p[20];
-}
-
 template <bool PROF>
 __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     typedef double T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[2];
-    __shared__ int lready[kFusedCols];                 // level + 1 whose L_jj (packed) is ready in lpk
+    __shared__ int lready[kFusedCols];                 // level + 1 whose updated diagonal block is ready in scr
     __shared__ int4 mbuf[3][2];                        // packed level metadata, rolling: levels l, l+1, l+2
     const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
     const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
     T *Lw = reinterpret_cast<T *>(smem);
-    // work region: per-column scratch (updated diagonal block, 36) and packed factor (24), staged diagonal blocks, lazy triples
-    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr, *lpk = scr + kFusedCols * 36, *dstage = scr + (size_t)nw * 36;
+    // work region: per-column scratch (updated diagonal block, 36), staged diagonal blocks, lazy triples
+    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr, *dstage = scr + (size_t)nw * 36;
     unsigned short *lazy = reinterpret_cast<unsigned short *>(dstage + 2 * kMaxLevelCols * 36);
     int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + fused_work_bytes(pd, nth)), *pfirst = row_idx + nnzb,
         *col_ptr = pfirst + nnzb;
@@ -1530,14 +1513,14 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
             if (feeder && l + 2 < nlev) mnext = pmeta[(size_t)(l + 2) * 2 + (tid - (nth - 2))];
             const int cnc = (c0b >> 24) & 3;
             const int nr0 = (c0b >> 16) & 255, nr1 = cnc > 1 ? (c1b >> 16) & 255 : 0;     // row waves of the two columns
-            const int nA = cnc + nr0 + nr1;                                               // factor waves, then row waves
+            const int nA = cnc + nr0 + nr1;                                               // diagonal waves, then row waves
             bool got_next = false;
             for (int aw = wave; aw < nA; aw += nw) {
                 __builtin_amdgcn_s_setprio(3);
                 if (PROF) tsub = clock64();
                 if (aw < cnc) {
-                    // ---- factor wave of column q = aw: bring the diagonal block up to date (lanes 0..35, one
-                    // element each), factor it (every lane, in registers), publish the packed factor
+                    // ---- diagonal wave of column q = aw: bring the diagonal block up to date with its pending
+                    // updates (lanes 0..35, one element each) and publish it to the column's row waves
                     const int q = aw, dpos = (q ? c1b : c0b) & 0xffff, md = q ? c1d : c0d;
                     const int el = lane < 36 ? lane : lane - 36, dr = el / 6, dc = el - 6 * dr;
                     const int sd = md & 0x7fff, nd = md >> 15;
@@ -1563,30 +1546,15 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         // the updated block goes in place one level later (its next reader is the back substitution)
                         dstage[(size_t)((l & 1) * kMaxLevelCols + q) * 36 + lane] = v;
                     }
-                    wave_fence();
+                    // the row waves factor it themselves (their own pending update runs meanwhile)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(&lready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     BT_SUB(0);
-                    T L[21];
-                    const T *dblk = scr + q * 36;
-#pragma unroll
-                    for (int rr = 0; rr < 6; ++rr) {
-                        T row[6];
-                        load_row6(dblk + 6 * rr, row);
-#pragma unroll
-                        for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
-                    }
-                    const bool ok = chol6_packed<T>(L);
-                    BT_SUB(1);
-                    if (lane == 0) {
-                        store_packed21(lpk + q * 24, L);
-                        if (!ok) flags[0] = 1;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        __hip_atomic_store(&lready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    BT_SUB(2);
                     __builtin_amdgcn_s_setprio(0);
                 } else {
-                    // ---- row wave: one panel row (or y_j) per lane: its pending update, then, once the factor
-                    // wave has published L_jj, the forward substitution
+                    // ---- row wave: one panel row (or y_j) per lane: its pending update, then, once the diagonal
+                    // wave has published the updated block, its factorisation (every lane, in registers) and the
+                    // forward substitution of the row
                     const int ra = aw - cnc, q = ra >= nr0 ? 1 : 0, part = ra - (q ? nr0 : 0);
                     const int ma = q ? c1a : c0a, dpos = (q ? c1b : c0b) & 0xffff;
                     const int j = ma & 255, cnt = (ma >> 8) & 255, ysrc = (ma >> 16) & 255;
@@ -1646,7 +1614,18 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     while (__hip_atomic_load(&lready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= l) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     T L[21];
-                    load_packed21(lpk + q * 24, L);
+                    {
+                        const T *dblk = scr + q * 36;
+#pragma unroll
+                        for (int rr = 0; rr < 6; ++rr) {
+                            T row[6];
+                            load_row6(dblk + 6 * rr, row);
+#pragma unroll
+                            for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
+                        }
+                    }
+                    const bool ok = chol6_packed<T>(L);
+                    if (!ok && part == 0 && lane == 0) flags[0] = 1;
                     BT_SUB(4);
                     if (valid) {
                         T out[6];

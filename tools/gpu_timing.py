@@ -57,7 +57,7 @@ if int(os.environ.get("BT_DEBUG_MODE", "0")) & 16:
     print("  solver per-wave busy cycles (phase1, phase2): " + " ".join(f"w{w}:{a}/{b}" for w, (a, b) in enumerate(ph)))
     if os.environ.get("BT_SOLVER_FUSED", "1") != "0":
         g = pf.reshape(-1)
-        print(f"  fused solver: load={g[0]} sweep_end={g[1]} total={g[2]} | tail: Linv_end={g[3]} Mform_end={g[4]} backsub_end={g[5]} | row wave: row_update={g[16]} wait+loadL={g[17]} trsm+store={g[18]}")
+        print(f"  fused solver: load={g[0]} sweep_end={g[1]} total={g[2]} | tail: Linv_end={g[3]} Mform_end={g[4]} backsub_end={g[5]} | row wave: row_update={g[16]} wait+load+chol={g[17]} trsm+store={g[18]}")
     for w in range(2):
         print(f"  solver wave{w} cycles: " + " ".join(f"{n}={v}" for n, v in zip(names, pf[w])) + f" total={pf[w].sum()}")
 print(f"mode={os.environ.get('BT_DEBUG_MODE','0')} {args.workload} E={plan.E} n={plan.n} tiles={plan.tiles} nnzb={plan.nnz_blocks}: " +
