@@ -886,34 +886,6 @@ __device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr
     if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); pf[9] += tn - *tcp; *tcp = tn; }
 }
 
-// Half a row of an update triple (outputs 3 hh .. 3 hh + 2): 12 vector loads and 18 FMAs.
-template <typename T>
-__device__ __forceinline__ void apply_update_half(T *Lw, const unsigned short *tr, int r, int hh) {
-    T a[6], b[18], v[3], o[3];
-    const unsigned d = tr[2];
-    T *dst = Lw + (size_t)(d & 0x7fffu) * 36 + 6 * r + 3 * hh;
-    const T *bb = Lw + (size_t)tr[1] * 36 + 18 * hh;
-    load_row6(Lw + (size_t)tr[0] * 36 + 6 * r, a);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) load_row6(bb + 6 * c, reinterpret_cast<T (&)[6]>(b[6 * c]));
-    v[0] = dst[0]; v[1] = dst[1]; v[2] = dst[2];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        T acc = a[0] * b[6 * c];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) acc += a[k] * b[6 * c + k];
-        o[c] = acc;
-    }
-    if (d & 0x8000u) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(dst + c, -o[c]);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dst[c] = v[c] - o[c];
-    }
-}
-
 // wave-uniform metadata: LDS -> SGPRs
 __device__ __forceinline__ int4 uniform4(const int4 v) {
     return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
@@ -1503,9 +1475,6 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         };
         take_next(0);
         const bool feeder = tid >= nth - 2;           // the last two threads bring in level l + 2's metadata
-        const bool half_rows = (a.dbg & 64) != 0;     // measurement only: two threads per lazy update row
-        unsigned pf_next = 0;                         // a row wave's pfirst entry of the next level, read ahead
-        int pf_level = -1;
         for (int l = 0; l < nlev; ++l) {
             c0a = n0a; c0b = n0b; c0c = n0c; c0d = n0d; c1a = n1a; c1b = n1b; c1c = n1c; c1d = n1d;
             if (PROF) tph = clock64();
@@ -1514,7 +1483,6 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
             const int cnc = (c0b >> 24) & 3;
             const int nr0 = (c0b >> 16) & 255, nr1 = cnc > 1 ? (c1b >> 16) & 255 : 0;     // row waves of the two columns
             const int nA = cnc + nr0 + nr1;                                               // diagonal waves, then row waves
-            bool got_next = false;
             for (int aw = wave; aw < nA; aw += nw) {
                 __builtin_amdgcn_s_setprio(3);
                 if (PROF) tsub = clock64();
@@ -1564,7 +1532,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     T *p = isy ? z + 6 * j : Lw + (size_t)bown * 36 + 6 * r;
                     // in[c] -= sum_e avec[e] M[c][e] with avec = row r of src1 and M = src2, or for the y row
                     // avec = y of the source column and M = src1; every load is in flight before the first FMA
-                    const unsigned pfo = (pf_level == l && aw == wave) ? pf_next : (unsigned)pfirst[valid && !isy ? bown : dpos];
+                    const unsigned pfo = (unsigned)pfirst[valid && !isy ? bown : dpos];
                     const int s1 = pfo & 0x7fff, s2 = (pfo >> 15) & 0x7fff, no = valid ? (int)(pfo >> 30) : 0;
                     T in[6], avec[6], m[36];
                     load_row6(p, in);
@@ -1597,20 +1565,6 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         }
                     }
                     BT_SUB(3);
-                    // while the factor wave works: the next level's metadata and this wave's pfirst entry there
-                    if ((a.dbg & 128) && !got_next && l + 1 < nlev) {        // measurement only
-                        take_next(l + 1);
-                        got_next = true;
-                        const int ncn = (n0b >> 24) & 3, mr0 = (n0b >> 16) & 255;
-                        const int ran = wave - ncn;
-                        if (ran >= 0) {
-                            const int qn = ran >= mr0 ? 1 : 0, partn = ran - (qn ? mr0 : 0);
-                            const int cntn = ((qn ? n1a : n0a) >> 8) & 255, dposn = (qn ? n1b : n0b) & 0xffff;
-                            const int rwn = partn * 64 + lane;
-                            pf_next = (unsigned)pfirst[rwn < cntn * 6 ? dposn + 1 + rwn / 6 : dposn];
-                            pf_level = l + 1;
-                        }
-                    }
                     while (__hip_atomic_load(&lready[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= l) __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     T L[21];
@@ -1659,26 +1613,15 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         }
                     }
                     const int rows0 = ((p0c >> 16) & 0xffff) * 6, rows1 = rows0 + (pnc > 1 ? ((p1c >> 16) & 0xffff) * 6 : 0);
-                    if (half_rows && 2 * rows1 <= hs) {
-                        // half rows: two threads per row of a triple, the shortest chain when the helpers are plenty
-                        if (h < 2 * rows1) {
-                            const int item = h >> 1, hh = h & 1;
-                            const bool sec = item >= rows0;
-                            const int idx = item - (sec ? rows0 : 0), t = idx / 6;
-                            apply_update_half<T>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t, hh);
-                        }
-                    } else {
-                        for (int item = h; item < rows1 && !(a.dbg & 256); item += hs) {     // (dbg 256: measurement only, skips the lazy updates)
-                            const bool sec = item >= rows0;
-                            const int idx = item - (sec ? rows0 : 0), t = idx / 6;
-                            apply_update_row<T, false>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t);
-                        }
+                    for (int item = h; item < rows1; item += hs) {
+                        const bool sec = item >= rows0;
+                        const int idx = item - (sec ? rows0 : 0), t = idx / 6;
+                        apply_update_row<T, false>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t);
                     }
                     // lazy y contributions of the level below, on the threads after those with update rows
                     {
-                        const int used = half_rows && 2 * rows1 <= hs ? 2 * rows1 : rows1;
                         const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
-                        const int shift = ((used + 63) >> 6) << 6;
+                        const int shift = ((rows1 + 63) >> 6) << 6;
                         for (int item = (h - shift % hs + hs) % hs; item < ys1; item += hs) {
                             const bool sec = item >= ys0;
                             const int qq = item - (sec ? ys0 : 0);
@@ -1699,7 +1642,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
             if (feeder && l + 2 < nlev) mbuf[(l + 2) % 3][tid - (nth - 2)] = mnext;
             if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); phL += clock64() - tph; }
             p0a = c0a; p0b = c0b; p0c = c0c; p1a = c1a; p1b = c1b; p1c = c1c; pnc = cnc;
-            if (!got_next && l + 1 < nlev) take_next(l + 1);
+            if (l + 1 < nlev) take_next(l + 1);
             __syncthreads();
         }
         // the last level's staged diagonal blocks (its columns have no lazy work: nothing lies above them)
