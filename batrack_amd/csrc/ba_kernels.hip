@@ -1622,7 +1622,9 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     {
                         const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
                         const int shift = ((rows1 + 63) >> 6) << 6;
-                        for (int item = (h - shift % hs + hs) % hs; item < ys1; item += hs) {
+                        int first = h - shift;                       // (no division in the usual one-round case)
+                        if (shift > hs) first = (h - shift % hs + hs) % hs; else if (first < 0) first += hs;
+                        for (int item = first; item < ys1; item += hs) {
                             const bool sec = item >= ys0;
                             const int qq = item - (sec ? ys0 : 0);
                             const int pj = (sec ? p1a : p0a) & 255, dposp = (sec ? p1b : p0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
