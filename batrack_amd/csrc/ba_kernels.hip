@@ -854,6 +854,34 @@ template <typename T> __device__ __forceinline__ void lds_sub(T *p, T v, bool at
 // One ROW of an update triple: dst[r][:] -= (row r of block tr[0]) . (rows of block tr[1])^T.
 // 21 vector LDS loads and 36 FMAs for 6 outputs.  Bit 15 of tr[2]: the destination is also
 // updated by another column of the same level -> LDS atomics.
+// (the triple as three values: callers that keep it packed in one 8-byte LDS word)
+template <typename T>
+__device__ __forceinline__ void apply_update_row3(T *Lw, unsigned s1, unsigned s2, unsigned d, int r) {
+    T a[6], b[36], o[6], v[6];
+    T *dst = Lw + (d & 0x7fffu) * 36 + 6 * r;
+    const T *bb = Lw + s2 * 36;
+    load_row6(Lw + s1 * 36 + 6 * r, a);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) load_row6(bb + 6 * c, reinterpret_cast<T (&)[6]>(b[6 * c]));
+    load_row6(dst, v);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        T acc = a[0] * b[6 * c];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += a[k] * b[6 * c + k];
+        o[c] = acc;
+    }
+    if (d & 0x8000u) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) atomicAdd(dst + c, -o[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] -= o[c];
+        store_row6(dst, v);
+    }
+}
+
 template <typename T, bool PROF = false>
 __device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr, int r, long long *pf = nullptr, long long *tcp = nullptr) {
     T a[6], b[36], o[6], v[6];
@@ -1416,7 +1444,7 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
 __host__ __device__ inline size_t fused_work_bytes(const PlanDev &pd, int nthreads) {
     const size_t nw = (size_t)nthreads / 64;
     const size_t b = (nw * 36 + 2 * kMaxLevelCols * 36) * sizeof(double) +
-                     (size_t)pd.fz_nlazy * 3 * sizeof(unsigned short) + 16;
+                     (size_t)pd.fz_nlazy * 4 * sizeof(unsigned short) + 16;
     const size_t zt = (size_t)pd.D * sizeof(double) + (size_t)pd.nlev * kMaxLevelCols * sizeof(int4);   // zt + compact level table
     return ((b > zt ? b : zt) + 15) / 16 * 16;
 }
@@ -1457,7 +1485,9 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
         if (tid < 2) flags[tid] = 0;
         if (tid < kFusedCols) lready[tid] = 0;
         // the sweep's tables (their LDS is reused for zt by the back substitution, so a retry reloads them)
-        for (int i = tid; i < pd.fz_nlazy * 3; i += nth) lazy[i] = (unsigned short)pd.fz_lazy[i];
+        for (int i = tid; i < pd.fz_nlazy; i += nth)          // one 8-byte word per triple: src1, src2, dst | shared << 15
+            reinterpret_cast<ushort4 *>(lazy)[i] = make_ushort4((unsigned short)pd.fz_lazy[3 * i], (unsigned short)pd.fz_lazy[3 * i + 1],
+                                                               (unsigned short)pd.fz_lazy[3 * i + 2], 0);
         if (tid < 4 && (tid >> 1) < nlev) mbuf[tid >> 1][tid & 1] = pmeta[tid];       // metadata of levels 0 and 1
         lds_load_system<T>(pd, a, Lw, z, row_idx, lm, tid, nth);
         __syncthreads();
@@ -1616,7 +1646,8 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     for (int item = h; item < rows1; item += hs) {
                         const bool sec = item >= rows0;
                         const int idx = item - (sec ? rows0 : 0), t = idx / 6;
-                        apply_update_row<T, false>(Lw, lazy + 3 * (((sec ? p1c : p0c) & 0xffff) + t), idx - 6 * t);
+                        const ushort4 tr = reinterpret_cast<const ushort4 *>(lazy)[((sec ? p1c : p0c) & 0xffff) + t];
+                        apply_update_row3<T>(Lw, tr.x, tr.y, tr.z, idx - 6 * t);
                     }
                     // lazy y contributions of the level below, on the threads after those with update rows
                     {
