@@ -1275,17 +1275,20 @@ __global__ __launch_bounds__(768) void k_solve_lds(PlanDev pd, StepArgs a) {
 constexpr int kLoadInFlight = 4;      // block rows of S a thread has in flight (6 doubles each)
 
 template <typename T>
-__device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArgs &a, T *Lw, T *z, const int *row_idx,
-                                                double lm, int tid, int nth) {
+__device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArgs &a, T *Lw, T *z, double lm, int tid, int nth) {
+    // reads global memory only (the block's place in S says whether it is a diagonal block), so the loads are in
+    // flight together with the table copies that precede the call; the caller's barrier covers both
     const int nnzb = pd.nnzb, D = pd.D;
     for (int base = 0; base < nnzb * 6; base += kLoadInFlight * nth) {
         double v[kLoadInFlight][6];
+        bool dg[kLoadInFlight];
 #pragma unroll
         for (int u = 0; u < kLoadInFlight; ++u) {
             const int idx = base + u * nth + tid;
             if (idx < nnzb * 6) {
                 const int b = idx / 6, r = idx - 6 * b, src = pd.blk_src[b];
                 const int rn = src >> 9, cn = (src >> 1) & 255;
+                dg[u] = rn == cn;
                 if (src & 1) {
 #pragma unroll
                     for (int c = 0; c < 6; ++c) v[u][c] = a.S[(size_t)(6 * rn + c) * D + 6 * cn + r];
@@ -1300,8 +1303,8 @@ __device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArg
         for (int u = 0; u < kLoadInFlight; ++u) {
             const int idx = base + u * nth + tid;
             if (idx < nnzb * 6) {
-                const int b = idx / 6, r = idx - 6 * b, rc = row_idx[b];
-                const bool diag = (rc & 255) == ((rc >> 8) & 255);
+                const int b = idx / 6, r = idx - 6 * b;
+                const bool diag = dg[u];
                 T w[6];
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
@@ -1477,7 +1480,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
     long long phA = 0, phL = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, sub[6] = {0, 0, 0, 0, 0, 0}, tsub = 0;
 #define BT_SUB(i) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tq = clock64(); sub[i] += tq - tsub; tsub = tq; } } while (0)
-    __syncthreads();
+    // (no barrier here: the load of S below does not read these tables; the barrier after it covers both)
 
     int status = BT_SOLVE_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1489,7 +1492,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
             reinterpret_cast<ushort4 *>(lazy)[i] = make_ushort4((unsigned short)pd.fz_lazy[3 * i], (unsigned short)pd.fz_lazy[3 * i + 1],
                                                                (unsigned short)pd.fz_lazy[3 * i + 2], 0);
         if (tid < 4 && (tid >> 1) < nlev) mbuf[tid >> 1][tid & 1] = pmeta[tid];       // metadata of levels 0 and 1
-        lds_load_system<T>(pd, a, Lw, z, row_idx, lm, tid, nth);
+        lds_load_system<T>(pd, a, Lw, z, lm, tid, nth);
         __syncthreads();
         if (PROF) tload = clock64() - tall;
 
