@@ -1453,7 +1453,7 @@ __host__ __device__ inline size_t fused_work_bytes(const PlanDev &pd, int nthrea
 }
 size_t solve_fused_lds_bytes(const PlanDev &pd, int nthreads) {
     return ((size_t)pd.nnzb * 36 + (size_t)pd.D) * sizeof(double) + fused_work_bytes(pd, nthreads) +
-           (2 * (size_t)pd.nnzb + (size_t)pd.n + 1) * sizeof(int) + 64;       // row_idx, pfirst, col_ptr
+           (3 * (size_t)pd.nnzb + (size_t)pd.n + 1) * sizeof(int) + 64;       // row_idx, pfirst, psecond, col_ptr
 }
 
 constexpr int kFusedCols = 2;     // columns per level k_solve_fused handles (two-ended chains); wider levels use k_solve_lds
@@ -1472,11 +1472,11 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr, *dstage = scr + (size_t)nw * 36;
     unsigned short *lazy = reinterpret_cast<unsigned short *>(dstage + 2 * kMaxLevelCols * 36);
     int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + fused_work_bytes(pd, nth)), *pfirst = row_idx + nnzb,
-        *col_ptr = pfirst + nnzb;
+        *psecond = pfirst + nnzb, *col_ptr = psecond + nnzb;
     const int4 *pmeta = reinterpret_cast<const int4 *>(pd.fz_pmeta);     // [nlev][2]
     // per block: row | col << 8 | shared-y << 24 | pending-y << 25, and its first pending pair
-    // src1 | src2 << 15 | min(count, 3) << 30 (further pairs, where chains merge, are read from global memory)
-    for (int i = tid; i < nnzb; i += nth) { row_idx[i] = pd.fz_rowinfo[i]; pfirst[i] = pd.fz_pfirst[i]; }
+    // src1 | src2 << 15 | count << 30, and the second pair (where chains merge) src1 | src2 << 15
+    for (int i = tid; i < nnzb; i += nth) { row_idx[i] = pd.fz_rowinfo[i]; pfirst[i] = pd.fz_pfirst[i]; psecond[i] = pd.fz_psecond[i]; }
     for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
     long long phA = 0, phL = 0, tph = 0, tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, sub[6] = {0, 0, 0, 0, 0, 0}, tsub = 0;
 #define BT_SUB(i) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tq = clock64(); sub[i] += tq - tsub; tsub = tq; } } while (0)
@@ -1535,13 +1535,15 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
                         v -= acc;
                     }
-                    if (nd > 1 && lane < 36)              // rare: further pending pairs, lists in global memory
-                        for (int k = pd.fz_pend_ptr[dpos] + 1; k < pd.fz_pend_ptr[dpos + 1]; ++k) {
-                            const T *src = Lw + (size_t)pd.fz_pend[2 * k] * 36;
-                            T acc = (T)0;
-                            for (int e = 0; e < 6; ++e) acc += src[6 * dr + e] * src[6 * dc + e];
-                            v -= acc;
-                        }
+                    if (nd > 1) {                         // where chains merge: a second pending pair (from the level's other column)
+                        const T *src = Lw + (size_t)(psecond[dpos] & 0x7fff) * 36;
+                        load_row6(src + 6 * dr, x);
+                        load_row6(src + 6 * dc, yv);
+                        T acc = x[0] * yv[0];
+#pragma unroll
+                        for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
+                        v -= acc;
+                    }
                     if (lane < 36) {
                         scr[q * 36 + lane] = v;
                         // the updated block goes in place one level later (its next reader is the back substitution)
@@ -1582,19 +1584,19 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                         for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
                         in[c] -= no > 0 ? acc : (T)0;
                     }
-                    if (__builtin_amdgcn_ballot_w64(no > 1)) {       // rare: further pending pairs, lists in global memory
-                        if (no > 1) {
-                            const int bsel = isy ? dpos : bown;
-                            for (int k = pd.fz_pend_ptr[bsel] + 1; k < pd.fz_pend_ptr[bsel + 1]; ++k) {
-                                const int t1 = pd.fz_pend[2 * k], t2 = pd.fz_pend[2 * k + 1];
-                                const T *av = isy ? z + 6 * ((row_idx[t1] >> 8) & 255) : Lw + (size_t)t1 * 36 + 6 * r;
-                                const T *M = Lw + (size_t)(isy ? t1 : t2) * 36;
-                                for (int c = 0; c < 6; ++c) {
-                                    T acc = (T)0;
-                                    for (int e = 0; e < 6; ++e) acc += av[e] * M[6 * c + e];
-                                    in[c] -= acc;
-                                }
-                            }
+                    if (__builtin_amdgcn_ballot_w64(no > 1)) {       // where chains merge: a second pending pair
+                        const unsigned ps = (unsigned)psecond[isy ? dpos : bown];
+                        const int t1 = ps & 0x7fff, t2 = (ps >> 15) & 0x7fff;
+                        load_row6(isy ? z + 6 * ((row_idx[t1] >> 8) & 255) : Lw + (size_t)t1 * 36 + 6 * r, avec);
+                        const T *M = Lw + (size_t)(isy ? t1 : t2) * 36;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) load_row6(M + 6 * c, reinterpret_cast<T (&)[6]>(m[6 * c]));
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            T acc = avec[0] * m[6 * c];
+#pragma unroll
+                            for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
+                            in[c] -= no > 1 ? acc : (T)0;
                         }
                     }
                     BT_SUB(3);

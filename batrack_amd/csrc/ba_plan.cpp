@@ -527,12 +527,17 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         // the first pending pair src1 | src2 << 15 | min(#pending, 3) << 30
         pl->fz_rowinfo.assign(nb, 0);
         pl->fz_pfirst.assign(nb, 0);
+        pl->fz_psecond.assign(nb, 0);                       // second pending pair src1 | src2 << 15 (a block gets at most
+        bool pend_ok = true;                                //  one from each of the two columns of the level below)
         for (size_t b = 0; b < nb; ++b) {
             pl->fz_rowinfo[b] = pl->row_idx[b] | ((pl->blk_col[b] & 255) << 8) | ((pl->blk_col[b] >> 16) << 24) | (pl->fz_yurg[b] << 25);
             const int32_t k0 = pl->fz_pend_ptr[b], c = pl->fz_pend_ptr[b + 1] - k0;
+            if (c > 2) pend_ok = false;
             if (c > 0 && nb < 32768)
                 pl->fz_pfirst[b] = (int32_t)((uint32_t)pl->fz_pend[(size_t)k0 * 2] | ((uint32_t)pl->fz_pend[(size_t)k0 * 2 + 1] << 15) |
                                              ((uint32_t)(c < 3 ? c : 3) << 30));
+            if (c > 1 && nb < 32768)
+                pl->fz_psecond[b] = (int32_t)((uint32_t)pl->fz_pend[(size_t)k0 * 2 + 2] | ((uint32_t)pl->fz_pend[(size_t)k0 * 2 + 3] << 15));
         }
         // back substitution, levels descending, one wave per column slot: a barrier is needed before a level
         // only if one of its columns reads an x_i written by another slot's wave since the last barrier
@@ -556,7 +561,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             }
         }
         pl->fz_meta.assign((size_t)nlev * kMaxLevelCols * 8, 0);
-        pl->fz_ok = (pl->fz_lazy.size() / 3 < 65536 && pl->row_idx.size() < 32768) ? 1 : 0;
+        pl->fz_ok = (pl->fz_lazy.size() / 3 < 65536 && pl->row_idx.size() < 32768 && pend_ok) ? 1 : 0;
         for (int32_t l = 0; l < nlev; ++l) {
             if (pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l] > 2) pl->fz_ok = 0;
             int32_t w0 = 0;

@@ -39,7 +39,7 @@ struct PlanDev {
     int nlev, ndp;
     const int32_t *perm, *blk_src, *lvl_ptr, *lvl_cols, *col_lvl, *dp_ptr, *dp;
     // fused schedule (k_solve_fused): pending updates per destination block, lazy triples per column
-    const int32_t *fz_pend_ptr, *fz_pend, *fz_lazy_ptr, *fz_lazy, *fz_yurg, *fz_meta, *fz_pmeta, *bs_sync, *fz_rowinfo, *fz_pfirst;
+    const int32_t *fz_pend_ptr, *fz_pend, *fz_lazy_ptr, *fz_lazy, *fz_yurg, *fz_meta, *fz_pmeta, *bs_sync, *fz_rowinfo, *fz_pfirst, *fz_psecond;
     int fz_npend, fz_nlazy, fz_ok;      // fz_ok: no level has more than two columns
     const int32_t *lvl_meta;   // [nlev][kMaxLevelCols][8]: col, diag pos, #sub-blocks, first rest triple, #rest triples, dp first, #dp, 0  (col = -1: unused)
 };
@@ -65,7 +65,7 @@ struct bt_plan {
     int max_tile_pairs = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
     std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp, lvl_meta;
-    std::vector<int32_t> fz_pend_ptr, fz_pend, fz_lazy_ptr, fz_lazy, fz_yurg, fz_meta, fz_pmeta, bs_sync, fz_rowinfo, fz_pfirst;   // fused schedule (k_solve_fused)
+    std::vector<int32_t> fz_pend_ptr, fz_pend, fz_lazy_ptr, fz_lazy, fz_yurg, fz_meta, fz_pmeta, bs_sync, fz_rowinfo, fz_pfirst, fz_psecond;   // fused schedule (k_solve_fused)
     int fz_ok = 0;
     int max_rows16 = 16;
     bt::WsLayout ws{};

@@ -264,6 +264,8 @@ def sparse_chol_solve_fused(A, S_lower, y, n, ep, lm):
         c = int(pend_ptr[b + 1] - pend_ptr[b])
         want = (int(pend[pend_ptr[b]][0]) | int(pend[pend_ptr[b]][1]) << 15 | min(c, 3) << 30) if c else 0
         assert pf[b] == want
+        want2 = (int(pend[pend_ptr[b] + 1][0]) | int(pend[pend_ptr[b] + 1][1]) << 15) if c > 1 else 0
+        assert A["fz_psecond"][b] == want2 and c <= 2
     assert len(pend) + len(lazy) == len(A["upd"]) // 3, "every update triple is either pending or lazy"
     L = np.zeros((nnzb, 6, 6))
     for b in range(nnzb):
