@@ -1442,11 +1442,12 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
 }
 
 // LDS of k_solve_fused: Lw | z | work | row_idx | pfirst | col_ptr, where `work` holds the sweep's tables
-// (per-wave scratch, staged diagonal blocks, lazy triples) and is reused for zt afterwards.
+// (published diagonal blocks, lazy triples) and is reused for zt afterwards.
 // The per-level metadata stays in global memory (prefetched a level ahead).
 __host__ __device__ inline size_t fused_work_bytes(const PlanDev &pd, int nthreads) {
-    const size_t nw = (size_t)nthreads / 64;
-    const size_t b = (nw * 36 + 2 * kMaxLevelCols * 36) * sizeof(double) +
+    (void)nthreads;
+    const size_t b = 2 * 36 * sizeof(double) +          // published diagonal blocks of the level's two columns
+
                      (size_t)pd.fz_nlazy * 4 * sizeof(unsigned short) + 16;
     const size_t zt = (size_t)pd.D * sizeof(double) + (size_t)pd.nlev * kMaxLevelCols * sizeof(int4);   // zt + compact level table
     return ((b > zt ? b : zt) + 15) / 16 * 16;
@@ -1468,9 +1469,9 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
     const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
     const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
     T *Lw = reinterpret_cast<T *>(smem);
-    // work region: per-column scratch (updated diagonal block, 36), staged diagonal blocks, lazy triples
-    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr, *dstage = scr + (size_t)nw * 36;
-    unsigned short *lazy = reinterpret_cast<unsigned short *>(dstage + 2 * kMaxLevelCols * 36);
+    // work region: per-column scratch (updated diagonal block, 36), lazy triples
+    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr;
+    unsigned short *lazy = reinterpret_cast<unsigned short *>(scr + kFusedCols * 36);
     int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + fused_work_bytes(pd, nth)), *pfirst = row_idx + nnzb,
         *psecond = pfirst + nnzb, *col_ptr = psecond + nnzb;
     const int4 *pmeta = reinterpret_cast<const int4 *>(pd.fz_pmeta);     // [nlev][2]
@@ -1546,8 +1547,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     }
                     if (lane < 36) {
                         scr[q * 36 + lane] = v;
-                        // the updated block goes in place one level later (its next reader is the back substitution)
-                        dstage[(size_t)((l & 1) * kMaxLevelCols + q) * 36 + lane] = v;
+                        Lw[(size_t)dpos * 36 + lane] = v;          // in place as well: its next reader is the back substitution
                     }
                     // the row waves factor it themselves (their own pending update runs meanwhile)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1638,15 +1638,6 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                 if (nA < nw) { h = tid - 64 * nA; hs = nth - 64 * nA; }
                 else { hs = nth; h = (tid + nth - (64 * nA) % nth) % nth; }
                 if (h >= 0) {
-                    {   // staged diagonal blocks of the previous level -> in place
-                        const int back = hs - 1 - h;
-                        if (back < pnc * 18) {
-                            const int q = back / 18, e = back - 18 * q;
-                            const int dpos = (q == 0 ? p0b : p1b) & 0xffff;
-                            reinterpret_cast<double2 *>(Lw + (size_t)dpos * 36)[e] =
-                                reinterpret_cast<const double2 *>(dstage + (size_t)(((l - 1) & 1) * kMaxLevelCols + q) * 36)[e];
-                        }
-                    }
                     const int rows0 = ((p0c >> 16) & 0xffff) * 6, rows1 = rows0 + (pnc > 1 ? ((p1c >> 16) & 0xffff) * 6 : 0);
                     for (int item = h; item < rows1; item += hs) {
                         const bool sec = item >= rows0;
@@ -1683,14 +1674,6 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
             if (l + 1 < nlev) take_next(l + 1);
             __syncthreads();
         }
-        // the last level's staged diagonal blocks (its columns have no lazy work: nothing lies above them)
-        if (tid < pnc * 18) {
-            const int q = tid / 18, e = tid - 18 * q;
-            const int dpos = (q == 0 ? p0b : p1b) & 0xffff;
-            reinterpret_cast<double2 *>(Lw + (size_t)dpos * 36)[e] =
-                reinterpret_cast<const double2 *>(dstage + (size_t)(((nlev - 1) & 1) * kMaxLevelCols + q) * 36)[e];
-        }
-        __syncthreads();
         if (PROF) tsweep = clock64() - tall;
 
         int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
