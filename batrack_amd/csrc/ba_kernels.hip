@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
         // this wave's first slot, in flight while the pair geometry is computed
         int e_nx = -1, pair_nx = 0, lp_nx = 0;
         unsigned lab_nx = 0xffffu;
-        if (s0 < s1) {
+        if (!PERSIST && s0 < s1) {            // (the persistent variant has no registers to spare for the look-ahead)
             const size_t idx = (size_t)(slot0 + s0) * kLanes + lane;
             e_nx = pd.slot_edge[idx]; pair_nx = pd.slot_pair[idx]; lab_nx = pd.slot_lab[idx]; lp_nx = pd.slot_lp[idx];
         }
@@ -306,11 +306,21 @@ __global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int til
         for (int s = s0; s < s1; ++s) {
             const size_t idx = (size_t)(slot0 + s) * kLanes + lane;
             // this slot's operands were loaded one iteration ahead (the first one before the barrier above)
+            if (PERSIST) {
+                e_nx = pd.slot_edge[idx]; pair_nx = pd.slot_pair[idx]; lab_nx = pd.slot_lab[idx]; lp_nx = pd.slot_lp[idx];
+                tu_nx = tv_nx = w0_nx = w1_nx = 0.0f;
+                if (e_nx >= 0) {
+                    const float *tp = a.targets + (size_t)e_nx * a.tstride;
+                    tu_nx = tp[0]; tv_nx = tp[1];
+                    const float2 w = reinterpret_cast<const float2 *>(a.weights)[e_nx];
+                    w0_nx = w.x; w1_nx = w.y;
+                }
+            }
             const int e = e_nx, pair = pair_nx, lp = lp_nx;
             const bool act = e >= 0;
             const unsigned lab = lab_nx;
             const float tu = tu_nx, tv = tv_nx, w0 = w0_nx, w1 = w1_nx;
-            if (s + 1 < s1) {
+            if (!PERSIST && s + 1 < s1) {
                 const size_t idn = idx + kLanes;
                 e_nx = pd.slot_edge[idn]; pair_nx = pd.slot_pair[idn]; lab_nx = pd.slot_lab[idn]; lp_nx = pd.slot_lp[idn];
                 tu_nx = tv_nx = w0_nx = w1_nx = 0.0f;
