@@ -1722,6 +1722,281 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
 #undef BT_SUB
 }
 
+// ------------------------------------------------------------------ k_solve_pipe
+// k_solve_fused without the per-level workgroup barrier.  Waves have fixed roles and walk the levels at
+// their own pace, ordered by flags in LDS only where data flows:
+//   wave q (q = 0, 1)      diagonal wave of the level's column q      -> lready[q]   = level + 1
+//   wave 2 + q             row wave of column q (panel rows and y_j)   -> colready[q] = level + 1
+//   waves 4 ..             helpers: batch b = the lazy updates whose sources are the columns of level b;
+//                          every helper wave adds 1 to hcnt when it has finished its share of a batch
+// What a step waits for (tests/plan_emulator.py checks that these waits order every conflicting access):
+//   column waves, level l   colready[*] >= l for the columns of level l - 1 (pending sources; the scratch
+//                           of the diagonal block is free again) and hcnt >= nh (l - 1): batches 0 .. l - 2
+//                           are complete, i.e. every lazy update into this level's blocks has landed
+//   row wave                additionally lready[q] >= l + 1 before it factors
+//   helpers, batch b        colready[*] >= b + 1 for the columns of level b (its sources) and
+//                           hcnt >= nh b (the whole group has finished the batches before: two batches may
+//                           read-modify-write the same destination row from different waves)
+// A chain's row wave therefore never waits for anything but its diagonal wave in steady state; the barrier
+// (~240 cycles by itself) and the wait for the slowest wave of every level are gone.  Requires columns of at
+// most 64 panel rows and levels of at most two columns (plan flag fzp_ok); other systems use k_solve_fused.
+__host__ __device__ inline size_t pipe_work_bytes(const PlanDev &pd) {
+    const size_t b = 2 * 36 * sizeof(double) + (size_t)pd.fz_nlazy * 4 * sizeof(unsigned short) + 16;
+    const size_t zt = (size_t)pd.D * sizeof(double) + (size_t)pd.nlev * kMaxLevelCols * sizeof(int4);   // zt + compact level table
+    return ((b > zt ? b : zt) + 15) / 16 * 16;
+}
+size_t solve_pipe_lds_bytes(const PlanDev &pd) {
+    return ((size_t)pd.nnzb * 36 + (size_t)pd.D) * sizeof(double) + pipe_work_bytes(pd) +
+           (3 * (size_t)pd.nnzb + (size_t)pd.n + 1 + (size_t)pd.nlev * 8) * sizeof(int) + 64;      // row_idx, pfirst, psecond, col_ptr, level records
+}
+
+__device__ __forceinline__ void wait_ge(int *flag, int target) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
+    typedef double T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int flags[2];
+    __shared__ int lready[2], colready[2], hcnt;
+    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
+    const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
+    T *Lw = reinterpret_cast<T *>(smem);
+    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr;
+    unsigned short *lazy = reinterpret_cast<unsigned short *>(scr + 2 * 36);
+    int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + pipe_work_bytes(pd)), *pfirst = row_idx + nnzb,
+        *psecond = pfirst + nnzb, *col_ptr = psecond + nnzb, *lrec = col_ptr + n + 1;
+    for (int i = tid; i < nnzb; i += nth) { row_idx[i] = pd.fz_rowinfo[i]; pfirst[i] = pd.fz_pfirst[i]; psecond[i] = pd.fz_psecond[i]; }
+    for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
+    for (int i = tid; i < nlev * 8; i += nth) lrec[i] = pd.fz_pmeta[i];
+    long long tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, twait = 0, twork = 0, tq = 0, sub[3] = {0, 0, 0};
+#define BT_TW(acc) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); acc += tn - tq; tq = tn; } } while (0)
+
+    int status = BT_SOLVE_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const double lm = attempt == 0 ? 1e-4 : 1e-3;
+        if (tid < 2) { flags[tid] = 0; lready[tid] = 0; colready[tid] = 0; }
+        if (tid == 2) hcnt = 0;
+        for (int i = tid; i < pd.fz_nlazy; i += nth)          // one 8-byte word per triple: src1, src2, dst | shared << 15
+            reinterpret_cast<ushort4 *>(lazy)[i] = make_ushort4((unsigned short)pd.fz_lazy[3 * i], (unsigned short)pd.fz_lazy[3 * i + 1],
+                                                               (unsigned short)pd.fz_lazy[3 * i + 2], 0);
+        lds_load_system<T>(pd, a, Lw, z, lm, tid, nth);
+        __syncthreads();
+        if (PROF) { tload = clock64() - tall; tq = clock64(); }
+
+        const int nh = nw - 4;                                   // helper waves
+        if (wave < 4) {
+            // ================= column waves: q = wave & 1, diagonal wave (wave < 2) or row wave
+            const int q = wave & 1;
+            const bool is_row = wave >= 2;
+            int ra = __builtin_amdgcn_readfirstlane(lrec[4 * q]), rb = __builtin_amdgcn_readfirstlane(lrec[4 * q + 1]),
+                rd = __builtin_amdgcn_readfirstlane(lrec[4 * q + 3]), nc = (__builtin_amdgcn_readfirstlane(lrec[1]) >> 24) & 3;
+            int npc = 0;                                         // columns of the level below
+            for (int l = 0; l < nlev; ++l) {
+                const int ma = ra, mb = rb, md = rd, ncl = nc;
+                if (l + 1 < nlev) {                              // the next level's record, in flight during this level
+                    ra = __builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 4 * q]); rb = __builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 4 * q + 1]);
+                    rd = __builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 4 * q + 3]); nc = (__builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 1]) >> 24) & 3;
+                }
+                if (q < ncl) {
+                    if (l > 0) {
+                        wait_ge(&colready[0], l);
+                        if (npc > 1) wait_ge(&colready[1], l);
+                        wait_ge(&hcnt, nh * (l - 1));
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    BT_TW(twait);
+                    const int dpos = mb & 0xffff;
+                    if (!is_row) {
+                        // ---- diagonal wave: bring the diagonal block up to date with its pending updates (lanes 0..35,
+                        // one element each) and publish it to the row wave
+                        const int el = lane < 36 ? lane : lane - 36, dr = el / 6, dc = el - 6 * dr;
+                        const int sd = md & 0x7fff, nd = md >> 15;
+                        T x[6], yv[6];
+                        T v = Lw[(size_t)dpos * 36 + el];
+                        load_row6(Lw + (size_t)sd * 36 + 6 * dr, x);
+                        load_row6(Lw + (size_t)sd * 36 + 6 * dc, yv);
+                        if (nd > 0) {
+                            T acc = x[0] * yv[0];
+#pragma unroll
+                            for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
+                            v -= acc;
+                        }
+                        if (nd > 1) {                         // where chains merge: a second pending pair (from the level's other column)
+                            const T *src = Lw + (size_t)(psecond[dpos] & 0x7fff) * 36;
+                            load_row6(src + 6 * dr, x);
+                            load_row6(src + 6 * dc, yv);
+                            T acc = x[0] * yv[0];
+#pragma unroll
+                            for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
+                            v -= acc;
+                        }
+                        if (lane < 36) {
+                            scr[q * 36 + lane] = v;
+                            Lw[(size_t)dpos * 36 + lane] = v;          // in place as well: its next reader is the back substitution
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(&lready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        BT_TW(twork);
+                    } else {
+                        // ---- row wave: one panel row (or y_j) per lane: its pending update, then, once the diagonal wave
+                        // has published the updated block, its factorisation (every lane, in registers) and the forward
+                        // substitution of the row
+                        const int j = ma & 255, cnt = (ma >> 8) & 255, ysrc = (ma >> 16) & 255;
+                        const int rw = lane;
+                        const bool valid = rw <= cnt * 6, isy = rw == cnt * 6;
+                        const int sb = rw / 6, r = rw - 6 * sb, bown = dpos + 1 + sb;
+                        T *p = isy ? z + 6 * j : Lw + (size_t)bown * 36 + 6 * r;
+                        const unsigned pfo = (unsigned)pfirst[valid && !isy ? bown : dpos];
+                        const int s1 = pfo & 0x7fff, s2 = (pfo >> 15) & 0x7fff, no = valid ? (int)(pfo >> 30) : 0;
+                        T in[6], avec[6], m[36];
+                        load_row6(p, in);
+                        load_row6(isy ? z + 6 * ysrc : Lw + (size_t)s1 * 36 + 6 * r, avec);
+                        {
+                            const T *M = Lw + (size_t)(isy ? s1 : s2) * 36;
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) load_row6(M + 6 * c, reinterpret_cast<T (&)[6]>(m[6 * c]));
+                        }
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            T acc = avec[0] * m[6 * c];
+#pragma unroll
+                            for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
+                            in[c] -= no > 0 ? acc : (T)0;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(no > 1)) {       // where chains merge: a second pending pair
+                            const unsigned ps = (unsigned)psecond[isy ? dpos : bown];
+                            const int t1 = ps & 0x7fff, t2 = (ps >> 15) & 0x7fff;
+                            load_row6(isy ? z + 6 * ((row_idx[t1] >> 8) & 255) : Lw + (size_t)t1 * 36 + 6 * r, avec);
+                            const T *M = Lw + (size_t)(isy ? t1 : t2) * 36;
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) load_row6(M + 6 * c, reinterpret_cast<T (&)[6]>(m[6 * c]));
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) {
+                                T acc = avec[0] * m[6 * c];
+#pragma unroll
+                                for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
+                                in[c] -= no > 1 ? acc : (T)0;
+                            }
+                        }
+                        BT_TW(sub[0]);
+                        wait_ge(&lready[q], l + 1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        BT_TW(sub[1]);
+                        T L[21];
+                        {
+                            const T *dblk = scr + q * 36;
+#pragma unroll
+                            for (int rr = 0; rr < 6; ++rr) {
+                                T row[6];
+                                load_row6(dblk + 6 * rr, row);
+#pragma unroll
+                                for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
+                            }
+                        }
+                        const bool ok = chol6_packed<T>(L);
+                        if (!ok && lane == 0) flags[0] = 1;
+                        if (valid) {
+                            T out[6];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) {
+                                T t = in[c];
+#pragma unroll
+                                for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
+                                out[c] = t * L[BT_LT(c, c)];
+                            }
+                            store_row6(p, out);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(&colready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        BT_TW(sub[2]);
+                    }
+                }
+                npc = ncl;
+            }
+        } else {
+            // ================= helper waves: batch b = lazy updates and lazy y contributions of the columns of level b
+            const int h = tid - 256, hs = nth - 256;
+            for (int b = 0; b + 1 < nlev; ++b) {
+                const int p0a = __builtin_amdgcn_readfirstlane(lrec[8 * b]), p0b = __builtin_amdgcn_readfirstlane(lrec[8 * b + 1]),
+                          p0c = __builtin_amdgcn_readfirstlane(lrec[8 * b + 2]), p1a = __builtin_amdgcn_readfirstlane(lrec[8 * b + 4]),
+                          p1b = __builtin_amdgcn_readfirstlane(lrec[8 * b + 5]), p1c = __builtin_amdgcn_readfirstlane(lrec[8 * b + 6]);
+                const int pnc = (p0b >> 24) & 3;
+                wait_ge(&colready[0], b + 1);
+                if (pnc > 1) wait_ge(&colready[1], b + 1);
+                wait_ge(&hcnt, nh * b);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                BT_TW(twait);
+                const int rows0 = ((p0c >> 16) & 0xffff) * 6, rows1 = rows0 + (pnc > 1 ? ((p1c >> 16) & 0xffff) * 6 : 0);
+                for (int item = h; item < rows1; item += hs) {
+                    const bool sec = item >= rows0;
+                    const int idx = item - (sec ? rows0 : 0), t = idx / 6;
+                    const ushort4 tr = reinterpret_cast<const ushort4 *>(lazy)[((sec ? p1c : p0c) & 0xffff) + t];
+                    apply_update_row3<T>(Lw, tr.x, tr.y, tr.z, idx - 6 * t);
+                }
+                {
+                    const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
+                    const int shift = ((rows1 + 63) >> 6) << 6;
+                    int first = h - shift;                       // (no division in the usual one-round case)
+                    if (shift > hs) first = (h - shift % hs + hs) % hs; else if (first < 0) first += hs;
+                    for (int item = first; item < ys1; item += hs) {
+                        const bool sec = item >= ys0;
+                        const int qq = item - (sec ? ys0 : 0);
+                        const int pj = (sec ? p1a : p0a) & 255, dposp = (sec ? p1b : p0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
+                        const int rcv = row_idx[dposp + 1 + sb];
+                        if (rcv & (1 << 25)) continue;            // pending: the destination column's y thread takes it
+                        T lr[6], zr[6];
+                        load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
+                        load_row6(z + 6 * pj, zr);
+                        T acc = lr[0] * zr[0];
+#pragma unroll
+                        for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
+                        lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv & (1 << 24)) != 0);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(&hcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                BT_TW(twork);
+            }
+        }
+        __syncthreads();
+        if (PROF) tsweep = clock64() - tall;
+
+        int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
+        for (int i = tid; i < nlev * kMaxLevelCols; i += nth) {          // (col, diag pos, #sub-blocks, barrier before this level)
+            int4 mm = reinterpret_cast<const int4 *>(pd.fz_meta)[2 * i];
+            mm.w = pd.bs_sync[i / kMaxLevelCols];
+            bmeta[i] = mm;
+        }
+        lds_back_substitute<T, true>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth, nullptr);
+        for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
+        __syncthreads();
+        const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
+        __syncthreads();
+        if (failed) {
+            for (int i = tid; i < D; i += nth) zt[i] = (T)0;
+            status = BT_SOLVE_CHOL_FAILED;
+            break;
+        }
+        if (!has_nan) break;
+        status = BT_SOLVE_RETRIED;
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
+    if (tid == 0) a.status[0] = status;
+    if (PROF && lane == 0) {        // measurement only: per-wave (waiting, working) cycles of the sweep
+        long long *o = reinterpret_cast<long long *>(a.status + 4) + 40 + wave * 2;
+        o[0] = twait; o[1] = twork + sub[0] + sub[2];
+        if (wave == 0 || wave == 2) {
+            long long *g = reinterpret_cast<long long *>(a.status + 4) + (wave ? 10 : 0);
+            g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
+            g[3] = sub[0]; g[4] = sub[1]; g[5] = sub[2]; g[6] = twait;
+        }
+    }
+#undef BT_TW
+}
+
 // ------------------------------------------------------------------ k_update
 __device__ inline void retract_pose(const float *pin, const float *xi, float *pout) {
     // poses' = Exp(xi) * G  (groups.py:153-156; so3.h:153-190; se3.h:134-142), in double
@@ -1895,6 +2170,12 @@ static bool use_fused_solver(const PlanDev &pd) {
     return on != 0 && pd.fz_ok != 0 && solve_fused_lds_bytes(pd, solver_threads()) <= kLdsBudget;
 }
 
+// barrier-free variant of k_solve_fused; BT_SOLVER_PIPE=0: one workgroup barrier per level
+static bool use_pipe_solver(const PlanDev &pd) {
+    static const int on = std::getenv("BT_SOLVER_PIPE") ? std::atoi(std::getenv("BT_SOLVER_PIPE")) : 1;   // measurement only
+    return on != 0 && pd.fzp_ok != 0 && pd.fz_ok != 0 && solve_pipe_lds_bytes(pd) <= kLdsBudget;
+}
+
 static int solver_threads() {
     // 12 waves: enough helper threads for one round of update rows on banded systems, and a
     // 170-register budget per thread so that a whole 6x6 operand block can be in flight from LDS
@@ -1924,6 +2205,12 @@ int configure_kernels(const PlanDev &pd) {
             if (hipFuncSetAttribute(fns[2 * mode + v], hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)solve_lds_bytes(pd, mode == 0 ? 8 : 4)) != hipSuccess)
                 return BT_EHIP;
+    if (mode == 0 && use_pipe_solver(pd))
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_pipe<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_pipe_lds_bytes(pd)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_pipe<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_pipe_lds_bytes(pd)) != hipSuccess)
+            return BT_EHIP;
     if (mode == 0 && use_fused_solver(pd))
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)solve_fused_lds_bytes(pd, solver_threads())) != hipSuccess ||
@@ -1975,7 +2262,9 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int mode = solver_mode(pd);
         const bool prof = (a.dbg & 16) != 0;
         const int nthr = solver_threads();
-        if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH(3, k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
+        if (mode == 0 && use_pipe_solver(pd) && !prof)  BT_LAUNCH(3, k_solve_pipe<false>, dim3(1), dim3(768), solve_pipe_lds_bytes(pd), pd, a);
+        else if (mode == 0 && use_pipe_solver(pd))      BT_LAUNCH(3, k_solve_pipe<true>, dim3(1), dim3(768), solve_pipe_lds_bytes(pd), pd, a);
+        else if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH(3, k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
         else if (mode == 0 && use_fused_solver(pd))     BT_LAUNCH(3, k_solve_fused<true>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
         else if (mode == 0 && !prof) BT_LAUNCH(3, (k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
         else if (mode == 0)          BT_LAUNCH(3, (k_solve_lds<double, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);

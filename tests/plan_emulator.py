@@ -375,3 +375,114 @@ def sparse_chol_solve_fused(A, S_lower, y, n, ep, lm):
     out = np.zeros((n, 6))
     out[perm] = x.reshape(n, 6)
     return out
+
+
+def pipe_schedule_applies(A):
+    """The plan-side condition of k_solve_pipe (ba_plan.cpp: fzp_ok)."""
+    col_ptr, lvl_ptr = A["col_ptr"], A["lvl_ptr"]
+    n = len(col_ptr) - 1
+    return (n > 0 and np.diff(lvl_ptr).max() <= 2 and np.diff(A["fz_pend_ptr"]).max(initial=0) <= 2 and
+            all(6 * (col_ptr[j + 1] - col_ptr[j] - 1) + 1 <= 64 for j in range(n)))
+
+
+def check_pipe_protocol(A, nw=12):
+    """k_solve_pipe has no workgroup barrier in the sweep: waves with fixed roles are ordered by the flags
+    lready / colready / hcnt only.  Build the happens-before relation those waits imply (program order per
+    wave + flag edges) and verify that EVERY pair of steps touching the same data with at least one write is
+    ordered by it.  Steps: D(l, q) diagonal wave, R(l, q) row wave, H(b, w) helper wave w on lazy batch b."""
+    col_ptr, row_idx = A["col_ptr"], A["row_idx"]
+    blk_col = A["blk_col"] & 255
+    lvl_ptr, lvl_cols = A["lvl_ptr"], A["lvl_cols"]
+    pend_ptr, pend = A["fz_pend_ptr"], A["fz_pend"].reshape(-1, 2)
+    lazy_ptr, lazy, yurg = A["fz_lazy_ptr"], A["fz_lazy"].reshape(-1, 3), A["fz_yurg"]
+    nlev = len(lvl_ptr) - 1
+    nh, hs = nw - 4, (nw - 4) * 64
+    cols = [[int(c) for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]] for l in range(nlev)]
+    nodes, idx = [], {}
+
+    def add(key, reads, writes):
+        idx[key] = len(nodes)
+        nodes.append((key, reads, writes))
+
+    ROWS = range(6)
+    for l in range(nlev):
+        for q, c in enumerate(cols[l]):
+            d = int(col_ptr[c])
+            srcs = {(int(s1), r) for s1, _ in pend[pend_ptr[d]:pend_ptr[d + 1]] for r in ROWS}
+            add(("D", l, q), {(d, r) for r in ROWS} | srcs, {(d, r) for r in ROWS} | {("scr", q)})
+            reads, writes = {("scr", q), ("z", c)}, {("z", c)}
+            for b in range(d + 1, int(col_ptr[c + 1])):
+                writes |= {(b, r) for r in ROWS}
+                reads |= {(b, r) for r in ROWS}
+                for s1, s2 in pend[pend_ptr[b]:pend_ptr[b + 1]]:
+                    reads |= {(int(s1), r) for r in ROWS} | {(int(s2), r) for r in ROWS}
+            for s1, _ in pend[pend_ptr[d]:pend_ptr[d + 1]]:                  # pending y contributions
+                reads |= {(int(s1), r) for r in ROWS} | {("z", int(blk_col[s1]))}
+            add(("R", l, q), reads, writes)
+    for b in range(nlev - 1):
+        per_wave = [(set(), set()) for _ in range(nh)]
+        item = 0
+        for c in cols[b]:
+            for s1, s2, dstf in lazy[lazy_ptr[c]:lazy_ptr[c + 1]]:
+                for r in ROWS:
+                    w = (item % hs) // 64
+                    per_wave[w][0].update({(int(s1), r)} | {(int(s2), rr) for rr in ROWS} | {(int(dstf) & 0x7fff, r)})
+                    per_wave[w][1].add((int(dstf) & 0x7fff, r))
+                    item += 1
+        shift = ((item + 63) // 64) * 64
+        yi = 0
+        for c in cols[b]:
+            for blk in range(int(col_ptr[c]) + 1, int(col_ptr[c + 1])):
+                for r in ROWS:
+                    if not yurg[blk]:
+                        w = ((shift + yi) % hs) // 64
+                        per_wave[w][0].update({(blk, r), ("z", c), ("z", int(row_idx[blk]))})
+                        per_wave[w][1].add(("z", int(row_idx[blk])))
+                    yi += 1
+        for w in range(nh):
+            add(("H", b, w), per_wave[w][0], per_wave[w][1])
+    N = len(nodes)
+    hb = np.zeros((N, N), bool)
+
+    def edge(a, b):
+        if a in idx and b in idx:
+            hb[idx[a], idx[b]] = True
+
+    for q in range(2):                                           # program order of the column waves
+        for kind in "DR":
+            seq = [(kind, l, q) for l in range(nlev) if q < len(cols[l])]
+            for x, y in zip(seq, seq[1:]):
+                edge(x, y)
+    for w in range(nh):
+        for b in range(nlev - 2):
+            edge(("H", b, w), ("H", b + 1, w))
+    for l in range(nlev):
+        for q in range(len(cols[l])):
+            edge(("D", l, q), ("R", l, q))                       # lready
+            if l > 0:
+                for q2 in range(len(cols[l - 1])):               # colready of the level below
+                    edge(("R", l - 1, q2), ("D", l, q)); edge(("R", l - 1, q2), ("R", l, q))
+            if l >= 2:
+                for w in range(nh):                              # hcnt >= nh (l - 1): batches 0 .. l - 2 complete
+                    edge(("H", l - 2, w), ("D", l, q)); edge(("H", l - 2, w), ("R", l, q))
+    for b in range(nlev - 1):
+        for w in range(nh):
+            for q2 in range(len(cols[b])):
+                edge(("R", b, q2), ("H", b, w))                  # sources of the batch
+            if b > 0:
+                for w2 in range(nh):
+                    edge(("H", b - 1, w2), ("H", b, w))          # hcnt >= nh b: the group has finished the batches before
+    for k in range(N):                                           # transitive closure (Warshall, vectorised)
+        hb |= np.outer(hb[:, k], hb[k, :])
+    bad = []
+    for i in range(N):
+        ki, ri, wi = nodes[i]
+        for j in range(i + 1, N):
+            kj, rj, wj = nodes[j]
+            if ki[0] == "H" and kj[0] == "H" and ki[1] == kj[1]:
+                continue                                         # same batch: shared destinations carry the atomic flag (checked elsewhere)
+            if (wi & (rj | wj)) or (wj & ri):
+                if not (hb[i, j] or hb[j, i]):
+                    bad.append((ki, kj, sorted((wi & (rj | wj)) | (wj & ri), key=str)[:3]))
+    assert not bad, f"unordered conflicting steps, e.g. {bad[:3]}"
+    return N

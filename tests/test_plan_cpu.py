@@ -195,3 +195,19 @@ def test_plan_limits():
     # a track whose edges name two source frames (the caller's invariant ii = ix[kk], batrack.py:199)
     with pytest.raises(RuntimeError, match="unsupported"):
         Plan(np.array([0, 1], np.int64), np.array([2, 3], np.int64), np.array([5, 5], np.int64), 4, 8, 1, upload=False)
+
+
+def test_barrier_free_solver_schedule_orders_every_conflict():
+    """k_solve_pipe synchronises its waves with three kinds of flags instead of a barrier per level; the waits it
+    makes must order every pair of steps that touch the same block, y segment or scratch with a write involved."""
+    from plan_emulator import check_pipe_protocol, pipe_schedule_applies
+    g = graphgen.make_config("C3", seed=0)
+    pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
+    A = pl.arrays()
+    assert pipe_schedule_applies(A)
+    assert check_pipe_protocol(A) > 300
+    for N, M, K, fp in ((48, 16, 8, 1), (12, 8, 4, 1), (9, 8, 8, 1), (40, 4, 6, 3)):
+        gg = graphgen.make_graph(N, M, K, seed=3)
+        A = Plan(gg.ii, gg.jj, gg.kk, gg.poses.shape[0], gg.patches.shape[0], fp, upload=False).arrays()
+        assert pipe_schedule_applies(A)
+        check_pipe_protocol(A)
