@@ -1800,10 +1800,15 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                     rd = __builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 4 * q + 3]); nc = (__builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 1]) >> 24) & 3;
                 }
                 if (q < ncl) {
-                    if (l > 0) {
-                        wait_ge(&colready[0], l);
-                        if (npc > 1) wait_ge(&colready[1], l);
-                        wait_ge(&hcnt, nh * (l - 1));
+                    if (l > 0) {                                 // the three flags in one LDS round trip
+                        const int need1 = npc > 1 ? l : 0, needh = nh * (l - 1);
+                        for (;;) {
+                            const int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const int f1 = __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const int fh = __hip_atomic_load(&hcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (f0 >= l && f1 >= need1 && fh >= needh) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
                     BT_TW(twait);
@@ -1923,9 +1928,16 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                           p0c = __builtin_amdgcn_readfirstlane(lrec[8 * b + 2]), p1a = __builtin_amdgcn_readfirstlane(lrec[8 * b + 4]),
                           p1b = __builtin_amdgcn_readfirstlane(lrec[8 * b + 5]), p1c = __builtin_amdgcn_readfirstlane(lrec[8 * b + 6]);
                 const int pnc = (p0b >> 24) & 3;
-                wait_ge(&colready[0], b + 1);
-                if (pnc > 1) wait_ge(&colready[1], b + 1);
-                wait_ge(&hcnt, nh * b);
+                {
+                    const int need1 = pnc > 1 ? b + 1 : 0;
+                    for (;;) {
+                        const int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const int f1 = __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const int fh = __hip_atomic_load(&hcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (f0 >= b + 1 && f1 >= need1 && fh >= nh * b) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 BT_TW(twait);
                 const int rows0 = ((p0c >> 16) & 0xffff) * 6, rows1 = rows0 + (pnc > 1 ? ((p1c >> 16) & 0xffff) * 6 : 0);
