@@ -1535,7 +1535,7 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
                     // updates (lanes 0..35, one element each) and publish it to the column's row waves
                     const int q = aw, dpos = (q ? c1b : c0b) & 0xffff, md = q ? c1d : c0d;
                     const int el = lane < 36 ? lane : lane - 36, dr = el / 6, dc = el - 6 * dr;
-                    const int sd = md & 0x7fff, nd = md >> 15;
+                    const int sd = md & 0x7fff, nd = (md >> 15) & 3;
                     T x[6], yv[6];
                     T v = Lw[(size_t)dpos * 36 + el];
                     load_row6(Lw + (size_t)sd * 36 + 6 * dr, x);
@@ -1730,9 +1730,10 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
 //   waves 4 ..             helpers: batch b = the lazy updates whose sources are the columns of level b;
 //                          every helper wave adds 1 to hcnt when it has finished its share of a batch
 // What a step waits for (tests/plan_emulator.py checks that these waits order every conflicting access):
-//   column waves, level l   colready[*] >= l for the columns of level l - 1 (pending sources; the scratch
-//                           of the diagonal block is free again) and hcnt >= nh (l - 1): batches 0 .. l - 2
-//                           are complete, i.e. every lazy update into this level's blocks has landed
+//   column waves, level l   colready[s] >= l for the columns s of level l - 1 that hold pending sources of this
+//                           column (on a chain: its own predecessor only, so the two chains do not wait for
+//                           each other) and hcnt >= nh (l - 1): batches 0 .. l - 2 are complete, i.e. every
+//                           lazy update into this level's blocks has landed
 //   row wave                additionally lready[q] >= l + 1 before it factors
 //   helpers, batch b        colready[*] >= b + 1 for the columns of level b (its sources) and
 //                           hcnt >= nh b (the whole group has finished the batches before: two batches may
@@ -1800,13 +1801,18 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                     rd = __builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 4 * q + 3]); nc = (__builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 1]) >> 24) & 3;
                 }
                 if (q < ncl) {
-                    if (l > 0) {                                 // the three flags in one LDS round trip
-                        const int need1 = npc > 1 ? l : 0, needh = nh * (l - 1);
+                    if (l > 0) {
+                        // only the columns of the level below that hold pending sources of this column (the record's
+                        // dependency bits: on a chain its own predecessor, which this very row wave wrote) and the
+                        // helpers' batches; the three flags in one LDS round trip
+                        // (the diagonal wave also waits for the row wave that last read its scratch slot)
+                        const int dep = ((md >> 20) & 3) | ((!is_row && q < npc) ? 1 << q : 0);
+                        const int need0 = (dep & 1) ? l : 0, need1 = (dep & 2) ? l : 0, needh = nh * (l - 1);
                         for (;;) {
                             const int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const int f1 = __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const int fh = __hip_atomic_load(&hcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (f0 >= l && f1 >= need1 && fh >= needh) break;
+                            if (f0 >= need0 && f1 >= need1 && fh >= needh) break;
                             __builtin_amdgcn_s_sleep(1);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1817,7 +1823,7 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                         // ---- diagonal wave: bring the diagonal block up to date with its pending updates (lanes 0..35,
                         // one element each) and publish it to the row wave
                         const int el = lane < 36 ? lane : lane - 36, dr = el / 6, dc = el - 6 * dr;
-                        const int sd = md & 0x7fff, nd = md >> 15;
+                        const int sd = md & 0x7fff, nd = (md >> 15) & 3;
                         T x[6], yv[6];
                         T v = Lw[(size_t)dpos * 36 + el];
                         load_row6(Lw + (size_t)sd * 36 + 6 * dr, x);

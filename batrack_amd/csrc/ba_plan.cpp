@@ -519,7 +519,16 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
                 m[4 * q] = j | (cnt << 8) | (ysrc << 16);
                 m[4 * q + 1] = dpos | (((6 * cnt + 1 + 63) / 64) << 16);
                 m[4 * q + 2] = lz0 | (nlz << 16);
-                m[4 * q + 3] = sd | ((np < 3 ? np : 3) << 15);
+                // which columns (slots) of the level below hold pending sources of this column's blocks: only those
+                // have to be waited for by the barrier-free solver (bits 20, 21)
+                int32_t dep = 0;
+                for (int32_t b = dpos; b < pl->col_ptr[(size_t)j + 1]; ++b)
+                    for (int32_t k = pl->fz_pend_ptr[(size_t)b]; k < pl->fz_pend_ptr[(size_t)b + 1]; ++k) {
+                        const int32_t sc = pl->blk_col[(size_t)pl->fz_pend[(size_t)k * 2]] & 255;
+                        for (int32_t q2 = 0; l > 0 && q2 < pl->lvl_ptr[(size_t)l] - pl->lvl_ptr[(size_t)l - 1]; ++q2)
+                            if (pl->lvl_cols[(size_t)pl->lvl_ptr[(size_t)l - 1] + q2] == sc) dep |= 1 << q2;
+                    }
+                m[4 * q + 3] = sd | ((np < 3 ? np : 3) << 15) | (dep << 20);
             }
             m[1] |= nc << 24;
         }

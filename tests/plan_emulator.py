@@ -302,7 +302,7 @@ def sparse_chol_solve_fused(A, S_lower, y, n, ep, lm):
             ysrc = int(blk_col[sd]) if npd else 0
             assert pm[4*q] == (c | cnt << 8 | ysrc << 16) and (pm[4*q + 1] & 0xffffff) == (d | ((6 * cnt + 1 + 63) // 64) << 16)
             assert pm[4*q + 2] == (int(lazy_ptr[c]) | (int(lazy_ptr[c + 1] - lazy_ptr[c]) << 16))
-            assert pm[4*q + 3] == (sd | min(npd, 3) << 15)
+            assert (pm[4*q + 3] & 0xfffff) == (sd | min(npd, 3) << 15)
         a_reads, a_writes = set(), set()              # blocks; ("z", col) for y segments
         for c in cols:
             d = int(col_ptr[c])
@@ -460,8 +460,12 @@ def check_pipe_protocol(A, nw=12):
         for q in range(len(cols[l])):
             edge(("D", l, q), ("R", l, q))                       # lready
             if l > 0:
-                for q2 in range(len(cols[l - 1])):               # colready of the level below
-                    edge(("R", l - 1, q2), ("D", l, q)); edge(("R", l - 1, q2), ("R", l, q))
+                dep = (int(A["fz_pmeta"].reshape(-1, 8)[l][4 * q + 3]) >> 20) & 3
+                for q2 in range(len(cols[l - 1])):               # colready of the columns that hold pending sources
+                    if dep >> q2 & 1:
+                        edge(("R", l - 1, q2), ("D", l, q)); edge(("R", l - 1, q2), ("R", l, q))
+                if q < len(cols[l - 1]):                         # the diagonal wave's scratch slot: its last reader
+                    edge(("R", l - 1, q), ("D", l, q))
             if l >= 2:
                 for w in range(nh):                              # hcnt >= nh (l - 1): batches 0 .. l - 2 complete
                     edge(("H", l - 2, w), ("D", l, q)); edge(("H", l - 2, w), ("R", l, q))
