@@ -1791,15 +1791,14 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
             // ================= column waves: q = wave & 1, diagonal wave (wave < 2) or row wave
             const int q = wave & 1;
             const bool is_row = wave >= 2;
-            int ra = __builtin_amdgcn_readfirstlane(lrec[4 * q]), rb = __builtin_amdgcn_readfirstlane(lrec[4 * q + 1]),
-                rd = __builtin_amdgcn_readfirstlane(lrec[4 * q + 3]), nc = (__builtin_amdgcn_readfirstlane(lrec[1]) >> 24) & 3;
+            const int4 *lrec4 = reinterpret_cast<const int4 *>(lrec);
+            int4 vrec = lrec4[q];                                // this wave's record and slot 0's (it carries the number of columns)
+            int vnc = lrec[1];
             int npc = 0;                                         // columns of the level below
             for (int l = 0; l < nlev; ++l) {
-                const int ma = ra, mb = rb, md = rd, ncl = nc;
-                if (l + 1 < nlev) {                              // the next level's record, in flight during this level
-                    ra = __builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 4 * q]); rb = __builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 4 * q + 1]);
-                    rd = __builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 4 * q + 3]); nc = (__builtin_amdgcn_readfirstlane(lrec[8 * (l + 1) + 1]) >> 24) & 3;
-                }
+                const int ma = __builtin_amdgcn_readfirstlane(vrec.x), mb = __builtin_amdgcn_readfirstlane(vrec.y),
+                          md = __builtin_amdgcn_readfirstlane(vrec.w), ncl = (__builtin_amdgcn_readfirstlane(vnc) >> 24) & 3;
+                if (l + 1 < nlev) { vrec = lrec4[2 * (l + 1) + q]; vnc = lrec[8 * (l + 1) + 1]; }   // next level's, in flight during this one
                 if (q < ncl) {
                     if (l > 0) {
                         // only the columns of the level below that hold pending sources of this column (the record's
