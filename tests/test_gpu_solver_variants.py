@@ -1,8 +1,8 @@
 """-m gpu: every reduced-system solver variant gives the reference's pose update.
 
 The library picks the variant from the system's size (ba_kernels.hip: solver_mode,
-use_fused_solver): the one-phase-per-level double LDS kernel (default), the two-phase double
-LDS kernel (levels wider than two columns), the float LDS kernel and the global-memory kernel
+use_pipe_solver, use_fused_solver): the barrier-free double LDS kernel (default where it applies), the
+one-phase-per-level kernel with a barrier per level, the two-phase double LDS kernel (levels wider than two columns), the float LDS kernel and the global-memory kernel
 (systems too large for LDS).  The environment switches that force a variant are read once per
 process, so each case runs in its own interpreter."""
 import json
@@ -44,8 +44,9 @@ print("RESULT " + json.dumps(out))
 # the reference itself (its own float32 run is 5e-3 off in dX on these fixtures).
 VARIANTS = [
     ({}, 2e-3, 1e-5),
-    ({"BT_SOLVER_FUSED": "0"}, 2e-3, 1e-5),
-    ({"BT_SOLVER_FUSED": "0", "BT_SOLVER_ORDER": "0"}, 2e-3, 1e-5),
+    ({"BT_SOLVER_PIPE": "0"}, 2e-3, 1e-5),
+    ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0"}, 2e-3, 1e-5),
+    ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0", "BT_SOLVER_ORDER": "0"}, 2e-3, 1e-5),
     ({"BT_SOLVER_MODE": "1"}, 2e-2, 1e-4),
     ({"BT_SOLVER_MODE": "2"}, 2e-2, 1e-4),
 ]
