@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
     typedef double T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[2];
-    __shared__ int lready[2], colready[4], hcnt;            // colready[2 q + part]
+    __shared__ int lready[2], colready[2], hcnt;
     const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
     const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
     T *Lw = reinterpret_cast<T *>(smem);
@@ -1777,9 +1777,8 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
     int status = BT_SOLVE_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const double lm = attempt == 0 ? 1e-4 : 1e-3;
-        if (tid < 2) { flags[tid] = 0; lready[tid] = 0; }
-        if (tid < 4) colready[tid] = 0;
-        if (tid == 4) hcnt = 0;
+        if (tid < 2) { flags[tid] = 0; lready[tid] = 0; colready[tid] = 0; }
+        if (tid == 2) hcnt = 0;
         for (int i = tid; i < pd.fz_nlazy; i += nth)          // one 8-byte word per triple: src1, src2, dst | shared << 15
             reinterpret_cast<ushort4 *>(lazy)[i] = make_ushort4((unsigned short)pd.fz_lazy[3 * i], (unsigned short)pd.fz_lazy[3 * i + 1],
                                                                (unsigned short)pd.fz_lazy[3 * i + 2], 0);
@@ -1787,11 +1786,10 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
         __syncthreads();
         if (PROF) { tload = clock64() - tall; tq = clock64(); }
 
-        const int R = pd.fzp_rw, first_helper = 2 + 2 * R;       // row waves per column (1 or 2); waves 2 + 2 part + q
-        const int nh = nw - first_helper;                        // helper waves
-        if (wave < first_helper) {
-            // ================= column waves: q = wave & 1, diagonal wave (wave < 2) or row wave `part` of the column
-            const int q = wave & 1, part = wave < 2 ? 0 : (wave - 2) >> 1;
+        const int nh = nw - 4;                                   // helper waves
+        if (wave < 4) {
+            // ================= column waves: q = wave & 1, diagonal wave (wave < 2) or row wave
+            const int q = wave & 1;
             const bool is_row = wave >= 2;
             const int4 *lrec4 = reinterpret_cast<const int4 *>(lrec);
             int4 vrec = lrec4[q];                                // this wave's record and slot 0's (it carries the number of columns)
@@ -1810,12 +1808,8 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                         const int dep = ((md >> 20) & 3) | ((!is_row && q < npc) ? 1 << q : 0);
                         const int need0 = (dep & 1) ? l : 0, need1 = (dep & 2) ? l : 0, needh = nh * (l - 1);
                         for (;;) {
-                            int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            int f1 = __hip_atomic_load(&colready[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (R > 1) {                             // both row waves of a column
-                                f0 = min(f0, __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                                f1 = min(f1, __hip_atomic_load(&colready[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            }
+                            const int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const int f1 = __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const int fh = __hip_atomic_load(&hcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (f0 >= need0 && f1 >= need1 && fh >= needh) break;
                             __builtin_amdgcn_s_sleep(1);
@@ -1860,7 +1854,7 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                         // has published the updated block, its factorisation (every lane, in registers) and the forward
                         // substitution of the row
                         const int j = ma & 255, cnt = (ma >> 8) & 255, ysrc = (ma >> 16) & 255;
-                        const int rw = part * 64 + lane;
+                        const int rw = lane;
                         const bool valid = rw <= cnt * 6, isy = rw == cnt * 6;
                         const int sb = rw / 6, r = rw - 6 * sb, bown = dpos + 1 + sb;
                         T *p = isy ? z + 6 * j : Lw + (size_t)bown * 36 + 6 * r;
@@ -1912,7 +1906,7 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                             }
                         }
                         const bool ok = chol6_packed<T>(L);
-                        if (!ok && part == 0 && lane == 0) flags[0] = 1;
+                        if (!ok && lane == 0) flags[0] = 1;
                         if (valid) {
                             T out[6];
 #pragma unroll
@@ -1925,7 +1919,7 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                             store_row6(p, out);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) __hip_atomic_store(&colready[2 * q + part], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (lane == 0) __hip_atomic_store(&colready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         BT_TW(sub[2]);
                     }
                 }
@@ -1933,7 +1927,7 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
             }
         } else {
             // ================= helper waves: batch b = lazy updates and lazy y contributions of the columns of level b
-            const int h = tid - 64 * first_helper, hs = nth - 64 * first_helper;
+            const int h = tid - 256, hs = nth - 256;
             for (int b = 0; b + 1 < nlev; ++b) {
                 const int p0a = __builtin_amdgcn_readfirstlane(lrec[8 * b]), p0b = __builtin_amdgcn_readfirstlane(lrec[8 * b + 1]),
                           p0c = __builtin_amdgcn_readfirstlane(lrec[8 * b + 2]), p1a = __builtin_amdgcn_readfirstlane(lrec[8 * b + 4]),
@@ -1942,12 +1936,8 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                 {
                     const int need1 = pnc > 1 ? b + 1 : 0;
                     for (;;) {
-                        int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        int f1 = __hip_atomic_load(&colready[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (R > 1) {
-                            f0 = min(f0, __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            f1 = min(f1, __hip_atomic_load(&colready[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        }
+                        const int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const int f1 = __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         const int fh = __hip_atomic_load(&hcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (f0 >= b + 1 && f1 >= need1 && fh >= nh * b) break;
                         __builtin_amdgcn_s_sleep(1);

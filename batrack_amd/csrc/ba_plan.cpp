@@ -571,13 +571,8 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
         pl->fz_meta.assign((size_t)nlev * kMaxLevelCols * 8, 0);
         pl->fz_ok = (pl->fz_lazy.size() / 3 < 65536 && pl->row_idx.size() < 32768 && pend_ok) ? 1 : 0;
-        pl->fzp_ok = pl->fz_ok;                          // additionally: every column's panel rows (+ y) fit two waves
-        pl->fzp_rw = 1;                                  // row waves per column the barrier-free solver needs (1 or 2)
-        for (int64_t j = 0; j < n; ++j) {
-            const int32_t rows = 6 * (pl->col_ptr[(size_t)j + 1] - pl->col_ptr[(size_t)j] - 1) + 1;
-            if (rows > 128) pl->fzp_ok = 0;
-            if (rows > 64) pl->fzp_rw = 2;
-        }
+        pl->fzp_ok = pl->fz_ok;                          // additionally: every column's panel rows (+ y) fit one wave
+        for (int64_t j = 0; j < n; ++j) if (6 * (pl->col_ptr[(size_t)j + 1] - pl->col_ptr[(size_t)j] - 1) + 1 > 64) pl->fzp_ok = 0;
         for (int32_t l = 0; l < nlev; ++l) {
             if (pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l] > 2) { pl->fz_ok = 0; pl->fzp_ok = 0; }
             int32_t w0 = 0;

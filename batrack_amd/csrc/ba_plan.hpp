@@ -41,7 +41,7 @@ struct PlanDev {
     // fused schedule (k_solve_fused): pending updates per destination block, lazy triples per column
     const int32_t *fz_pend_ptr, *fz_pend, *fz_lazy_ptr, *fz_lazy, *fz_yurg, *fz_meta, *fz_pmeta, *bs_sync, *fz_rowinfo, *fz_pfirst, *fz_psecond;
     int fz_npend, fz_nlazy, fz_ok;      // fz_ok: no level has more than two columns
-    int fzp_ok, fzp_rw;                 // and every column's panel fits fzp_rw (1 or 2) waves (k_solve_pipe)
+    int fzp_ok;                         // and every column's panel fits one wave (k_solve_pipe)
     const int32_t *lvl_meta;   // [nlev][kMaxLevelCols][8]: col, diag pos, #sub-blocks, first rest triple, #rest triples, dp first, #dp, 0  (col = -1: unused)
 };
 
@@ -67,7 +67,7 @@ struct bt_plan {
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
     std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp, lvl_meta;
     std::vector<int32_t> fz_pend_ptr, fz_pend, fz_lazy_ptr, fz_lazy, fz_yurg, fz_meta, fz_pmeta, bs_sync, fz_rowinfo, fz_pfirst, fz_psecond;   // fused schedule (k_solve_fused)
-    int fz_ok = 0, fzp_ok = 0, fzp_rw = 1;
+    int fz_ok = 0, fzp_ok = 0;
     int max_rows16 = 16;
     bt::WsLayout ws{};
     void *dev_base = nullptr;   // one device allocation holding every array above

@@ -378,30 +378,25 @@ def sparse_chol_solve_fused(A, S_lower, y, n, ep, lm):
 
 
 def pipe_schedule_applies(A):
-    """The plan-side condition of k_solve_pipe (ba_plan.cpp: fzp_ok) and the row waves per column it needs."""
+    """The plan-side condition of k_solve_pipe (ba_plan.cpp: fzp_ok)."""
     col_ptr, lvl_ptr = A["col_ptr"], A["lvl_ptr"]
     n = len(col_ptr) - 1
-    rows = [6 * (col_ptr[j + 1] - col_ptr[j] - 1) + 1 for j in range(n)]
-    ok = (n > 0 and np.diff(lvl_ptr).max() <= 2 and np.diff(A["fz_pend_ptr"]).max(initial=0) <= 2 and max(rows) <= 128)
-    return (2 if max(rows, default=0) > 64 else 1) if ok else 0
+    return (n > 0 and np.diff(lvl_ptr).max() <= 2 and np.diff(A["fz_pend_ptr"]).max(initial=0) <= 2 and
+            all(6 * (col_ptr[j + 1] - col_ptr[j] - 1) + 1 <= 64 for j in range(n)))
 
 
 def check_pipe_protocol(A, nw=12):
     """k_solve_pipe has no workgroup barrier in the sweep: waves with fixed roles are ordered by the flags
     lready / colready / hcnt only.  Build the happens-before relation those waits imply (program order per
     wave + flag edges) and verify that EVERY pair of steps touching the same data with at least one write is
-    ordered by it.  Steps: D(l, q) diagonal wave, R(l, q, part) row waves, H(b, w) helper wave w on lazy batch b."""
+    ordered by it.  Steps: D(l, q) diagonal wave, R(l, q) row wave, H(b, w) helper wave w on lazy batch b."""
     col_ptr, row_idx = A["col_ptr"], A["row_idx"]
     blk_col = A["blk_col"] & 255
     lvl_ptr, lvl_cols = A["lvl_ptr"], A["lvl_cols"]
     pend_ptr, pend = A["fz_pend_ptr"], A["fz_pend"].reshape(-1, 2)
     lazy_ptr, lazy, yurg = A["fz_lazy_ptr"], A["fz_lazy"].reshape(-1, 3), A["fz_yurg"]
-    pmeta = A["fz_pmeta"].reshape(-1, 8)
     nlev = len(lvl_ptr) - 1
-    R = pipe_schedule_applies(A)
-    assert R in (1, 2)
-    first_helper = 2 + 2 * R
-    nh, hs = nw - first_helper, (nw - first_helper) * 64
+    nh, hs = nw - 4, (nw - 4) * 64
     cols = [[int(c) for c in lvl_cols[lvl_ptr[l]:lvl_ptr[l + 1]]] for l in range(nlev)]
     nodes, idx = [], {}
 
@@ -412,22 +407,18 @@ def check_pipe_protocol(A, nw=12):
     ROWS = range(6)
     for l in range(nlev):
         for q, c in enumerate(cols[l]):
-            d = int(col_ptr[c]); cnt = int(col_ptr[c + 1]) - d - 1
+            d = int(col_ptr[c])
             srcs = {(int(s1), r) for s1, _ in pend[pend_ptr[d]:pend_ptr[d + 1]] for r in ROWS}
             add(("D", l, q), {(d, r) for r in ROWS} | srcs, {(d, r) for r in ROWS} | {("scr", q)})
-            for part in range(R):
-                reads, writes = {("scr", q)}, set()
-                for rw in range(64 * part, 64 * part + 64):
-                    if rw < 6 * cnt:
-                        b, r = d + 1 + rw // 6, rw % 6
-                        writes.add((b, r)); reads.add((b, r))
-                        for s1, s2 in pend[pend_ptr[b]:pend_ptr[b + 1]]:
-                            reads |= {(int(s1), r)} | {(int(s2), rr) for rr in ROWS}
-                    elif rw == 6 * cnt:                                      # the y row
-                        reads.add(("z", c)); writes.add(("z", c))
-                        for s1, _ in pend[pend_ptr[d]:pend_ptr[d + 1]]:
-                            reads |= {(int(s1), rr) for rr in ROWS} | {("z", int(blk_col[s1]))}
-                add(("R", l, q, part), reads, writes)
+            reads, writes = {("scr", q), ("z", c)}, {("z", c)}
+            for b in range(d + 1, int(col_ptr[c + 1])):
+                writes |= {(b, r) for r in ROWS}
+                reads |= {(b, r) for r in ROWS}
+                for s1, s2 in pend[pend_ptr[b]:pend_ptr[b + 1]]:
+                    reads |= {(int(s1), r) for r in ROWS} | {(int(s2), r) for r in ROWS}
+            for s1, _ in pend[pend_ptr[d]:pend_ptr[d + 1]]:                  # pending y contributions
+                reads |= {(int(s1), r) for r in ROWS} | {("z", int(blk_col[s1]))}
+            add(("R", l, q), reads, writes)
     for b in range(nlev - 1):
         per_wave = [(set(), set()) for _ in range(nh)]
         item = 0
@@ -458,11 +449,8 @@ def check_pipe_protocol(A, nw=12):
             hb[idx[a], idx[b]] = True
 
     for q in range(2):                                           # program order of the column waves
-        seq = [("D", l, q) for l in range(nlev) if q < len(cols[l])]
-        for x, y in zip(seq, seq[1:]):
-            edge(x, y)
-        for part in range(R):
-            seq = [("R", l, q, part) for l in range(nlev) if q < len(cols[l])]
+        for kind in "DR":
+            seq = [(kind, l, q) for l in range(nlev) if q < len(cols[l])]
             for x, y in zip(seq, seq[1:]):
                 edge(x, y)
     for w in range(nh):
@@ -470,28 +458,21 @@ def check_pipe_protocol(A, nw=12):
             edge(("H", b, w), ("H", b + 1, w))
     for l in range(nlev):
         for q in range(len(cols[l])):
-            mine = [("D", l, q)] + [("R", l, q, part) for part in range(R)]
-            for part in range(R):
-                edge(("D", l, q), ("R", l, q, part))             # lready
+            edge(("D", l, q), ("R", l, q))                       # lready
             if l > 0:
-                dep = (int(pmeta[l][4 * q + 3]) >> 20) & 3
-                for q2 in range(len(cols[l - 1])):               # colready (all parts) of the columns that hold pending sources
+                dep = (int(A["fz_pmeta"].reshape(-1, 8)[l][4 * q + 3]) >> 20) & 3
+                for q2 in range(len(cols[l - 1])):               # colready of the columns that hold pending sources
                     if dep >> q2 & 1:
-                        for part in range(R):
-                            for m in mine:
-                                edge(("R", l - 1, q2, part), m)
-                if q < len(cols[l - 1]):                         # the diagonal wave's scratch slot: its last readers
-                    for part in range(R):
-                        edge(("R", l - 1, q, part), ("D", l, q))
+                        edge(("R", l - 1, q2), ("D", l, q)); edge(("R", l - 1, q2), ("R", l, q))
+                if q < len(cols[l - 1]):                         # the diagonal wave's scratch slot: its last reader
+                    edge(("R", l - 1, q), ("D", l, q))
             if l >= 2:
                 for w in range(nh):                              # hcnt >= nh (l - 1): batches 0 .. l - 2 complete
-                    for m in mine:
-                        edge(("H", l - 2, w), m)
+                    edge(("H", l - 2, w), ("D", l, q)); edge(("H", l - 2, w), ("R", l, q))
     for b in range(nlev - 1):
         for w in range(nh):
             for q2 in range(len(cols[b])):
-                for part in range(R):
-                    edge(("R", b, q2, part), ("H", b, w))        # sources of the batch
+                edge(("R", b, q2), ("H", b, w))                  # sources of the batch
             if b > 0:
                 for w2 in range(nh):
                     edge(("H", b - 1, w2), ("H", b, w))          # hcnt >= nh b: the group has finished the batches before

@@ -206,12 +206,8 @@ def test_barrier_free_solver_schedule_orders_every_conflict():
     A = pl.arrays()
     assert pipe_schedule_applies(A)
     assert check_pipe_protocol(A) > 300
-    for N, M, K, fp in ((48, 16, 8, 1), (12, 8, 4, 1), (9, 8, 8, 1), (30, 8, 5, 1), (20, 4, 3, 2), (64, 4, 10, 1)):
+    for N, M, K, fp in ((48, 16, 8, 1), (12, 8, 4, 1), (9, 8, 8, 1)):
         gg = graphgen.make_graph(N, M, K, seed=3)
         A = Plan(gg.ii, gg.jj, gg.kk, gg.poses.shape[0], gg.patches.shape[0], fp, upload=False).arrays()
         assert pipe_schedule_applies(A)
         check_pipe_protocol(A)
-    d = load("window_small")
-    A = host_plan(d, int(d["fixedp"])).arrays()
-    assert pipe_schedule_applies(A) == 2                      # dense 15-pose window: two row waves per column
-    check_pipe_protocol(A)
