@@ -1331,14 +1331,11 @@ __device__ __forceinline__ void lds_load_system(const PlanDev &pd, const StepArg
 
 // Back substitution of the LDS-resident factor (diagonal blocks hold L_jj with 1/l_cc on the
 // diagonal): brings it into M form, then x_j = zt_j - sum_{i>j} M_ij x_i by levels, descending.
-// prep_from: columns of a level below it are already in back-substitution form (the sweep did it), and every
-// diagonal block already holds L_jj^-1 (prep_from >= 0); -1: nothing is prepared.
 template <typename T, bool RAW_DIAG = false>
 __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T *z, T *zt, const int *row_idx,
-                                                    const int *col_ptr, const int4 *lvl_meta, int mstride, int tid, int nth, long long *tprof = nullptr,
-                                                    int prep_from = -1) {
+                                                    const int *col_ptr, const int4 *lvl_meta, int mstride, int tid, int nth, long long *tprof = nullptr) {
     const int n = pd.n, nnzb = pd.nnzb, nlev = pd.nlev, wave = tid >> 6, lane = tid & 63;
-    for (int j = tid; j < n && prep_from < 0; j += nth) {
+    for (int j = tid; j < n; j += nth) {
         T *dblk = Lw + (size_t)col_ptr[j] * 36;
         T L[21], li[21];
 #pragma unroll
@@ -1380,7 +1377,6 @@ __device__ __forceinline__ void lds_back_substitute(const PlanDev &pd, T *Lw, T 
             j = idx - nnzb * 6;
             p = z + 6 * j; q = zt + 6 * j;
         }
-        if (prep_from > 0 && pd.col_lvl[j] < prep_from) continue;
         const T *dblk = Lw + (size_t)col_ptr[j] * 36;
         T in[6], out[6];
         load_row6(p, in);
@@ -1747,11 +1743,11 @@ __global__ __launch_bounds__(768) void k_solve_fused(PlanDev pd, StepArgs a) {
 // most 64 panel rows and levels of at most two columns (plan flag fzp_ok); other systems use k_solve_fused.
 __host__ __device__ inline size_t pipe_work_bytes(const PlanDev &pd) {
     const size_t b = 2 * 36 * sizeof(double) + (size_t)pd.fz_nlazy * 4 * sizeof(unsigned short) + 16;
-    const size_t t = (size_t)pd.nlev * kMaxLevelCols * sizeof(int4);                       // compact level table (after the sweep)
-    return ((b > t ? b : t) + 15) / 16 * 16;
+    const size_t zt = (size_t)pd.D * sizeof(double) + (size_t)pd.nlev * kMaxLevelCols * sizeof(int4);   // zt + compact level table
+    return ((b > zt ? b : zt) + 15) / 16 * 16;
 }
 size_t solve_pipe_lds_bytes(const PlanDev &pd) {
-    return ((size_t)pd.nnzb * 36 + 2 * (size_t)pd.D) * sizeof(double) + pipe_work_bytes(pd) +
+    return ((size_t)pd.nnzb * 36 + (size_t)pd.D) * sizeof(double) + pipe_work_bytes(pd) +
            (3 * (size_t)pd.nnzb + (size_t)pd.n + 1 + (size_t)pd.nlev * 8) * sizeof(int) + 64;      // row_idx, pfirst, psecond, col_ptr, level records
 }
 
@@ -1764,11 +1760,11 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
     typedef double T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int flags[2];
-    __shared__ int lready[2], colready[2], invready[2], hcnt;
+    __shared__ int lready[2], colready[2], hcnt;
     const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
     const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
     T *Lw = reinterpret_cast<T *>(smem);
-    T *z = Lw + (size_t)nnzb * 36, *zt = z + D, *scr = zt + D;       // zt is filled during the sweep: its own region
+    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr;
     unsigned short *lazy = reinterpret_cast<unsigned short *>(scr + 2 * 36);
     int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + pipe_work_bytes(pd)), *pfirst = row_idx + nnzb,
         *psecond = pfirst + nnzb, *col_ptr = psecond + nnzb, *lrec = col_ptr + n + 1;
@@ -1781,7 +1777,7 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
     int status = BT_SOLVE_OK;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const double lm = attempt == 0 ? 1e-4 : 1e-3;
-        if (tid < 2) { flags[tid] = 0; lready[tid] = 0; colready[tid] = 0; invready[tid] = 0; }
+        if (tid < 2) { flags[tid] = 0; lready[tid] = 0; colready[tid] = 0; }
         if (tid == 2) hcnt = 0;
         for (int i = tid; i < pd.fz_nlazy; i += nth)          // one 8-byte word per triple: src1, src2, dst | shared << 15
             reinterpret_cast<ushort4 *>(lazy)[i] = make_ushort4((unsigned short)pd.fz_lazy[3 * i], (unsigned short)pd.fz_lazy[3 * i + 1],
@@ -1846,46 +1842,12 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                             for (int e = 1; e < 6; ++e) acc += x[e] * yv[e];
                             v -= acc;
                         }
-                        if (lane < 36) scr[q * 36 + lane] = v;
+                        if (lane < 36) {
+                            scr[q * 36 + lane] = v;
+                            Lw[(size_t)dpos * 36 + lane] = v;          // in place as well: its next reader is the back substitution
+                        }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) __hip_atomic_store(&lready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        // With the rest of the level to itself, this wave leaves the diagonal block in the form the back
-                        // substitution wants (L_jj below the diagonal, 1/l_cc on it, L_jj^-1 transposed above it), so
-                        // the helpers can bring the column's panel into M form two levels later, still inside the sweep.
-                        {
-                            T L[21], li[21];
-                            const T *dblk = scr + q * 36;
-#pragma unroll
-                            for (int rr = 0; rr < 6; ++rr) {
-                                T row[6];
-                                load_row6(dblk + 6 * rr, row);
-#pragma unroll
-                                for (int c = 0; c <= rr; ++c) L[BT_LT(rr, c)] = row[c];
-                            }
-                            (void)chol6_packed<T>(L);
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) {
-                                li[BT_LT(c, c)] = L[BT_LT(c, c)];
-#pragma unroll
-                                for (int r = c + 1; r < 6; ++r) {
-                                    T t = (T)0;
-#pragma unroll
-                                    for (int kk = c; kk < r; ++kk) t += L[BT_LT(r, kk)] * li[BT_LT(kk, c)];
-                                    li[BT_LT(r, c)] = -t * L[BT_LT(r, r)];
-                                }
-                            }
-                            if (lane == 0) {
-#pragma unroll
-                                for (int rr = 0; rr < 6; ++rr) {
-                                    T row[6];
-#pragma unroll
-                                    for (int c = 0; c < 6; ++c) row[c] = c <= rr ? L[BT_LT(rr, c)] : li[BT_LT(c, rr)];
-                                    store_row6(Lw + (size_t)dpos * 36 + 6 * rr, row);
-                                }
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            if (lane == 0) __hip_atomic_store(&invready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
                         BT_TW(twork);
                     } else {
                         // ---- row wave: one panel row (or y_j) per lane: its pending update, then, once the diagonal wave
@@ -2010,36 +1972,6 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                         lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv & (1 << 24)) != 0);
                     }
                 }
-                // back-substitution form of the columns of level b - 1 (nobody reads their panels any more: the
-                // columns of level b and batch b - 1 are done): M rows in place and zt_j, on the threads from the top end
-                if (b > 0) {
-                    const int m0a = __builtin_amdgcn_readfirstlane(lrec[8 * (b - 1)]), m0b = __builtin_amdgcn_readfirstlane(lrec[8 * (b - 1) + 1]),
-                              m1a = __builtin_amdgcn_readfirstlane(lrec[8 * (b - 1) + 4]), m1b = __builtin_amdgcn_readfirstlane(lrec[8 * (b - 1) + 5]);
-                    const int mnc = (m0b >> 24) & 3;
-                    wait_ge(&invready[0], b);
-                    if (mnc > 1) wait_ge(&invready[1], b);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const int mr0 = ((m0a >> 8) & 255) * 6 + 1, mr1 = mr0 + (mnc > 1 ? ((m1a >> 8) & 255) * 6 + 1 : 0);
-                    for (int item = hs - 1 - h; item < mr1; item += hs) {
-                        const bool sec = item >= mr0;
-                        const int rw = item - (sec ? mr0 : 0);
-                        const int ma2 = sec ? m1a : m0a, dposm = (sec ? m1b : m0b) & 0xffff;
-                        const int jm = ma2 & 255, cntm = (ma2 >> 8) & 255;
-                        const T *src = rw < cntm * 6 ? Lw + (size_t)(dposm + 1) * 36 + 6 * rw : z + 6 * jm;
-                        T *dst = rw < cntm * 6 ? Lw + (size_t)(dposm + 1) * 36 + 6 * rw : zt + 6 * jm;
-                        const T *dblk = Lw + (size_t)dposm * 36;
-                        T in[6], out[6];
-                        load_row6(src, in);
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            T t = dblk[7 * c] * in[c];
-#pragma unroll
-                            for (int kk = c + 1; kk < 6; ++kk) t += dblk[6 * c + kk] * in[kk];
-                            out[c] = t;
-                        }
-                        store_row6(dst, out);
-                    }
-                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_fetch_add(&hcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 BT_TW(twork);
@@ -2048,14 +1980,13 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
         __syncthreads();
         if (PROF) tsweep = clock64() - tall;
 
-        int4 *bmeta = reinterpret_cast<int4 *>(scr);                          // compact level table (the sweep's tables are done with)
+        int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
         for (int i = tid; i < nlev * kMaxLevelCols; i += nth) {          // (col, diag pos, #sub-blocks, barrier before this level)
             int4 mm = reinterpret_cast<const int4 *>(pd.fz_meta)[2 * i];
             mm.w = pd.bs_sync[i / kMaxLevelCols];
             bmeta[i] = mm;
         }
-        // batches 1 .. nlev - 2 prepared the columns of levels 0 .. nlev - 3; the diagonal blocks are all final
-        lds_back_substitute<T, false>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth, nullptr, nlev >= 3 ? nlev - 2 : 0);
+        lds_back_substitute<T, true>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth, nullptr);
         for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
         __syncthreads();
         const bool failed = flags[0] != 0, has_nan = flags[1] != 0;

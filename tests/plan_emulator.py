@@ -439,20 +439,6 @@ def check_pipe_protocol(A, nw=12):
                         per_wave[w][0].update({(blk, r), ("z", c), ("z", int(row_idx[blk]))})
                         per_wave[w][1].add(("z", int(row_idx[blk])))
                     yi += 1
-        # back-substitution form of the columns of level b - 1, on the threads from the top end:
-        # reads the (final) diagonal block, rewrites the panel rows in place, z_j -> zt_j
-        if b > 0:
-            mi = 0
-            for c in cols[b - 1]:
-                d = int(col_ptr[c]); cnt = int(col_ptr[c + 1]) - d - 1
-                for rw in range(6 * cnt + 1):
-                    w = ((hs - 1 - mi) % hs) // 64
-                    per_wave[w][0].update({(d, r) for r in ROWS})
-                    if rw < 6 * cnt:
-                        per_wave[w][0].add((d + 1 + rw // 6, rw % 6)); per_wave[w][1].add((d + 1 + rw // 6, rw % 6))
-                    else:
-                        per_wave[w][0].add(("z", c)); per_wave[w][1].add(("zt", c))
-                    mi += 1
         for w in range(nh):
             add(("H", b, w), per_wave[w][0], per_wave[w][1])
     N = len(nodes)
@@ -487,9 +473,6 @@ def check_pipe_protocol(A, nw=12):
         for w in range(nh):
             for q2 in range(len(cols[b])):
                 edge(("R", b, q2), ("H", b, w))                  # sources of the batch
-            if b > 0:
-                for q2 in range(len(cols[b - 1])):
-                    edge(("D", b - 1, q2), ("H", b, w))          # invready: the final diagonal blocks of level b - 1
             if b > 0:
                 for w2 in range(nh):
                     edge(("H", b - 1, w2), ("H", b, w))          # hcnt >= nh b: the group has finished the batches before
