@@ -291,3 +291,35 @@ def test_packed_exchange_form_roundtrip():
     st.step(*args, phase="solve_update")
     torch.cuda.synchronize()
     assert rel(Pout.cpu().numpy(), o["poses_out"]) < 1e-7 and rel(pout.cpu().numpy(), o["patches_out"]) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["C3", "band48", "C1"])
+def test_solver_gives_the_same_answer_every_time(name):
+    """The barrier-free solver orders its waves with LDS flags only; a missing wait would show up as a result
+    that depends on timing.  The same reduced system solved 400 times must give the same dX bit for bit."""
+    g = {"C3": lambda: graphgen.make_config("C3", seed=0), "band48": lambda: graphgen.make_graph(48, 16, 8, seed=3),
+         "C1": lambda: graphgen.make_config("C1", seed=0)}[name]()
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics),
+             targets3=f(g.targets3), weights=f(g.weights), weights_pose=f(g.weights_pose),
+             ii=g.ii, jj=g.jj, kk=g.kk, bounds=np.asarray(g.bounds))
+    hp = HipProblem(d)
+    st = hp.raw_step("weights_pose", 1)["stepper"]
+    P = hp.poses[0].contiguous(); pat = hp.patches.reshape(-1, 3).contiguous()
+    Pout, pout = torch.empty_like(P), torch.empty_like(pat)
+    tg = hp.t3[0]
+    args = (P, pat, hp.mono.reshape(-1), hp.intr[0], tg, tg.stride(0), hp.w["weights_pose"][0].contiguous(),
+            Pout, pout, hp.bounds, 1e-4, 10.0, 0.05, "huber", False)
+    st.step(*args, phase="reduce")
+    torch.cuda.synchronize()
+    sys0 = st.system.clone()
+    ref = None
+    for it in range(400):
+        st.system.copy_(sys0)
+        st.step(*args, phase="solve_update")
+        dx = st.dx.clone()
+        if ref is None:
+            ref = dx
+        else:
+            assert torch.equal(dx, ref), it
+    assert st.status() == 0
