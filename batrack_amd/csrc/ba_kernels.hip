@@ -546,11 +546,13 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
         ia = pd.pair_i[p] - pd.fixedp; ib = pd.pair_j[p] - pd.fixedp;
         double *acc = a.pairacc + (size_t)p * kPairAccStride;
         float *g = sgeo[w];
+        // the sums first (they need only the pair index), so their latency runs under the pose loads and the geometry
+        const double accv = lane < 36 ? acc[sym21(lane / 6, lane % 6)] : lane < 42 ? acc[21 + lane - 36] : 0.0;
         if (lane == 0) pair_geometry(a.poses, a.intr, pd.pair_i[p], pd.pair_j[p], g);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (lane < 36) {
             const int r = lane / 6, c = lane % 6;
-            sB[w][lane] = acc[sym21(r, c)];
+            sB[w][lane] = accv;
             // Ad = [[R, [t]x R], [0, R]]                                   (se3.h:58-67)
             double v = 0.0;
             if (r < 3 && c < 3) v = g[3*r + c];
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
             }
             sAd[w][lane] = v;
         } else if (lane < 42) {
-            sg[w][lane - 36] = acc[21 + lane - 36];
+            sg[w][lane - 36] = accv;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (lane < 27) acc[lane] = 0.0;                 // leave the per-pair sums clear for the next step
