@@ -1908,18 +1908,18 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                             }
                         }
                         const bool ok = chol6_packed<T>(L);
-                        if (!ok && lane == 0) flags[0] = 1;
-                        if (valid) {
-                            T out[6];
+                        // (substitution computed by every lane, only the store is predicated: one basic block, so the
+                        //  compiler can slot its FMAs into the latency gaps of the factorisation)
+                        T out[6];
 #pragma unroll
-                            for (int c = 0; c < 6; ++c) {
-                                T t = in[c];
+                        for (int c = 0; c < 6; ++c) {
+                            T t = in[c];
 #pragma unroll
-                                for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
-                                out[c] = t * L[BT_LT(c, c)];
-                            }
-                            store_row6(p, out);
+                            for (int k = 0; k < c; ++k) t -= out[k] * L[BT_LT(c, k)];
+                            out[c] = t * L[BT_LT(c, c)];
                         }
+                        if (valid) store_row6(p, out);
+                        if (!ok && lane == 0) flags[0] = 1;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) __hip_atomic_store(&colready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         BT_TW(sub[2]);
