@@ -1,4 +1,5 @@
-"""-m gpu: every reduced-system solver variant gives the reference's pose update.
+"""-m gpu: every reduced-system solver variant, and the persistent variant of the Jacobian kernel, give the
+reference's pose update.
 
 The library picks the variant from the system's size (ba_kernels.hip: solver_mode,
 use_pipe_solver, use_fused_solver): the barrier-free double LDS kernel (default where it applies), the
@@ -47,6 +48,8 @@ VARIANTS = [
     ({"BT_SOLVER_PIPE": "0"}, 2e-3, 1e-5),
     ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0"}, 2e-3, 1e-5),
     ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0", "BT_SOLVER_ORDER": "0"}, 2e-3, 1e-5),
+    ({"BT_TILE_MAX_WGS": "16"}, 2e-3, 1e-5),         # persistent k_tile: 16 tiles per workgroup at C3 (graphs > 1024 tiles use it)
+    ({"BT_TILE_MAX_WGS": "3"}, 2e-3, 1e-5),          # ... with uneven tile ranges
     ({"BT_SOLVER_MODE": "1"}, 2e-2, 1e-4),
     ({"BT_SOLVER_MODE": "2"}, 2e-2, 1e-4),
 ]
