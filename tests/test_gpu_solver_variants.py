@@ -30,6 +30,8 @@ for name, tag, fixedp in (("c1", "ps_fp1", 1), ("window_small", "ps", None)):
     o = HipProblem(d).raw_step("weights_pose", fp)
     out[name] = dict(dX=rel(o["dX"].reshape(-1), d[tag + ".f64.dX"].reshape(-1)),
                      poses=rel(o["poses_out"], d[tag + ".f64.poses_out"]), status=int(o["status"]))
+    so = HipProblem(d).raw_step("weights", fp, True)                       # structure-only path of the same variant
+    out[name]["so_patches"] = rel(so["patches_out"], d["so.f64.patches_out"])
 g = graphgen.make_config("C3", seed=0)
 f = lambda a: np.asarray(a, np.float32).astype(np.float64)
 d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics), targets3=f(g.targets3),
@@ -65,3 +67,4 @@ def test_solver_variant(env, tol_dx, tol_pose):
     for name, v in res.items():
         assert v["status"] == 0, (name, v)
         assert v["dX"] < tol_dx and v["poses"] < tol_pose, (env, name, v)
+        assert v.get("so_patches", 0.0) < 1e-5, (env, name, v)
