@@ -323,3 +323,31 @@ def test_solver_gives_the_same_answer_every_time(name):
         else:
             assert torch.equal(dx, ref), it
     assert st.status() == 0
+
+
+def test_track_seen_by_many_cameras_vs_oracle():
+    """A few tracks observed from 40 frames each (tiles with far more than 16 cameras: large local E blocks, the
+    Schur product spread over many 16x16 tiles, the depth back-substitution's long camera lists) next to an
+    ordinary banded graph."""
+    g = graphgen.make_graph(48, 8, 4, seed=21)
+    rng = np.random.default_rng(5)
+    ii, jj, kk = [g.ii], [g.jj], [g.kk]
+    for k in (3, 100, 200):                                   # hub tracks: their source frame to 40 other frames
+        tgt = rng.choice(48, size=40, replace=False)
+        ii.append(np.full(40, k // 8)); jj.append(tgt); kk.append(np.full(40, k))
+    ii, jj, kk = (np.concatenate(a).astype(np.int64) for a in (ii, jj, kk))
+    gt = g.patches.copy(); gt[:, 2] = g.disp_gt
+    u, v, _ = graphgen.reproject(g.poses_gt, gt, g.intrinsics, ii, jj, kk)
+    E = len(kk)
+    t3 = np.stack([u + rng.normal(0, 0.5, E), v + rng.normal(0, 0.5, E), g.disp_gt[kk]], 1)
+    w = rng.uniform(0.3, 1.0, (E, 2))
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics),
+             targets3=f(t3), weights=f(w), weights_pose=f(w), ii=ii, jj=jj, kk=kk, bounds=np.asarray(g.bounds))
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"],
+                         d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, want_system=True)
+    o = HipProblem(d).raw_step("weights_pose", 1)
+    assert o["plan"].max_tile_cams >= 38 and o["status"] == 0
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
+    assert rel(o["poses_out"], ref["poses_out"]) < 1e-4              # a 47-pose dense system: float32 factor in LDS or global memory
+    assert rel(o["patches_out"], ref["patches_out"]) < 1e-4
