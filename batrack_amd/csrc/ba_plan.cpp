@@ -15,6 +15,9 @@
 #include "ba_plan.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdlib>
 #include <numeric>
 
@@ -56,7 +59,11 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     if (own_hi <= 0) { own_lo = 0; own_hi = p_tot; }
     if (own_lo < 0 || own_hi > p_tot || own_lo > own_hi) return BT_EINVAL;
     auto owned = [&](int64_t e) { return kk[e] >= own_lo && kk[e] < own_hi; };
+    static const bool plan_prof = std::getenv("BT_PLAN_PROF") != nullptr;          // measurement only: time per phase on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+#define BT_TICK(name) do { if (plan_prof) { const auto t_now = std::chrono::steady_clock::now(); std::fprintf(stderr, "plan phase before %s: %.3f ms\n", name, std::chrono::duration<double, std::milli>(t_now - t_prev).count()); t_prev = t_now; } } while (0)
 
+    BT_TICK("0");
     // ---- n_all, validation (ba.py:219) ------------------------------------
     int64_t n_all = n_all_min;
     bool sorted = true;
@@ -72,6 +79,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     I.n = n;
     if (n > kMaxFree) return BT_EUNSUPPORTED;
 
+    BT_TICK("1");
     // ---- unique tracks, ascending (ba.py:276) ------------------------------
     pl->trk_of_patch.assign((size_t)p_tot, -1);
     int64_t E_own = 0;
@@ -83,6 +91,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         if (pl->trk_of_patch[(size_t)p] == 0) { pl->trk_of_patch[(size_t)p] = m++; pl->kx.push_back((int32_t)p); }
     I.m = m;
 
+    BT_TICK("2");
     // ---- distinct camera pairs, ascending (i, j) ---------------------------
     std::vector<int32_t> pair_of((size_t)(n_all * n_all), -1);
     for (int64_t e = 0; e < E; ++e) if (owned(e)) pair_of[(size_t)(ii[e] * n_all + jj[e])] = 0;
@@ -95,6 +104,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     I.pairs = (int64_t)pl->pair_i.size();
 
+    BT_TICK("3");
     // ---- edges grouped by track, ordered by (pair, original index) ---------
     std::vector<int32_t> off((size_t)m + 1, 0);
     for (int64_t e = 0; e < E; ++e) if (owned(e)) off[(size_t)pl->trk_of_patch[(size_t)kk[e]] + 1]++;
@@ -108,11 +118,13 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             return pa != pb ? pa < pb : a < b;
         });
 
+    BT_TICK("4");
     // ---- one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)
     for (int32_t k = 0; k < m; ++k)
         for (int32_t sidx = off[(size_t)k] + 1; sidx < off[(size_t)k + 1]; ++sidx)
             if (ii[ord[(size_t)sidx]] != ii[ord[(size_t)off[(size_t)k]]]) return BT_EUNSUPPORTED;
 
+    BT_TICK("5");
     // ---- tiles: greedy over sorted tracks ----------------------------------
     pl->tile_trk0.clear(); pl->tile_ntrk.clear(); pl->tile_ncam.clear(); pl->tile_cam0.clear();
     pl->tile_slot0.clear(); pl->tile_nslot.clear(); pl->tile_erow0.clear(); pl->tile_cams.clear();
@@ -162,6 +174,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
     pl->max_rows16 = (int)((6 * max_cams + 1 + 15) / 16 * 16);
 
+    BT_TICK("6");
     // ---- slot arrays [slots][64] -------------------------------------------
     pl->slot_edge.assign((size_t)slots * kLanes, -1);
     pl->slot_pair.assign((size_t)slots * kLanes, 0);
@@ -185,6 +198,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     }
 
+    BT_TICK("7");
     // ---- distinct camera pairs of every tile (their relative pose is computed once per tile)
     pl->tile_pair0.assign((size_t)T, 0); pl->tile_npair.assign((size_t)T, 0);
     pl->tile_pairs.clear();
@@ -224,6 +238,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             pl->tile_flags[(size_t)t] |= 2;
     }
 
+    BT_TICK("8");
     // ---- block structure of S (lower) and symbolic Cholesky ----------------
     // S[u][v] (u >= v) may be non-zero if u and v share a tile (Schur term,
     // ba.py:321) or form a camera pair with both ends free (B, ba.py:279-282).
@@ -262,6 +277,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
                 for (size_t v = 0; v <= u; ++v) nz[(size_t)cset[u]][(size_t)cset[v]] = 1;
         }
     }
+    BT_TICK("9");
     // ---- elimination order: two-ended ("twisted") when an index cut gives a small separator
     // Cameras are time-ordered and co-visibility is local in time, so a vertex separator is
     // looked for as S_k = { j >= k : some i < k is coupled to j }.  Order = [A = {<k} ascending |
@@ -343,6 +359,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             pl->blk_src[(size_t)b] = x >= y ? ((x << 9) | (y << 1)) : ((y << 9) | (x << 1) | 1);
         }
 
+    BT_TICK("10");
     // ---- level schedule: level(j) = 1 + max level of its children in the elimination tree;
     // columns of one level are independent.  At most kMaxLevelCols per level (extra ones move up).
     std::vector<int32_t> lvl((size_t)n, 0);
@@ -379,6 +396,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         for (int64_t j = 0; j < n; ++j) pl->lvl_cols[(size_t)cur[(size_t)lvl[(size_t)j]]++] = (int32_t)j;
     }
 
+    BT_TICK("11");
     // ---- update triples of every column (src1, src2, dst | atomic << 15).  First those whose
     // destination is the DIAGONAL block of a column of the next level (that column's critical wave
     // applies them itself before factoring: listed per target column in dp), then the rest.
@@ -465,6 +483,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             mrow[7] = pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l];     // columns in this level
         }
 
+    BT_TICK("12");
     // ---- fused schedule (k_solve_fused): ONE phase and one barrier per level.  A column's wave
     // applies the updates coming from the level right below to its own diagonal block and panel
     // rows itself ("pending": listed per destination block), factors and substitutes; every other
@@ -589,6 +608,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     }
 
+    BT_TICK("13");
     // ---- k_tile's first loads, indexed by the tile alone (no dependent index chain in its prologue):
     //   tile_ij[t][max_tile_pairs]   cameras (i | j << 16) of the tile's pairs, in local pair order
     //   tile_kx[t][64]               patch of every track of the tile (-1: no track in this lane)
@@ -607,6 +627,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         if (n_buf >= 65536) return BT_EUNSUPPORTED;
     }
 
+    BT_TICK("14");
     // ---- k_update: everything a patch's depth back-substitution needs in one 32-byte record,
     // [track or -1, first E row * 64 + lane, #cameras (bit 30: more than 16, use the tile arrays), 0, 16 camera bytes]
     pl->upd_rec.assign((size_t)p_tot * 8, 0);
@@ -624,6 +645,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
                 r[4 + c / 4] |= (pl->tile_cams[(size_t)(c0 + c)] & 255) << (8 * (c % 4));
     }
 
+    BT_TICK("end");
     layout_workspace(pl);
     return BT_OK;
 }
