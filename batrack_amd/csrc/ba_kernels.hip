@@ -161,8 +161,10 @@ constexpr int kTileAccMax = 16;  // Schur output tiles (16x16) a workgroup accum
 // PERSIST = false: one tile per workgroup (graphs with up to ~1024 tiles, e.g. the 64-KF / 131k-edge
 // benchmark): no cross-tile state, Schur tiles go straight from the MFMA registers to the atomics.
 // PERSIST = true: a workgroup walks tiles_per_wg consecutive tiles and keeps its accumulators.
-template <bool SO, bool PROF, bool PERSIST>
-__global__ __launch_bounds__(512, 4) void k_tile(PlanDev pd, StepArgs a, int tiles_per_wg) {
+// WIDE: 16 waves per tile instead of 8, for graphs of few tiles with deep slot loops (a sliding window of 50 frames:
+// 40 tiles of 54 slots): the tile's latency, which is all there is on a quarter-empty GPU, shrinks with the chunk.
+template <bool SO, bool PROF, bool PERSIST, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDev pd, StepArgs a, int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthr = blockDim.x, kTileWaves = nthr >> 6;          // 8 or 16 waves per tile (launch parameter)
@@ -2156,15 +2158,17 @@ __global__ __launch_bounds__(256) void k_pack_system(PlanDev pd, StepArgs a) {
 }
 
 // ------------------------------------------------------------------ launchers
-static int tile_threads() {
-    // 8 waves per tile; 16 only on request (measurement): it shortens deep slot loops a little but
-    // halves the tiles resident per CU, which costs more on large graphs
-    return 512;
+// 8 waves per tile; 16 for graphs of few tiles with deep slot loops (BT_TILE_WIDE = 0 / 1 forces: measurement only)
+static bool tile_wide(const PlanDev &pd) {
+    static const int env = std::getenv("BT_TILE_WIDE") ? std::atoi(std::getenv("BT_TILE_WIDE")) : -1;
+    if (env >= 0) return env != 0;
+    return pd.T <= 128 && pd.max_tile_slots >= 24;
 }
+static int tile_threads(const PlanDev &pd) { return tile_wide(pd) ? 1024 : 512; }
 
 static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     const size_t rows = so ? 0 : (size_t)pd.max_rows16;
-    const size_t kTileWaves = (size_t)tile_threads() / 64;
+    const size_t kTileWaves = (size_t)tile_threads(pd) / 64;
     const size_t nt = rows / 16, ntl = nt * (nt + 1) / 2;
     return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 64 + rows +
             (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) + (ntl < 16 ? ntl : 16) * 2048 + 64;
@@ -2209,6 +2213,8 @@ int configure_kernels(const PlanDev &pd) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)
@@ -2257,11 +2263,15 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         // contiguous range of tiles and keeps its accumulators across tiles with the same cameras
         static const int max_wgs = std::getenv("BT_TILE_MAX_WGS") ? std::atoi(std::getenv("BT_TILE_MAX_WGS")) : 1024;   // measurement only
         const int tpw = (pd.T + max_wgs - 1) / max_wgs, nwg = (pd.T + tpw - 1) / tpw;
-        if (so && tpw == 1)    BT_LAUNCH(1, (k_tile<true, false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
-        else if (so)           BT_LAUNCH(1, (k_tile<true, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, true), pd, a, tpw);
-        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true, false>), dim3(pd.T), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, 1);
-        else if (tpw == 1)     BT_LAUNCH(1, (k_tile<false, false, false>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
-        else                   BT_LAUNCH(1, (k_tile<false, false, true>), dim3(nwg), dim3(tile_threads()), tile_lds_bytes(pd, false), pd, a, tpw);
+        const bool wide = tpw == 1 && tile_wide(pd);
+        const dim3 blk(tile_threads(pd));
+        if (so && wide)        BT_LAUNCH(1, (k_tile<true, false, false, true>), dim3(nwg), blk, tile_lds_bytes(pd, true), pd, a, tpw);
+        else if (so && tpw == 1) BT_LAUNCH(1, (k_tile<true, false, false>), dim3(nwg), blk, tile_lds_bytes(pd, true), pd, a, tpw);
+        else if (so)           BT_LAUNCH(1, (k_tile<true, false, true>), dim3(nwg), dim3(512), tile_lds_bytes(pd, true), pd, a, tpw);
+        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true, false>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, false), pd, a, 1);
+        else if (wide)         BT_LAUNCH(1, (k_tile<false, false, false, true>), dim3(nwg), blk, tile_lds_bytes(pd, false), pd, a, tpw);
+        else if (tpw == 1)     BT_LAUNCH(1, (k_tile<false, false, false>), dim3(nwg), blk, tile_lds_bytes(pd, false), pd, a, tpw);
+        else                   BT_LAUNCH(1, (k_tile<false, false, true>), dim3(nwg), dim3(512), tile_lds_bytes(pd, false), pd, a, tpw);
     }
     if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);

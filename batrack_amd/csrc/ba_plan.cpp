@@ -628,6 +628,9 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     }
 
     BT_TICK("14");
+    pl->max_tile_slots = 0;
+    for (int64_t t = 0; t < I.tiles; ++t) pl->max_tile_slots = std::max(pl->max_tile_slots, (int)pl->tile_nslot[(size_t)t]);
+
     // ---- k_update: everything a patch's depth back-substitution needs in one 32-byte record,
     // [track or -1, first E row * 64 + lane, #cameras (bit 30: more than 16, use the tile arrays), 0, 16 camera bytes]
     pl->upd_rec.assign((size_t)p_tot * 8, 0);

@@ -33,7 +33,7 @@ struct PlanDev {
     const int32_t *tile_ij, *tile_kx;                        // per tile: cameras of its pairs [max_tile_pairs], patch of its tracks [64]
     const int32_t *tile_flags;                               // bit 0: same cameras as the previous tile, bit 1: same pair list
     const uint8_t *slot_lp;                                  // local pair index of a (slot, lane) within its tile
-    int max_tile_pairs;
+    int max_tile_pairs, max_tile_slots;
     const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
     // elimination order and level schedule of the reduced solver
     int nlev, ndp;
@@ -63,7 +63,7 @@ struct bt_plan {
     std::vector<uint16_t> slot_lab;
     std::vector<int32_t> tile_pair0, tile_npair, tile_pairs, tile_flags, tile_ij, tile_kx;
     std::vector<uint8_t> slot_lp;
-    int max_tile_pairs = 0;
+    int max_tile_pairs = 0, max_tile_slots = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
     std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp, lvl_meta;
     std::vector<int32_t> fz_pend_ptr, fz_pend, fz_lazy_ptr, fz_lazy, fz_yurg, fz_meta, fz_pmeta, bs_sync, fz_rowinfo, fz_pfirst, fz_psecond;   // fused schedule (k_solve_fused)
