@@ -1,0 +1,44 @@
+"""ATE parity on a replayed sequence ("ATE vs reference within 1 %"): the caller loop
+of batrack_amd/sequence.py driven by the HIP BA_rgbd_droid on the GPU and by the CPU oracle, same
+synthetic observations, same bookkeeping; trajectories compared by APE-RMSE after Sim(3) alignment."""
+import numpy as np
+import pytest
+import torch
+
+from batrack_amd import evaluation
+from batrack_amd.sequence import SlamConfig, SyntheticObservations, WindowedBA
+from sequence_util import oracle_BA_rgbd_droid
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(n_frames, M, seed, cfg_kw=None):
+    from batrack_amd.backend.ba import BA_rgbd_droid
+    out = {}
+    for name, ba, dev in (("hip", BA_rgbd_droid, "cuda:0"), ("oracle", oracle_BA_rgbd_droid, "cpu")):
+        obs = SyntheticObservations(n_frames=n_frames, M=M, seed=seed)          # same seed -> same observations
+        cfg = SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=n_frames + 1, **(cfg_kw or {}))
+        trk = WindowedBA(obs, ba, cfg, device=dev)
+        poses = trk.run()
+        out[name] = dict(poses=poses, stats=trk.stats, weights=trk.weights.cpu().numpy(),
+                         ate=evaluation.ate_rmse(evaluation.camera_centres(poses), obs.centres_gt()))
+    return out
+
+
+@pytest.mark.parametrize("n_frames,M,seed", [(40, 64, 5), (30, 128, 11)])
+def test_ate_matches_the_oracle_driven_run(n_frames, M, seed):
+    r = run_pair(n_frames, M, seed)
+    ate_h, ate_o = r["hip"]["ate"], r["oracle"]["ate"]
+    assert abs(ate_h - ate_o) <= 0.01 * ate_o, (ate_h, ate_o)
+    # the trajectories themselves agree far below the ATE (translations ~1, unit quaternions)
+    assert np.abs(r["hip"]["poses"] - r["oracle"]["poses"]).max() < 2e-4, np.abs(r["hip"]["poses"] - r["oracle"]["poses"]).max()
+    assert r["hip"]["stats"]["ba_calls"] == r["oracle"]["stats"]["ba_calls"]
+    assert r["hip"]["stats"]["edges_max"] == r["oracle"]["stats"]["edges_max"]
+    # map filtering (5 px reprojection gate after each update) decides alike up to borderline edges
+    flips = int((r["hip"]["weights"] != r["oracle"]["weights"]).sum())
+    assert flips <= 0.002 * r["hip"]["weights"].size, flips
+
+
+def test_short_window_config():
+    r = run_pair(24, 32, 2, dict(num_init=6, init_updates=6, ITER=2, OPTIMIZATION_WINDOW=8, REMOVAL_WINDOW=10, S_slam=6))
+    assert abs(r["hip"]["ate"] - r["oracle"]["ate"]) <= 0.01 * r["oracle"]["ate"]

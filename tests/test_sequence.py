@@ -1,0 +1,86 @@
+"""Caller loop and the ATE measurement (§8d), CPU side: the replay of
+BATRACK.__call__/update() driven by the oracle, and the Umeyama / APE-RMSE restatement."""
+import numpy as np
+import pytest
+import torch
+
+from batrack_amd import evaluation, graphgen
+from batrack_amd.sequence import SlamConfig, SyntheticObservations, WindowedBA
+from sequence_util import oracle_BA_rgbd_droid
+
+
+def test_umeyama_recovers_similarity():
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(40, 3))
+    R = graphgen._quat_rot(graphgen.se3_exp(np.array([[0, 0, 0, 0.3, -0.2, 0.5]]))[0, 3:], np.eye(3)).T
+    s, t = 1.7, np.array([0.3, -2.0, 5.0])
+    y = s * x @ R.T + t
+    s2, R2, t2 = evaluation.umeyama(x, y)
+    assert abs(s2 - s) < 1e-12 and np.abs(R2 - R).max() < 1e-12 and np.abs(t2 - t).max() < 1e-12
+    assert evaluation.ate_rmse(x, y) < 1e-12
+    assert abs(evaluation.ate_rmse(x, y, correct_scale=False) - evaluation.ate_rmse(x, y, correct_scale=False)) == 0
+    assert evaluation.ate_rmse(x, y, align=False) > 1.0
+    # a reflection is not a rotation: the alignment must not use it
+    ym = y * np.array([1.0, 1.0, -1.0])
+    assert np.linalg.det(evaluation.umeyama(x, ym)[1]) > 0.0
+    noisy = y + rng.normal(scale=0.01, size=y.shape)
+    assert 0.005 < evaluation.ate_rmse(x, noisy) < 0.03
+
+
+def test_camera_centres_match_inverse_pose():
+    xi = np.random.default_rng(1).normal(scale=0.3, size=(5, 6))
+    G = graphgen.se3_exp(xi)
+    assert np.abs(evaluation.camera_centres(G) - graphgen.se3_inv(G)[:, :3]).max() < 1e-12
+
+
+def small_cfg(obs, **kw):
+    base = dict(PATCHES_PER_FRAME=obs.M, BUFFER_SIZE=obs.n_frames + 1, num_init=6, init_updates=6, ITER=2,
+                OPTIMIZATION_WINDOW=8, REMOVAL_WINDOW=10, S_slam=6)
+    base.update(kw)
+    return SlamConfig(**base)
+
+
+def test_edge_bookkeeping_follows_the_reference_rules():
+    """batrack.py:399-410 (window keyframes x window frames, appended every kf_stride frames, duplicates kept),
+    :1020-1024 (edges of sources older than REMOVAL_WINDOW dropped) — driven with a BA that does nothing."""
+    obs = SyntheticObservations(n_frames=24, M=4, seed=3)
+    calls = []
+
+    def noop_ba(Gs, patches, *a, **k):
+        calls.append((k["fixedp"], k["structure_only"], a[7].numel()))
+        return Gs, patches
+
+    cfg = small_cfg(obs, USE_MAP_FILTERING=False)
+    trk = WindowedBA(obs, noop_ba, cfg)
+    n_edges = []
+    for f in range(obs.n_frames):
+        trk()
+        n_edges.append(int(trk.ii.numel()))
+        assert trk.targets_3d.shape[1] == trk.weights.shape[1] == trk.weights_pose.shape[1] == trk.ii.numel()
+        assert bool((trk.ii == trk.kk // obs.M).all())
+        if trk.is_initialized and f >= cfg.num_init + 1:
+            assert int(trk.ii.min()) >= trk.n - cfg.REMOVAL_WINDOW
+    # frame 1 adds 1 keyframe x 1 frame, frame 3: keyframes {0, 2} x frames {0, 1, 2}, ...
+    assert n_edges[0] == 4 and n_edges[1] == 4 and n_edges[2] == 4 + 2 * 4 * 3
+    # steady state: S_slam/kf_stride keyframes x M tracks x S_slam frames per append
+    assert n_edges[-1] - n_edges[-3] <= 3 * 4 * 6
+    # call pattern: init_updates*ITER dual calls with fixedp=1, then ITER dual calls per frame with fixedp = n - window
+    assert calls[0][:2] == (1, False) and calls[1][:2] == (1, True)
+    assert len(calls) == 2 * cfg.ITER * (cfg.init_updates + obs.n_frames - cfg.num_init - 1)
+    assert calls[-1][0] == obs.n_frames - cfg.OPTIMIZATION_WINDOW
+    # duplicates (same track, same frame, fresh targets) are normal
+    key = (trk.kk * 1000 + trk.jj).cpu().numpy()
+    assert np.unique(key).size < key.size
+
+
+def test_oracle_driven_sequence_tracks_the_camera():
+    obs = SyntheticObservations(n_frames=22, M=24, seed=5)
+    trk = WindowedBA(obs, oracle_BA_rgbd_droid, small_cfg(obs))
+    poses = trk.run()
+    gt = obs.centres_gt()
+    ate = evaluation.ate_rmse(evaluation.camera_centres(poses), gt)
+    # a camera that never moves, for scale (the path is ~0.4 long; convergence is limited by ep = 10 and ITER = 2)
+    still = evaluation.ate_rmse(np.zeros_like(gt) + 1e-9 * np.arange(gt.shape[0])[:, None], gt)
+    assert ate < 0.25 * still and ate < 0.005, (ate, still)
+    assert trk.stats["ba_calls"] == 2 * 2 * trk.stats["updates"]
+    assert np.abs(np.linalg.norm(poses[:, 3:], axis=1) - 1.0).max() < 1e-5
