@@ -75,6 +75,8 @@ def lib():
     L.bt_plan_create.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, ctypes.POINTER(vp)]
     L.bt_plan_destroy.restype = None
     L.bt_plan_destroy.argtypes = [vp]
+    L.bt_plan_pool_trim.restype = None
+    L.bt_plan_pool_trim.argtypes = []
     L.bt_plan_get_info.restype = i32
     L.bt_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
     L.bt_plan_workspace_bytes.restype = ctypes.c_size_t

@@ -2,8 +2,14 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <utility>
+#include <vector>
 
 #include "ba_kernels.hpp"
 
@@ -19,7 +25,99 @@ static size_t put(std::vector<char> &buf, const std::vector<T> &v) {
     return off;
 }
 
+// Device buffers of destroyed plans are kept for the next plan: the caller replaces its edge list every frame
+// (batrack.py:189-212), so a plan lives for 2*ITER steps, and hipMalloc / hipFree per frame is what a frame
+// would otherwise wait for (hipFree synchronises the device and unmaps).  Sizes are rounded up so that the
+// slowly varying edge count of a sliding window maps onto the same bucket.
+struct DevPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> free_list;
+    static size_t bucket(size_t bytes) {           // 12.5 % head room, whole MiB, at least 2 MiB
+        const size_t g = (size_t)1 << 20;
+        return std::max<size_t>(2 * g, (bytes + bytes / 8 + g - 1) / g * g);
+    }
+    void *acquire(size_t bytes, size_t *cap) {
+        const size_t want = bucket(bytes);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = free_list.size();
+            for (size_t i = 0; i < free_list.size(); ++i)
+                if (free_list[i].second >= bytes && free_list[i].second <= 2 * want &&
+                    (best == free_list.size() || free_list[i].second < free_list[best].second)) best = i;
+            if (best != free_list.size()) {
+                void *p = free_list[best].first;
+                *cap = free_list[best].second;
+                free_list.erase(free_list.begin() + (long)best);
+                return p;
+            }
+        }
+        void *d = nullptr;
+        if (hipMalloc(&d, want) != hipSuccess) return nullptr;
+        *cap = want;
+        return d;
+    }
+    void release(void *p, size_t cap) {
+        void *drop = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_list.emplace_back(p, cap);
+            if (free_list.size() > 8) {            // keep the eight largest
+                size_t sm = 0;
+                for (size_t i = 1; i < free_list.size(); ++i) if (free_list[i].second < free_list[sm].second) sm = i;
+                drop = free_list[sm].first;
+                free_list.erase(free_list.begin() + (long)sm);
+            }
+        }
+        if (drop) (void)hipFree(drop);
+    }
+    void trim() {
+        std::vector<std::pair<void *, size_t>> all;
+        { std::lock_guard<std::mutex> lk(mu); all.swap(free_list); }
+        for (auto &e : all) (void)hipFree(e.first);
+    }
+};
+static DevPool &dev_pool() { static DevPool *p = new DevPool(); return *p; }   // never destroyed: no HIP call at exit
+
+// Destroyed plan objects, vectors emptied but not released (bt_plan::recycle).
+struct PlanPool {
+    std::mutex mu;
+    std::vector<bt_plan *> idle;
+    bt_plan *take() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!idle.empty()) { bt_plan *p = idle.back(); idle.pop_back(); return p; }
+        }
+        return new (std::nothrow) bt_plan();
+    }
+    void give(bt_plan *p) {
+        p->recycle();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (idle.size() < 8) { idle.push_back(p); return; }
+        }
+        delete p;
+    }
+    void trim() {
+        std::vector<bt_plan *> all;
+        { std::lock_guard<std::mutex> lk(mu); all.swap(idle); }
+        for (bt_plan *p : all) delete p;
+    }
+};
+static PlanPool &plan_pool() { static PlanPool *p = new PlanPool(); return *p; }
+
+static bool api_prof() { static const bool p = std::getenv("BT_PLAN_PROF") != nullptr; return p; }
+struct ApiTick {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        if (!api_prof()) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "plan api %s: %.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 int upload_plan(bt_plan *pl) {
+    ApiTick tick;
     std::vector<char> buf;
     const size_t o_kx = put(buf, pl->kx), o_top = put(buf, pl->trk_of_patch), o_loc = put(buf, pl->trk_loc);
     const size_t o_pi = put(buf, pl->pair_i), o_pj = put(buf, pl->pair_j);
@@ -35,10 +133,15 @@ int upload_plan(bt_plan *pl) {
     const size_t o_cl = put(buf, pl->col_lvl), o_dpp = put(buf, pl->dp_ptr), o_dp = put(buf, pl->dp);
     const size_t o_fpp = put(buf, pl->fz_pend_ptr), o_fp = put(buf, pl->fz_pend), o_flp = put(buf, pl->fz_lazy_ptr), o_fl = put(buf, pl->fz_lazy);
     const size_t o_fy = put(buf, pl->fz_yurg), o_fm = put(buf, pl->fz_meta), o_fpm = put(buf, pl->fz_pmeta), o_bss = put(buf, pl->bs_sync), o_fri = put(buf, pl->fz_rowinfo), o_fpf = put(buf, pl->fz_pfirst), o_fps = put(buf, pl->fz_psecond), o_ur = put(buf, pl->upd_rec), o_tij = put(buf, pl->tile_ij), o_tkx = put(buf, pl->tile_kx);
-    void *d = nullptr;
-    if (hipMalloc(&d, buf.size() + 256) != hipSuccess) return BT_ENOMEM;
-    if (hipMemcpy(d, buf.data(), buf.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return BT_EHIP; }
+    tick("pack arrays");
+    size_t cap = 0;
+    void *d = dev_pool().acquire(buf.size() + 256, &cap);
+    if (!d) return BT_ENOMEM;
+    tick("device buffer");
+    if (hipMemcpy(d, buf.data(), buf.size(), hipMemcpyHostToDevice) != hipSuccess) { dev_pool().release(d, cap); return BT_EHIP; }
+    tick("H2D copy");
     pl->dev_base = d;
+    pl->dev_cap = cap;
     const char *b = static_cast<const char *>(d);
     const bt_plan_info &I = pl->info;
     PlanDev &P = pl->dev;
@@ -64,7 +167,9 @@ int upload_plan(bt_plan *pl) {
     P.tile_pair0 = BT_I32(o_tp0); P.tile_npair = BT_I32(o_tnp); P.tile_pairs = BT_I32(o_tps);
     P.slot_lp = reinterpret_cast<const uint8_t *>(b + o_slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots;
 #undef BT_I32
-    return configure_kernels(P);
+    const int rc = configure_kernels(P);
+    tick("configure kernels");
+    return rc;
 }
 
 static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
@@ -115,6 +220,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
     *out = nullptr;
     std::vector<int64_t> host;
     const int64_t *hi = ii, *hj = jj, *hk = kk;
+    ApiTick tick;
     if (on_device && E > 0) {
         host.resize((size_t)(3 * E));
         if (hipMemcpy(host.data(), ii, (size_t)E * 8, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -122,12 +228,14 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
             hipMemcpy(host.data() + 2 * E, kk, (size_t)E * 8, hipMemcpyDeviceToHost) != hipSuccess)
             return BT_EHIP;
         hi = host.data(); hj = host.data() + E; hk = host.data() + 2 * E;
+        tick("D2H indices");
     }
-    bt_plan *pl = new (std::nothrow) bt_plan();
+    bt_plan *pl = plan_pool().take();
     if (!pl) return BT_ENOMEM;
     int rc = BT_OK;
     try {
         rc = build_plan_host(hi, hj, hk, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl);
+        tick("host analysis");
         if (rc == BT_OK && upload) rc = upload_plan(pl);
     } catch (const std::bad_alloc &) {
         rc = BT_ENOMEM;
@@ -139,9 +247,11 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
 
 void bt_plan_destroy(bt_plan *pl) {
     if (!pl) return;
-    if (pl->dev_base) (void)hipFree(pl->dev_base);
-    delete pl;
+    if (pl->dev_base) dev_pool().release(pl->dev_base, pl->dev_cap);
+    plan_pool().give(pl);
 }
+
+void bt_plan_pool_trim(void) { dev_pool().trim(); plan_pool().trim(); }
 
 int bt_plan_get_info(const bt_plan *pl, bt_plan_info *info) {
     if (!pl || !info) return BT_EINVAL;

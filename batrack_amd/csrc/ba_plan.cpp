@@ -109,14 +109,26 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     std::vector<int32_t> off((size_t)m + 1, 0);
     for (int64_t e = 0; e < E; ++e) if (owned(e)) off[(size_t)pl->trk_of_patch[(size_t)kk[e]] + 1]++;
     for (int32_t k = 0; k < m; ++k) off[(size_t)k + 1] += off[(size_t)k];
-    std::vector<int32_t> ord((size_t)E_own + 1), cur(off.begin(), off.end() - 1);
-    for (int64_t e = 0; e < E; ++e) if (owned(e)) ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = (int32_t)e;
+    // Two stable counting passes instead of a sort per track: first by target frame, then by track.  Within a
+    // track the source frame is the same for all edges (checked below), so ascending target frame IS ascending
+    // pair id, and stability keeps the original index as the tie-break (duplicates are normal, batrack.py:399-410).
+    // (edge-sized temporaries persist per thread: the caller builds one plan per frame, and fresh pages cost more
+    // than the passes over them)
+    static thread_local std::vector<int32_t> ord_scratch, byj_scratch;
+    std::vector<int32_t> &ord = ord_scratch, &byj = byj_scratch;
+    ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1);
+    std::vector<int32_t> cur(off.begin(), off.end() - 1);
+    {
+        std::vector<int32_t> cj((size_t)n_all + 1, 0);
+        for (int64_t e = 0; e < E; ++e) if (owned(e)) cj[(size_t)jj[e] + 1]++;
+        for (int64_t j = 0; j < n_all; ++j) cj[(size_t)j + 1] += cj[(size_t)j];
+        for (int64_t e = 0; e < E; ++e) if (owned(e)) byj[(size_t)cj[(size_t)jj[e]]++] = (int32_t)e;
+        for (int64_t q = 0; q < E_own; ++q) {
+            const int32_t e = byj[(size_t)q];
+            ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = e;
+        }
+    }
     auto pair_id = [&](int32_t e) { return pair_of[(size_t)(ii[e] * n_all + jj[e])]; };
-    for (int32_t k = 0; k < m; ++k)
-        std::sort(ord.begin() + off[(size_t)k], ord.begin() + off[(size_t)k + 1], [&](int32_t a, int32_t b) {
-            const int32_t pa = pair_id(a), pb = pair_id(b);
-            return pa != pb ? pa < pb : a < b;
-        });
 
     BT_TICK("4");
     // ---- one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)

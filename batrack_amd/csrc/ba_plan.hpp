@@ -70,8 +70,29 @@ struct bt_plan {
     int fz_ok = 0, fzp_ok = 0;
     int max_rows16 = 16;
     bt::WsLayout ws{};
-    void *dev_base = nullptr;   // one device allocation holding every array above
+    void *dev_base = nullptr;   // one device allocation holding every array above (from the pool in ba_api.cpp)
+    size_t dev_cap = 0;
     bt::PlanDev dev{};
+
+    // Back to the state of a new object, but with the vectors' capacity kept: destroyed plans are recycled
+    // by bt_plan_create (ba_api.cpp), so that a plan per frame costs no heap traffic.
+    void recycle() {
+        info = bt_plan_info{};
+        for (auto *v : {&kx, &trk_of_patch, &trk_loc, &upd_rec, &pair_i, &pair_j, &tile_trk0, &tile_ntrk, &tile_ncam,
+                        &tile_cam0, &tile_slot0, &tile_nslot, &tile_erow0, &tile_cams, &slot_edge, &slot_pair,
+                        &tile_pair0, &tile_npair, &tile_pairs, &tile_flags, &tile_ij, &tile_kx, &col_ptr, &row_idx,
+                        &upd_ptr, &upd, &blk_col, &upd_next, &perm, &blk_src, &lvl_ptr, &lvl_cols, &col_lvl, &dp_ptr,
+                        &dp, &lvl_meta, &fz_pend_ptr, &fz_pend, &fz_lazy_ptr, &fz_lazy, &fz_yurg, &fz_meta, &fz_pmeta,
+                        &bs_sync, &fz_rowinfo, &fz_pfirst, &fz_psecond})
+            v->clear();
+        slot_lab.clear(); slot_lp.clear();
+        max_tile_pairs = max_tile_slots = 0;
+        fz_ok = fzp_ok = 0;
+        max_rows16 = 16;
+        ws = bt::WsLayout{};
+        dev_base = nullptr; dev_cap = 0;
+        dev = bt::PlanDev{};
+    }
 };
 
 namespace bt {

@@ -57,6 +57,8 @@ def main():
     from batrack_amd.plan import Plan, Stepper
     from batrack_amd.parallel import ShardedBA
 
+    from batrack_amd.hostenv import limit_host_threads
+    limit_host_threads()          # a CPU pool wider than the cgroup quota freezes the launching thread (hostenv.py)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

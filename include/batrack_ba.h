@@ -77,7 +77,12 @@ typedef struct {
 int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
                    int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
                    int64_t own_lo, int64_t own_hi, int on_device, int upload, bt_plan **out);
+/* The device buffer and the host arrays of a destroyed plan are kept (up to eight of each) for the next
+ * bt_plan_create: the caller replaces its edge list every frame (batrack.py:189-212), and a
+ * hipMalloc/hipFree pair plus fresh host pages per frame cost more than the analysis itself.
+ * bt_plan_pool_trim() releases everything that is kept. */
 void bt_plan_destroy(bt_plan *plan);
+void bt_plan_pool_trim(void);
 int bt_plan_get_info(const bt_plan *plan, bt_plan_info *info);
 size_t bt_plan_workspace_bytes(const bt_plan *plan);
 

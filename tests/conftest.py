@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    from batrack_amd.hostenv import limit_host_threads
+    limit_host_threads()        # a CPU pool wider than the cgroup quota stalls the whole process (hostenv.py)
 
 
 @pytest.fixture(scope="session")

@@ -15,9 +15,11 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 import torch  # noqa: E402
 from batrack_amd import evaluation  # noqa: E402
+from batrack_amd.hostenv import limit_host_threads  # noqa: E402
 from batrack_amd.sequence import SlamConfig, SyntheticObservations, WindowedBA  # noqa: E402
 from sequence_util import oracle_BA_rgbd_droid  # noqa: E402
 
+limit_host_threads()
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=50)
 ap.add_argument("--M", type=int, default=256)

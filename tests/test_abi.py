@@ -108,3 +108,42 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_host_thread_guard():
+    """hostenv: the CPU pool is capped at the cgroup quota (a wider pool freezes the launching thread)."""
+    import torch
+    from batrack_amd import hostenv
+    q = hostenv.cpu_quota()
+    assert 1 <= q <= (os.cpu_count() or 1)
+    assert hostenv.limit_host_threads() <= q
+    before = torch.get_num_threads()
+    assert hostenv.limit_host_threads(cap=10 ** 6) == before      # never raises the count
+
+
+def test_destroyed_plans_are_recycled():
+    """bt_plan_destroy keeps host arrays for the next bt_plan_create; a recycled plan is indistinguishable."""
+    from batrack_amd import graphgen
+    from batrack_amd.plan import Plan, PLAN_ARRAYS
+    g1 = graphgen.make_config("C1", seed=0)
+    g2 = graphgen.make_random_graph(12, 40, seed=3)
+    ref = {}
+    for name, g in (("a", g1), ("b", g2)):
+        pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
+        ref[name] = (dict(pl.info), pl.arrays())
+        pl.close()
+        _lib.lib().bt_plan_pool_trim()                     # nothing kept: the next plan is a new object
+    for name, g in (("a", g1), ("b", g2), ("a", g1)):          # big -> small -> big through the same recycled object
+        pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
+        info, arrs = ref[name]
+        assert dict(pl.info) == info
+        got = pl.arrays()
+        assert set(got) == set(arrs) and all(np.array_equal(got[k], arrs[k]) for k in PLAN_ARRAYS)
+        pl.close()
+    # an invalid edge list goes back to the pool too and does not poison the next plan
+    bad = g1.jj.copy(); bad[0] = 10 ** 6
+    with pytest.raises(Exception):
+        Plan(g1.ii, bad, g1.kk, g1.poses.shape[0], g1.patches.shape[0], 1, upload=False)
+    pl = Plan(g1.ii, g1.jj, g1.kk, g1.poses.shape[0], g1.patches.shape[0], 1, upload=False)
+    assert all(np.array_equal(pl.arrays()[k], ref["a"][1][k]) for k in PLAN_ARRAYS)
+    pl.close()

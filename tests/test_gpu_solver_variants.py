@@ -52,6 +52,8 @@ VARIANTS = [
     ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0", "BT_SOLVER_ORDER": "0"}, 2e-3, 1e-5),
     ({"BT_TILE_MAX_WGS": "16"}, 2e-3, 1e-5),         # persistent k_tile: 16 tiles per workgroup at C3 (graphs > 1024 tiles use it)
     ({"BT_TILE_MAX_WGS": "3"}, 2e-3, 1e-5),          # ... with uneven tile ranges
+    ({"BT_TILE_WIDE": "1"}, 2e-3, 1e-5),             # 16-wave k_tile (chosen by itself for <= 128 tiles with >= 24 slots)
+    ({"BT_TILE_WIDE": "0"}, 2e-3, 1e-5),
     ({"BT_SOLVER_MODE": "1"}, 2e-2, 1e-4),
     ({"BT_SOLVER_MODE": "2"}, 2e-2, 1e-4),
 ]

@@ -8,7 +8,10 @@ import torch
 from batrack_amd import graphgen
 from batrack_amd.plan import Plan
 
-g = graphgen.make_config("C3", seed=0)
+if len(sys.argv) > 1 and sys.argv[1] == "window":
+    g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
+else:
+    g, fixedp = graphgen.make_config("C3", seed=0), 1
 n_buf, p_tot = g.poses.shape[0], g.patches.shape[0]
 dev = "cuda:0"
 ii, jj, kk = (torch.as_tensor(a, device=dev) for a in (g.ii, g.jj, g.kk))
@@ -19,8 +22,19 @@ for name, args, kw in (("host arrays, no upload", (g.ii, g.jj, g.kk), dict(uploa
     for _ in range(8):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pl = Plan(*args, n_buf, p_tot, 1, **kw)
+        pl = Plan(*args, n_buf, p_tot, fixedp, **kw)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
         pl.close()
     print(f"{name:26s}: first {ts[0]:.2f} ms, then median {np.median(ts[1:]):.2f} ms")
+
+from batrack_amd.plan import Stepper
+ts = []
+for _ in range(6):
+    pl = Plan(ii, jj, kk, n_buf, p_tot, fixedp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = Stepper(pl, dev)
+    torch.cuda.synchronize()
+    ts.append((time.perf_counter() - t0) * 1e3)
+print(f"Stepper (workspace) creation: first {ts[0]:.2f} ms, then median {np.median(ts[1:]):.2f} ms")
