@@ -255,6 +255,16 @@ class WindowedBA:
             self.update()
             self.keyframe_simple()
 
+    # ---- batrack.py:1080-1135, the BA-owned part of the hand-off to the next stage
+    def get_results(self):
+        """`cams_T_world` [n,4,4] (inverse pose matrices), `intrinsics` [n,4], `tstamps` [n] with the reference's
+        keys and layout.  The tracker-owned entries of results.pkl (`trajs_2d_disp`, `trajs_valid`, `trajs_static`,
+        `trajs_vis`, `grid_query_frames`, `dmaps`, `rgbs`) have no counterpart in this replay and are not emitted."""
+        G = SE3(self.poses_[:self.n])
+        return {"cams_T_world": G.inv().matrix().detach().cpu().numpy(),
+                "intrinsics": self.intrinsics_[:self.n].detach().cpu().numpy(),
+                "tstamps": np.arange(self.n, dtype=float)}
+
     def run(self, n_frames=None):
         for _ in range(self.obs.n_frames if n_frames is None else n_frames):
             self()

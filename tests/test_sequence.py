@@ -84,3 +84,16 @@ def test_oracle_driven_sequence_tracks_the_camera():
     assert ate < 0.25 * still and ate < 0.005, (ate, still)
     assert trk.stats["ba_calls"] == 2 * 2 * trk.stats["updates"]
     assert np.abs(np.linalg.norm(poses[:, 3:], axis=1) - 1.0).max() < 1e-5
+
+
+def test_results_hand_off_layout():
+    """batrack.py:1086-1087: cams_T_world = poses.inv().matrix(); the ATE computed from it is the one from the poses."""
+    obs = SyntheticObservations(n_frames=14, M=8, seed=7)
+    trk = WindowedBA(obs, oracle_BA_rgbd_droid, small_cfg(obs))
+    poses = trk.run()
+    res = trk.get_results()
+    T = res["cams_T_world"]
+    assert T.shape == (14, 4, 4) and res["intrinsics"].shape == (14, 4) and res["tstamps"].shape == (14,)
+    assert np.allclose(T[:, 3], [0, 0, 0, 1]) and np.allclose(T[:, :3, :3] @ T[:, :3, :3].transpose(0, 2, 1), np.eye(3), atol=1e-5)
+    assert np.abs(T[:, :3, 3] - evaluation.camera_centres(poses)).max() < 1e-5
+    assert np.allclose(T[0], np.eye(4), atol=1e-6)            # frame 0 is the fixed gauge (fixedp >= 1)
