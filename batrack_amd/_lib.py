@@ -8,9 +8,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "lib", "libbatrack_ba.so")
-SOURCES = ["ba_kernels.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip"]
+SOURCES = ["ba_kernels.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip"]
 HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
-           os.path.join("..", "..", "include", "batrack_se3.h"), os.path.join("..", "..", "include", "batrack_patchify.h")]
+           os.path.join("..", "..", "include", "batrack_se3.h"), os.path.join("..", "..", "include", "batrack_patchify.h"),
+           os.path.join("..", "..", "include", "batrack_projective.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 
 BT_OK, BT_EINVAL, BT_ENOMEM, BT_EHIP, BT_EUNSUPPORTED = 0, -1, -2, -3, -4
@@ -104,6 +105,8 @@ def lib():
         f = getattr(L, name)
         f.restype = i32
         f.argtypes = [vp] * nptr + [i64, i32, vp]
+    L.bt_reproject.restype = i32
+    L.bt_reproject.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp]
     L.bt_patchify.restype = i32
     L.bt_patchify.argtypes = [vp, i64, i64, i64, i64, vp, i64, i32, i32, vp, vp]
     _lib = L
