@@ -51,3 +51,15 @@ print(f"update() total {1e3 * trk.stats['ba_seconds'] / trk.stats['updates']:.3f
 print("mean us per position:", " ".join(f"{np.mean(p):.0f}" for p in per), "| max:", " ".join(f"{np.max(p):.0f}" for p in per))
 print("sum of timed calls %.3f s of update total %.3f s" % (sum(map(sum, per)) * 1e-6, trk.stats["ba_seconds"]))
 print("position-0 calls (ms):", " ".join(f"{t/1e3:.1f}" for t in per[0]))
+
+# the map-filtering reprojection over the final edge list: fused kernel vs composed tensor operations
+from batrack_amd.backend import projective_ops as pops
+from batrack_amd.backend.lietorch import SE3
+for fused in (True, False):
+    for _ in range(3):
+        pops.transform(SE3(trk.poses), trk.patches, trk.intrinsics, trk.ii, trk.jj, trk.kk, fused=fused)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        pops.transform(SE3(trk.poses), trk.patches, trk.intrinsics, trk.ii, trk.jj, trk.kk, fused=fused)
+    torch.cuda.synchronize()
+    print(f"transform over {trk.ii.numel()} edges, fused={fused}: {(time.perf_counter() - t0) / 20 * 1e6:.1f} us")
