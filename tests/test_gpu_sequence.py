@@ -12,11 +12,12 @@ from sequence_util import oracle_BA_rgbd_droid
 pytestmark = pytest.mark.gpu
 
 
-def run_pair(n_frames, M, seed, cfg_kw=None):
+def run_pair(n_frames, M, seed, cfg_kw=None, cam=None):
     from batrack_amd.backend.ba import BA_rgbd_droid
     out = {}
     for name, ba, dev in (("hip", BA_rgbd_droid, "cuda:0"), ("oracle", oracle_BA_rgbd_droid, "cpu")):
-        obs = SyntheticObservations(n_frames=n_frames, M=M, seed=seed)          # same seed -> same observations
+        kw = {} if cam is None else dict(cam=cam)
+        obs = SyntheticObservations(n_frames=n_frames, M=M, seed=seed, **kw)    # same seed -> same observations
         cfg = SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=n_frames + 1, **(cfg_kw or {}))
         trk = WindowedBA(obs, ba, cfg, device=dev)
         poses = trk.run()
@@ -42,3 +43,13 @@ def test_ate_matches_the_oracle_driven_run(n_frames, M, seed):
 def test_short_window_config():
     r = run_pair(24, 32, 2, dict(num_init=6, init_updates=6, ITER=2, OPTIMIZATION_WINDOW=8, REMOVAL_WINDOW=10, S_slam=6))
     assert abs(r["hip"]["ate"] - r["oracle"]["ate"]) <= 0.01 * r["oracle"]["ate"]
+
+
+def test_davis_shaped_stage():
+    """BASELINE.json configs[1] stand-in: DAVIS-shaped frames (848x480 after the crop to multiples of
+    16), 400 tracks per frame (davis_demo.yaml:14), sintel-style window -> ~216k edges, the full update() pattern."""
+    from batrack_amd import graphgen
+    r = run_pair(26, 400, 21, cam=graphgen.DAVIS)
+    assert r["hip"]["stats"]["edges_max"] > 150000
+    assert abs(r["hip"]["ate"] - r["oracle"]["ate"]) <= 0.01 * r["oracle"]["ate"], (r["hip"]["ate"], r["oracle"]["ate"])
+    assert np.abs(r["hip"]["poses"] - r["oracle"]["poses"]).max() < 2e-4

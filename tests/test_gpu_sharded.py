@@ -15,15 +15,18 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _inputs(seed=3):
+def _inputs(seed=3, shape="band"):
     from batrack_amd import graphgen
-    g = graphgen.make_graph(16, 64, 8, seed=seed)
+    if shape == "shibuya":      # BASELINE.json configs[3] stand-in: Shibuya camera, sliding-window edge list
+        g, _ = graphgen.make_window_graph(n_frames=24, M=64, seed=seed, cam=graphgen.SHIBUYA)
+    else:
+        g = graphgen.make_graph(16, 64, 8, seed=seed)
     f = lambda a: np.asarray(a, np.float32)
     return g, dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intr=f(g.intrinsics),
                    t3=f(g.targets3), w=f(g.weights_pose), ii=g.ii, jj=g.jj, kk=g.kk)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, shape, fixedp):
     sys.path[:0] = [os.path.dirname(HERE), HERE]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,11 +34,11 @@ def _worker(rank, world, port, out):
     try:
         from batrack_amd.parallel import ShardedBA
         dev = torch.device("cuda:0")
-        g, d = _inputs()
+        g, d = _inputs(shape=shape)
         T = lambda a: torch.as_tensor(a, device=dev)
         poses, patches, mono, intr, t3, w = (T(d[k]) for k in ("poses", "patches", "mono", "intr", "t3", "w"))
         ii, jj, kk = T(d["ii"]), T(d["jj"]), T(d["kk"])
-        eng = ShardedBA(ii, jj, kk, poses.shape[0], patches.shape[0], 1, dev)
+        eng = ShardedBA(ii, jj, kk, poses.shape[0], patches.shape[0], fixedp, dev)
         tg, wl = eng.local(t3), eng.local(w)
         scal = (list(g.bounds), 1e-4, 10.0, 0.05, "huber")
         P, X = [poses, torch.empty_like(poses)], [patches, torch.empty_like(patches)]
@@ -48,14 +51,15 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_step_equals_single_gpu():
+@pytest.mark.parametrize("shape,fixedp", [("band", 1), ("shibuya", 9)])
+def test_two_rank_sharded_step_equals_single_gpu(shape, fixedp):
     from batrack_amd.plan import Plan, Stepper
-    g, d = _inputs()
+    g, d = _inputs(shape=shape)
     dev = "cuda:0"
     T = lambda a: torch.as_tensor(a, device=dev)
     poses, patches, mono, intr, t3, w = (T(d[k]) for k in ("poses", "patches", "mono", "intr", "t3", "w"))
     ii, jj, kk = T(d["ii"]), T(d["jj"]), T(d["kk"])
-    st = Stepper(Plan(ii, jj, kk, poses.shape[0], patches.shape[0], 1), dev)
+    st = Stepper(Plan(ii, jj, kk, poses.shape[0], patches.shape[0], fixedp), dev)
     scal = (list(g.bounds), 1e-4, 10.0, 0.05, "huber")
     P, X = [poses, torch.empty_like(poses)], [patches, torch.empty_like(patches)]
     for k in range(2):
@@ -66,7 +70,7 @@ def test_two_rank_sharded_step_equals_single_gpu():
     world, port = 2, 29700 + (os.getpid() % 1000)
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, shape, fixedp), nprocs=world, join=True)
     assert len(out) == world and sum(out[r][2] for r in range(world)) == len(d["ii"])
     rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b)
     for r in range(world):
