@@ -45,7 +45,6 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--sweep", action="store_true", help="also print an edge-count sweep of k_tile (stderr)")
     return ap.parse_args()
 
 
