@@ -80,21 +80,31 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     if (n > kMaxFree) return BT_EUNSUPPORTED;
 
     BT_TICK("1");
-    // ---- unique tracks, ascending (ba.py:276) ------------------------------
-    pl->trk_of_patch.assign((size_t)p_tot, -1);
+    // ---- one pass over the edges: edges per track, per target frame, and the camera pairs in use
+    pl->trk_of_patch.assign((size_t)p_tot, 0);
+    std::vector<int32_t> pair_of((size_t)(n_all * n_all), -1), cj((size_t)n_all + 1, 0);
     int64_t E_own = 0;
-    for (int64_t e = 0; e < E; ++e) if (owned(e)) { pl->trk_of_patch[(size_t)kk[e]] = 0; ++E_own; }
+    for (int64_t e = 0; e < E; ++e)
+        if (owned(e)) {
+            ++pl->trk_of_patch[(size_t)kk[e]];
+            pair_of[(size_t)(ii[e] * n_all + jj[e])] = 0;
+            ++cj[(size_t)jj[e] + 1];
+            ++E_own;
+        }
     I.E = E_own;
+    // unique tracks, ascending (ba.py:276); off = first position of a track's edges in the grouped order
     int32_t m = 0;
     pl->kx.clear();
-    for (int64_t p = 0; p < p_tot; ++p)
-        if (pl->trk_of_patch[(size_t)p] == 0) { pl->trk_of_patch[(size_t)p] = m++; pl->kx.push_back((int32_t)p); }
+    std::vector<int32_t> off(1, 0);
+    for (int64_t p = 0; p < p_tot; ++p) {
+        const int32_t c = pl->trk_of_patch[(size_t)p];
+        if (c > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + c); pl->trk_of_patch[(size_t)p] = m++; }
+        else pl->trk_of_patch[(size_t)p] = -1;
+    }
     I.m = m;
 
     BT_TICK("2");
     // ---- distinct camera pairs, ascending (i, j) ---------------------------
-    std::vector<int32_t> pair_of((size_t)(n_all * n_all), -1);
-    for (int64_t e = 0; e < E; ++e) if (owned(e)) pair_of[(size_t)(ii[e] * n_all + jj[e])] = 0;
     pl->pair_i.clear(); pl->pair_j.clear();
     for (int64_t key = 0; key < n_all * n_all; ++key)
         if (pair_of[(size_t)key] == 0) {
@@ -106,9 +116,6 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
     BT_TICK("3");
     // ---- edges grouped by track, ordered by (pair, original index) ---------
-    std::vector<int32_t> off((size_t)m + 1, 0);
-    for (int64_t e = 0; e < E; ++e) if (owned(e)) off[(size_t)pl->trk_of_patch[(size_t)kk[e]] + 1]++;
-    for (int32_t k = 0; k < m; ++k) off[(size_t)k + 1] += off[(size_t)k];
     // Two stable counting passes instead of a sort per track: first by target frame, then by track.  Within a
     // track the source frame is the same for all edges (checked below), so ascending target frame IS ascending
     // pair id, and stability keeps the original index as the tie-break (duplicates are normal, batrack.py:399-410).
@@ -118,24 +125,15 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     std::vector<int32_t> &ord = ord_scratch, &byj = byj_scratch;
     ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1);
     std::vector<int32_t> cur(off.begin(), off.end() - 1);
-    {
-        std::vector<int32_t> cj((size_t)n_all + 1, 0);
-        for (int64_t e = 0; e < E; ++e) if (owned(e)) cj[(size_t)jj[e] + 1]++;
-        for (int64_t j = 0; j < n_all; ++j) cj[(size_t)j + 1] += cj[(size_t)j];
-        for (int64_t e = 0; e < E; ++e) if (owned(e)) byj[(size_t)cj[(size_t)jj[e]]++] = (int32_t)e;
-        for (int64_t q = 0; q < E_own; ++q) {
-            const int32_t e = byj[(size_t)q];
-            ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = e;
-        }
+    for (int64_t j = 0; j < n_all; ++j) cj[(size_t)j + 1] += cj[(size_t)j];
+    for (int64_t e = 0; e < E; ++e) if (owned(e)) byj[(size_t)cj[(size_t)jj[e]]++] = (int32_t)e;
+    for (int64_t q = 0; q < E_own; ++q) {
+        const int32_t e = byj[(size_t)q];
+        ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = e;
     }
     auto pair_id = [&](int32_t e) { return pair_of[(size_t)(ii[e] * n_all + jj[e])]; };
 
     BT_TICK("4");
-    // ---- one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)
-    for (int32_t k = 0; k < m; ++k)
-        for (int32_t sidx = off[(size_t)k] + 1; sidx < off[(size_t)k + 1]; ++sidx)
-            if (ii[ord[(size_t)sidx]] != ii[ord[(size_t)off[(size_t)k]]]) return BT_EUNSUPPORTED;
-
     BT_TICK("5");
     // ---- tiles: greedy over sorted tracks ----------------------------------
     pl->tile_trk0.clear(); pl->tile_ntrk.clear(); pl->tile_ncam.clear(); pl->tile_cam0.clear();
@@ -168,8 +166,10 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     };
     for (int32_t k = 0; k < m; ++k) {
         trk_set.clear();
+        const int64_t src = off[(size_t)k] < off[(size_t)k + 1] ? ii[ord[(size_t)off[(size_t)k]]] : 0;
         for (int32_t s = off[(size_t)k]; s < off[(size_t)k + 1]; ++s) {
             const int32_t e = ord[(size_t)s];
+            if (ii[e] != src) return BT_EUNSUPPORTED;      // one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)
             const int64_t cams[2] = { ii[e] - fixedp, jj[e] - fixedp };
             for (int64_t c : cams)
                 if (c >= 0 && tstamp[(size_t)c] != k) { tstamp[(size_t)c] = k; trk_set.push_back((int32_t)c); }
