@@ -87,6 +87,15 @@ class Plan:
             pass
 
 
+def _raw_stream(device):
+    """hipStream_t of PyTorch's current stream on `device` (without building a Stream object per call)."""
+    import torch
+    try:
+        return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+    except AttributeError:
+        return torch.cuda.current_stream(device).cuda_stream
+
+
 class Stepper:
     """A plan bound to a device: owns the workspace, fills bt_ba_args, launches."""
 
@@ -100,16 +109,31 @@ class Stepper:
         self.ws = torch.zeros(max(plan.workspace_bytes, 256), dtype=torch.uint8, device=self.device)
         self._args = _lib.BaArgs()
         self._lib = _lib.lib()
-        cnt = ctypes.c_int64()
-        sys_ptr = self._lib.bt_ba_system(plan.handle, self.ws.data_ptr(), ctypes.byref(cnt))
-        off = sys_ptr - self.ws.data_ptr()
-        self.system = self.ws[off:off + 8 * cnt.value].view(torch.float64)      # [S | y], dense
-        pk_ptr = self._lib.bt_ba_packed(plan.handle, self.ws.data_ptr(), ctypes.byref(cnt))
-        off = pk_ptr - self.ws.data_ptr()
-        self.packed = self.ws[off:off + 8 * cnt.value].view(torch.float64)      # its non-zero blocks, for the all-reduce
-        D = 6 * plan.n
-        dx_off = self._lib.bt_ba_dx(plan.handle, self.ws.data_ptr()) - self.ws.data_ptr()
-        self.dx = self.ws[dx_off:dx_off + 4 * D].view(torch.float32).view(plan.n, 6)
+        self._ws_ptr = self.ws.data_ptr()
+        self._views = {}
+
+    def _view(self, name):
+        """Typed views into the workspace, made on first use (the per-frame path never needs them)."""
+        v = self._views.get(name)
+        if v is None:
+            import torch
+            plan, base = self.plan, self._ws_ptr
+            cnt = ctypes.c_int64()
+            if name == "system":          # [S | y], dense
+                off = self._lib.bt_ba_system(plan.handle, base, ctypes.byref(cnt)) - base
+                v = self.ws[off:off + 8 * cnt.value].view(torch.float64)
+            elif name == "packed":        # its non-zero blocks, for the all-reduce
+                off = self._lib.bt_ba_packed(plan.handle, base, ctypes.byref(cnt)) - base
+                v = self.ws[off:off + 8 * cnt.value].view(torch.float64)
+            else:                         # dX [n, 6]
+                off = self._lib.bt_ba_dx(plan.handle, base) - base
+                v = self.ws[off:off + 4 * 6 * plan.n].view(torch.float32).view(plan.n, 6)
+            self._views[name] = v
+        return v
+
+    system = property(lambda self: self._view("system"))
+    packed = property(lambda self: self._view("packed"))
+    dx = property(lambda self: self._view("dx"))
 
     def _fill(self, poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
               bounds, lmbda, ep, alpha, loss, structure_only):
@@ -127,16 +151,16 @@ class Stepper:
     def step(self, *args, stream=None, phase="all"):
         import torch
         a = self._fill(*args)
-        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        st = _raw_stream(self.device) if stream is None else stream
         fn = {"all": self._lib.bt_ba_step, "reduce": self._lib.bt_ba_reduce, "pack": self._lib.bt_ba_pack,
               "unpack": self._lib.bt_ba_unpack, "solve_update": self._lib.bt_ba_solve_update}[phase]
-        _lib.check(fn(self.plan.handle, ctypes.byref(a), self.ws.data_ptr(), st), f"bt_ba_{phase}")
+        _lib.check(fn(self.plan.handle, ctypes.byref(a), self._ws_ptr, st), f"bt_ba_{phase}")
 
     def step_timed(self, *args, stream=None):
         """One step with per-kernel HIP-event timing -> dict of milliseconds."""
         import torch
         a = self._fill(*args)
-        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        st = _raw_stream(self.device) if stream is None else stream
         ms = (ctypes.c_float * 5)()
         _lib.check(self._lib.bt_ba_step_timed(self.plan.handle, ctypes.byref(a), self.ws.data_ptr(), st, ms),
                    "bt_ba_step_timed")
@@ -145,6 +169,6 @@ class Stepper:
     def status(self):
         import torch
         s = ctypes.c_int32(-1)
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        st = _raw_stream(self.device)
         _lib.check(self._lib.bt_ba_status(self.plan.handle, self.ws.data_ptr(), st, ctypes.byref(s)), "bt_ba_status")
         return s.value
