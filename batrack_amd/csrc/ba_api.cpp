@@ -118,8 +118,9 @@ struct ApiTick {
 
 int upload_plan(bt_plan *pl) {
     ApiTick tick;
-    std::vector<char> buf;
-    const size_t o_kx = put(buf, pl->kx), o_top = put(buf, pl->trk_of_patch), o_loc = put(buf, pl->trk_loc);
+    std::vector<char> &buf = pl->stage;           // capacity survives with the recycled plan object
+    buf.clear();
+    const size_t o_kx = put(buf, pl->kx), o_ab = put(buf, pl->act_bits), o_ar = put(buf, pl->act_rank), o_loc = put(buf, pl->trk_loc);
     const size_t o_pi = put(buf, pl->pair_i), o_pj = put(buf, pl->pair_j);
     const size_t o_t0 = put(buf, pl->tile_trk0), o_tn = put(buf, pl->tile_ntrk), o_tc = put(buf, pl->tile_ncam);
     const size_t o_c0 = put(buf, pl->tile_cam0), o_s0 = put(buf, pl->tile_slot0), o_sn = put(buf, pl->tile_nslot);
@@ -150,7 +151,8 @@ int upload_plan(bt_plan *pl) {
     P.T = (int)I.tiles; P.slots = (int)I.slots; P.erows = (int)I.erows; P.nnzb = (int)I.nnz_blocks;
     P.nupd = (int)I.updates; P.max_rows16 = pl->max_rows16;
 #define BT_I32(off) reinterpret_cast<const int32_t *>(b + (off))
-    P.kx = BT_I32(o_kx); P.trk_of_patch = BT_I32(o_top); P.trk_loc = BT_I32(o_loc);
+    P.kx = BT_I32(o_kx); P.trk_loc = BT_I32(o_loc);
+    P.act_bits = reinterpret_cast<const uint32_t *>(b + o_ab); P.act_rank = BT_I32(o_ar);
     P.pair_i = BT_I32(o_pi); P.pair_j = BT_I32(o_pj);
     P.tile_trk0 = BT_I32(o_t0); P.tile_ntrk = BT_I32(o_tn); P.tile_ncam = BT_I32(o_tc); P.tile_cam0 = BT_I32(o_c0);
     P.tile_slot0 = BT_I32(o_s0); P.tile_nslot = BT_I32(o_sn); P.tile_erow0 = BT_I32(o_e0); P.tile_cams = BT_I32(o_cams);
@@ -270,7 +272,7 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
     BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next) BT_ARR(perm) BT_ARR(blk_src) BT_ARR(lvl_ptr) BT_ARR(lvl_cols)
     BT_ARR(col_lvl) BT_ARR(dp_ptr) BT_ARR(dp) BT_ARR(tile_pair0) BT_ARR(tile_npair) BT_ARR(tile_pairs) BT_ARR(slot_lp) BT_ARR(tile_flags)
-    BT_ARR(fz_pend_ptr) BT_ARR(fz_pend) BT_ARR(fz_lazy_ptr) BT_ARR(fz_lazy) BT_ARR(fz_yurg) BT_ARR(fz_meta) BT_ARR(fz_pmeta) BT_ARR(bs_sync) BT_ARR(fz_rowinfo) BT_ARR(fz_pfirst) BT_ARR(fz_psecond) BT_ARR(upd_rec) BT_ARR(tile_ij) BT_ARR(tile_kx) BT_ARR(lvl_meta)
+    BT_ARR(fz_pend_ptr) BT_ARR(fz_pend) BT_ARR(fz_lazy_ptr) BT_ARR(fz_lazy) BT_ARR(fz_yurg) BT_ARR(fz_meta) BT_ARR(fz_pmeta) BT_ARR(bs_sync) BT_ARR(fz_rowinfo) BT_ARR(fz_pfirst) BT_ARR(fz_psecond) BT_ARR(upd_rec) BT_ARR(act_bits) BT_ARR(act_rank) BT_ARR(tile_ij) BT_ARR(tile_kx) BT_ARR(lvl_meta)
 #undef BT_ARR
     return -1;
 }

@@ -2080,14 +2080,15 @@ __global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_p
     if (gid < pd.p_tot) {
         const float x = a.patches[3*gid], y = a.patches[3*gid + 1], d = a.patches[3*gid + 2];
         float dz = 0.0f;
+        // track of this patch, or -1: bitmap + rank (most of the buffer's patches are not in the window)
+        const unsigned aw = pd.act_bits[gid >> 5], ab = (unsigned)gid & 31u;
+        const int k = (aw >> ab) & 1u ? pd.act_rank[gid >> 5] + __popc(aw & ((1u << ab) - 1u)) : -1;
         if (SO) {
-            const int k = pd.trk_of_patch[gid];
             if (k >= 0) { const float2 qw = a.qw[k]; dz = qw.x * qw.y; }               // ba.py:316-317
         } else {
-            // one record per patch (ba_plan.cpp: upd_rec): track, where its E rows start, its cameras
-            const int4 r0 = reinterpret_cast<const int4 *>(pd.upd_rec)[2 * gid], r1 = reinterpret_cast<const int4 *>(pd.upd_rec)[2 * gid + 1];
-            const int k = r0.x;
             if (k >= 0) {
+                // one record per track (ba_plan.cpp: upd_rec): where its E rows start, its cameras
+                const int4 r0 = reinterpret_cast<const int4 *>(pd.upd_rec)[2 * k], r1 = reinterpret_cast<const int4 *>(pd.upd_rec)[2 * k + 1];
                 const float2 qw = a.qw[k];
                 const float *base = a.esave + (size_t)r0.y;
                 float acc = 0.0f;

@@ -643,14 +643,22 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     pl->max_tile_slots = 0;
     for (int64_t t = 0; t < I.tiles; ++t) pl->max_tile_slots = std::max(pl->max_tile_slots, (int)pl->tile_nslot[(size_t)t]);
 
-    // ---- k_update: everything a patch's depth back-substitution needs in one 32-byte record,
-    // [track or -1, first E row * 64 + lane, #cameras (bit 30: more than 16, use the tile arrays), 0, 16 camera bytes]
-    pl->upd_rec.assign((size_t)p_tot * 8, 0);
-    for (int64_t p = 0; p < p_tot; ++p) {
-        int32_t *r = pl->upd_rec.data() + (size_t)p * 8;
-        const int32_t k = pl->trk_of_patch[(size_t)p];
+    // ---- k_update: which patches carry a track (bitmap + rank per 32 patches: the patch buffer is BUFFER_SIZE x M
+    // = 262,144 slots in the reference's configuration, the window's tracks a few thousand), and per TRACK
+    // everything its depth back-substitution needs in one 32-byte record:
+    // [track, first E row * 64 + lane, #cameras (bit 30: more than 16, use the tile arrays), 0, 16 camera bytes]
+    const size_t nwords = (size_t)((p_tot + 31) / 32);
+    pl->act_bits.assign(nwords, 0u);
+    pl->act_rank.assign(nwords, 0);
+    for (int32_t k = 0; k < I.m; ++k) pl->act_bits[(size_t)(pl->kx[(size_t)k] >> 5)] |= 1u << (pl->kx[(size_t)k] & 31);
+    {
+        int32_t run = 0;
+        for (size_t w = 0; w < nwords; ++w) { pl->act_rank[w] = run; run += __builtin_popcount(pl->act_bits[w]); }
+    }
+    pl->upd_rec.assign((size_t)I.m * 8, 0);
+    for (int32_t k = 0; k < I.m; ++k) {
+        int32_t *r = pl->upd_rec.data() + (size_t)k * 8;
         r[0] = k;
-        if (k < 0) continue;
         const int32_t loc = pl->trk_loc[(size_t)k], tile = loc >> 6, ln = loc & 63;
         const int32_t nc = pl->tile_ncam[(size_t)tile], c0 = pl->tile_cam0[(size_t)tile];
         r[1] = pl->tile_erow0[(size_t)tile] * kLanes + ln;

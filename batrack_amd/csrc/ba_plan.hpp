@@ -23,7 +23,9 @@ constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geom
 // Device-side view: raw pointers into one device allocation + sizes.
 struct PlanDev {
     int E, n_buf, p_tot, fixedp, n_all, n, D, m, P, T, slots, erows, nnzb, nupd, max_rows16;
-    const int32_t *kx, *trk_of_patch, *trk_loc, *upd_rec;
+    const int32_t *kx, *trk_loc, *upd_rec;                   // upd_rec: 8 ints per TRACK
+    const uint32_t *act_bits;                                // bit p: patch p has a track; [ceil(p_tot / 32)]
+    const int32_t *act_rank;                                 // tracks before the word's first patch: track(p) = act_rank[p>>5] + popc(bits below p)
     const int32_t *pair_i, *pair_j;
     const int32_t *tile_trk0, *tile_ntrk, *tile_ncam, *tile_cam0, *tile_slot0, *tile_nslot, *tile_erow0;
     const int32_t *tile_cams;
@@ -55,7 +57,9 @@ struct WsLayout {
 
 struct bt_plan {
     bt_plan_info info{};
-    std::vector<int32_t> kx, trk_of_patch, trk_loc, upd_rec;
+    std::vector<int32_t> kx, trk_of_patch, trk_loc, upd_rec, act_rank;      // trk_of_patch: host only
+    std::vector<uint32_t> act_bits;
+    std::vector<char> stage;     // upload staging (kept with the object: ba_api.cpp)
     std::vector<int32_t> pair_i, pair_j;
     std::vector<int32_t> tile_trk0, tile_ntrk, tile_ncam, tile_cam0, tile_slot0, tile_nslot, tile_erow0;
     std::vector<int32_t> tile_cams;
@@ -85,7 +89,7 @@ struct bt_plan {
                         &dp, &lvl_meta, &fz_pend_ptr, &fz_pend, &fz_lazy_ptr, &fz_lazy, &fz_yurg, &fz_meta, &fz_pmeta,
                         &bs_sync, &fz_rowinfo, &fz_pfirst, &fz_psecond})
             v->clear();
-        slot_lab.clear(); slot_lp.clear();
+        slot_lab.clear(); slot_lp.clear(); act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;
         fz_ok = fzp_ok = 0;
         max_rows16 = 16;

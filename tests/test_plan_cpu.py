@@ -211,3 +211,41 @@ def test_barrier_free_solver_schedule_orders_every_conflict():
         A = Plan(gg.ii, gg.jj, gg.kk, gg.poses.shape[0], gg.patches.shape[0], fp, upload=False).arrays()
         assert pipe_schedule_applies(A)
         check_pipe_protocol(A)
+
+
+def test_patch_activity_tables_and_track_records():
+    """k_update's tables: bitmap + rank give every patch its track (or none), also with the reference's buffer of
+    1024 x 256 patch slots of which a window uses a few thousand; one 32-byte record per track."""
+    from batrack_amd import graphgen
+    from batrack_amd.plan import Plan
+    g, fixedp = graphgen.make_window_graph(n_frames=30, M=64, seed=2, n_buf=1024)
+    n_buf, p_tot = g.poses.shape[0], g.patches.shape[0]
+    assert p_tot == 1024 * 64
+    for graph, fp in ((g, fixedp), (graphgen.make_random_graph(14, 40, seed=9), 1)):
+        pl = Plan(graph.ii, graph.jj, graph.kk, graph.poses.shape[0], graph.patches.shape[0], fp, upload=False)
+        A = pl.arrays()
+        P = graph.patches.shape[0]
+        bits, rank, top = A["act_bits"], A["act_rank"], A["trk_of_patch"]
+        assert bits.dtype == np.uint32 and bits.shape[0] == rank.shape[0] == (P + 31) // 32
+        p = np.arange(P)
+        w, b = p >> 5, (p & 31).astype(np.uint32)
+        on = (bits[w] >> b) & 1
+        below = bits[w] & ((np.uint32(1) << b) - np.uint32(1))
+        pop = np.array([bin(int(x)).count("1") for x in below])
+        trk = np.where(on == 1, rank[w] + pop, -1)
+        assert np.array_equal(trk, top)
+        assert np.array_equal(np.flatnonzero(on), A["kx"]) and pl.m == int(on.sum())
+        rec = A["upd_rec"].reshape(-1, 8)
+        assert rec.shape[0] == pl.m
+        loc = A["trk_loc"]
+        tile, lane = loc >> 6, loc & 63
+        assert np.array_equal(rec[:, 0], np.arange(pl.m))
+        assert np.array_equal(rec[:, 1], A["tile_erow0"][tile] * 64 + lane)
+        nc = A["tile_ncam"][tile]
+        assert np.array_equal(rec[:, 2] & 0xffff, nc) and np.array_equal((rec[:, 2] >> 30) & 1, (nc > 16).astype(np.int32))
+        for k in range(0, pl.m, max(1, pl.m // 50)):
+            if nc[k] <= 16:
+                cams = A["tile_cams"][A["tile_cam0"][tile[k]]:A["tile_cam0"][tile[k]] + nc[k]]
+                got = [(int(rec[k, 4 + c // 4]) >> (8 * (c % 4))) & 255 for c in range(nc[k])]
+                assert got == list(cams)
+        pl.close()

@@ -12,7 +12,7 @@ from batrack_amd.sequence import SlamConfig, SyntheticObservations, WindowedBA
 frames, M = int(os.environ.get("FRAMES", 50)), int(os.environ.get("M", 256))
 for rep in range(2):
     obs = SyntheticObservations(n_frames=frames, M=M, seed=0)
-    trk = WindowedBA(obs, BA_rgbd_droid, SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=frames + 1), device="cuda:0")
+    trk = WindowedBA(obs, BA_rgbd_droid, SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=int(os.environ.get("BUFFER", frames + 1))), device="cuda:0")
     if rep == 1:
         pr = cProfile.Profile(); pr.enable()
     t0 = time.perf_counter(); trk.run(); wall = time.perf_counter() - t0
@@ -30,7 +30,7 @@ def _timed(self, *a, **k):
     torch.cuda.synchronize(); t = time.perf_counter(); _orig(self, *a, **k); _times.append((time.perf_counter() - t) * 1e3)
 _plan.Plan.__init__ = _timed
 obs = SyntheticObservations(n_frames=frames, M=M, seed=0)
-trk = WindowedBA(obs, BA_rgbd_droid, SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=frames + 1), device="cuda:0")
+trk = WindowedBA(obs, BA_rgbd_droid, SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=int(os.environ.get("BUFFER", frames + 1))), device="cuda:0")
 trk.run()
 print("Plan() wall ms per call:", " ".join(f"{t:.2f}" for t in _times))
 
@@ -43,7 +43,7 @@ def timed_ba(*a, **k):
     per[state["k"] % 8].append((time.perf_counter() - t) * 1e6); state["k"] += 1
     return r
 obs = SyntheticObservations(n_frames=frames, M=M, seed=0)
-trk = WindowedBA(obs, timed_ba, SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=frames + 1), device="cuda:0")
+trk = WindowedBA(obs, timed_ba, SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=int(os.environ.get("BUFFER", frames + 1))), device="cuda:0")
 trk.run()
 import numpy as np
 print("median us per BA call by position in update():", " ".join(f"{np.median(p[-30:]):.0f}" for p in per))
