@@ -65,12 +65,13 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
     BT_TICK("0");
     // ---- n_all, validation (ba.py:219) ------------------------------------
-    int64_t n_all = n_all_min;
+    int64_t n_all = n_all_min, kmin = p_tot, kmax = -1;       // [kmin, kmax]: patches the edges name (a window of the buffer)
     bool sorted = true;
     for (int64_t e = 0; e < E; ++e) {
         if (ii[e] < 0 || jj[e] < 0 || ii[e] >= n_buf || jj[e] >= n_buf) return BT_EINVAL;
         if (kk[e] < 0 || kk[e] >= p_tot) return BT_EINVAL;
         n_all = std::max(n_all, std::max(ii[e], jj[e]) + 1);
+        kmin = std::min(kmin, kk[e]); kmax = std::max(kmax, kk[e]);
         if (e && kk[e] < kk[e - 1]) sorted = false;
     }
     I.n_all = n_all;
@@ -81,7 +82,8 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
     BT_TICK("1");
     // ---- one pass over the edges: edges per track, per target frame, and the camera pairs in use
-    pl->trk_of_patch.assign((size_t)p_tot, 0);
+    pl->trk_of_patch.assign((size_t)p_tot, -1);
+    for (int64_t p = kmin; p <= kmax; ++p) pl->trk_of_patch[(size_t)p] = 0;
     std::vector<int32_t> pair_of((size_t)(n_all * n_all), -1), cj((size_t)n_all + 1, 0);
     int64_t E_own = 0;
     for (int64_t e = 0; e < E; ++e)
@@ -96,7 +98,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     int32_t m = 0;
     pl->kx.clear();
     std::vector<int32_t> off(1, 0);
-    for (int64_t p = 0; p < p_tot; ++p) {
+    for (int64_t p = kmin; p <= kmax; ++p) {
         const int32_t c = pl->trk_of_patch[(size_t)p];
         if (c > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + c); pl->trk_of_patch[(size_t)p] = m++; }
         else pl->trk_of_patch[(size_t)p] = -1;

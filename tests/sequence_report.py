@@ -24,6 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=50)
 ap.add_argument("--M", type=int, default=256)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--buffer", type=int, default=1024, help="BUFFER_SIZE (sintel.yaml: 1024 pose slots, x M patch slots)")
 ap.add_argument("--skip-oracle", action="store_true")
 args = ap.parse_args()
 
@@ -34,14 +35,14 @@ for name, ba, dev in (("hip", BA_rgbd_droid, "cuda:0"), ("oracle", oracle_BA_rgb
         continue
     for rep in range(2 if name == "hip" else 1):            # second HIP run: warm allocator / code objects
         obs = SyntheticObservations(n_frames=args.frames, M=args.M, seed=args.seed)
-        trk = WindowedBA(obs, ba, SlamConfig(PATCHES_PER_FRAME=args.M, BUFFER_SIZE=args.frames + 1), device=dev)
+        trk = WindowedBA(obs, ba, SlamConfig(PATCHES_PER_FRAME=args.M, BUFFER_SIZE=max(args.buffer, args.frames + 1)), device=dev)
         t0 = time.perf_counter()
         poses = trk.run()
         wall = time.perf_counter() - t0
     rows[name] = dict(poses=poses, wall=wall, stats=trk.stats,
                       ate=evaluation.ate_rmse(evaluation.camera_centres(poses), obs.centres_gt()))
     s = trk.stats
-    print(f"{name:6s}: frames={args.frames} M={args.M} updates={s['updates']} ba_calls={s['ba_calls']} edges_max={s['edges_max']} "
+    print(f"{name:6s}: frames={args.frames} M={args.M} buffer={max(args.buffer, args.frames + 1)} updates={s['updates']} ba_calls={s['ba_calls']} edges_max={s['edges_max']} "
           f"ATE={rows[name]['ate']:.6e}  BA time={s['ba_seconds']:.3f}s ({1e3 * s['ba_seconds'] / s['updates']:.3f} ms/update, "
           f"{1e6 * s['ba_seconds'] / s['ba_calls']:.1f} us/call incl. plan builds)  loop wall={wall:.2f}s", flush=True)
 if "oracle" in rows:
