@@ -212,29 +212,55 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     if (n > kMaxFree) return BT_EUNSUPPORTED;
 
     BT_TICK("1");
-    // ---- one pass over the edges: edges per track, per target frame, and the camera pairs in use
-    pl->trk_of_patch.assign((size_t)p_tot, -1);
-    for (int64_t p = kmin; p <= kmax; ++p) pl->trk_of_patch[(size_t)p] = 0;
+    // ---- counting passes over the edges (in chunks of the edge list, histograms per chunk so that the scatters
+    // below are stable whichever thread runs a chunk): edges per track, per target frame, the camera pairs in use
+    const int64_t R = kmax >= kmin ? kmax - kmin + 1 : 0;          // patch range in use
+    int nch = std::max(1, std::min(team.threads() * 2, (int)(E / 16384)));
+    if (R * nch > ((int64_t)1 << 22)) nch = 1;
+    const size_t hstride = (size_t)std::max<int64_t>(R, 1) + (size_t)n_all + 1;
+    static thread_local std::vector<int32_t> hist_scratch;
+    hist_scratch.assign((size_t)nch * hstride, 0);
+    int32_t *hist = hist_scratch.data();                           // chunk c: [R] per patch, then [n_all + 1] per target frame
     std::vector<int32_t> pair_of((size_t)(n_all * n_all), -1), cj((size_t)n_all + 1, 0);
+    std::vector<int64_t> own_cnt((size_t)nch, 0);
+    auto chunk_lo = [&](int c) { return E * c / nch; };
+    team.parallel(nch, [&](int c) {
+        int32_t *hp = hist + (size_t)c * hstride, *hj = hp + std::max<int64_t>(R, 1);
+        int64_t cnt = 0;
+        for (int64_t e = chunk_lo(c); e < chunk_lo(c + 1); ++e)
+            if (owned(e)) {
+                ++hp[kk[e] - kmin];
+                ++hj[jj[e]];
+                __atomic_store_n(&pair_of[(size_t)(ii[e] * n_all + jj[e])], 0, __ATOMIC_RELAXED);   // same value from every chunk
+                ++cnt;
+            }
+        own_cnt[(size_t)c] = cnt;
+    });
     int64_t E_own = 0;
-    for (int64_t e = 0; e < E; ++e)
-        if (owned(e)) {
-            ++pl->trk_of_patch[(size_t)kk[e]];
-            pair_of[(size_t)(ii[e] * n_all + jj[e])] = 0;
-            ++cj[(size_t)jj[e] + 1];
-            ++E_own;
-        }
+    for (int c = 0; c < nch; ++c) E_own += own_cnt[(size_t)c];
     I.E = E_own;
     // unique tracks, ascending (ba.py:276); off = first position of a track's edges in the grouped order
+    pl->trk_of_patch.assign((size_t)p_tot, -1);
     int32_t m = 0;
     pl->kx.clear();
     std::vector<int32_t> off(1, 0);
     for (int64_t p = kmin; p <= kmax; ++p) {
-        const int32_t c = pl->trk_of_patch[(size_t)p];
-        if (c > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + c); pl->trk_of_patch[(size_t)p] = m++; }
-        else pl->trk_of_patch[(size_t)p] = -1;
+        int32_t cnt = 0;
+        for (int c = 0; c < nch; ++c) cnt += hist[(size_t)c * hstride + (size_t)(p - kmin)];
+        if (cnt > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + cnt); pl->trk_of_patch[(size_t)p] = m++; }
     }
     I.m = m;
+    // target frames: cj[j] = first position of frame j in the by-frame order; per chunk, where its edges of frame j go
+    for (int64_t j = 0; j < n_all; ++j) {
+        int32_t run = cj[(size_t)j];
+        for (int c = 0; c < nch; ++c) {
+            int32_t &h = hist[(size_t)c * hstride + (size_t)std::max<int64_t>(R, 1) + (size_t)j];
+            const int32_t cnt = h;
+            h = run;
+            run += cnt;
+        }
+        cj[(size_t)j + 1] = run;
+    }
 
     BT_TICK("2");
     // ---- distinct camera pairs, ascending (i, j) ---------------------------
@@ -249,7 +275,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
     BT_TICK("3");
     // ---- edges grouped by track, ordered by (pair, original index) ---------
-    // Two stable counting passes instead of a sort per track: first by target frame, then by track.  Within a
+    // Two stable counting scatters instead of a sort per track: first by target frame, then by track.  Within a
     // track the source frame is the same for all edges (checked below), so ascending target frame IS ascending
     // pair id, and stability keeps the original index as the tie-break (duplicates are normal, batrack.py:399-410).
     // (edge-sized temporaries persist per thread: the caller builds one plan per frame, and fresh pages cost more
@@ -257,13 +283,31 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     static thread_local std::vector<int32_t> ord_scratch, byj_scratch;
     std::vector<int32_t> &ord = ord_scratch, &byj = byj_scratch;
     ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1);
-    std::vector<int32_t> cur(off.begin(), off.end() - 1);
-    for (int64_t j = 0; j < n_all; ++j) cj[(size_t)j + 1] += cj[(size_t)j];
-    for (int64_t e = 0; e < E; ++e) if (owned(e)) byj[(size_t)cj[(size_t)jj[e]]++] = (int32_t)e;
-    for (int64_t q = 0; q < E_own; ++q) {
-        const int32_t e = byj[(size_t)q];
-        ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = e;
+    team.parallel(nch, [&](int c) {                                // by target frame: chunk c of the EDGE list
+        int32_t *hj = hist + (size_t)c * hstride + std::max<int64_t>(R, 1);
+        for (int64_t e = chunk_lo(c); e < chunk_lo(c + 1); ++e) if (owned(e)) byj[(size_t)hj[jj[e]]++] = (int32_t)e;
+    });
+    // by track: chunk c of the BY-FRAME order; its per-track counts first, then their running sums are the cursors
+    const size_t tstride = (size_t)std::max<int32_t>(m, 1);
+    static thread_local std::vector<int32_t> tcur_scratch;
+    tcur_scratch.assign((size_t)nch * tstride, 0);
+    int32_t *tcur = tcur_scratch.data();
+    auto q_lo = [&](int c) { return E_own * c / nch; };
+    team.parallel(nch, [&](int c) {
+        int32_t *tc = tcur + (size_t)c * tstride;
+        for (int64_t q = q_lo(c); q < q_lo(c + 1); ++q) ++tc[pl->trk_of_patch[(size_t)kk[byj[(size_t)q]]]];
+    });
+    for (int32_t k = 0; k < m; ++k) {
+        int32_t run = off[(size_t)k];
+        for (int c = 0; c < nch; ++c) { int32_t &h = tcur[(size_t)c * tstride + (size_t)k]; const int32_t cnt = h; h = run; run += cnt; }
     }
+    team.parallel(nch, [&](int c) {
+        int32_t *tc = tcur + (size_t)c * tstride;
+        for (int64_t q = q_lo(c); q < q_lo(c + 1); ++q) {
+            const int32_t e = byj[(size_t)q];
+            ord[(size_t)tc[pl->trk_of_patch[(size_t)kk[e]]]++] = e;
+        }
+    });
     auto pair_id = [&](int32_t e) { return pair_of[(size_t)(ii[e] * n_all + jj[e])]; };
 
     BT_TICK("4");
