@@ -15,129 +15,13 @@
 #include "ba_plan.hpp"
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
-#include <fstream>
-#include <functional>
-#include <mutex>
+#include <cstdlib>
 #include <numeric>
-#include <thread>
-
-#include <pthread.h>
-#include <sched.h>
 
 namespace bt {
-
-// ---- a few helper threads for the edge- and tile-sized passes -------------------------------------------
-// The caller needs a plan per frame, so the analysis is on its critical path.  Workers sleep on a condition
-// variable between plans, spin only while a plan is being built, and take chunks dynamically (a worker that
-// wakes late simply finds fewer chunks left; results are indexed by chunk, never by thread, so the plan does
-// not depend on the scheduling).  BT_PLAN_THREADS (default 4, capped by the CPU quota) = 1 turns them off.
-namespace {
-
-int cpu_quota() {
-    int n = (int)std::thread::hardware_concurrency();
-    if (n <= 0) n = 1;
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
-    std::ifstream f("/sys/fs/cgroup/cpu.max");
-    std::string q;
-    long long period = 0;
-    if (f >> q >> period && q != "max" && period > 0) n = std::min<long long>(n, std::max<long long>(1, std::atoll(q.c_str()) / period));
-    return n;
-}
-
-inline void cpu_relax() {
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#else
-    std::this_thread::yield();
-#endif
-}
-
-class Workers {
-public:
-    static Workers &get() {
-        static std::once_flag once;
-        std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { inst_ = nullptr; }); });   // a forked child starts its own
-        Workers *w = inst_;
-        if (!w) { w = new Workers(); inst_ = w; }      // never destroyed: no join at exit
-        return *w;
-    }
-    int threads() const { return nthreads_; }
-
-    // One plan build at a time uses the helpers (a second concurrent build just runs its passes itself).
-    class Scope {
-    public:
-        Scope(Workers &w, bool want) : w_(w), mine_(want && w.nthreads_ > 1 && w.owner_.try_lock()) {
-            if (mine_) { { std::lock_guard<std::mutex> lk(w_.mu_); w_.active_.store(true); } w_.cv_.notify_all(); }
-        }
-        ~Scope() { if (mine_) { w_.active_.store(false); w_.owner_.unlock(); } }
-        int threads() const { return mine_ ? w_.nthreads_ : 1; }
-        // run f(chunk) for chunk in [0, nchunks); the caller takes part; returns when all chunks are done
-        void parallel(int nchunks, const std::function<void(int)> &f) {
-            if (!mine_ || nchunks <= 1 || nchunks >= (1 << 20)) { for (int c = 0; c < nchunks; ++c) f(c); return; }
-            w_.fn_ = &f;
-            w_.done_.store(0, std::memory_order_relaxed);
-            const uint64_t ep = (++w_.epoch_) & 0xffffffu;
-            w_.ticket_.store((ep << 40) | ((uint64_t)nchunks << 20), std::memory_order_release);
-            w_.work();
-            while (w_.done_.load(std::memory_order_acquire) < nchunks) cpu_relax();
-        }
-    private:
-        Workers &w_;
-        bool mine_;
-    };
-
-private:
-    Workers() {
-        static const int env = std::getenv("BT_PLAN_THREADS") ? std::atoi(std::getenv("BT_PLAN_THREADS")) : 4;
-        nthreads_ = std::max(1, std::min(std::min(env, 8), cpu_quota()));
-        for (int t = 1; t < nthreads_; ++t) std::thread([this] { loop(); }).detach();
-    }
-    // ticket = epoch (24 bits) | number of chunks (20) | next chunk (20): one word, so a helper that is late by a
-    // whole region can neither take a chunk of the wrong region nor disturb its counter (compare-and-swap)
-    void work() {
-        for (;;) {
-            uint64_t v = ticket_.load(std::memory_order_acquire);
-            const uint32_t n = (uint32_t)(v >> 20) & 0xfffffu, i = (uint32_t)v & 0xfffffu;
-            if (i >= n) return;
-            if (!ticket_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) continue;
-            (*fn_)((int)i);                      // the region cannot end before this chunk is counted: fn_ is its function
-            done_.fetch_add(1, std::memory_order_release);
-        }
-    }
-    void loop() {
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [this] { return active_.load(); });
-            }
-            int idle = 0;
-            while (active_.load(std::memory_order_acquire)) {
-                const uint64_t v = ticket_.load(std::memory_order_acquire);
-                if (((uint32_t)v & 0xfffffu) < ((uint32_t)(v >> 20) & 0xfffffu)) { work(); idle = 0; }
-                else if (++idle > 4096) { std::this_thread::yield(); idle = 0; }
-                else cpu_relax();
-            }
-        }
-    }
-    static Workers *inst_;
-    int nthreads_ = 1;
-    std::mutex mu_, owner_;
-    std::condition_variable cv_;
-    std::atomic<bool> active_{false};
-    const std::function<void(int)> *fn_ = nullptr;
-    std::atomic<uint64_t> ticket_{0};
-    std::atomic<int> done_{0};
-    uint64_t epoch_ = 0;
-};
-Workers *Workers::inst_ = nullptr;
-
-}  // namespace
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -181,29 +65,14 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
     BT_TICK("0");
     // ---- n_all, validation (ba.py:219) ------------------------------------
-    Workers::Scope team(Workers::get(), E >= 32768);
     int64_t n_all = n_all_min, kmin = p_tot, kmax = -1;       // [kmin, kmax]: patches the edges name (a window of the buffer)
     bool sorted = true;
-    {
-        const int nch = std::max(1, std::min(team.threads() * 2, (int)(E / 16384)));
-        struct Part { int64_t n_all, kmin, kmax; bool sorted, bad; };
-        std::vector<Part> part((size_t)nch);
-        team.parallel(nch, [&](int c) {
-            Part r{0, p_tot, -1, true, false};
-            const int64_t e0 = E * c / nch, e1 = E * (c + 1) / nch;
-            for (int64_t e = e0; e < e1; ++e) {
-                if (ii[e] < 0 || jj[e] < 0 || ii[e] >= n_buf || jj[e] >= n_buf || kk[e] < 0 || kk[e] >= p_tot) { r.bad = true; break; }
-                r.n_all = std::max(r.n_all, std::max(ii[e], jj[e]) + 1);
-                r.kmin = std::min(r.kmin, kk[e]); r.kmax = std::max(r.kmax, kk[e]);
-                if (e && kk[e] < kk[e - 1]) r.sorted = false;         // (kk[e0 - 1] was validated, or will fail, in its own part)
-            }
-            part[(size_t)c] = r;
-        });
-        for (const Part &r : part) {
-            if (r.bad) return BT_EINVAL;
-            n_all = std::max(n_all, r.n_all); kmin = std::min(kmin, r.kmin); kmax = std::max(kmax, r.kmax);
-            sorted = sorted && r.sorted;
-        }
+    for (int64_t e = 0; e < E; ++e) {
+        if (ii[e] < 0 || jj[e] < 0 || ii[e] >= n_buf || jj[e] >= n_buf) return BT_EINVAL;
+        if (kk[e] < 0 || kk[e] >= p_tot) return BT_EINVAL;
+        n_all = std::max(n_all, std::max(ii[e], jj[e]) + 1);
+        kmin = std::min(kmin, kk[e]); kmax = std::max(kmax, kk[e]);
+        if (e && kk[e] < kk[e - 1]) sorted = false;
     }
     I.n_all = n_all;
     I.sorted_input = sorted ? 1 : 0;
@@ -212,55 +81,29 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     if (n > kMaxFree) return BT_EUNSUPPORTED;
 
     BT_TICK("1");
-    // ---- counting passes over the edges (in chunks of the edge list, histograms per chunk so that the scatters
-    // below are stable whichever thread runs a chunk): edges per track, per target frame, the camera pairs in use
-    const int64_t R = kmax >= kmin ? kmax - kmin + 1 : 0;          // patch range in use
-    int nch = std::max(1, std::min(team.threads() * 2, (int)(E / 16384)));
-    if (R * nch > ((int64_t)1 << 22)) nch = 1;
-    const size_t hstride = (size_t)std::max<int64_t>(R, 1) + (size_t)n_all + 1;
-    static thread_local std::vector<int32_t> hist_scratch;
-    hist_scratch.assign((size_t)nch * hstride, 0);
-    int32_t *hist = hist_scratch.data();                           // chunk c: [R] per patch, then [n_all + 1] per target frame
+    // ---- one pass over the edges: edges per track, per target frame, and the camera pairs in use
+    pl->trk_of_patch.assign((size_t)p_tot, -1);
+    for (int64_t p = kmin; p <= kmax; ++p) pl->trk_of_patch[(size_t)p] = 0;
     std::vector<int32_t> pair_of((size_t)(n_all * n_all), -1), cj((size_t)n_all + 1, 0);
-    std::vector<int64_t> own_cnt((size_t)nch, 0);
-    auto chunk_lo = [&](int c) { return E * c / nch; };
-    team.parallel(nch, [&](int c) {
-        int32_t *hp = hist + (size_t)c * hstride, *hj = hp + std::max<int64_t>(R, 1);
-        int64_t cnt = 0;
-        for (int64_t e = chunk_lo(c); e < chunk_lo(c + 1); ++e)
-            if (owned(e)) {
-                ++hp[kk[e] - kmin];
-                ++hj[jj[e]];
-                __atomic_store_n(&pair_of[(size_t)(ii[e] * n_all + jj[e])], 0, __ATOMIC_RELAXED);   // same value from every chunk
-                ++cnt;
-            }
-        own_cnt[(size_t)c] = cnt;
-    });
     int64_t E_own = 0;
-    for (int c = 0; c < nch; ++c) E_own += own_cnt[(size_t)c];
+    for (int64_t e = 0; e < E; ++e)
+        if (owned(e)) {
+            ++pl->trk_of_patch[(size_t)kk[e]];
+            pair_of[(size_t)(ii[e] * n_all + jj[e])] = 0;
+            ++cj[(size_t)jj[e] + 1];
+            ++E_own;
+        }
     I.E = E_own;
     // unique tracks, ascending (ba.py:276); off = first position of a track's edges in the grouped order
-    pl->trk_of_patch.assign((size_t)p_tot, -1);
     int32_t m = 0;
     pl->kx.clear();
     std::vector<int32_t> off(1, 0);
     for (int64_t p = kmin; p <= kmax; ++p) {
-        int32_t cnt = 0;
-        for (int c = 0; c < nch; ++c) cnt += hist[(size_t)c * hstride + (size_t)(p - kmin)];
-        if (cnt > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + cnt); pl->trk_of_patch[(size_t)p] = m++; }
+        const int32_t c = pl->trk_of_patch[(size_t)p];
+        if (c > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + c); pl->trk_of_patch[(size_t)p] = m++; }
+        else pl->trk_of_patch[(size_t)p] = -1;
     }
     I.m = m;
-    // target frames: cj[j] = first position of frame j in the by-frame order; per chunk, where its edges of frame j go
-    for (int64_t j = 0; j < n_all; ++j) {
-        int32_t run = cj[(size_t)j];
-        for (int c = 0; c < nch; ++c) {
-            int32_t &h = hist[(size_t)c * hstride + (size_t)std::max<int64_t>(R, 1) + (size_t)j];
-            const int32_t cnt = h;
-            h = run;
-            run += cnt;
-        }
-        cj[(size_t)j + 1] = run;
-    }
 
     BT_TICK("2");
     // ---- distinct camera pairs, ascending (i, j) ---------------------------
@@ -275,7 +118,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
     BT_TICK("3");
     // ---- edges grouped by track, ordered by (pair, original index) ---------
-    // Two stable counting scatters instead of a sort per track: first by target frame, then by track.  Within a
+    // Two stable counting passes instead of a sort per track: first by target frame, then by track.  Within a
     // track the source frame is the same for all edges (checked below), so ascending target frame IS ascending
     // pair id, and stability keeps the original index as the tie-break (duplicates are normal, batrack.py:399-410).
     // (edge-sized temporaries persist per thread: the caller builds one plan per frame, and fresh pages cost more
@@ -283,31 +126,13 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     static thread_local std::vector<int32_t> ord_scratch, byj_scratch;
     std::vector<int32_t> &ord = ord_scratch, &byj = byj_scratch;
     ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1);
-    team.parallel(nch, [&](int c) {                                // by target frame: chunk c of the EDGE list
-        int32_t *hj = hist + (size_t)c * hstride + std::max<int64_t>(R, 1);
-        for (int64_t e = chunk_lo(c); e < chunk_lo(c + 1); ++e) if (owned(e)) byj[(size_t)hj[jj[e]]++] = (int32_t)e;
-    });
-    // by track: chunk c of the BY-FRAME order; its per-track counts first, then their running sums are the cursors
-    const size_t tstride = (size_t)std::max<int32_t>(m, 1);
-    static thread_local std::vector<int32_t> tcur_scratch;
-    tcur_scratch.assign((size_t)nch * tstride, 0);
-    int32_t *tcur = tcur_scratch.data();
-    auto q_lo = [&](int c) { return E_own * c / nch; };
-    team.parallel(nch, [&](int c) {
-        int32_t *tc = tcur + (size_t)c * tstride;
-        for (int64_t q = q_lo(c); q < q_lo(c + 1); ++q) ++tc[pl->trk_of_patch[(size_t)kk[byj[(size_t)q]]]];
-    });
-    for (int32_t k = 0; k < m; ++k) {
-        int32_t run = off[(size_t)k];
-        for (int c = 0; c < nch; ++c) { int32_t &h = tcur[(size_t)c * tstride + (size_t)k]; const int32_t cnt = h; h = run; run += cnt; }
+    std::vector<int32_t> cur(off.begin(), off.end() - 1);
+    for (int64_t j = 0; j < n_all; ++j) cj[(size_t)j + 1] += cj[(size_t)j];
+    for (int64_t e = 0; e < E; ++e) if (owned(e)) byj[(size_t)cj[(size_t)jj[e]]++] = (int32_t)e;
+    for (int64_t q = 0; q < E_own; ++q) {
+        const int32_t e = byj[(size_t)q];
+        ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = e;
     }
-    team.parallel(nch, [&](int c) {
-        int32_t *tc = tcur + (size_t)c * tstride;
-        for (int64_t q = q_lo(c); q < q_lo(c + 1); ++q) {
-            const int32_t e = byj[(size_t)q];
-            ord[(size_t)tc[pl->trk_of_patch[(size_t)kk[e]]]++] = e;
-        }
-    });
     auto pair_id = [&](int32_t e) { return pair_of[(size_t)(ii[e] * n_all + jj[e])]; };
 
     BT_TICK("4");
@@ -364,61 +189,53 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     pl->max_rows16 = (int)((6 * max_cams + 1 + 15) / 16 * 16);
 
     BT_TICK("6");
-    // ---- slot arrays [slots][64], and the distinct camera pairs of every tile (their relative pose is computed
-    // once per tile): independent per tile, so tiles are handed out in chunks
+    // ---- slot arrays [slots][64] -------------------------------------------
     pl->slot_edge.assign((size_t)slots * kLanes, -1);
     pl->slot_pair.assign((size_t)slots * kLanes, 0);
     pl->slot_lab.assign((size_t)slots * kLanes, 0xffff);
-    pl->slot_lp.assign((size_t)slots * kLanes, 0);
-    pl->tile_pair0.assign((size_t)T, 0); pl->tile_npair.assign((size_t)T, 0);
-    {
-        static thread_local std::vector<int32_t> tp_scratch;              // [T][kMaxTilePairs] pair lists, concatenated below
-        tp_scratch.resize((size_t)T * kMaxTilePairs);
-        int32_t *tps = tp_scratch.data();
-        const int tiles_per_chunk = std::max(1, T / (team.threads() * 4));
-        const int nch = (T + tiles_per_chunk - 1) / tiles_per_chunk;
-        std::atomic<int> too_many{0};
-        team.parallel(nch, [&](int c) {
-            std::vector<int32_t> local((size_t)n + 1, -1), lp_of(pl->pair_i.size(), -1), mine;
-            for (int32_t t = c * tiles_per_chunk; t < std::min<int32_t>(T, (c + 1) * tiles_per_chunk); ++t) {
-                const int32_t c0 = pl->tile_cam0[(size_t)t], nc = pl->tile_ncam[(size_t)t];
-                for (int32_t q = 0; q < nc; ++q) local[(size_t)pl->tile_cams[(size_t)(c0 + q)]] = q;
-                mine.clear();
-                for (int32_t l = 0; l < pl->tile_ntrk[(size_t)t]; ++l) {
-                    const int32_t k = pl->tile_trk0[(size_t)t] + l;
-                    for (int32_t s = off[(size_t)k]; s < off[(size_t)k + 1]; ++s) {
-                        const int32_t e = ord[(size_t)s];
-                        const size_t idx = ((size_t)pl->tile_slot0[(size_t)t] + (size_t)(s - off[(size_t)k])) * kLanes + (size_t)l;
-                        const int64_t a = ii[e] - fixedp, b = jj[e] - fixedp;
-                        const uint16_t la = a >= 0 ? (uint16_t)local[(size_t)a] : 0xff;
-                        const uint16_t lb = b >= 0 ? (uint16_t)local[(size_t)b] : 0xff;
-                        const int32_t pr = pair_id(e);
-                        pl->slot_edge[idx] = e;
-                        pl->slot_pair[idx] = pr;
-                        pl->slot_lab[idx] = (uint16_t)(la | (lb << 8));
-                        if (lp_of[(size_t)pr] < 0) { lp_of[(size_t)pr] = 0; mine.push_back(pr); }
-                    }
-                }
-                std::sort(mine.begin(), mine.end());
-                pl->tile_npair[(size_t)t] = (int32_t)mine.size();
-                if ((int)mine.size() > kMaxTilePairs) { too_many.store(1); for (int32_t q : mine) lp_of[(size_t)q] = -1; continue; }
-                for (size_t q = 0; q < mine.size(); ++q) { lp_of[(size_t)mine[q]] = (int32_t)q; tps[(size_t)t * kMaxTilePairs + q] = mine[q]; }
-                const size_t b0 = (size_t)pl->tile_slot0[(size_t)t] * kLanes, b1 = b0 + (size_t)pl->tile_nslot[(size_t)t] * kLanes;
-                for (size_t i = b0; i < b1; ++i) if (pl->slot_edge[i] >= 0) pl->slot_lp[i] = (uint8_t)lp_of[(size_t)pl->slot_pair[i]];
-                for (int32_t q : mine) lp_of[(size_t)q] = -1;
+    std::vector<int32_t> local((size_t)n + 1, -1);
+    for (int32_t t = 0; t < T; ++t) {
+        const int32_t c0 = pl->tile_cam0[(size_t)t], nc = pl->tile_ncam[(size_t)t];
+        for (int32_t c = 0; c < nc; ++c) local[(size_t)pl->tile_cams[(size_t)(c0 + c)]] = c;
+        for (int32_t l = 0; l < pl->tile_ntrk[(size_t)t]; ++l) {
+            const int32_t k = pl->tile_trk0[(size_t)t] + l;
+            for (int32_t s = off[(size_t)k]; s < off[(size_t)k + 1]; ++s) {
+                const int32_t e = ord[(size_t)s];
+                const size_t idx = ((size_t)pl->tile_slot0[(size_t)t] + (size_t)(s - off[(size_t)k])) * kLanes + (size_t)l;
+                const int64_t a = ii[e] - fixedp, b = jj[e] - fixedp;
+                const uint16_t la = a >= 0 ? (uint16_t)local[(size_t)a] : 0xff;
+                const uint16_t lb = b >= 0 ? (uint16_t)local[(size_t)b] : 0xff;
+                pl->slot_edge[idx] = e;
+                pl->slot_pair[idx] = pair_id(e);
+                pl->slot_lab[idx] = (uint16_t)(la | (lb << 8));
             }
-        });
-        if (too_many.load()) return BT_EUNSUPPORTED;
-        pl->tile_pairs.clear();
-        pl->max_tile_pairs = 0;
-        for (int32_t t = 0; t < T; ++t) {
-            const int32_t np = pl->tile_npair[(size_t)t];
-            pl->tile_pair0[(size_t)t] = (int32_t)pl->tile_pairs.size();
-            pl->tile_pairs.insert(pl->tile_pairs.end(), tps + (size_t)t * kMaxTilePairs, tps + (size_t)t * kMaxTilePairs + np);
-            pl->max_tile_pairs = std::max(pl->max_tile_pairs, (int)np);
         }
     }
+
     BT_TICK("7");
+    // ---- distinct camera pairs of every tile (their relative pose is computed once per tile)
+    pl->tile_pair0.assign((size_t)T, 0); pl->tile_npair.assign((size_t)T, 0);
+    pl->tile_pairs.clear();
+    pl->slot_lp.assign((size_t)slots * kLanes, 0);
+    pl->max_tile_pairs = 0;
+    {
+        std::vector<int32_t> lp_of(pl->pair_i.size(), -1), mine;
+        for (int32_t t = 0; t < T; ++t) {
+            mine.clear();
+            const size_t b0 = (size_t)pl->tile_slot0[(size_t)t] * kLanes, b1 = b0 + (size_t)pl->tile_nslot[(size_t)t] * kLanes;
+            for (size_t i = b0; i < b1; ++i)
+                if (pl->slot_edge[i] >= 0 && lp_of[(size_t)pl->slot_pair[i]] < 0) { lp_of[(size_t)pl->slot_pair[i]] = 0; mine.push_back(pl->slot_pair[i]); }
+            std::sort(mine.begin(), mine.end());
+            if ((int)mine.size() > kMaxTilePairs) return BT_EUNSUPPORTED;
+            for (size_t q = 0; q < mine.size(); ++q) lp_of[(size_t)mine[q]] = (int32_t)q;
+            for (size_t i = b0; i < b1; ++i) if (pl->slot_edge[i] >= 0) pl->slot_lp[i] = (uint8_t)lp_of[(size_t)pl->slot_pair[i]];
+            pl->tile_pair0[(size_t)t] = (int32_t)pl->tile_pairs.size();
+            pl->tile_npair[(size_t)t] = (int32_t)mine.size();
+            pl->tile_pairs.insert(pl->tile_pairs.end(), mine.begin(), mine.end());
+            pl->max_tile_pairs = std::max(pl->max_tile_pairs, (int)mine.size());
+            for (int32_t q : mine) lp_of[(size_t)q] = -1;
+        }
+    }
 
     // consecutive tiles with identical camera / pair lists: a persistent workgroup keeps its
     // accumulators across them

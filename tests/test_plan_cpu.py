@@ -249,40 +249,3 @@ def test_patch_activity_tables_and_track_records():
                 got = [(int(rec[k, 4 + c // 4]) >> (8 * (c % 4))) & 255 for c in range(nc[k])]
                 assert got == list(cams)
         pl.close()
-
-
-def test_plan_does_not_depend_on_helper_threads():
-    """The analysis hands edge ranges and tiles to helper threads (BT_PLAN_THREADS, read once per process):
-    every array must come out the same with 1, 3 and 8 threads, and repeatedly."""
-    import hashlib, json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = r'''
-import sys, hashlib, json
-sys.path.insert(0, ROOT)
-import numpy as np
-from batrack_amd import graphgen
-from batrack_amd.plan import Plan
-out = {}
-graphs = {"window": graphgen.make_window_graph(n_frames=40, M=256, seed=1),
-          "c3": (graphgen.make_config("C3", seed=0), 1),
-          "random": (graphgen.make_random_graph(40, 700, seed=4), 2)}
-for rep in range(3):
-    for name, (g, fp) in graphs.items():
-        pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], fp, upload=False)
-        h = hashlib.sha256()
-        for k, v in sorted(pl.arrays().items()):
-            h.update(k.encode()); h.update(np.ascontiguousarray(v).tobytes())
-        h.update(json.dumps(pl.info, sort_keys=True).encode())
-        out.setdefault(name, set()).add(h.hexdigest())
-        pl.close()
-print("RESULT " + json.dumps({k: sorted(v) for k, v in out.items()}))
-'''
-    digests = {}
-    for nt in ("1", "3", "8"):
-        r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + script], env=dict(os.environ, BT_PLAN_THREADS=nt),
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        digests[nt] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
-    for name in digests["1"]:
-        assert all(len(digests[nt][name]) == 1 for nt in digests), (name, digests)      # repeatable
-        assert digests["1"][name] == digests["3"][name] == digests["8"][name], name
