@@ -188,7 +188,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
     int p_cur = -1;
     auto flush_pair = [&]() {
         const int vi = (lane >> 1) & 31;
-        if (p_cur >= 0 && (lane & 1) == 0 && vi < 27 && !(a.dbg & 2))
+        if (p_cur >= 0 && (lane & 1) == 0 && vi < 27)
             atomicAdd(&a.pairacc[(size_t)p_cur * kPairAccStride + vi], pacc);
         pacc = 0.0; p_cur = -1;
     };
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
                 const double val = *slot;
                 *slot = 0.0;
                 const int row = 16 * ti + (lane >> 4) + 4 * r;
-                if (gc >= 0 && row <= Racc && !(a.dbg & 1)) {
+                if (gc >= 0 && row <= Racc) {
                     if (row == Racc) {
                         atomicAdd(&a.y[gc], -val);
                     } else {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         float Ejacc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         unsigned lb_acc = 0xffu;
         auto flush_ej = [&](unsigned lbf) {
-            if (lbf != 0xffu && !(a.dbg & 8)) {
+            if (lbf != 0xffu) {
                 float *row = Eh + lbf * 6 * kLdsRowStride + lane;
                 if (lbf == lb_prev || lbf == lb_next) {
 #pragma unroll
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         // accumulators stay in registers across consecutive tiles with the same cameras.
         const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
         const bool keep = ntl <= ntl_max;           // else: more output tiles than LDS accumulators, emit per tile
-        for (int t = wave; t < ntl && !(a.dbg & 4); t += kTileWaves) {
+        for (int t = wave; t < ntl; t += kTileWaves) {
             int ti = 0, base = 0;
             while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
             const int tj = t - base;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + (lane >> 4) + 4 * r;
-                    if (gc >= 0 && row <= R && !(a.dbg & 1)) {
+                    if (gc >= 0 && row <= R) {
                         if (row == R) atomicAdd(&a.y[gc], -acc[r]);
                         else { const int gr = gidx[row]; if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]); }
                     }

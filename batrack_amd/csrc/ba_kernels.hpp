@@ -18,7 +18,7 @@ struct StepArgs {
     float2 *qw;
     float *esave, *lfac, *linv, *zvec, *dx;
     int *status;
-    int dbg;                      // measurement-only switches (env BT_DEBUG_MODE), 0 in production
+    int dbg;                      // env BT_DEBUG_MODE, 0 in production: 16 / 32 launch the cycle-counting variants of the solver / k_tile
 };
 
 int configure_kernels(const PlanDev &pd);

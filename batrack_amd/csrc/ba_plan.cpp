@@ -18,7 +18,6 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include <cstdlib>
 #include <numeric>
 
 namespace bt {
@@ -136,7 +135,6 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     auto pair_id = [&](int32_t e) { return pair_of[(size_t)(ii[e] * n_all + jj[e])]; };
 
     BT_TICK("4");
-    BT_TICK("5");
     // ---- tiles: greedy over sorted tracks ----------------------------------
     pl->tile_trk0.clear(); pl->tile_ntrk.clear(); pl->tile_ncam.clear(); pl->tile_cam0.clear();
     pl->tile_slot0.clear(); pl->tile_nslot.clear(); pl->tile_erow0.clear(); pl->tile_cams.clear();
