@@ -249,10 +249,19 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         }
         if (!(flags & 2)) {                                        // relative pose of the tile's camera pairs
             const int np = pd.tile_npair[tile];
-            if (tid < np) pair_geometry(a.poses, a.intr, ij0 & 0xffff, ij0 >> 16, geo + tid * kPairGeomFloats);
-            for (int p = tid + nthr; p < np; p += nthr) {          // (more pairs than threads: never with kMaxTilePairs = 192)
-                const int ij = pd.tile_ij[(size_t)tile * mtp + p];
-                pair_geometry(a.poses, a.intr, ij & 0xffff, ij >> 16, geo + p * kPairGeomFloats);
+            // (the pair's global index: only to leave the result for k_pair_finalize, which then need not redo it)
+            const int gp0 = !SO && tid < np ? pd.tile_pairs[pd.tile_pair0[tile] + tid] : 0;
+            for (int p = tid; p < np; p += nthr) {                 // (more pairs than threads: never with kMaxTilePairs = 192)
+                const int ij = p == tid ? ij0 : pd.tile_ij[(size_t)tile * mtp + p];
+                float *g = geo + p * kPairGeomFloats;
+                pair_geometry(a.poses, a.intr, ij & 0xffff, ij >> 16, g);
+                if (!SO) {
+                    const int gp = p == tid ? gp0 : pd.tile_pairs[pd.tile_pair0[tile] + p];
+                    float4 *dst = reinterpret_cast<float4 *>(a.pairgeo + (size_t)gp * kPairGeomFloats);
+                    const float4 *src = reinterpret_cast<const float4 *>(g);
+#pragma unroll
+                    for (int c = 0; c < kPairGeomFloats / 4; ++c) dst[c] = src[c];
+                }
             }
         }
         for (int i = tid; i < R16 * kLdsRowStride; i += nthr) Eh[i] = 0.0f;
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
         float *g = sgeo[w];
         // the sums first (they need only the pair index), so their latency runs under the pose loads and the geometry
         const double accv = lane < 36 ? acc[sym21(lane / 6, lane % 6)] : lane < 42 ? acc[21 + lane - 36] : 0.0;
-        if (lane == 0) pair_geometry(a.poses, a.intr, pd.pair_i[p], pd.pair_j[p], g);
+        if (lane < kPairGeomFloats) g[lane] = a.pairgeo[(size_t)p * kPairGeomFloats + lane];     // computed by k_tile
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (lane < 36) {
             const int r = lane / 6, c = lane % 6;

@@ -17,6 +17,7 @@ struct StepArgs {
     double *packed;               // the non-zero blocks of [S | y] in factor order (multi-GPU exchange buffer)
     float2 *qw;
     float *esave, *lfac, *linv, *zvec, *dx;
+    float *pairgeo;               // [pairs][kPairGeomFloats]: relative pose of every camera pair, left by k_tile for k_pair_finalize
     int *status;
     int dbg;                      // env BT_DEBUG_MODE, 0 in production: 16 / 32 launch the cycle-counting variants of the solver / k_tile
 };

@@ -50,7 +50,7 @@ struct PlanDev {
 // Byte offsets of the regions inside the caller's workspace.
 struct WsLayout {
     size_t sys, pairacc, zero_bytes;   // [sys, sys+zero_bytes) is cleared every reduce
-    size_t packed, qw, esave, lfac, linv, zvec, dx, status, total;
+    size_t packed, pairgeo, qw, esave, lfac, linv, zvec, dx, status, total;
 };
 
 }  // namespace bt
