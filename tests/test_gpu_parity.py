@@ -16,6 +16,7 @@ import torch
 
 import oracle
 from batrack_amd import graphgen
+from batrack_amd.plan import Plan, Stepper
 from gpu_util import HipProblem, rel
 
 pytestmark = pytest.mark.gpu
@@ -351,3 +352,39 @@ def test_track_seen_by_many_cameras_vs_oracle():
     assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
     assert rel(o["poses_out"], ref["poses_out"]) < 1e-4              # a 47-pose dense system: float32 factor in LDS or global memory
     assert rel(o["patches_out"], ref["patches_out"]) < 1e-4
+
+
+def test_nan_in_solution_retries_with_larger_damping():
+    """ba.py:324-325: a NaN in dX makes the reference solve once more with lm = 1e-3 and keep whatever that gives.
+    The path cannot be reached through finite inputs (a NaN in the matrix fails the factorisation first,
+    ba.py:9-13), so the right-hand side of the reduced system is poisoned between the two halves of the step."""
+    d = load("c1")
+    hp = HipProblem(d)
+    plan = Plan(hp.ii, hp.jj, hp.kk, hp.poses.shape[1], hp.patches.shape[1], 1)
+    st = Stepper(plan, "cuda:0")
+    P = hp.poses[0].contiguous()
+    pat = hp.patches.reshape(-1, 3).contiguous()
+    Pout, pout = torch.empty_like(P), torch.empty_like(pat)
+    tg = hp.t3[0]
+    args = (P, pat, hp.mono.reshape(-1), hp.intr[0], tg, tg.stride(0), hp.w["weights_pose"][0].contiguous(),
+            Pout, pout, hp.bounds, 1e-4, 10.0, 0.05, "huber", False)
+    D = 6 * plan.n
+    st.step(*args, phase="reduce")
+    good = st.system.clone()
+    st.step(*args, phase="solve_update")
+    torch.cuda.synchronize()
+    assert st.status() == 0 and bool(torch.isfinite(Pout).all())
+    ref_pose = Pout.clone()
+    # same system, y[3] = NaN: the factorisation succeeds, the solution is NaN, the retry cannot cure it
+    st.system.copy_(good)
+    st.system[D * D + 3] = float("nan")
+    st.step(*args, phase="solve_update")
+    torch.cuda.synchronize()
+    assert st.status() == 2                                    # BT_SOLVE_RETRIED
+    assert bool(torch.isnan(st.dx).any())
+    assert bool(torch.isfinite(Pout[0]).all()) and bool(torch.isnan(Pout[1:plan.n + 1]).any())   # pose 0 is fixed
+    # and the plan is still usable afterwards
+    st.system.copy_(good)
+    st.step(*args, phase="solve_update")
+    torch.cuda.synchronize()
+    assert st.status() == 0 and torch.equal(Pout, ref_pose)
