@@ -186,5 +186,20 @@ def main():
     save("c3", **arrs)
 
 
+def main_nan():
+    """Non-finite input: the C1 graph with ONE NaN target (first coordinate of the 6th edge that carries pose
+    weight).  The reference masks by multiplication, so the NaN survives as 0 * NaN (ba.py:233-251)."""
+    g = graphgen.make_config("C1", seed=0, n_buf=10)
+    inp = as_inputs(g)
+    e0 = int(np.flatnonzero(inp["weights_pose"][:, 0] > 0)[5])
+    t = inp["targets3"].copy()
+    t[e0, 0] = np.nan
+    arrs = dict(e0=np.int64(e0))
+    for loss in ("huber", "cauchy", "trivial"):
+        o = run_ref(dict(inp, targets3=t), torch.float64, "weights_pose", 1, False, loss=loss)
+        arrs.update(pack(loss, dict(poses_out=o["poses_out"], patches_out=o["patches_out"], dX=o["dX"], n_solves=o["n_solves"])))
+    save("c1_nan", **arrs)
+
+
 if __name__ == "__main__":
-    main()
+    main_nan() if sys.argv[1:] == ["nan"] else (main(), main_nan())

@@ -388,3 +388,27 @@ def test_nan_in_solution_retries_with_larger_damping():
     st.step(*args, phase="solve_update")
     torch.cuda.synchronize()
     assert st.status() == 0 and torch.equal(Pout, ref_pose)
+
+
+@pytest.mark.parametrize("loss,status,n_pose_nan,n_patch_nan", [("huber", 2, 49, 256), ("cauchy", 1, 0, 1)])
+def test_nan_target_poisons_the_state_as_in_the_reference(loss, status, n_pose_nan, n_patch_nan):
+    """The reference masks an edge by MULTIPLYING with v = 0 (ba.py:233-251), so a NaN target survives as 0 * NaN.
+    Run on the C1 graph with one NaN target (tests/golden/make_golden.py machinery, float64) the reference gives:
+    huber / trivial — S finite, y NaN, two solves (ba.py:324-325), all 7 free poses NaN (49 numbers) and all 256
+    active disparities NaN; cauchy — the weight itself is NaN, S is NaN, the factorisation fails (ba.py:9-13),
+    dX = 0, no pose is touched and only that track's disparity is NaN.  The oracle and the kernels multiply too."""
+    d = load("c1")
+    e0 = int(np.flatnonzero(d["weights_pose"][:, 0] > 0)[5])
+    t = d["targets3"].copy()
+    t[e0, 0] = np.nan
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], t, d["weights_pose"],
+                         d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, loss=loss)
+    o = HipProblem(dict(d, targets3=t)).raw_step("weights_pose", 1, loss=loss)
+    assert o["status"] == status and ref["failed"] == (status == 1)
+    for name, n in (("poses_out", n_pose_nan), ("patches_out", n_patch_nan)):
+        nr, nh = np.isnan(ref[name]), np.isnan(o[name])
+        assert nr.sum() == n and np.array_equal(nr, nh), (name, nr.sum(), nh.sum())
+        if (~nr).any():
+            assert rel(o[name][~nr], ref[name][~nr]) < STATE_TOL
+    if status == 1:
+        assert np.all(o["dX"] == 0) and np.isnan(o["patches_out"][d["kk"][e0], 2])

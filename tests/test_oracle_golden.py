@@ -113,3 +113,27 @@ def test_c3_full_size():
     o2 = oracle.ba_step(o["poses_out"], o["patches_out"], f(g.mono_disp), f(g.intrinsics), f(g.targets3),
                         f(g.weights), g.ii, g.jj, g.kk, g.bounds, fixedp=1, structure_only=True)
     assert rel(o2["patches_out"][:, 2], d["so.f64.disp_out"]) < 1e-10
+
+
+@pytest.mark.parametrize("loss", ["huber", "cauchy", "trivial"])
+def test_nan_target_matches_reference(loss):
+    """tests/golden/c1_nan.npz (make_golden.py nan): one NaN target on the C1 graph.  The reference masks by
+    multiplication, so 0 * NaN poisons the right-hand side (huber / trivial: retry, every free pose and active
+    disparity NaN) or the matrix (cauchy: failed factorisation, dX = 0, one disparity NaN).  Same NaN pattern and,
+    where finite, the same numbers from the oracle."""
+    d = dict(np.load(os.path.join(GOLD, "c1.npz")))
+    gold = dict(np.load(os.path.join(GOLD, "c1_nan.npz")))
+    t = d["targets3"].copy()
+    t[int(gold["e0"]), 0] = np.nan
+    o = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], t, d["weights_pose"],
+                       d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, loss=loss, want_system=True)
+    for name in ("poses_out", "patches_out"):
+        ref = gold[f"{loss}.{name}"]
+        assert np.array_equal(np.isnan(ref), np.isnan(o[name])), name
+        ok = ~np.isnan(ref)
+        assert np.abs(o[name][ok] - ref[ok]).max() < 1e-9
+    assert o["failed"] == (loss == "cauchy")
+    if loss == "cauchy":
+        assert int(gold["cauchy.n_solves"]) == 1 and np.all(gold["cauchy.dX"] == 0) and np.all(o["dX"] == 0)
+    else:
+        assert int(gold[f"{loss}.n_solves"]) == 2 and np.isnan(gold[f"{loss}.dX"]).all() and np.isnan(o["dX"]).all()
