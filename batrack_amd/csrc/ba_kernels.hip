@@ -1,17 +1,18 @@
 // ba_kernels.hip — gfx950 (CDNA4, wave64) kernels of the BA step.
 //
-// One BA_rgbd_droid call (/root/reference/main/backend/ba.py:217-339) becomes
-//   k_prep           relative pose of every camera pair (Gij is per PAIR, not per
-//                    edge: projective_ops.py:61) + clearing of the accumulators
-//   k_tile           per-edge reprojection, Jacobians, robust weights
-//                    (projective_ops.py:54-100, ba.py:228-266), per-track C/w/E,
-//                    per-pair J^T W J, and the tile's Schur product E Q E^T
-//                    (ba.py:284-323) — one workgroup of 4 waves per 64-track tile
+// One BA_rgbd_droid call (/root/reference/main/backend/ba.py:217-339) becomes four launches
+//   k_tile           one workgroup of 8 (16) waves per tile of up to 64 tracks: relative pose of
+//                    the tile's camera pairs (Gij is per PAIR, not per edge: projective_ops.py:61),
+//                    per-edge reprojection, Jacobians, robust weights (projective_ops.py:54-100,
+//                    ba.py:228-266), per-track C / w / E, per-pair J^T W J, and the tile's Schur
+//                    product E Q E^T on the f64 MFMA (ba.py:284-323)
 //   k_pair_finalize  B and v of ba.py:279-290 from the per-pair sums
-//   k_solve          damped block-sparse Cholesky of the reduced camera system,
-//                    forward/back substitution (ba.py:60-70,323-325)
-//   k_update         back-substitution of the depths, clamp, pose retraction
-//                    (ba.py:328-337, groups.py:153-156)
+//   k_solve_*        damped block-sparse Cholesky of the reduced camera system in LDS, forward and
+//                    back substitution (ba.py:60-70,323-325): k_solve_pipe (barrier-free sweep) where
+//                    the plan allows it, else k_solve_fused / k_solve_lds / k_solve_global
+//   k_update         back-substitution of the depths, clamp of the whole buffer, pose retraction
+//                    (ba.py:328-337, groups.py:153-156); leaves [S | y] clear for the next step
+// plus k_pack_system for the multi-GPU exchange form.  A structure-only call is k_tile<SO> + k_update<SO>.
 //
 // Algebra used throughout: Ji = -Jj * Ad(Gij), so with
 // per-pair sums  Bjj = sum Jj^T W Jj,  gj = sum Jj^T W r  the blocks are
