@@ -18,6 +18,7 @@ re-normalised but unmoved (ba.py:9-13), nothing raises.
 There is no CPU path: tensors must live on a ROCm device and the HIP library
 must be built, otherwise this raises.
 """
+import threading
 import weakref
 
 import torch
@@ -28,28 +29,93 @@ from .lietorch import SE3
 
 _CACHE = {}          # key -> (stepper, (weakref ii, jj, kk))
 _CACHE_MAX = 8
+_PENDING = {}        # key -> (thread, result box, (ii, jj, kk)): plans being built by prefetch_plan
+
+
+def _key(ii, jj, kk, n_buf, p_tot, fixedp, device):
+    return (id(ii), id(jj), id(kk), ii._version, jj._version, kk._version,
+            ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii.numel(), int(fixedp), int(n_buf), int(p_tot), str(device))
+
+
+def _store(key, stepper, ii, jj, kk):
+    if len(_CACHE) >= _CACHE_MAX:
+        _CACHE.pop(next(iter(_CACHE)))
+    _CACHE[key] = (stepper, tuple(weakref.ref(t) for t in (ii, jj, kk)))
 
 
 def _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, device):
     """One plan per (edge list, fixedp): the caller keeps self.ii/jj/kk alive and
     unmodified across the 2*ITER calls of an update() (batrack.py:869-875) and
     replaces the tensors when edges are appended/removed (batrack.py:189-204)."""
-    key = (id(ii), id(jj), id(kk), ii._version, jj._version, kk._version,
-           ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii.numel(), int(fixedp), int(n_buf), int(p_tot), str(device))
+    key = _key(ii, jj, kk, n_buf, p_tot, fixedp, device)
     hit = _CACHE.get(key)
     if hit is not None:
         stepper, refs = hit
         if all(r() is t for r, t in zip(refs, (ii, jj, kk))):
             return stepper
         del _CACHE[key]
-    if len(_CACHE) >= _CACHE_MAX:
-        _CACHE.pop(next(iter(_CACHE)))
+    pend = _PENDING.pop(key, None)
+    if pend is not None:                          # prefetch_plan is building exactly this one: wait for it
+        thread, box, held = pend
+        thread.join()
+        if "stepper" in box and all(h is t for h, t in zip(held, (ii, jj, kk))):
+            _store(key, box["stepper"], ii, jj, kk)
+            return box["stepper"]
+        if "error" in box and not isinstance(box["error"], Exception):
+            raise box["error"]                    # KeyboardInterrupt and the like; ordinary errors are re-raised by the build below
     stepper = Stepper(Plan(ii, jj, kk, n_buf, p_tot, fixedp), device)
-    _CACHE[key] = (stepper, tuple(weakref.ref(t) for t in (ii, jj, kk)))
+    _store(key, stepper, ii, jj, kk)
     return stepper
 
 
+def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True):
+    """Build the plan of an edge list ahead of the BA calls that will use it.
+
+    The caller knows `(ii, jj, kk)` and `fixedp` of an `update()` as soon as it has appended / removed factors —
+    a whole tracker pass before it calls `BA_rgbd_droid` (batrack.py:983-993: `append_factors`, then
+    `predict_target`, then `update`).  Called there, this takes the per-frame plan (host analysis + table upload,
+    ~1.5 ms for the 138k-edge window) off the critical path: a host thread builds it while the GPU and the main
+    thread are busy; the first `BA_rgbd_droid` call with the same tensors picks it up (or waits for it).
+    The index tensors must not be modified in place afterwards (the reference replaces them, it never edits them
+    between `append_factors` and `update`)."""
+    dev = torch.device(device) if device is not None else ii.device
+    if dev.type != "cuda":
+        raise RuntimeError("prefetch_plan: the edge list must be on the GPU (no CPU fallback in batrack_amd)")
+    if ii.numel() == 0:
+        return
+    key = _key(ii, jj, kk, n_buf, p_tot, fixedp, dev)
+    if key in _CACHE or key in _PENDING:
+        return
+    _lib.lib()
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))               # the indices are complete once this has passed
+    box = {}
+
+    def build():
+        try:
+            ready.synchronize()
+            with torch.cuda.device(dev):                       # the current device is per host thread
+                box["stepper"] = Stepper(Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=False), dev)
+        except BaseException as e:                              # reported (or retried in the open) by _plan_for
+            box["error"] = e
+
+    while len(_PENDING) >= 4:                                  # stale prefetches (edge lists that were never used)
+        _PENDING.pop(next(iter(_PENDING)))[0].join()
+    if background:
+        th = threading.Thread(target=build, name="batrack-plan", daemon=True)
+        th.start()
+        _PENDING[key] = (th, box, (ii, jj, kk))
+    else:
+        build()
+        if "error" in box:
+            raise box["error"]
+        _store(key, box["stepper"], ii, jj, kk)
+
+
 def clear_plan_cache():
+    for th, _, _ in list(_PENDING.values()):
+        th.join()
+    _PENDING.clear()
     _CACHE.clear()
 
 

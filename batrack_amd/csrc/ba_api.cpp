@@ -105,6 +105,23 @@ struct PlanPool {
 };
 static PlanPool &plan_pool() { static PlanPool *p = new PlanPool(); return *p; }
 
+// Plan transfers (index download, table upload) run on a stream of their own, created non-blocking: a plan can
+// then be built from a second host thread while the caller's streams are busy — BATRACK knows the edge list of an
+// update() a whole tracker pass before it calls the BA (batrack.py:983-993) — without the implicit waits a
+// synchronous hipMemcpy on the null stream would bring.
+static hipStream_t copy_stream() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    static std::mutex mu;
+    static std::vector<std::pair<int, hipStream_t>> *streams = new std::vector<std::pair<int, hipStream_t>>();
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : *streams) if (e.first == dev) return e.second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;   // null stream: still correct
+    streams->emplace_back(dev, s);
+    return s;
+}
+
 static bool api_prof() { static const bool p = std::getenv("BT_PLAN_PROF") != nullptr; return p; }
 struct ApiTick {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -139,7 +156,9 @@ int upload_plan(bt_plan *pl) {
     void *d = dev_pool().acquire(buf.size() + 256, &cap);
     if (!d) return BT_ENOMEM;
     tick("device buffer");
-    if (hipMemcpy(d, buf.data(), buf.size(), hipMemcpyHostToDevice) != hipSuccess) { dev_pool().release(d, cap); return BT_EHIP; }
+    hipStream_t cs = copy_stream();
+    if (hipMemcpyAsync(d, buf.data(), buf.size(), hipMemcpyHostToDevice, cs) != hipSuccess ||
+        hipStreamSynchronize(cs) != hipSuccess) { dev_pool().release(d, cap); return BT_EHIP; }
     tick("H2D copy");
     pl->dev_base = d;
     pl->dev_cap = cap;
@@ -226,9 +245,11 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
     ApiTick tick;
     if (on_device && E > 0) {
         host.resize((size_t)(3 * E));
-        if (hipMemcpy(host.data(), ii, (size_t)E * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(host.data() + E, jj, (size_t)E * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(host.data() + 2 * E, kk, (size_t)E * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        hipStream_t cs = copy_stream();
+        if (hipMemcpyAsync(host.data(), ii, (size_t)E * 8, hipMemcpyDeviceToHost, cs) != hipSuccess ||
+            hipMemcpyAsync(host.data() + E, jj, (size_t)E * 8, hipMemcpyDeviceToHost, cs) != hipSuccess ||
+            hipMemcpyAsync(host.data() + 2 * E, kk, (size_t)E * 8, hipMemcpyDeviceToHost, cs) != hipSuccess ||
+            hipStreamSynchronize(cs) != hipSuccess)
             return BT_EHIP;
         hi = host.data(); hj = host.data() + E; hk = host.data() + 2 * E;
         tick("D2H indices");

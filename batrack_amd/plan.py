@@ -21,7 +21,7 @@ PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0",
 class Plan:
     """bt_plan handle.  ii/jj/kk: int64 torch tensors (CPU or GPU) or numpy arrays."""
 
-    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, upload=True, n_all_min=0, own=(0, 0)):
+    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, upload=True, n_all_min=0, own=(0, 0), sync=True):
         L = _lib.lib()
         self._lib = L
         self._h = ctypes.c_void_p()
@@ -38,6 +38,8 @@ class Plan:
                 if a.dtype != torch.int64:
                     raise TypeError("edge indices must be int64 (batrack.py:100-102)")
             on_device = 1 if arrs[0].is_cuda else 0
+            if on_device and sync:
+                torch.cuda.current_stream(arrs[0].device).synchronize()   # the indices must be complete (batrack_ba.h)
             ptrs = [a.data_ptr() for a in arrs]
             E = arrs[0].numel()
         self._keep = arrs

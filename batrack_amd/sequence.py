@@ -100,8 +100,12 @@ class WindowedBA:
     BATRACK object where they exist: n, m, M, N, poses_, patches_, ii, jj, kk, targets_3d,
     weights, weights_pose)."""
 
-    def __init__(self, obs, ba, cfg=None, device="cpu", sync=None):
+    def __init__(self, obs, ba, cfg=None, device="cpu", sync=None, prefetch=None):
+        """prefetch: optional `batrack_amd.backend.ba.prefetch_plan`; it is called where the reference knows the
+        edge list of the coming update() — after `append_factors` (before the tracker pass that `predict_target`
+        stands for) and after `keyframe_simple` when the next frame appends nothing."""
         self.obs, self.ba, self.device = obs, ba, torch.device(device)
+        self.prefetch = prefetch
         self.cfg = cfg or SlamConfig(PATCHES_PER_FRAME=obs.M, BUFFER_SIZE=obs.n_frames + 1)
         c = self.cfg
         if c.PATCHES_PER_FRAME != obs.M or c.BUFFER_SIZE < obs.n_frames + 1:
@@ -228,6 +232,16 @@ class WindowedBA:
         if c.USE_MAP_FILTERING:
             self.map_point_filtering()
 
+    def _prefetch(self, n_at_update):
+        """Hand the edge list of the update() that will run with `n_at_update` frames to the plan builder."""
+        c = self.cfg
+        if self.prefetch is None or self.ii.numel() == 0:
+            return
+        if not (self.is_initialized or n_at_update == c.num_init + 1):
+            return                                              # no update() before the initialisation frame
+        t0 = max(n_at_update - c.OPTIMIZATION_WINDOW, 1)        # update(): is_initialized is set by then
+        self.prefetch(self.ii, self.jj, self.kk, self.N, self.N * self.M, t0, self.device)
+
     # ---- batrack.py:1020-1024
     def keyframe_simple(self):
         self.remove_factors(self.kk // self.M < self.n - self.cfg.REMOVAL_WINDOW)
@@ -246,6 +260,7 @@ class WindowedBA:
         self.m += self.M
         if (self.n - 1) % c.kf_stride == 0:
             self.append_factors(*self._edges())
+            self._prefetch(self.n)
             self.predict_target()
         if self.n == c.num_init + 1 and not self.is_initialized:
             self.is_initialized = True
@@ -254,6 +269,8 @@ class WindowedBA:
         elif self.is_initialized:
             self.update()
             self.keyframe_simple()
+            if self.n % c.kf_stride != 0:                       # the next frame appends nothing: its edge list is final now
+                self._prefetch(self.n + 1)
 
     # ---- batrack.py:1080-1135, the BA-owned part of the hand-off to the next stage
     def get_results(self):

@@ -62,8 +62,11 @@ typedef struct {
 } bt_plan_info;
 
 /* Build the plan.  ii/jj/kk are int64[E] (the dtype the reference's caller
- * holds, batrack.py:100-102), on the device (on_device=1; copied back once,
- * synchronously) or on the host (on_device=0).  upload=0 keeps the plan
+ * holds, batrack.py:100-102), on the device (on_device=1; copied back once, on an
+ * internal non-blocking stream that is synchronised before the call returns — the
+ * caller makes sure the arrays are complete, i.e. synchronises the stream that
+ * produced them; the call may then come from any host thread while other streams
+ * are busy) or on the host (on_device=0).  upload=0 keeps the plan
  * host-only (no HIP call is made: CPU tests).  Errors: BT_EINVAL for indices
  * out of range, BT_EUNSUPPORTED if a single track is seen by more than 64 free
  * cameras, n > 255, or the edges of one track name different source frames (the

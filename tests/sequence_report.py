@@ -30,19 +30,21 @@ args = ap.parse_args()
 
 from batrack_amd.backend.ba import BA_rgbd_droid  # noqa: E402
 rows = {}
-for name, ba, dev in (("hip", BA_rgbd_droid, "cuda:0"), ("oracle", oracle_BA_rgbd_droid, "cpu")):
+from batrack_amd.backend.ba import prefetch_plan  # noqa: E402
+for name, ba, dev in (("hip", BA_rgbd_droid, "cuda:0"), ("hip+prefetch", BA_rgbd_droid, "cuda:0"), ("oracle", oracle_BA_rgbd_droid, "cpu")):
     if name == "oracle" and args.skip_oracle:
         continue
-    for rep in range(2 if name == "hip" else 1):            # second HIP run: warm allocator / code objects
+    for rep in range(2 if name.startswith("hip") else 1):            # second HIP run: warm allocator / code objects
         obs = SyntheticObservations(n_frames=args.frames, M=args.M, seed=args.seed)
-        trk = WindowedBA(obs, ba, SlamConfig(PATCHES_PER_FRAME=args.M, BUFFER_SIZE=max(args.buffer, args.frames + 1)), device=dev)
+        trk = WindowedBA(obs, ba, SlamConfig(PATCHES_PER_FRAME=args.M, BUFFER_SIZE=max(args.buffer, args.frames + 1)), device=dev,
+                         prefetch=prefetch_plan if name == "hip+prefetch" else None)
         t0 = time.perf_counter()
         poses = trk.run()
         wall = time.perf_counter() - t0
     rows[name] = dict(poses=poses, wall=wall, stats=trk.stats,
                       ate=evaluation.ate_rmse(evaluation.camera_centres(poses), obs.centres_gt()))
     s = trk.stats
-    print(f"{name:6s}: frames={args.frames} M={args.M} buffer={max(args.buffer, args.frames + 1)} updates={s['updates']} ba_calls={s['ba_calls']} edges_max={s['edges_max']} "
+    print(f"{name:12s}: frames={args.frames} M={args.M} buffer={max(args.buffer, args.frames + 1)} updates={s['updates']} ba_calls={s['ba_calls']} edges_max={s['edges_max']} "
           f"ATE={rows[name]['ate']:.6e}  BA time={s['ba_seconds']:.3f}s ({1e3 * s['ba_seconds'] / s['updates']:.3f} ms/update, "
           f"{1e6 * s['ba_seconds'] / s['ba_calls']:.1f} us/call incl. plan builds)  loop wall={wall:.2f}s", flush=True)
 if "oracle" in rows:

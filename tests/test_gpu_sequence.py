@@ -53,3 +53,33 @@ def test_davis_shaped_stage():
     assert r["hip"]["stats"]["edges_max"] > 150000
     assert abs(r["hip"]["ate"] - r["oracle"]["ate"]) <= 0.01 * r["oracle"]["ate"], (r["hip"]["ate"], r["oracle"]["ate"])
     assert np.abs(r["hip"]["poses"] - r["oracle"]["poses"]).max() < 2e-4
+
+
+def test_prefetched_plans_give_the_same_trajectory():
+    """prefetch_plan builds the plan of the coming update() on a host thread while the frame's other work runs
+    (batrack.py:983-993: the edge list is known before the tracker pass).  Same trajectory bit for bit as without,
+    every plan taken from the prefetch (none built inside BA_rgbd_droid), and less BA time on the critical path."""
+    from batrack_amd.backend import ba as hip_ba
+    from batrack_amd import plan as plan_mod
+    runs = {}
+    for name, pf in (("plain", None), ("prefetch", hip_ba.prefetch_plan)):
+        hip_ba.clear_plan_cache()
+        built = {"main": 0, "other": 0}
+        orig = plan_mod.Plan.__init__
+        import threading
+
+        def counted(self, *a, **k):
+            built["main" if threading.current_thread() is threading.main_thread() else "other"] += 1
+            return orig(self, *a, **k)
+        plan_mod.Plan.__init__ = counted
+        try:
+            obs = SyntheticObservations(n_frames=36, M=96, seed=3)
+            trk = WindowedBA(obs, hip_ba.BA_rgbd_droid, SlamConfig(PATCHES_PER_FRAME=96, BUFFER_SIZE=64), device="cuda:0", prefetch=pf)
+            poses = trk.run()
+        finally:
+            plan_mod.Plan.__init__ = orig
+        runs[name] = dict(poses=poses, built=dict(built), ba=trk.stats["ba_seconds"], updates=trk.stats["updates"])
+    assert np.array_equal(runs["plain"]["poses"], runs["prefetch"]["poses"])
+    assert runs["plain"]["built"]["other"] == 0 and runs["plain"]["built"]["main"] > 10
+    assert runs["prefetch"]["built"]["main"] == 0 and runs["prefetch"]["built"]["other"] == runs["plain"]["built"]["main"]
+    hip_ba.clear_plan_cache()
