@@ -18,8 +18,8 @@ re-normalised but unmoved (ba.py:9-13), nothing raises.
 There is no CPU path: tensors must live on a ROCm device and the HIP library
 must be built, otherwise this raises.
 """
-import threading
 import weakref
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
@@ -29,7 +29,8 @@ from .lietorch import SE3
 
 _CACHE = {}          # key -> (stepper, (weakref ii, jj, kk))
 _CACHE_MAX = 8
-_PENDING = {}        # key -> (thread, result box, (ii, jj, kk)): plans being built by prefetch_plan
+_PENDING = {}        # key -> (future, result box, (ii, jj, kk)): plans being built by prefetch_plan
+_WORKER = None       # one long-lived host thread (the planner keeps edge-sized scratch per thread)
 
 
 def _key(ii, jj, kk, n_buf, p_tot, fixedp, device):
@@ -56,8 +57,8 @@ def _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, device):
         del _CACHE[key]
     pend = _PENDING.pop(key, None)
     if pend is not None:                          # prefetch_plan is building exactly this one: wait for it
-        thread, box, held = pend
-        thread.join()
+        future, box, held = pend
+        future.result()
         if "stepper" in box and all(h is t for h, t in zip(held, (ii, jj, kk))):
             _store(key, box["stepper"], ii, jj, kk)
             return box["stepper"]
@@ -100,11 +101,12 @@ def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True
             box["error"] = e
 
     while len(_PENDING) >= 4:                                  # stale prefetches (edge lists that were never used)
-        _PENDING.pop(next(iter(_PENDING)))[0].join()
+        _PENDING.pop(next(iter(_PENDING)))[0].result()
     if background:
-        th = threading.Thread(target=build, name="batrack-plan", daemon=True)
-        th.start()
-        _PENDING[key] = (th, box, (ii, jj, kk))
+        global _WORKER
+        if _WORKER is None:
+            _WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="batrack-plan")
+        _PENDING[key] = (_WORKER.submit(build), box, (ii, jj, kk))
     else:
         build()
         if "error" in box:
@@ -113,8 +115,8 @@ def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True
 
 
 def clear_plan_cache():
-    for th, _, _ in list(_PENDING.values()):
-        th.join()
+    for fut, _, _ in list(_PENDING.values()):
+        fut.result()
     _PENDING.clear()
     _CACHE.clear()
 
