@@ -14,7 +14,7 @@ ap.add_argument("--reps", type=int, default=50)
 args = ap.parse_args()
 dev = "cuda:0"
 if args.workload == "window":
-    g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4, n_buf=int(os.environ.get("BUFFER", 50)))
+    g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4, n_buf=int(os.environ.get("BUFFER", 50)), window=int(os.environ.get("WINDOW", 12)), removal=int(os.environ.get("REMOVAL", 20)))
 else:
     g, fixedp = graphgen.make_config(args.workload, seed=0), 1
 f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
