@@ -1785,7 +1785,7 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
     for (int i = tid; i < nnzb; i += nth) { row_idx[i] = pd.fz_rowinfo[i]; pfirst[i] = pd.fz_pfirst[i]; psecond[i] = pd.fz_psecond[i]; }
     for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
     for (int i = tid; i < nlev * 8; i += nth) lrec[i] = pd.fz_pmeta[i];
-    long long tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, twait = 0, twork = 0, tq = 0, sub[3] = {0, 0, 0};
+    long long tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, twait = 0, twork = 0, tq = 0, sub[3] = {0, 0, 0}, wsplit[2] = {0, 0};
 #define BT_TW(acc) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); acc += tn - tq; tq = tn; } } while (0)
 
     int status = BT_SOLVE_OK;
@@ -1821,13 +1821,17 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
                         // (the diagonal wave also waits for the row wave that last read its scratch slot)
                         const int dep = ((md >> 20) & 3) | ((!is_row && q < npc) ? 1 << q : 0);
                         const int need0 = (dep & 1) ? l : 0, need1 = (dep & 2) ? l : 0, needh = nh * (l - 1);
+                        const long long tw0 = PROF ? clock64() : 0;
+                        int lastfail = -1;                           // (PROF: what the wait was for: 1 = the helpers' batch, 0 = a column)
                         for (;;) {
                             const int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const int f1 = __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const int fh = __hip_atomic_load(&hcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (f0 >= need0 && f1 >= need1 && fh >= needh) break;
+                            if (PROF) lastfail = fh < needh ? 1 : 0;
                             __builtin_amdgcn_s_sleep(1);
                         }
+                        if (PROF && lastfail >= 0) wsplit[lastfail] += clock64() - tw0;
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
                     BT_TW(twait);
@@ -2022,7 +2026,7 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
         if (wave == 0 || wave == 2) {
             long long *g = reinterpret_cast<long long *>(a.status + 4) + (wave ? 10 : 0);
             g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
-            g[3] = sub[0]; g[4] = sub[1]; g[5] = sub[2]; g[6] = twait;
+            g[3] = sub[0]; g[4] = sub[1]; g[5] = sub[2]; g[6] = twait; g[7] = wsplit[0]; g[8] = wsplit[1];
         }
     }
 #undef BT_TW
