@@ -234,8 +234,19 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"track-sharded x{world}, 1 all-reduce of the non-zero blocks of [S|y] per step",
                        "plan_build_ms": round(plan_ms, 2), "solver_status": status, **extra},
         }
-        if roofline is not None:
-            out["roofline"] = roofline
+        if roofline is None:
+            # N > 1: the Jacobian kernel of rank 0's shard (its own plan: this rank's tracks), same definition
+            acc = []
+            for k in range(min(args.steps, 50)):
+                a, b = k & 1, (k + 1) & 1
+                acc.append(stepper.step_timed(P[a], X[a], mono, intr, tg, tg.stride(0), wp_l, P[b], X[b], *scal, False)["tile"])
+            tile_us = 1e3 * float(np.mean(acc))
+            alg_bytes = 40 * plan.E + 20 * plan.m + 72 * plan.n_all
+            achieved = alg_bytes / (tile_us * 1e-6) / 1e9 if tile_us > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes": alg_bytes, "kernel_us": round(tile_us, 3), "scope": f"rank 0's shard of {world}"}
+        out["roofline"] = roofline
         if cpu_baseline is not None:
             out["cpu_baseline"] = cpu_baseline
         print(json.dumps(out), flush=True)
