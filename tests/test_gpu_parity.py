@@ -412,3 +412,30 @@ def test_nan_target_poisons_the_state_as_in_the_reference(loss, status, n_pose_n
             assert rel(o[name][~nr], ref[name][~nr]) < STATE_TOL
     if status == 1:
         assert np.all(o["dX"] == 0) and np.isnan(o["patches_out"][d["kk"][e0], 2])
+
+
+def test_random_graph_sweep():
+    """40 random co-visibility graphs of random size, density, forest structure, fixed prefix and call kind (the short
+    form of tests/gpu_random_sweep.py): the state stays within max(1e-5, 3x what float32 arithmetic throughout — the
+    reference's own precision — loses against float64 on that graph)."""
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for t in range(40):
+        N = int(rng.integers(3, 60)); M = int(rng.integers(2, 60))
+        far = float(rng.choice([0.0, 0.05, 0.2, 0.5, 1.0])); groups = int(rng.choice([1, 1, 1, 2, 4]))
+        fixedp = int(rng.integers(0, min(4, N - 1)))
+        so = bool(rng.random() < 0.15)
+        g = graphgen.make_random_graph(N, M, seed=500 + t, far_frac=far, groups=groups)
+        f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+        d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics), targets3=f(g.targets3),
+                 weights=f(g.weights), weights_pose=f(g.weights_pose), ii=g.ii, jj=g.jj, kk=g.kk, bounds=np.asarray(g.bounds))
+        args = (d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"], d["ii"], d["jj"], d["kk"], d["bounds"])
+        r64 = oracle.ba_step(*args, fixedp=fixedp, structure_only=so)
+        r32 = oracle.ba_step(*args, fixedp=fixedp, structure_only=so, dtype=np.float32)
+        o = HipProblem(d).raw_step("weights_pose", fixedp, so=so)
+        for name in ("poses_out", "patches_out"):
+            err, own = rel(o[name], r64[name]), rel(r32[name], r64[name])
+            assert err < max(1e-5, 3.0 * own), (t, N, M, far, groups, fixedp, so, name, err, own)
+            worst = max(worst, err)
+        assert so or o["status"] == 0
+    assert worst < 1e-4
