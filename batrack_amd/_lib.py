@@ -8,8 +8,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "lib", "libbatrack_ba.so")
-SOURCES = ["ba_kernels.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip"]
-HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
+SOURCES = ["ba_kernels.hip", "ba_stream.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip"]
+HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", "ba_edge.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
            os.path.join("..", "..", "include", "batrack_se3.h"), os.path.join("..", "..", "include", "batrack_patchify.h"),
            os.path.join("..", "..", "include", "batrack_projective.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]

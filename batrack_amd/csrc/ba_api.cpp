@@ -137,7 +137,7 @@ int upload_plan(bt_plan *pl) {
     ApiTick tick;
     std::vector<char> &buf = pl->stage;           // capacity survives with the recycled plan object
     buf.clear();
-    const size_t o_kx = put(buf, pl->kx), o_ab = put(buf, pl->act_bits), o_ar = put(buf, pl->act_rank), o_loc = put(buf, pl->trk_loc);
+    const size_t o_kx = put(buf, pl->kx), o_ab = put(buf, pl->act_bits), o_ar = put(buf, pl->act_rank);
     const size_t o_pi = put(buf, pl->pair_i), o_pj = put(buf, pl->pair_j);
     const size_t o_t0 = put(buf, pl->tile_trk0), o_tn = put(buf, pl->tile_ntrk), o_tc = put(buf, pl->tile_ncam);
     const size_t o_c0 = put(buf, pl->tile_cam0), o_s0 = put(buf, pl->tile_slot0), o_sn = put(buf, pl->tile_nslot);
@@ -150,7 +150,8 @@ int upload_plan(bt_plan *pl) {
     const size_t o_pm = put(buf, pl->perm), o_bs = put(buf, pl->blk_src), o_lp = put(buf, pl->lvl_ptr), o_lc = put(buf, pl->lvl_cols);
     const size_t o_cl = put(buf, pl->col_lvl), o_dpp = put(buf, pl->dp_ptr), o_dp = put(buf, pl->dp);
     const size_t o_fpp = put(buf, pl->fz_pend_ptr), o_fp = put(buf, pl->fz_pend), o_flp = put(buf, pl->fz_lazy_ptr), o_fl = put(buf, pl->fz_lazy);
-    const size_t o_fy = put(buf, pl->fz_yurg), o_fm = put(buf, pl->fz_meta), o_fpm = put(buf, pl->fz_pmeta), o_bss = put(buf, pl->bs_sync), o_fri = put(buf, pl->fz_rowinfo), o_fpf = put(buf, pl->fz_pfirst), o_fps = put(buf, pl->fz_psecond), o_ur = put(buf, pl->upd_rec), o_tij = put(buf, pl->tile_ij), o_tkx = put(buf, pl->tile_kx);
+    const size_t o_fy = put(buf, pl->fz_yurg), o_fm = put(buf, pl->fz_meta), o_fpm = put(buf, pl->fz_pmeta), o_bss = put(buf, pl->bs_sync), o_fri = put(buf, pl->fz_rowinfo), o_fpf = put(buf, pl->fz_pfirst), o_fps = put(buf, pl->fz_psecond), o_tij = put(buf, pl->tile_ij), o_tkx = put(buf, pl->tile_kx);
+    const size_t o_sc = put(buf, pl->slot_code), o_tla = put(buf, pl->tile_la), o_trec = put(buf, pl->tile_rec);
     tick("pack arrays");
     size_t cap = 0;
     void *d = dev_pool().acquire(buf.size() + 256, &cap);
@@ -170,7 +171,7 @@ int upload_plan(bt_plan *pl) {
     P.T = (int)I.tiles; P.slots = (int)I.slots; P.erows = (int)I.erows; P.nnzb = (int)I.nnz_blocks;
     P.nupd = (int)I.updates; P.max_rows16 = pl->max_rows16;
 #define BT_I32(off) reinterpret_cast<const int32_t *>(b + (off))
-    P.kx = BT_I32(o_kx); P.trk_loc = BT_I32(o_loc);
+    P.kx = BT_I32(o_kx);
     P.act_bits = reinterpret_cast<const uint32_t *>(b + o_ab); P.act_rank = BT_I32(o_ar);
     P.pair_i = BT_I32(o_pi); P.pair_j = BT_I32(o_pj);
     P.tile_trk0 = BT_I32(o_t0); P.tile_ntrk = BT_I32(o_tn); P.tile_ncam = BT_I32(o_tc); P.tile_cam0 = BT_I32(o_c0);
@@ -183,10 +184,11 @@ int upload_plan(bt_plan *pl) {
     P.nlev = (int)pl->lvl_ptr.size() - 1; P.ndp = (int)pl->dp.size();
     P.lvl_meta = BT_I32(o_lm); P.tile_flags = BT_I32(o_tf);
     P.fz_pend_ptr = BT_I32(o_fpp); P.fz_pend = BT_I32(o_fp); P.fz_lazy_ptr = BT_I32(o_flp); P.fz_lazy = BT_I32(o_fl);
-    P.fz_yurg = BT_I32(o_fy); P.fz_meta = BT_I32(o_fm); P.fz_pmeta = BT_I32(o_fpm); P.bs_sync = BT_I32(o_bss); P.fz_rowinfo = BT_I32(o_fri); P.fz_pfirst = BT_I32(o_fpf); P.fz_psecond = BT_I32(o_fps); P.upd_rec = BT_I32(o_ur); P.tile_ij = BT_I32(o_tij); P.tile_kx = BT_I32(o_tkx);
+    P.fz_yurg = BT_I32(o_fy); P.fz_meta = BT_I32(o_fm); P.fz_pmeta = BT_I32(o_fpm); P.bs_sync = BT_I32(o_bss); P.fz_rowinfo = BT_I32(o_fri); P.fz_pfirst = BT_I32(o_fpf); P.fz_psecond = BT_I32(o_fps); P.tile_ij = BT_I32(o_tij); P.tile_kx = BT_I32(o_tkx);
     P.fz_npend = (int)(pl->fz_pend.size() / 2); P.fz_nlazy = (int)(pl->fz_lazy.size() / 3); P.fz_ok = pl->fz_ok; P.fzp_ok = pl->fzp_ok;
     P.tile_pair0 = BT_I32(o_tp0); P.tile_npair = BT_I32(o_tnp); P.tile_pairs = BT_I32(o_tps);
-    P.slot_lp = reinterpret_cast<const uint8_t *>(b + o_slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots;
+    P.slot_lp = reinterpret_cast<const uint8_t *>(b + o_slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams;
+    P.slot_code = reinterpret_cast<const uint16_t *>(b + o_sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + o_tla); P.tile_rec = BT_I32(o_trec);
 #undef BT_I32
     const int rc = configure_kernels(P);
     tick("configure kernels");
@@ -207,7 +209,7 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     s.pairacc = reinterpret_cast<double *>(w + L.pairacc);
     s.pairgeo = reinterpret_cast<float *>(w + L.pairgeo);
     s.packed = reinterpret_cast<double *>(w + L.packed); s.qw = reinterpret_cast<float2 *>(w + L.qw);
-    s.esave = reinterpret_cast<float *>(w + L.esave); s.lfac = reinterpret_cast<float *>(w + L.lfac);
+    s.lfac = reinterpret_cast<float *>(w + L.lfac);
     s.linv = reinterpret_cast<float *>(w + L.linv); s.zvec = reinterpret_cast<float *>(w + L.zvec);
     s.dx = reinterpret_cast<float *>(w + L.dx); s.status = reinterpret_cast<int *>(w + L.status);
     static const int dbg = std::getenv("BT_DEBUG_MODE") ? std::atoi(std::getenv("BT_DEBUG_MODE")) : 0;
@@ -294,7 +296,7 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
     BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next) BT_ARR(perm) BT_ARR(blk_src) BT_ARR(lvl_ptr) BT_ARR(lvl_cols)
     BT_ARR(col_lvl) BT_ARR(dp_ptr) BT_ARR(dp) BT_ARR(tile_pair0) BT_ARR(tile_npair) BT_ARR(tile_pairs) BT_ARR(slot_lp) BT_ARR(tile_flags)
-    BT_ARR(fz_pend_ptr) BT_ARR(fz_pend) BT_ARR(fz_lazy_ptr) BT_ARR(fz_lazy) BT_ARR(fz_yurg) BT_ARR(fz_meta) BT_ARR(fz_pmeta) BT_ARR(bs_sync) BT_ARR(fz_rowinfo) BT_ARR(fz_pfirst) BT_ARR(fz_psecond) BT_ARR(upd_rec) BT_ARR(act_bits) BT_ARR(act_rank) BT_ARR(tile_ij) BT_ARR(tile_kx) BT_ARR(lvl_meta)
+    BT_ARR(fz_pend_ptr) BT_ARR(fz_pend) BT_ARR(fz_lazy_ptr) BT_ARR(fz_lazy) BT_ARR(fz_yurg) BT_ARR(fz_meta) BT_ARR(fz_pmeta) BT_ARR(bs_sync) BT_ARR(fz_rowinfo) BT_ARR(fz_pfirst) BT_ARR(fz_psecond) BT_ARR(act_bits) BT_ARR(act_rank) BT_ARR(tile_ij) BT_ARR(tile_kx) BT_ARR(lvl_meta) BT_ARR(slot_code) BT_ARR(tile_la) BT_ARR(tile_rec)
 #undef BT_ARR
     return -1;
 }

@@ -25,121 +25,9 @@
 #include <cstdlib>
 
 #include "ba_kernels.hpp"
+#include "ba_edge.hpp"
 
 namespace bt {
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------ pair geometry
-// 1/sqrt(x) in double from the fp32 hardware seed and two Newton steps (relative error < 1e-15; the IEEE
-// sqrt + divide it replaces is ~60 instructions on the prologue's critical path)
-__device__ __forceinline__ double rsqrt_nr2(double x) {
-    double y = (double)__builtin_amdgcn_rsqf((float)x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y * (1.5 - 0.5 * x * y * y);
-}
-
-__device__ inline void quat_to_rot(const double *q, double R[9]) {
-    const double n = rsqrt_nr2(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
-    const double x = q[0]*n, y = q[1]*n, z = q[2]*n, w = q[3]*n;
-    R[0] = 1 - 2*(y*y + z*z); R[1] = 2*(x*y - z*w);     R[2] = 2*(x*z + y*w);
-    R[3] = 2*(x*y + z*w);     R[4] = 1 - 2*(x*x + z*z); R[5] = 2*(y*z - x*w);
-    R[6] = 2*(x*z - y*w);     R[7] = 2*(y*z + x*w);     R[8] = 1 - 2*(x*x + y*y);
-}
-
-// Relative pose of camera pair (i, j) and the intrinsics the edge maths needs, 20 floats:
-// R_ij (9, row-major), t_ij (3), (1/fx_i, 1/fy_i, cx_i, cy_i), (fx_j, fy_j, cx_j, cy_j).
-// Gij = Gj * Gi^-1 (projective_ops.py:61) in double; a self edge is exactly the identity.
-__device__ inline void pair_geometry(const float *poses, const float *intr, int i, int j, float *g) {
-    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
-    if (i != j) {
-        double qi[4], qj[4], Ri[9], Rj[9], ti[3], tj[3];
-        for (int c = 0; c < 3; ++c) { ti[c] = poses[7*i + c]; tj[c] = poses[7*j + c]; }
-        for (int c = 0; c < 4; ++c) { qi[c] = poses[7*i + 3 + c]; qj[c] = poses[7*j + 3 + c]; }
-        quat_to_rot(qi, Ri); quat_to_rot(qj, Rj);
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c)
-                R[3*r + c] = Rj[3*r]*Ri[3*c] + Rj[3*r + 1]*Ri[3*c + 1] + Rj[3*r + 2]*Ri[3*c + 2];
-        for (int r = 0; r < 3; ++r)
-            t[r] = tj[r] - (R[3*r]*ti[0] + R[3*r + 1]*ti[1] + R[3*r + 2]*ti[2]);
-    }
-    for (int c = 0; c < 9; ++c) g[c] = (float)R[c];
-    for (int c = 0; c < 3; ++c) g[9 + c] = (float)t[c];
-    // source intrinsics as (1/fx, 1/fy, cx, cy): iproj divides (projective_ops.py:25-26)
-    g[12] = 1.0f / intr[4*i]; g[13] = 1.0f / intr[4*i + 1]; g[14] = intr[4*i + 2]; g[15] = intr[4*i + 3];
-    for (int c = 0; c < 4; ++c) g[16 + c] = intr[4*j + c];
-}
-
-// ------------------------------------------------------------------ per-edge math
-struct EdgeQ {
-    float a0, a2, a3, a4, a5;      // Jj row 0 = (a0, 0, a2, a3, a4, a5)
-    float b1, b2, b3, b4, b5;      // Jj row 1 = (0, b1, b2, b3, b4, b5)
-    float jz0, jz1, r0, r1, W0, W1;
-};
-
-__device__ __forceinline__ float robust_weight(float r, int loss) {          // ba.py:81-100
-    const float s = r * r;
-    if (loss == BT_LOSS_HUBER) return s > 1.0f ? 1.0f / sqrtf(s) : 1.0f;
-    if (loss == BT_LOSS_CAUCHY) return 1.0f / (1.0f + s);
-    return 1.0f;
-}
-
-__device__ __forceinline__ void edge_eval(const float *g, float x, float y, float d, float tu, float tv,
-                                          float w0, float w1, const StepArgs &a, EdgeQ &o) {
-    // projective_ops.py:19-29 (iproj), :61-66 (act4), :43-45 (proj)
-    const float X0 = (x - g[14]) * g[12], Y0 = (y - g[15]) * g[13];
-    const float X = fmaf(g[0], X0, fmaf(g[1], Y0, g[2])) + g[9] * d;
-    const float Y = fmaf(g[3], X0, fmaf(g[4], Y0, g[5])) + g[10] * d;
-    const float Z = fmaf(g[6], X0, fmaf(g[7], Y0, g[8])) + g[11] * d;
-    const float fx = g[16], fy = g[17];
-    const float iz = 1.0f / fmaxf(Z, 1e-2f);
-    const float u = fmaf(fx, iz * X, g[18]), v = fmaf(fy, iz * Y, g[19]);
-    // projective_ops.py:80-98
-    const float dj = fabsf(Z) > 0.2f ? 1.0f / Z : 0.0f;
-    const float A = fx * dj, B = -fx * X * dj * dj, C = fy * dj, Dd = -fy * Y * dj * dj;
-    o.a0 = d * A;  o.a2 = d * B;  o.a3 = B * Y;            o.a4 = A * Z - B * X;  o.a5 = -A * Y;
-    o.b1 = d * C;  o.b2 = d * Dd; o.b3 = Dd * Y - C * Z;   o.b4 = -Dd * X;        o.b5 = C * X;
-    o.jz0 = fmaf(A, g[9], B * g[11]);
-    o.jz1 = fmaf(C, g[10], Dd * g[11]);
-    // ba.py:230-251
-    const float r0 = tu - u, r1 = tv - v;
-    float vld = Z > 0.2f ? 1.0f : 0.0f;
-    vld *= sqrtf(r0 * r0 + r1 * r1) < 250.0f ? 1.0f : 0.0f;
-    vld *= (u > a.b0 && v > a.b1 && u < a.b2 && v < a.b3) ? 1.0f : 0.0f;
-    o.W0 = vld * (w0 * robust_weight(r0, a.loss));
-    o.W1 = vld * (w1 * robust_weight(r1, a.loss));
-    o.r0 = vld * r0; o.r1 = vld * r1;
-}
-
-// Sum v[0..31] over the 64 lanes of a wave; afterwards every lane holds, in v[0], the
-// total of element ((lane >> 1) & 31).  Halving exchange: 16 + 8 lane-swap instructions
-// (v_permlane32_swap / v_permlane16_swap move two registers at once) and 7 shuffles,
-// instead of 32 * 6 shuffles for a plain butterfly.
-typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {       // lanes < 32 keep v[i], lanes >= 32 keep v[i+16]
-        const uint2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
-        v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {        // even 16-lane rows keep v[i], odd rows keep v[i+8]
-        const uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
-        v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
-    }
-#define BT_RS_STEP(M, H)                                            \
-    {                                                               \
-        const bool up = (lane & (M)) != 0;                          \
-        _Pragma("unroll") for (int i = 0; i < (H); ++i) {           \
-            const float send = up ? v[i] : v[i + (H)];              \
-            const float keep = up ? v[i + (H)] : v[i];              \
-            v[i] = keep + __shfl_xor(send, (M));                    \
-        }                                                           \
-    }
-    BT_RS_STEP(8, 4) BT_RS_STEP(4, 2) BT_RS_STEP(2, 1)
-#undef BT_RS_STEP
-    v[0] += __shfl_xor(v[0], 1);
-}
 
 // ------------------------------------------------------------------ k_tile
 // One workgroup of 8 waves per tile of <= 64 tracks; lane l of every wave owns track l.
@@ -470,9 +358,6 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         BT_PF(4);
         if (SO) continue;
 
-        // keep E for the depth back-substitution (ba.py:328)
-        for (int row = wave; row < R; row += kTileWaves)
-            a.esave[((size_t)pd.tile_erow0[tile] + row) * kLanes + lane] = Eh[row * kLdsRowStride + lane];
         BT_PF(5);
 
         // Schur product of the tile on the matrix cores: out[i][j] += sum_k Q_k Eh[i][k] Eh[j][k]
@@ -2074,66 +1959,134 @@ __device__ inline void retract_pose(const float *pin, const float *xi, float *po
     for (int c = 0; c < 4; ++c) pout[3 + c] = (float)(qo[c] * nq);
 }
 
+// One BA step's last kernel.  Block ranges (512 threads each):
+//   [0, tile_blocks)         pose+structure steps only: one block per tile of tracks.  The depth update
+//                            dZ_k = Q_k (w'_k - sum_c E[c,k]^T dX_c) (ba.py:328) is evaluated WITHOUT a stored E:
+//                            E[c,k]^T dX_c summed over the cameras of a track is, edge by edge,
+//                            Jz^T W (Jj dX_j + Ji dX_i) = Jz^T W Jj (dX_j - Ad(Gij) dX_i)  (Ji = -Jj Ad, projective_ops.py:96),
+//                            so the block forms delta = dX_j - Ad dX_i once per camera pair of the tile (from the
+//                            pair geometry k_tile left in the workspace) and re-evaluates the edge Jacobians from
+//                            targets / weights: 16 B per edge read again instead of 24 B per edge written and read back.
+//   [.., + patch_blocks)     the whole patch buffer: copy of x, y and the clamp of ba.py:333; structure-only steps
+//                            add dZ = Q w' (ba.py:316-317) here; pose+structure steps skip the patches that carry
+//                            a track (the tile blocks write those).  Followed by one thread per buffer pose:
+//                            Exp(dX) * G in double (groups.py:153-156).
+//   [first_zero_block, ..)   [S | y] has been consumed by the solver: cleared for the next step's accumulation.
+constexpr int kUpdThreads = 512;
+constexpr int kUpdGeo = 28;          // floats per pair in LDS: the 20 of kPairGeomFloats, delta (6), padding to 16 bytes
+
 template <bool SO>
-__global__ __launch_bounds__(256) void k_update(PlanDev pd, StepArgs a, int do_poses, int first_zero_block) {
+__global__ __launch_bounds__(kUpdThreads) void k_update(PlanDev pd, StepArgs a, int do_poses, int tile_blocks, int first_zero_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     if (!SO && (int)blockIdx.x >= first_zero_block) {
-        // [S | y] has been consumed by the solver: leave it clear for the next step's accumulation
         const size_t nz = (size_t)pd.D * pd.D + pd.D;
         const size_t i0 = ((size_t)(blockIdx.x - first_zero_block) * blockDim.x + threadIdx.x) * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (i0 + k < nz) a.S[i0 + k] = 0.0;
         return;
     }
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ float sdx[SO ? 1 : 6 * kMaxFree];
-    const bool patch_block = (int)(blockIdx.x * blockDim.x) < pd.p_tot;
-    if (!SO && patch_block) {                          // the pose update, once per workgroup
-        for (int i = threadIdx.x; i < pd.D; i += blockDim.x) sdx[i] = a.dx[i];
+    if (!SO && (int)blockIdx.x < tile_blocks) {
+        const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+        constexpr int kWaves = kUpdThreads / 64;
+        float *geo = lds;                                           // [npair][kUpdGeo]
+        float *part = lds + (size_t)pd.max_tile_pairs * kUpdGeo;    // [kWaves][64]
+        const int np = pd.tile_npair[tile];
+        const int patch = pd.tile_kx[(size_t)tile * kLanes + lane];
+        const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
+        const int chunk = (nslot + kWaves - 1) / kWaves;
+        const int s0 = wave * chunk, s1 = min(nslot, s0 + chunk);
+        int e_nx = -1, lp_nx = 0;
+        if (s0 < s1) { const size_t idx = (size_t)(slot0 + s0) * kLanes + lane; e_nx = pd.slot_edge[idx]; lp_nx = pd.slot_lp[idx]; }
+        for (int p = tid; p < np; p += kUpdThreads) {
+            const int gp = pd.tile_pairs[pd.tile_pair0[tile] + p];
+            const int ia = pd.pair_i[gp] - pd.fixedp, ib = pd.pair_j[gp] - pd.fixedp;
+            float g[kPairGeomFloats];
+            const float4 *src = reinterpret_cast<const float4 *>(a.pairgeo + (size_t)gp * kPairGeomFloats);
+#pragma unroll
+            for (int c = 0; c < kPairGeomFloats / 4; ++c) { const float4 t4 = src[c]; g[4*c] = t4.x; g[4*c + 1] = t4.y; g[4*c + 2] = t4.z; g[4*c + 3] = t4.w; }
+            float xi[6] = {0, 0, 0, 0, 0, 0}, xj[6] = {0, 0, 0, 0, 0, 0};
+            if (ia >= 0) for (int c = 0; c < 6; ++c) xi[c] = a.dx[6 * ia + c];
+            if (ib >= 0) for (int c = 0; c < 6; ++c) xj[c] = a.dx[6 * ib + c];
+            // Ad(Gij) (tau, phi) = (R tau + t x (R phi), R phi)        (se3.h:58-67)
+            float Rt[3], Rp[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                Rt[r] = g[3*r] * xi[0] + g[3*r + 1] * xi[1] + g[3*r + 2] * xi[2];
+                Rp[r] = g[3*r] * xi[3] + g[3*r + 1] * xi[4] + g[3*r + 2] * xi[5];
+            }
+            float *o = geo + (size_t)p * kUpdGeo;
+#pragma unroll
+            for (int c = 0; c < kPairGeomFloats; ++c) o[c] = g[c];
+            o[20] = xj[0] - (Rt[0] + g[10] * Rp[2] - g[11] * Rp[1]);
+            o[21] = xj[1] - (Rt[1] + g[11] * Rp[0] - g[9]  * Rp[2]);
+            o[22] = xj[2] - (Rt[2] + g[9]  * Rp[1] - g[10] * Rp[0]);
+            o[23] = xj[3] - Rp[0]; o[24] = xj[4] - Rp[1]; o[25] = xj[5] - Rp[2];
+            o[26] = 0.0f; o[27] = 0.0f;
+        }
+        float px = 0.0f, py = 0.0f, pdisp = 0.0f;
+        if (patch >= 0) { px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2]; }
+        float tu_nx = 0.0f, tv_nx = 0.0f, w0_nx = 0.0f, w1_nx = 0.0f;
+        if (e_nx >= 0) {
+            const float *tp = a.targets + (size_t)e_nx * a.tstride;
+            tu_nx = tp[0]; tv_nx = tp[1];
+            const float2 w = reinterpret_cast<const float2 *>(a.weights)[e_nx];
+            w0_nx = w.x; w1_nx = w.y;
+        }
         __syncthreads();
+        float acc = 0.0f;
+#pragma unroll 1
+        for (int s = s0; s < s1; ++s) {
+            const int e = e_nx, lp = lp_nx;
+            const float tu = tu_nx, tv = tv_nx, w0 = w0_nx, w1 = w1_nx;
+            if (s + 1 < s1) {
+                const size_t idn = (size_t)(slot0 + s + 1) * kLanes + lane;
+                e_nx = pd.slot_edge[idn]; lp_nx = pd.slot_lp[idn];
+                tu_nx = tv_nx = w0_nx = w1_nx = 0.0f;
+                if (e_nx >= 0) {
+                    const float *tp = a.targets + (size_t)e_nx * a.tstride;
+                    tu_nx = tp[0]; tv_nx = tp[1];
+                    const float2 w = reinterpret_cast<const float2 *>(a.weights)[e_nx];
+                    w0_nx = w.x; w1_nx = w.y;
+                }
+            }
+            float g[kUpdGeo];
+            {
+                const float4 *g4 = reinterpret_cast<const float4 *>(geo + (size_t)lp * kUpdGeo);
+#pragma unroll
+                for (int c = 0; c < kUpdGeo / 4; ++c) { const float4 t4 = g4[c]; g[4*c] = t4.x; g[4*c + 1] = t4.y; g[4*c + 2] = t4.z; g[4*c + 3] = t4.w; }
+            }
+            EdgeQ q;
+            edge_eval(g, px, py, pdisp, tu, tv, w0, w1, a, q);
+            if (e < 0) continue;
+            const float d0 = q.a0 * g[20] + q.a2 * g[22] + q.a3 * g[23] + q.a4 * g[24] + q.a5 * g[25];
+            const float d1 = q.b1 * g[21] + q.b2 * g[22] + q.b3 * g[23] + q.b4 * g[24] + q.b5 * g[25];
+            acc += q.W0 * q.jz0 * d0 + q.W1 * q.jz1 * d1;
+        }
+        part[wave * 64 + lane] = acc;
+        __syncthreads();
+        if (wave == 0 && patch >= 0) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) tot += part[w * 64 + lane];
+            const float2 qw = a.qw[pd.tile_trk0[tile] + lane];
+            float dd = pdisp + qw.x * (qw.y - tot);                         // ba.py:328, :333
+            dd = dd < 1e-3f ? 1e-3f : dd;
+            dd = dd > 10.0f ? 10.0f : dd;
+            a.patches_out[3*patch] = px; a.patches_out[3*patch + 1] = py; a.patches_out[3*patch + 2] = dd;
+        }
+        return;
     }
+    const int gid = (blockIdx.x - (SO ? 0 : tile_blocks)) * blockDim.x + threadIdx.x;
     if (gid < pd.p_tot) {
-        const float x = a.patches[3*gid], y = a.patches[3*gid + 1], d = a.patches[3*gid + 2];
-        float dz = 0.0f;
         // track of this patch, or -1: bitmap + rank (most of the buffer's patches are not in the window)
         const unsigned aw = pd.act_bits[gid >> 5], ab = (unsigned)gid & 31u;
-        const int k = (aw >> ab) & 1u ? pd.act_rank[gid >> 5] + __popc(aw & ((1u << ab) - 1u)) : -1;
-        if (SO) {
-            if (k >= 0) { const float2 qw = a.qw[k]; dz = qw.x * qw.y; }               // ba.py:316-317
-        } else {
-            if (k >= 0) {
-                // one record per track (ba_plan.cpp: upd_rec): where its E rows start, its cameras
-                const int4 r0 = reinterpret_cast<const int4 *>(pd.upd_rec)[2 * k], r1 = reinterpret_cast<const int4 *>(pd.upd_rec)[2 * k + 1];
-                const float2 qw = a.qw[k];
-                const float *base = a.esave + (size_t)r0.y;
-                float acc = 0.0f;
-                if (!(r0.z & (1 << 30))) {
-                    const int nc = r0.z;
-                    const int cw[4] = {r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) {
-                        if (4 * w4 >= nc) break;
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int c = 4 * w4 + b;
-                            if (c < nc) {
-                                const float *dxc = sdx + 6 * ((cw[w4] >> (8 * b)) & 255);
-#pragma unroll
-                                for (int r = 0; r < 6; ++r) acc = fmaf(base[(size_t)(6 * c + r) * kLanes], dxc[r], acc);
-                            }
-                        }
-                    }
-                } else {                                   // a tile with more than 16 cameras: camera list in the tile arrays
-                    const int loc = pd.trk_loc[k], tile = loc >> 6;
-                    const int nc = pd.tile_ncam[tile];
-                    const int *cams = pd.tile_cams + pd.tile_cam0[tile];
-                    for (int c = 0; c < nc; ++c) {
-                        const float *dxc = sdx + 6 * cams[c];
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) acc = fmaf(base[(size_t)(6 * c + r) * kLanes], dxc[r], acc);
-                    }
-                }
-                dz = qw.x * (qw.y - acc);                               // ba.py:328
-            }
+        const bool has = (aw >> ab) & 1u;
+        if (!SO && has) return;                                         // written by its tile's block
+        const float x = a.patches[3*gid], y = a.patches[3*gid + 1], d = a.patches[3*gid + 2];
+        float dz = 0.0f;
+        if (SO && has) {
+            const float2 qw = a.qw[pd.act_rank[gid >> 5] + __popc(aw & ((1u << ab) - 1u))];
+            dz = qw.x * qw.y;                                           // ba.py:316-317
         }
         float dd = d + dz;                                              // ba.py:333 (whole buffer)
         dd = dd < 1e-3f ? 1e-3f : dd;
@@ -2273,7 +2226,11 @@ int configure_kernels(const PlanDev &pd) {
 
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev, unsigned *ran) {
     (void)zero_doubles;   // the accumulators are cleared by their consumers (k_pair_finalize, k_update)
-    if (pd.T > 0) {
+    if (pd.T > 0 && stream_applies(pd)) {
+        if (ran) *ran |= 1u << 1;
+        const int rc = launch_stream(pd, a, so ? 1 : 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+        if (rc != BT_OK) return rc;
+    } else if (pd.T > 0) {
         // persistent workgroups once there are more tiles than ~4 per CU: a workgroup then walks a
         // contiguous range of tiles and keeps its accumulators across tiles with the same cameras
         static const int max_wgs = std::getenv("BT_TILE_MAX_WGS") ? std::atoi(std::getenv("BT_TILE_MAX_WGS")) : 1024;   // measurement only
@@ -2318,11 +2275,18 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
     }
     const int do_poses = so ? (copy_poses ? 1 : 0) : 1;
     const int total = pd.p_tot + (do_poses ? pd.n_buf : 0);
-    const int nb = (total + 255) / 256;
+    const int nb = (total + kUpdThreads - 1) / kUpdThreads;
     const size_t nz = (size_t)pd.D * pd.D + pd.D;
-    const int zb = (int)((nz + 1023) / 1024);
-    if (so) BT_LAUNCH(4, k_update<true>, dim3(nb), dim3(256), 0, pd, a, do_poses, nb);
-    else    BT_LAUNCH(4, k_update<false>, dim3(nb + zb), dim3(256), 0, pd, a, do_poses, nb);
+    const int zb = (int)((nz + 4 * kUpdThreads - 1) / (4 * kUpdThreads));
+    const size_t upd_lds = ((size_t)pd.max_tile_pairs * kUpdGeo + kUpdThreads) * sizeof(float);
+    if (so) BT_LAUNCH(4, k_update<true>, dim3(nb), dim3(kUpdThreads), 0, pd, a, do_poses, 0, nb);
+    else if (pd.T > 0 && stream_applies(pd)) {
+        // the tracks' depths by the wave-per-tile walk (its duration is not in the event pair of kernel 4), then the rest
+        const int rc = launch_stream(pd, a, 2, st, nullptr, nullptr);
+        if (rc != BT_OK) return rc;
+        BT_LAUNCH(4, k_update<false>, dim3(nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, 0, nb);
+    }
+    else    BT_LAUNCH(4, k_update<false>, dim3(pd.T + nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, pd.T, pd.T + nb);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 #undef BT_LAUNCH

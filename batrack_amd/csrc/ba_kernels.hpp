@@ -16,13 +16,17 @@ struct StepArgs {
     double *S, *y, *pairacc;      // S, y, pairacc are contiguous (cleared together)
     double *packed;               // the non-zero blocks of [S | y] in factor order (multi-GPU exchange buffer)
     float2 *qw;
-    float *esave, *lfac, *linv, *zvec, *dx;
+    float *lfac, *linv, *zvec, *dx;
     float *pairgeo;               // [pairs][kPairGeomFloats]: relative pose of every camera pair, left by k_tile for k_pair_finalize
     int *status;
     int dbg;                      // env BT_DEBUG_MODE, 0 in production: 16 / 32 launch the cycle-counting variants of the solver / k_tile
 };
 
 int configure_kernels(const PlanDev &pd);
+// wave-per-tile streaming kernels (ba_stream.hip) for graphs of many tiles; mode 0 = pose+structure, 1 = structure-only,
+// 2 = depth back-substitution
+bool stream_applies(const PlanDev &pd);
+int launch_stream(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 // ev != nullptr: a (start, stop) event pair per kernel; *ran gets bit k set for every kernel k that was launched
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
 // dense [S | y] <-> its non-zero blocks in factor order (bt_ba_pack / bt_ba_unpack)

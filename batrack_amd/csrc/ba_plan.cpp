@@ -37,7 +37,6 @@ static void layout_workspace(bt_plan *pl) {
     w.packed = off;   off = align_up(off + ((size_t)I.nnz_blocks * 36 + D) * sizeof(double), 256);   // exchange form of [S | y]
     w.pairgeo = off;  off = align_up(off + (size_t)I.pairs * kPairGeomFloats * sizeof(float), 256);          // k_tile -> k_pair_finalize
     w.qw = off;       off = align_up(off + (size_t)I.m * 2 * sizeof(float), 256);
-    w.esave = off;    off = align_up(off + (size_t)I.erows * kLanes * sizeof(float), 256);
     w.lfac = off;     off = align_up(off + (size_t)I.nnz_blocks * 36 * sizeof(float), 256);
     w.linv = off;     off = align_up(off + (size_t)I.n * 36 * sizeof(float), 256);
     w.zvec = off;     off = align_up(off + D * sizeof(float), 256);
@@ -640,14 +639,37 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         if (n_buf >= 65536) return BT_EUNSUPPORTED;
     }
 
+    // ---- compact tables of the wave-per-tile kernels (k_stream): per (slot, lane) a 16-bit code
+    // (local target camera | local pair << 8; the global pair id is tile_pairs[pair0 + local pair]); per (tile,
+    // lane) the local source camera (one per track: ii = ix[kk], checked above); per tile one 32-byte record
+    //   [0] ntrk | ncam << 8 | npair << 16 | flags << 24   [1] slot0  [2] nslot  [3] cam0  [4] pair0  [5] trk0
+    {
+        pl->slot_code.assign((size_t)slots * kLanes, 0xffff);
+        pl->tile_la.assign((size_t)I.tiles * kLanes, 0xff);
+        pl->tile_rec.assign((size_t)I.tiles * 8, 0);
+        for (int64_t t = 0; t < I.tiles; ++t) {
+            const size_t b0 = (size_t)pl->tile_slot0[(size_t)t] * kLanes;
+            const int32_t ns = pl->tile_nslot[(size_t)t];
+            for (int32_t sl = 0; sl < ns; ++sl)
+                for (int ln = 0; ln < kLanes; ++ln) {
+                    const size_t i = b0 + (size_t)sl * kLanes + (size_t)ln;
+                    if (pl->slot_edge[i] < 0) continue;
+                    pl->slot_code[i] = (uint16_t)((pl->slot_lab[i] >> 8) | ((uint16_t)pl->slot_lp[i] << 8));
+                    pl->tile_la[(size_t)t * kLanes + (size_t)ln] = (uint8_t)(pl->slot_lab[i] & 0xff);
+                }
+            int32_t *r = pl->tile_rec.data() + (size_t)t * 8;
+            r[0] = pl->tile_ntrk[(size_t)t] | (pl->tile_ncam[(size_t)t] << 8) | (pl->tile_npair[(size_t)t] << 16) | (pl->tile_flags[(size_t)t] << 24);
+            r[1] = pl->tile_slot0[(size_t)t]; r[2] = ns; r[3] = pl->tile_cam0[(size_t)t];
+            r[4] = pl->tile_pair0[(size_t)t]; r[5] = pl->tile_trk0[(size_t)t];
+        }
+    }
+
     BT_TICK("14");
     pl->max_tile_slots = 0;
     for (int64_t t = 0; t < I.tiles; ++t) pl->max_tile_slots = std::max(pl->max_tile_slots, (int)pl->tile_nslot[(size_t)t]);
 
     // ---- k_update: which patches carry a track (bitmap + rank per 32 patches: the patch buffer is BUFFER_SIZE x M
-    // = 262,144 slots in the reference's configuration, the window's tracks a few thousand), and per TRACK
-    // everything its depth back-substitution needs in one 32-byte record:
-    // [track, first E row * 64 + lane, #cameras (bit 30: more than 16, use the tile arrays), 0, 16 camera bytes]
+    // = 262,144 slots in the reference's configuration, the window's tracks a few thousand)
     const size_t nwords = (size_t)((p_tot + 31) / 32);
     pl->act_bits.assign(nwords, 0u);
     pl->act_rank.assign(nwords, 0);
@@ -655,18 +677,6 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     {
         int32_t run = 0;
         for (size_t w = 0; w < nwords; ++w) { pl->act_rank[w] = run; run += __builtin_popcount(pl->act_bits[w]); }
-    }
-    pl->upd_rec.assign((size_t)I.m * 8, 0);
-    for (int32_t k = 0; k < I.m; ++k) {
-        int32_t *r = pl->upd_rec.data() + (size_t)k * 8;
-        r[0] = k;
-        const int32_t loc = pl->trk_loc[(size_t)k], tile = loc >> 6, ln = loc & 63;
-        const int32_t nc = pl->tile_ncam[(size_t)tile], c0 = pl->tile_cam0[(size_t)tile];
-        r[1] = pl->tile_erow0[(size_t)tile] * kLanes + ln;
-        r[2] = nc > 16 ? (nc | (1 << 30)) : nc;
-        if (nc <= 16)
-            for (int32_t c = 0; c < nc; ++c)
-                r[4 + c / 4] |= (pl->tile_cams[(size_t)(c0 + c)] & 255) << (8 * (c % 4));
     }
 
     BT_TICK("end");

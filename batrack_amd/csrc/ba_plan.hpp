@@ -23,7 +23,7 @@ constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geom
 // Device-side view: raw pointers into one device allocation + sizes.
 struct PlanDev {
     int E, n_buf, p_tot, fixedp, n_all, n, D, m, P, T, slots, erows, nnzb, nupd, max_rows16;
-    const int32_t *kx, *trk_loc, *upd_rec;                   // upd_rec: 8 ints per TRACK
+    const int32_t *kx;
     const uint32_t *act_bits;                                // bit p: patch p has a track; [ceil(p_tot / 32)]
     const int32_t *act_rank;                                 // tracks before the word's first patch: track(p) = act_rank[p>>5] + popc(bits below p)
     const int32_t *pair_i, *pair_j;
@@ -35,7 +35,10 @@ struct PlanDev {
     const int32_t *tile_ij, *tile_kx;                        // per tile: cameras of its pairs [max_tile_pairs], patch of its tracks [64]
     const int32_t *tile_flags;                               // bit 0: same cameras as the previous tile, bit 1: same pair list
     const uint8_t *slot_lp;                                  // local pair index of a (slot, lane) within its tile
-    int max_tile_pairs, max_tile_slots;
+    int max_tile_pairs, max_tile_slots, max_cams;
+    const uint16_t *slot_code;                               // (slot, lane): local target camera | local pair << 8
+    const uint8_t *tile_la;                                  // (tile, lane): local source camera of the lane's track (0xff: fixed)
+    const int32_t *tile_rec;                                 // 8 ints per tile (ba_plan.cpp)
     const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
     // elimination order and level schedule of the reduced solver
     int nlev, ndp;
@@ -50,14 +53,14 @@ struct PlanDev {
 // Byte offsets of the regions inside the caller's workspace.
 struct WsLayout {
     size_t sys, pairacc, zero_bytes;   // [sys, sys+zero_bytes) is cleared every reduce
-    size_t packed, pairgeo, qw, esave, lfac, linv, zvec, dx, status, total;
+    size_t packed, pairgeo, qw, lfac, linv, zvec, dx, status, total;
 };
 
 }  // namespace bt
 
 struct bt_plan {
     bt_plan_info info{};
-    std::vector<int32_t> kx, trk_of_patch, trk_loc, upd_rec, act_rank;      // trk_of_patch: host only
+    std::vector<int32_t> kx, trk_of_patch, trk_loc, act_rank;      // trk_of_patch, trk_loc: host only
     std::vector<uint32_t> act_bits;
     std::vector<char> stage;     // upload staging (kept with the object: ba_api.cpp)
     std::vector<int32_t> pair_i, pair_j;
@@ -66,7 +69,9 @@ struct bt_plan {
     std::vector<int32_t> slot_edge, slot_pair;
     std::vector<uint16_t> slot_lab;
     std::vector<int32_t> tile_pair0, tile_npair, tile_pairs, tile_flags, tile_ij, tile_kx;
-    std::vector<uint8_t> slot_lp;
+    std::vector<uint8_t> slot_lp, tile_la;
+    std::vector<uint16_t> slot_code;
+    std::vector<int32_t> tile_rec;
     int max_tile_pairs = 0, max_tile_slots = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
     std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp, lvl_meta;
@@ -82,14 +87,14 @@ struct bt_plan {
     // by bt_plan_create (ba_api.cpp), so that a plan per frame costs no heap traffic.
     void recycle() {
         info = bt_plan_info{};
-        for (auto *v : {&kx, &trk_of_patch, &trk_loc, &upd_rec, &pair_i, &pair_j, &tile_trk0, &tile_ntrk, &tile_ncam,
+        for (auto *v : {&kx, &trk_of_patch, &trk_loc, &pair_i, &pair_j, &tile_trk0, &tile_ntrk, &tile_ncam,
                         &tile_cam0, &tile_slot0, &tile_nslot, &tile_erow0, &tile_cams, &slot_edge, &slot_pair,
                         &tile_pair0, &tile_npair, &tile_pairs, &tile_flags, &tile_ij, &tile_kx, &col_ptr, &row_idx,
                         &upd_ptr, &upd, &blk_col, &upd_next, &perm, &blk_src, &lvl_ptr, &lvl_cols, &col_lvl, &dp_ptr,
                         &dp, &lvl_meta, &fz_pend_ptr, &fz_pend, &fz_lazy_ptr, &fz_lazy, &fz_yurg, &fz_meta, &fz_pmeta,
                         &bs_sync, &fz_rowinfo, &fz_pfirst, &fz_psecond})
             v->clear();
-        slot_lab.clear(); slot_lp.clear(); act_bits.clear(); act_rank.clear(); stage.clear();
+        slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;
         fz_ok = fzp_ok = 0;
         max_rows16 = 16;
