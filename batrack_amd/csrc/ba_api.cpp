@@ -187,7 +187,7 @@ int upload_plan(bt_plan *pl) {
     P.fz_yurg = BT_I32(o_fy); P.fz_meta = BT_I32(o_fm); P.fz_pmeta = BT_I32(o_fpm); P.bs_sync = BT_I32(o_bss); P.fz_rowinfo = BT_I32(o_fri); P.fz_pfirst = BT_I32(o_fpf); P.fz_psecond = BT_I32(o_fps); P.tile_ij = BT_I32(o_tij); P.tile_kx = BT_I32(o_tkx);
     P.fz_npend = (int)(pl->fz_pend.size() / 2); P.fz_nlazy = (int)(pl->fz_lazy.size() / 3); P.fz_ok = pl->fz_ok; P.fzp_ok = pl->fzp_ok;
     P.tile_pair0 = BT_I32(o_tp0); P.tile_npair = BT_I32(o_tnp); P.tile_pairs = BT_I32(o_tps);
-    P.slot_lp = reinterpret_cast<const uint8_t *>(b + o_slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams;
+    P.slot_lp = reinterpret_cast<const uint8_t *>(b + o_slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams; P.e_all = pl->e_all;
     P.slot_code = reinterpret_cast<const uint16_t *>(b + o_sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + o_tla); P.tile_rec = BT_I32(o_trec);
 #undef BT_I32
     const int rc = configure_kernels(P);

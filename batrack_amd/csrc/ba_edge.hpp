@@ -58,10 +58,15 @@ struct EdgeQ {
     float jz0, jz1, r0, r1, W0, W1;
 };
 
+// Reciprocal and reciprocal square root on the hardware approximations (v_rcp_f32 / v_rsq_f32, 1 ulp) instead of
+// the IEEE-exact sequences (~10 instructions each, five of them per edge): an ulp here is the same size as the
+// float32 rounding of every other operation of the edge maths.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 __device__ __forceinline__ float robust_weight(float r, int loss) {          // ba.py:81-100
     const float s = r * r;
-    if (loss == BT_LOSS_HUBER) return s > 1.0f ? 1.0f / sqrtf(s) : 1.0f;
-    if (loss == BT_LOSS_CAUCHY) return 1.0f / (1.0f + s);
+    if (loss == BT_LOSS_HUBER) return s > 1.0f ? __builtin_amdgcn_rsqf(s) : 1.0f;
+    if (loss == BT_LOSS_CAUCHY) return frcp(1.0f + s);
     return 1.0f;
 }
 
@@ -73,10 +78,10 @@ __device__ __forceinline__ void edge_eval(const float *g, float x, float y, floa
     const float Y = fmaf(g[3], X0, fmaf(g[4], Y0, g[5])) + g[10] * d;
     const float Z = fmaf(g[6], X0, fmaf(g[7], Y0, g[8])) + g[11] * d;
     const float fx = g[16], fy = g[17];
-    const float iz = 1.0f / fmaxf(Z, 1e-2f);
+    const float iz = frcp(fmaxf(Z, 1e-2f));
     const float u = fmaf(fx, iz * X, g[18]), v = fmaf(fy, iz * Y, g[19]);
     // projective_ops.py:80-98
-    const float dj = fabsf(Z) > 0.2f ? 1.0f / Z : 0.0f;
+    const float dj = fabsf(Z) > 0.2f ? frcp(Z) : 0.0f;
     const float A = fx * dj, B = -fx * X * dj * dj, C = fy * dj, Dd = -fy * Y * dj * dj;
     o.a0 = d * A;  o.a2 = d * B;  o.a3 = B * Y;            o.a4 = A * Z - B * X;  o.a5 = -A * Y;
     o.b1 = d * C;  o.b2 = d * Dd; o.b3 = Dd * Y - C * Z;   o.b4 = -Dd * X;        o.b5 = C * X;
@@ -85,7 +90,7 @@ __device__ __forceinline__ void edge_eval(const float *g, float x, float y, floa
     // ba.py:230-251
     const float r0 = tu - u, r1 = tv - v;
     float vld = Z > 0.2f ? 1.0f : 0.0f;
-    vld *= sqrtf(r0 * r0 + r1 * r1) < 250.0f ? 1.0f : 0.0f;
+    vld *= r0 * r0 + r1 * r1 < 62500.0f ? 1.0f : 0.0f;        // |r| < 250 (ba.py:233), compared squared
     vld *= (u > a.b0 && v > a.b1 && u < a.b2 && v < a.b3) ? 1.0f : 0.0f;
     o.W0 = vld * (w0 * robust_weight(r0, a.loss));
     o.W1 = vld * (w1 * robust_weight(r1, a.loss));
@@ -108,18 +113,25 @@ __device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) 
         const uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
         v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
     }
-#define BT_RS_STEP(M, H)                                            \
+    // the last four halvings stay inside a row of 16 lanes: DPP operands of the adds (full VALU rate, no LDS
+    // round trip as a ds_bpermute shuffle would cost):  lane ^ 8 = row_ror:8,  lane ^ 4 = row_shl:4 on the banks
+    // with bit 2 clear + row_shr:4 on the others,  lane ^ 2 / lane ^ 1 = quad_perm
+#define BT_DPP(x, ctrl, bank, old) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(x), (ctrl), 0xf, (bank), false))
+#define BT_RS_STEP(M, H, XCH)                                       \
     {                                                               \
         const bool up = (lane & (M)) != 0;                          \
         _Pragma("unroll") for (int i = 0; i < (H); ++i) {           \
             const float send = up ? v[i] : v[i + (H)];              \
             const float keep = up ? v[i + (H)] : v[i];              \
-            v[i] = keep + __shfl_xor(send, (M));                    \
+            v[i] = keep + (XCH);                                    \
         }                                                           \
     }
-    BT_RS_STEP(8, 4) BT_RS_STEP(4, 2) BT_RS_STEP(2, 1)
+    BT_RS_STEP(8, 4, BT_DPP(send, 0x128, 0xf, send))
+    BT_RS_STEP(4, 2, BT_DPP(send, 0x114, 0xa, BT_DPP(send, 0x104, 0x5, send)))
+    BT_RS_STEP(2, 1, BT_DPP(send, 0x4e, 0xf, send))
 #undef BT_RS_STEP
-    v[0] += __shfl_xor(v[0], 1);
+    v[0] += BT_DPP(v[0], 0xb1, 0xf, v[0]);
+#undef BT_DPP
 }
 
 }  // namespace bt

@@ -55,6 +55,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     bt_plan_info &I = pl->info;
     I = bt_plan_info{};
     I.n_buf = n_buf; I.p_tot = p_tot; I.fixedp = fixedp;
+    pl->e_all = E;
     if (own_hi <= 0) { own_lo = 0; own_hi = p_tot; }
     if (own_lo < 0 || own_hi > p_tot || own_lo > own_hi) return BT_EINVAL;
     auto owned = [&](int64_t e) { return kk[e] >= own_lo && kk[e] < own_hi; };
@@ -657,8 +658,18 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
                     pl->slot_code[i] = (uint16_t)((pl->slot_lab[i] >> 8) | ((uint16_t)pl->slot_lp[i] << 8));
                     pl->tile_la[(size_t)t * kLanes + (size_t)ln] = (uint8_t)(pl->slot_lab[i] & 0xff);
                 }
+            // flag bit 2: some track repeats a target camera across the boundary of the two half-chunks of slots the
+            // streaming kernel gives its two waves (both then add to the same element of the local E)
+            int32_t straddle = 0;
+            const int32_t ch = (ns + 1) >> 1;
+            if (ch < ns)
+                for (int ln = 0; ln < kLanes && !straddle; ++ln) {
+                    const size_t i0 = b0 + (size_t)(ch - 1) * kLanes + (size_t)ln, i1 = i0 + kLanes;
+                    if (pl->slot_edge[i0] >= 0 && pl->slot_edge[i1] >= 0 && (pl->slot_lab[i0] >> 8) != 0xff &&
+                        (pl->slot_lab[i0] >> 8) == (pl->slot_lab[i1] >> 8)) straddle = 4;
+                }
             int32_t *r = pl->tile_rec.data() + (size_t)t * 8;
-            r[0] = pl->tile_ntrk[(size_t)t] | (pl->tile_ncam[(size_t)t] << 8) | (pl->tile_npair[(size_t)t] << 16) | (pl->tile_flags[(size_t)t] << 24);
+            r[0] = pl->tile_ntrk[(size_t)t] | (pl->tile_ncam[(size_t)t] << 8) | (pl->tile_npair[(size_t)t] << 16) | ((pl->tile_flags[(size_t)t] | straddle) << 24);
             r[1] = pl->tile_slot0[(size_t)t]; r[2] = ns; r[3] = pl->tile_cam0[(size_t)t];
             r[4] = pl->tile_pair0[(size_t)t]; r[5] = pl->tile_trk0[(size_t)t];
         }

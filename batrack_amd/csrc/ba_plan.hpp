@@ -36,6 +36,7 @@ struct PlanDev {
     const int32_t *tile_flags;                               // bit 0: same cameras as the previous tile, bit 1: same pair list
     const uint8_t *slot_lp;                                  // local pair index of a (slot, lane) within its tile
     int max_tile_pairs, max_tile_slots, max_cams;
+    long long e_all;                                         // length of the caller's edge list (slot_edge indexes it)
     const uint16_t *slot_code;                               // (slot, lane): local target camera | local pair << 8
     const uint8_t *tile_la;                                  // (tile, lane): local source camera of the lane's track (0xff: fixed)
     const int32_t *tile_rec;                                 // 8 ints per tile (ba_plan.cpp)
@@ -78,6 +79,7 @@ struct bt_plan {
     std::vector<int32_t> fz_pend_ptr, fz_pend, fz_lazy_ptr, fz_lazy, fz_yurg, fz_meta, fz_pmeta, bs_sync, fz_rowinfo, fz_pfirst, fz_psecond;   // fused schedule (k_solve_fused)
     int fz_ok = 0, fzp_ok = 0;
     int max_rows16 = 16;
+    long long e_all = 0;
     bt::WsLayout ws{};
     void *dev_base = nullptr;   // one device allocation holding every array above (from the pool in ba_api.cpp)
     size_t dev_cap = 0;
