@@ -8,11 +8,12 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(_HERE, "lib", "libbatrack_ba.so")   # BT_LIB_PATH: measurement builds only
-SOURCES = ["ba_kernels.hip", "ba_stream.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip"]
+SOURCES = ["ba_kernels.hip", "ba_stream.hip", "ba_stream3.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip"]
 HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", "ba_edge.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
            os.path.join("..", "..", "include", "batrack_se3.h"), os.path.join("..", "..", "include", "batrack_patchify.h"),
            os.path.join("..", "..", "include", "batrack_projective.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+# -fno-slp-vectorize: packed f32 pairs cost more register moves than the packed instructions save (measured on k_edge)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
 
 BT_OK, BT_EINVAL, BT_ENOMEM, BT_EHIP, BT_EUNSUPPORTED = 0, -1, -2, -3, -4
 ERRORS = {BT_EINVAL: "invalid argument", BT_ENOMEM: "out of memory", BT_EHIP: "HIP runtime error",

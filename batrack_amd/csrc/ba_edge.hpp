@@ -113,24 +113,24 @@ __device__ __forceinline__ void wave_reduce_scatter32(float (&v)[32], int lane) 
         const uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
         v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
     }
-    // the last four halvings stay inside a row of 16 lanes: DPP operands of the adds (full VALU rate, no LDS
-    // round trip as a ds_bpermute shuffle would cost):  lane ^ 8 = row_ror:8,  lane ^ 4 = row_shl:4 on the banks
-    // with bit 2 clear + row_shr:4 on the others,  lane ^ 2 / lane ^ 1 = quad_perm
-#define BT_DPP(x, ctrl, bank, old) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(x), (ctrl), 0xf, (bank), false))
-#define BT_RS_STEP(M, H, XCH)                                       \
+    // the last four halvings stay inside a row of 16 lanes: DPP operands of the adds (v_add_f32_dpp: full VALU rate, no
+    // LDS round trip as a ds_bpermute shuffle would cost).  The partner of a step only has to differ in the step's lane
+    // bit and agree in the higher ones: row_ror:8 (lane ^ 8), row_half_mirror (lane ^ 7), quad_perm (lane ^ 2, lane ^ 1).
+#define BT_DPP(x, ctrl) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), (ctrl), 0xf, 0xf, true))
+#define BT_RS_STEP(M, H, CTRL)                                      \
     {                                                               \
         const bool up = (lane & (M)) != 0;                          \
         _Pragma("unroll") for (int i = 0; i < (H); ++i) {           \
             const float send = up ? v[i] : v[i + (H)];              \
             const float keep = up ? v[i + (H)] : v[i];              \
-            v[i] = keep + (XCH);                                    \
+            v[i] = keep + BT_DPP(send, CTRL);                       \
         }                                                           \
     }
-    BT_RS_STEP(8, 4, BT_DPP(send, 0x128, 0xf, send))
-    BT_RS_STEP(4, 2, BT_DPP(send, 0x114, 0xa, BT_DPP(send, 0x104, 0x5, send)))
-    BT_RS_STEP(2, 1, BT_DPP(send, 0x4e, 0xf, send))
+    BT_RS_STEP(8, 4, 0x128)
+    BT_RS_STEP(4, 2, 0x141)
+    BT_RS_STEP(2, 1, 0x4e)
 #undef BT_RS_STEP
-    v[0] += BT_DPP(v[0], 0xb1, 0xf, v[0]);
+    v[0] += BT_DPP(v[0], 0xb1);
 #undef BT_DPP
 }
 

@@ -2226,7 +2226,11 @@ int configure_kernels(const PlanDev &pd) {
 
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev, unsigned *ran) {
     (void)zero_doubles;   // the accumulators are cleared by their consumers (k_pair_finalize, k_update)
-    if (pd.T > 0 && stream_applies(pd)) {
+    if (pd.T > 0 && edge_applies(pd)) {
+        if (ran) *ran |= 1u << 1;
+        const int rc = launch_edge(pd, a, so ? 1 : 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+        if (rc != BT_OK) return rc;
+    } else if (pd.T > 0 && stream_applies(pd)) {
         if (ran) *ran |= 1u << 1;
         const int rc = launch_stream(pd, a, so ? 1 : 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
         if (rc != BT_OK) return rc;
@@ -2280,6 +2284,11 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
     const int zb = (int)((nz + 4 * kUpdThreads - 1) / (4 * kUpdThreads));
     const size_t upd_lds = ((size_t)pd.max_tile_pairs * kUpdGeo + kUpdThreads) * sizeof(float);
     if (so) BT_LAUNCH(4, k_update<true>, dim3(nb), dim3(kUpdThreads), 0, pd, a, do_poses, 0, nb);
+    else if (pd.T > 0 && edge_applies(pd)) {
+        const int rc = launch_edge(pd, a, 2, st, nullptr, nullptr);
+        if (rc != BT_OK) return rc;
+        BT_LAUNCH(4, k_update<false>, dim3(nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, 0, nb);
+    }
     else if (pd.T > 0 && stream_applies(pd)) {
         // the tracks' depths by the wave-per-tile walk (its duration is not in the event pair of kernel 4), then the rest
         const int rc = launch_stream(pd, a, 2, st, nullptr, nullptr);

@@ -27,6 +27,9 @@ int configure_kernels(const PlanDev &pd);
 // 2 = depth back-substitution
 bool stream_applies(const PlanDev &pd);
 int launch_stream(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+// the same for slot-uniform graphs in the edge-major layout (ba_stream3.hip)
+bool edge_applies(const PlanDev &pd);
+int launch_edge(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 // ev != nullptr: a (start, stop) event pair per kernel; *ran gets bit k set for every kernel k that was launched
 int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
 // dense [S | y] <-> its non-zero blocks in factor order (bt_ba_pack / bt_ba_unpack)

@@ -675,6 +675,71 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         }
     }
 
+    // ---- edge-major layout of the same tiles (k_edge, ba_stream3.hip): the slots of a track padded to S = the next
+    // power of two, an ITERATION = 64 lanes = 64 / S consecutive tracks x S slots (lane = track_in_iteration * S + slot),
+    // so that on the caller's track-major edge lists a wave reads 64 consecutive edges, a track's sums are reductions over
+    // S adjacent lanes, and a lane meets the same camera pair in every iteration of a tile (per-lane pair sums, no
+    // wave-wide reduction per slot).  Usable when every tile is SLOT-UNIFORM: all tracks of the tile have the same pair
+    // (or no edge) in slot s.
+    //   it_edge[(it0 + i) * 64 + lane]   edge of (tile, iteration i, lane), -1 = none
+    //   tile_sinfo[t * 64 + s]           local target camera | local pair << 8 | repeat << 16 | used << 17   (s < S)
+    //                                    repeat: this slot or a neighbour holds the same pair again (repeated observation)
+    //   tile_rec[6] = it0, tile_rec[7] = log2 S | iterations << 8
+    {
+        pl->em_ok = 1;
+        int64_t its = 0;
+        std::vector<int32_t> it0((size_t)I.tiles), lgS((size_t)I.tiles), nit((size_t)I.tiles);
+        for (int64_t t = 0; t < I.tiles; ++t) {
+            const int32_t ns = pl->tile_nslot[(size_t)t], nt = pl->tile_ntrk[(size_t)t];
+            int lg = 0;
+            while ((1 << lg) < ns) ++lg;
+            if (lg > 6) { pl->em_ok = 0; break; }
+            const int32_t G = kLanes >> lg;
+            it0[(size_t)t] = (int32_t)its; lgS[(size_t)t] = lg; nit[(size_t)t] = (nt + G - 1) / G;
+            its += nit[(size_t)t];
+        }
+        pl->tile_sinfo.assign(pl->em_ok ? (size_t)I.tiles * kLanes : 0, 0);
+        for (int64_t t = 0; t < I.tiles && pl->em_ok; ++t) {
+            const size_t b0 = (size_t)pl->tile_slot0[(size_t)t] * kLanes;
+            const int32_t ns = pl->tile_nslot[(size_t)t], nt = pl->tile_ntrk[(size_t)t];
+            for (int32_t sl = 0; sl < ns && pl->em_ok; ++sl) {
+                int32_t code = -1;
+                for (int ln = 0; ln < nt; ++ln) {
+                    const size_t i = b0 + (size_t)sl * kLanes + (size_t)ln;
+                    if (pl->slot_edge[i] < 0) continue;
+                    const int32_t c = (int32_t)pl->slot_code[i];
+                    if (code < 0) code = c; else if (code != c) { pl->em_ok = 0; break; }
+                }
+                if (code >= 0) pl->tile_sinfo[(size_t)t * kLanes + (size_t)sl] = (uint32_t)code | (1u << 17);
+            }
+            for (int32_t sl = 0; sl + 1 < ns && pl->em_ok; ++sl) {
+                uint32_t &x = pl->tile_sinfo[(size_t)t * kLanes + (size_t)sl], &y = pl->tile_sinfo[(size_t)t * kLanes + (size_t)sl + 1];
+                if ((x >> 17 & 1u) && (y >> 17 & 1u) && ((x >> 8) & 0xffu) == ((y >> 8) & 0xffu)) { x |= 1u << 16; y |= 1u << 16; }
+            }
+        }
+        if (pl->em_ok) {
+            pl->it_edge.assign((size_t)its * kLanes, -1);
+            for (int64_t t = 0; t < I.tiles; ++t) {
+                const size_t b0 = (size_t)pl->tile_slot0[(size_t)t] * kLanes;
+                const int32_t ns = pl->tile_nslot[(size_t)t], nt = pl->tile_ntrk[(size_t)t], lg = lgS[(size_t)t], G = kLanes >> lg;
+                for (int32_t k = 0; k < nt; ++k)
+                    for (int32_t sl = 0; sl < ns; ++sl)
+                        pl->it_edge[((size_t)it0[(size_t)t] + (size_t)(k / G)) * kLanes + (size_t)((k % G) << lg) + (size_t)sl] =
+                            pl->slot_edge[b0 + (size_t)sl * kLanes + (size_t)k];
+                pl->tile_rec[(size_t)t * 8 + 6] = it0[(size_t)t];
+                pl->tile_rec[(size_t)t * 8 + 7] = lg | (nit[(size_t)t] << 8);
+            }
+        } else {
+            pl->it_edge.clear(); pl->tile_sinfo.clear();
+        }
+        pl->em_its = pl->em_ok ? its : 0;
+        pl->em_lgs = -1;
+        if (pl->em_ok && I.tiles > 0) {
+            pl->em_lgs = lgS[0];
+            for (int64_t t = 1; t < I.tiles; ++t) if (lgS[(size_t)t] != pl->em_lgs) { pl->em_lgs = -1; break; }
+        }
+    }
+
     BT_TICK("14");
     pl->max_tile_slots = 0;
     for (int64_t t = 0; t < I.tiles; ++t) pl->max_tile_slots = std::max(pl->max_tile_slots, (int)pl->tile_nslot[(size_t)t]);

@@ -40,6 +40,9 @@ struct PlanDev {
     const uint16_t *slot_code;                               // (slot, lane): local target camera | local pair << 8
     const uint8_t *tile_la;                                  // (tile, lane): local source camera of the lane's track (0xff: fixed)
     const int32_t *tile_rec;                                 // 8 ints per tile (ba_plan.cpp)
+    const int32_t *it_edge;                                  // edge-major layout (ba_plan.cpp): [iterations][64]
+    const uint32_t *tile_sinfo;                              // [tiles][64]
+    int em_ok, em_its, em_lgs;                               // every tile slot-uniform; total iterations; log2 S if the same for all tiles, else -1
     const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
     // elimination order and level schedule of the reduced solver
     int nlev, ndp;
@@ -72,7 +75,10 @@ struct bt_plan {
     std::vector<int32_t> tile_pair0, tile_npair, tile_pairs, tile_flags, tile_ij, tile_kx;
     std::vector<uint8_t> slot_lp, tile_la;
     std::vector<uint16_t> slot_code;
-    std::vector<int32_t> tile_rec;
+    std::vector<int32_t> tile_rec, it_edge;
+    std::vector<uint32_t> tile_sinfo;
+    int em_ok = 0, em_lgs = -1;
+    long long em_its = 0;
     int max_tile_pairs = 0, max_tile_slots = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
     std::vector<int32_t> perm, blk_src, lvl_ptr, lvl_cols, col_lvl, dp_ptr, dp, lvl_meta;
@@ -96,7 +102,7 @@ struct bt_plan {
                         &dp, &lvl_meta, &fz_pend_ptr, &fz_pend, &fz_lazy_ptr, &fz_lazy, &fz_yurg, &fz_meta, &fz_pmeta,
                         &bs_sync, &fz_rowinfo, &fz_pfirst, &fz_psecond})
             v->clear();
-        slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); act_bits.clear(); act_rank.clear(); stage.clear();
+        slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); it_edge.clear(); tile_sinfo.clear(); em_ok = 0; em_its = 0; em_lgs = -1; act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;
         fz_ok = fzp_ok = 0;
         max_rows16 = 16;

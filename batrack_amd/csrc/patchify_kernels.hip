@@ -15,6 +15,8 @@ __device__ __forceinline__ float tap(const float *plane, int i, int j, int H, in
 template <bool BILINEAR>
 __global__ void k_patchify(const float *net, const float *coords, float *out,
                            int64_t total, int C, int H, int W, int M, int R) {
+    // the blend reproduces the reference's float32 products and sums one by one (correlation.py:55-66): no fused multiply-add
+#pragma clang fp contract(off)
     const int d = BILINEAR ? 2 * R + 1 : 2 * R + 2;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < total; n += (int64_t)gridDim.x * blockDim.x) {
         int64_t t = n;
@@ -34,11 +36,10 @@ __global__ void k_patchify(const float *net, const float *coords, float *out,
             const float dx = x - fx, dy = y - fy;
             const float p00 = tap(plane, i, j, H, W), p01 = tap(plane, i, j + 1, H, W);
             const float p10 = tap(plane, i + 1, j, H, W), p11 = tap(plane, i + 1, j + 1, H, W);
-            const float w00 = __fmul_rn(1.0f - dy, 1.0f - dx), w01 = __fmul_rn(1.0f - dy, dx);
-            const float w10 = __fmul_rn(dy, 1.0f - dx), w11 = __fmul_rn(dy, dx);
-            float s = __fadd_rn(__fmul_rn(w00, p00), __fmul_rn(w01, p01));
-            s = __fadd_rn(s, __fmul_rn(w10, p10));
-            out[n] = __fadd_rn(s, __fmul_rn(w11, p11));
+            const float w00 = (1.0f - dy) * (1.0f - dx), w01 = (1.0f - dy) * dx;
+            const float w10 = dy * (1.0f - dx), w11 = dy * dx;
+            const float t00 = w00 * p00, t01 = w01 * p01, t10 = w10 * p10, t11 = w11 * p11;     // (contract(off): products rounded, then summed)
+            out[n] = ((t00 + t01) + t10) + t11;
         }
     }
 }

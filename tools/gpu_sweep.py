@@ -39,8 +39,12 @@ for M in [int(x) for x in (sys.argv[1:] or ["256", "1024", "4096", "16384"])]:
         raw = st.ws.cpu().numpy()
         stat_off = off + ((6 * plan.n * 4 + 64 + 255) // 256) * 256
         pf = np.frombuffer(raw[stat_off + 16 + 160: stat_off + 16 + 320].tobytes(), dtype=np.int64).reshape(2, 10)
-        names = ["tile top", "slots", "finish+stageA", "y", "stageB", "schur", "flush", "drain", "tiles", "-"]
+        names = ["tile top", "iterations", "finish", "y", "schur", "flush", "drain", "-", "tiles", "-"]
         for w, nm in enumerate(("wave 0", "wave mid")):
-            print(f"  k_stream {nm} cycles: " + " ".join(f"{n}={v}" for n, v in zip(names, pf[w])))
+            print(f"  k_edge {nm} cycles: " + " ".join(f"{n}={v}" for n, v in zip(names, pf[w])))
+        pf2 = np.frombuffer(raw[stat_off + 16 + 320: stat_off + 16 + 480].tobytes(), dtype=np.int64).reshape(2, 10)
+        names2 = ["issue loads", "lds operands", "edge_eval", "Ej/Ei", "group_sum", "E stores", "pair fma", "rotate(prev)"]
+        for w, nm in enumerate(("wave 0", "wave mid")):
+            print(f"  k_edge {nm} inside the iterations: " + " ".join(f"{n}={v}" for n, v in zip(names2, pf2[w])))
     del st, plan
     torch.cuda.empty_cache()
