@@ -33,7 +33,12 @@ class BaArgs(ctypes.Structure):
                 ("intrinsics", ctypes.c_void_p), ("targets", ctypes.c_void_p), ("target_stride", ctypes.c_int64),
                 ("weights", ctypes.c_void_p), ("poses_out", ctypes.c_void_p), ("patches_out", ctypes.c_void_p),
                 ("bounds", ctypes.c_float * 4), ("lmbda", ctypes.c_float), ("ep", ctypes.c_float),
-                ("alpha", ctypes.c_float), ("loss", ctypes.c_int32), ("structure_only", ctypes.c_int32)]
+                ("alpha", ctypes.c_float), ("loss", ctypes.c_int32), ("structure_only", ctypes.c_int32),
+                ("mono_stride", ctypes.c_int64)]
+
+
+TORCH_LIB_PATH = os.path.join(_HERE, "lib", "libbatrack_torch.so")
+TORCH_SRC = os.path.join(CSRC, "torch_ops.cpp")
 
 
 def needs_build():
@@ -44,15 +49,51 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU present."""
-    if not force and not needs_build():
-        return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    cmd = ["hipcc"] + HIPCC_FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
+    """hipcc cross-compiles for gfx950 without a GPU present; then the torch.ops registration (host code, g++)."""
+    if force or needs_build():
+        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+        cmd = ["hipcc"] + HIPCC_FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    build_torch_ops(force, verbose)
+    return LIB_PATH
+
+
+def build_torch_ops(force=False, verbose=False):
+    """libbatrack_torch.so: TORCH_LIBRARY(batrack_hip) over the C ABI (csrc/torch_ops.cpp)."""
+    default_lib = os.path.join(_HERE, "lib", "libbatrack_ba.so")
+    if (not force and os.path.exists(TORCH_LIB_PATH) and os.path.getmtime(TORCH_LIB_PATH) >= os.path.getmtime(TORCH_SRC)
+            and os.path.getmtime(TORCH_LIB_PATH) >= os.path.getmtime(os.path.join(_HERE, "..", "include", "batrack_ba.h"))):
+        return TORCH_LIB_PATH
+    import torch
+    ti = os.path.join(os.path.dirname(torch.__file__), "include")
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I" + ti,
+           "-I" + os.path.join(ti, "torch", "csrc", "api", "include"), "-I/opt/rocm/include", TORCH_SRC, "-o", TORCH_LIB_PATH,
+           "-L" + tl, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-L" + os.path.dirname(default_lib), "-lbatrack_ba",
+           "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return TORCH_LIB_PATH
+
+
+_torch_ops = None
+
+
+def torch_ops():
+    """torch.ops.batrack_hip (loads libbatrack_torch.so once).  No fallback: raises if the library is missing."""
+    global _torch_ops
+    if _torch_ops is None:
+        lib()                                           # the C ABI library first: the registration links against it
+        if not os.path.exists(TORCH_LIB_PATH):
+            raise RuntimeError(f"batrack_amd: {TORCH_LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        import torch
+        torch.ops.load_library(TORCH_LIB_PATH)
+        _torch_ops = torch.ops.batrack_hip
+    return _torch_ops
 
 
 _lib = None

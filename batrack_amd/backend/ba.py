@@ -146,7 +146,13 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     dev = P.device
     Pc = P.contiguous()
     pat = _f32c(patches, "patches").reshape(p_tot, 3).contiguous()
-    mono = _f32c(patches_monodisp, "patches_monodisp").reshape(-1).contiguous()
+    mono = _f32c(patches_monodisp, "patches_monodisp")
+    if mono.numel() == p_tot and not mono.is_contiguous() and p_tot > 1:
+        # the caller's prior is a strided view (patches_local[:, :, mid, 2:], batrack.py:866): used in place through mono_stride
+        d = [i for i, n in enumerate(mono.shape) if n == p_tot]
+        mono = torch.as_strided(mono, (p_tot,), (mono.stride(d[0]),), mono.storage_offset()) if len(d) == 1 else mono.reshape(-1).contiguous()
+    else:
+        mono = mono.reshape(-1)
     intr = _f32c(intrinsics, "intrinsics").reshape(-1, 4).contiguous()
     if mono.numel() != p_tot or intr.shape[0] != n_buf:
         raise ValueError("patches_monodisp / intrinsics do not match the patch / pose buffers")

@@ -13,7 +13,7 @@
 
 #include "ba_kernels.hpp"
 
-#define BT_VERSION 100
+#define BT_VERSION 200
 
 namespace bt {
 
@@ -200,7 +200,7 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     const WsLayout &L = pl->ws;
     StepArgs s{};
     s.poses = a->poses; s.patches = a->patches; s.mono = a->mono_disp; s.intr = a->intrinsics;
-    s.targets = a->targets; s.weights = a->weights; s.tstride = (int)a->target_stride;
+    s.targets = a->targets; s.weights = a->weights; s.tstride = (int)a->target_stride; s.mstride = a->mono_stride > 1 ? (int)a->mono_stride : 1;
     s.poses_out = a->poses_out; s.patches_out = a->patches_out;
     s.b0 = a->bounds[0]; s.b1 = a->bounds[1]; s.b2 = a->bounds[2]; s.b3 = a->bounds[3];
     s.lmbda = a->lmbda; s.ep = a->ep; s.alpha = a->alpha; s.loss = a->loss;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         if (has_trk) {
             patch = patch_ld;
             px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2];
-            mono_v = a.mono[patch];                 // needed only after the slot loop: no load latency there
+            mono_v = a.mono[(size_t)patch * a.mstride];                 // needed only after the slot loop: no load latency there
         }
         float tu_nx = 0.0f, tv_nx = 0.0f, w0_nx = 0.0f, w1_nx = 0.0f;
         if (e_nx >= 0) {

@@ -9,7 +9,7 @@ namespace bt {
 // bt_ba_args plus the workspace regions, passed by value to every kernel.
 struct StepArgs {
     const float *poses, *patches, *mono, *intr, *targets, *weights;
-    int tstride;
+    int tstride, mstride;         // floats between consecutive edges' targets / patches' depth priors
     float *poses_out, *patches_out;
     float b0, b1, b2, b3, lmbda, ep, alpha;
     int loss;

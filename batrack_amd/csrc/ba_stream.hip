@@ -226,7 +226,7 @@ __global__ __launch_bounds__(128, MODE == kModeFull ? BT_STREAM_FULL_WAVES : 4) 
     float px = 0.0f, py = 0.0f, pdisp = 0.0f, mono_v = 0.0f;
     if (kx_c >= 0) {
         px = a.patches[3u * (unsigned)kx_c]; py = a.patches[3u * (unsigned)kx_c + 1u]; pdisp = a.patches[3u * (unsigned)kx_c + 2u];
-        if (MODE != kModeUpd) mono_v = a.mono[(unsigned)kx_c];
+        if (MODE != kModeUpd) mono_v = a.mono[(unsigned)kx_c * (unsigned)a.mstride];
     }
 
 #pragma unroll 1
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(128, MODE == kModeFull ? BT_STREAM_FULL_WAVES : 4) 
                 load_gather(a, e_n, code_n, grp_n);
                 if (kx_n >= 0) {
                     px_n = a.patches[3u * (unsigned)kx_n]; py_n = a.patches[3u * (unsigned)kx_n + 1u]; pd_n = a.patches[3u * (unsigned)kx_n + 2u];
-                    if (MODE != kModeUpd) mono_n = a.mono[(unsigned)kx_n];
+                    if (MODE != kModeUpd) mono_n = a.mono[(unsigned)kx_n * (unsigned)a.mstride];
                 }
             }
         };
@@ -580,6 +580,7 @@ static int launch_stream_t(const PlanDev &pd, const StepArgs &a, hipStream_t st,
 
 int launch_stream(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     if ((unsigned long long)pd.e_all * (unsigned long long)a.tstride * 4ull >= (1ull << 32)) return BT_EUNSUPPORTED;   // 32-bit byte offsets into the targets
+    if ((unsigned long long)pd.p_tot * (unsigned long long)a.mstride * 4ull >= (1ull << 32)) return BT_EUNSUPPORTED;
     if (mode == kModeSO) return launch_stream_t<kModeSO, 1>(pd, a, st, ev0, ev1);
     if (mode == kModeUpd) return launch_stream_t<kModeUpd, 1>(pd, a, st, ev0, ev1);
     if (pd.max_cams <= 8 && (a.dbg & 32)) return launch_stream_t<kModeFull, 3, true>(pd, a, st, ev0, ev1);

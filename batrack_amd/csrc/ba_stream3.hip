@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
     float px = 0.0f, py = 0.0f, pdisp = 0.0f, mono_v = 0.0f;
     if (kx_c >= 0) {
         px = a.patches[3u * (unsigned)kx_c]; py = a.patches[3u * (unsigned)kx_c + 1u]; pdisp = a.patches[3u * (unsigned)kx_c + 2u];
-        if (MODE != kEmUpd) mono_v = a.mono[(unsigned)kx_c];
+        if (MODE != kEmUpd) mono_v = a.mono[(unsigned)kx_c * (unsigned)a.mstride];
     }
 
 #pragma unroll 1
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
             const int e_nn = gi + kEmIds < gi_end ? pd.it_edge[(unsigned)(gi + kEmIds) * kLanes + (unsigned)lane] : -1;
             if (it == 0 && has_next && kx_n >= 0) {          // (its index has arrived by now: the first iteration's arithmetic lies between)
                 px_n = a.patches[3u * (unsigned)kx_n]; py_n = a.patches[3u * (unsigned)kx_n + 1u]; pd_n = a.patches[3u * (unsigned)kx_n + 2u];
-                if (MODE != kEmUpd) mono_n = a.mono[(unsigned)kx_n];
+                if (MODE != kEmUpd) mono_n = a.mono[(unsigned)kx_n * (unsigned)a.mstride];
             }
 
             BT_PF(8);
@@ -567,6 +567,7 @@ static int launch_edge_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, h
 
 int launch_edge(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     if ((unsigned long long)pd.e_all * (unsigned long long)a.tstride * 4ull >= (1ull << 32)) return BT_EUNSUPPORTED;   // 32-bit byte offsets into the targets
+    if ((unsigned long long)pd.p_tot * (unsigned long long)a.mstride * 4ull >= (1ull << 32)) return BT_EUNSUPPORTED;
     const bool s8 = pd.em_lgs == 3;            // the 8-observation graphs of the benchmark generator
     if (mode == kEmSO) return s8 ? launch_edge_t<kEmSO, 1, 3>(pd, a, st, ev0, ev1) : launch_edge_t<kEmSO, 1, -1>(pd, a, st, ev0, ev1);
     if (mode == kEmUpd) return s8 ? launch_edge_t<kEmUpd, 1, 3>(pd, a, st, ev0, ev1) : launch_edge_t<kEmUpd, 1, -1>(pd, a, st, ev0, ev1);

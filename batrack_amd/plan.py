@@ -8,7 +8,11 @@ import ctypes
 
 import numpy as np
 
+import os
+
 from . import _lib
+
+_USE_CTYPES = os.environ.get("BT_PY_BINDING", "") == "ctypes"      # measurement only: the ctypes route for every step
 
 _NP_TYPES = {"slot_lab": np.uint16, "slot_lp": np.uint8, "act_bits": np.uint32, "slot_code": np.uint16, "tile_la": np.uint8, "tile_sinfo": np.uint32}
 PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0", "tile_ntrk", "tile_ncam",
@@ -111,6 +115,7 @@ class Stepper:
         self.ws = torch.zeros(max(plan.workspace_bytes, 256), dtype=torch.uint8, device=self.device)
         self._args = _lib.BaArgs()
         self._lib = _lib.lib()
+        self._ops = None if _USE_CTYPES else _lib.torch_ops()
         self._ws_ptr = self.ws.data_ptr()
         self._views = {}
 
@@ -143,6 +148,7 @@ class Stepper:
         a.poses, a.patches, a.mono_disp = poses.data_ptr(), patches.data_ptr(), mono.data_ptr()
         a.intrinsics, a.targets, a.weights = intrinsics.data_ptr(), targets.data_ptr(), weights.data_ptr()
         a.target_stride = int(tstride)
+        a.mono_stride = int(mono.stride(0)) if mono.dim() == 1 and mono.numel() > 1 else 1     # a strided 1-D view is used in place
         a.poses_out, a.patches_out = poses_out.data_ptr(), patches_out.data_ptr()
         a.bounds[0], a.bounds[1], a.bounds[2], a.bounds[3] = (float(b) for b in bounds)
         a.lmbda, a.ep, a.alpha = float(lmbda), float(ep), float(alpha)
@@ -150,13 +156,26 @@ class Stepper:
         a.structure_only = 1 if structure_only else 0
         return a
 
-    def step(self, *args, stream=None, phase="all"):
-        import torch
-        a = self._fill(*args)
-        st = _raw_stream(self.device) if stream is None else stream
-        fn = {"all": self._lib.bt_ba_step, "reduce": self._lib.bt_ba_reduce, "pack": self._lib.bt_ba_pack,
-              "unpack": self._lib.bt_ba_unpack, "solve_update": self._lib.bt_ba_solve_update}[phase]
-        _lib.check(fn(self.plan.handle, ctypes.byref(a), self._ws_ptr, st), f"bt_ba_{phase}")
+    _PHASES = {"all": 0, "reduce": 1, "pack": 2, "unpack": 3, "solve_update": 4}
+
+    def step(self, poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
+             bounds, lmbda, ep, alpha, loss, structure_only, stream=None, phase="all"):
+        """One BA_rgbd_droid call (or one of its multi-GPU phases) on PyTorch's current stream, through
+        torch.ops.batrack_hip.ba_step — the operator registered over the C ABI (csrc/torch_ops.cpp).  `stream` (a raw
+        hipStream_t) selects the ctypes route instead (tools that launch on a stream of their own)."""
+        if stream is not None or _USE_CTYPES:
+            a = self._fill(poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
+                           bounds, lmbda, ep, alpha, loss, structure_only)
+            st = _raw_stream(self.device) if stream is None else stream
+            fn = {"all": self._lib.bt_ba_step, "reduce": self._lib.bt_ba_reduce, "pack": self._lib.bt_ba_pack,
+                  "unpack": self._lib.bt_ba_unpack, "solve_update": self._lib.bt_ba_solve_update}[phase]
+            _lib.check(fn(self.plan.handle, ctypes.byref(a), self._ws_ptr, st), f"bt_ba_{phase}")
+            return
+        mstride = int(mono.stride(0)) if mono.dim() == 1 and mono.numel() > 1 else 1
+        rc = self._ops.ba_step(self.plan.handle.value, self.ws, poses, patches, mono, mstride, intrinsics, targets, int(tstride),
+                               weights, poses_out, patches_out, [float(b) for b in bounds], float(lmbda), float(ep), float(alpha),
+                               _lib.LOSS[loss] if isinstance(loss, str) else int(loss), bool(structure_only), self._PHASES[phase])
+        _lib.check(rc, f"batrack_hip::ba_step (phase {phase})")
 
     def step_timed(self, *args, stream=None):
         """One step with per-kernel HIP-event timing -> dict of milliseconds."""

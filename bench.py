@@ -19,8 +19,10 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel named in
 BASELINE.json (the Jacobian kernel, k_tile): algorithmic bytes (SURVEY.md §8d:
 40 B/edge + 20 B/track + 72 B/pose) over the kernel's own duration measured with
 HIP events recorded by the launch on its stream (bt_ba_step_timed).
-`cpu_baseline` = the C oracle (a scalar port of the reference algorithm) timed on
-this host, rank 0, N = 1 only.
+`cpu_baseline` = `oracle.refseq`, the torch-CPU restatement that keeps the reference's
+operator sequence, timed on this host at 8 threads and at the
+container's CPU quota (rank 0, N = 1 only); the scalar C port of the checker is reported beside it.
+The timed region is extended to at least 50 ms whatever --steps says (`steps` = the steps timed).
 """
 import argparse
 import json
@@ -44,7 +46,7 @@ def parse():
     ap.add_argument("--workload", default="C3", choices=["C1", "C3"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
     return ap.parse_args()
 
 
@@ -115,16 +117,21 @@ def main():
 
     for k in range(args.warmup):
         ba_iter(k)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        ba_iter(k)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    steps = args.steps
+    while True:
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.warmup, args.warmup + steps):
+            ba_iter(k)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        if elapsed >= 0.05:
+            break
+        steps = int(steps * max(2.0, 0.06 / max(elapsed, 1e-6))) + 1      # too short to mean anything: time more steps (same on every rank)
     status = stepper.status()
 
     extra = {}
@@ -205,6 +212,26 @@ def main():
 
         if not args.no_cpu_baseline:
             import oracle
+            from oracle import refseq
+            from batrack_amd.hostenv import cpu_quota
+            tc = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+            rin = (tc(g.poses), tc(g.patches), tc(g.mono_disp), tc(g.intrinsics), tc(g.targets3), tc(g.weights_pose),
+                   torch.as_tensor(g.ii), torch.as_tensor(g.jj), torch.as_tensor(g.kk), list(g.bounds))
+            quota = cpu_quota()
+            runs = {}
+            for nthr in sorted({min(8, quota), quota}):
+                torch.set_num_threads(nthr)
+                for _ in range(3):
+                    refseq.ba_step(*rin, fixedp=1)
+                ts = []
+                t_end = time.perf_counter() + args.cpu_seconds
+                while len(ts) < 10 or (time.perf_counter() < t_end and len(ts) < 200):
+                    t0 = time.perf_counter()
+                    refseq.ba_step(*rin, fixedp=1)
+                    ts.append(time.perf_counter() - t0)
+                runs[nthr] = (float(np.median(ts)), len(ts))
+            limit_host_threads()
+            best = min(runs, key=lambda k: runs[k][0])
             f64 = lambda a: np.asarray(a, np.float32).astype(np.float64)
             cin = (f64(g.poses), f64(g.patches), f64(g.mono_disp), f64(g.intrinsics), f64(g.targets3),
                    f64(g.weights_pose), g.ii, g.jj, g.kk, g.bounds)
@@ -214,18 +241,23 @@ def main():
             while time.perf_counter() - t0 < args.cpu_seconds:
                 oracle.ba_step(*cin, fixedp=1, dtype=np.float32)
                 nc += 1
-            cpu_rate = nc / (time.perf_counter() - t0)
-            cpu_baseline = {"value": round(cpu_rate, 3), "unit": "BA iterations/s", "cores": 1, "kind": "port",
-                            "host_cores": os.cpu_count(),
-                            "sample": f"{nc} pose+structure steps of the same {args.workload} graph, float32, "
-                                      "scalar C port of the reference algorithm (oracle/ba_oracle_impl.h)"}
+            c_rate = nc / (time.perf_counter() - t0)
+            cpu_baseline = {"value": round(1.0 / runs[best][0], 3), "unit": "BA iterations/s", "cores": best, "kind": "refseq",
+                            "host_cores": os.cpu_count(), "cpu_quota": quota,
+                            "by_threads": {str(k): {"iterations_per_s": round(1.0 / v[0], 3), "median_ms": round(1e3 * v[0], 2), "calls": v[1]}
+                                           for k, v in runs.items()},
+                            "c_port_1core": {"iterations_per_s": round(c_rate, 3), "calls": nc,
+                                             "what": "scalar float32 C port of the algorithm (oracle/ba_oracle_impl.h), edge-major, no block materialisation"},
+                            "sample": f"median of {runs[best][1]} pose+structure steps of the same {args.workload} graph, float32, torch {torch.__version__} CPU ops in the "
+                                      "reference's operator sequence (oracle/refseq.py: block materialisation, 12 scatter-adds, dense E, GEMM Schur, "
+                                      "cholesky_ex), 3 warm-up calls"}
 
     if rank == 0:
         out = {
             "metric": "BA iterations/s on 64-KF/128k-edge graph",
-            "value": round(args.steps / elapsed, 2), "unit": "BA iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "value": round(steps / elapsed, 2), "unit": "BA iterations/s",
+            "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {g.n_frames} keyframes, {plan.E if world == 1 else len(g.ii)} edges, "

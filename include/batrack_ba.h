@@ -108,6 +108,8 @@ typedef struct {
     float lmbda, ep, alpha;    /* ba.py:217 (lm = 1e-4 inside block_solve is fixed)   */
     int32_t loss;              /* BT_LOSS_*                                           */
     int32_t structure_only;    /* ba.py:316                                           */
+    int64_t mono_stride;       /* in floats between consecutive patches of mono_disp: the caller's prior is the
+                                  strided view patches_local[:, :, mid, 2:] (batrack.py:866); 0 or 1 = contiguous */
 } bt_ba_args;
 
 /* Clears the accumulators ([S | y] and the per-pair sums) inside `workspace`.  Call once

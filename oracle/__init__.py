@@ -9,7 +9,7 @@ this package; batrack_amd/ never does.
   oracle.ba_step(...)                 one BA_rgbd_droid call, float64 or float32
   oracle.edges(...)                   per-edge reprojection / Jacobians / masks
   oracle.refseq (module)              torch-CPU restatement keeping the reference's
-                                      operator sequence (timed as cpu_baseline 'port')
+                                      operator sequence (oracle/refseq.py; timed as cpu_baseline "refseq")
 """
 import ctypes
 import os

@@ -18,6 +18,17 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
+def update_err(out, ref_out, inp, rows=None):
+    """Relative error of the UPDATE (out - inp against ref_out - inp) over the rows the step touched: the
+    north-star tolerance is on the pose / depth update, and a state norm dominated by unit quaternions and O(1)
+    translations would hide two orders of magnitude of it."""
+    out, ref_out, inp = (np.asarray(a, np.float64) for a in (out, ref_out, inp))
+    if rows is not None:
+        out, ref_out, inp = out[rows], ref_out[rows], inp[rows]
+    du, dr = out - inp, ref_out - inp
+    return np.linalg.norm(du - dr) / max(np.linalg.norm(dr), 1e-300)
+
+
 class HipProblem:
     """Device copies of a golden/generated input dict, laid out as the caller holds them."""
 

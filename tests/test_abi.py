@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("batrack_ba.h", "batrack_se3.h", "batrack_patchify.h"):
+    for h in sorted(f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h")):     # every header of the boundary
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(bt_[A-Za-z_0-9]+)\s*\(", src))
@@ -24,7 +24,7 @@ def declared_symbols():
 def test_header_symbols_are_exported():
     L = ctypes.CDLL(_lib.LIB_PATH)
     names = declared_symbols()
-    assert len(names) >= 24 and "bt_se3_adjT" in names
+    assert len(names) >= 24 and "bt_se3_adjT" in names and "bt_reproject" in names
     for n in names:
         assert hasattr(L, n), f"{n} declared in batrack_ba.h but not exported"
 

@@ -1,13 +1,16 @@
 """-m gpu: the HIP path (C ABI -> gfx950 kernels) against the golden vectors of the
 reference and against the float64 oracle.
 
-Tolerances (north_star: pose/depth update matches the reference to <= 1e-5 relative):
-  state (poses', disparities')   <= 1e-5 relative to the reference's float64 result
-  reduced system S, y            <= 4e-6 relative: fp32 per-edge maths (the robust weights are
-                                 functions of fp32 residuals), fp64 accumulation
-  camera update dX               <= 2e-3 relative (the reference's own fp32 run is 5e-3 off)
-For comparison each test also checks that we are no worse than the reference's own
-float32 result stored in the fixture."""
+Tolerances, set at about 3x what is measured on the fixtures (tools/gpu_check.py prints the numbers; the
+reference's own float32 run is given for scale):
+  state (poses', disparities')   <= 5e-6 relative to the reference's float64 result   (measured <= 2.7e-6)
+  reduced system S, y            <= 4e-6: fp32 per-edge maths (the robust weights are functions of fp32 residuals),
+                                 fp64 accumulation                                     (measured <= 2.6e-6)
+  camera update dX               <= 3e-4 (measured 1.5e-6 .. 1.6e-4; reference float32: 5e-3)
+  the UPDATE itself, over the entries the step touched (north_star's tolerance is on the update):
+      poses' - poses over the free poses        <= 3e-4   (measured 1.4e-6 .. 1.6e-4; reference float32 8e-5 .. 6e-3)
+      disparities' - disparities over the active tracks <= 1e-4   (measured 1.9e-7 .. 5.2e-5; reference float32 3e-6 .. 1.9e-3)
+  and the update must beat the reference's own float32 run wherever that run is off by more than 1e-4."""
 import os
 
 import numpy as np
@@ -17,11 +20,13 @@ import torch
 import oracle
 from batrack_amd import graphgen
 from batrack_amd.plan import Plan, Stepper
-from gpu_util import HipProblem, rel
+from gpu_util import HipProblem, rel, update_err
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-STATE_TOL = 1e-5
+STATE_TOL = 5e-6
+DX_TOL = 3e-4
+UPD_POSE_TOL, UPD_DISP_TOL = 3e-4, 1e-4
 
 
 def load(name):
@@ -48,12 +53,23 @@ def test_reduced_system_and_update_vs_reference(name, tag, wkey, fixedp, so, los
     d = load(name)
     fixedp = int(d["fixedp"]) if fixedp is None else fixedp
     o = HipProblem(d).raw_step(wkey, fixedp, so, loss, **kw)
+    act = np.unique(d["kk"])
+    disp_in = d["patches"][:, 2].astype(np.float32)
     if f"{tag}.f64.S" in d:
         Sref = d[f"{tag}.f64.S"]
         assert rel(np.tril(o["S_lower"]), np.tril(Sref)) < 4e-6
         assert rel(o["y"], d[f"{tag}.f64.y"]) < 4e-6
-        assert rel(o["dX"].reshape(-1), d[f"{tag}.f64.dX"].reshape(-1)) < 2e-3
+        assert rel(o["dX"].reshape(-1), d[f"{tag}.f64.dX"].reshape(-1)) < DX_TOL
         assert o["status"] == 0
+        n = Sref.shape[0] // 6
+        free = np.arange(fixedp, fixedp + n)
+        poses_in = d["poses"].astype(np.float32)
+        u_pose = update_err(o["poses_out"], d[f"{tag}.f64.poses_out"], poses_in, free)
+        u_ref = update_err(d[f"{tag}.f32.poses_out"], d[f"{tag}.f64.poses_out"], poses_in, free)
+        assert u_pose < UPD_POSE_TOL and (u_ref < 1e-4 or u_pose < u_ref), (u_pose, u_ref)
+    u_disp = update_err(o["patches_out"][:, 2], d[f"{tag}.f64.patches_out"][:, 2], disp_in, act)
+    u_ref = update_err(d[f"{tag}.f32.patches_out"][:, 2], d[f"{tag}.f64.patches_out"][:, 2], disp_in, act)
+    assert u_disp < UPD_DISP_TOL and (u_ref < 1e-4 or u_disp < u_ref), (u_disp, u_ref)
     e_pose = rel(o["poses_out"], d[f"{tag}.f64.poses_out"])
     e_pat = rel(o["patches_out"], d[f"{tag}.f64.patches_out"])
     assert e_pose < STATE_TOL and e_pat < STATE_TOL, (e_pose, e_pat)
@@ -81,6 +97,25 @@ def test_api_dual_iterations(name, fixedp):
     assert np.array_equal(hp.patches[0, :, :, 0, 0].cpu().numpy(), d["patches"].astype(np.float32))
 
 
+def test_strided_depth_prior_is_used_in_place():
+    """The caller's prior is the view patches_local[:, :, mid, 2:] (batrack.py:866): stride S_local * 3 floats between
+    patches.  Same result, bit for bit, as a contiguous copy of it, and no copy is made (ABI field mono_stride)."""
+    d = load("c1_rough")
+    hp = HipProblem(d)
+    P = hp.mono.shape[1]
+    local = torch.zeros(1, P, 5, 3, device=hp.mono.device)
+    local[:, :, 2, 2:] = hp.mono
+    view = local[:, :, 2, 2:]
+    assert not view.is_contiguous() and tuple(view.shape) == (1, P, 1)
+    a = hp.api_step("weights_pose", 2, False)
+    contiguous = hp.mono
+    hp.mono = view
+    b = hp.api_step("weights_pose", 2, False)
+    hp.mono = contiguous
+    torch.cuda.synchronize()
+    assert torch.equal(a[0].data, b[0].data) and torch.equal(a[1], b[1])
+
+
 def c3_inputs(seed=0, **kw):
     g = graphgen.make_config("C3", seed=seed, **kw)
     f = lambda a: np.asarray(a, np.float32).astype(np.float64)
@@ -95,7 +130,7 @@ def test_c3_full_size_vs_reference():
     hp = HipProblem(d)
     o = hp.raw_step("weights_pose", 1)
     assert o["status"] == 0
-    assert rel(o["dX"].reshape(-1), gold["ps.f64.dX"].reshape(-1)) < 2e-3
+    assert rel(o["dX"].reshape(-1), gold["ps.f64.dX"].reshape(-1)) < DX_TOL
     assert rel(np.diag(o["S_lower"]), gold["ps.f64.S_diag"]) < 2e-6
     assert rel(o["y"], gold["ps.f64.y"]) < 2e-6
     assert rel(o["poses_out"], gold["ps.f64.poses_out"]) < STATE_TOL

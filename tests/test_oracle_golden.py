@@ -137,3 +137,36 @@ def test_nan_target_matches_reference(loss):
         assert int(gold["cauchy.n_solves"]) == 1 and np.all(gold["cauchy.dX"] == 0) and np.all(o["dX"] == 0)
     else:
         assert int(gold[f"{loss}.n_solves"]) == 2 and np.isnan(gold[f"{loss}.dX"]).all() and np.isnan(o["dX"]).all()
+
+
+# ---- oracle.refseq: the torch-CPU restatement with the reference's operator sequence (the timed CPU baseline)
+@pytest.mark.parametrize("name,tag,wkey,fixedp,so,loss,kw", CASES)
+def test_refseq_f64_matches_reference(name, tag, wkey, fixedp, so, loss, kw):
+    import torch
+    from oracle import refseq
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    fixedp = int(d["fixedp"]) if fixedp is None else fixedp
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float64))
+    o = refseq.ba_step(t(d["poses"]), t(d["patches"]), t(d["mono"]), t(d["intrinsics"]), t(d["targets3"]), t(d[wkey]),
+                       torch.as_tensor(d["ii"]), torch.as_tensor(d["jj"]), torch.as_tensor(d["kk"]),
+                       [float(x) for x in d["bounds"]], fixedp=fixedp, structure_only=so, loss=loss, want_system=True, **kw)
+    assert rel(o["poses_out"].numpy(), d[f"{tag}.f64.poses_out"]) < 1e-10
+    assert rel(o["patches_out"].numpy(), d[f"{tag}.f64.patches_out"]) < 1e-10
+    if f"{tag}.f64.S" in d.files:
+        assert rel(o["S"].numpy(), d[f"{tag}.f64.S"]) < 1e-9
+        assert rel(o["y"].numpy(), d[f"{tag}.f64.y"]) < 1e-9
+        assert rel(o["dX"].numpy(), d[f"{tag}.f64.dX"]) < 1e-7
+
+
+def test_refseq_f32_c3_close_to_reference_float32():
+    """Full-size C3 in float32, as bench.py times it: within float32 noise of the reference's float64 result."""
+    import torch
+    from oracle import refseq
+    from batrack_amd import graphgen
+    g = graphgen.make_config("C3", seed=0)
+    gold = np.load(os.path.join(GOLD, "c3.npz"))
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    o = refseq.ba_step(t(g.poses), t(g.patches), t(g.mono_disp), t(g.intrinsics), t(g.targets3), t(g.weights_pose),
+                       torch.as_tensor(g.ii), torch.as_tensor(g.jj), torch.as_tensor(g.kk), list(g.bounds), fixedp=1)
+    assert rel(o["poses_out"].numpy(), gold["ps.f64.poses_out"]) < 5e-4
+    assert rel(o["patches_out"].numpy()[:, 2], gold["ps.f64.disp_out"]) < 5e-4
