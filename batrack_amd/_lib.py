@@ -34,7 +34,7 @@ class BaArgs(ctypes.Structure):
                 ("weights", ctypes.c_void_p), ("poses_out", ctypes.c_void_p), ("patches_out", ctypes.c_void_p),
                 ("bounds", ctypes.c_float * 4), ("lmbda", ctypes.c_float), ("ep", ctypes.c_float),
                 ("alpha", ctypes.c_float), ("loss", ctypes.c_int32), ("structure_only", ctypes.c_int32),
-                ("mono_stride", ctypes.c_int64)]
+                ("mono_stride", ctypes.c_int64), ("lmbda_per_track", ctypes.c_void_p)]
 
 
 TORCH_LIB_PATH = os.path.join(_HERE, "lib", "libbatrack_torch.so")

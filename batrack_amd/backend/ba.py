@@ -89,13 +89,16 @@ def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True
         return
     _lib.lib()
     ready = torch.cuda.Event()
-    ready.record(torch.cuda.current_stream(dev))               # the indices are complete once this has passed
+    caller_stream = torch.cuda.current_stream(dev)
+    ready.record(caller_stream)                                # the indices are complete once this has passed
     box = {}
 
     def build():
         try:
             ready.synchronize()
-            with torch.cuda.device(dev):                       # the current device is per host thread
+            # the current device and stream are per host thread: the workspace is allocated and zero-filled on the stream
+            # the steps will run on, so its accumulators are clear before the first of them whatever stream that is
+            with torch.cuda.device(dev), torch.cuda.stream(caller_stream):
                 box["stepper"] = Stepper(Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=False), dev)
         except BaseException as e:                              # reported (or retried in the open) by _plan_for
             box["error"] = e
@@ -163,16 +166,21 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     if tg.stride(1) != 1:                          # the caller's view has strides (3, 1): used in place
         tg = tg.contiguous()
     w = _f32c(weights, "weights").reshape(E, 2).contiguous()
-    if isinstance(lmbda, torch.Tensor):
-        if lmbda.numel() != 1:
-            raise NotImplementedError("per-track lmbda tensors are not supported")
-        lmbda = float(lmbda)
     stepper = _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, dev)
+    lm_trk = None
+    if isinstance(lmbda, torch.Tensor):
+        if lmbda.numel() == 1:
+            lmbda = float(lmbda)
+        elif lmbda.numel() == stepper.plan.m:           # ba.py:299-300: lmbda.reshape(*C.shape), one value per distinct track
+            lm_trk = _f32c(lmbda, "lmbda").reshape(-1).contiguous()
+            lmbda = 0.0
+        else:
+            raise ValueError(f"a lmbda tensor must hold 1 or m = {stepper.plan.m} values (ba.py:299-300), got {lmbda.numel()}")
     so = bool(structure_only) or stepper.plan.n == 0
     patches_out = torch.empty_like(pat)
     poses_out = Pc if so else torch.empty_like(Pc)
     stepper.step(Pc, pat, mono, intr, tg, tg.stride(0), w, poses_out, patches_out,
-                 bounds, lmbda, ep, alpha, loss, so)
+                 bounds, lmbda, ep, alpha, loss, so, lmbda_per_track=lm_trk)
     if PRINT:
         print("BA_rgbd_droid: PRINT is not implemented in batrack_amd (debug only, ba.py:244-245)")
     out_patches = patches_out.view(1, p_tot, 3, 1, 1)

@@ -30,25 +30,30 @@ static size_t put(std::vector<char> &buf, const std::vector<T> &v) {
 // would otherwise wait for (hipFree synchronises the device and unmaps).  Sizes are rounded up so that the
 // slowly varying edge count of a sliding window maps onto the same bucket.
 struct DevPool {
+    struct Entry { void *p; size_t cap; hipEvent_t ev; bool pending; };   // ev: recorded behind the last kernels that read the buffer
     std::mutex mu;
-    std::vector<std::pair<void *, size_t>> free_list;
+    std::vector<Entry> free_list;
     static size_t bucket(size_t bytes) {           // 12.5 % head room, whole MiB, at least 2 MiB
         const size_t g = (size_t)1 << 20;
         return std::max<size_t>(2 * g, (bytes + bytes / 8 + g - 1) / g * g);
     }
-    void *acquire(size_t bytes, size_t *cap) {
+    // *wait: an event the caller's first write into the buffer has to be ordered behind (nullptr: none); the caller hands
+    // it back with give_event() once the wait is enqueued
+    void *acquire(size_t bytes, size_t *cap, hipEvent_t *wait) {
         const size_t want = bucket(bytes);
+        *wait = nullptr;
         {
             std::lock_guard<std::mutex> lk(mu);
             size_t best = free_list.size();
             for (size_t i = 0; i < free_list.size(); ++i)
-                if (free_list[i].second >= bytes && free_list[i].second <= 2 * want &&
-                    (best == free_list.size() || free_list[i].second < free_list[best].second)) best = i;
+                if (free_list[i].cap >= bytes && free_list[i].cap <= 2 * want &&
+                    (best == free_list.size() || free_list[i].cap < free_list[best].cap)) best = i;
             if (best != free_list.size()) {
-                void *p = free_list[best].first;
-                *cap = free_list[best].second;
+                const Entry e = free_list[best];
                 free_list.erase(free_list.begin() + (long)best);
-                return p;
+                *cap = e.cap;
+                if (e.pending) *wait = e.ev; else if (e.ev) spare.push_back(e.ev);
+                return e.p;
             }
         }
         void *d = nullptr;
@@ -56,24 +61,41 @@ struct DevPool {
         *cap = want;
         return d;
     }
-    void release(void *p, size_t cap) {
+    std::vector<hipEvent_t> spare;                 // events not attached to a buffer (guarded by mu)
+    void give_event(hipEvent_t ev) { if (ev) { std::lock_guard<std::mutex> lk(mu); spare.push_back(ev); } }
+    // last_stream != nullptr / launched: kernels reading the buffer may still be queued there
+    void release(void *p, size_t cap, bool launched, hipStream_t last_stream) {
+        Entry e{p, cap, nullptr, false};
+        if (launched) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!spare.empty()) { e.ev = spare.back(); spare.pop_back(); }
+            }
+            if (!e.ev && hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) e.ev = nullptr;
+            if (e.ev && hipEventRecord(e.ev, last_stream) == hipSuccess) e.pending = true;
+            else (void)hipStreamSynchronize(last_stream);            // no event: the plain hipFree this pool replaces synchronised too
+        }
         void *drop = nullptr;
+        hipEvent_t drop_ev = nullptr;
         {
             std::lock_guard<std::mutex> lk(mu);
-            free_list.emplace_back(p, cap);
+            free_list.push_back(e);
             if (free_list.size() > 8) {            // keep the eight largest
                 size_t sm = 0;
-                for (size_t i = 1; i < free_list.size(); ++i) if (free_list[i].second < free_list[sm].second) sm = i;
-                drop = free_list[sm].first;
+                for (size_t i = 1; i < free_list.size(); ++i) if (free_list[i].cap < free_list[sm].cap) sm = i;
+                drop = free_list[sm].p; drop_ev = free_list[sm].ev;
                 free_list.erase(free_list.begin() + (long)sm);
             }
         }
-        if (drop) (void)hipFree(drop);
+        if (drop) (void)hipFree(drop);             // (hipFree waits for the device: nothing can still read the buffer)
+        if (drop_ev) (void)hipEventDestroy(drop_ev);
     }
     void trim() {
-        std::vector<std::pair<void *, size_t>> all;
-        { std::lock_guard<std::mutex> lk(mu); all.swap(free_list); }
-        for (auto &e : all) (void)hipFree(e.first);
+        std::vector<Entry> all;
+        std::vector<hipEvent_t> evs;
+        { std::lock_guard<std::mutex> lk(mu); all.swap(free_list); evs.swap(spare); }
+        for (auto &e : all) { (void)hipFree(e.p); if (e.ev) (void)hipEventDestroy(e.ev); }
+        for (auto ev : evs) (void)hipEventDestroy(ev);
     }
 };
 static DevPool &dev_pool() { static DevPool *p = new DevPool(); return *p; }   // never destroyed: no HIP call at exit
@@ -154,12 +176,18 @@ int upload_plan(bt_plan *pl) {
     const size_t o_sc = put(buf, pl->slot_code), o_tla = put(buf, pl->tile_la), o_trec = put(buf, pl->tile_rec), o_ite = put(buf, pl->it_edge), o_tsi = put(buf, pl->tile_sinfo);
     tick("pack arrays");
     size_t cap = 0;
-    void *d = dev_pool().acquire(buf.size() + 256, &cap);
+    hipEvent_t reuse_after = nullptr;
+    void *d = dev_pool().acquire(buf.size() + 256, &cap, &reuse_after);
     if (!d) return BT_ENOMEM;
     tick("device buffer");
     hipStream_t cs = copy_stream();
+    // a recycled buffer may still be read by kernels of the destroyed plan queued on the caller's stream: the upload
+    // is ordered behind them on the device (no host wait)
+    const bool waited = !reuse_after || hipStreamWaitEvent(cs, reuse_after, 0) == hipSuccess;
+    if (!waited) (void)hipEventSynchronize(reuse_after);
+    dev_pool().give_event(reuse_after);
     if (hipMemcpyAsync(d, buf.data(), buf.size(), hipMemcpyHostToDevice, cs) != hipSuccess ||
-        hipStreamSynchronize(cs) != hipSuccess) { dev_pool().release(d, cap); return BT_EHIP; }
+        hipStreamSynchronize(cs) != hipSuccess) { dev_pool().release(d, cap, false, nullptr); return BT_EHIP; }
     tick("H2D copy");
     pl->dev_base = d;
     pl->dev_cap = cap;
@@ -204,6 +232,7 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     s.poses_out = a->poses_out; s.patches_out = a->patches_out;
     s.b0 = a->bounds[0]; s.b1 = a->bounds[1]; s.b2 = a->bounds[2]; s.b3 = a->bounds[3];
     s.lmbda = a->lmbda; s.ep = a->ep; s.alpha = a->alpha; s.loss = a->loss;
+    s.lmbda_trk = a->lmbda_per_track;
     const size_t D = (size_t)(6 * pl->info.n);
     s.S = reinterpret_cast<double *>(w + L.sys); s.y = s.S + D * D;
     s.pairacc = reinterpret_cast<double *>(w + L.pairacc);
@@ -222,6 +251,7 @@ static int check(const bt_plan *pl, const bt_ba_args *a, const void *ws) {
     if (!a->poses || !a->patches || !a->mono_disp || !a->intrinsics || !a->patches_out) return BT_EINVAL;
     if (pl->info.E > 0 && (!a->targets || !a->weights || a->target_stride < 2)) return BT_EINVAL;
     if (a->loss < BT_LOSS_TRIVIAL || a->loss > BT_LOSS_CAUCHY) return BT_EINVAL;
+    if (a->lmbda_per_track && pl->info.E != pl->e_all) return BT_EUNSUPPORTED;      // sharded plan: track numbers are per rank
     return BT_OK;
 }
 
@@ -273,7 +303,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
 
 void bt_plan_destroy(bt_plan *pl) {
     if (!pl) return;
-    if (pl->dev_base) dev_pool().release(pl->dev_base, pl->dev_cap);
+    if (pl->dev_base) dev_pool().release(pl->dev_base, pl->dev_cap, pl->launched, static_cast<hipStream_t>(pl->last_stream));
     plan_pool().give(pl);
 }
 
@@ -311,6 +341,7 @@ int bt_ba_reduce(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream)
     const int rc = check(pl, a, ws);
     if (rc != BT_OK) return rc;
     const StepArgs s = make_args(pl, a, ws);
+    pl->last_stream = stream; pl->launched = true;
     return launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), is_so(pl, a), static_cast<hipStream_t>(stream));
 }
 
@@ -322,6 +353,7 @@ int bt_ba_solve_update(const bt_plan *pl, const bt_ba_args *a, void *ws, void *s
     if (!so && a->poses_out == a->poses) return BT_EINVAL;
     const StepArgs s = make_args(pl, a, ws);
     const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
+    pl->last_stream = stream; pl->launched = true;
     return launch_solve_update(pl->dev, s, so, copy_poses, static_cast<hipStream_t>(stream));
 }
 
@@ -336,6 +368,7 @@ int bt_ba_step_timed(const bt_plan *pl, const bt_ba_args *a, void *ws, void *str
     const bool so = is_so(pl, a);
     if (!so && (!a->poses_out || a->poses_out == a->poses)) return BT_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    pl->last_stream = stream; pl->launched = true;
     hipEvent_t ev[10];
     for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return BT_EHIP;
     const StepArgs s = make_args(pl, a, ws);
@@ -356,6 +389,7 @@ int bt_ba_pack(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
     const int rc = check(pl, a, ws);
     if (rc != BT_OK) return rc;
     if (is_so(pl, a)) return BT_OK;
+    pl->last_stream = stream; pl->launched = true;
     return launch_pack(pl->dev, make_args(pl, a, ws), false, static_cast<hipStream_t>(stream));
 }
 
@@ -363,6 +397,7 @@ int bt_ba_unpack(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream)
     const int rc = check(pl, a, ws);
     if (rc != BT_OK) return rc;
     if (is_so(pl, a)) return BT_OK;
+    pl->last_stream = stream; pl->launched = true;
     return launch_pack(pl->dev, make_args(pl, a, ws), true, static_cast<hipStream_t>(stream));
 }
 

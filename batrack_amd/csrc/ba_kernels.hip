@@ -23,6 +23,9 @@
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "ba_kernels.hpp"
 #include "ba_edge.hpp"
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
                 const float mono = mono_v;
                 const float pm = mono > 1e-2f ? 1.0f : 0.0f;
                 float Ca = C + pm * a.alpha;
-                Ca = Ca + a.lmbda;
+                Ca = Ca + (a.lmbda_trk ? a.lmbda_trk[trk] : a.lmbda);
                 wp = wv - pm * a.alpha * (pdisp - mono);
                 Q = 1.0f / Ca;
                 a.qw[trk] = make_float2(Q, wp);
@@ -2174,20 +2177,32 @@ static int solver_threads() {
     return t >= 256 && t <= 768 ? (t / 64) * 64 : 768;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is one value per kernel for the whole process, while up to eight cached
+// plans (and the prefetch thread building the next one) coexist: the limit is only ever RAISED, under a lock, so a
+// small plan uploaded later cannot pull it below what an earlier plan launches with.
+static int raise_lds_limit(const void *fn, size_t need) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, size_t>> *set = new std::vector<std::pair<const void *, size_t>>();
+    if (need <= 48 * 1024) return BT_OK;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : *set)
+        if (e.first == fn) {
+            if (e.second >= need) return BT_OK;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return BT_EHIP;
+            e.second = need;
+            return BT_OK;
+        }
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return BT_EHIP;
+    set->emplace_back(fn, need);
+    return BT_OK;
+}
+
 int configure_kernels(const PlanDev &pd) {
     const size_t need = tile_lds_bytes(pd, false);
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
-    if (need > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, false, false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile<false, true, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess)
-            return BT_EHIP;
-    }
+    const void *tiles[4] = { reinterpret_cast<const void *>(&k_tile<false, false, false>), reinterpret_cast<const void *>(&k_tile<false, false, true>),
+                             reinterpret_cast<const void *>(&k_tile<false, false, false, true>), reinterpret_cast<const void *>(&k_tile<false, true, false>) };
+    for (const void *fn : tiles) if (raise_lds_limit(fn, need) != BT_OK) return BT_EHIP;
     const int mode = solver_mode(pd);
     const void *fns[4] = { reinterpret_cast<const void *>(&k_solve_lds<double, false>),
                            reinterpret_cast<const void *>(&k_solve_lds<double, true>),
@@ -2195,20 +2210,14 @@ int configure_kernels(const PlanDev &pd) {
                            reinterpret_cast<const void *>(&k_solve_lds<float, true>) };
     if (mode < 2)
         for (int v = 0; v < 2; ++v)
-            if (hipFuncSetAttribute(fns[2 * mode + v], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)solve_lds_bytes(pd, mode == 0 ? 8 : 4)) != hipSuccess)
-                return BT_EHIP;
+            if (raise_lds_limit(fns[2 * mode + v], solve_lds_bytes(pd, mode == 0 ? 8 : 4)) != BT_OK) return BT_EHIP;
     if (mode == 0 && use_pipe_solver(pd))
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_pipe<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_pipe_lds_bytes(pd)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_pipe<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_pipe_lds_bytes(pd)) != hipSuccess)
+        if (raise_lds_limit(reinterpret_cast<const void *>(&k_solve_pipe<false>), solve_pipe_lds_bytes(pd)) != BT_OK ||
+            raise_lds_limit(reinterpret_cast<const void *>(&k_solve_pipe<true>), solve_pipe_lds_bytes(pd)) != BT_OK)
             return BT_EHIP;
     if (mode == 0 && use_fused_solver(pd))
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_fused_lds_bytes(pd, solver_threads())) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_fused_lds_bytes(pd, solver_threads())) != hipSuccess)
+        if (raise_lds_limit(reinterpret_cast<const void *>(&k_solve_fused<false>), solve_fused_lds_bytes(pd, solver_threads())) != BT_OK ||
+            raise_lds_limit(reinterpret_cast<const void *>(&k_solve_fused<true>), solve_fused_lds_bytes(pd, solver_threads())) != BT_OK)
             return BT_EHIP;
     return BT_OK;
 }

@@ -12,6 +12,7 @@ struct StepArgs {
     int tstride, mstride;         // floats between consecutive edges' targets / patches' depth priors
     float *poses_out, *patches_out;
     float b0, b1, b2, b3, lmbda, ep, alpha;
+    const float *lmbda_trk;       // per-track lmbda (ba.py:299-300) or nullptr
     int loss;
     double *S, *y, *pairacc;      // S, y, pairacc are contiguous (cleared together)
     double *packed;               // the non-zero blocks of [S | y] in factor order (multi-GPU exchange buffer)

@@ -66,11 +66,13 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     BT_TICK("0");
     // ---- n_all, validation (ba.py:219) ------------------------------------
     int64_t n_all = n_all_min, kmin = p_tot, kmax = -1;       // [kmin, kmax]: patches the edges name (a window of the buffer)
+    int64_t f_lo = n_buf;                                     // first frame the edges name (the window's start, not the buffer's)
     bool sorted = true;
     for (int64_t e = 0; e < E; ++e) {
         if (ii[e] < 0 || jj[e] < 0 || ii[e] >= n_buf || jj[e] >= n_buf) return BT_EINVAL;
         if (kk[e] < 0 || kk[e] >= p_tot) return BT_EINVAL;
         n_all = std::max(n_all, std::max(ii[e], jj[e]) + 1);
+        f_lo = std::min(f_lo, std::min(ii[e], jj[e]));
         kmin = std::min(kmin, kk[e]); kmax = std::max(kmax, kk[e]);
         if (e && kk[e] < kk[e - 1]) sorted = false;
     }
@@ -84,12 +86,16 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     // ---- one pass over the edges: edges per track, per target frame, and the camera pairs in use
     pl->trk_of_patch.assign((size_t)p_tot, -1);
     for (int64_t p = kmin; p <= kmax; ++p) pl->trk_of_patch[(size_t)p] = 0;
-    std::vector<int32_t> pair_of((size_t)(n_all * n_all), -1), cj((size_t)n_all + 1, 0);
+    // camera pairs are looked up in a table over the frames the edges name, [f_lo, n_all): the window (about 20 frames),
+    // not the keyframe count of the whole sequence
+    if (E == 0) f_lo = 0;
+    const int64_t nw = n_all - f_lo;
+    std::vector<int32_t> pair_of((size_t)(nw * nw), -1), cj((size_t)n_all + 1, 0);
     int64_t E_own = 0;
     for (int64_t e = 0; e < E; ++e)
         if (owned(e)) {
             ++pl->trk_of_patch[(size_t)kk[e]];
-            pair_of[(size_t)(ii[e] * n_all + jj[e])] = 0;
+            pair_of[(size_t)((ii[e] - f_lo) * nw + (jj[e] - f_lo))] = 0;
             ++cj[(size_t)jj[e] + 1];
             ++E_own;
         }
@@ -108,11 +114,11 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     BT_TICK("2");
     // ---- distinct camera pairs, ascending (i, j) ---------------------------
     pl->pair_i.clear(); pl->pair_j.clear();
-    for (int64_t key = 0; key < n_all * n_all; ++key)
+    for (int64_t key = 0; key < nw * nw; ++key)
         if (pair_of[(size_t)key] == 0) {
             pair_of[(size_t)key] = (int32_t)pl->pair_i.size();
-            pl->pair_i.push_back((int32_t)(key / n_all));
-            pl->pair_j.push_back((int32_t)(key % n_all));
+            pl->pair_i.push_back((int32_t)(key / nw + f_lo));
+            pl->pair_j.push_back((int32_t)(key % nw + f_lo));
         }
     I.pairs = (int64_t)pl->pair_i.size();
 
@@ -133,7 +139,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         const int32_t e = byj[(size_t)q];
         ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = e;
     }
-    auto pair_id = [&](int32_t e) { return pair_of[(size_t)(ii[e] * n_all + jj[e])]; };
+    auto pair_id = [&](int32_t e) { return pair_of[(size_t)((ii[e] - f_lo) * nw + (jj[e] - f_lo))]; };
 
     BT_TICK("4");
     // ---- tiles: greedy over sorted tracks ----------------------------------

@@ -88,6 +88,10 @@ struct bt_plan {
     long long e_all = 0;
     bt::WsLayout ws{};
     void *dev_base = nullptr;   // one device allocation holding every array above (from the pool in ba_api.cpp)
+    // the stream the plan's kernels were last launched on: bt_plan_destroy records an event there, and the next plan that
+    // reuses the device buffer makes its table upload wait for it (the tables must not change under queued kernels)
+    mutable void *last_stream = nullptr;
+    mutable bool launched = false;
     size_t dev_cap = 0;
     bt::PlanDev dev{};
 
@@ -108,6 +112,7 @@ struct bt_plan {
         max_rows16 = 16;
         ws = bt::WsLayout{};
         dev_base = nullptr; dev_cap = 0;
+        last_stream = nullptr; launched = false;
         dev = bt::PlanDev{};
     }
 };

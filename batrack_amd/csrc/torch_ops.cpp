@@ -9,7 +9,8 @@
 //   batrack_hip::plan_info(int plan) -> int[]                 (the fields of bt_plan_info, in order)
 //   batrack_hip::ba_step(int plan, Tensor ws, Tensor poses, Tensor patches, Tensor mono, int mono_stride, Tensor intrinsics,
 //                        Tensor targets, int target_stride, Tensor weights, Tensor poses_out, Tensor patches_out,
-//                        float[] bounds, float lmbda, float ep, float alpha, int loss, bool structure_only, int phase) -> int
+//                        float[] bounds, float lmbda, float ep, float alpha, int loss, bool structure_only, int phase,
+//                        Tensor? lmbda_per_track=None) -> int
 //       phase 0 = the whole step, 1 = bt_ba_reduce, 2 = bt_ba_pack, 3 = bt_ba_unpack, 4 = bt_ba_solve_update
 // Built by batrack_amd/_lib.py:build() into batrack_amd/lib/libbatrack_torch.so (g++, host code only).
 #include <ATen/ATen.h>
@@ -55,7 +56,8 @@ std::vector<int64_t> plan_info(int64_t plan) {
 int64_t ba_step(int64_t plan, const at::Tensor &ws, const at::Tensor &poses, const at::Tensor &patches, const at::Tensor &mono,
                 int64_t mono_stride, const at::Tensor &intrinsics, const at::Tensor &targets, int64_t target_stride,
                 const at::Tensor &weights, const at::Tensor &poses_out, const at::Tensor &patches_out, c10::ArrayRef<double> bounds,
-                double lmbda, double ep, double alpha, int64_t loss, bool structure_only, int64_t phase) {
+                double lmbda, double ep, double alpha, int64_t loss, bool structure_only, int64_t phase,
+                const c10::optional<at::Tensor> &lmbda_per_track) {
     TORCH_CHECK(bounds.size() == 4, "batrack_hip::ba_step: bounds = [x0, y0, x1, y1]");
     TORCH_CHECK(ws.is_cuda() && ws.is_contiguous(), "batrack_hip::ba_step: the workspace must be a contiguous GPU tensor");
     bt_ba_args a{};
@@ -64,6 +66,8 @@ int64_t ba_step(int64_t plan, const at::Tensor &ws, const at::Tensor &poses, con
     a.target_stride = target_stride; a.mono_stride = mono_stride;
     a.poses_out = const_cast<float *>(f32(poses_out, "poses_out")); a.patches_out = const_cast<float *>(f32(patches_out, "patches_out"));
     for (int i = 0; i < 4; ++i) a.bounds[i] = (float)bounds[i];
+    a.lmbda_per_track = lmbda_per_track.has_value() ? f32(*lmbda_per_track, "lmbda_per_track") : nullptr;
+    if (lmbda_per_track.has_value()) TORCH_CHECK(lmbda_per_track->is_contiguous(), "batrack_hip::ba_step: lmbda_per_track must be contiguous");
     a.lmbda = (float)lmbda; a.ep = (float)ep; a.alpha = (float)alpha; a.loss = (int32_t)loss; a.structure_only = structure_only ? 1 : 0;
     const bt_plan *p = reinterpret_cast<const bt_plan *>(plan);
     void *st = c10::hip::getCurrentHIPStream(ws.device().index()).stream();
@@ -87,5 +91,5 @@ TORCH_LIBRARY(batrack_hip, m) {
     m.def("plan_info(int plan) -> int[]", &plan_info);
     m.def("ba_step(int plan, Tensor ws, Tensor poses, Tensor patches, Tensor mono, int mono_stride, Tensor intrinsics, Tensor targets, "
           "int target_stride, Tensor weights, Tensor(a!) poses_out, Tensor(b!) patches_out, float[] bounds, float lmbda, float ep, "
-          "float alpha, int loss, bool structure_only, int phase) -> int", &ba_step);
+          "float alpha, int loss, bool structure_only, int phase, Tensor? lmbda_per_track=None) -> int", &ba_step);
 }

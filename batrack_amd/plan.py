@@ -154,18 +154,20 @@ class Stepper:
         a.lmbda, a.ep, a.alpha = float(lmbda), float(ep), float(alpha)
         a.loss = _lib.LOSS[loss] if isinstance(loss, str) else int(loss)
         a.structure_only = 1 if structure_only else 0
+        a.lmbda_per_track = None
         return a
 
     _PHASES = {"all": 0, "reduce": 1, "pack": 2, "unpack": 3, "solve_update": 4}
 
     def step(self, poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
-             bounds, lmbda, ep, alpha, loss, structure_only, stream=None, phase="all"):
+             bounds, lmbda, ep, alpha, loss, structure_only, stream=None, phase="all", lmbda_per_track=None):
         """One BA_rgbd_droid call (or one of its multi-GPU phases) on PyTorch's current stream, through
         torch.ops.batrack_hip.ba_step — the operator registered over the C ABI (csrc/torch_ops.cpp).  `stream` (a raw
         hipStream_t) selects the ctypes route instead (tools that launch on a stream of their own)."""
         if stream is not None or _USE_CTYPES:
             a = self._fill(poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
                            bounds, lmbda, ep, alpha, loss, structure_only)
+            a.lmbda_per_track = lmbda_per_track.data_ptr() if lmbda_per_track is not None else None
             st = _raw_stream(self.device) if stream is None else stream
             fn = {"all": self._lib.bt_ba_step, "reduce": self._lib.bt_ba_reduce, "pack": self._lib.bt_ba_pack,
                   "unpack": self._lib.bt_ba_unpack, "solve_update": self._lib.bt_ba_solve_update}[phase]
@@ -174,7 +176,8 @@ class Stepper:
         mstride = int(mono.stride(0)) if mono.dim() == 1 and mono.numel() > 1 else 1
         rc = self._ops.ba_step(self.plan.handle.value, self.ws, poses, patches, mono, mstride, intrinsics, targets, int(tstride),
                                weights, poses_out, patches_out, [float(b) for b in bounds], float(lmbda), float(ep), float(alpha),
-                               _lib.LOSS[loss] if isinstance(loss, str) else int(loss), bool(structure_only), self._PHASES[phase])
+                               _lib.LOSS[loss] if isinstance(loss, str) else int(loss), bool(structure_only), self._PHASES[phase],
+                               lmbda_per_track)
         _lib.check(rc, f"batrack_hip::ba_step (phase {phase})")
 
     def step_timed(self, *args, stream=None):

@@ -197,6 +197,8 @@ def ba_step(poses, patches, mono, intrinsics, targets3, weights, ii, jj, kk, bou
     # ---- depth prior, Q, ba.py:296-311
     mono_kx = mono[None, kx, None, None]
     pm = (mono_kx > 1e-2).to(dt)
+    if torch.is_tensor(lmbda):
+        lmbda = lmbda.reshape(*C.shape)                                             # ba.py:299-300
     Cadj = C + pm * alpha
     Cadj = Cadj + lmbda
     wadj = w - pm * alpha * (pat[:, kx, 2, None, None] - mono_kx)

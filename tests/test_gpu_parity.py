@@ -116,6 +116,27 @@ def test_strided_depth_prior_is_used_in_place():
     assert torch.equal(a[0].data, b[0].data) and torch.equal(a[1], b[1])
 
 
+def test_per_track_lmbda_tensor():
+    """ba.py:299-300: `lmbda` may be a tensor shaped like C — one damping value per distinct track, ascending patch order."""
+    from oracle import refseq
+    d = load("c1_rough")
+    hp = HipProblem(d)
+    m = len(np.unique(d["kk"]))
+    lm = np.random.default_rng(3).uniform(1e-4, 0.5, m)
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float64))
+    ref = refseq.ba_step(t(d["poses"]), t(d["patches"]), t(d["mono"]), t(d["intrinsics"]), t(d["targets3"]), t(d["weights_pose"]),
+                         torch.as_tensor(d["ii"]), torch.as_tensor(d["jj"]), torch.as_tensor(d["kk"]),
+                         [float(x) for x in d["bounds"]], fixedp=2, lmbda=t(lm.astype(np.float32)))
+    Gs, pat = hp.api_step("weights_pose", 2, False, lmbda=torch.as_tensor(lm, dtype=torch.float32, device="cuda:0"))
+    torch.cuda.synchronize()
+    assert rel(Gs.data[0].cpu().numpy(), ref["poses_out"].numpy()) < STATE_TOL
+    assert rel(pat[0, :, :, 0, 0].cpu().numpy(), ref["patches_out"].numpy()) < STATE_TOL
+    plain = hp.api_step("weights_pose", 2, False)
+    assert rel(pat[0, :, 2, 0, 0].cpu().numpy(), plain[1][0, :, 2, 0, 0].cpu().numpy()) > 1e-4       # and it is not the scalar result
+    with pytest.raises(ValueError):
+        hp.api_step("weights_pose", 2, False, lmbda=torch.ones(m + 1, device="cuda:0"))
+
+
 def c3_inputs(seed=0, **kw):
     g = graphgen.make_config("C3", seed=seed, **kw)
     f = lambda a: np.asarray(a, np.float32).astype(np.float64)
