@@ -24,6 +24,15 @@ namespace bt {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+int edge_min_tiles() {
+    static const int t = std::getenv("BT_EDGE_MIN_TILES") ? std::atoi(std::getenv("BT_EDGE_MIN_TILES")) : 2048;
+    return t;
+}
+int stream_min_tiles() {
+    static const int t = std::getenv("BT_STREAM_MIN_TILES") ? std::atoi(std::getenv("BT_STREAM_MIN_TILES")) : 2048;
+    return t;
+}
+
 static void layout_workspace(bt_plan *pl) {
     const bt_plan_info &I = pl->info;
     const size_t D = (size_t)(6 * I.n);
@@ -650,7 +659,8 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     // (local target camera | local pair << 8; the global pair id is tile_pairs[pair0 + local pair]); per (tile,
     // lane) the local source camera (one per track: ii = ix[kk], checked above); per tile one 32-byte record
     //   [0] ntrk | ncam << 8 | npair << 16 | flags << 24   [1] slot0  [2] nslot  [3] cam0  [4] pair0  [5] trk0
-    {
+    const bool want_stream_tables = I.tiles >= std::min(edge_min_tiles(), stream_min_tiles());
+    if (want_stream_tables) {
         pl->slot_code.assign((size_t)slots * kLanes, 0xffff);
         pl->tile_la.assign((size_t)I.tiles * kLanes, 0xff);
         pl->tile_rec.assign((size_t)I.tiles * 8, 0);
@@ -691,7 +701,8 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     //   tile_sinfo[t * 64 + s]           local target camera | local pair << 8 | repeat << 16 | used << 17   (s < S)
     //                                    repeat: this slot or a neighbour holds the same pair again (repeated observation)
     //   tile_rec[6] = it0, tile_rec[7] = log2 S | iterations << 8
-    {
+    pl->em_ok = 0; pl->em_its = 0; pl->em_lgs = -1;
+    if (want_stream_tables && I.tiles >= edge_min_tiles()) {
         pl->em_ok = 1;
         int64_t its = 0;
         std::vector<int32_t> it0((size_t)I.tiles), lgS((size_t)I.tiles), nit((size_t)I.tiles);

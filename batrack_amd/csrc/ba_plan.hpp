@@ -118,6 +118,10 @@ struct bt_plan {
 };
 
 namespace bt {
+// Tile counts from which the wave-per-tile kernels take a graph (k_edge, k_stream; the environment overrides are for
+// measurement and tests).  The planner lays out their tables only for plans that will use them.
+int edge_min_tiles();
+int stream_min_tiles();
 // Pure host analysis (no HIP).  Returns BT_OK or an error code.
 int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
                     int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,

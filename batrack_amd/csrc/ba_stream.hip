@@ -528,10 +528,6 @@ __global__ __launch_bounds__(128, MODE == kModeFull ? BT_STREAM_FULL_WAVES : 4) 
 }
 
 // ------------------------------------------------------------------ dispatch
-static int stream_threshold() {
-    static const int t = std::getenv("BT_STREAM_MIN_TILES") ? std::atoi(std::getenv("BT_STREAM_MIN_TILES")) : 2048;   // measurement only
-    return t;
-}
 
 static size_t stream_lds_bytes(const PlanDev &pd, int mode) {
     const size_t mtp = (size_t)(pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1);
@@ -545,7 +541,7 @@ static size_t stream_lds_bytes(const PlanDev &pd, int mode) {
 // The streaming kernels take graphs of many tiles whose tiles see at most 10 cameras (row tiles of the register
 // accumulators) and 32 camera pairs (one lane per pair in the prologue, LDS of the per-pair sums).
 bool stream_applies(const PlanDev &pd) {
-    return pd.T >= stream_threshold() && pd.max_cams <= 10 && pd.max_tile_pairs <= 32 && pd.max_tile_pairs > 0;
+    return pd.T >= stream_min_tiles() && pd.max_cams <= 10 && pd.max_tile_pairs <= 32 && pd.max_tile_pairs > 0;
 }
 
 template <int MODE, int NT, bool PROF = false>

@@ -515,10 +515,6 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
 #undef BT_DPPF
 
 // ------------------------------------------------------------------ dispatch
-static int edge_threshold() {
-    static const int t = std::getenv("BT_EDGE_MIN_TILES") ? std::atoi(std::getenv("BT_EDGE_MIN_TILES")) : 2048;   // measurement only
-    return t;
-}
 
 static size_t edge_lds_bytes(const PlanDev &pd, int mode) {
     const size_t mtp = (size_t)(pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1);
@@ -533,7 +529,7 @@ static size_t edge_lds_bytes(const PlanDev &pd, int mode) {
 // tiles of the register accumulators) and 64 camera pairs (one lane per pair in the prologue)
 bool edge_applies(const PlanDev &pd) {
     static const int off = std::getenv("BT_EDGE_OFF") ? std::atoi(std::getenv("BT_EDGE_OFF")) : 0;   // measurement only
-    return !off && pd.em_ok && pd.T >= edge_threshold() && pd.max_cams <= 10 && pd.max_cams > 0 && pd.max_tile_pairs <= 64 && pd.max_tile_pairs > 0;
+    return !off && pd.em_ok && pd.T >= edge_min_tiles() && pd.max_cams <= 10 && pd.max_cams > 0 && pd.max_tile_pairs <= 64 && pd.max_tile_pairs > 0;
 }
 
 template <int MODE, int NT, int LGS, bool PROF = false>

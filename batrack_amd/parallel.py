@@ -41,6 +41,12 @@ def partition_tracks(kk, world):
     return bounds
 
 
+def plan_range(own, p_tot):
+    """(own_lo, own_hi) as bt_plan_create takes it: an empty range must not read as "all tracks" (own_hi = 0)."""
+    lo, hi = own
+    return (max(int(p_tot), 1),) * 2 if hi <= lo else (int(lo), int(hi))
+
+
 def shard_edges(kk, world, rank):
     """Indices (ascending, int64 tensor on kk's device) of the edges rank `rank` owns."""
     lo, hi = partition_tracks(kk, world)[rank]
@@ -73,17 +79,17 @@ class ShardedBA:
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
         self.device = torch.device(device)
-        self.owned = partition_tracks(kk, self.world)[self.rank]
-        self.plan = Plan(ii, jj, kk, n_buf, p_tot, fixedp, own=self.owned if self.world > 1 else (0, 0))
+        # every rank derives every rank's track range from the same edge list: nothing about the partition is exchanged
+        self.ranges = partition_tracks(kk, self.world)
+        self.owned = self.ranges[self.rank]
+        # (a rank without tracks — more ranks than tracks — plans an empty range and still takes part in the all-reduce and the solve)
+        self.plan = Plan(ii, jj, kk, n_buf, p_tot, fixedp, own=plan_range(self.owned, p_tot) if self.world > 1 else (0, 0))
         self.stepper = Stepper(self.plan, self.device)
-
-    def local(self, per_edge):
-        """Kept for callers written against the first version: per-edge tensors are used whole."""
-        return per_edge
+        self._covered = None
 
     def step(self, poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
              bounds, lmbda, ep, alpha, loss, structure_only):
-        """targets / weights are already local (see `local`).  Same argument order as Stepper.step."""
+        """Same argument order as Stepper.step; per-edge tensors are the full ones on every rank."""
         args = (poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
                 bounds, lmbda, ep, alpha, loss, structure_only)
         so = bool(structure_only) or self.plan.n == 0
@@ -104,17 +110,18 @@ class ShardedBA:
         _lib.check(L.bt_ba_solve_update(h, ctypes.byref(a), ws, stream), "bt_ba_solve_update")
 
     def gather_patches(self, patches_out):
-        """Merge disparities: every patch slot is owned by exactly one rank (its track
-        range); slots outside every range are identical on all ranks."""
+        """Merge disparities: every patch slot is owned by exactly one rank (its track range); slots outside every
+        range are identical on all ranks.  One fixed-shape all-reduce over the span of the ranges (a sum of disjoint
+        pieces); no Python objects are exchanged."""
         if self.world == 1:
             return patches_out
-        ranges = [None] * self.world
-        dist.all_gather_object(ranges, self.owned, group=self.group)
+        span_lo = min(a for a, b in self.ranges if b > a)
+        span_hi = max(b for a, b in self.ranges if b > a)
         lo, hi = self.owned
-        mine = torch.zeros_like(patches_out)
-        mine[lo:hi] = patches_out[lo:hi]
+        mine = torch.zeros_like(patches_out[span_lo:span_hi])
+        if hi > lo:
+            mine[lo - span_lo:hi - span_lo] = patches_out[lo:hi]
         allreduce_system(mine, self.group)
-        covered = torch.zeros(patches_out.shape[0], dtype=torch.bool, device=patches_out.device)
-        for a, b in ranges:
-            covered[a:b] = True
-        return torch.where(covered[:, None], mine, patches_out)
+        out = patches_out.clone()
+        out[span_lo:span_hi] = mine                     # the ranges tile [span_lo, span_hi): every slot in it has exactly one owner
+        return out

@@ -92,7 +92,7 @@ def main():
     if world > 1:
         eng = ShardedBA(ii, jj, kk, n_buf, p_tot, fixedp, dev)
         plan, stepper = eng.plan, eng.stepper
-        tg, wp_l, wa_l = eng.local(t3), eng.local(w_pose), eng.local(w_all)
+        tg, wp_l, wa_l = t3, w_pose, w_all
         step = eng.step
     else:
         plan = Plan(ii, jj, kk, n_buf, p_tot, fixedp)

@@ -22,16 +22,20 @@ def _worker(rank, world, port, name, fixedp, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import oracle
-        from batrack_amd.parallel import shard_edges, allreduce_system, partition_tracks
+        from batrack_amd.parallel import shard_edges, allreduce_system, partition_tracks, plan_range
         from batrack_amd.plan import Plan
         from plan_emulator import run as emulate
-        d = dict(np.load(os.path.join(GOLD, name + ".npz")))
+        d = dict(np.load(os.path.join(GOLD, ("c1" if name == "few" else name) + ".npz")))
+        if name == "few":                                    # fewer tracks than ranks: the edges of three tracks of different frames
+            keep = np.isin(d["kk"], [40, 100, 200])
+            for k in ("ii", "jj", "kk", "targets3", "weights", "weights_pose"):
+                d[k] = d[k][keep]
         n_all = int(max(d["ii"].max(), d["jj"].max())) + 1
         idx = shard_edges(torch.as_tensor(d["kk"]), world, rank).numpy()
         own = partition_tracks(d["kk"], world)[rank]
         # every rank plans from the FULL edge list and assembles only its own track range
         pl = Plan(d["ii"], d["jj"], d["kk"], d["poses"].shape[0], d["patches"].shape[0], fixedp,
-                  upload=False, own=own)
+                  upload=False, own=plan_range(own, d["patches"].shape[0]))
         assert pl.n == n_all - fixedp and pl.E == len(idx)   # same-size system on every rank
         loc = d
         em = emulate(pl, pl.arrays(), loc, "weights_pose")
@@ -55,13 +59,14 @@ def _worker(rank, world, port, name, fixedp, out):
         lo, hi = partition_tracks(d["kk"], world)[rank]
         ok_part = bool((cover == 1).all()) and bool(((d["kk"][idx] >= lo) & (d["kk"][idx] < hi)).all())
         out[rank] = (float(eS), float(ey), ok_part, len(idx))
+        assert (pl.E == 0) == (own[1] <= own[0])
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,fixedp", [("c1", 1), ("c1_rough", 2)])
-def test_two_rank_sharded_reduce_equals_full(name, fixedp):
-    world = 2
+@pytest.mark.parametrize("name,fixedp,world", [("c1", 1, 2), ("c1_rough", 2, 2), ("c1", 1, 4), ("c1_rough", 2, 8), ("few", 1, 4), ("few", 1, 8)])
+def test_sharded_reduce_equals_full(name, fixedp, world):
+    """world = 2, 4, 8; "few": a graph of three tracks, so that most ranks own no track at all."""
     port = 29500 + (os.getpid() % 2000)
     mgr = mp.Manager()
     out = mgr.dict()
@@ -73,8 +78,12 @@ def test_two_rank_sharded_reduce_equals_full(name, fixedp):
         assert ok_part
         assert eS < 1e-10 and ey < 1e-10, (eS, ey)
         sizes.append(nloc)
-    assert sum(sizes) == len(np.load(os.path.join(GOLD, name + ".npz"))["kk"])
-    assert min(sizes) > 0.3 * max(sizes)                 # balanced by edge count
+    total = len(np.load(os.path.join(GOLD, "c1.npz" if name == "few" else name + ".npz"))["kk"])
+    if name == "few":
+        assert sum(sizes) < total and sum(1 for s in sizes if s == 0) >= world - 3      # ranks without tracks took part
+    else:
+        assert sum(sizes) == total
+        assert min(sizes) > 0.3 * max(sizes)                 # balanced by edge count
 
 
 def test_partition_tracks_properties():
