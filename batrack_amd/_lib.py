@@ -8,10 +8,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(_HERE, "lib", "libbatrack_ba.so")   # BT_LIB_PATH: measurement builds only
-SOURCES = ["ba_kernels.hip", "ba_stream.hip", "ba_stream3.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip"]
+SOURCES = ["ba_kernels.hip", "ba_stream.hip", "ba_stream3.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip", "ga_kernels.hip"]
 HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", "ba_edge.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
            os.path.join("..", "..", "include", "batrack_se3.h"), os.path.join("..", "..", "include", "batrack_patchify.h"),
-           os.path.join("..", "..", "include", "batrack_projective.h")]
+           os.path.join("..", "..", "include", "batrack_projective.h"), os.path.join("..", "..", "include", "batrack_ga.h")]
 # -fno-slp-vectorize: packed f32 pairs cost more register moves than the packed instructions save (measured on k_edge)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
 
@@ -39,6 +39,13 @@ class BaArgs(ctypes.Structure):
 
 TORCH_LIB_PATH = os.path.join(_HERE, "lib", "libbatrack_torch.so")
 TORCH_SRC = os.path.join(CSRC, "torch_ops.cpp")
+
+
+class GaArgs(ctypes.Structure):                       # == bt_ga_args in include/batrack_ga.h
+    _fields_ = ([(n, ctypes.c_int64) for n in ("T", "N", "S", "gh", "gw", "H", "W", "Q")] +
+                [(n, ctypes.c_void_p) for n in ("trajs_2d", "trajs_disp", "trajs_disp_mono", "trajs_vis", "trajs_static", "jj",
+                                                "intrinsics", "pose", "query", "trajs_scales", "frame_scales", "frame_shifts")] +
+                [("pw_break", ctypes.c_float), ("half_disp", ctypes.c_int32)])
 
 
 def needs_build():
@@ -149,6 +156,8 @@ def lib():
         f.argtypes = [vp] * nptr + [i64, i32, vp]
     L.bt_reproject.restype = i32
     L.bt_reproject.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp]
+    L.bt_ga_forward.restype = i32
+    L.bt_ga_forward.argtypes = [vp, vp, vp, i32, vp]
     L.bt_patchify.restype = i32
     L.bt_patchify.argtypes = [vp, i64, i64, i64, i64, vp, i64, i32, i32, vp, vp]
     _lib = L

@@ -1,0 +1,49 @@
+/* batrack_ga.h — C ABI of the dense global-alignment LOSSES (forward), SURVEY.md §8 row f-4.
+ *
+ * Reference: RefineNet.forward and the losses it calls,
+ *   /root/reference/main/global_refine/model/refine_net.py:123-127 (get_trajs_scales), :148-174 (get_frame_scaled_depth),
+ *   :252-268 (spatial huber term), :199-225 (inter_frame_loss, O(Q S N^2)), :300-345 (pts_3d_loss),
+ * driven by the Adam loop of model/trainer.py:23-77.  The reference is a Python/autograd module (pypose for the poses);
+ * it has no FFI.  This header is what a binding of those forward computations binds; batrack_amd/global_refine.py does
+ * so.  Forward values only (the optimiser's backward pass is not provided).  Device pointers, sizes, integer status
+ * codes (include/batrack_ba.h); nothing allocates or synchronises.
+ */
+#ifndef BATRACK_GA_H
+#define BATRACK_GA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int64_t T, N, S;               /* frames, tracks per frame, local window (slots per track)      */
+    int64_t gh, gw, H, W, Q;       /* scale grid, image size (refine_net.py:158-159), query frames */
+    const float *trajs_2d;         /* [T,N,S,2]                                                    */
+    const void *trajs_disp;        /* [T,N,S] float32, or float16 when half_disp                   */
+    const void *trajs_disp_mono;   /* [T,N,S] float32, or float16 when half_disp                   */
+    const float *trajs_vis;        /* [T,N,S]                                                      */
+    const float *trajs_static;     /* [T,N,S]                                                      */
+    const int64_t *jj;             /* [T,S] target frame of slot s, UNclamped (refine_net.py:92-97) */
+    const float *intrinsics;       /* [T,4] fx fy cx cy                                            */
+    const float *pose;             /* [T,7] tx ty tz qx qy qz qw (pypose SE3 layout)               */
+    const int64_t *query;          /* [Q] grid_query_frames                                        */
+    const float *trajs_scales;     /* [T,N,S] parameter (refine_net.py:42)                          */
+    const float *frame_scales;     /* [T,gh,gw] parameter, raw: exp(x / 10) is applied (scale_mode 'exp') */
+    const float *frame_shifts;     /* [T]                                                          */
+    float pw_break;                /* refine_net.py:39                                             */
+    int32_t half_disp;             /* 1: disparities are float16 and the depth residual of the spatial term is formed in
+                                      float16 (BASELINE.json configs[4]); everything else stays float32 */
+} bt_ga_args;
+
+/* mono_scaled_out [T,N,S] float32 = get_frame_scaled_depth(); losses[3] (device, float64) = spatial huber term,
+ * inter_frame_loss, pts_3d_loss — each the reference's mean.  `which` selects: bit 0 spatial (always computes
+ * mono_scaled_out), bit 1 inter-frame, bit 2 3-D points.  Enqueued on `stream`. */
+int bt_ga_forward(const bt_ga_args *args, float *mono_scaled_out, double *losses, int32_t which, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BATRACK_GA_H */

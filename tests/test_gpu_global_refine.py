@@ -1,0 +1,83 @@
+"""-m gpu: the dense global-alignment losses on the HIP kernels against the reference's vectors
+(tests/golden/ga_small.npz, produced by the unmodified refine_net.py) and against the float64 oracle on a larger case.
+Tolerances: float32 kernels vs float64 reference 2e-6 on the scaled depth, 1e-5 on the losses (sums of ~1e4..1e6 float32
+terms, float64 across workgroups); the float16 depth-residual variant 2e-3 (float16 has 11 bits)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ga_losses as ga
+
+pytestmark = pytest.mark.gpu
+D = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ga_small.npz")))
+
+
+def build(d, half=False):
+    from batrack_amd.global_refine import RefineLosses
+    t = lambda k: torch.as_tensor(np.asarray(d[k]), device="cuda:0")
+    return RefineLosses(t("trajs_2d"), t("trajs_disp"), t("trajs_disp_mono"), t("trajs_vis"), t("trajs_static"), t("jj"),
+                        t("intrinsics"), t("grid_query_frames"), t("trajs_scales"), t("frame_scales_"), t("frame_shifts"), t("pose"),
+                        int(d["H"]), int(d["W"]), float(d["pw_break"]), half_disp=half)
+
+
+def test_losses_match_the_reference_vectors():
+    net = build(D)
+    ms = net.get_frame_scaled_depth().cpu().numpy()
+    assert np.linalg.norm(ms - D["f64.mono_scaled"]) / np.linalg.norm(D["f64.mono_scaled"]) < 2e-6
+    l = net.losses().cpu().numpy()
+    for got, key in zip(l, ("f64.loss_spatial", "f64.loss_rigid", "f64.loss_pts3d")):
+        assert abs(got / D[key] - 1) < 1e-5, (key, got, D[key])
+    assert abs(float(net.forward(0.5)) / D["f64.total_alpha05"] - 1) < 1e-5
+    assert abs(float(net.forward(0.0)) / D["f64.loss_spatial"] - 1) < 1e-5
+
+
+def make_case(T, N, S, seed):
+    rng = np.random.default_rng(seed)
+    H, W, gh, gw = 436, 1024, 4, 4
+    jj = np.arange(T)[:, None] + np.arange(S)[None] - S // 2
+    disp = rng.uniform(0.05, 1.5, (T, N, S))
+    q = rng.standard_normal((T, 4)) * 0.03 + np.array([0, 0, 0, 1.0])
+    d = dict(trajs_2d=np.stack([rng.uniform(0, W - 1, (T, N, S)), rng.uniform(0, H - 1, (T, N, S))], -1), trajs_disp=disp,
+             trajs_disp_mono=disp * rng.uniform(0.8, 1.25, (T, 1, 1)) * (1 + 0.03 * rng.standard_normal((T, N, S))),
+             trajs_vis=rng.uniform(0.5, 1.0, (T, N, S)), trajs_static=rng.uniform(0.2, 1.0, (T, N, S)), jj=jj.astype(np.int64),
+             intrinsics=np.tile(np.array([500.0, 500.0, W / 2, H / 2]), (T, 1)),
+             pose=np.concatenate([rng.standard_normal((T, 3)) * 0.1, q / np.linalg.norm(q, axis=1, keepdims=True)], 1),
+             grid_query_frames=np.arange(0, T, 2).astype(np.int64), trajs_scales=rng.standard_normal((T, N, S)) * 0.2,
+             frame_scales_=rng.standard_normal((T, gh, gw)), frame_shifts=np.zeros(T), H=np.int64(H), W=np.int64(W), pw_break=np.float64(20.0))
+    return {k: (np.asarray(v, np.float32).astype(np.float64) if np.asarray(v).dtype == np.float64 and np.ndim(v) > 0 else v) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("T,N,S", [(12, 300, 7), (6, 520, 5)])
+def test_larger_cases_vs_oracle(T, N, S):
+    d = make_case(T, N, S, seed=T + N)
+    net = build(d)
+    l = net.losses().cpu().numpy()
+    ms = ga.frame_scaled_depth(d)
+    ref = (ga.spatial_loss(d, ms), ga.inter_frame_loss(d, ms), ga.pts_3d_loss(d, ms))
+    for got, want in zip(l, ref):
+        assert abs(got / want - 1) < 1e-5, (got, want)
+
+
+def test_float16_depth_residuals():
+    """BASELINE.json configs[4]: disparities stored in float16, the depth residual formed in float16."""
+    d = make_case(10, 256, 7, seed=5)
+    d16 = dict(d)
+    for k in ("trajs_disp", "trajs_disp_mono"):
+        d16[k] = d[k].astype(np.float16).astype(np.float64)            # the oracle sees exactly the float16 values
+    net = build(d16, half=True)
+    l = net.losses().cpu().numpy()
+    ms = ga.frame_scaled_depth(d16)
+    ref = (ga.spatial_loss(d16, ms), ga.inter_frame_loss(d16, ms), ga.pts_3d_loss(d16, ms))
+    assert abs(l[0] / ref[0] - 1) < 2e-3                              # residual rounded to float16
+    assert abs(l[1] / ref[1] - 1) < 1e-5 and abs(l[2] / ref[2] - 1) < 1e-5
+    assert net.trajs_disp.dtype == torch.float16
+
+
+def test_cpu_tensors_raise():
+    from batrack_amd.global_refine import RefineLosses
+    t = lambda k: torch.as_tensor(np.asarray(D[k]))
+    with pytest.raises(RuntimeError):
+        RefineLosses(t("trajs_2d"), t("trajs_disp"), t("trajs_disp_mono"), t("trajs_vis"), t("trajs_static"), t("jj"), t("intrinsics"),
+                     t("grid_query_frames"), t("trajs_scales"), t("frame_scales_"), t("frame_shifts"), t("pose"), 96, 128)

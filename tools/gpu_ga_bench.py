@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Timing of the dense global-alignment losses on a Sintel-sized case (market_5: 50 frames), the
+O(Q S N^2) rigidity kernel against the f32 vector peak: per pair 2 x (3 sub, 3 fma-class, 1 sqrt) + 1 sub + masks ~ 20 flop."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch
+from test_gpu_global_refine import make_case, build
+
+for T, N, S in ((50, 400, 12), (50, 1024, 12)):
+    d = make_case(T, N, S, seed=1)
+    d["grid_query_frames"] = np.arange(T).astype(np.int64)
+    for half in (False, True):
+        net = build(d, half=half)
+        for which, name in ((1, "scale+spatial"), (3, "+ pairwise"), (7, "+ pts3d")):
+            net._run(which); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                net._run(which)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / 50 * 1e6
+            print(f"T={T} N={N} S={S} half={half} {name:14s}: {us:9.1f} us per forward", flush=True)
+    pairs = T * (S - 1) * N * N
+    print(f"  pairwise work: {pairs/1e6:.1f} M pairs x ~20 flop = {pairs*20/1e9:.2f} GFLOP")
