@@ -240,7 +240,7 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     s.packed = reinterpret_cast<double *>(w + L.packed); s.qw = reinterpret_cast<float2 *>(w + L.qw);
     s.lfac = reinterpret_cast<float *>(w + L.lfac);
     s.linv = reinterpret_cast<float *>(w + L.linv); s.zvec = reinterpret_cast<float *>(w + L.zvec);
-    s.dx = reinterpret_cast<float *>(w + L.dx); s.status = reinterpret_cast<int *>(w + L.status);
+    s.dx = reinterpret_cast<float *>(w + L.dx); s.dx0 = reinterpret_cast<float *>(w + L.dx0); s.status = reinterpret_cast<int *>(w + L.status);
     static const int dbg = std::getenv("BT_DEBUG_MODE") ? std::atoi(std::getenv("BT_DEBUG_MODE")) : 0;
     s.dbg = dbg;
     return s;

@@ -1920,6 +1920,33 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
 #undef BT_TW
 }
 
+// ------------------------------------------------------------------ refinement of float32-factor solves
+// Systems whose factor does not fit LDS as double are factored in float32 (k_solve_lds<float>, k_solve_global): dX is then
+// 5e-5 .. 1e-4 off the exact solution of [S | y] — outside the parity contract.  One step of iterative refinement, only for
+// those systems: r = y - A dX0 in double from the S still in global memory (A = S + (ep + lm S) I, ba.py:67, with the lm the
+// first solve ended on), the same solver once more on r, dX = dX0 + delta.  A failed factorisation gives 0 + 0 (ba.py:9-13).
+__global__ __launch_bounds__(256) void k_refine_residual(PlanDev pd, StepArgs a) {
+    const int D = pd.D, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + w;
+    if (i >= D) return;
+    const double lm = a.status[0] == BT_SOLVE_RETRIED ? 1e-3 : 1e-4;
+    double acc = 0.0;
+    for (int j = lane; j < D; j += 64) {
+        double s = i >= j ? a.S[(size_t)i * D + j] : a.S[(size_t)j * D + i];            // S holds the lower triangle
+        if (i == j) s = s + ((double)a.ep + lm * s);
+        acc += s * (double)a.dx[j];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) a.y[i] = a.y[i] - acc;
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+        for (int k = threadIdx.x; k < D; k += 64) a.dx0[k] = a.dx[k];
+}
+
+__global__ __launch_bounds__(256) void k_refine_add(PlanDev pd, StepArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < pd.D) a.dx[k] = a.dx0[k] + a.dx[k];
+}
+
 // ------------------------------------------------------------------ k_update
 __device__ inline void retract_pose(const float *pin, const float *xi, float *pout) {
     // poses' = Exp(xi) * G  (groups.py:153-156; so3.h:153-190; se3.h:134-142), in double
@@ -2276,15 +2303,30 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int mode = solver_mode(pd);
         const bool prof = (a.dbg & 16) != 0;
         const int nthr = solver_threads();
-        if (mode == 0 && use_pipe_solver(pd) && !prof)  BT_LAUNCH(3, k_solve_pipe<false>, dim3(1), dim3(768), solve_pipe_lds_bytes(pd), pd, a);
-        else if (mode == 0 && use_pipe_solver(pd))      BT_LAUNCH(3, k_solve_pipe<true>, dim3(1), dim3(768), solve_pipe_lds_bytes(pd), pd, a);
-        else if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH(3, k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
-        else if (mode == 0 && use_fused_solver(pd))     BT_LAUNCH(3, k_solve_fused<true>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr), pd, a);
-        else if (mode == 0 && !prof) BT_LAUNCH(3, (k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
-        else if (mode == 0)          BT_LAUNCH(3, (k_solve_lds<double, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8), pd, a);
-        else if (mode == 1 && !prof) BT_LAUNCH(3, (k_solve_lds<float, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4), pd, a);
-        else if (mode == 1)          BT_LAUNCH(3, (k_solve_lds<float, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4), pd, a);
-        else                BT_LAUNCH(3, k_solve_global, dim3(1), dim3(1024), 0, pd, a);
+        static const int refine_env = std::getenv("BT_SOLVER_REFINE") ? std::atoi(std::getenv("BT_SOLVER_REFINE")) : 1;   // measurement only
+        const int passes = (mode >= 1 && refine_env) ? 2 : 1;        // float32 factor: one step of iterative refinement
+        for (int pass = 0; pass < passes; ++pass) {
+            if (pass == 1) hipLaunchKernelGGL(k_refine_residual, dim3((pd.D + 3) / 4), dim3(256), 0, st, pd, a);
+            hipEvent_t *evp = pass == 0 ? ev : nullptr;                // (the event pair of kernel 3 times the first pass)
+            unsigned *ranp = pass == 0 ? ran : nullptr;
+#define BT_LAUNCH_S(kern, grid, block, lds)                                                                                  \
+            do {                                                                                                             \
+                if (ranp) *ranp |= 1u << 3;                                                                                  \
+                if (evp) hipExtLaunchKernelGGL(kern, grid, block, lds, st, evp[6], evp[7], 0, pd, a);                        \
+                else hipLaunchKernelGGL(kern, grid, block, lds, st, pd, a);                                                  \
+            } while (0)
+            if (mode == 0 && use_pipe_solver(pd) && !prof)  BT_LAUNCH_S(k_solve_pipe<false>, dim3(1), dim3(768), solve_pipe_lds_bytes(pd));
+            else if (mode == 0 && use_pipe_solver(pd))      BT_LAUNCH_S(k_solve_pipe<true>, dim3(1), dim3(768), solve_pipe_lds_bytes(pd));
+            else if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH_S(k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr));
+            else if (mode == 0 && use_fused_solver(pd))     BT_LAUNCH_S(k_solve_fused<true>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr));
+            else if (mode == 0 && !prof) BT_LAUNCH_S((k_solve_lds<double, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8));
+            else if (mode == 0)          BT_LAUNCH_S((k_solve_lds<double, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 8));
+            else if (mode == 1 && !prof) BT_LAUNCH_S((k_solve_lds<float, false>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4));
+            else if (mode == 1)          BT_LAUNCH_S((k_solve_lds<float, true>), dim3(1), dim3(nthr), solve_lds_bytes(pd, 4));
+            else                BT_LAUNCH_S(k_solve_global, dim3(1), dim3(1024), 0);
+#undef BT_LAUNCH_S
+            if (pass == 1) hipLaunchKernelGGL(k_refine_add, dim3((pd.D + 255) / 256), dim3(256), 0, st, pd, a);
+        }
     }
     const int do_poses = so ? (copy_poses ? 1 : 0) : 1;
     const int total = pd.p_tot + (do_poses ? pd.n_buf : 0);

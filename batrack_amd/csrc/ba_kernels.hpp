@@ -17,7 +17,7 @@ struct StepArgs {
     double *S, *y, *pairacc;      // S, y, pairacc are contiguous (cleared together)
     double *packed;               // the non-zero blocks of [S | y] in factor order (multi-GPU exchange buffer)
     float2 *qw;
-    float *lfac, *linv, *zvec, *dx;
+    float *lfac, *linv, *zvec, *dx, *dx0;
     float *pairgeo;               // [pairs][kPairGeomFloats]: relative pose of every camera pair, left by k_tile for k_pair_finalize
     int *status;
     int dbg;                      // env BT_DEBUG_MODE, 0 in production: 16 / 32 launch the cycle-counting variants of the solver / k_tile

@@ -50,6 +50,7 @@ static void layout_workspace(bt_plan *pl) {
     w.linv = off;     off = align_up(off + (size_t)I.n * 36 * sizeof(float), 256);
     w.zvec = off;     off = align_up(off + D * sizeof(float), 256);
     w.dx = off;       off = align_up(off + D * sizeof(float) + 64, 256);
+    w.dx0 = off;      off = align_up(off + D * sizeof(float) + 64, 256);     // first solution of a refined solve (float32-factor systems)
     w.status = off;   off = align_up(off + 1024, 256);
     w.total = off;
     pl->ws = w;

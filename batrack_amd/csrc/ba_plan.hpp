@@ -57,7 +57,7 @@ struct PlanDev {
 // Byte offsets of the regions inside the caller's workspace.
 struct WsLayout {
     size_t sys, pairacc, zero_bytes;   // [sys, sys+zero_bytes) is cleared every reduce
-    size_t packed, pairgeo, qw, lfac, linv, zvec, dx, status, total;
+    size_t packed, pairgeo, qw, lfac, linv, zvec, dx, dx0, status, total;
 };
 
 }  // namespace bt

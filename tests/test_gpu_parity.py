@@ -99,7 +99,7 @@ def test_api_dual_iterations(name, fixedp):
 
 def test_strided_depth_prior_is_used_in_place():
     """The caller's prior is the view patches_local[:, :, mid, 2:] (batrack.py:866): stride S_local * 3 floats between
-    patches.  Same result, bit for bit, as a contiguous copy of it, and no copy is made (ABI field mono_stride)."""
+    patches.  Same result as a contiguous copy of it, and no copy is made (ABI field mono_stride)."""
     d = load("c1_rough")
     hp = HipProblem(d)
     P = hp.mono.shape[1]
@@ -113,7 +113,12 @@ def test_strided_depth_prior_is_used_in_place():
     b = hp.api_step("weights_pose", 2, False)
     hp.mono = contiguous
     torch.cuda.synchronize()
-    assert torch.equal(a[0].data, b[0].data) and torch.equal(a[1], b[1])
+    # (two executions differ by the order of their float64 atomics: last-bit noise, not a different prior)
+    assert rel(b[0].data.cpu().numpy(), a[0].data.cpu().numpy()) < 1e-6 and rel(b[1].cpu().numpy(), a[1].cpu().numpy()) < 1e-6
+    hp.mono = torch.zeros_like(contiguous)
+    c = hp.api_step("weights_pose", 2, False)                  # and the prior does matter
+    hp.mono = contiguous
+    assert rel(c[1].cpu().numpy(), a[1].cpu().numpy()) > 1e-4
 
 
 def test_per_track_lmbda_tensor():
@@ -290,9 +295,9 @@ def test_random_covisibility_graphs_vs_oracle(seed, N, M, fixedp, far, groups):
     # (fp32 per-edge residuals feed the robust weights; with a few hundred edges there is less averaging
     #  than in the fixtures, so S gets 2e-5 here; the state keeps the north-star tolerance)
     assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
-    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 2e-3
-    assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL
-    assert rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
+    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 1e-3       # (a few hundred edges: the float32 residuals average less)
+    assert rel(o["poses_out"], ref["poses_out"]) < 1e-5
+    assert rel(o["patches_out"], ref["patches_out"]) < 1e-5
 
 
 def test_largest_supported_system_vs_oracle():
@@ -308,9 +313,10 @@ def test_largest_supported_system_vs_oracle():
     o = HipProblem(d).raw_step("weights_pose", 1)
     assert o["plan"].n == 255 and o["status"] == 0
     assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
-    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 2e-2          # float32 factor for a system this size
-    assert rel(o["poses_out"], ref["poses_out"]) < 1e-4
-    assert rel(o["patches_out"], ref["patches_out"]) < 1e-4
+    # (float32 factor for a system this size, brought back inside the contract by one step of iterative refinement)
+    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < DX_TOL
+    assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL
+    assert rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
 
 
 def test_packed_exchange_form_roundtrip():
@@ -406,8 +412,8 @@ def test_track_seen_by_many_cameras_vs_oracle():
     o = HipProblem(d).raw_step("weights_pose", 1)
     assert o["plan"].max_tile_cams >= 38 and o["status"] == 0
     assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
-    assert rel(o["poses_out"], ref["poses_out"]) < 1e-4              # a 47-pose dense system: float32 factor in LDS or global memory
-    assert rel(o["patches_out"], ref["patches_out"]) < 1e-4
+    assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL         # a 47-pose dense system: float32 factor + one refinement step
+    assert rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
 
 
 def test_nan_in_solution_retries_with_larger_damping():
