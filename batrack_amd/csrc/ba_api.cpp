@@ -144,6 +144,24 @@ static hipStream_t copy_stream() {
     return s;
 }
 
+// Per host thread: device words + flag and their pinned host mirror for the packed edge list (grown, never shrunk)
+struct PackBuffers {
+    uint64_t *d_words = nullptr, *h_words = nullptr;
+    int *d_bad = nullptr, *h_bad = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap && d_words) return true;
+        if (d_words) { (void)hipFree(d_words); (void)hipHostFree(h_words); d_words = nullptr; h_words = nullptr; cap = 0; }
+        const size_t want = n + n / 4 + 4096;
+        if (hipMalloc(reinterpret_cast<void **>(&d_words), want * sizeof(uint64_t)) != hipSuccess) return false;
+        if (hipHostMalloc(reinterpret_cast<void **>(&h_words), want * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) return false;
+        if (!d_bad && hipMalloc(reinterpret_cast<void **>(&d_bad), sizeof(int)) != hipSuccess) return false;
+        if (!h_bad && hipHostMalloc(reinterpret_cast<void **>(&h_bad), sizeof(int), hipHostMallocDefault) != hipSuccess) return false;
+        cap = want;
+        return true;
+    }
+};
+
 static bool api_prof() { static const bool p = std::getenv("BT_PLAN_PROF") != nullptr; return p; }
 struct ApiTick {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -272,25 +290,29 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
                    int on_device, int upload, bt_plan **out) {
     if (!out || E < 0 || (E > 0 && (!ii || !jj || !kk))) return BT_EINVAL;
     *out = nullptr;
-    std::vector<int64_t> host;
-    const int64_t *hi = ii, *hj = jj, *hk = kk;
+    const uint64_t *packed = nullptr;
     ApiTick tick;
     if (on_device && E > 0) {
-        host.resize((size_t)(3 * E));
+        // packed and range-checked on the device (8 of the 24 bytes per edge cross PCIe), into a pinned host buffer
+        if (n_buf >= 65536 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;
+        static thread_local PackBuffers pb;
+        if (!pb.ensure((size_t)E)) return BT_ENOMEM;
         hipStream_t cs = copy_stream();
-        if (hipMemcpyAsync(host.data(), ii, (size_t)E * 8, hipMemcpyDeviceToHost, cs) != hipSuccess ||
-            hipMemcpyAsync(host.data() + E, jj, (size_t)E * 8, hipMemcpyDeviceToHost, cs) != hipSuccess ||
-            hipMemcpyAsync(host.data() + 2 * E, kk, (size_t)E * 8, hipMemcpyDeviceToHost, cs) != hipSuccess ||
+        if (hipMemsetAsync(pb.d_bad, 0, sizeof(int), cs) != hipSuccess ||
+            launch_pack_edges(ii, jj, kk, E, n_buf, p_tot, pb.d_words, pb.d_bad, cs) != BT_OK ||
+            hipMemcpyAsync(pb.h_words, pb.d_words, (size_t)E * sizeof(uint64_t), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+            hipMemcpyAsync(pb.h_bad, pb.d_bad, sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess ||
             hipStreamSynchronize(cs) != hipSuccess)
             return BT_EHIP;
-        hi = host.data(); hj = host.data() + E; hk = host.data() + 2 * E;
+        if (*pb.h_bad) return BT_EINVAL;
+        packed = pb.h_words;
         tick("D2H indices");
     }
     bt_plan *pl = plan_pool().take();
     if (!pl) return BT_ENOMEM;
     int rc = BT_OK;
     try {
-        rc = build_plan_host(hi, hj, hk, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl);
+        rc = build_plan_host(packed ? nullptr : ii, packed ? nullptr : jj, packed ? nullptr : kk, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed);
         tick("host analysis");
         if (rc == BT_OK && upload) rc = upload_plan(pl);
     } catch (const std::bad_alloc &) {
@@ -321,7 +343,13 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
     if (!pl || !name || !data) return -1;
 #define BT_ARR(n)                                                        \
     if (std::strcmp(name, #n) == 0) { *data = pl->n.data(); return (int64_t)pl->n.size(); }
-    BT_ARR(kx) BT_ARR(trk_of_patch) BT_ARR(trk_loc) BT_ARR(pair_i) BT_ARR(pair_j)
+    if (std::strcmp(name, "trk_of_patch") == 0) {            // kept for the window of patches only: expanded here (tests, tooling)
+        pl->trk_of_patch.assign((size_t)pl->info.p_tot, -1);
+        for (size_t i = 0; i < pl->trk_win.size(); ++i) pl->trk_of_patch[(size_t)pl->trk_win_lo + i] = pl->trk_win[i];
+        *data = pl->trk_of_patch.data();
+        return (int64_t)pl->trk_of_patch.size();
+    }
+    BT_ARR(kx) BT_ARR(trk_loc) BT_ARR(pair_i) BT_ARR(pair_j)
     BT_ARR(tile_trk0) BT_ARR(tile_ntrk) BT_ARR(tile_ncam) BT_ARR(tile_cam0) BT_ARR(tile_slot0)
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
     BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next) BT_ARR(perm) BT_ARR(blk_src) BT_ARR(lvl_ptr) BT_ARR(lvl_cols)

@@ -57,72 +57,120 @@ static void layout_workspace(bt_plan *pl) {
     pl->info.workspace_bytes = (int64_t)w.total;
 }
 
-int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+// Edges as the planner reads them: one 8-byte word per edge, kk << 32 | ii << 16 | jj (n_buf < 65536, p_tot < 2^31).
+// For index tensors on the device the words are packed (and range-checked) by a kernel and copied back in one piece —
+// a third of the bytes of the three int64 arrays (ba_api.cpp); host arrays are packed here.
+int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot, uint64_t *out) {
+    for (int64_t e = 0; e < E; ++e) {
+        if (ii[e] < 0 || jj[e] < 0 || ii[e] >= n_buf || jj[e] >= n_buf) return BT_EINVAL;
+        if (kk[e] < 0 || kk[e] >= p_tot) return BT_EINVAL;
+        out[e] = ((uint64_t)kk[e] << 32) | ((uint64_t)ii[e] << 16) | (uint64_t)jj[e];
+    }
+    return BT_OK;
+}
+
+int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk64, int64_t E,
                     int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
-                    int64_t own_lo, int64_t own_hi, bt_plan *pl) {
+                    int64_t own_lo, int64_t own_hi, bt_plan *pl, const uint64_t *packed) {
     if (E < 0 || n_buf <= 0 || p_tot <= 0 || fixedp < 0 || n_all_min < 0 || n_all_min > n_buf) return BT_EINVAL;
     if (E > (int64_t)0x7fffffff / 2 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;
+    if (n_buf >= 65536) return BT_EUNSUPPORTED;
     bt_plan_info &I = pl->info;
     I = bt_plan_info{};
     I.n_buf = n_buf; I.p_tot = p_tot; I.fixedp = fixedp;
     pl->e_all = E;
     if (own_hi <= 0) { own_lo = 0; own_hi = p_tot; }
     if (own_lo < 0 || own_hi > p_tot || own_lo > own_hi) return BT_EINVAL;
-    auto owned = [&](int64_t e) { return kk[e] >= own_lo && kk[e] < own_hi; };
     static const bool plan_prof = std::getenv("BT_PLAN_PROF") != nullptr;          // measurement only: time per phase on stderr
     auto t_prev = std::chrono::steady_clock::now();
 #define BT_TICK(name) do { if (plan_prof) { const auto t_now = std::chrono::steady_clock::now(); std::fprintf(stderr, "plan phase before %s: %.3f ms\n", name, std::chrono::duration<double, std::milli>(t_now - t_prev).count()); t_prev = t_now; } } while (0)
 
     BT_TICK("0");
-    // ---- n_all, validation (ba.py:219) ------------------------------------
+    static thread_local std::vector<uint64_t> pk_scratch;
+    const uint64_t *pk = packed;
+    if (!pk) {
+        pk_scratch.resize((size_t)E + 1);
+        const int rc = pack_edges_host(ii64, jj64, kk64, E, n_buf, p_tot, pk_scratch.data());
+        if (rc != BT_OK) return rc;
+        pk = pk_scratch.data();
+    }
+    auto KK = [&](int64_t e) { return (int64_t)(pk[e] >> 32); };
+    auto II = [&](int64_t e) { return (int64_t)((pk[e] >> 16) & 0xffff); };
+    auto JJ = [&](int64_t e) { return (int64_t)(pk[e] & 0xffff); };
+    auto owned = [&](int64_t e) { return KK(e) >= own_lo && KK(e) < own_hi; };
+
+    // ---- ONE pass over the edges: n_all (ba.py:219), the window of patches and frames they name, edges per track and per
+    // target frame, the camera pairs in use, and per track its source frame and the set of its target frames (a 64-bit mask
+    // around the first target seen: a track's observations span a window of frames, batrack.py:399-410)
+    struct PerPatch { int32_t cnt, src, base, last_j; uint64_t mask; };
+    static thread_local std::vector<PerPatch> pp_tab;            // indexed by patch; only [kmin, kmax] of the previous plan is dirty
+    static thread_local int64_t pp_lo = 0, pp_hi = -1;
+    if ((int64_t)pp_tab.size() < p_tot) { pp_tab.assign((size_t)p_tot, PerPatch{0, 0, 0, 0, 0}); pp_lo = 0; pp_hi = -1; }
+    for (int64_t p = pp_lo; p <= pp_hi; ++p) pp_tab[(size_t)p].cnt = 0;
+    PerPatch *pp = pp_tab.data();
     int64_t n_all = n_all_min, kmin = p_tot, kmax = -1;       // [kmin, kmax]: patches the edges name (a window of the buffer)
     int64_t f_lo = n_buf;                                     // first frame the edges name (the window's start, not the buffer's)
-    bool sorted = true;
+    bool sorted = true, masks_ok = true, mono_j = true;       // mono_j: within every track the target frames come in ascending order
+    std::vector<int32_t> cj((size_t)n_buf + 2, 0);
+    int64_t E_own = 0, k_prev = -1;
+    bool src_ok = true;
     for (int64_t e = 0; e < E; ++e) {
-        if (ii[e] < 0 || jj[e] < 0 || ii[e] >= n_buf || jj[e] >= n_buf) return BT_EINVAL;
-        if (kk[e] < 0 || kk[e] >= p_tot) return BT_EINVAL;
-        n_all = std::max(n_all, std::max(ii[e], jj[e]) + 1);
-        f_lo = std::min(f_lo, std::min(ii[e], jj[e]));
-        kmin = std::min(kmin, kk[e]); kmax = std::max(kmax, kk[e]);
-        if (e && kk[e] < kk[e - 1]) sorted = false;
+        const int64_t k = KK(e), i = II(e), j = JJ(e);
+        n_all = std::max(n_all, std::max(i, j) + 1);
+        f_lo = std::min(f_lo, std::min(i, j));
+        kmin = std::min(kmin, k); kmax = std::max(kmax, k);
+        if (k < k_prev) sorted = false;
+        k_prev = k;
+        if (k < own_lo || k >= own_hi) continue;
+        ++E_own;
+        ++cj[(size_t)j + 1];
+        PerPatch &t = pp[k];
+        if (t.cnt++ == 0) { t.src = (int32_t)i; t.base = (int32_t)j - 32; t.mask = 0; }
+        else { if (t.src != (int32_t)i) src_ok = false; if ((int32_t)j < t.last_j) mono_j = false; }
+        t.last_j = (int32_t)j;          // one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)
+        const int64_t bit = j - t.base;
+        if (bit < 0 || bit >= 64) masks_ok = false; else t.mask |= 1ull << bit;
     }
+    pp_lo = kmin; pp_hi = kmax;
+    if (E == 0) f_lo = 0;
     I.n_all = n_all;
     I.sorted_input = sorted ? 1 : 0;
     const int64_t n = std::max<int64_t>(n_all - fixedp, 0);
     I.n = n;
     if (n > kMaxFree) return BT_EUNSUPPORTED;
+    if (!src_ok) return BT_EUNSUPPORTED;
+    I.E = E_own;
 
     BT_TICK("1");
-    // ---- one pass over the edges: edges per track, per target frame, and the camera pairs in use
-    pl->trk_of_patch.assign((size_t)p_tot, -1);
-    for (int64_t p = kmin; p <= kmax; ++p) pl->trk_of_patch[(size_t)p] = 0;
-    // camera pairs are looked up in a table over the frames the edges name, [f_lo, n_all): the window (about 20 frames),
-    // not the keyframe count of the whole sequence
-    if (E == 0) f_lo = 0;
-    const int64_t nw = n_all - f_lo;
-    std::vector<int32_t> pair_of((size_t)(nw * nw), -1), cj((size_t)n_all + 1, 0);
-    int64_t E_own = 0;
-    for (int64_t e = 0; e < E; ++e)
-        if (owned(e)) {
-            ++pl->trk_of_patch[(size_t)kk[e]];
-            pair_of[(size_t)((ii[e] - f_lo) * nw + (jj[e] - f_lo))] = 0;
-            ++cj[(size_t)jj[e] + 1];
-            ++E_own;
-        }
-    I.E = E_own;
-    // unique tracks, ascending (ba.py:276); off = first position of a track's edges in the grouped order
+    // unique tracks, ascending (ba.py:276); off = first position of a track's edges in the grouped order.
+    // trk_of_patch is kept for the window only (trk_win[p - kmin]); bt_plan_array expands it on request.
     int32_t m = 0;
     pl->kx.clear();
+    pl->trk_win_lo = kmin <= kmax ? kmin : 0;
+    pl->trk_win.assign(kmin <= kmax ? (size_t)(kmax - kmin + 1) : 0, -1);
     std::vector<int32_t> off(1, 0);
     for (int64_t p = kmin; p <= kmax; ++p) {
-        const int32_t c = pl->trk_of_patch[(size_t)p];
-        if (c > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + c); pl->trk_of_patch[(size_t)p] = m++; }
-        else pl->trk_of_patch[(size_t)p] = -1;
+        const int32_t c = pp[p].cnt;
+        if (c > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + c); pl->trk_win[(size_t)(p - kmin)] = m++; }
     }
     I.m = m;
+    auto trk_of = [&](int64_t k) { return pl->trk_win[(size_t)(k - kmin)]; };
 
     BT_TICK("2");
-    // ---- distinct camera pairs, ascending (i, j) ---------------------------
+    // ---- distinct camera pairs, ascending (i, j); looked up through a table over the frames the edges name, [f_lo, n_all):
+    // the window (about 20 frames), not the keyframe count of the whole sequence
+    const int64_t nw = n_all - f_lo;
+    std::vector<int32_t> pair_of((size_t)(nw * nw), -1);
+    if (masks_ok) {
+        // from the tracks' (source frame, target mask): a few thousand tracks instead of every edge
+        for (int32_t k = 0; k < m; ++k) {
+            const PerPatch &t = pp[pl->kx[(size_t)k]];
+            int32_t *row = pair_of.data() + (size_t)(t.src - f_lo) * nw - f_lo;
+            for (uint64_t mk = t.mask; mk; mk &= mk - 1) row[t.base + __builtin_ctzll(mk)] = 0;
+        }
+    } else {
+        for (int64_t e = 0; e < E; ++e) if (owned(e)) pair_of[(size_t)((II(e) - f_lo) * nw + (JJ(e) - f_lo))] = 0;
+    }
     pl->pair_i.clear(); pl->pair_j.clear();
     for (int64_t key = 0; key < nw * nw; ++key)
         if (pair_of[(size_t)key] == 0) {
@@ -135,7 +183,7 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     BT_TICK("3");
     // ---- edges grouped by track, ordered by (pair, original index) ---------
     // Two stable counting passes instead of a sort per track: first by target frame, then by track.  Within a
-    // track the source frame is the same for all edges (checked below), so ascending target frame IS ascending
+    // track the source frame is the same for all edges (checked above), so ascending target frame IS ascending
     // pair id, and stability keeps the original index as the tie-break (duplicates are normal, batrack.py:399-410).
     // (edge-sized temporaries persist per thread: the caller builds one plan per frame, and fresh pages cost more
     // than the passes over them)
@@ -143,13 +191,22 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     std::vector<int32_t> &ord = ord_scratch, &byj = byj_scratch;
     ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1);
     std::vector<int32_t> cur(off.begin(), off.end() - 1);
-    for (int64_t j = 0; j < n_all; ++j) cj[(size_t)j + 1] += cj[(size_t)j];
-    for (int64_t e = 0; e < E; ++e) if (owned(e)) byj[(size_t)cj[(size_t)jj[e]]++] = (int32_t)e;
-    for (int64_t q = 0; q < E_own; ++q) {
-        const int32_t e = byj[(size_t)q];
-        ord[(size_t)cur[(size_t)pl->trk_of_patch[(size_t)kk[e]]]++] = e;
+    if (mono_j) {
+        // every track's edges already come in (target frame, index) order: one stable scatter by track
+        for (int64_t e = 0; e < E; ++e) if (E_own == E || owned(e)) ord[(size_t)cur[(size_t)trk_of(KK(e))]++] = (int32_t)e;
+    } else {
+        for (int64_t j = 0; j < n_all; ++j) cj[(size_t)j + 1] += cj[(size_t)j];
+        if (E_own == E) {
+            for (int64_t e = 0; e < E; ++e) byj[(size_t)cj[(size_t)JJ(e)]++] = (int32_t)e;
+        } else {
+            for (int64_t e = 0; e < E; ++e) if (owned(e)) byj[(size_t)cj[(size_t)JJ(e)]++] = (int32_t)e;
+        }
+        for (int64_t q = 0; q < E_own; ++q) {
+            const int32_t e = byj[(size_t)q];
+            ord[(size_t)cur[(size_t)trk_of(KK(e))]++] = e;
+        }
     }
-    auto pair_id = [&](int32_t e) { return pair_of[(size_t)((ii[e] - f_lo) * nw + (jj[e] - f_lo))]; };
+    auto pair_id = [&](int32_t e) { return pair_of[(size_t)((II(e) - f_lo) * nw + (JJ(e) - f_lo))]; };
 
     BT_TICK("4");
     // ---- tiles: greedy over sorted tracks ----------------------------------
@@ -183,13 +240,22 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     };
     for (int32_t k = 0; k < m; ++k) {
         trk_set.clear();
-        const int64_t src = off[(size_t)k] < off[(size_t)k + 1] ? ii[ord[(size_t)off[(size_t)k]]] : 0;
-        for (int32_t s = off[(size_t)k]; s < off[(size_t)k + 1]; ++s) {
-            const int32_t e = ord[(size_t)s];
-            if (ii[e] != src) return BT_EUNSUPPORTED;      // one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)
-            const int64_t cams[2] = { ii[e] - fixedp, jj[e] - fixedp };
-            for (int64_t c : cams)
+        if (masks_ok) {
+            // the track's free cameras from its source frame and target mask (no walk over its edges)
+            const PerPatch &t = pp[pl->kx[(size_t)k]];
+            const int64_t cs = (int64_t)t.src - fixedp;
+            if (cs >= 0) { tstamp[(size_t)cs] = k; trk_set.push_back((int32_t)cs); }
+            for (uint64_t mk = t.mask; mk; mk &= mk - 1) {
+                const int64_t c = (int64_t)t.base + __builtin_ctzll(mk) - fixedp;
                 if (c >= 0 && tstamp[(size_t)c] != k) { tstamp[(size_t)c] = k; trk_set.push_back((int32_t)c); }
+            }
+        } else {
+            for (int32_t sidx = off[(size_t)k]; sidx < off[(size_t)k + 1]; ++sidx) {
+                const int32_t e = ord[(size_t)sidx];
+                const int64_t cams[2] = { II(e) - fixedp, JJ(e) - fixedp };
+                for (int64_t c : cams)
+                    if (c >= 0 && tstamp[(size_t)c] != k) { tstamp[(size_t)c] = k; trk_set.push_back((int32_t)c); }
+            }
         }
         if ((int)trk_set.size() > kTileCamHard) return BT_EUNSUPPORTED;
         int add = 0;
@@ -204,46 +270,55 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
     pl->max_rows16 = (int)((6 * max_cams + 1 + 15) / 16 * 16);
 
     BT_TICK("6");
-    // ---- slot arrays [slots][64] -------------------------------------------
+    // ---- per tile: its distinct camera pairs (their relative pose is computed once per tile), then the slot arrays
+    // [slots][64] with the local pair index of every edge, in one walk over the tile's edges
     pl->slot_edge.assign((size_t)slots * kLanes, -1);
     pl->slot_pair.assign((size_t)slots * kLanes, 0);
     pl->slot_lab.assign((size_t)slots * kLanes, 0xffff);
-    std::vector<int32_t> local((size_t)n + 1, -1);
-    for (int32_t t = 0; t < T; ++t) {
-        const int32_t c0 = pl->tile_cam0[(size_t)t], nc = pl->tile_ncam[(size_t)t];
-        for (int32_t c = 0; c < nc; ++c) local[(size_t)pl->tile_cams[(size_t)(c0 + c)]] = c;
-        for (int32_t l = 0; l < pl->tile_ntrk[(size_t)t]; ++l) {
-            const int32_t k = pl->tile_trk0[(size_t)t] + l;
-            for (int32_t s = off[(size_t)k]; s < off[(size_t)k + 1]; ++s) {
-                const int32_t e = ord[(size_t)s];
-                const size_t idx = ((size_t)pl->tile_slot0[(size_t)t] + (size_t)(s - off[(size_t)k])) * kLanes + (size_t)l;
-                const int64_t a = ii[e] - fixedp, b = jj[e] - fixedp;
-                const uint16_t la = a >= 0 ? (uint16_t)local[(size_t)a] : 0xff;
-                const uint16_t lb = b >= 0 ? (uint16_t)local[(size_t)b] : 0xff;
-                pl->slot_edge[idx] = e;
-                pl->slot_pair[idx] = pair_id(e);
-                pl->slot_lab[idx] = (uint16_t)(la | (lb << 8));
-            }
-        }
-    }
-
-    BT_TICK("7");
-    // ---- distinct camera pairs of every tile (their relative pose is computed once per tile)
+    pl->slot_lp.assign((size_t)slots * kLanes, 0);
     pl->tile_pair0.assign((size_t)T, 0); pl->tile_npair.assign((size_t)T, 0);
     pl->tile_pairs.clear();
-    pl->slot_lp.assign((size_t)slots * kLanes, 0);
     pl->max_tile_pairs = 0;
     {
-        std::vector<int32_t> lp_of(pl->pair_i.size(), -1), mine;
+        std::vector<int32_t> local((size_t)n + 1, -1), lp_of(pl->pair_i.size(), -1), mine;
         for (int32_t t = 0; t < T; ++t) {
+            const int32_t c0 = pl->tile_cam0[(size_t)t], nc = pl->tile_ncam[(size_t)t], t0 = pl->tile_trk0[(size_t)t], nt = pl->tile_ntrk[(size_t)t];
+            for (int32_t c = 0; c < nc; ++c) local[(size_t)pl->tile_cams[(size_t)(c0 + c)]] = c;
             mine.clear();
-            const size_t b0 = (size_t)pl->tile_slot0[(size_t)t] * kLanes, b1 = b0 + (size_t)pl->tile_nslot[(size_t)t] * kLanes;
-            for (size_t i = b0; i < b1; ++i)
-                if (pl->slot_edge[i] >= 0 && lp_of[(size_t)pl->slot_pair[i]] < 0) { lp_of[(size_t)pl->slot_pair[i]] = 0; mine.push_back(pl->slot_pair[i]); }
+            if (masks_ok) {
+                for (int32_t l = 0; l < nt; ++l) {
+                    const PerPatch &tp = pp[pl->kx[(size_t)(t0 + l)]];
+                    const int32_t *row = pair_of.data() + (size_t)(tp.src - f_lo) * nw - f_lo;
+                    for (uint64_t mk = tp.mask; mk; mk &= mk - 1) {
+                        const int32_t gp = row[tp.base + __builtin_ctzll(mk)];
+                        if (lp_of[(size_t)gp] < 0) { lp_of[(size_t)gp] = 0; mine.push_back(gp); }
+                    }
+                }
+            } else {
+                for (int32_t q = off[(size_t)t0]; q < off[(size_t)(t0 + nt)]; ++q) {
+                    const int32_t gp = pair_id(ord[(size_t)q]);
+                    if (lp_of[(size_t)gp] < 0) { lp_of[(size_t)gp] = 0; mine.push_back(gp); }
+                }
+            }
             std::sort(mine.begin(), mine.end());
             if ((int)mine.size() > kMaxTilePairs) return BT_EUNSUPPORTED;
             for (size_t q = 0; q < mine.size(); ++q) lp_of[(size_t)mine[q]] = (int32_t)q;
-            for (size_t i = b0; i < b1; ++i) if (pl->slot_edge[i] >= 0) pl->slot_lp[i] = (uint8_t)lp_of[(size_t)pl->slot_pair[i]];
+            for (int32_t l = 0; l < nt; ++l) {
+                const int32_t k = t0 + l;
+                for (int32_t sidx = off[(size_t)k]; sidx < off[(size_t)k + 1]; ++sidx) {
+                    const int32_t e = ord[(size_t)sidx];
+                    const size_t idx = ((size_t)pl->tile_slot0[(size_t)t] + (size_t)(sidx - off[(size_t)k])) * kLanes + (size_t)l;
+                    const int64_t i = II(e), j = JJ(e);
+                    const int64_t a = i - fixedp, b = j - fixedp;
+                    const uint16_t la = a >= 0 ? (uint16_t)local[(size_t)a] : 0xff;
+                    const uint16_t lb = b >= 0 ? (uint16_t)local[(size_t)b] : 0xff;
+                    const int32_t gp = pair_of[(size_t)((i - f_lo) * nw + (j - f_lo))];
+                    pl->slot_edge[idx] = e;
+                    pl->slot_pair[idx] = gp;
+                    pl->slot_lab[idx] = (uint16_t)(la | (lb << 8));
+                    pl->slot_lp[idx] = (uint8_t)lp_of[(size_t)gp];
+                }
+            }
             pl->tile_pair0[(size_t)t] = (int32_t)pl->tile_pairs.size();
             pl->tile_npair[(size_t)t] = (int32_t)mine.size();
             pl->tile_pairs.insert(pl->tile_pairs.end(), mine.begin(), mine.end());
@@ -287,18 +362,18 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         // sharded: tracks owned by other ranks contribute blocks to the all-reduced system too.
         // Their pattern: every camera pair of an edge, and all pairs among the free cameras of a track.
         std::vector<int32_t> toff((size_t)p_tot + 1, 0);
-        for (int64_t e = 0; e < E; ++e) if (!owned(e)) toff[(size_t)kk[e] + 1]++;
+        for (int64_t e = 0; e < E; ++e) if (!owned(e)) toff[(size_t)KK(e) + 1]++;
         for (int64_t p = 0; p < p_tot; ++p) toff[(size_t)p + 1] += toff[(size_t)p];
         std::vector<int32_t> tord((size_t)(E - E_own) + 1), tcur(toff.begin(), toff.end() - 1);
-        for (int64_t e = 0; e < E; ++e) if (!owned(e)) tord[(size_t)tcur[(size_t)kk[e]]++] = (int32_t)e;
+        for (int64_t e = 0; e < E; ++e) if (!owned(e)) tord[(size_t)tcur[(size_t)KK(e)]++] = (int32_t)e;
         std::vector<int32_t> cset;
         for (int64_t p = 0; p < p_tot; ++p) {
             if (toff[(size_t)p] == toff[(size_t)p + 1]) continue;
             cset.clear();
             for (int32_t q = toff[(size_t)p]; q < toff[(size_t)p + 1]; ++q) {
                 const int32_t e = tord[(size_t)q];
-                if (ii[e] >= fixedp) cset.push_back((int32_t)(ii[e] - fixedp));
-                if (jj[e] >= fixedp) cset.push_back((int32_t)(jj[e] - fixedp));
+                if (II(e) >= fixedp) cset.push_back((int32_t)(II(e) - fixedp));
+                if (JJ(e) >= fixedp) cset.push_back((int32_t)(JJ(e) - fixedp));
             }
             std::sort(cset.begin(), cset.end());
             cset.erase(std::unique(cset.begin(), cset.end()), cset.end());
@@ -653,7 +728,6 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
             for (int32_t ln = 0; ln < pl->tile_ntrk[(size_t)t]; ++ln)
                 pl->tile_kx[(size_t)t * kLanes + (size_t)ln] = pl->kx[(size_t)(pl->tile_trk0[(size_t)t] + ln)];
         }
-        if (n_buf >= 65536) return BT_EUNSUPPORTED;
     }
 
     // ---- compact tables of the wave-per-tile kernels (k_stream): per (slot, lane) a 16-bit code

@@ -64,7 +64,10 @@ struct WsLayout {
 
 struct bt_plan {
     bt_plan_info info{};
-    std::vector<int32_t> kx, trk_of_patch, trk_loc, act_rank;      // trk_of_patch, trk_loc: host only
+    std::vector<int32_t> kx, trk_loc, act_rank;                    // trk_loc: host only
+    std::vector<int32_t> trk_win;                                  // track of patch trk_win_lo + i (-1: none): the window of patches the edges name
+    int64_t trk_win_lo = 0;
+    mutable std::vector<int32_t> trk_of_patch;                     // the same over the whole patch buffer, expanded on request (bt_plan_array: tests)
     std::vector<uint32_t> act_bits;
     std::vector<char> stage;     // upload staging (kept with the object: ba_api.cpp)
     std::vector<int32_t> pair_i, pair_j;
@@ -99,7 +102,7 @@ struct bt_plan {
     // by bt_plan_create (ba_api.cpp), so that a plan per frame costs no heap traffic.
     void recycle() {
         info = bt_plan_info{};
-        for (auto *v : {&kx, &trk_of_patch, &trk_loc, &pair_i, &pair_j, &tile_trk0, &tile_ntrk, &tile_ncam,
+        for (auto *v : {&kx, &trk_of_patch, &trk_win, &trk_loc, &pair_i, &pair_j, &tile_trk0, &tile_ntrk, &tile_ncam,
                         &tile_cam0, &tile_slot0, &tile_nslot, &tile_erow0, &tile_cams, &slot_edge, &slot_pair,
                         &tile_pair0, &tile_npair, &tile_pairs, &tile_flags, &tile_ij, &tile_kx, &col_ptr, &row_idx,
                         &upd_ptr, &upd, &blk_col, &upd_next, &perm, &blk_src, &lvl_ptr, &lvl_cols, &col_lvl, &dp_ptr,
@@ -123,9 +126,14 @@ namespace bt {
 int edge_min_tiles();
 int stream_min_tiles();
 // Pure host analysis (no HIP).  Returns BT_OK or an error code.
+// `packed` (optional): the edges as 8-byte words kk << 32 | ii << 16 | jj, already range-checked (ii / jj / kk are then not read)
 int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
                     int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
-                    int64_t own_lo, int64_t own_hi, bt_plan *plan);
+                    int64_t own_lo, int64_t own_hi, bt_plan *plan, const uint64_t *packed = nullptr);
+// the same packing on the device (plan_pack.hip): `out` E words and `bad` one int (set to 1 on an index out of range), device memory
+int launch_pack_edges(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
+                      uint64_t *out, int *bad, void *stream);
+int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot, uint64_t *out);
 // Copies the arrays to the device and fills plan->dev (ba_api.cpp).
 int upload_plan(bt_plan *plan);
 }  // namespace bt
