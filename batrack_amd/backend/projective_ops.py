@@ -5,16 +5,14 @@ magnitude for keyframing (:1017), back-projection helpers (:440-518).
 
 Row f-3 of SURVEY.md §8.  Tensor layout follows the caller: poses SE3 [1,N,7], patches
 [1,P,3,p,p] = (x, y, inverse depth), intrinsics [1,N,4] = (fx fy cx cy), index vectors
-ii/jj/kk [E].  The SE3 group operations run the HIP kernels of se3_kernels.hip when the data
-is on the GPU; the pinhole arithmetic around them is plain tensor code.  The Jacobian variant
+ii/jj/kk [E].  The SE3 group operations are those of the pose object handed in (the HIP kernels of
+se3_kernels.hip for batrack_amd's SE3); the pinhole arithmetic around them is plain tensor code, as in the reference.  The Jacobian variant
 is kept for API completeness and for tests against the golden vectors — inside the BA step the
 same quantities are produced by k_tile without being materialised.
 """
 import ctypes
 
 import torch
-
-from .lietorch import SE3
 
 MIN_DEPTH = 0.2
 
@@ -91,7 +89,7 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     if tonly:                                                  # translation-only motion (flow_mag)
         data = Gij.data.clone()
         data[..., 3:] = torch.as_tensor([0.0, 0.0, 0.0, 1.0], dtype=data.dtype, device=data.device)
-        Gij = SE3(data)
+        Gij = type(Gij)(data)
     X1 = Gij[:, :, None, None] * X0
     x1 = proj(X1, intrinsics[:, jj], depth)
 

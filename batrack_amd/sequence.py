@@ -100,12 +100,15 @@ class WindowedBA:
     BATRACK object where they exist: n, m, M, N, poses_, patches_, ii, jj, kk, targets_3d,
     weights, weights_pose)."""
 
-    def __init__(self, obs, ba, cfg=None, device="cpu", sync=None, prefetch=None):
-        """prefetch: optional `batrack_amd.backend.ba.prefetch_plan`; it is called where the reference knows the
+    def __init__(self, obs, ba, cfg=None, device="cpu", sync=None, prefetch=None, se3=SE3):
+        """se3: the pose class (default: the HIP-backed batrack_amd.backend.lietorch.SE3, GPU tensors only; the CPU-side
+        tests of this loop pass the test oracle's torch formulas (SE3Ref) together with the oracle `ba`).
+        prefetch: optional `batrack_amd.backend.ba.prefetch_plan`; it is called where the reference knows the
         edge list of the coming update() — after `append_factors` (before the tracker pass that `predict_target`
         stands for) and after `keyframe_simple` when the next frame appends nothing."""
         self.obs, self.ba, self.device = obs, ba, torch.device(device)
         self.prefetch = prefetch
+        self.SE3 = se3
         self.cfg = cfg or SlamConfig(PATCHES_PER_FRAME=obs.M, BUFFER_SIZE=obs.n_frames + 1)
         c = self.cfg
         if c.PATCHES_PER_FRAME != obs.M or c.BUFFER_SIZE < obs.n_frames + 1:
@@ -144,6 +147,7 @@ class WindowedBA:
     # ---- batrack.py:176-187
     def init_motion(self):
         if self.n > 1:
+            SE3 = self.SE3
             P1 = SE3(self.poses_[self.n - 1][None])
             P2 = SE3(self.poses_[self.n - 2][None])
             xi = self.cfg.MOTION_DAMPING * (P1 * P2.inv()).log()
@@ -197,7 +201,7 @@ class WindowedBA:
 
     # ---- batrack.py:327-338
     def map_point_filtering(self):
-        coords = pops.transform(SE3(self.poses), self.patches, self.intrinsics, self.ii, self.jj, self.kk)
+        coords = pops.transform(self.SE3(self.poses), self.patches, self.intrinsics, self.ii, self.jj, self.kk)
         err = torch.norm(coords[:, :, 0, 0] - self.targets_3d[..., :2], dim=-1)
         bad = ~(err < self.cfg.MAP_FILTERING_TH)
         self.stats["filtered"] += int((bad & (self.weights[..., 0] > 0)).sum())
@@ -210,7 +214,7 @@ class WindowedBA:
         t0 = max(self.n - c.OPTIMIZATION_WINDOW if self.is_initialized else 1, 1)
         ep, lmbda = 10, 1e-4
         bounds = [0, 0, self.wd, self.ht]
-        Gs = SE3(self.poses)
+        Gs = self.SE3(self.poses)
         patches = self.patches
         mono = self.monodisp_.view(1, self.N * self.M, 1)
         self._sync()
@@ -277,7 +281,7 @@ class WindowedBA:
         """`cams_T_world` [n,4,4] (inverse pose matrices), `intrinsics` [n,4], `tstamps` [n] with the reference's
         keys and layout.  The tracker-owned entries of results.pkl (`trajs_2d_disp`, `trajs_valid`, `trajs_static`,
         `trajs_vis`, `grid_query_frames`, `dmaps`, `rgbs`) have no counterpart in this replay and are not emitted."""
-        G = SE3(self.poses_[:self.n])
+        G = self.SE3(self.poses_[:self.n])
         return {"cams_T_world": G.inv().matrix().detach().cpu().numpy(),
                 "intrinsics": self.intrinsics_[:self.n].detach().cpu().numpy(),
                 "tstamps": np.arange(self.n, dtype=float)}

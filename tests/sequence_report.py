@@ -18,6 +18,7 @@ from batrack_amd import evaluation  # noqa: E402
 from batrack_amd.hostenv import limit_host_threads  # noqa: E402
 from batrack_amd.sequence import SlamConfig, SyntheticObservations, WindowedBA  # noqa: E402
 from sequence_util import oracle_BA_rgbd_droid  # noqa: E402
+from oracle.se3_torch import SE3Ref  # noqa: E402
 
 limit_host_threads()
 ap = argparse.ArgumentParser()
@@ -37,7 +38,7 @@ for name, ba, dev in (("hip", BA_rgbd_droid, "cuda:0"), ("hip+prefetch", BA_rgbd
     for rep in range(2 if name.startswith("hip") else 1):            # second HIP run: warm allocator / code objects
         obs = SyntheticObservations(n_frames=args.frames, M=args.M, seed=args.seed)
         trk = WindowedBA(obs, ba, SlamConfig(PATCHES_PER_FRAME=args.M, BUFFER_SIZE=max(args.buffer, args.frames + 1)), device=dev,
-                         prefetch=prefetch_plan if name == "hip+prefetch" else None)
+                         prefetch=prefetch_plan if name == "hip+prefetch" else None, **({} if dev != "cpu" else dict(se3=SE3Ref)))
         t0 = time.perf_counter()
         poses = trk.run()
         wall = time.perf_counter() - t0

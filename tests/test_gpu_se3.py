@@ -1,5 +1,5 @@
 """-m gpu: the element-wise SE3 HIP kernels (include/batrack_se3.h, row f-1 of SURVEY.md §8)
-against the float64 torch formulas of the SE3 wrapper on CPU, plus the identities of the
+against the float64 torch formulas of oracle/se3_torch.py on the CPU, plus the identities of the
 reference's own test script (lietorch/run_tests.py:16-52) evaluated on the device."""
 import numpy as np
 import pytest
@@ -7,6 +7,7 @@ import torch
 
 from batrack_amd.backend import lietorch_backends as lb
 from batrack_amd.backend.lietorch import SE3
+from oracle.se3_torch import SE3Ref
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -22,15 +23,15 @@ def test_ops_match_cpu_float64(dtype, tol):
     B = 4099
     a = (0.7 * torch.randn(B, 6, dtype=torch.float64)).to(dtype)
     a[:5] *= 1e-8                                            # small-angle branch
-    X = SE3.exp(cpu64(a))
-    Y = SE3.exp(0.5 * torch.randn(B, 6, dtype=torch.float64))
+    X = SE3Ref.exp(cpu64(a))
+    Y = SE3Ref.exp(0.5 * torch.randn(B, 6, dtype=torch.float64))
     p4 = torch.randn(B, 4, dtype=torch.float64)
     v6 = torch.randn(B, 6, dtype=torch.float64)
     g = lambda t: t.to(dtype).to(DEV).contiguous()
     Xg, Yg = g(X.data), g(Y.data)
-    Xr, Yr = SE3(cpu64(Xg)), SE3(cpu64(Yg))                 # reference on the same rounded inputs
+    Xr, Yr = SE3Ref(cpu64(Xg)), SE3Ref(cpu64(Yg))                 # reference on the same rounded inputs
     rel = lambda got, ref: float((cpu64(got) - ref).norm() / ref.norm())
-    assert rel(lb.expm(3, g(a)), SE3.exp(cpu64(g(a))).data) < tol
+    assert rel(lb.expm(3, g(a)), SE3Ref.exp(cpu64(g(a))).data) < tol
     assert rel(lb.inv(3, Xg), Xr.inv().data) < tol
     assert rel(lb.mul(3, Xg, Yg), (Xr * Yr).data) < tol
     assert rel(lb.act4(3, Xg, g(p4)), Xr.act(cpu64(g(p4)))) < tol
@@ -70,7 +71,7 @@ def test_wrapper_broadcasts_like_the_reference():
     X0 = torch.randn(1, 40, 3, 3, 4, device=DEV)
     X1 = Gij[:, :, None, None] * X0
     assert tuple(X1.shape) == (1, 40, 3, 3, 4)
-    Pc = SE3(P.data.cpu().double())
+    Pc = SE3Ref(P.data.cpu().double())
     Gc = Pc[:, jj.cpu()] * Pc[:, ii.cpu()].inv()
     X1c = Gc[:, :, None, None] * X0.cpu().double()
     assert float((X1.cpu().double() - X1c).abs().max()) < 2e-5
@@ -86,3 +87,7 @@ def test_rejects_other_groups_and_cpu_tensors():
         lb.inv(3, x.cpu())
     with pytest.raises(NotImplementedError):
         lb.inv_backward(3, x, x)
+    with pytest.raises(RuntimeError):
+        SE3(x.cpu()).inv()                                   # the wrapper has no host path either
+    with pytest.raises(RuntimeError):
+        SE3.exp(torch.zeros(2, 6))

@@ -7,6 +7,7 @@ import torch
 
 from batrack_amd import evaluation
 from batrack_amd.sequence import SlamConfig, SyntheticObservations, WindowedBA
+from oracle.se3_torch import SE3Ref
 from sequence_util import oracle_BA_rgbd_droid
 
 pytestmark = pytest.mark.gpu
@@ -19,7 +20,7 @@ def run_pair(n_frames, M, seed, cfg_kw=None, cam=None):
         kw = {} if cam is None else dict(cam=cam)
         obs = SyntheticObservations(n_frames=n_frames, M=M, seed=seed, **kw)    # same seed -> same observations
         cfg = SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=n_frames + 1, **(cfg_kw or {}))
-        trk = WindowedBA(obs, ba, cfg, device=dev)
+        trk = WindowedBA(obs, ba, cfg, device=dev, **({} if dev != "cpu" else dict(se3=SE3Ref)))   # CPU leg: oracle step + torch pose formulas
         poses = trk.run()
         out[name] = dict(poses=poses, stats=trk.stats, weights=trk.weights.cpu().numpy(),
                          ate=evaluation.ate_rmse(evaluation.camera_centres(poses), obs.centres_gt()))

@@ -8,7 +8,7 @@ import torch
 
 import oracle
 from batrack_amd.backend import projective_ops as pops
-from batrack_amd.backend.lietorch import SE3
+from oracle.se3_torch import SE3Ref as SE3     # CPU float64 pose arithmetic: the torch formulas, not the product's HIP kernels
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from batrack_amd.backend.lietorch import SE3
+from oracle.se3_torch import SE3Ref as SE3
 
 torch.manual_seed(0)
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -6,6 +6,7 @@ import torch
 
 from batrack_amd import evaluation, graphgen
 from batrack_amd.sequence import SlamConfig, SyntheticObservations, WindowedBA
+from oracle.se3_torch import SE3Ref
 from sequence_util import oracle_BA_rgbd_droid
 
 
@@ -51,7 +52,7 @@ def test_edge_bookkeeping_follows_the_reference_rules():
         return Gs, patches
 
     cfg = small_cfg(obs, USE_MAP_FILTERING=False)
-    trk = WindowedBA(obs, noop_ba, cfg)
+    trk = WindowedBA(obs, noop_ba, cfg, se3=SE3Ref)
     n_edges = []
     for f in range(obs.n_frames):
         trk()
@@ -75,7 +76,7 @@ def test_edge_bookkeeping_follows_the_reference_rules():
 
 def test_oracle_driven_sequence_tracks_the_camera():
     obs = SyntheticObservations(n_frames=22, M=24, seed=5)
-    trk = WindowedBA(obs, oracle_BA_rgbd_droid, small_cfg(obs))
+    trk = WindowedBA(obs, oracle_BA_rgbd_droid, small_cfg(obs), se3=SE3Ref)
     poses = trk.run()
     gt = obs.centres_gt()
     ate = evaluation.ate_rmse(evaluation.camera_centres(poses), gt)
@@ -89,7 +90,7 @@ def test_oracle_driven_sequence_tracks_the_camera():
 def test_results_hand_off_layout():
     """batrack.py:1086-1087: cams_T_world = poses.inv().matrix(); the ATE computed from it is the one from the poses."""
     obs = SyntheticObservations(n_frames=14, M=8, seed=7)
-    trk = WindowedBA(obs, oracle_BA_rgbd_droid, small_cfg(obs))
+    trk = WindowedBA(obs, oracle_BA_rgbd_droid, small_cfg(obs), se3=SE3Ref)
     poses = trk.run()
     res = trk.get_results()
     T = res["cams_T_world"]
