@@ -10,6 +10,9 @@ this package; batrack_amd/ never does.
   oracle.edges(...)                   per-edge reprojection / Jacobians / masks
   oracle.refseq (module)              torch-CPU restatement keeping the reference's
                                       operator sequence (oracle/refseq.py; timed as cpu_baseline "refseq")
+  oracle.se3_torch (module)           torch statement of the SE3 formulas + SE3Ref (checker of row f-1)
+  oracle.patchify (module)            numpy restatement of altcorr.patchify (checker of row f-2)
+  oracle.ga_losses (module)           torch statement of the global-refinement forward losses (row f-4)
 """
 import ctypes
 import os

@@ -1,39 +1,16 @@
-"""-m gpu: altcorr.patchify (row f-2) against a numpy restatement of the reference's gather
-(correlation_kernel.cu:16-47) and blend (correlation.py:49-68).  The reference's extension
-cannot be built here (CUDA), so this row is pinned by the restatement only.  Bit-exact."""
+"""-m gpu: altcorr.patchify (row f-2) against the vectors the reference's own Python produced
+(tests/golden/patchify.npz — blend by correlation.py:51-68 itself, gather by a stand-in for the CUDA
+extension, which cannot be built here) and against oracle/patchify.py on larger inputs.  Bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from batrack_amd.backend.altcorr import patchify
+from oracle import patchify as op
 
 pytestmark = pytest.mark.gpu
-
-
-def ref_patchify(net, coords, R, mode="bilinear"):
-    B, C, H, W = net.shape
-    M = coords.shape[1]
-    D = 2 * R + 2
-    pat = np.zeros((B, M, C, D, D), np.float32)
-    fl = np.floor(coords).astype(np.int64)
-    for b in range(B):
-        for m in range(M):
-            for a in range(D):
-                for e in range(D):
-                    i, j = fl[b, m, 1] + a - R, fl[b, m, 0] + e - R
-                    if 0 <= i < H and 0 <= j < W:
-                        pat[b, m, :, a, e] = net[b, :, i, j]
-    if mode != "bilinear":
-        return pat
-    off = (coords - np.floor(coords)).astype(np.float32)
-    dx, dy = off[..., 0][:, :, None, None, None], off[..., 1][:, :, None, None, None]
-    d = 2 * R + 1
-    one = np.float32(1)
-    x00 = ((one - dy) * (one - dx)) * pat[..., :d, :d]
-    x01 = ((one - dy) * dx) * pat[..., :d, 1:]
-    x10 = (dy * (one - dx)) * pat[..., 1:, :d]
-    x11 = (dy * dx) * pat[..., 1:, 1:]
-    return x00 + x01 + x10 + x11
 
 
 @pytest.mark.parametrize("R,mode", [(0, "bilinear"), (1, "bilinear"), (0, "nearest"), (2, "nearest")])
@@ -44,9 +21,19 @@ def test_patchify_matches_restatement(R, mode):
     coords = np.stack([rng.uniform(-3, W + 3, (B, M)), rng.uniform(-3, H + 3, (B, M))], -1).astype(np.float32)
     coords[0, :4] = [[0, 0], [W - 1, H - 1], [10.0, 20.0], [W - 0.5, H - 0.5]]      # borders, integer coordinates
     out = patchify(torch.as_tensor(net).cuda(), torch.as_tensor(coords).cuda(), R, mode=mode).cpu().numpy()
-    ref = ref_patchify(net, coords, R, mode)
+    ref = op.patchify(net, coords, R, mode)
     assert out.shape == ref.shape
     assert np.array_equal(out, ref)
+
+
+def test_patchify_matches_reference_vectors():
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "patchify.npz")))
+    for n in range(5):
+        R, mode = int(g[f"case{n}.R"]), str(g[f"case{n}.mode"])
+        out = patchify(torch.as_tensor(g[f"case{n}.net"]).cuda(), torch.as_tensor(g[f"case{n}.coords"]).cuda(), R, mode=mode)
+        assert np.array_equal(out.cpu().numpy(), g[f"case{n}.out"]), (n, R, mode)
+    clr = patchify(torch.as_tensor(g["caller.img"]).cuda(), torch.as_tensor(g["caller.coords"]).cuda() + 0.5, 0).view(1, -1, 3)
+    assert np.array_equal(clr.cpu().numpy(), g["caller.clr"])
 
 
 def test_patchify_caller_shapes():
