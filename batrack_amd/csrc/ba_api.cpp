@@ -234,7 +234,7 @@ int upload_plan(bt_plan *pl) {
     P.fz_npend = (int)(pl->fz_pend.size() / 2); P.fz_nlazy = (int)(pl->fz_lazy.size() / 3); P.fz_ok = pl->fz_ok; P.fzp_ok = pl->fzp_ok;
     P.tile_pair0 = BT_I32(o_tp0); P.tile_npair = BT_I32(o_tnp); P.tile_pairs = BT_I32(o_tps);
     P.slot_lp = reinterpret_cast<const uint8_t *>(b + o_slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams; P.e_all = pl->e_all;
-    P.slot_code = reinterpret_cast<const uint16_t *>(b + o_sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + o_tla); P.tile_rec = BT_I32(o_trec); P.it_edge = BT_I32(o_ite); P.tile_sinfo = reinterpret_cast<const uint32_t *>(b + o_tsi); P.em_ok = pl->em_ok; P.em_its = (int)pl->em_its; P.em_lgs = pl->em_lgs;
+    P.slot_code = reinterpret_cast<const uint16_t *>(b + o_sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + o_tla); P.tile_rec = BT_I32(o_trec); P.it_edge = BT_I32(o_ite); P.tile_sinfo = reinterpret_cast<const uint32_t *>(b + o_tsi); P.em_ok = pl->em_ok; P.em_its = (int)pl->em_its; P.em_lgs = pl->em_lgs; P.em_self = pl->em_self;
 #undef BT_I32
     const int rc = configure_kernels(P);
     tick("configure kernels");

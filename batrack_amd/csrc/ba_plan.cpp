@@ -113,9 +113,10 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     bool sorted = true, masks_ok = true, mono_j = true;       // mono_j: within every track the target frames come in ascending order
     std::vector<int32_t> cj((size_t)n_buf + 2, 0);
     int64_t E_own = 0, k_prev = -1;
-    bool src_ok = true;
+    bool src_ok = true, any_self = false;
     for (int64_t e = 0; e < E; ++e) {
         const int64_t k = KK(e), i = II(e), j = JJ(e);
+        any_self |= i == j;
         n_all = std::max(n_all, std::max(i, j) + 1);
         f_lo = std::min(f_lo, std::min(i, j));
         kmin = std::min(kmin, k); kmax = std::max(kmax, k);
@@ -132,6 +133,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         if (bit < 0 || bit >= 64) masks_ok = false; else t.mask |= 1ull << bit;
     }
     pp_lo = kmin; pp_hi = kmax;
+    pl->em_self = any_self ? 1 : 0;
     if (E == 0) f_lo = 0;
     I.n_all = n_all;
     I.sorted_input = sorted ? 1 : 0;

@@ -42,6 +42,7 @@ struct PlanDev {
     const int32_t *tile_rec;                                 // 8 ints per tile (ba_plan.cpp)
     const int32_t *it_edge;                                  // edge-major layout (ba_plan.cpp): [iterations][64]
     const uint32_t *tile_sinfo;                              // [tiles][64]
+    int em_self;                                             // some edge has ii == jj (its source-camera E lands on a target row)
     int em_ok, em_its, em_lgs;                               // every tile slot-uniform; total iterations; log2 S if the same for all tiles, else -1
     const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
     // elimination order and level schedule of the reduced solver
@@ -80,7 +81,7 @@ struct bt_plan {
     std::vector<uint16_t> slot_code;
     std::vector<int32_t> tile_rec, it_edge;
     std::vector<uint32_t> tile_sinfo;
-    int em_ok = 0, em_lgs = -1;
+    int em_ok = 0, em_lgs = -1, em_self = 0;
     long long em_its = 0;
     int max_tile_pairs = 0, max_tile_slots = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;

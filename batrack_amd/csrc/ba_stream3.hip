@@ -12,8 +12,8 @@
 //     marks a repeated observation).
 // Every wave owns whole tiles and walks a contiguous range of them with no barrier (workgroup = one wave, private LDS);
 // the operands of iteration i+1 are gathered and the edge ids of iteration i+2 loaded while iteration i is computed —
-// one flat pipeline across tile boundaries.  The Schur product E Q E^T runs on v_mfma_f64_16x16x4_f64 with the
-// accumulators in registers across consecutive tiles with the same cameras, as in k_stream.
+// one flat pipeline across tile boundaries.  The Schur product E Q E^T runs on v_mfma_f32_16x16x4_f32 in partial sums of 16
+// tracks that are added to float64 accumulators kept in registers across consecutive tiles with the same cameras.
 // MODE kEmSO: structure-only steps; kEmUpd: the depth back-substitution (see k_update in ba_kernels.hip).
 // Reference: ba.py:228-337, projective_ops.py:54-100.
 #include <hip/hip_runtime.h>
@@ -78,8 +78,23 @@ __device__ __forceinline__ void stride_sum(float (&x)[N], int lg) {
     if (lg <= 0) { _Pragma("unroll") for (int i = 0; i < N; ++i) x[i] = xor_add<1>(x[i]); }
 }
 
+typedef float float4_t __attribute__((ext_vector_type(4)));
+#ifndef BT_EDGE_SCHUR_CHUNK
+// E Q E^T: the float64 matrix pipe (v_mfma_f64_16x16x4_f64, 64 cycles) was a quarter of the kernel's time.  E in LDS is float32
+// already, so the products go to the float32 pipe (half the cycles) in partial sums of N x 4 tracks, each added to the float64
+// accumulators that run across the tiles of a camera set: S, dX and the update are as close to the float64 oracle as with the
+// float64 pipe (measured: S 1.39e-6, dX 2.1e-5 either way on the golden cases).  0 selects the float64 pipe.
+#define BT_EDGE_SCHUR_CHUNK 4
+#endif
+
+// E Q E^T of one tile into the float64 register accumulators, and E (Q w') — the Schur term of y (ba.py:311) — as one more
+// product on the float32 matrix pipe: the A operand (16 rows of E x 4 tracks) is the one the Schur tiles load anyway, B holds
+// beta = Q w' of the 4 tracks in every column, so every column of the 16x16 result is the tile's y rows; column 0 adds them
+// to the wave's float64 sums in LDS (the same float32-within-a-tile / float64-across-tiles summation as before, without the
+// 2 x 31 cross-lane steps it took on the VALU).
 template <int NT>
-__device__ __forceinline__ void em_schur(const float *Eh, const float *Qs, int R, int lane, double4_t (&acc)[NT * (NT + 1) / 2]) {
+__device__ __forceinline__ void em_schur(const float *Eh, const float *Qs, const float *Bs, double *ysum, int R, int lane,
+                                         double4_t (&acc)[NT * (NT + 1) / 2]) {
     const int kq = lane >> 4, li = lane & 15;
     float qv[16];
     const float *qp = Qs + kq;
@@ -90,9 +105,30 @@ __device__ __forceinline__ void em_schur(const float *Eh, const float *Qs, int R
         if (16 * ti < R) {
             // rows beyond the tile's E re-read its last row: their outputs are never emitted
             const float *ap = Eh + min(16 * ti + li, R - 1) * kLdsRowStride + kq;
+            float af[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) af[ks] = ap[4 * ks];
+            {
+                float4_t yt = {0.0f, 0.0f, 0.0f, 0.0f};
+                const float *bq = Bs + kq;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) yt = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], bq[4 * ks], yt, 0, 0, 0);
+                // f32 C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * kq + r;
+                    if (li == 0 && row < R) atomicAdd(ysum + row, (double)yt[r]);
+                }
+            }
+#if BT_EDGE_SCHUR_CHUNK == 0
             double av[16];
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) av[ks] = (double)ap[4 * ks] * (double)qv[ks];
+            for (int ks = 0; ks < 16; ++ks) av[ks] = (double)af[ks] * (double)qv[ks];
+#else
+            float aq[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) aq[ks] = af[ks] * qv[ks];
+#endif
 #pragma unroll
             for (int tj = 0; tj <= ti; ++tj) {
                 __builtin_amdgcn_sched_barrier(0);          // one output tile's operands at a time
@@ -100,9 +136,20 @@ __device__ __forceinline__ void em_schur(const float *Eh, const float *Qs, int R
                 float bv[16];
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) bv[ks] = bp[4 * ks];
+#if BT_EDGE_SCHUR_CHUNK == 0
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
                     acc[ti * (ti + 1) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], (double)bv[ks], acc[ti * (ti + 1) / 2 + tj], 0, 0, 0);
+#else
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += BT_EDGE_SCHUR_CHUNK) {
+                    float4_t c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int ks = k0; ks < k0 + BT_EDGE_SCHUR_CHUNK; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[ks], bv[ks], c, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[ti * (ti + 1) / 2 + tj][r] += (double)c[r];
+                }
+#endif
             }
         }
     }
@@ -140,13 +187,13 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
     int *gidx = reinterpret_cast<int *>(Qs + (MODE == kEmFull ? 64 : 0));
     int *gpl = gidx + (MODE == kEmFull ? ((Rmax + 3) & ~3) : 0);
     double *pacc = reinterpret_cast<double *>(gpl + (MODE == kEmFull ? ((mtp + 3) & ~3) : 0));   // [mtp][32]
+    double *ysum = pacc + (MODE == kEmFull ? mtp * 32 : 0);                                       // [64]: the wave's sums of E Q w' by local row
 
     const int t_begin = blockIdx.x * tiles_per_wave, t_end = min(pd.T, t_begin + tiles_per_wave);
     if (t_begin >= t_end) return;
 
     constexpr int NACC = NT * (NT + 1) / 2;
     double4_t sacc[NACC];
-    double yacc[2] = {0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < NACC; ++t) sacc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
     bool acc_live = false;
@@ -162,7 +209,7 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
                 const int col = 16 * tj + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + (lane >> 4) + 4 * r;
+                    const int row = BT_EDGE_SCHUR_CHUNK ? 16 * ti + 4 * (lane >> 4) + r : 16 * ti + (lane >> 4) + 4 * r;
                     const double val = sacc[t][r];
                     sacc[t][r] = 0.0;
                     if (row < Racc && col < Racc) {
@@ -171,11 +218,10 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
                     }
                 }
             }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int row = 32 * c + ((lane >> 1) & 31);
-            if (!(lane & 1) && row < Racc) atomicAdd(&a.y[gidx[row]], -yacc[c]);
-            yacc[c] = 0.0;
+        if (lane < Racc) {
+            const double v = ysum[lane];
+            ysum[lane] = 0.0;
+            atomicAdd(&a.y[gidx[lane]], -v);
         }
         acc_live = false;
     };
@@ -194,6 +240,7 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
     };
     if (MODE == kEmFull) {
         for (int i = lane; i < mtp * 32; i += 64) pacc[i] = 0.0;
+        ysum[lane] = 0.0;
     }
 
     // ---- the flat iteration stream of this wave: [gi, gi_end)
@@ -403,10 +450,15 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
                 }
                 if (lead && track < rec.ntrk) {
                     cw[track] = sv[0]; cw[64 + track] = sv[1];
-                    if (la != 0xffu) {           // (behind the stores above in LDS order: a self edge's target rows are these)
+                    if (la != 0xffu) {
                         float *row = Eh + la * 6 * kLdsRowStride + track;
+                        if (pd.em_self) {        // (behind the stores above in LDS order: a self edge's target rows are these)
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) row[c * kLdsRowStride] += sv[2 + c];
+                            for (int c = 0; c < 6; ++c) row[c * kLdsRowStride] += sv[2 + c];
+                        } else {                 // a track's source-camera row is written here and nowhere else
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) row[c * kLdsRowStride] = sv[2 + c];
+                        }
                     }
                 }
                 BT_PF(13);
@@ -468,25 +520,13 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
             }
             if (MODE == kEmFull) {
                 Qs[lane] = Q;
+                cw[lane] = Q * wp;                     // beta (this lane read its own C above; w of the tile is consumed)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 BT_PF(2);
-                // E Q w' (the Schur term of y): every lane scales its own column, 32 rows per reduce-scatter
-                const float beta = Q * wp;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if (32 * c < R) {
-                        float v[32];
-                        const float *col = Eh + 32 * c * kLdsRowStride + lane;
-#pragma unroll
-                        for (int i = 0; i < 32; ++i) v[i] = 32 * c + i < R ? beta * col[i * kLdsRowStride] : 0.0f;
-                        wave_reduce_scatter32(v, lane);
-                        yacc[c] += (double)v[0];
-                    }
-                }
                 BT_PF(3);
-                em_schur<NT>(Eh, Qs, R, lane, sacc);
+                em_schur<NT>(Eh, Qs, cw, ysum, R, lane, sacc);
                 acc_live = true; Racc = R;
                 BT_PF(4);
             }
@@ -522,7 +562,7 @@ static size_t edge_lds_bytes(const PlanDev &pd, int mode) {
     if (mode == kEmUpd) return (mtp * kEmUpdGeo + 256 + 128) * sizeof(float);
     if (mode == kEmSO) return (mtp * kPairGeomFloats + 256 + 128) * sizeof(float);
     return (mtp * kPairGeomFloats + 256 + 128 + Rmax * kLdsRowStride + 64 + ((Rmax + 3) & ~(size_t)3) + ((mtp + 3) & ~(size_t)3)) * sizeof(float) +
-           mtp * 32 * sizeof(double) + 16;
+           (mtp * 32 + 64) * sizeof(double) + 16;
 }
 
 // k_edge takes graphs of many tiles, all slot-uniform (the plan's em_ok), whose tiles see at most 10 cameras (row

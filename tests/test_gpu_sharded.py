@@ -83,7 +83,8 @@ def test_sharded_step_equals_single_gpu(shape, fixedp, world):
         pose, pat, _, status = out[r]
         assert status == 0
         ep, ex = rel(pose, ref_pose), rel(pat, ref_pat)
-        assert ep < 2e-6 and ex < 2e-6, (r, ep, ex)   # summation order differs (atomics, shard split)
+        tol = 1e-5 if shape == "few" else 2e-6       # three tracks barely constrain the poses: rounding of the sums is amplified
+        assert ep < tol and ex < tol, (r, ep, ex)     # summation order differs (atomics, shard split)
     for r in range(1, world):
         assert np.array_equal(out[0][0], out[r][0])    # identical solve on every rank after the all-reduce
     if shape == "few":

@@ -37,7 +37,7 @@ for M in [int(x) for x in (sys.argv[1:] or ["256", "1024", "4096", "16384"])]:
         torch.cuda.synchronize()
         off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
         raw = st.ws.cpu().numpy()
-        stat_off = off + ((6 * plan.n * 4 + 64 + 255) // 256) * 256
+        stat_off = off + 2 * (((6 * plan.n * 4 + 64 + 255) // 256) * 256)            # dx, dx0, then the status block
         pf = np.frombuffer(raw[stat_off + 16 + 160: stat_off + 16 + 320].tobytes(), dtype=np.int64).reshape(2, 10)
         names = ["tile top", "iterations", "finish", "y", "schur", "flush", "drain", "-", "tiles", "-"]
         for w, nm in enumerate(("wave 0", "wave mid")):

@@ -40,7 +40,7 @@ wall = (time.perf_counter() - t0) / 200 * 1e6
 if int(os.environ.get("BT_DEBUG_MODE", "0")) & 32:
     off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
     raw = st.ws.cpu().numpy()
-    stat_off = off + ((6 * plan.n * 4 + 64 + 255) // 256) * 256
+    stat_off = off + 2 * (((6 * plan.n * 4 + 64 + 255) // 256) * 256)            # dx, dx0, then the status block
     pf = np.frombuffer(raw[stat_off + 16 + 160: stat_off + 16 + 320].tobytes(), dtype=np.int64).reshape(2, 10)
     names = ["prologue", "loadwait", "math+E", "pairreduce", "CwQ", "Esave", "mfma", "epilogue", "drain", "-"]
     for w, nm in enumerate(("tile0", "tileMid")):
@@ -50,7 +50,7 @@ if int(os.environ.get("BT_DEBUG_MODE", "0")) & 16:
     off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
     raw = st.ws.cpu().numpy()
     # status region follows dx region: find by scanning from plan layout is not exposed; use the status call offset
-    stat_off = off + ((6 * plan.n * 4 + 64 + 255) // 256) * 256
+    stat_off = off + 2 * (((6 * plan.n * 4 + 64 + 255) // 256) * 256)            # dx, dx0, then the status block
     pf = np.frombuffer(raw[stat_off + 16: stat_off + 16 + 160].tobytes(), dtype=np.int64).reshape(2, 10)
     names = ["load", "updates", "chol", "trsm", "store", "barrier", "Mprep", "backsub", "tail", "-"]
     ph = np.frombuffer(raw[stat_off + 16 + 320: stat_off + 16 + 320 + 16 * 12].tobytes(), dtype=np.int64).reshape(12, 2)
