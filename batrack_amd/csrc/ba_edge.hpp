@@ -10,6 +10,7 @@
 namespace bt {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ pair geometry
 // 1/sqrt(x) in double from the fp32 hardware seed and two Newton steps (relative error < 1e-15; the IEEE

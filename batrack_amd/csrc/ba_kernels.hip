@@ -48,15 +48,13 @@ namespace bt {
 // waves' chunks falls back to ds_add_f32.
 constexpr int kTileWavesMax = 16;
 
-constexpr int kTileAccMax = 16;  // Schur output tiles (16x16) a workgroup accumulates across tiles, in LDS (up to 13 cameras)
-
-// PERSIST = false: one tile per workgroup (graphs with up to ~1024 tiles, e.g. the 64-KF / 131k-edge
-// benchmark): no cross-tile state, Schur tiles go straight from the MFMA registers to the atomics.
-// PERSIST = true: a workgroup walks tiles_per_wg consecutive tiles and keeps its accumulators.
+// One tile per workgroup (graphs of up to a few thousand tiles, e.g. the 64-KF / 131k-edge benchmark and the
+// sliding-window graphs; larger ones take k_edge / k_stream): no cross-tile state, Schur tiles go straight from
+// the MFMA registers to the atomics.
 // WIDE: 16 waves per tile instead of 8, for graphs of few tiles with deep slot loops (a sliding window of 50 frames:
 // 40 tiles of 54 slots): the tile's latency, which is all there is on a quarter-empty GPU, shrinks with the chunk.
-template <bool SO, bool PROF, bool PERSIST, bool WIDE = false>
-__global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDev pd, StepArgs a, int tiles_per_wg) {
+template <bool SO, bool PROF, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDev pd, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthr = blockDim.x, kTileWaves = nthr >> 6;          // 8 or 16 waves per tile (launch parameter)
@@ -67,15 +65,9 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
     float *Eh = lds, *stg = Eh + R16max * kLdsRowStride;
     int *las = reinterpret_cast<int *>(stg + kTileWaves * 8 * 64);
     float *Qs = reinterpret_cast<float *>(las + kTileWaves * 64);
-    int *gidx = reinterpret_cast<int *>(Qs + 64);
+    int *gidx = reinterpret_cast<int *>(Qs + 128);                // (Qs: Q of the 64 tracks, then beta = Q w')
     float *geo = reinterpret_cast<float *>(gidx + R16max);        // [npair][20], 16-byte aligned
-    // persistent accumulators: the Schur output tiles of the workgroup in LDS ([tile][reg][lane] doubles,
-    // each tile owned by one wave), and one per-pair sum per wave in registers
-    double *lacc = reinterpret_cast<double *>(geo + (size_t)pd.max_tile_pairs * kPairGeomFloats);
-    const int ntl_max = (SO || !PERSIST) ? 0 : min(kTileAccMax, (R16max >> 4) * ((R16max >> 4) + 1) / 2);
-    for (int i = tid; i < ntl_max * 256; i += nthr) lacc[i] = 0.0;
-    bool sacc_live = false;
-    int Racc = 0;                      // 6 * cameras of the tiles accumulated in sacc
+    // one per-pair sum per wave in registers
     double pacc = 0.0;
     int p_cur = -1;
     auto flush_pair = [&]() {
@@ -84,45 +76,14 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             atomicAdd(&a.pairacc[(size_t)p_cur * kPairAccStride + vi], pacc);
         pacc = 0.0; p_cur = -1;
     };
-    auto flush_schur = [&]() {         // uses gidx of the tiles the accumulators belong to (still in LDS)
-        if (!sacc_live) return;
-        const int nt = ((Racc + 1 + 15) >> 4), ntl = nt * (nt + 1) / 2;
-        for (int t = wave; t < ntl; t += kTileWaves) {
-            int ti = 0, base = 0;
-            while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
-            const int tj = t - base;
-            // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-            const int gc = gidx[16 * tj + (lane & 15)];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double *slot = lacc + (size_t)(t * 4 + r) * 64 + lane;
-                const double val = *slot;
-                *slot = 0.0;
-                const int row = 16 * ti + (lane >> 4) + 4 * r;
-                if (gc >= 0 && row <= Racc) {
-                    if (row == Racc) {
-                        atomicAdd(&a.y[gc], -val);
-                    } else {
-                        const int gr = gidx[row];
-                        if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -val);
-                    }
-                }
-            }
-        }
-        sacc_live = false;
-    };
-
-    const int tile_begin = PERSIST ? blockIdx.x * tiles_per_wg : blockIdx.x;
-    const int tile_end = PERSIST ? min(pd.T, tile_begin + tiles_per_wg) : tile_begin + 1;
+    const int tile_begin = blockIdx.x, tile_end = tile_begin + 1;
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const int flags = tile == tile_begin ? 0 : pd.tile_flags[tile];
+        const int flags = 0;
         const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
-        const int R = 6 * ncam, R16 = SO ? 0 : ((R + 1 + 15) >> 4) << 4;
+        const int R = 6 * ncam, R16 = SO ? 0 : ((R + 15) >> 4) << 4;
         const int *cams = pd.tile_cams + pd.tile_cam0[tile];
-        if (!SO && !(flags & 1)) {                                 // other cameras: emit what was accumulated, new row map
-            flush_schur();
-            __syncthreads();
+        if (!SO) {                                                 // local row -> row of the reduced system
             for (int i = tid; i < R16max; i += nthr) gidx[i] = i < R ? 6 * cams[i / 6] + i % 6 : -1;
         }
         // first loads that need nothing but the tile index: the cameras of its pairs and the patch of this lane's track
@@ -135,7 +96,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         // this wave's first slot, in flight while the pair geometry is computed
         int e_nx = -1, pair_nx = 0, lp_nx = 0;
         unsigned lab_nx = 0xffffu;
-        if (!PERSIST && s0 < s1) {            // (the persistent variant has no registers to spare for the look-ahead)
+        if (s0 < s1) {
             const size_t idx = (size_t)(slot0 + s0) * kLanes + lane;
             e_nx = pd.slot_edge[idx]; pair_nx = pd.slot_pair[idx]; lab_nx = pd.slot_lab[idx]; lp_nx = pd.slot_lp[idx];
         }
@@ -209,21 +170,11 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         for (int s = s0; s < s1; ++s) {
             const size_t idx = (size_t)(slot0 + s) * kLanes + lane;
             // this slot's operands were loaded one iteration ahead (the first one before the barrier above)
-            if (PERSIST) {
-                e_nx = pd.slot_edge[idx]; pair_nx = pd.slot_pair[idx]; lab_nx = pd.slot_lab[idx]; lp_nx = pd.slot_lp[idx];
-                tu_nx = tv_nx = w0_nx = w1_nx = 0.0f;
-                if (e_nx >= 0) {
-                    const float *tp = a.targets + (size_t)e_nx * a.tstride;
-                    tu_nx = tp[0]; tv_nx = tp[1];
-                    const float2 w = reinterpret_cast<const float2 *>(a.weights)[e_nx];
-                    w0_nx = w.x; w1_nx = w.y;
-                }
-            }
             const int e = e_nx, pair = pair_nx, lp = lp_nx;
             const bool act = e >= 0;
             const unsigned lab = lab_nx;
             const float tu = tu_nx, tv = tv_nx, w0 = w0_nx, w1 = w1_nx;
-            if (!PERSIST && s + 1 < s1) {
+            if (s + 1 < s1) {
                 const size_t idn = idx + kLanes;
                 e_nx = pd.slot_edge[idn]; pair_nx = pd.slot_pair[idn]; lab_nx = pd.slot_lab[idn]; lp_nx = pd.slot_lp[idn];
                 tu_nx = tv_nx = w0_nx = w1_nx = 0.0f;
@@ -355,7 +306,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
                 Q = 1.0f / Ca;
                 a.qw[trk] = make_float2(Q, wp);
             }
-            if (!SO) { Qs[lane] = Q; Eh[R * kLdsRowStride + lane] = wp; }
+            if (!SO) { Qs[lane] = Q; Qs[64 + lane] = Q * wp; }
         }
         __syncthreads();
         BT_PF(4);
@@ -363,60 +314,51 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
 
         BT_PF(5);
 
-        // Schur product of the tile on the matrix cores: out[i][j] += sum_k Q_k Eh[i][k] Eh[j][k]
-        // over the 64 tracks; row R gives E Q w'.  f64 MFMA: the fp32 products are exact in
-        // double, so the sums carry no fp32 accumulation error (DESIGN.md "precision").  The
-        // accumulators stay in registers across consecutive tiles with the same cameras.
+        // Schur product of the tile on the matrix cores: out[i][j] += sum_k Q_k Eh[i][k] Eh[j][k] over the 64 tracks,
+        // one 16x16 output tile per wave, on v_mfma_f64_16x16x4_f64: the float32 products are exact in double, so the sums
+        // carry no float32 accumulation error (float32 partial sums were measured: no faster here — the tile's time is
+        // its atomics — and 8x the dX error on the reference's ill-conditioned 8-frame case, for S and for y alike).
+        // The wave of a diagonal tile has the rows of E it needs for E (Q w'), the Schur term of y (ba.py:311), in
+        // registers: one more product with beta = Q w' in every column of B, column 0 of the result emitted.
         const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
-        const bool keep = ntl <= ntl_max;           // else: more output tiles than LDS accumulators, emit per tile
         for (int t = wave; t < ntl; t += kTileWaves) {
             int ti = 0, base = 0;
             while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
             const int tj = t - base;
-            const float *ar = Eh + (16 * ti + (lane & 15)) * kLdsRowStride + (lane >> 4);
-            const float *br = Eh + (16 * tj + (lane & 15)) * kLdsRowStride + (lane >> 4);
-            const float *qr = Qs + (lane >> 4);
+            const int li = lane & 15, kq = lane >> 4;
+            const float *ar = Eh + (16 * ti + li) * kLdsRowStride + kq;
+            const float *br = Eh + (16 * tj + li) * kLdsRowStride + kq;
+            const float *qr = Qs + kq;
+            float av[16], bv[16], qv[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) { av[ks] = ar[4 * ks]; bv[ks] = br[4 * ks]; qv[ks] = qr[4 * ks]; }
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
-            if constexpr (PERSIST) {
-#pragma unroll 1
-                for (int quarter = 0; quarter < 4; ++quarter) {
-                    float av[4], bv[4], qv[4];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { av[ks] = ar[4 * (4 * quarter + ks)]; bv[ks] = br[4 * (4 * quarter + ks)]; qv[ks] = qr[4 * (4 * quarter + ks)]; }
+            for (int ks = 0; ks < 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks] * (double)qv[ks], (double)bv[ks], acc, 0, 0, 0);
+            // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+            const int gc = gidx[16 * tj + li];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks] * (double)qv[ks], (double)bv[ks], acc, 0, 0, 0);
-                }
-            } else {
-                float av[16], bv[16], qv[16];
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) { av[ks] = ar[4 * ks]; bv[ks] = br[4 * ks]; qv[ks] = qr[4 * ks]; }
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + kq + 4 * r;
+                if (gc >= 0 && row < R) { const int gr = gidx[row]; if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]); }
+            }
+            if (ti == tj) {
+                double4_t yt = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks] * (double)qv[ks], (double)bv[ks], acc, 0, 0, 0);
-            }
-            if (keep) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) lacc[(size_t)(t * 4 + r) * 64 + lane] += acc[r];
-            } else {
-                const int gc = gidx[16 * tj + (lane & 15)];
+                    yt = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks], (double)qr[64 + 4 * ks], yt, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + (lane >> 4) + 4 * r;
-                    if (gc >= 0 && row <= R) {
-                        if (row == R) atomicAdd(&a.y[gc], -acc[r]);
-                        else { const int gr = gidx[row]; if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]); }
-                    }
+                    const int row = 16 * ti + kq + 4 * r;
+                    if (li == 0 && row < R) atomicAdd(&a.y[gidx[row]], -yt[r]);
                 }
             }
         }
-        if (keep) { sacc_live = true; Racc = R; }
         BT_PF(6);
-        if (PERSIST) __syncthreads();            // the next tile of this workgroup reuses Eh / stg
     }
     if (!SO) {
         flush_pair();
-        flush_schur();
         BT_PF(7);
     }
     if (PROF && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {
@@ -2167,9 +2109,8 @@ static int tile_threads(const PlanDev &pd) { return tile_wide(pd) ? 1024 : 512; 
 static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     const size_t rows = so ? 0 : (size_t)pd.max_rows16;
     const size_t kTileWaves = (size_t)tile_threads(pd) / 64;
-    const size_t nt = rows / 16, ntl = nt * (nt + 1) / 2;
-    return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 64 + rows +
-            (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) + (ntl < 16 ? ntl : 16) * 2048 + 64;
+    return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 128 + rows +
+            (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) + 64;
 }
 
 constexpr size_t kLdsBudget = 160 * 1024 - 512;
@@ -2227,8 +2168,8 @@ static int raise_lds_limit(const void *fn, size_t need) {
 int configure_kernels(const PlanDev &pd) {
     const size_t need = tile_lds_bytes(pd, false);
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
-    const void *tiles[4] = { reinterpret_cast<const void *>(&k_tile<false, false, false>), reinterpret_cast<const void *>(&k_tile<false, false, true>),
-                             reinterpret_cast<const void *>(&k_tile<false, false, false, true>), reinterpret_cast<const void *>(&k_tile<false, true, false>) };
+    const void *tiles[3] = { reinterpret_cast<const void *>(&k_tile<false, false>), reinterpret_cast<const void *>(&k_tile<false, false, true>),
+                             reinterpret_cast<const void *>(&k_tile<false, true>) };
     for (const void *fn : tiles) if (raise_lds_limit(fn, need) != BT_OK) return BT_EHIP;
     const int mode = solver_mode(pd);
     const void *fns[4] = { reinterpret_cast<const void *>(&k_solve_lds<double, false>),
@@ -2271,19 +2212,13 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         const int rc = launch_stream(pd, a, so ? 1 : 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
         if (rc != BT_OK) return rc;
     } else if (pd.T > 0) {
-        // persistent workgroups once there are more tiles than ~4 per CU: a workgroup then walks a
-        // contiguous range of tiles and keeps its accumulators across tiles with the same cameras
-        static const int max_wgs = std::getenv("BT_TILE_MAX_WGS") ? std::atoi(std::getenv("BT_TILE_MAX_WGS")) : 1024;   // measurement only
-        const int tpw = (pd.T + max_wgs - 1) / max_wgs, nwg = (pd.T + tpw - 1) / tpw;
-        const bool wide = tpw == 1 && tile_wide(pd);
-        const dim3 blk(tile_threads(pd));
-        if (so && wide)        BT_LAUNCH(1, (k_tile<true, false, false, true>), dim3(nwg), blk, tile_lds_bytes(pd, true), pd, a, tpw);
-        else if (so && tpw == 1) BT_LAUNCH(1, (k_tile<true, false, false>), dim3(nwg), blk, tile_lds_bytes(pd, true), pd, a, tpw);
-        else if (so)           BT_LAUNCH(1, (k_tile<true, false, true>), dim3(nwg), dim3(512), tile_lds_bytes(pd, true), pd, a, tpw);
-        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true, false>), dim3(pd.T), dim3(512), tile_lds_bytes(pd, false), pd, a, 1);
-        else if (wide)         BT_LAUNCH(1, (k_tile<false, false, false, true>), dim3(nwg), blk, tile_lds_bytes(pd, false), pd, a, tpw);
-        else if (tpw == 1)     BT_LAUNCH(1, (k_tile<false, false, false>), dim3(nwg), blk, tile_lds_bytes(pd, false), pd, a, tpw);
-        else                   BT_LAUNCH(1, (k_tile<false, false, true>), dim3(nwg), dim3(512), tile_lds_bytes(pd, false), pd, a, tpw);
+        const bool wide = tile_wide(pd);
+        const dim3 blk(tile_threads(pd)), grid(pd.T);
+        if (so && wide)        BT_LAUNCH(1, (k_tile<true, false, true>), grid, blk, tile_lds_bytes(pd, true), pd, a);
+        else if (so)           BT_LAUNCH(1, (k_tile<true, false>), grid, blk, tile_lds_bytes(pd, true), pd, a);
+        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), grid, dim3(512), tile_lds_bytes(pd, false), pd, a);
+        else if (wide)         BT_LAUNCH(1, (k_tile<false, false, true>), grid, blk, tile_lds_bytes(pd, false), pd, a);
+        else                   BT_LAUNCH(1, (k_tile<false, false>), grid, blk, tile_lds_bytes(pd, false), pd, a);
     }
     if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);

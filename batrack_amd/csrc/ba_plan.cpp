@@ -269,7 +269,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     close_tile(m);
     const int32_t T = (int32_t)pl->tile_trk0.size();
     I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
-    pl->max_rows16 = (int)((6 * max_cams + 1 + 15) / 16 * 16);
+    pl->max_rows16 = (int)((6 * max_cams + 15) / 16 * 16);
 
     BT_TICK("6");
     // ---- per tile: its distinct camera pairs (their relative pose is computed once per tile), then the slot arrays

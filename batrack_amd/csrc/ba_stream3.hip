@@ -78,7 +78,6 @@ __device__ __forceinline__ void stride_sum(float (&x)[N], int lg) {
     if (lg <= 0) { _Pragma("unroll") for (int i = 0; i < N; ++i) x[i] = xor_add<1>(x[i]); }
 }
 
-typedef float float4_t __attribute__((ext_vector_type(4)));
 #ifndef BT_EDGE_SCHUR_CHUNK
 // E Q E^T: the float64 matrix pipe (v_mfma_f64_16x16x4_f64, 64 cycles) was a quarter of the kernel's time.  E in LDS is float32
 // already, so the products go to the float32 pipe (half the cycles) in partial sums of N x 4 tracks, each added to the float64
