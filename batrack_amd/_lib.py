@@ -120,6 +120,8 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
     L.bt_version.restype = i32
+    L.bt_plan_jacobian_kernel.restype = i32
+    L.bt_plan_jacobian_kernel.argtypes = [vp]
     L.bt_target_arch.restype = ctypes.c_char_p
     L.bt_plan_create.restype = i32
     L.bt_plan_create.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, ctypes.POINTER(vp)]

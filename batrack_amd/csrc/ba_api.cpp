@@ -13,7 +13,7 @@
 
 #include "ba_kernels.hpp"
 
-#define BT_VERSION 200
+#define BT_VERSION 201
 
 namespace bt {
 
@@ -283,6 +283,10 @@ using namespace bt;
 extern "C" {
 
 int bt_version(void) { return BT_VERSION; }
+int bt_plan_jacobian_kernel(const bt_plan *pl) {
+    if (!pl || !pl->dev_base) return -1;
+    return edge_applies(pl->dev) ? 2 : stream_applies(pl->dev) ? 1 : 0;
+}
 const char *bt_target_arch(void) { return "gfx950"; }
 
 int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf,

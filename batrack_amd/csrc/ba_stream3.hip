@@ -566,9 +566,15 @@ static size_t edge_lds_bytes(const PlanDev &pd, int mode) {
 
 // k_edge takes graphs of many tiles, all slot-uniform (the plan's em_ok), whose tiles see at most 10 cameras (row
 // tiles of the register accumulators) and 64 camera pairs (one lane per pair in the prologue)
+// Measured on the benchmark generator (profiles/r02_kernel_choice.txt): k_tile is fastest up to ~768 tiles, k_stream from 1024
+// to ~4096 (two waves per tile fill the chip sooner), k_edge from 8192 on (fewer instructions per edge once every SIMD has its
+// two waves); where both apply, k_stream keeps the graphs below kEdgePrefTiles.
 bool edge_applies(const PlanDev &pd) {
     static const int off = std::getenv("BT_EDGE_OFF") ? std::atoi(std::getenv("BT_EDGE_OFF")) : 0;   // measurement only
-    return !off && pd.em_ok && pd.T >= edge_min_tiles() && pd.max_cams <= 10 && pd.max_cams > 0 && pd.max_tile_pairs <= 64 && pd.max_tile_pairs > 0;
+    static const int pref = std::getenv("BT_EDGE_PREF_TILES") ? std::atoi(std::getenv("BT_EDGE_PREF_TILES")) : 6144;
+    if (off || !pd.em_ok || pd.T < edge_min_tiles() || pd.max_cams > 10 || pd.max_cams <= 0 || pd.max_tile_pairs > 64 || pd.max_tile_pairs <= 0)
+        return false;
+    return pd.T >= pref || !stream_applies(pd);
 }
 
 template <int MODE, int NT, int LGS, bool PROF = false>

@@ -66,6 +66,11 @@ class Plan:
     def handle(self):
         return self._h
 
+    @property
+    def jacobian_kernel(self):
+        """'k_tile' | 'k_stream' | 'k_edge': what the steps of this plan launch (bt_plan_jacobian_kernel)."""
+        return {0: "k_tile", 1: "k_stream", 2: "k_edge"}.get(self._lib.bt_plan_jacobian_kernel(self._h), "host-only")
+
     def array(self, name):
         """Host copy of a plan array (tests / tooling)."""
         p = ctypes.c_void_p()

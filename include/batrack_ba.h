@@ -157,6 +157,11 @@ float *bt_ba_dx(const bt_plan *plan, void *workspace);
 /* Synchronous read-back of the solver status word (BT_SOLVE_*). */
 int bt_ba_status(const bt_plan *plan, void *workspace, void *stream, int32_t *status);
 
+/* Which Jacobian kernel the steps of this (uploaded) plan launch: 0 = k_tile (one tile per workgroup), 1 = k_stream (two
+ * waves per tile, tiles streamed), 2 = k_edge (edge-major, one wave per tile) — chosen from the plan's size and shape
+ * (DESIGN.md §4); -1 for a host-only plan.  For tests and tooling. */
+int bt_plan_jacobian_kernel(const bt_plan *plan);
+
 /* Library/ABI version and the gfx target the kernels were compiled for. */
 int bt_version(void);
 const char *bt_target_arch(void);

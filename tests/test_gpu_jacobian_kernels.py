@@ -1,0 +1,58 @@
+"""-m gpu: the three Jacobian kernels.  A plan picks k_tile, k_stream or k_edge from its size and shape; the
+fixtures are small and all take k_tile, so (a) graphs of the benchmark generator large enough for the plan to pick k_stream
+and k_edge BY ITSELF are compared with the float64 oracle, and (b) the whole parity suite is re-run in child processes with
+the selection forced (the thresholds are read once per process), so every fixture that fits a kernel's layout goes through it."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from batrack_amd import graphgen
+from gpu_util import HipProblem, rel, update_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("frames,M,kernel,so", [(16, 16, "k_tile", False), (64, 1024, "k_stream", False), (64, 1024, "k_stream", True),
+                                              (64, 6144, "k_edge", False), (64, 6144, "k_edge", True)])
+def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so):
+    g = graphgen.make_graph(frames, M, 8, seed=5)
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics), targets3=f(g.targets3),
+             weights=f(g.weights), weights_pose=f(g.weights_pose), ii=g.ii, jj=g.jj, kk=g.kk, bounds=np.asarray(g.bounds))
+    wkey = "weights" if so else "weights_pose"
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"],
+                         d["bounds"], fixedp=1, structure_only=so, want_system=not so)
+    o = HipProblem(d).raw_step(wkey, 1, so)
+    assert o["plan"].jacobian_kernel == kernel, (o["plan"].jacobian_kernel, o["plan"].tiles)
+    act = np.unique(g.kk)
+    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], act) < 1e-4
+    assert rel(o["patches_out"], ref["patches_out"]) < 5e-6
+    if not so:
+        assert o["status"] == 0
+        assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 5e-6 and rel(o["y"], ref["y"]) < 5e-6
+        assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 3e-4
+        assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(1, 1 + o["plan"].n)) < 3e-4
+        assert rel(o["poses_out"], ref["poses_out"]) < 5e-6
+
+
+FORCED = {"k_edge": dict(BT_EDGE_MIN_TILES="1", BT_EDGE_PREF_TILES="1", BT_STREAM_MIN_TILES="1"),      # wherever the tiles are slot-uniform
+          "k_stream": dict(BT_EDGE_OFF="1", BT_STREAM_MIN_TILES="1"),
+          "k_tile": dict(BT_EDGE_OFF="1", BT_STREAM_MIN_TILES="100000000")}
+
+
+@pytest.mark.parametrize("kernel", ["k_edge", "k_stream", "k_tile"])
+def test_parity_suite_with_the_selection_forced(kernel):
+    env = dict(os.environ, **FORCED[kernel])
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_solver_variants.py", "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    # and the forced choice is what a slot-uniform graph really takes
+    code = ("import numpy as np, torch; from batrack_amd import graphgen; from batrack_amd.plan import Plan; g = graphgen.make_graph(16, 64, 8, seed=1);"
+            "T = lambda a: torch.as_tensor(a, device='cuda:0'); p = Plan(T(g.ii), T(g.jj), T(g.kk), g.poses.shape[0], g.patches.shape[0], 1); print(p.jacobian_kernel)")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == kernel, r.stdout + r.stderr[-2000:]

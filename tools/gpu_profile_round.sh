@@ -29,4 +29,5 @@ python tests/sequence_report.py > $OUT/sequence_ate.txt 2>&1
 python tools/gpu_ga_bench.py > $OUT/global_refine_losses.txt 2>&1
 python tools/gpu_check.py > $OUT/parity_numbers.txt 2>&1
 python tools/gpu_refine_check.py >> $OUT/parity_numbers.txt 2>&1
+BT_EDGE_MIN_TILES=1 python tools/gpu_edge_accuracy.py >> $OUT/parity_numbers.txt 2>&1
 ls -la $OUT
