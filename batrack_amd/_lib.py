@@ -160,6 +160,8 @@ def lib():
     L.bt_reproject.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp, vp, i64, i32, vp, vp, vp]
     L.bt_ga_forward.restype = i32
     L.bt_ga_forward.argtypes = [vp, vp, vp, i32, vp]
+    L.bt_ga_backward.restype = i32
+    L.bt_ga_backward.argtypes = [vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
     L.bt_patchify.restype = i32
     L.bt_patchify.argtypes = [vp, i64, i64, i64, i64, vp, i64, i32, i32, vp, vp]
     _lib = L

@@ -79,7 +79,6 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
     const int tile_begin = blockIdx.x, tile_end = tile_begin + 1;
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const int flags = 0;
         const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
         const int R = 6 * ncam, R16 = SO ? 0 : ((R + 15) >> 4) << 4;
         const int *cams = pd.tile_cams + pd.tile_cam0[tile];
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             const size_t idx = (size_t)(slot0 + s0) * kLanes + lane;
             e_nx = pd.slot_edge[idx]; pair_nx = pd.slot_pair[idx]; lab_nx = pd.slot_lab[idx]; lp_nx = pd.slot_lp[idx];
         }
-        if (!(flags & 2)) {                                        // relative pose of the tile's camera pairs
+        {                                                          // relative pose of the tile's camera pairs
             const int np = pd.tile_npair[tile];
             // (the pair's global index: only to leave the result for k_pair_finalize, which then need not redo it)
             const int gp0 = !SO && tid < np ? pd.tile_pairs[pd.tile_pair0[tile] + tid] : 0;

@@ -1,20 +1,22 @@
-// ba_stream.hip — wave-per-tile streaming kernels for graphs of many tiles (gfx950, wave64).
+// ba_stream.hip — k_stream: tiles streamed through two-wave workgroups, for graphs of 1024 .. ~6000 tiles (gfx950, wave64).
 //
 // The tile kernel of ba_kernels.hip spreads one tile of 64 tracks over a workgroup of 8-16 waves: right for
 // graphs of a few hundred tiles, where a tile's latency is all there is.  On graphs of thousands of tiles the
 // chain  tile tables -> poses / patches -> edge list -> targets -> barriers -> Schur product -> atomics  of ONE
-// tile at a time keeps a CU's pipes idle.  Here every WAVE owns whole tiles and walks a contiguous range of them
-// with no workgroup barrier anywhere (workgroup = one wave, its LDS is private):
-//   * lane l = track l of the tile (as in k_tile); the wave runs ALL edge slots of the tile, in groups of kSG
+// tile at a time keeps a CU's pipes idle.  Here a workgroup is TWO waves that own whole tiles and walk a contiguous
+// range of them (LDS private to the pair, one barrier per tile where their partial sums merge):
+//   * lane l = track l of the tile (as in k_tile); each wave runs half of the tile's edge slots, in groups of kSG
 //     slots whose operands (edge ids, 16-bit slot codes, targets, weights) are loaded in one burst — the first
 //     group of tile t+1 while tile t is still being computed (tables at its top, the gathers before its Schur
 //     product), so the tile-to-tile critical path holds no exposed memory round trip;
-//   * local E in LDS (lane-private columns: plain read-add-write), per-pair sums in LDS doubles;
-//   * the Schur product E Q E^T on v_mfma_f64_16x16x4_f64 with the accumulators kept in REGISTERS across
-//     consecutive tiles with the same cameras (tracks of one frame), atomics only when the cameras change;
-//     E Q w' by a wave reduce-scatter (the MFMA form would spend three 16x16 output tiles on one row);
+//   * local E in LDS (lane-private columns: plain read-add-write; the planner flags the tiles where the two waves'
+//     slot ranges split a run of repeated observations), per-pair sums per wave in LDS doubles;
+//   * the Schur product E Q E^T on v_mfma_f64_16x16x4_f64, its row tiles split between the two waves, with the
+//     accumulators kept in REGISTERS across consecutive tiles with the same cameras (tracks of one frame), atomics
+//     only when the cameras change; E Q w' by a wave reduce-scatter;
 //   * MODE kModeSO: structure-only steps (C, w, Q, w' only);  kModeUpd: the depth back-substitution of k_update
 //     (ba_kernels.hip) for the same tile walk.
+// Which graphs take this kernel: stream_applies() below and edge_applies() in ba_stream3.hip (profiles/r02_kernel_choice.txt).
 // Reference: ba.py:228-337, projective_ops.py:54-100.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>

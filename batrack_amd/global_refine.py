@@ -1,4 +1,4 @@
-"""Forward losses of the reference's dense global-alignment stage on the gfx950 kernels.
+"""Losses of the reference's dense global-alignment stage and their gradients on the gfx950 kernels.
 
 `RefineLosses` holds what `RefineNet` (/root/reference/main/global_refine/model/refine_net.py) holds after its
 `_init_from_ba` — same attribute names (`trajs_2d`, `trajs_disp`, `trajs_disp_mono`, `trajs_vis`, `trajs_static`, `jj`,
@@ -8,7 +8,10 @@
   inter_frame_loss()         refine_net.py:199-225 (the O(Q S N^2) rigidity term)
   pts_3d_loss()              refine_net.py:300-345
   forward(alpha)             total of refine_net.py:291-293 (loss_weight_dict = None, no scale-grid smoothness)
-through include/batrack_ga.h.  Forward values only: the Adam loop's backward pass (trainer.py:23-77) is not provided.
+  backward(alpha) / loss(alpha)   gradients of forward(alpha) w.r.t. `trajs_scales` and `frame_scales_` (what the reference
+                             gets from autograd and steps with Adam, trainer.py:23-77): explicit, or as a torch.autograd
+                             node so that `net.loss(alpha).backward()` fills `.grad` of the two parameters
+through include/batrack_ga.h.  pts_3d_loss (poses, intrinsics) is forward only.
 `half_disp=True` keeps the two disparity arrays in float16 and forms the depth residual in float16 (BASELINE.json
 configs[4]).  GPU tensors only; there is no CPU fallback.
 """
@@ -43,8 +46,9 @@ class RefineLosses:
         self._lib = _lib.lib()
         self._mono_scaled = torch.empty(self.T, self.N, self.S_local, device=dev, dtype=torch.float32)
         self._losses = torch.zeros(3, device=dev, dtype=torch.float64)
+        self._g_ms = None
 
-    def _run(self, which):
+    def _args(self):
         a = _lib.GaArgs()
         a.T, a.N, a.S = self.T, self.N, self.S_local
         a.gh, a.gw = self.frame_scales_.shape[1:]
@@ -53,8 +57,31 @@ class RefineLosses:
                      ("trajs_vis", self.trajs_vis), ("trajs_static", self.trajs_static), ("jj", self.jj), ("intrinsics", self.intrinsics),
                      ("pose", self.pose), ("query", self.grid_query_frames), ("trajs_scales", self.trajs_scales),
                      ("frame_scales", self.frame_scales_), ("frame_shifts", self.frame_shifts_)):
+            if not (t.is_cuda and t.is_contiguous()):
+                raise RuntimeError(f"RefineLosses: `{n}` must be a contiguous GPU tensor")
             setattr(a, n, t.data_ptr())
         a.pw_break, a.half_disp = self.pw_break, 1 if self.half_disp else 0
+        return a
+
+    def backward(self, alpha=0.5):
+        """(d forward(alpha) / d trajs_scales [T,N,S], d forward(alpha) / d frame_scales_ [T,gh,gw]) as new float32 tensors."""
+        self._run(1)                                                      # mono_scaled for the current parameters
+        if self._g_ms is None:
+            self._g_ms = torch.empty_like(self._mono_scaled)
+        g_ts, g_fs = torch.empty_like(self._mono_scaled), torch.empty_like(self.frame_scales_, dtype=torch.float32)
+        a = self._args()
+        st = torch.cuda.current_stream(self.trajs_2d.device).cuda_stream
+        _lib.check(self._lib.bt_ga_backward(ctypes.byref(a), self._mono_scaled.data_ptr(), 1.0, float(alpha), self._g_ms.data_ptr(),
+                                            g_ts.data_ptr(), g_fs.data_ptr(), st), "bt_ga_backward")
+        return g_ts, g_fs
+
+    def loss(self, alpha=0.5):
+        """forward(alpha) as a float32 scalar attached to autograd: `.backward()` fills `.grad` of `self.trajs_scales` and
+        `self.frame_scales_` when they are leaves that require grad (the reference's nn.Parameters)."""
+        return _TotalLoss.apply(self.trajs_scales, self.frame_scales_, self, float(alpha))
+
+    def _run(self, which):
+        a = self._args()
         st = torch.cuda.current_stream(self.trajs_2d.device).cuda_stream
         _lib.check(self._lib.bt_ga_forward(ctypes.byref(a), self._mono_scaled.data_ptr(), self._losses.data_ptr(), int(which), st),
                    "bt_ga_forward")
@@ -80,3 +107,17 @@ class RefineLosses:
     def forward(self, alpha=0.5):
         l = self._run(3 if alpha > 0 else 1)
         return l[0] + alpha * l[1] if alpha > 0 else l[0].clone()
+
+
+class _TotalLoss(torch.autograd.Function):
+    """spatial + alpha * inter-frame as one autograd node over bt_ga_forward / bt_ga_backward."""
+
+    @staticmethod
+    def forward(ctx, trajs_scales, frame_scales_, net, alpha):
+        ctx.net, ctx.alpha = net, alpha
+        return net.forward(alpha).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g_ts, g_fs = ctx.net.backward(ctx.alpha)
+        return g_ts * gout, g_fs * gout, None, None

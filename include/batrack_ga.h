@@ -1,11 +1,11 @@
-/* batrack_ga.h — C ABI of the dense global-alignment LOSSES (forward), SURVEY.md §8 row f-4.
+/* batrack_ga.h — C ABI of the dense global-alignment LOSSES and their gradients, SURVEY.md §8 row f-4.
  *
  * Reference: RefineNet.forward and the losses it calls,
  *   /root/reference/main/global_refine/model/refine_net.py:123-127 (get_trajs_scales), :148-174 (get_frame_scaled_depth),
  *   :252-268 (spatial huber term), :199-225 (inter_frame_loss, O(Q S N^2)), :300-345 (pts_3d_loss),
  * driven by the Adam loop of model/trainer.py:23-77.  The reference is a Python/autograd module (pypose for the poses);
  * it has no FFI.  This header is what a binding of those forward computations binds; batrack_amd/global_refine.py does
- * so.  Forward values only (the optimiser's backward pass is not provided).  Device pointers, sizes, integer status
+ * so.  bt_ga_forward gives the values, bt_ga_backward the gradients of the default total (spatial + alpha * rigid).  Device pointers, sizes, integer status
  * codes (include/batrack_ba.h); nothing allocates or synchronises.
  */
 #ifndef BATRACK_GA_H
@@ -42,6 +42,16 @@ typedef struct {
  * inter_frame_loss, pts_3d_loss — each the reference's mean.  `which` selects: bit 0 spatial (always computes
  * mono_scaled_out), bit 1 inter-frame, bit 2 3-D points.  Enqueued on `stream`. */
 int bt_ga_forward(const bt_ga_args *args, float *mono_scaled_out, double *losses, int32_t which, void *stream);
+
+/* Gradient of  w_spatial * (spatial huber term) + w_rigid * inter_frame_loss  — RefineNet.forward's total with
+ * loss_weight_dict = None is that with w_spatial = 1, w_rigid = alpha (refine_net.py:252-293) — with respect to the two
+ * parameters it reaches: grad_trajs_scales [T,N,S] (through exp((p - mean_n p) / pw_break), refine_net.py:123-127) and
+ * grad_frame_scales [T,gh,gw] (through exp(g / 10) and the bilinear sample, :139-174), what the reference obtains from
+ * autograd (trainer.py:23-77).  `mono_scaled` is the [T,N,S] output of bt_ga_forward for the same arguments;
+ * `g_mono_scaled` is [T,N,S] float scratch (on return: d total / d mono_scaled).  Query frames must be distinct.  The three
+ * outputs are overwritten.  pts_3d_loss (poses, intrinsics) has no backward here.  Enqueued on `stream`. */
+int bt_ga_backward(const bt_ga_args *args, const float *mono_scaled, float w_spatial, float w_rigid, float *g_mono_scaled,
+                   float *grad_trajs_scales, float *grad_frame_scales, void *stream);
 
 #ifdef __cplusplus
 }

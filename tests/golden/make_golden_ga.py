@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Golden vectors for the dense global-alignment losses: runs the reference's UNMODIFIED
 /root/reference/main/global_refine/model/refine_net.py (RefineNet.get_frame_scaled_depth, the spatial huber term of
-forward(), inter_frame_loss, pts_3d_loss) on synthetic tracks, in this container only.  `pypose` is absent: the
+forward(), inter_frame_loss, pts_3d_loss, and the gradients of forward() by the reference's autograd) on synthetic tracks,
+in this container only.  `pypose` is absent: the
 stand-in of tests/golden/refstubs/pypose is used (SE3 compose / inverse / action — our restatement; what these vectors
 pin is refine_net.py).  A RefineNet object is built without its __init__ (which reads a results.pkl): the attributes
 forward() reads are set directly.  Only inputs we generated and numeric outputs are written (tests/golden/ga_small.npz).
@@ -87,6 +88,16 @@ def main():
             out[f"{tag}.loss_pts3d"] = np.float64(net.pts_3d_loss().item())
             net.alpha = 0.5
             out[f"{tag}.total_alpha05"] = np.float64(net.forward().item())
+    # gradients of forward() (spatial + alpha * rigid) w.r.t. the two parameters the default loss reaches, by the reference's
+    # own autograd
+    for tag, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+        for alpha in (0.0, 0.5):
+            net = build(d, dtype)
+            net.alpha = alpha
+            net.forward().backward()
+            key = "a00" if alpha == 0.0 else "a05"
+            out[f"{tag}.grad_trajs_scales_{key}"] = net.trajs_scales.grad.numpy()
+            out[f"{tag}.grad_frame_scales_{key}"] = net.frame_scales_.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "ga_small.npz"), **out)
     print({k: float(v) for k, v in out.items() if np.ndim(v) == 0 and k[0] == "f"})
 

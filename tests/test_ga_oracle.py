@@ -25,3 +25,18 @@ def test_float32_within_rounding():
     assert rel(ga.frame_scaled_depth(d32), D["f64.mono_scaled"]) < 1e-6
     assert abs(ga.inter_frame_loss(d32) / D["f64.loss_rigid"] - 1) < 1e-5
     assert abs(ga.spatial_loss(d32) / D["f64.loss_spatial"] - 1) < 1e-5
+
+
+def test_torch_statement_and_its_gradients_match_the_reference_autograd():
+    """oracle/ga_torch.py: forward equal to the numpy oracle and to the reference, gradients of forward() equal to the ones
+    the reference's own autograd produced (fixture keys *.grad_*)."""
+    from oracle import ga_torch
+    for alpha, key in ((0.0, "a00"), (0.5, "a05")):
+        tot, sp, rg, g_ts, g_fs = ga_torch.total_and_grads(D, alpha)
+        assert abs(sp / float(D["f64.loss_spatial"]) - 1) < 1e-12
+        if alpha > 0:
+            assert abs(rg / float(D["f64.loss_rigid"]) - 1) < 1e-12 and abs(tot / float(D["f64.total_alpha05"]) - 1) < 1e-12
+        for got, name in ((g_ts, "grad_trajs_scales"), (g_fs, "grad_frame_scales")):
+            ref = D[f"f64.{name}_{key}"]
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-30) + 1e-18, (name, key, np.abs(got - ref).max())

@@ -81,3 +81,61 @@ def test_cpu_tensors_raise():
     with pytest.raises(RuntimeError):
         RefineLosses(t("trajs_2d"), t("trajs_disp"), t("trajs_disp_mono"), t("trajs_vis"), t("trajs_static"), t("jj"), t("intrinsics"),
                      t("grid_query_frames"), t("trajs_scales"), t("frame_scales_"), t("frame_shifts"), t("pose"), 96, 128)
+
+
+def _gerr(got, ref):
+    """Error of a gradient tensor relative to its largest entry (many entries are exactly zero: masked tracks, frames
+    that are no query frame)."""
+    return float(np.abs(np.asarray(got, np.float64) - ref).max() / np.abs(ref).max())
+
+
+@pytest.mark.parametrize("alpha,key", [(0.0, "a00"), (0.5, "a05")])
+def test_gradients_match_the_reference_autograd(alpha, key):
+    """bt_ga_backward against the gradients the reference's OWN autograd produced for forward() (fixture keys *.grad_*)."""
+    net = build(D)
+    g_ts, g_fs = net.backward(alpha)
+    assert _gerr(g_ts.cpu().numpy(), D[f"f64.grad_trajs_scales_{key}"]) < 2e-5
+    assert _gerr(g_fs.cpu().numpy(), D[f"f64.grad_frame_scales_{key}"]) < 2e-5
+    # frames that are no query frame carry no gradient in trajs_scales, exactly
+    notq = np.setdiff1d(np.arange(net.T), D["grid_query_frames"])
+    assert float(g_ts[torch.as_tensor(notq, device=g_ts.device)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("T,N,S", [(12, 300, 7), (6, 520, 5)])
+def test_gradients_of_larger_cases_vs_torch_oracle(T, N, S):
+    from oracle import ga_torch
+    d = make_case(T, N, S, seed=T + N)
+    net = build(d)
+    g_ts, g_fs = net.backward(0.5)
+    tot, _, _, r_ts, r_fs = ga_torch.total_and_grads(d, 0.5)
+    assert abs(float(net.forward(0.5)) / tot - 1) < 1e-5
+    # float32 sums of up to N signed unit vectors per track against float64 autograd
+    assert _gerr(g_ts.cpu().numpy(), r_ts) < 5e-5 and _gerr(g_fs.cpu().numpy(), r_fs) < 2e-4, (_gerr(g_ts.cpu().numpy(), r_ts), _gerr(g_fs.cpu().numpy(), r_fs))
+
+
+def test_adam_steps_through_the_autograd_node():
+    """The reference's refinement loop (trainer.py:23-77) in miniature: Adam on the two parameters through
+    `net.loss(alpha).backward()`; same loss trajectory as the float64 torch oracle under the same optimiser."""
+    from oracle import ga_torch
+    d = make_case(8, 200, 5, seed=3)
+    net = build(d)
+    net.trajs_scales.requires_grad_(True); net.frame_scales_.requires_grad_(True)
+    opt = torch.optim.Adam([net.trajs_scales, net.frame_scales_], lr=0.05)
+    ts = torch.as_tensor(d["trajs_scales"], dtype=torch.float64).requires_grad_(True)
+    fs = torch.as_tensor(d["frame_scales_"], dtype=torch.float64).requires_grad_(True)
+    ropt = torch.optim.Adam([ts, fs], lr=0.05)
+    hip, ref = [], []
+    for _ in range(8):
+        opt.zero_grad()
+        l = net.loss(0.5)
+        l.backward()
+        opt.step()
+        hip.append(float(l.detach()))
+        ropt.zero_grad()
+        ms = ga_torch.frame_scaled_depth(d, fs)
+        lr_ = ga_torch.spatial_loss(d, ts, ms) + 0.5 * ga_torch.inter_frame_loss(d, ms)
+        lr_.backward()
+        ropt.step()
+        ref.append(float(lr_.detach()))
+    assert hip[-1] < 0.98 * hip[0] and all(b < a for a, b in zip(hip, hip[1:]))      # the optimiser makes progress, every step
+    assert max(abs(a / b - 1) for a, b in zip(hip, ref)) < 2e-3, (hip, ref)

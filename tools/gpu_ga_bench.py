@@ -21,5 +21,23 @@ for T, N, S in ((50, 400, 12), (50, 1024, 12)):
             torch.cuda.synchronize()
             us = (time.perf_counter() - t0) / 50 * 1e6
             print(f"T={T} N={N} S={S} half={half} {name:14s}: {us:9.1f} us per forward", flush=True)
+    net = build(d)
+    for alpha, name in ((0.0, "backward, spatial only"), (0.5, "backward, spatial + rigid")):
+        net.backward(alpha); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            net.backward(alpha)
+        torch.cuda.synchronize()
+        print(f"T={T} N={N} S={S} {name:26s}: {(time.perf_counter() - t0) / 30 * 1e6:9.1f} us (incl. the forward pass of the scaled depth)", flush=True)
+    net.trajs_scales.requires_grad_(True); net.frame_scales_.requires_grad_(True)
+    opt = torch.optim.Adam([net.trajs_scales, net.frame_scales_], lr=1e-2)
+    def it():
+        opt.zero_grad(); net.loss(0.5).backward(); opt.step()
+    it(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        it()
+    torch.cuda.synchronize()
+    print(f"T={T} N={N} S={S} one Adam iteration (loss, backward, step): {(time.perf_counter() - t0) / 20 * 1e6:9.1f} us", flush=True)
     pairs = T * (S - 1) * N * N
     print(f"  pairwise work: {pairs/1e6:.1f} M pairs x ~20 flop = {pairs*20/1e9:.2f} GFLOP")
