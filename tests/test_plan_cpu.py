@@ -241,3 +241,20 @@ def test_patch_activity_tables_and_track_records():
         tile, lane = loc >> 6, loc & 63
         assert np.array_equal(A["tile_kx"].reshape(-1, 64)[tile, lane], A["kx"])
         pl.close()
+
+
+@pytest.mark.parametrize("case", ["one_edge", "one_track", "two_frames", "all_fixed", "all_masked", "self_edges"])
+def test_degenerate_problems_through_the_plan(case):
+    """Single edge / single track / two frames / every pose fixed / every edge masked / self edges only: the host plan
+    executed in float64 equals the oracle (the same problems run on the device in tests/test_gpu_edge_cases.py)."""
+    from edge_problems import CASES
+    make, fixedp = CASES[case]
+    d = make()
+    pl = host_plan(d, fixedp)
+    out = emulate(pl, pl.arrays(), d, "weights_pose", structure_only=pl.n == 0)
+    so = pl.n == 0
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"], d["ii"], d["jj"], d["kk"],
+                         d["bounds"], fixedp=fixedp, structure_only=so, want_system=not so)
+    assert rel(out["patches_out"], ref["patches_out"]) < 1e-10
+    if not so:
+        assert np.abs(out["dX"] - ref["dX"].reshape(-1, 6)).max() <= 1e-9 * max(np.abs(ref["dX"]).max(), 1e-30) + 1e-15
