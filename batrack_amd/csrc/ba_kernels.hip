@@ -1946,8 +1946,10 @@ __device__ inline void retract_pose(const float *pin, const float *xi, float *po
 constexpr int kUpdThreads = 512;
 constexpr int kUpdGeo = 28;          // floats per pair in LDS: the 20 of kPairGeomFloats, delta (6), padding to 16 bytes
 
-template <bool SO>
-__global__ __launch_bounds__(kUpdThreads) void k_update(PlanDev pd, StepArgs a, int do_poses, int tile_blocks, int first_zero_block) {
+// THREADS: 512, or 1024 for the few-tiles / many-slots graphs that k_tile runs 16 waves wide (tile_wide): the tile blocks'
+// slot loop, which is all the time there is on 40 tiles, halves.
+template <bool SO, int THREADS = kUpdThreads>
+__global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int do_poses, int tile_blocks, int first_zero_block) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (!SO && (int)blockIdx.x >= first_zero_block) {
         const size_t nz = (size_t)pd.D * pd.D + pd.D;
@@ -1958,7 +1960,7 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(PlanDev pd, StepArgs a, 
     }
     if (!SO && (int)blockIdx.x < tile_blocks) {
         const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-        constexpr int kWaves = kUpdThreads / 64;
+        constexpr int kWaves = THREADS / 64;
         float *geo = lds;                                           // [npair][kUpdGeo]
         float *part = lds + (size_t)pd.max_tile_pairs * kUpdGeo;    // [kWaves][64]
         const int np = pd.tile_npair[tile];
@@ -1968,7 +1970,7 @@ __global__ __launch_bounds__(kUpdThreads) void k_update(PlanDev pd, StepArgs a, 
         const int s0 = wave * chunk, s1 = min(nslot, s0 + chunk);
         int e_nx = -1, lp_nx = 0;
         if (s0 < s1) { const size_t idx = (size_t)(slot0 + s0) * kLanes + lane; e_nx = pd.slot_edge[idx]; lp_nx = pd.slot_lp[idx]; }
-        for (int p = tid; p < np; p += kUpdThreads) {
+        for (int p = tid; p < np; p += THREADS) {
             const int gp = pd.tile_pairs[pd.tile_pair0[tile] + p];
             const int ia = pd.pair_i[gp] - pd.fixedp, ib = pd.pair_j[gp] - pd.fixedp;
             float g[kPairGeomFloats];
@@ -2279,6 +2281,11 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int rc = launch_stream(pd, a, 2, st, nullptr, nullptr);
         if (rc != BT_OK) return rc;
         BT_LAUNCH(4, k_update<false>, dim3(nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, 0, nb);
+    }
+    else if (tile_wide(pd)) {
+        constexpr int W = 1024;
+        const int nbw = (total + W - 1) / W, zbw = (int)((nz + 4 * W - 1) / (4 * W));
+        BT_LAUNCH(4, (k_update<false, W>), dim3(pd.T + nbw + zbw), dim3(W), ((size_t)pd.max_tile_pairs * kUpdGeo + W) * sizeof(float), pd, a, do_poses, pd.T, pd.T + nbw);
     }
     else    BT_LAUNCH(4, k_update<false>, dim3(pd.T + nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, pd.T, pd.T + nb);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
