@@ -2169,8 +2169,8 @@ static int raise_lds_limit(const void *fn, size_t need) {
 int configure_kernels(const PlanDev &pd) {
     const size_t need = tile_lds_bytes(pd, false);
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
-    const void *tiles[3] = { reinterpret_cast<const void *>(&k_tile<false, false>), reinterpret_cast<const void *>(&k_tile<false, false, true>),
-                             reinterpret_cast<const void *>(&k_tile<false, true>) };
+    const void *tiles[4] = { reinterpret_cast<const void *>(&k_tile<false, false>), reinterpret_cast<const void *>(&k_tile<false, false, true>),
+                             reinterpret_cast<const void *>(&k_tile<false, true>), reinterpret_cast<const void *>(&k_tile<false, true, true>) };
     for (const void *fn : tiles) if (raise_lds_limit(fn, need) != BT_OK) return BT_EHIP;
     const int mode = solver_mode(pd);
     const void *fns[4] = { reinterpret_cast<const void *>(&k_solve_lds<double, false>),
@@ -2217,6 +2217,7 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         const dim3 blk(tile_threads(pd)), grid(pd.T);
         if (so && wide)        BT_LAUNCH(1, (k_tile<true, false, true>), grid, blk, tile_lds_bytes(pd, true), pd, a);
         else if (so)           BT_LAUNCH(1, (k_tile<true, false>), grid, blk, tile_lds_bytes(pd, true), pd, a);
+        else if ((a.dbg & 32) && wide) BT_LAUNCH(1, (k_tile<false, true, true>), grid, blk, tile_lds_bytes(pd, false), pd, a);
         else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), grid, dim3(512), tile_lds_bytes(pd, false), pd, a);
         else if (wide)         BT_LAUNCH(1, (k_tile<false, false, true>), grid, blk, tile_lds_bytes(pd, false), pd, a);
         else                   BT_LAUNCH(1, (k_tile<false, false>), grid, blk, tile_lds_bytes(pd, false), pd, a);
