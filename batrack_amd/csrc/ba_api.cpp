@@ -191,6 +191,7 @@ int upload_plan(bt_plan *pl) {
     const size_t o_cl = put(buf, pl->col_lvl), o_dpp = put(buf, pl->dp_ptr), o_dp = put(buf, pl->dp);
     const size_t o_fpp = put(buf, pl->fz_pend_ptr), o_fp = put(buf, pl->fz_pend), o_flp = put(buf, pl->fz_lazy_ptr), o_fl = put(buf, pl->fz_lazy);
     const size_t o_fy = put(buf, pl->fz_yurg), o_fm = put(buf, pl->fz_meta), o_fpm = put(buf, pl->fz_pmeta), o_bss = put(buf, pl->bs_sync), o_fri = put(buf, pl->fz_rowinfo), o_fpf = put(buf, pl->fz_pfirst), o_fps = put(buf, pl->fz_psecond), o_tij = put(buf, pl->tile_ij), o_tkx = put(buf, pl->tile_kx);
+    const size_t o_tc8 = put(buf, pl->tile_cut8), o_tc16 = put(buf, pl->tile_cut16);
     const size_t o_sc = put(buf, pl->slot_code), o_tla = put(buf, pl->tile_la), o_trec = put(buf, pl->tile_rec), o_ite = put(buf, pl->it_edge), o_tsi = put(buf, pl->tile_sinfo);
     tick("pack arrays");
     size_t cap = 0;
@@ -231,6 +232,7 @@ int upload_plan(bt_plan *pl) {
     P.lvl_meta = BT_I32(o_lm); P.tile_flags = BT_I32(o_tf);
     P.fz_pend_ptr = BT_I32(o_fpp); P.fz_pend = BT_I32(o_fp); P.fz_lazy_ptr = BT_I32(o_flp); P.fz_lazy = BT_I32(o_fl);
     P.fz_yurg = BT_I32(o_fy); P.fz_meta = BT_I32(o_fm); P.fz_pmeta = BT_I32(o_fpm); P.bs_sync = BT_I32(o_bss); P.fz_rowinfo = BT_I32(o_fri); P.fz_pfirst = BT_I32(o_fpf); P.fz_psecond = BT_I32(o_fps); P.tile_ij = BT_I32(o_tij); P.tile_kx = BT_I32(o_tkx);
+    P.tile_cut8 = reinterpret_cast<const uint16_t *>(b + o_tc8); P.tile_cut16 = reinterpret_cast<const uint16_t *>(b + o_tc16);
     P.fz_npend = (int)(pl->fz_pend.size() / 2); P.fz_nlazy = (int)(pl->fz_lazy.size() / 3); P.fz_ok = pl->fz_ok; P.fzp_ok = pl->fzp_ok;
     P.tile_pair0 = BT_I32(o_tp0); P.tile_npair = BT_I32(o_tnp); P.tile_pairs = BT_I32(o_tps);
     P.slot_lp = reinterpret_cast<const uint8_t *>(b + o_slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams; P.e_all = pl->e_all;
@@ -358,7 +360,7 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
     BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next) BT_ARR(perm) BT_ARR(blk_src) BT_ARR(lvl_ptr) BT_ARR(lvl_cols)
     BT_ARR(col_lvl) BT_ARR(dp_ptr) BT_ARR(dp) BT_ARR(tile_pair0) BT_ARR(tile_npair) BT_ARR(tile_pairs) BT_ARR(slot_lp) BT_ARR(tile_flags)
-    BT_ARR(fz_pend_ptr) BT_ARR(fz_pend) BT_ARR(fz_lazy_ptr) BT_ARR(fz_lazy) BT_ARR(fz_yurg) BT_ARR(fz_meta) BT_ARR(fz_pmeta) BT_ARR(bs_sync) BT_ARR(fz_rowinfo) BT_ARR(fz_pfirst) BT_ARR(fz_psecond) BT_ARR(act_bits) BT_ARR(act_rank) BT_ARR(tile_ij) BT_ARR(tile_kx) BT_ARR(lvl_meta) BT_ARR(slot_code) BT_ARR(tile_la) BT_ARR(tile_rec) BT_ARR(it_edge) BT_ARR(tile_sinfo)
+    BT_ARR(fz_pend_ptr) BT_ARR(fz_pend) BT_ARR(fz_lazy_ptr) BT_ARR(fz_lazy) BT_ARR(fz_yurg) BT_ARR(fz_meta) BT_ARR(fz_pmeta) BT_ARR(bs_sync) BT_ARR(fz_rowinfo) BT_ARR(fz_pfirst) BT_ARR(fz_psecond) BT_ARR(act_bits) BT_ARR(act_rank) BT_ARR(tile_ij) BT_ARR(tile_kx) BT_ARR(lvl_meta) BT_ARR(slot_code) BT_ARR(tile_la) BT_ARR(tile_rec) BT_ARR(it_edge) BT_ARR(tile_sinfo) BT_ARR(tile_cut8) BT_ARR(tile_cut16)
 #undef BT_ARR
     return -1;
 }

@@ -90,8 +90,9 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         const int ij0 = tid < mtp ? pd.tile_ij[(size_t)tile * mtp + tid] : 0;
         const int patch_ld = pd.tile_kx[(size_t)tile * kLanes + lane];
         const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
-        const int chunk = (nslot + kTileWaves - 1) / kTileWaves;
-        const int s0 = wave * chunk, s1 = min(nslot, s0 + chunk);
+        // this wave's slots: the plan's cuts (at boundaries that no run of repeated observations crosses, ba_plan.cpp)
+        const uint16_t *cut = WIDE ? pd.tile_cut16 + (size_t)tile * 17 : pd.tile_cut8 + (size_t)tile * 9;
+        const int s0 = cut[wave], s1 = cut[wave + 1];
         // this wave's first slot, in flight while the pair geometry is computed
         int e_nx = -1, pair_nx = 0, lp_nx = 0;
         unsigned lab_nx = 0xffffu;

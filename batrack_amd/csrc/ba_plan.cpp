@@ -281,10 +281,21 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     pl->tile_pair0.assign((size_t)T, 0); pl->tile_npair.assign((size_t)T, 0);
     pl->tile_pairs.clear();
     pl->max_tile_pairs = 0;
+    // tile_cut8 / tile_cut16: where k_tile's 8 or 16 waves split the tile's slots.  Repeated observations of one (track,
+    // target camera) are consecutive slots of that track; a wave sums such a run in registers and writes it once, but a run
+    // that continues into the next wave's chunk forces LDS float atomics on every slot of it (~500 cycles per wave
+    // instruction on this part).  The sliding-window caller repeats observations all the time and all tracks of a tile
+    // share their pattern, so the cuts are moved to the nearest slot boundary that no track's run crosses.
+    pl->tile_cut8.assign((size_t)T * 9, 0);
+    pl->tile_cut16.assign((size_t)T * 17, 0);
     {
         std::vector<int32_t> local((size_t)n + 1, -1), lp_of(pl->pair_i.size(), -1), mine;
+        std::vector<uint8_t> crossed;                              // crossed[s]: some track's run spans slots s - 1 and s
         for (int32_t t = 0; t < T; ++t) {
             const int32_t c0 = pl->tile_cam0[(size_t)t], nc = pl->tile_ncam[(size_t)t], t0 = pl->tile_trk0[(size_t)t], nt = pl->tile_ntrk[(size_t)t];
+            const int32_t ns_t = pl->tile_nslot[(size_t)t];
+            if (ns_t > 0xffff) return BT_EUNSUPPORTED;           // (a track with more than 65535 observations)
+            crossed.assign((size_t)ns_t + 1, 0);
             for (int32_t c = 0; c < nc; ++c) local[(size_t)pl->tile_cams[(size_t)(c0 + c)]] = c;
             mine.clear();
             if (masks_ok) {
@@ -307,6 +318,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             for (size_t q = 0; q < mine.size(); ++q) lp_of[(size_t)mine[q]] = (int32_t)q;
             for (int32_t l = 0; l < nt; ++l) {
                 const int32_t k = t0 + l;
+                uint16_t lb_before = 0xff;
                 for (int32_t sidx = off[(size_t)k]; sidx < off[(size_t)k + 1]; ++sidx) {
                     const int32_t e = ord[(size_t)sidx];
                     const size_t idx = ((size_t)pl->tile_slot0[(size_t)t] + (size_t)(sidx - off[(size_t)k])) * kLanes + (size_t)l;
@@ -319,7 +331,29 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                     pl->slot_pair[idx] = gp;
                     pl->slot_lab[idx] = (uint16_t)(la | (lb << 8));
                     pl->slot_lp[idx] = (uint8_t)lp_of[(size_t)gp];
+                    if (lb != 0xff && lb == lb_before) crossed[(size_t)(sidx - off[(size_t)k])] = 1;
+                    lb_before = lb;
                 }
+            }
+            for (int W = 8; W <= 16; W += 8) {
+                uint16_t *cut = (W == 8 ? pl->tile_cut8.data() + (size_t)t * 9 : pl->tile_cut16.data() + (size_t)t * 17);
+                const int32_t chunk = (ns_t + W - 1) / W;
+                int32_t prev = 0;
+                cut[0] = 0;
+                for (int w = 1; w < W; ++w) {
+                    const int32_t ideal = std::min(ns_t, w * chunk);
+                    int32_t best = ideal;
+                    if (ideal < ns_t && crossed[(size_t)ideal]) {          // nearest uncrossed boundary within a chunk's reach, else keep it
+                        for (int32_t d = 1; d <= chunk; ++d) {
+                            if (ideal - d >= prev && !crossed[(size_t)(ideal - d)]) { best = ideal - d; break; }
+                            if (ideal + d <= ns_t && (ideal + d == ns_t || !crossed[(size_t)(ideal + d)])) { best = ideal + d; break; }
+                        }
+                    }
+                    best = std::max(best, prev);
+                    cut[w] = (uint16_t)best;
+                    prev = best;
+                }
+                cut[W] = (uint16_t)ns_t;
             }
             pl->tile_pair0[(size_t)t] = (int32_t)pl->tile_pairs.size();
             pl->tile_npair[(size_t)t] = (int32_t)mine.size();

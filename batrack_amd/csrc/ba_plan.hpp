@@ -32,6 +32,7 @@ struct PlanDev {
     const int32_t *slot_edge, *slot_pair;
     const uint16_t *slot_lab;
     const int32_t *tile_pair0, *tile_npair, *tile_pairs;     // distinct camera pairs of a tile (global pair ids)
+    const uint16_t *tile_cut8, *tile_cut16;                  // per tile: slot ranges of k_tile's 8 / 16 waves [9] / [17] (ba_plan.cpp)
     const int32_t *tile_ij, *tile_kx;                        // per tile: cameras of its pairs [max_tile_pairs], patch of its tracks [64]
     const int32_t *tile_flags;                               // bit 0: same cameras as the previous tile, bit 1: same pair list
     const uint8_t *slot_lp;                                  // local pair index of a (slot, lane) within its tile
@@ -77,6 +78,7 @@ struct bt_plan {
     std::vector<int32_t> slot_edge, slot_pair;
     std::vector<uint16_t> slot_lab;
     std::vector<int32_t> tile_pair0, tile_npair, tile_pairs, tile_flags, tile_ij, tile_kx;
+    std::vector<uint16_t> tile_cut8, tile_cut16;
     std::vector<uint8_t> slot_lp, tile_la;
     std::vector<uint16_t> slot_code;
     std::vector<int32_t> tile_rec, it_edge;
@@ -110,6 +112,7 @@ struct bt_plan {
                         &dp, &lvl_meta, &fz_pend_ptr, &fz_pend, &fz_lazy_ptr, &fz_lazy, &fz_yurg, &fz_meta, &fz_pmeta,
                         &bs_sync, &fz_rowinfo, &fz_pfirst, &fz_psecond})
             v->clear();
+        tile_cut8.clear(); tile_cut16.clear();
         slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); it_edge.clear(); tile_sinfo.clear(); em_ok = 0; em_its = 0; em_lgs = -1; act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;
         fz_ok = fzp_ok = 0;

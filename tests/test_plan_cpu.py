@@ -258,3 +258,34 @@ def test_degenerate_problems_through_the_plan(case):
     assert rel(out["patches_out"], ref["patches_out"]) < 1e-10
     if not so:
         assert np.abs(out["dX"] - ref["dX"].reshape(-1, 6)).max() <= 1e-9 * max(np.abs(ref["dX"]).max(), 1e-30) + 1e-15
+
+
+@pytest.mark.parametrize("name", ["c1", "c1_rough", "window_small"])
+def test_wave_cuts_partition_the_slots_and_avoid_runs(name):
+    """tile_cut8 / tile_cut16: k_tile's waves take [cut[w], cut[w+1]) — a partition of the tile's slots; a cut sits inside a run
+    of repeated observations (same track, same target camera in consecutive slots) only when no run-free boundary exists
+    within a chunk of the even split."""
+    d = load(name)
+    pl = host_plan(d, int(d["fixedp"]) if name == "window_small" else 1)
+    A = pl.arrays()
+    lab = A["slot_lab"].reshape(-1, 64)
+    edge = A["slot_edge"].reshape(-1, 64)
+    crossed_cuts = total_cuts = 0
+    for t in range(pl.tiles):
+        s0, ns = int(A["tile_slot0"][t]), int(A["tile_nslot"][t])
+        lb = lab[s0:s0 + ns] >> 8
+        act = edge[s0:s0 + ns] >= 0
+        crossed = np.zeros(ns + 1, bool)
+        crossed[1:ns] = ((lb[1:] == lb[:-1]) & (lb[1:] != 0xff) & act[1:] & act[:-1]).any(axis=1)
+        for W, key in ((8, "tile_cut8"), (16, "tile_cut16")):
+            cut = A[key].reshape(-1, W + 1)[t].astype(int)
+            assert cut[0] == 0 and cut[W] == ns and (np.diff(cut) >= 0).all()
+            chunk = -(-ns // W)
+            for w in range(1, W):
+                c = cut[w]
+                total_cuts += 1
+                if 0 < c < ns and crossed[c]:
+                    crossed_cuts += 1
+                    lo, hi = max(cut[w - 1], min(ns, w * chunk) - chunk), min(ns, min(ns, w * chunk) + chunk)
+                    assert crossed[max(lo, 1):hi].all() or c == cut[w - 1], (t, W, w, c)     # nothing better was in reach
+    assert total_cuts > 0
