@@ -76,7 +76,11 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             atomicAdd(&a.pairacc[(size_t)p_cur * kPairAccStride + vi], pacc);
         pacc = 0.0; p_cur = -1;
     };
-    const int tile_begin = blockIdx.x, tile_end = tile_begin + 1;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): XCD x gets workgroups x, x + 8, ...  Give it a
+    // CONTIGUOUS range of tiles instead — the tiles of one source frame are neighbours and share cameras, pair geometry and
+    // the rows of S they add to (1024 tiles: 38.9 -> 32.7 us; nothing at 256 tiles, where every CU holds one workgroup).
+    const int tq_ = gridDim.x >> 3, tr_ = gridDim.x & 7, xcd_ = blockIdx.x & 7;
+    const int tile_begin = xcd_ * tq_ + min(xcd_, tr_) + (blockIdx.x >> 3), tile_end = tile_begin + 1;
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
@@ -1960,7 +1964,9 @@ __global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int 
         return;
     }
     if (!SO && (int)blockIdx.x < tile_blocks) {
-        const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+        // (an XCD's workgroups take a contiguous range of tiles, as in k_tile)
+        const int tq_ = tile_blocks >> 3, tr_ = tile_blocks & 7, xcd_ = blockIdx.x & 7;
+        const int tile = xcd_ * tq_ + min(xcd_, tr_) + ((int)blockIdx.x >> 3), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
         constexpr int kWaves = THREADS / 64;
         float *geo = lds;                                           // [npair][kUpdGeo]
         float *part = lds + (size_t)pd.max_tile_pairs * kUpdGeo;    // [kWaves][64]

@@ -29,7 +29,7 @@ int edge_min_tiles() {
     return t;
 }
 int stream_min_tiles() {
-    static const int t = std::getenv("BT_STREAM_MIN_TILES") ? std::atoi(std::getenv("BT_STREAM_MIN_TILES")) : 1024;
+    static const int t = std::getenv("BT_STREAM_MIN_TILES") ? std::atoi(std::getenv("BT_STREAM_MIN_TILES")) : 2048;
     return t;
 }
 

@@ -168,7 +168,11 @@ __global__ __launch_bounds__(128, MODE == kModeFull ? BT_STREAM_FULL_WAVES : 4) 
     int *gpl = gidx + (MODE == kModeFull ? ((Rmax + 3) & ~3) : 0);
     double *pacc = reinterpret_cast<double *>(gpl + (MODE == kModeFull ? ((mtp + 3) & ~3) : 0)) + wave * mtp * 32;   // [2 waves][mtp][32]: this wave's
 
-    const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(pd.T, t_begin + tiles_per_wg);
+    // workgroups are dealt round-robin to the 8 XCDs: an XCD's workgroups take neighbouring tile ranges (shared cameras, pair
+    // geometry and rows of S stay in one L2): 48.7 -> 46.0 us at 2048 tiles
+    const int wq_ = gridDim.x >> 3, wr_ = gridDim.x & 7, wx_ = blockIdx.x & 7;
+    const int wg_ = wx_ * wq_ + min(wx_, wr_) + ((int)blockIdx.x >> 3);
+    const int t_begin = wg_ * tiles_per_wg, t_end = min(pd.T, t_begin + tiles_per_wg);
     if (t_begin >= t_end) return;
 
     constexpr int NACC = stream_nacc(NT);

@@ -188,7 +188,10 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
     double *pacc = reinterpret_cast<double *>(gpl + (MODE == kEmFull ? ((mtp + 3) & ~3) : 0));   // [mtp][32]
     double *ysum = pacc + (MODE == kEmFull ? mtp * 32 : 0);                                       // [64]: the wave's sums of E Q w' by local row
 
-    const int t_begin = blockIdx.x * tiles_per_wave, t_end = min(pd.T, t_begin + tiles_per_wave);
+    // (workgroup -> tile range stays plain: handing each XCD a contiguous block of ranges, which helps k_tile and k_stream,
+    //  made this kernel 4 % slower at 8.4M edges)
+    const int wg_ = blockIdx.x;
+    const int t_begin = wg_ * tiles_per_wave, t_end = min(pd.T, t_begin + tiles_per_wave);
     if (t_begin >= t_end) return;
 
     constexpr int NACC = NT * (NT + 1) / 2;
@@ -566,9 +569,9 @@ static size_t edge_lds_bytes(const PlanDev &pd, int mode) {
 
 // k_edge takes graphs of many tiles, all slot-uniform (the plan's em_ok), whose tiles see at most 10 cameras (row
 // tiles of the register accumulators) and 64 camera pairs (one lane per pair in the prologue)
-// Measured on the benchmark generator (profiles/r02_kernel_choice.txt): k_tile is fastest up to ~768 tiles, k_stream from 1024
-// to ~4096 (two waves per tile fill the chip sooner), k_edge from 8192 on (fewer instructions per edge once every SIMD has its
-// two waves); where both apply, k_stream keeps the graphs below kEdgePrefTiles.
+// Measured on the benchmark generator (profiles/r02_kernel_choice.txt, whole-step times): k_tile is fastest up to ~1500 tiles,
+// k_stream from 2048 to ~4096 (two waves per tile fill the chip sooner), k_edge from 8192 on (fewer instructions per edge once
+// every SIMD has its two waves); where both apply, k_stream keeps the graphs below BT_EDGE_PREF_TILES.
 bool edge_applies(const PlanDev &pd) {
     static const int off = std::getenv("BT_EDGE_OFF") ? std::atoi(std::getenv("BT_EDGE_OFF")) : 0;   // measurement only
     static const int pref = std::getenv("BT_EDGE_PREF_TILES") ? std::atoi(std::getenv("BT_EDGE_PREF_TILES")) : 6144;

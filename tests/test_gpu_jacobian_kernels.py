@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("frames,M,kernel,so", [(16, 16, "k_tile", False), (64, 1024, "k_stream", False), (64, 1024, "k_stream", True),
+@pytest.mark.parametrize("frames,M,kernel,so", [(16, 16, "k_tile", False), (64, 1024, "k_tile", False), (64, 2048, "k_stream", False), (64, 2048, "k_stream", True),
                                               (64, 6144, "k_edge", False), (64, 6144, "k_edge", True)])
 def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so):
     g = graphgen.make_graph(frames, M, 8, seed=5)

@@ -29,9 +29,15 @@ for M in [int(x) for x in (sys.argv[1:] or ["256", "1024", "4096", "16384"])]:
             for n, v in ms.items():
                 acc.setdefault(n, []).append(v * 1e3)
     med = {n: float(np.median(v)) for n, v in acc.items()}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(100):
+        st.step(poses, patches, mono, intr, t3, 3, w, Po, Xo, *scal, False)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 100 * 1e6
     alg = 40 * plan.E + 20 * plan.m + 72 * plan.n_all
     print(f"E={plan.E:9d} tracks={plan.m:8d} tiles={plan.tiles:6d} plan={plan_ms:8.1f}ms | " +
-          " ".join(f"{n}={v:9.2f}us" for n, v in med.items()) +
+          " ".join(f"{n}={v:9.2f}us" for n, v in med.items()) + f" step={wall:8.1f}us {plan.jacobian_kernel}" +
           f" | k_tile: {alg/1e6:8.2f} MB algorithmic -> {alg/med['tile']/1e3:8.1f} GB/s = {alg/med['tile']/1e3/8000*100:5.2f}% of 8 TB/s, {plan.E/med['tile']:.0f} edges/us", flush=True)
     if int(os.environ.get("BT_DEBUG_MODE", "0")) & 32:
         torch.cuda.synchronize()
