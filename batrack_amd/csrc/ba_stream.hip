@@ -1,4 +1,4 @@
-// ba_stream.hip — k_stream: tiles streamed through two-wave workgroups, for graphs of 1024 .. ~6000 tiles (gfx950, wave64).
+// ba_stream.hip — k_stream: tiles streamed through two-wave workgroups, for graphs of 2048 .. ~6000 tiles (gfx950, wave64).
 //
 // The tile kernel of ba_kernels.hip spreads one tile of 64 tracks over a workgroup of 8-16 waves: right for
 // graphs of a few hundred tiles, where a tile's latency is all there is.  On graphs of thousands of tiles the
