@@ -18,6 +18,7 @@ re-normalised but unmoved (ba.py:9-13), nothing raises.
 There is no CPU path: tensors must live on a ROCm device and the HIP library
 must be built, otherwise this raises.
 """
+import os
 import weakref
 from concurrent.futures import ThreadPoolExecutor
 
@@ -30,6 +31,7 @@ from .lietorch import SE3
 _CACHE = {}          # key -> (stepper, (weakref ii, jj, kk))
 _CACHE_MAX = 8
 _PENDING = {}        # key -> (future, result box, (ii, jj, kk)): plans being built by prefetch_plan
+_LAST_SHIFT = [None]  # frame shift of the last plan that was made as a shifted copy
 _WORKER = None       # one long-lived host thread (the planner keeps edge-sized scratch per thread)
 
 
@@ -64,9 +66,29 @@ def _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, device):
             return box["stepper"]
         if "error" in box and not isinstance(box["error"], Exception):
             raise box["error"]                    # KeyboardInterrupt and the like; ordinary errors are re-raised by the build below
-    stepper = Stepper(Plan(ii, jj, kk, n_buf, p_tot, fixedp), device)
+    stepper = Stepper(_build_plan(ii, jj, kk, n_buf, p_tot, fixedp, True), device)
     _store(key, stepper, ii, jj, kk)
     return stepper
+
+
+def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync):
+    """A new plan: first as a shifted copy of one of the most recent plans (the caller's window in steady state repeats its
+    edge list with all frame / patch indices moved up, batrack.py:189-212 — ~0.1 ms on the device), else from scratch
+    (host analysis, ~1 ms for the 138k-edge window)."""
+    tried = 0
+    if os.environ.get("BT_PLAN_SHIFT", "1") != "0":
+        E = ii.numel()
+        cands = [st.plan for st, _ in reversed(list(_CACHE.values()))      # most recent first
+                 if st.plan.E == E and st.plan.n_buf == int(n_buf) and st.plan.p_tot == int(p_tot) and st.plan.fixedp < int(fixedp)]
+        # (with a keyframe stride of 2 the match is two updates back: the frame shift that worked last time is tried first)
+        cands.sort(key=lambda pl: int(fixedp) - pl.fixedp != _LAST_SHIFT[0])
+        for src in cands[:3]:                          # (each comparison is ~40 us; a list that matches none is built the ordinary way)
+            pl = Plan.shifted(src, ii, jj, kk, n_buf, p_tot, fixedp, sync=sync and tried == 0)
+            tried += 1
+            if pl is not None:
+                _LAST_SHIFT[0] = int(fixedp) - src.fixedp
+                return pl
+    return Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=sync and tried == 0)      # (the stream was synchronised by the first comparison)
 
 
 def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True):
@@ -99,7 +121,7 @@ def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True
             # the current device and stream are per host thread: the workspace is allocated and zero-filled on the stream
             # the steps will run on, so its accumulators are clear before the first of them whatever stream that is
             with torch.cuda.device(dev), torch.cuda.stream(caller_stream):
-                box["stepper"] = Stepper(Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=False), dev)
+                box["stepper"] = Stepper(_build_plan(ii, jj, kk, n_buf, p_tot, fixedp, False), dev)
         except BaseException as e:                              # reported (or retried in the open) by _plan_for
             box["error"] = e
 

@@ -13,7 +13,7 @@
 
 #include "ba_kernels.hpp"
 
-#define BT_VERSION 201
+#define BT_VERSION 202
 
 namespace bt {
 
@@ -148,6 +148,7 @@ static hipStream_t copy_stream() {
 struct PackBuffers {
     uint64_t *d_words = nullptr, *h_words = nullptr;
     int *d_bad = nullptr, *h_bad = nullptr;
+    int *d_cmp = nullptr, *h_cmp = nullptr;                  // result of the shift comparison (bt_plan_create_shifted)
     size_t cap = 0;
     bool ensure(size_t n) {
         if (n <= cap && d_words) return true;
@@ -162,6 +163,8 @@ struct PackBuffers {
     }
 };
 
+static PackBuffers &pack_buffers() { static thread_local PackBuffers pb; return pb; }
+
 static bool api_prof() { static const bool p = std::getenv("BT_PLAN_PROF") != nullptr; return p; }
 struct ApiTick {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -173,30 +176,70 @@ struct ApiTick {
     }
 };
 
-int upload_plan(bt_plan *pl) {
+// PlanDev of a plan whose arrays sit at `d` in the layout recorded in pl->off (upload_plan, clone_plan_shifted)
+static void bind_pointers(bt_plan *pl, const void *d) {
+    const PlanOffsets &O = pl->off;
+    const char *b = static_cast<const char *>(d);
+    const bt_plan_info &I = pl->info;
+    PlanDev &P = pl->dev;
+    P.E = (int)I.E; P.n_buf = (int)I.n_buf; P.p_tot = (int)I.p_tot; P.fixedp = (int)I.fixedp;
+    P.n_all = (int)I.n_all; P.n = (int)I.n; P.D = (int)(6 * I.n); P.m = (int)I.m; P.P = (int)I.pairs;
+    P.T = (int)I.tiles; P.slots = (int)I.slots; P.erows = (int)I.erows; P.nnzb = (int)I.nnz_blocks;
+    P.nupd = (int)I.updates; P.max_rows16 = pl->max_rows16;
+#define BT_I32(off) reinterpret_cast<const int32_t *>(b + (off))
+    P.kx = BT_I32(O.kx);
+    P.act_bits = reinterpret_cast<const uint32_t *>(b + O.ab); P.act_rank = BT_I32(O.ar);
+    P.pair_i = BT_I32(O.pi); P.pair_j = BT_I32(O.pj);
+    P.tile_trk0 = BT_I32(O.t0); P.tile_ntrk = BT_I32(O.tn); P.tile_ncam = BT_I32(O.tc); P.tile_cam0 = BT_I32(O.c0);
+    P.tile_slot0 = BT_I32(O.s0); P.tile_nslot = BT_I32(O.sn); P.tile_erow0 = BT_I32(O.e0); P.tile_cams = BT_I32(O.cams);
+    P.slot_edge = BT_I32(O.se); P.slot_pair = BT_I32(O.sp);
+    P.slot_lab = reinterpret_cast<const uint16_t *>(b + O.sl);
+    P.col_ptr = BT_I32(O.cp); P.row_idx = BT_I32(O.ri); P.upd_ptr = BT_I32(O.up); P.upd = BT_I32(O.u); P.blk_col = BT_I32(O.bc); P.upd_next = BT_I32(O.un);
+    P.perm = BT_I32(O.pm); P.blk_src = BT_I32(O.bs); P.lvl_ptr = BT_I32(O.lp); P.lvl_cols = BT_I32(O.lc);
+    P.col_lvl = BT_I32(O.cl); P.dp_ptr = BT_I32(O.dpp); P.dp = BT_I32(O.dp);
+    P.nlev = pl->cnt_nlev; P.ndp = pl->cnt_ndp;
+    P.lvl_meta = BT_I32(O.lm); P.tile_flags = BT_I32(O.tf);
+    P.fz_pend_ptr = BT_I32(O.fpp); P.fz_pend = BT_I32(O.fp); P.fz_lazy_ptr = BT_I32(O.flp); P.fz_lazy = BT_I32(O.fl);
+    P.fz_yurg = BT_I32(O.fy); P.fz_meta = BT_I32(O.fm); P.fz_pmeta = BT_I32(O.fpm); P.bs_sync = BT_I32(O.bss); P.fz_rowinfo = BT_I32(O.fri); P.fz_pfirst = BT_I32(O.fpf); P.fz_psecond = BT_I32(O.fps); P.tile_ij = BT_I32(O.tij); P.tile_kx = BT_I32(O.tkx);
+    P.tile_cut8 = reinterpret_cast<const uint16_t *>(b + O.tc8); P.tile_cut16 = reinterpret_cast<const uint16_t *>(b + O.tc16);
+    P.fz_npend = pl->cnt_npend; P.fz_nlazy = pl->cnt_nlazy; P.fz_ok = pl->fz_ok; P.fzp_ok = pl->fzp_ok;
+    P.tile_pair0 = BT_I32(O.tp0); P.tile_npair = BT_I32(O.tnp); P.tile_pairs = BT_I32(O.tps);
+    P.slot_lp = reinterpret_cast<const uint8_t *>(b + O.slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams; P.e_all = pl->e_all;
+    P.slot_code = reinterpret_cast<const uint16_t *>(b + O.sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + O.tla); P.tile_rec = BT_I32(O.trec); P.it_edge = BT_I32(O.ite); P.tile_sinfo = reinterpret_cast<const uint32_t *>(b + O.tsi); P.em_ok = pl->em_ok; P.em_its = (int)pl->em_its; P.em_lgs = pl->em_lgs; P.em_self = pl->em_self;
+#undef BT_I32
+}
+
+// Plans of up to this many edges keep their packed edge list on the device (8 bytes per edge) so that the next edge
+// list can be recognised as a shifted copy (bt_plan_create_shifted)
+constexpr int64_t kKeepPackedMaxEdges = 4 << 20;
+
+int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
     ApiTick tick;
     std::vector<char> &buf = pl->stage;           // capacity survives with the recycled plan object
+    PlanOffsets &O = pl->off;
     buf.clear();
-    const size_t o_kx = put(buf, pl->kx), o_ab = put(buf, pl->act_bits), o_ar = put(buf, pl->act_rank);
-    const size_t o_pi = put(buf, pl->pair_i), o_pj = put(buf, pl->pair_j);
-    const size_t o_t0 = put(buf, pl->tile_trk0), o_tn = put(buf, pl->tile_ntrk), o_tc = put(buf, pl->tile_ncam);
-    const size_t o_c0 = put(buf, pl->tile_cam0), o_s0 = put(buf, pl->tile_slot0), o_sn = put(buf, pl->tile_nslot);
-    const size_t o_e0 = put(buf, pl->tile_erow0), o_cams = put(buf, pl->tile_cams);
-    const size_t o_se = put(buf, pl->slot_edge), o_sp = put(buf, pl->slot_pair), o_sl = put(buf, pl->slot_lab);
-    const size_t o_cp = put(buf, pl->col_ptr), o_ri = put(buf, pl->row_idx), o_up = put(buf, pl->upd_ptr), o_u = put(buf, pl->upd);
-    const size_t o_bc = put(buf, pl->blk_col), o_un = put(buf, pl->upd_next);
-    const size_t o_lm = put(buf, pl->lvl_meta), o_tf = put(buf, pl->tile_flags);
-    const size_t o_tp0 = put(buf, pl->tile_pair0), o_tnp = put(buf, pl->tile_npair), o_tps = put(buf, pl->tile_pairs), o_slp = put(buf, pl->slot_lp);
-    const size_t o_pm = put(buf, pl->perm), o_bs = put(buf, pl->blk_src), o_lp = put(buf, pl->lvl_ptr), o_lc = put(buf, pl->lvl_cols);
-    const size_t o_cl = put(buf, pl->col_lvl), o_dpp = put(buf, pl->dp_ptr), o_dp = put(buf, pl->dp);
-    const size_t o_fpp = put(buf, pl->fz_pend_ptr), o_fp = put(buf, pl->fz_pend), o_flp = put(buf, pl->fz_lazy_ptr), o_fl = put(buf, pl->fz_lazy);
-    const size_t o_fy = put(buf, pl->fz_yurg), o_fm = put(buf, pl->fz_meta), o_fpm = put(buf, pl->fz_pmeta), o_bss = put(buf, pl->bs_sync), o_fri = put(buf, pl->fz_rowinfo), o_fpf = put(buf, pl->fz_pfirst), o_fps = put(buf, pl->fz_psecond), o_tij = put(buf, pl->tile_ij), o_tkx = put(buf, pl->tile_kx);
-    const size_t o_tc8 = put(buf, pl->tile_cut8), o_tc16 = put(buf, pl->tile_cut16);
-    const size_t o_sc = put(buf, pl->slot_code), o_tla = put(buf, pl->tile_la), o_trec = put(buf, pl->tile_rec), o_ite = put(buf, pl->it_edge), o_tsi = put(buf, pl->tile_sinfo);
+    O.kx = put(buf, pl->kx), O.ab = put(buf, pl->act_bits), O.ar = put(buf, pl->act_rank);
+    O.pi = put(buf, pl->pair_i), O.pj = put(buf, pl->pair_j);
+    O.t0 = put(buf, pl->tile_trk0), O.tn = put(buf, pl->tile_ntrk), O.tc = put(buf, pl->tile_ncam);
+    O.c0 = put(buf, pl->tile_cam0), O.s0 = put(buf, pl->tile_slot0), O.sn = put(buf, pl->tile_nslot);
+    O.e0 = put(buf, pl->tile_erow0), O.cams = put(buf, pl->tile_cams);
+    O.se = put(buf, pl->slot_edge), O.sp = put(buf, pl->slot_pair), O.sl = put(buf, pl->slot_lab);
+    O.cp = put(buf, pl->col_ptr), O.ri = put(buf, pl->row_idx), O.up = put(buf, pl->upd_ptr), O.u = put(buf, pl->upd);
+    O.bc = put(buf, pl->blk_col), O.un = put(buf, pl->upd_next);
+    O.lm = put(buf, pl->lvl_meta), O.tf = put(buf, pl->tile_flags);
+    O.tp0 = put(buf, pl->tile_pair0), O.tnp = put(buf, pl->tile_npair), O.tps = put(buf, pl->tile_pairs), O.slp = put(buf, pl->slot_lp);
+    O.pm = put(buf, pl->perm), O.bs = put(buf, pl->blk_src), O.lp = put(buf, pl->lvl_ptr), O.lc = put(buf, pl->lvl_cols);
+    O.cl = put(buf, pl->col_lvl), O.dpp = put(buf, pl->dp_ptr), O.dp = put(buf, pl->dp);
+    O.fpp = put(buf, pl->fz_pend_ptr), O.fp = put(buf, pl->fz_pend), O.flp = put(buf, pl->fz_lazy_ptr), O.fl = put(buf, pl->fz_lazy);
+    O.fy = put(buf, pl->fz_yurg), O.fm = put(buf, pl->fz_meta), O.fpm = put(buf, pl->fz_pmeta), O.bss = put(buf, pl->bs_sync), O.fri = put(buf, pl->fz_rowinfo), O.fpf = put(buf, pl->fz_pfirst), O.fps = put(buf, pl->fz_psecond), O.tij = put(buf, pl->tile_ij), O.tkx = put(buf, pl->tile_kx);
+    O.tc8 = put(buf, pl->tile_cut8), O.tc16 = put(buf, pl->tile_cut16);
+    O.sc = put(buf, pl->slot_code), O.tla = put(buf, pl->tile_la), O.trec = put(buf, pl->tile_rec), O.ite = put(buf, pl->it_edge), O.tsi = put(buf, pl->tile_sinfo);
     tick("pack arrays");
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
-    void *d = dev_pool().acquire(buf.size() + 256, &cap, &reuse_after);
+    const bool keep_pk = d_packed && pl->e_all > 0 && pl->e_all <= kKeepPackedMaxEdges && pl->info.E == pl->e_all;
+    const size_t pk_off = (buf.size() + 255) / 256 * 256, total = keep_pk ? pk_off + (size_t)pl->e_all * sizeof(uint64_t) : buf.size();
+    void *d = dev_pool().acquire(total + 256, &cap, &reuse_after);
     if (!d) return BT_ENOMEM;
     tick("device buffer");
     hipStream_t cs = copy_stream();
@@ -206,38 +249,18 @@ int upload_plan(bt_plan *pl) {
     if (!waited) (void)hipEventSynchronize(reuse_after);
     dev_pool().give_event(reuse_after);
     if (hipMemcpyAsync(d, buf.data(), buf.size(), hipMemcpyHostToDevice, cs) != hipSuccess ||
+        (keep_pk && hipMemcpyAsync(static_cast<char *>(d) + pk_off, d_packed, (size_t)pl->e_all * sizeof(uint64_t), hipMemcpyDeviceToDevice, cs) != hipSuccess) ||
         hipStreamSynchronize(cs) != hipSuccess) { dev_pool().release(d, cap, false, nullptr); return BT_EHIP; }
     tick("H2D copy");
     pl->dev_base = d;
     pl->dev_cap = cap;
-    const char *b = static_cast<const char *>(d);
-    const bt_plan_info &I = pl->info;
+    pl->dev_bytes = total;
+    pl->pk_off = keep_pk ? pk_off : 0;
+    pl->n_act_words = (int)pl->act_bits.size(); pl->n_tile_ij = (int)pl->tile_ij.size();
+    pl->cnt_nlev = (int)pl->lvl_ptr.size() - 1; pl->cnt_ndp = (int)pl->dp.size();
+    pl->cnt_npend = (int)(pl->fz_pend.size() / 2); pl->cnt_nlazy = (int)(pl->fz_lazy.size() / 3);
+    bind_pointers(pl, d);
     PlanDev &P = pl->dev;
-    P.E = (int)I.E; P.n_buf = (int)I.n_buf; P.p_tot = (int)I.p_tot; P.fixedp = (int)I.fixedp;
-    P.n_all = (int)I.n_all; P.n = (int)I.n; P.D = (int)(6 * I.n); P.m = (int)I.m; P.P = (int)I.pairs;
-    P.T = (int)I.tiles; P.slots = (int)I.slots; P.erows = (int)I.erows; P.nnzb = (int)I.nnz_blocks;
-    P.nupd = (int)I.updates; P.max_rows16 = pl->max_rows16;
-#define BT_I32(off) reinterpret_cast<const int32_t *>(b + (off))
-    P.kx = BT_I32(o_kx);
-    P.act_bits = reinterpret_cast<const uint32_t *>(b + o_ab); P.act_rank = BT_I32(o_ar);
-    P.pair_i = BT_I32(o_pi); P.pair_j = BT_I32(o_pj);
-    P.tile_trk0 = BT_I32(o_t0); P.tile_ntrk = BT_I32(o_tn); P.tile_ncam = BT_I32(o_tc); P.tile_cam0 = BT_I32(o_c0);
-    P.tile_slot0 = BT_I32(o_s0); P.tile_nslot = BT_I32(o_sn); P.tile_erow0 = BT_I32(o_e0); P.tile_cams = BT_I32(o_cams);
-    P.slot_edge = BT_I32(o_se); P.slot_pair = BT_I32(o_sp);
-    P.slot_lab = reinterpret_cast<const uint16_t *>(b + o_sl);
-    P.col_ptr = BT_I32(o_cp); P.row_idx = BT_I32(o_ri); P.upd_ptr = BT_I32(o_up); P.upd = BT_I32(o_u); P.blk_col = BT_I32(o_bc); P.upd_next = BT_I32(o_un);
-    P.perm = BT_I32(o_pm); P.blk_src = BT_I32(o_bs); P.lvl_ptr = BT_I32(o_lp); P.lvl_cols = BT_I32(o_lc);
-    P.col_lvl = BT_I32(o_cl); P.dp_ptr = BT_I32(o_dpp); P.dp = BT_I32(o_dp);
-    P.nlev = (int)pl->lvl_ptr.size() - 1; P.ndp = (int)pl->dp.size();
-    P.lvl_meta = BT_I32(o_lm); P.tile_flags = BT_I32(o_tf);
-    P.fz_pend_ptr = BT_I32(o_fpp); P.fz_pend = BT_I32(o_fp); P.fz_lazy_ptr = BT_I32(o_flp); P.fz_lazy = BT_I32(o_fl);
-    P.fz_yurg = BT_I32(o_fy); P.fz_meta = BT_I32(o_fm); P.fz_pmeta = BT_I32(o_fpm); P.bs_sync = BT_I32(o_bss); P.fz_rowinfo = BT_I32(o_fri); P.fz_pfirst = BT_I32(o_fpf); P.fz_psecond = BT_I32(o_fps); P.tile_ij = BT_I32(o_tij); P.tile_kx = BT_I32(o_tkx);
-    P.tile_cut8 = reinterpret_cast<const uint16_t *>(b + o_tc8); P.tile_cut16 = reinterpret_cast<const uint16_t *>(b + o_tc16);
-    P.fz_npend = (int)(pl->fz_pend.size() / 2); P.fz_nlazy = (int)(pl->fz_lazy.size() / 3); P.fz_ok = pl->fz_ok; P.fzp_ok = pl->fzp_ok;
-    P.tile_pair0 = BT_I32(o_tp0); P.tile_npair = BT_I32(o_tnp); P.tile_pairs = BT_I32(o_tps);
-    P.slot_lp = reinterpret_cast<const uint8_t *>(b + o_slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams; P.e_all = pl->e_all;
-    P.slot_code = reinterpret_cast<const uint16_t *>(b + o_sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + o_tla); P.tile_rec = BT_I32(o_trec); P.it_edge = BT_I32(o_ite); P.tile_sinfo = reinterpret_cast<const uint32_t *>(b + o_tsi); P.em_ok = pl->em_ok; P.em_its = (int)pl->em_its; P.em_lgs = pl->em_lgs; P.em_self = pl->em_self;
-#undef BT_I32
     const int rc = configure_kernels(P);
     tick("configure kernels");
     return rc;
@@ -301,7 +324,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
     if (on_device && E > 0) {
         // packed and range-checked on the device (8 of the 24 bytes per edge cross PCIe), into a pinned host buffer
         if (n_buf >= 65536 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;
-        static thread_local PackBuffers pb;
+        PackBuffers &pb = pack_buffers();
         if (!pb.ensure((size_t)E)) return BT_ENOMEM;
         hipStream_t cs = copy_stream();
         if (hipMemsetAsync(pb.d_bad, 0, sizeof(int), cs) != hipSuccess ||
@@ -320,10 +343,78 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
     try {
         rc = build_plan_host(packed ? nullptr : ii, packed ? nullptr : jj, packed ? nullptr : kk, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed);
         tick("host analysis");
-        if (rc == BT_OK && upload) rc = upload_plan(pl);
+        if (rc == BT_OK && upload) rc = upload_plan(pl, packed ? pack_buffers().d_words : nullptr);
     } catch (const std::bad_alloc &) {
         rc = BT_ENOMEM;
     }
+    if (rc != BT_OK) { bt_plan_destroy(pl); return rc; }
+    *out = pl;
+    return BT_OK;
+}
+
+int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                           int64_t n_buf, int64_t p_tot, int64_t fixedp, bt_plan **out) {
+    if (!out) return BT_EINVAL;
+    *out = nullptr;
+    if (!src || !ii || !jj || !kk || E <= 0) return BT_EINVAL;
+    if (!src->dev_base || !src->pk_off || src->e_all != E || src->info.E != E || src->info.n_buf != n_buf || src->info.p_tot != p_tot)
+        return BT_NO_MATCH;
+    if (n_buf >= 65536 || p_tot > (int64_t)0x7fffffff) return BT_NO_MATCH;
+    PackBuffers &pb = pack_buffers();
+    if (!pb.ensure((size_t)E)) return BT_ENOMEM;
+    if (!pb.d_cmp && (hipMalloc(reinterpret_cast<void **>(&pb.d_cmp), 4 * sizeof(int)) != hipSuccess ||
+                      hipHostMalloc(reinterpret_cast<void **>(&pb.h_cmp), 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)) return BT_ENOMEM;
+    hipStream_t cs = copy_stream();
+    const uint64_t *old_words = reinterpret_cast<const uint64_t *>(static_cast<const char *>(src->dev_base) + src->pk_off);
+    if (hipMemsetAsync(pb.d_bad, 0, sizeof(int), cs) != hipSuccess || hipMemsetAsync(pb.d_cmp, 0, 4 * sizeof(int), cs) != hipSuccess ||
+        launch_pack_edges(ii, jj, kk, E, n_buf, p_tot, pb.d_words, pb.d_bad, cs) != BT_OK ||
+        launch_shift_match(pb.d_words, old_words, E, pb.d_cmp, cs) != BT_OK ||
+        hipMemcpyAsync(pb.h_cmp, pb.d_cmp, 4 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+        hipMemcpyAsync(pb.h_bad, pb.d_bad, sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+        hipStreamSynchronize(cs) != hipSuccess)
+        return BT_EHIP;
+    if (*pb.h_bad) return BT_EINVAL;
+    if (pb.h_cmp[0]) return BT_NO_MATCH;
+    const uint64_t d0 = (uint64_t)(uint32_t)pb.h_cmp[2] | ((uint64_t)(uint32_t)pb.h_cmp[3] << 32);
+    const int64_t dj = (int64_t)(d0 & 0xffff), di = (int64_t)((d0 >> 16) & 0xffff), dk = (int64_t)(d0 >> 32);
+    // (shifts forward in time only; both frame fields by the same amount; the fixed prefix moves along)
+    if (di != dj || dk >= ((int64_t)1 << 31) || fixedp != src->info.fixedp + di || src->info.n_all + di > n_buf) return BT_NO_MATCH;
+    if (di == 0 && dk == 0) return BT_NO_MATCH;                      // the same list: the caller's cache has that plan already
+    bt_plan *pl = plan_pool().take();
+    if (!pl) return BT_ENOMEM;
+    pl->info = src->info; pl->info.fixedp = fixedp; pl->info.n_all = src->info.n_all + di;
+    pl->ws = src->ws; pl->off = src->off; pl->dev_bytes = src->dev_bytes; pl->pk_off = src->pk_off;
+    pl->n_act_words = src->n_act_words; pl->n_tile_ij = src->n_tile_ij;
+    pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
+    pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
+    pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
+    pl->em_self = src->em_self; pl->e_all = src->e_all;
+    size_t cap = 0;
+    hipEvent_t reuse_after = nullptr;
+    void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);
+    if (!d) { plan_pool().give(pl); return BT_ENOMEM; }
+    const bool waited = !reuse_after || hipStreamWaitEvent(cs, reuse_after, 0) == hipSuccess;
+    if (!waited) (void)hipEventSynchronize(reuse_after);
+    dev_pool().give_event(reuse_after);
+    char *nb = static_cast<char *>(d);
+    const char *ob = static_cast<const char *>(src->dev_base);
+    const PlanOffsets &O = pl->off;
+    auto I32 = [&](size_t off) { return reinterpret_cast<int32_t *>(nb + off); };
+    int rc = BT_OK;
+    // the tables as they are, the new packed edge list behind them, then the ones that hold absolute frame / patch numbers
+    if (hipMemcpyAsync(nb, ob, src->pk_off, hipMemcpyDeviceToDevice, cs) != hipSuccess ||
+        hipMemcpyAsync(nb + pl->pk_off, pb.d_words, (size_t)E * sizeof(uint64_t), hipMemcpyDeviceToDevice, cs) != hipSuccess)
+        rc = BT_EHIP;
+    if (rc == BT_OK)
+        rc = launch_plan_shift(I32(O.kx), (int)pl->info.m, I32(O.tkx), (int)pl->info.tiles * kLanes, I32(O.tij), pl->n_tile_ij, I32(O.pi), I32(O.pj),
+                               (int)pl->info.pairs, reinterpret_cast<const uint32_t *>(ob + O.ab), reinterpret_cast<uint32_t *>(nb + O.ab), I32(O.ar),
+                               pl->n_act_words, (int)di, (int)dk, cs);
+    if (rc == BT_OK && hipStreamSynchronize(cs) != hipSuccess) rc = BT_EHIP;
+    if (rc != BT_OK) { dev_pool().release(d, cap, false, nullptr); plan_pool().give(pl); return rc; }
+    pl->dev_base = d;
+    pl->dev_cap = cap;
+    bind_pointers(pl, d);
+    rc = configure_kernels(pl->dev);
     if (rc != BT_OK) { bt_plan_destroy(pl); return rc; }
     *out = pl;
     return BT_OK;

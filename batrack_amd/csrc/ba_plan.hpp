@@ -64,8 +64,15 @@ struct WsLayout {
 
 }  // namespace bt
 
+namespace bt { struct PlanOffsets { size_t ab, ar, bc, bs, bss, c0, cams, cl, cp, dp, dpp, e0, fl, flp, fm, fp, fpf, fpm, fpp, fps, fri, fy, ite, kx, lc, lm, lp, pi, pj, pm, ri, s0, sc, se, sl, slp, sn, sp, t0, tc, tc16, tc8, tf, tij, tkx, tla, tn, tnp, tp0, tps, trec, tsi, u, un, up; }; }
+
 struct bt_plan {
     bt_plan_info info{};
+    bt::PlanOffsets off{};        // byte offsets of the arrays inside the device buffer (ba_api.cpp)
+    size_t dev_bytes = 0;          // bytes of the device buffer in use
+    size_t pk_off = 0;             // packed edge list (kk << 32 | ii << 16 | jj, 8 bytes per edge) inside the device buffer, 0 = not kept
+    int n_act_words = 0, n_tile_ij = 0;   // sizes of act_bits / tile_ij (for shifted clones)
+    int cnt_nlev = 0, cnt_ndp = 0, cnt_npend = 0, cnt_nlazy = 0;   // sizes bind_pointers needs without the host arrays (shifted clones have none)
     std::vector<int32_t> kx, trk_loc, act_rank;                    // trk_loc: host only
     std::vector<int32_t> trk_win;                                  // track of patch trk_win_lo + i (-1: none): the window of patches the edges name
     int64_t trk_win_lo = 0;
@@ -135,6 +142,9 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
                     int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
                     int64_t own_lo, int64_t own_hi, bt_plan *plan, const uint64_t *packed = nullptr);
 // the same packing on the device (plan_pack.hip): `out` E words and `bad` one int (set to 1 on an index out of range), device memory
+int launch_shift_match(const uint64_t *nw, const uint64_t *ow, int64_t E, int *out, void *stream);
+int launch_plan_shift(int32_t *kx, int m, int32_t *tile_kx, int nkx, int32_t *tile_ij, int nij, int32_t *pair_i, int32_t *pair_j, int P,
+                      const uint32_t *old_bits, uint32_t *new_bits, int32_t *new_rank, int nwords, int df, int dk, void *stream);
 int launch_pack_edges(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
                       uint64_t *out, int *bad, void *stream);
 int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot, uint64_t *out);

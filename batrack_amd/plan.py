@@ -56,6 +56,33 @@ class Plan:
         self.info = {n: int(getattr(info, n)) for n, _ in _lib.PlanInfo._fields_}
         self.uploaded = bool(upload)
 
+    @classmethod
+    def shifted(cls, src, ii, jj, kk, n_buf, p_tot, fixedp, sync=True):
+        """The plan of an edge list that is `src`'s with every frame index moved by one constant and every patch index by
+        another (the caller's sliding window in steady state): a device-side copy of `src`'s tables with those numbers
+        shifted, no host analysis (bt_plan_create_shifted).  Returns None when the list is no such copy."""
+        import torch
+        if not (src.uploaded and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64 for t in (ii, jj, kk))):
+            return None
+        arrs = [a.contiguous() for a in (ii, jj, kk)]
+        if arrs[0].numel() != src.E:
+            return None
+        if sync:
+            torch.cuda.current_stream(arrs[0].device).synchronize()
+        h = ctypes.c_void_p()
+        rc = src._lib.bt_plan_create_shifted(src.handle, arrs[0].data_ptr(), arrs[1].data_ptr(), arrs[2].data_ptr(), arrs[0].numel(),
+                                             int(n_buf), int(p_tot), int(fixedp), ctypes.byref(h))
+        if rc > 0:
+            return None
+        _lib.check(rc, "bt_plan_create_shifted")
+        self = cls.__new__(cls)
+        self._lib, self._h, self._keep = src._lib, h, None
+        info = _lib.PlanInfo()
+        _lib.check(self._lib.bt_plan_get_info(self._h, ctypes.byref(info)), "bt_plan_get_info")
+        self.info = {n: int(getattr(info, n)) for n, _ in _lib.PlanInfo._fields_}
+        self.uploaded = True
+        return self
+
     def __getattr__(self, name):
         info = self.__dict__.get("info")
         if info is not None and name in info:
