@@ -78,7 +78,11 @@ def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync):
     tried = 0
     if os.environ.get("BT_PLAN_SHIFT", "1") != "0":
         E = ii.numel()
-        cands = [st.plan for st, _ in reversed(list(_CACHE.values()))      # most recent first
+        try:
+            cached = list(_CACHE.values())             # (prefetch_plan calls this from its worker thread while the cache may change)
+        except RuntimeError:
+            cached = []
+        cands = [st.plan for st, _ in reversed(cached)  # most recent first
                  if st.plan.E == E and st.plan.n_buf == int(n_buf) and st.plan.p_tot == int(p_tot) and st.plan.fixedp < int(fixedp)]
         # (with a keyframe stride of 2 the match is two updates back: the frame shift that worked last time is tried first)
         cands.sort(key=lambda pl: int(fixedp) - pl.fixedp != _LAST_SHIFT[0])
