@@ -46,8 +46,6 @@ namespace bt {
 // source-camera row is summed in registers and merged by an owner thread after the
 // barrier.  Only a duplicated (track, target camera) observation that straddles two
 // waves' chunks falls back to ds_add_f32.
-constexpr int kTileWavesMax = 16;
-
 // One tile per workgroup (graphs of up to a few thousand tiles, e.g. the 64-KF / 131k-edge benchmark and the
 // sliding-window graphs; larger ones take k_edge / k_stream): no cross-tile state, Schur tiles go straight from
 // the MFMA registers to the atomics.

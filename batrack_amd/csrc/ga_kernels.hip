@@ -27,7 +27,7 @@ __device__ __forceinline__ float block_sum(float v, float *red) {          // bl
     __syncthreads();
     float t = 0.0f;
     if (threadIdx.x < 64) {
-        t = threadIdx.x < nw ? red[threadIdx.x] : 0.0f;
+        t = (int)threadIdx.x < nw ? red[threadIdx.x] : 0.0f;
         for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
     }
     __syncthreads();
