@@ -37,15 +37,15 @@ namespace bt {
 // Wave w takes a contiguous chunk of the tile's edge slots (one slot each on the
 // regular 8-observation graphs), so a wave sees one camera pair per slot and the
 // per-pair sums are full-wave reductions.
-// LDS: Eh[R16][66]   local E: row = 6*local_cam + comp, column = lane = track; row R = w'
+// LDS: Eh[R16][66]   local E: row = 6*local_cam + comp, column = lane = track
 //      stg[8][8][64] per-wave partials of (E at the source camera, C, w) per track
 //      las[8][64]    local source camera of those partials
-//      Qs[64], gidx[R16] (global row of a local row)
+//      Qs[128] (Q, then beta = Q w' per track), gidx[R16] (global row of a local row), geo[pairs][20]
 // E accumulation never uses LDS atomics on the common path: a track's target-camera
 // rows are written by the wave that owns the slot (plain read-add-write), its
 // source-camera row is summed in registers and merged by an owner thread after the
 // barrier.  Only a duplicated (track, target camera) observation that straddles two
-// waves' chunks falls back to ds_add_f32.
+// waves' slot ranges falls back to ds_add_f32, and the plan cuts the ranges where no such run crosses if it can.
 // One tile per workgroup (graphs of up to a few thousand tiles, e.g. the 64-KF / 131k-edge benchmark and the
 // sliding-window graphs; larger ones take k_edge / k_stream): no cross-tile state, Schur tiles go straight from
 // the MFMA registers to the atomics.
