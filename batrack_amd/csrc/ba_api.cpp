@@ -483,8 +483,18 @@ int bt_ba_solve_update(const bt_plan *pl, const bt_ba_args *a, void *ws, void *s
 }
 
 int bt_ba_step(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
-    const int rc = bt_ba_reduce(pl, a, ws, stream);
-    return rc != BT_OK ? rc : bt_ba_solve_update(pl, a, ws, stream);
+    const int rc = check(pl, a, ws);
+    if (rc != BT_OK) return rc;
+    const bool so = is_so(pl, a);
+    if (!so && (!a->poses_out || a->poses_out == a->poses)) return BT_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    pl->last_stream = stream; pl->launched = true;
+    const StepArgs s = make_args(pl, a, ws);
+    const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
+    bool fused = false;              // (structure-only steps on the k_tile path are one launch)
+    int r = launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), so, st, nullptr, nullptr, so ? (copy_poses ? 1 : 0) : -1, &fused);
+    if (r == BT_OK && !fused) r = launch_solve_update(pl->dev, s, so, copy_poses, st);
+    return r;
 }
 
 int bt_ba_step_timed(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream, float *ms) {

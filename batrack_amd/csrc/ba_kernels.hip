@@ -51,8 +51,21 @@ namespace bt {
 // the MFMA registers to the atomics.
 // WIDE: 16 waves per tile instead of 8, for graphs of few tiles with deep slot loops (a sliding window of 50 frames:
 // 40 tiles of 54 slots): the tile's latency, which is all there is on a quarter-empty GPU, shrinks with the chunk.
-template <bool SO, bool PROF, bool WIDE = false>
-__global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDev pd, StepArgs a) {
+// The part of a step's last kernel that is not per tile: patch `gid` < p_tot of the buffer is copied and clamped (ba.py:333;
+// TRACKS_ELSEWHERE: patches that carry a track are written by the tile blocks and skipped here, else — the unfused
+// structure-only update — their dZ = Q w' is applied here, ba.py:316-317), then one thread per buffer pose: Exp(dX) * G in
+// double (groups.py:153-156) or, structure-only, a plain copy.
+template <bool SO, bool TRACKS_ELSEWHERE>
+__device__ __forceinline__ void update_rest(const PlanDev &pd, const StepArgs &a, int gid, int do_poses);
+
+// FUSE (structure-only steps): the workgroups behind the pd.T tile workgroups do update_rest, and every tile writes its
+// tracks' new disparities itself: the whole structure-only step is ONE launch instead of k_tile<SO> + k_update<SO>.
+template <bool SO, bool PROF, bool WIDE = false, bool FUSE = false>
+__global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDev pd, StepArgs a, int do_poses) {
+    if (FUSE && (int)blockIdx.x >= pd.T) {
+        update_rest<true, true>(pd, a, ((int)blockIdx.x - pd.T) * (int)blockDim.x + (int)threadIdx.x, do_poses);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthr = blockDim.x, kTileWaves = nthr >> 6;          // 8 or 16 waves per tile (launch parameter)
@@ -77,7 +90,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): XCD x gets workgroups x, x + 8, ...  Give it a
     // CONTIGUOUS range of tiles instead — the tiles of one source frame are neighbours and share cameras, pair geometry and
     // the rows of S they add to (1024 tiles: 38.9 -> 32.7 us; nothing at 256 tiles, where every CU holds one workgroup).
-    const int tq_ = gridDim.x >> 3, tr_ = gridDim.x & 7, xcd_ = blockIdx.x & 7;
+    const int tq_ = pd.T >> 3, tr_ = pd.T & 7, xcd_ = blockIdx.x & 7;
     const int tile_begin = xcd_ * tq_ + min(xcd_, tr_) + (blockIdx.x >> 3), tile_end = tile_begin + 1;
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -306,7 +319,14 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
                 Ca = Ca + (a.lmbda_trk ? a.lmbda_trk[trk] : a.lmbda);
                 wp = wv - pm * a.alpha * (pdisp - mono);
                 Q = 1.0f / Ca;
-                a.qw[trk] = make_float2(Q, wp);
+                if (FUSE) {                                                // ba.py:316-317, :333
+                    float dd = pdisp + Q * wp;
+                    dd = dd < 1e-3f ? 1e-3f : dd;
+                    dd = dd > 10.0f ? 10.0f : dd;
+                    a.patches_out[3*patch] = px; a.patches_out[3*patch + 1] = py; a.patches_out[3*patch + 2] = dd;
+                } else {
+                    a.qw[trk] = make_float2(Q, wp);
+                }
             }
             if (!SO) { Qs[lane] = Q; Qs[64 + lane] = Q * wp; }
         }
@@ -2054,12 +2074,16 @@ __global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int 
         }
         return;
     }
-    const int gid = (blockIdx.x - (SO ? 0 : tile_blocks)) * blockDim.x + threadIdx.x;
+    update_rest<SO, !SO>(pd, a, (int)(blockIdx.x - (SO ? 0 : tile_blocks)) * (int)blockDim.x + (int)threadIdx.x, do_poses);
+}
+
+template <bool SO, bool TRACKS_ELSEWHERE>
+__device__ __forceinline__ void update_rest(const PlanDev &pd, const StepArgs &a, int gid, int do_poses) {
     if (gid < pd.p_tot) {
         // track of this patch, or -1: bitmap + rank (most of the buffer's patches are not in the window)
         const unsigned aw = pd.act_bits[gid >> 5], ab = (unsigned)gid & 31u;
         const bool has = (aw >> ab) & 1u;
-        if (!SO && has) return;                                         // written by its tile's block
+        if (TRACKS_ELSEWHERE && has) return;                            // written by its tile's block
         const float x = a.patches[3*gid], y = a.patches[3*gid + 1], d = a.patches[3*gid + 2];
         float dz = 0.0f;
         if (SO && has) {
@@ -2207,7 +2231,9 @@ int configure_kernels(const PlanDev &pd) {
         else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                \
     } while (0)
 
-int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev, unsigned *ran) {
+int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev, unsigned *ran,
+                  int fuse_so_poses, bool *fused) {
+    if (fused) *fused = false;
     (void)zero_doubles;   // the accumulators are cleared by their consumers (k_pair_finalize, k_update)
     if (pd.T > 0 && edge_applies(pd)) {
         if (ran) *ran |= 1u << 1;
@@ -2220,12 +2246,20 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
     } else if (pd.T > 0) {
         const bool wide = tile_wide(pd);
         const dim3 blk(tile_threads(pd)), grid(pd.T);
-        if (so && wide)        BT_LAUNCH(1, (k_tile<true, false, true>), grid, blk, tile_lds_bytes(pd, true), pd, a);
-        else if (so)           BT_LAUNCH(1, (k_tile<true, false>), grid, blk, tile_lds_bytes(pd, true), pd, a);
-        else if ((a.dbg & 32) && wide) BT_LAUNCH(1, (k_tile<false, true, true>), grid, blk, tile_lds_bytes(pd, false), pd, a);
-        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), grid, dim3(512), tile_lds_bytes(pd, false), pd, a);
-        else if (wide)         BT_LAUNCH(1, (k_tile<false, false, true>), grid, blk, tile_lds_bytes(pd, false), pd, a);
-        else                   BT_LAUNCH(1, (k_tile<false, false>), grid, blk, tile_lds_bytes(pd, false), pd, a);
+        if (so && fuse_so_poses >= 0 && fused) {
+            // the whole structure-only step in this launch: tile workgroups, then the rest of the patch buffer and the poses
+            const int total = pd.p_tot + (fuse_so_poses ? pd.n_buf : 0), nbr = (total + (int)blk.x - 1) / (int)blk.x;
+            const dim3 gridf(pd.T + nbr);
+            if (wide) BT_LAUNCH(1, (k_tile<true, false, true, true>), gridf, blk, tile_lds_bytes(pd, true), pd, a, fuse_so_poses);
+            else      BT_LAUNCH(1, (k_tile<true, false, false, true>), gridf, blk, tile_lds_bytes(pd, true), pd, a, fuse_so_poses);
+            *fused = true;
+        }
+        else if (so && wide)   BT_LAUNCH(1, (k_tile<true, false, true>), grid, blk, tile_lds_bytes(pd, true), pd, a, 0);
+        else if (so)           BT_LAUNCH(1, (k_tile<true, false>), grid, blk, tile_lds_bytes(pd, true), pd, a, 0);
+        else if ((a.dbg & 32) && wide) BT_LAUNCH(1, (k_tile<false, true, true>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
+        else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), grid, dim3(512), tile_lds_bytes(pd, false), pd, a, 0);
+        else if (wide)         BT_LAUNCH(1, (k_tile<false, false, true>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
+        else                   BT_LAUNCH(1, (k_tile<false, false>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
     }
     if (!so && pd.P > 0)
         BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);

@@ -32,7 +32,10 @@ int launch_stream(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st
 bool edge_applies(const PlanDev &pd);
 int launch_edge(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 // ev != nullptr: a (start, stop) event pair per kernel; *ran gets bit k set for every kernel k that was launched
-int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
+// fuse_so_poses >= 0 (and `fused` given): a structure-only step on the k_tile path also does the step's update in the same
+// launch (fuse_so_poses = 1: copy the poses too) and sets *fused; the caller then skips launch_solve_update
+int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, bool so, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr,
+                  int fuse_so_poses = -1, bool *fused = nullptr);
 // dense [S | y] <-> its non-zero blocks in factor order (bt_ba_pack / bt_ba_unpack)
 int launch_pack(const PlanDev &pd, const StepArgs &a, bool unpack, hipStream_t st);
 int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
