@@ -286,6 +286,7 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     s.dx = reinterpret_cast<float *>(w + L.dx); s.dx0 = reinterpret_cast<float *>(w + L.dx0); s.status = reinterpret_cast<int *>(w + L.status);
     static const int dbg = std::getenv("BT_DEBUG_MODE") ? std::atoi(std::getenv("BT_DEBUG_MODE")) : 0;
     s.dbg = dbg;
+    s.prec = edge_precision(pl->dev);
     return s;
 }
 

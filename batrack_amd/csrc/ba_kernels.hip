@@ -60,24 +60,28 @@ __device__ __forceinline__ void update_rest(const PlanDev &pd, const StepArgs &a
 
 // FUSE (structure-only steps): the workgroups behind the pd.T tile workgroups do update_rest, and every tile writes its
 // tracks' new disparities itself: the whole structure-only step is ONE launch instead of k_tile<SO> + k_update<SO>.
-template <bool SO, bool PROF, bool WIDE = false, bool FUSE = false>
-__global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDev pd, StepArgs a, int do_poses) {
+// R: float or double — the precision of the per-edge maths, of E in LDS and of the (Q, w') it leaves for k_update (float64 is
+// the default of this kernel: StepArgs::prec).  The float64 variant is allowed 256 registers (two 8-wave tiles per CU).
+template <bool SO, bool PROF, bool WIDE = false, bool FUSE = false, typename R = float>
+__global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? 2 : 4)) void k_tile(PlanDev pd, StepArgs a, int do_poses) {
     if (FUSE && (int)blockIdx.x >= pd.T) {
         update_rest<true, true>(pd, a, ((int)blockIdx.x - pd.T) * (int)blockDim.x + (int)threadIdx.x, do_poses);
         return;
     }
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R *lds = reinterpret_cast<R *>(lds_raw);
+    typedef typename Vec2<R>::type R2;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthr = blockDim.x, kTileWaves = nthr >> 6;          // 8 or 16 waves per tile (launch parameter)
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); tn = clock64(); pf[i] += tn - tc; tc = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
     // LDS carve-up for the largest tile of the plan (fixed offsets: tiles of one workgroup differ in size)
     const int R16max = SO ? 0 : pd.max_rows16;
-    float *Eh = lds, *stg = Eh + R16max * kLdsRowStride;
-    int *las = reinterpret_cast<int *>(stg + kTileWaves * 8 * 64);
-    float *Qs = reinterpret_cast<float *>(las + kTileWaves * 64);
-    int *gidx = reinterpret_cast<int *>(Qs + 128);                // (Qs: Q of the 64 tracks, then beta = Q w')
-    float *geo = reinterpret_cast<float *>(gidx + R16max);        // [npair][20], 16-byte aligned
+    R *Eh = lds, *stg = Eh + R16max * kLdsRowStride;
+    R *Qs = stg + kTileWaves * 8 * 64;                            // (Qs: Q of the 64 tracks, then beta = Q w')
+    R *geo = Qs + 128;                                            // [npair][20], 16-byte aligned
+    int *las = reinterpret_cast<int *>(geo + (size_t)(pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1) * kPairGeomFloats);
+    int *gidx = las + kTileWaves * 64;
     // one per-pair sum per wave in registers
     double pacc = 0.0;
     int p_cur = -1;
@@ -95,10 +99,10 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
 #pragma unroll 1
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int ntrk = pd.tile_ntrk[tile], ncam = pd.tile_ncam[tile];
-        const int R = 6 * ncam, R16 = SO ? 0 : ((R + 15) >> 4) << 4;
+        const int Rw = 6 * ncam, R16 = SO ? 0 : ((Rw + 15) >> 4) << 4;
         const int *cams = pd.tile_cams + pd.tile_cam0[tile];
         if (!SO) {                                                 // local row -> row of the reduced system
-            for (int i = tid; i < R16max; i += nthr) gidx[i] = i < R ? 6 * cams[i / 6] + i % 6 : -1;
+            for (int i = tid; i < R16max; i += nthr) gidx[i] = i < Rw ? 6 * cams[i / 6] + i % 6 : -1;
         }
         // first loads that need nothing but the tile index: the cameras of its pairs and the patch of this lane's track
         const int mtp = pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1;
@@ -121,30 +125,30 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             const int gp0 = !SO && tid < np ? pd.tile_pairs[pd.tile_pair0[tile] + tid] : 0;
             for (int p = tid; p < np; p += nthr) {                 // (more pairs than threads: never with kMaxTilePairs = 192)
                 const int ij = p == tid ? ij0 : pd.tile_ij[(size_t)tile * mtp + p];
-                float *g = geo + p * kPairGeomFloats;
-                pair_geometry(a.poses, a.intr, ij & 0xffff, ij >> 16, g);
+                R *g = geo + p * kPairGeomFloats;
+                pair_geometry<R>(a.poses, a.intr, ij & 0xffff, ij >> 16, g);
                 if (!SO) {
                     const int gp = p == tid ? gp0 : pd.tile_pairs[pd.tile_pair0[tile] + p];
-                    float4 *dst = reinterpret_cast<float4 *>(a.pairgeo + (size_t)gp * kPairGeomFloats);
-                    const float4 *src = reinterpret_cast<const float4 *>(g);
+                    R2 *dst = reinterpret_cast<R2 *>(reinterpret_cast<R *>(a.pairgeo) + (size_t)gp * kPairGeomFloats);
+                    const R2 *src = reinterpret_cast<const R2 *>(g);
 #pragma unroll
-                    for (int c = 0; c < kPairGeomFloats / 4; ++c) dst[c] = src[c];
+                    for (int c = 0; c < kPairGeomFloats / 2; ++c) dst[c] = src[c];
                 }
             }
         }
-        for (int i = tid; i < R16 * kLdsRowStride; i += nthr) Eh[i] = 0.0f;
+        for (int i = tid; i < R16 * kLdsRowStride; i += nthr) Eh[i] = (R)0;
 
         const int trk = pd.tile_trk0[tile] + lane;
         const bool has_trk = lane < ntrk;
         int patch = 0;
-        float px = 0.0f, py = 0.0f, pdisp = 0.0f;
-        float mono_v = 0.0f;
+        R px = 0, py = 0, pdisp = 0;
+        R mono_v = 0;
         if (has_trk) {
             patch = patch_ld;
             px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2];
             mono_v = a.mono[(size_t)patch * a.mstride];                 // needed only after the slot loop: no load latency there
         }
-        float tu_nx = 0.0f, tv_nx = 0.0f, w0_nx = 0.0f, w1_nx = 0.0f;
+        R tu_nx = 0, tv_nx = 0, w0_nx = 0, w1_nx = 0;
         if (e_nx >= 0) {
             const float *tp = a.targets + (size_t)e_nx * a.tstride;
             tu_nx = tp[0]; tv_nx = tp[1];
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         __syncthreads();
         BT_PF(0);
 
-        float Cacc = 0.0f, wacc = 0.0f, Ei[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        R Cacc = 0, wacc = 0, Ei[6] = {0, 0, 0, 0, 0, 0};
         unsigned la_cur = 0xffu;
         // Target cameras this track also observes in the neighbouring waves' chunks right across the
         // chunk boundary.  Observations of one (track, camera) are contiguous in slot order, so a run
@@ -165,11 +169,11 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             if (s0 > 0) lb_prev = pd.slot_lab[(size_t)(slot0 + s0 - 1) * kLanes + lane] >> 8;
             if (s1 < nslot) lb_next = pd.slot_lab[(size_t)(slot0 + s1) * kLanes + lane] >> 8;
         }
-        float Ejacc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        R Ejacc[6] = {0, 0, 0, 0, 0, 0};
         unsigned lb_acc = 0xffu;
         auto flush_ej = [&](unsigned lbf) {
             if (lbf != 0xffu) {
-                float *row = Eh + lbf * 6 * kLdsRowStride + lane;
+                R *row = Eh + lbf * 6 * kLdsRowStride + lane;
                 if (lbf == lb_prev || lbf == lb_next) {
 #pragma unroll
                     for (int c = 0; c < 6; ++c) atomicAdd(row + c * kLdsRowStride, Ejacc[c]);
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) Ejacc[c] = 0.0f;
+            for (int c = 0; c < 6; ++c) Ejacc[c] = (R)0;
         };
 #pragma unroll 1
         for (int s = s0; s < s1; ++s) {
@@ -188,11 +192,11 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             const int e = e_nx, pair = pair_nx, lp = lp_nx;
             const bool act = e >= 0;
             const unsigned lab = lab_nx;
-            const float tu = tu_nx, tv = tv_nx, w0 = w0_nx, w1 = w1_nx;
+            const R tu = tu_nx, tv = tv_nx, w0 = w0_nx, w1 = w1_nx;
             if (s + 1 < s1) {
                 const size_t idn = idx + kLanes;
                 e_nx = pd.slot_edge[idn]; pair_nx = pd.slot_pair[idn]; lab_nx = pd.slot_lab[idn]; lp_nx = pd.slot_lp[idn];
-                tu_nx = tv_nx = w0_nx = w1_nx = 0.0f;
+                tu_nx = tv_nx = w0_nx = w1_nx = (R)0;
                 if (e_nx >= 0) {
                     const float *tp = a.targets + (size_t)e_nx * a.tstride;
                     tu_nx = tp[0]; tv_nx = tp[1];
@@ -200,31 +204,35 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
                     w0_nx = w.x; w1_nx = w.y;
                 }
             }
-            float g[kPairGeomFloats];
-            {
+            R g[kPairGeomFloats];
+            if (sizeof(R) == 4) {
                 const float4 *g4 = reinterpret_cast<const float4 *>(geo + (size_t)lp * kPairGeomFloats);
 #pragma unroll
                 for (int c = 0; c < 5; ++c) {
                     const float4 t4 = g4[c];
                     g[4*c] = t4.x; g[4*c + 1] = t4.y; g[4*c + 2] = t4.z; g[4*c + 3] = t4.w;
                 }
+            } else {
+                const double2 *g2 = reinterpret_cast<const double2 *>(geo + (size_t)lp * kPairGeomFloats);
+#pragma unroll
+                for (int c = 0; c < 10; ++c) { const double2 t2 = g2[c]; g[2*c] = t2.x; g[2*c + 1] = t2.y; }
             }
             if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             BT_PF(1);
-            EdgeQ q;
-            edge_eval(g, px, py, pdisp, tu, tv, w0, w1, a, q);
-            if (!act) { q.W0 = 0.0f; q.W1 = 0.0f; q.r0 = 0.0f; q.r1 = 0.0f; }
+            EdgeQT<R> q;
+            edge_eval<R>(g, px, py, pdisp, tu, tv, w0, w1, a, q);
+            if (!act) { q.W0 = (R)0; q.W1 = (R)0; q.r0 = (R)0; q.r1 = (R)0; }
 
             // C, w of the track (ba.py:287,292)
             Cacc += q.W0 * q.jz0 * q.jz0 + q.W1 * q.jz1 * q.jz1;
             wacc += q.W0 * q.jz0 * q.r0 + q.W1 * q.jz1 * q.r1;
             if (SO) continue;
 
-            const float wa0 = q.W0 * q.a0, wa2 = q.W0 * q.a2, wa3 = q.W0 * q.a3, wa4 = q.W0 * q.a4, wa5 = q.W0 * q.a5;
-            const float wb1 = q.W1 * q.b1, wb2 = q.W1 * q.b2, wb3 = q.W1 * q.b3, wb4 = q.W1 * q.b4, wb5 = q.W1 * q.b5;
+            const R wa0 = q.W0 * q.a0, wa2 = q.W0 * q.a2, wa3 = q.W0 * q.a3, wa4 = q.W0 * q.a4, wa5 = q.W0 * q.a5;
+            const R wb1 = q.W1 * q.b1, wb2 = q.W1 * q.b2, wb3 = q.W1 * q.b3, wb4 = q.W1 * q.b4, wb5 = q.W1 * q.b5;
             // Ej = Jj^T W Jz (ba.py:263) and Ei = -Ad^T Ej
-            const float Ej[6] = { wa0 * q.jz0, wb1 * q.jz1, fmaf(wa2, q.jz0, wb2 * q.jz1), fmaf(wa3, q.jz0, wb3 * q.jz1),
-                                  fmaf(wa4, q.jz0, wb4 * q.jz1), fmaf(wa5, q.jz0, wb5 * q.jz1) };
+            const R Ej[6] = { wa0 * q.jz0, wb1 * q.jz1, fma_t(wa2, q.jz0, wb2 * q.jz1), fma_t(wa3, q.jz0, wb3 * q.jz1),
+                              fma_t(wa4, q.jz0, wb4 * q.jz1), fma_t(wa5, q.jz0, wb5 * q.jz1) };
             const unsigned la = lab & 0xffu, lb = lab >> 8;
             // target-camera E: repeated observations of one (track, camera) are consecutive slots, so they
             // are summed in registers and written once when the camera changes (or the chunk ends)
@@ -239,9 +247,9 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             if (act && la != 0xffu) {
                 la_cur = la;                 // one source camera per track: enforced by the plan (ii = ix[kk], batrack.py:199)
                 // o_tau = R^T e_tau ; o_phi = R^T (e_tau x t + e_phi)      (se3.h:58-67)
-                const float cx = Ej[1]*g[11] - Ej[2]*g[10] + Ej[3];
-                const float cy = Ej[2]*g[9]  - Ej[0]*g[11] + Ej[4];
-                const float cz = Ej[0]*g[10] - Ej[1]*g[9]  + Ej[5];
+                const R cx = Ej[1]*g[11] - Ej[2]*g[10] + Ej[3];
+                const R cy = Ej[2]*g[9]  - Ej[0]*g[11] + Ej[4];
+                const R cz = Ej[0]*g[10] - Ej[1]*g[9]  + Ej[5];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     Ei[c]     -= g[c]*Ej[0] + g[3 + c]*Ej[1] + g[6 + c]*Ej[2];
@@ -257,22 +265,22 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             while (todo) {
                 const int leader = __ffsll((long long)todo) - 1;
                 const int p0 = __shfl(pair, leader);
-                const float m = (act && pair == p0) ? 1.0f : 0.0f;
-                const float ma0 = m * wa0, mb1 = m * wb1, ma2 = m * wa2, mb2 = m * wb2, ma3 = m * wa3, mb3 = m * wb3,
+                const R m = (act && pair == p0) ? (R)1 : (R)0;
+                const R ma0 = m * wa0, mb1 = m * wb1, ma2 = m * wa2, mb2 = m * wb2, ma3 = m * wa3, mb3 = m * wb3,
                             ma4 = m * wa4, mb4 = m * wb4, ma5 = m * wa5, mb5 = m * wb5;
-                float v[32];
-                v[0] = ma0 * q.a0;  v[1] = 0.0f;        v[2] = ma0 * q.a2;  v[3] = ma0 * q.a3;
+                R v[32];
+                v[0] = ma0 * q.a0;  v[1] = (R)0;        v[2] = ma0 * q.a2;  v[3] = ma0 * q.a3;
                 v[4] = ma0 * q.a4;  v[5] = ma0 * q.a5;
                 v[6] = mb1 * q.b1;  v[7] = mb1 * q.b2;  v[8] = mb1 * q.b3;  v[9] = mb1 * q.b4;  v[10] = mb1 * q.b5;
-                v[11] = fmaf(ma2, q.a2, mb2 * q.b2); v[12] = fmaf(ma2, q.a3, mb2 * q.b3);
-                v[13] = fmaf(ma2, q.a4, mb2 * q.b4); v[14] = fmaf(ma2, q.a5, mb2 * q.b5);
-                v[15] = fmaf(ma3, q.a3, mb3 * q.b3); v[16] = fmaf(ma3, q.a4, mb3 * q.b4); v[17] = fmaf(ma3, q.a5, mb3 * q.b5);
-                v[18] = fmaf(ma4, q.a4, mb4 * q.b4); v[19] = fmaf(ma4, q.a5, mb4 * q.b5);
-                v[20] = fmaf(ma5, q.a5, mb5 * q.b5);
+                v[11] = fma_t(ma2, q.a2, mb2 * q.b2); v[12] = fma_t(ma2, q.a3, mb2 * q.b3);
+                v[13] = fma_t(ma2, q.a4, mb2 * q.b4); v[14] = fma_t(ma2, q.a5, mb2 * q.b5);
+                v[15] = fma_t(ma3, q.a3, mb3 * q.b3); v[16] = fma_t(ma3, q.a4, mb3 * q.b4); v[17] = fma_t(ma3, q.a5, mb3 * q.b5);
+                v[18] = fma_t(ma4, q.a4, mb4 * q.b4); v[19] = fma_t(ma4, q.a5, mb4 * q.b5);
+                v[20] = fma_t(ma5, q.a5, mb5 * q.b5);
                 v[21] = ma0 * q.r0; v[22] = mb1 * q.r1;
-                v[23] = fmaf(ma2, q.r0, mb2 * q.r1); v[24] = fmaf(ma3, q.r0, mb3 * q.r1);
-                v[25] = fmaf(ma4, q.r0, mb4 * q.r1); v[26] = fmaf(ma5, q.r0, mb5 * q.r1);
-                v[27] = v[28] = v[29] = v[30] = v[31] = 0.0f;
+                v[23] = fma_t(ma2, q.r0, mb2 * q.r1); v[24] = fma_t(ma3, q.r0, mb3 * q.r1);
+                v[25] = fma_t(ma4, q.r0, mb4 * q.r1); v[26] = fma_t(ma5, q.r0, mb5 * q.r1);
+                v[27] = v[28] = v[29] = v[30] = v[31] = (R)0;
                 wave_reduce_scatter32(v, lane);
                 if (p0 != p_cur) { flush_pair(); p_cur = p0; }   // same pair as this wave's previous slot / tile: keep summing
                 pacc += (double)v[0];
@@ -292,16 +300,16 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
         if (!SO && wave < 6) {                          // owner of component `wave` of every track's source-camera E
             // a track has ONE source camera (plan-enforced), so the waves' partials of a lane all go to the same
             // element: all loads first, one read-modify-write
-            float sum = 0.0f;
+            R sum = 0;
             int la = 0xff;
             for (int w0 = 0; w0 < kTileWaves; w0 += 8) {
                 int lw[8];
-                float pv[8];
+                R pv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool in = w0 + u < kTileWaves;
                     lw[u] = in ? las[(w0 + u) * 64 + lane] : 0xff;
-                    pv[u] = in ? stg[((w0 + u) * 8 + wave) * 64 + lane] : 0.0f;
+                    pv[u] = in ? stg[((w0 + u) * 8 + wave) * 64 + lane] : (R)0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (lw[u] != 0xff) { sum += pv[u]; la = lw[u]; }
@@ -309,23 +317,24 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             if (la != 0xff) Eh[(la * 6 + wave) * kLdsRowStride + lane] += sum;
         }
         if (wave == 6) {                                                   // ba.py:296-311
-            float C = 0.0f, wv = 0.0f;
+            R C = 0, wv = 0;
             for (int w = 0; w < kTileWaves; ++w) { C += stg[(w * 8 + 6) * 64 + lane]; wv += stg[(w * 8 + 7) * 64 + lane]; }
-            float Q = 0.0f, wp = 0.0f;
+            R Q = 0, wp = 0;
             if (has_trk) {
-                const float mono = mono_v;
-                const float pm = mono > 1e-2f ? 1.0f : 0.0f;
-                float Ca = C + pm * a.alpha;
-                Ca = Ca + (a.lmbda_trk ? a.lmbda_trk[trk] : a.lmbda);
-                wp = wv - pm * a.alpha * (pdisp - mono);
-                Q = 1.0f / Ca;
+                const R mono = mono_v;
+                const R pm = mono > (R)1e-2f ? (R)1 : (R)0;               // (the prior is float32 data: compared as such)
+                R Ca = C + pm * (R)a.alpha;
+                Ca = Ca + (R)(a.lmbda_trk ? a.lmbda_trk[trk] : a.lmbda);
+                wp = wv - pm * (R)a.alpha * (pdisp - mono);
+                Q = (R)1 / Ca;
                 if (FUSE) {                                                // ba.py:316-317, :333
-                    float dd = pdisp + Q * wp;
+                    float dd = (float)(pdisp + Q * wp);
                     dd = dd < 1e-3f ? 1e-3f : dd;
                     dd = dd > 10.0f ? 10.0f : dd;
-                    a.patches_out[3*patch] = px; a.patches_out[3*patch + 1] = py; a.patches_out[3*patch + 2] = dd;
+                    a.patches_out[3*patch] = (float)px; a.patches_out[3*patch + 1] = (float)py; a.patches_out[3*patch + 2] = dd;
                 } else {
-                    a.qw[trk] = make_float2(Q, wp);
+                    R2 qw2; qw2.x = Q; qw2.y = wp;
+                    reinterpret_cast<R2 *>(a.qw)[trk] = qw2;
                 }
             }
             if (!SO) { Qs[lane] = Q; Qs[64 + lane] = Q * wp; }
@@ -348,10 +357,10 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
             while (base + ti + 1 <= t) { base += ti + 1; ++ti; }
             const int tj = t - base;
             const int li = lane & 15, kq = lane >> 4;
-            const float *ar = Eh + (16 * ti + li) * kLdsRowStride + kq;
-            const float *br = Eh + (16 * tj + li) * kLdsRowStride + kq;
-            const float *qr = Qs + kq;
-            float av[16], bv[16], qv[16];
+            const R *ar = Eh + (16 * ti + li) * kLdsRowStride + kq;
+            const R *br = Eh + (16 * tj + li) * kLdsRowStride + kq;
+            const R *qr = Qs + kq;
+            R av[16], bv[16], qv[16];
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) { av[ks] = ar[4 * ks]; bv[ks] = br[4 * ks]; qv[ks] = qr[4 * ks]; }
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + kq + 4 * r;
-                if (gc >= 0 && row < R) { const int gr = gidx[row]; if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]); }
+                if (gc >= 0 && row < Rw) { const int gr = gidx[row]; if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]); }
             }
             if (ti == tj) {
                 double4_t yt = {0.0, 0.0, 0.0, 0.0};
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : 4) void k_tile(PlanDe
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * ti + kq + 4 * r;
-                    if (li == 0 && row < R) atomicAdd(&a.y[gidx[row]], -yt[r]);
+                    if (li == 0 && row < Rw) atomicAdd(&a.y[gidx[row]], -yt[r]);
                 }
             }
         }
@@ -401,7 +410,7 @@ __device__ __forceinline__ int sym21(int p, int q) {
 
 __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
     __shared__ double sB[4][36], sAd[4][36], sM[4][36], sg[4][6];
-    __shared__ float sgeo[4][kPairGeomFloats];
+    __shared__ double sgeo[4][kPairGeomFloats];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + w;
     const bool live = p < pd.P;
@@ -409,10 +418,12 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
     if (live) {
         ia = pd.pair_i[p] - pd.fixedp; ib = pd.pair_j[p] - pd.fixedp;
         double *acc = a.pairacc + (size_t)p * kPairAccStride;
-        float *g = sgeo[w];
+        double *g = sgeo[w];
         // the sums first (they need only the pair index), so their latency runs under the pose loads and the geometry
         const double accv = lane < 36 ? acc[sym21(lane / 6, lane % 6)] : lane < 42 ? acc[21 + lane - 36] : 0.0;
-        if (lane < kPairGeomFloats) g[lane] = a.pairgeo[(size_t)p * kPairGeomFloats + lane];     // computed by k_tile
+        if (lane < kPairGeomFloats)                                                              // computed by the Jacobian kernel
+            g[lane] = a.prec ? reinterpret_cast<const double *>(a.pairgeo)[(size_t)p * kPairGeomFloats + lane]
+                             : (double)a.pairgeo[(size_t)p * kPairGeomFloats + lane];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (lane < 36) {
             const int r = lane / 6, c = lane % 6;
@@ -650,9 +661,6 @@ template <> __device__ __forceinline__ double rsqrt_t<double>(double x) {
     return y * (1.5 - 0.5 * x * y * y);
 }
 
-template <typename T> struct Vec2;
-template <> struct Vec2<float> { typedef float2 type; };
-template <> struct Vec2<double> { typedef double2 type; };
 
 template <typename T>
 __device__ __forceinline__ void load_row6(const T *p, T (&v)[6]) {
@@ -1971,9 +1979,11 @@ constexpr int kUpdGeo = 28;          // floats per pair in LDS: the 20 of kPairG
 
 // THREADS: 512, or 1024 for the few-tiles / many-slots graphs that k_tile runs 16 waves wide (tile_wide): the tile blocks'
 // slot loop, which is all the time there is on 40 tiles, halves.
-template <bool SO, int THREADS = kUpdThreads>
+template <bool SO, int THREADS = kUpdThreads, typename R = float>
 __global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int do_poses, int tile_blocks, int first_zero_block) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R *lds = reinterpret_cast<R *>(lds_raw);
+    typedef typename Vec2<R>::type R2;
     if (!SO && (int)blockIdx.x >= first_zero_block) {
         const size_t nz = (size_t)pd.D * pd.D + pd.D;
         const size_t i0 = ((size_t)(blockIdx.x - first_zero_block) * blockDim.x + threadIdx.x) * 4;
@@ -1986,8 +1996,8 @@ __global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int 
         const int tq_ = tile_blocks >> 3, tr_ = tile_blocks & 7, xcd_ = blockIdx.x & 7;
         const int tile = xcd_ * tq_ + min(xcd_, tr_) + ((int)blockIdx.x >> 3), tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
         constexpr int kWaves = THREADS / 64;
-        float *geo = lds;                                           // [npair][kUpdGeo]
-        float *part = lds + (size_t)pd.max_tile_pairs * kUpdGeo;    // [kWaves][64]
+        R *geo = lds;                                               // [npair][kUpdGeo]
+        R *part = lds + (size_t)pd.max_tile_pairs * kUpdGeo;        // [kWaves][64]
         const int np = pd.tile_npair[tile];
         const int patch = pd.tile_kx[(size_t)tile * kLanes + lane];
         const int slot0 = pd.tile_slot0[tile], nslot = pd.tile_nslot[tile];
@@ -1998,32 +2008,32 @@ __global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int 
         for (int p = tid; p < np; p += THREADS) {
             const int gp = pd.tile_pairs[pd.tile_pair0[tile] + p];
             const int ia = pd.pair_i[gp] - pd.fixedp, ib = pd.pair_j[gp] - pd.fixedp;
-            float g[kPairGeomFloats];
-            const float4 *src = reinterpret_cast<const float4 *>(a.pairgeo + (size_t)gp * kPairGeomFloats);
+            R g[kPairGeomFloats];
+            const R2 *src = reinterpret_cast<const R2 *>(reinterpret_cast<const R *>(a.pairgeo) + (size_t)gp * kPairGeomFloats);
 #pragma unroll
-            for (int c = 0; c < kPairGeomFloats / 4; ++c) { const float4 t4 = src[c]; g[4*c] = t4.x; g[4*c + 1] = t4.y; g[4*c + 2] = t4.z; g[4*c + 3] = t4.w; }
-            float xi[6] = {0, 0, 0, 0, 0, 0}, xj[6] = {0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < kPairGeomFloats / 2; ++c) { const R2 t2 = src[c]; g[2*c] = t2.x; g[2*c + 1] = t2.y; }
+            R xi[6] = {0, 0, 0, 0, 0, 0}, xj[6] = {0, 0, 0, 0, 0, 0};
             if (ia >= 0) for (int c = 0; c < 6; ++c) xi[c] = a.dx[6 * ia + c];
             if (ib >= 0) for (int c = 0; c < 6; ++c) xj[c] = a.dx[6 * ib + c];
             // Ad(Gij) (tau, phi) = (R tau + t x (R phi), R phi)        (se3.h:58-67)
-            float Rt[3], Rp[3];
+            R Rt[3], Rp[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 Rt[r] = g[3*r] * xi[0] + g[3*r + 1] * xi[1] + g[3*r + 2] * xi[2];
                 Rp[r] = g[3*r] * xi[3] + g[3*r + 1] * xi[4] + g[3*r + 2] * xi[5];
             }
-            float *o = geo + (size_t)p * kUpdGeo;
+            R *o = geo + (size_t)p * kUpdGeo;
 #pragma unroll
             for (int c = 0; c < kPairGeomFloats; ++c) o[c] = g[c];
             o[20] = xj[0] - (Rt[0] + g[10] * Rp[2] - g[11] * Rp[1]);
             o[21] = xj[1] - (Rt[1] + g[11] * Rp[0] - g[9]  * Rp[2]);
             o[22] = xj[2] - (Rt[2] + g[9]  * Rp[1] - g[10] * Rp[0]);
             o[23] = xj[3] - Rp[0]; o[24] = xj[4] - Rp[1]; o[25] = xj[5] - Rp[2];
-            o[26] = 0.0f; o[27] = 0.0f;
+            o[26] = (R)0; o[27] = (R)0;
         }
-        float px = 0.0f, py = 0.0f, pdisp = 0.0f;
+        R px = 0, py = 0, pdisp = 0;
         if (patch >= 0) { px = a.patches[3*patch]; py = a.patches[3*patch + 1]; pdisp = a.patches[3*patch + 2]; }
-        float tu_nx = 0.0f, tv_nx = 0.0f, w0_nx = 0.0f, w1_nx = 0.0f;
+        R tu_nx = 0, tv_nx = 0, w0_nx = 0, w1_nx = 0;
         if (e_nx >= 0) {
             const float *tp = a.targets + (size_t)e_nx * a.tstride;
             tu_nx = tp[0]; tv_nx = tp[1];
@@ -2031,15 +2041,15 @@ __global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int 
             w0_nx = w.x; w1_nx = w.y;
         }
         __syncthreads();
-        float acc = 0.0f;
+        R acc = 0;
 #pragma unroll 1
         for (int s = s0; s < s1; ++s) {
             const int e = e_nx, lp = lp_nx;
-            const float tu = tu_nx, tv = tv_nx, w0 = w0_nx, w1 = w1_nx;
+            const R tu = tu_nx, tv = tv_nx, w0 = w0_nx, w1 = w1_nx;
             if (s + 1 < s1) {
                 const size_t idn = (size_t)(slot0 + s + 1) * kLanes + lane;
                 e_nx = pd.slot_edge[idn]; lp_nx = pd.slot_lp[idn];
-                tu_nx = tv_nx = w0_nx = w1_nx = 0.0f;
+                tu_nx = tv_nx = w0_nx = w1_nx = (R)0;
                 if (e_nx >= 0) {
                     const float *tp = a.targets + (size_t)e_nx * a.tstride;
                     tu_nx = tp[0]; tv_nx = tp[1];
@@ -2047,30 +2057,34 @@ __global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int 
                     w0_nx = w.x; w1_nx = w.y;
                 }
             }
-            float g[kUpdGeo];
-            {
+            R g[kUpdGeo];
+            if (sizeof(R) == 4) {
                 const float4 *g4 = reinterpret_cast<const float4 *>(geo + (size_t)lp * kUpdGeo);
 #pragma unroll
                 for (int c = 0; c < kUpdGeo / 4; ++c) { const float4 t4 = g4[c]; g[4*c] = t4.x; g[4*c + 1] = t4.y; g[4*c + 2] = t4.z; g[4*c + 3] = t4.w; }
+            } else {
+                const double2 *g2 = reinterpret_cast<const double2 *>(geo + (size_t)lp * kUpdGeo);
+#pragma unroll
+                for (int c = 0; c < kUpdGeo / 2; ++c) { const double2 t2 = g2[c]; g[2*c] = t2.x; g[2*c + 1] = t2.y; }
             }
-            EdgeQ q;
-            edge_eval(g, px, py, pdisp, tu, tv, w0, w1, a, q);
+            EdgeQT<R> q;
+            edge_eval<R>(g, px, py, pdisp, tu, tv, w0, w1, a, q);
             if (e < 0) continue;
-            const float d0 = q.a0 * g[20] + q.a2 * g[22] + q.a3 * g[23] + q.a4 * g[24] + q.a5 * g[25];
-            const float d1 = q.b1 * g[21] + q.b2 * g[22] + q.b3 * g[23] + q.b4 * g[24] + q.b5 * g[25];
+            const R d0 = q.a0 * g[20] + q.a2 * g[22] + q.a3 * g[23] + q.a4 * g[24] + q.a5 * g[25];
+            const R d1 = q.b1 * g[21] + q.b2 * g[22] + q.b3 * g[23] + q.b4 * g[24] + q.b5 * g[25];
             acc += q.W0 * q.jz0 * d0 + q.W1 * q.jz1 * d1;
         }
         part[wave * 64 + lane] = acc;
         __syncthreads();
         if (wave == 0 && patch >= 0) {
-            float tot = 0.0f;
+            R tot = 0;
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) tot += part[w * 64 + lane];
-            const float2 qw = a.qw[pd.tile_trk0[tile] + lane];
-            float dd = pdisp + qw.x * (qw.y - tot);                         // ba.py:328, :333
+            const R2 qw = reinterpret_cast<const R2 *>(a.qw)[pd.tile_trk0[tile] + lane];
+            float dd = (float)(pdisp + qw.x * (qw.y - tot));                // ba.py:328, :333
             dd = dd < 1e-3f ? 1e-3f : dd;
             dd = dd > 10.0f ? 10.0f : dd;
-            a.patches_out[3*patch] = px; a.patches_out[3*patch + 1] = py; a.patches_out[3*patch + 2] = dd;
+            a.patches_out[3*patch] = (float)px; a.patches_out[3*patch + 1] = (float)py; a.patches_out[3*patch + 2] = dd;
         }
         return;
     }
@@ -2085,12 +2099,12 @@ __device__ __forceinline__ void update_rest(const PlanDev &pd, const StepArgs &a
         const bool has = (aw >> ab) & 1u;
         if (TRACKS_ELSEWHERE && has) return;                            // written by its tile's block
         const float x = a.patches[3*gid], y = a.patches[3*gid + 1], d = a.patches[3*gid + 2];
-        float dz = 0.0f;
-        if (SO && has) {
-            const float2 qw = a.qw[pd.act_rank[gid >> 5] + __popc(aw & ((1u << ab) - 1u))];
-            dz = qw.x * qw.y;                                           // ba.py:316-317
+        float dd = d;                                                   // ba.py:333 (whole buffer)
+        if (SO && has) {                                                // ba.py:316-317
+            const int trk = pd.act_rank[gid >> 5] + __popc(aw & ((1u << ab) - 1u));
+            if (a.prec) { const double2 qw = reinterpret_cast<const double2 *>(a.qw)[trk]; dd = (float)((double)d + qw.x * qw.y); }
+            else { const float2 qw = a.qw[trk]; dd = d + qw.x * qw.y; }
         }
-        float dd = d + dz;                                              // ba.py:333 (whole buffer)
         dd = dd < 1e-3f ? 1e-3f : dd;
         dd = dd > 10.0f ? 10.0f : dd;
         a.patches_out[3*gid] = x; a.patches_out[3*gid + 1] = y; a.patches_out[3*gid + 2] = dd;
@@ -2129,21 +2143,35 @@ __global__ __launch_bounds__(256) void k_pack_system(PlanDev pd, StepArgs a) {
 
 // ------------------------------------------------------------------ launchers
 // 8 waves per tile; 16 for graphs of few tiles with deep slot loops (BT_TILE_WIDE = 0 / 1 forces: measurement only)
+int edge_precision(const PlanDev &pd);
 static bool tile_wide(const PlanDev &pd) {
+    if (edge_precision(pd)) return false;
     static const int env = std::getenv("BT_TILE_WIDE") ? std::atoi(std::getenv("BT_TILE_WIDE")) : -1;
     if (env >= 0) return env != 0;
     return pd.T <= 128 && pd.max_tile_slots >= 24;
 }
+// (the float64 instantiation runs 8 waves per tile whatever the graph: its slot loop wants more than the 128 registers
+// a 16-wave workgroup leaves a thread, and the window graphs' SIMDs are issue-saturated at 8 waves already)
 static int tile_threads(const PlanDev &pd) { return tile_wide(pd) ? 1024 : 512; }
 
-static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
+constexpr size_t kLdsBudget = 160 * 1024 - 512;
+
+// rsz: sizeof(R) of the k_tile instantiation
+static inline size_t tile_lds_bytes_r(const PlanDev &pd, bool so, size_t rsz, size_t kTileWaves) {
     const size_t rows = so ? 0 : (size_t)pd.max_rows16;
-    const size_t kTileWaves = (size_t)tile_threads(pd) / 64;
-    return (rows * kLdsRowStride + kTileWaves * 8 * 64 + kTileWaves * 64 + 128 + rows +
-            (size_t)pd.max_tile_pairs * kPairGeomFloats) * sizeof(float) + 64;
+    const size_t mtp = pd.max_tile_pairs > 0 ? (size_t)pd.max_tile_pairs : 1;
+    return (rows * kLdsRowStride + kTileWaves * 8 * 64 + 128 + mtp * kPairGeomFloats) * rsz + (kTileWaves * 64 + rows) * sizeof(int) + 64;
 }
 
-constexpr size_t kLdsBudget = 160 * 1024 - 512;
+int edge_precision(const PlanDev &pd) {
+    static const int env = std::getenv("BT_EDGE_PREC") ? std::atoi(std::getenv("BT_EDGE_PREC")) : 1;   // 0: measurement only
+    if (env == 0 || pd.T <= 0 || edge_applies(pd) || stream_applies(pd)) return 0;
+    return tile_lds_bytes_r(pd, false, sizeof(double), 8) <= kLdsBudget ? 1 : 0;
+}
+
+static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
+    return tile_lds_bytes_r(pd, so, edge_precision(pd) ? sizeof(double) : sizeof(float), (size_t)tile_threads(pd) / 64);
+}
 
 // 0: factor in LDS as double, 1: in LDS as float, 2: in the global workspace (float)
 int solver_mode(const PlanDev &pd) {
@@ -2198,9 +2226,19 @@ static int raise_lds_limit(const void *fn, size_t need) {
 int configure_kernels(const PlanDev &pd) {
     const size_t need = tile_lds_bytes(pd, false);
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
-    const void *tiles[4] = { reinterpret_cast<const void *>(&k_tile<false, false>), reinterpret_cast<const void *>(&k_tile<false, false, true>),
-                             reinterpret_cast<const void *>(&k_tile<false, true>), reinterpret_cast<const void *>(&k_tile<false, true, true>) };
-    for (const void *fn : tiles) if (raise_lds_limit(fn, need) != BT_OK) return BT_EHIP;
+    const void *tiles[6] = { reinterpret_cast<const void *>(&k_tile<false, false>), reinterpret_cast<const void *>(&k_tile<false, false, true>),
+                             reinterpret_cast<const void *>(&k_tile<false, true>), reinterpret_cast<const void *>(&k_tile<false, true, true>),
+                             reinterpret_cast<const void *>(&k_tile<false, false, false, false, double>),
+                             reinterpret_cast<const void *>(&k_tile<false, true, false, false, double>) };
+    const bool dbl = edge_precision(pd) != 0;
+    for (int i = dbl ? 4 : 0; i < (dbl ? 6 : 4); ++i) if (raise_lds_limit(tiles[i], need) != BT_OK) return BT_EHIP;
+    if (dbl) {
+        const size_t nu = ((size_t)pd.max_tile_pairs * kUpdGeo + kUpdThreads) * sizeof(double);
+        if (nu > kLdsBudget) return BT_EUNSUPPORTED;
+        if (raise_lds_limit(reinterpret_cast<const void *>(&k_update<false, kUpdThreads, double>), nu) != BT_OK) return BT_EHIP;
+        if (raise_lds_limit(reinterpret_cast<const void *>(&k_tile<true, false, false, true, double>), tile_lds_bytes(pd, true)) != BT_OK ||
+            raise_lds_limit(reinterpret_cast<const void *>(&k_tile<true, false, false, false, double>), tile_lds_bytes(pd, true)) != BT_OK) return BT_EHIP;
+    }
     const int mode = solver_mode(pd);
     const void *fns[4] = { reinterpret_cast<const void *>(&k_solve_lds<double, false>),
                            reinterpret_cast<const void *>(&k_solve_lds<double, true>),
@@ -2246,7 +2284,17 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
     } else if (pd.T > 0) {
         const bool wide = tile_wide(pd);
         const dim3 blk(tile_threads(pd)), grid(pd.T);
-        if (so && fuse_so_poses >= 0 && fused) {
+        if (a.prec) {                      // float64 per-edge path (8 waves per tile)
+            if (so && fuse_so_poses >= 0 && fused) {
+                const int total = pd.p_tot + (fuse_so_poses ? pd.n_buf : 0), nbr = (total + (int)blk.x - 1) / (int)blk.x;
+                BT_LAUNCH(1, (k_tile<true, false, false, true, double>), dim3(pd.T + nbr), blk, tile_lds_bytes(pd, true), pd, a, fuse_so_poses);
+                *fused = true;
+            }
+            else if (so)         BT_LAUNCH(1, (k_tile<true, false, false, false, double>), grid, blk, tile_lds_bytes(pd, true), pd, a, 0);
+            else if (a.dbg & 32) BT_LAUNCH(1, (k_tile<false, true, false, false, double>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
+            else                 BT_LAUNCH(1, (k_tile<false, false, false, false, double>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
+        }
+        else if (so && fuse_so_poses >= 0 && fused) {
             // the whole structure-only step in this launch: tile workgroups, then the rest of the patch buffer and the poses
             const int total = pd.p_tot + (fuse_so_poses ? pd.n_buf : 0), nbr = (total + (int)blk.x - 1) / (int)blk.x;
             const dim3 gridf(pd.T + nbr);
@@ -2322,6 +2370,8 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         if (rc != BT_OK) return rc;
         BT_LAUNCH(4, k_update<false>, dim3(nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, 0, nb);
     }
+    else if (a.prec)
+        BT_LAUNCH(4, (k_update<false, kUpdThreads, double>), dim3(pd.T + nb + zb), dim3(kUpdThreads), ((size_t)pd.max_tile_pairs * kUpdGeo + kUpdThreads) * sizeof(double), pd, a, do_poses, pd.T, pd.T + nb);
     else if (tile_wide(pd)) {
         constexpr int W = 1024;
         const int nbw = (total + W - 1) / W, zbw = (int)((nz + 4 * W - 1) / (4 * W));

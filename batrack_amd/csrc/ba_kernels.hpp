@@ -20,10 +20,14 @@ struct StepArgs {
     float *lfac, *linv, *zvec, *dx, *dx0;
     float *pairgeo;               // [pairs][kPairGeomFloats]: relative pose of every camera pair, left by k_tile for k_pair_finalize
     int *status;
+    int prec;                     // 1: the per-edge maths, E, pairgeo and qw are float64 (k_tile path, the default there); 0: float32
     int dbg;                      // env BT_DEBUG_MODE, 0 in production: 16 / 32 launch the cycle-counting variants of the solver / k_tile
 };
 
 int configure_kernels(const PlanDev &pd);
+// precision of the per-edge maths for this plan: 1 = float64 (graphs that take k_tile, unless BT_EDGE_PREC=0 or the
+// tile's E would not fit LDS as double), 0 = float32 (k_stream / k_edge: graphs of >= 2048 tiles)
+int edge_precision(const PlanDev &pd);
 // wave-per-tile streaming kernels (ba_stream.hip) for graphs of many tiles; mode 0 = pose+structure, 1 = structure-only,
 // 2 = depth back-substitution
 bool stream_applies(const PlanDev &pd);

@@ -44,8 +44,8 @@ static void layout_workspace(bt_plan *pl) {
     off = align_up(off, 256);
     w.zero_bytes = off - w.sys;
     w.packed = off;   off = align_up(off + ((size_t)I.nnz_blocks * 36 + D) * sizeof(double), 256);   // exchange form of [S | y]
-    w.pairgeo = off;  off = align_up(off + (size_t)I.pairs * kPairGeomFloats * sizeof(float), 256);          // k_tile -> k_pair_finalize
-    w.qw = off;       off = align_up(off + (size_t)I.m * 2 * sizeof(float), 256);
+    w.pairgeo = off;  off = align_up(off + (size_t)I.pairs * kPairGeomFloats * sizeof(double), 256);         // k_tile -> k_pair_finalize (float or double)
+    w.qw = off;       off = align_up(off + (size_t)I.m * 2 * sizeof(double), 256);                           // (Q, w') per track (float2 or double2)
     w.lfac = off;     off = align_up(off + (size_t)I.nnz_blocks * 36 * sizeof(float), 256);
     w.linv = off;     off = align_up(off + (size_t)I.n * 36 * sizeof(float), 256);
     w.zvec = off;     off = align_up(off + D * sizeof(float), 256);

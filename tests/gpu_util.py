@@ -1,4 +1,6 @@
 """Helpers for the -m gpu tests: run the HIP path (through the C ABI) on numpy inputs."""
+import os
+
 import numpy as np
 import torch
 
@@ -7,6 +9,19 @@ from batrack_amd.backend.lietorch import SE3
 from batrack_amd.plan import Plan, Stepper
 
 DEV = "cuda:0"
+
+# Precision of the per-edge maths of the process under test: graphs that take k_tile — every graph a real
+# window produces, every fixture — run float64 per edge; BT_EDGE_PREC=0 or a forced k_stream / k_edge (the float32
+# kernels of >= 2048-tile graphs) run float32 per edge like the reference's own float32 run.
+F32_EDGE = (os.environ.get("BT_EDGE_PREC") == "0" or os.environ.get("BT_STREAM_MIN_TILES") == "1"
+            or os.environ.get("BT_EDGE_MIN_TILES") == "1")
+# relative tolerances against the reference's float64 result: state (poses', disparities'), reduced system (S, y), camera
+# update dX, and the UPDATE itself over the touched poses / tracks (north_star: <= 1e-5).
+#   float64 per edge, measured on the fixtures: S, y <= 7e-14; dX <= 2.6e-8 (it is stored as float32); update poses
+#   <= 1.3e-6, disparities <= 2.8e-7 (the float32 rounding of the state they are written to); state <= 2e-8
+#   float32 per edge (round 2): S, y <= 2.6e-6, dX <= 1.6e-4, update <= 1.6e-4 / 5.2e-5, state <= 2.7e-6
+TOL = (dict(state=5e-6, sys=4e-6, dx=3e-4, upd_pose=3e-4, upd_disp=1e-4) if F32_EDGE else
+       dict(state=2e-7, sys=1e-10, dx=1e-5, upd_pose=1e-5, upd_disp=1e-5))
 
 
 def t32(a):

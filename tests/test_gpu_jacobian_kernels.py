@@ -30,14 +30,17 @@ def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so):
     o = HipProblem(d).raw_step(wkey, 1, so)
     assert o["plan"].jacobian_kernel == kernel, (o["plan"].jacobian_kernel, o["plan"].tiles)
     act = np.unique(g.kk)
-    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], act) < 1e-4
-    assert rel(o["patches_out"], ref["patches_out"]) < 5e-6
+    # k_tile: float64 per edge (north_star's 1e-5 on the update); k_stream / k_edge (>= 2048 tiles): float32 per edge
+    f64 = kernel == "k_tile" and os.environ.get("BT_EDGE_PREC") != "0"
+    t_upd_d, t_upd_p, t_state, t_sys, t_dx = (1e-5, 1e-5, 2e-7, 1e-10, 1e-5) if f64 else (1e-4, 3e-4, 5e-6, 5e-6, 3e-4)
+    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], act) < t_upd_d
+    assert rel(o["patches_out"], ref["patches_out"]) < t_state
     if not so:
         assert o["status"] == 0
-        assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 5e-6 and rel(o["y"], ref["y"]) < 5e-6
-        assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 3e-4
-        assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(1, 1 + o["plan"].n)) < 3e-4
-        assert rel(o["poses_out"], ref["poses_out"]) < 5e-6
+        assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < t_sys and rel(o["y"], ref["y"]) < t_sys
+        assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < t_dx
+        assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(1, 1 + o["plan"].n)) < t_upd_p
+        assert rel(o["poses_out"], ref["poses_out"]) < t_state
 
 
 FORCED = {"k_edge": dict(BT_EDGE_MIN_TILES="1", BT_EDGE_PREF_TILES="1", BT_STREAM_MIN_TILES="1"),      # wherever the tiles are slot-uniform

@@ -1,16 +1,17 @@
 """-m gpu: the HIP path (C ABI -> gfx950 kernels) against the golden vectors of the
 reference and against the float64 oracle.
 
-Tolerances, set at about 3x what is measured on the fixtures (tools/gpu_check.py prints the numbers; the
-reference's own float32 run is given for scale):
-  state (poses', disparities')   <= 5e-6 relative to the reference's float64 result   (measured <= 2.7e-6)
-  reduced system S, y            <= 4e-6: fp32 per-edge maths (the robust weights are functions of fp32 residuals),
-                                 fp64 accumulation                                     (measured <= 2.6e-6)
-  camera update dX               <= 3e-4 (measured 1.5e-6 .. 1.6e-4; reference float32: 5e-3)
+Tolerances (tests/gpu_util.py: TOL; tools/gpu_check.py prints the measured numbers, profiles/r03_parity_numbers.txt):
+the per-edge maths of every graph that takes k_tile — all fixtures, every real window — is float64 on the float32
+inputs, so against the reference's float64 result
+  reduced system S, y            <= 1e-10                                 (measured <= 7e-14)
+  camera update dX               <= 1e-5   (north_star)                   (measured <= 2.6e-8: stored as float32)
   the UPDATE itself, over the entries the step touched (north_star's tolerance is on the update):
-      poses' - poses over the free poses        <= 3e-4   (measured 1.4e-6 .. 1.6e-4; reference float32 8e-5 .. 6e-3)
-      disparities' - disparities over the active tracks <= 1e-4   (measured 1.9e-7 .. 5.2e-5; reference float32 3e-6 .. 1.9e-3)
-  and the update must beat the reference's own float32 run wherever that run is off by more than 1e-4."""
+      poses' - poses over the free poses                <= 1e-5           (measured <= 1.3e-6; reference float32 8e-5 .. 6e-3)
+      disparities' - disparities over the active tracks <= 1e-5           (measured <= 2.8e-7; reference float32 3e-6 .. 1.9e-3)
+  state (poses', disparities')   <= 2e-7                                  (measured <= 2e-8: float32 rounding of the output)
+With the float32 per-edge kernels forced (k_stream / k_edge, or BT_EDGE_PREC=0) the round-2 gates apply (5e-6 state,
+4e-6 system, 3e-4 / 1e-4 update)."""
 import os
 
 import numpy as np
@@ -20,13 +21,19 @@ import torch
 import oracle
 from batrack_amd import graphgen
 from batrack_amd.plan import Plan, Stepper
-from gpu_util import HipProblem, rel, update_err
+from gpu_util import F32_EDGE, TOL, HipProblem, rel, update_err
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-STATE_TOL = 5e-6
-DX_TOL = 3e-4
-UPD_POSE_TOL, UPD_DISP_TOL = 3e-4, 1e-4
+STATE_TOL = TOL["state"]
+DX_TOL = TOL["dx"]
+SYS_TOL = TOL["sys"]
+UPD_POSE_TOL, UPD_DISP_TOL = TOL["upd_pose"], TOL["upd_disp"]
+
+
+def tol(f64, f32):
+    """A gate that depends on the precision of the per-edge maths (gpu_util.F32_EDGE)."""
+    return f32 if F32_EDGE else f64
 
 
 def load(name):
@@ -57,8 +64,8 @@ def test_reduced_system_and_update_vs_reference(name, tag, wkey, fixedp, so, los
     disp_in = d["patches"][:, 2].astype(np.float32)
     if f"{tag}.f64.S" in d:
         Sref = d[f"{tag}.f64.S"]
-        assert rel(np.tril(o["S_lower"]), np.tril(Sref)) < 4e-6
-        assert rel(o["y"], d[f"{tag}.f64.y"]) < 4e-6
+        assert rel(np.tril(o["S_lower"]), np.tril(Sref)) < SYS_TOL
+        assert rel(o["y"], d[f"{tag}.f64.y"]) < SYS_TOL
         assert rel(o["dX"].reshape(-1), d[f"{tag}.f64.dX"].reshape(-1)) < DX_TOL
         assert o["status"] == 0
         n = Sref.shape[0] // 6
@@ -90,8 +97,8 @@ def test_api_dual_iterations(name, fixedp):
         assert Gs2 is Gs                                      # structure-only returns the same object
     torch.cuda.synchronize()
     assert tuple(pat.shape) == (1, d["patches"].shape[0], 3, 1, 1)
-    assert rel(Gs.data[0].cpu().numpy(), d["dual2.f64.poses_out"]) < 2e-5
-    assert rel(pat[0, :, :, 0, 0].cpu().numpy(), d["dual2.f64.patches_out"]) < 2e-5
+    assert rel(Gs.data[0].cpu().numpy(), d["dual2.f64.poses_out"]) < tol(1e-6, 2e-5)
+    assert rel(pat[0, :, :, 0, 0].cpu().numpy(), d["dual2.f64.patches_out"]) < tol(1e-6, 2e-5)
     # inputs untouched (functional semantics, ba.py:332-339)
     assert np.array_equal(hp.poses[0].cpu().numpy(), d["poses"].astype(np.float32))
     assert np.array_equal(hp.patches[0, :, :, 0, 0].cpu().numpy(), d["patches"].astype(np.float32))
@@ -157,13 +164,16 @@ def test_c3_full_size_vs_reference():
     o = hp.raw_step("weights_pose", 1)
     assert o["status"] == 0
     assert rel(o["dX"].reshape(-1), gold["ps.f64.dX"].reshape(-1)) < DX_TOL
-    assert rel(np.diag(o["S_lower"]), gold["ps.f64.S_diag"]) < 2e-6
-    assert rel(o["y"], gold["ps.f64.y"]) < 2e-6
+    assert rel(np.diag(o["S_lower"]), gold["ps.f64.S_diag"]) < tol(1e-10, 2e-6)
+    assert rel(o["y"], gold["ps.f64.y"]) < tol(1e-10, 2e-6)
+    free, act = np.arange(1, 64), np.unique(d["kk"])
+    assert update_err(o["poses_out"], gold["ps.f64.poses_out"], d["poses"], free) < UPD_POSE_TOL
+    assert update_err(o["patches_out"][:, 2], gold["ps.f64.disp_out"], d["patches"][:, 2], act) < UPD_DISP_TOL
     assert rel(o["poses_out"], gold["ps.f64.poses_out"]) < STATE_TOL
     assert rel(o["patches_out"][:, 2], gold["ps.f64.disp_out"]) < STATE_TOL
     Gs, pat = hp.api_step("weights_pose", 1, False)
     _, pat = hp.api_step("weights", 1, True, poses=Gs, patches=pat)
-    assert rel(pat[0, :, 2, 0, 0].cpu().numpy(), gold["so.f64.disp_out"]) < 2e-5
+    assert rel(pat[0, :, 2, 0, 0].cpu().numpy(), gold["so.f64.disp_out"]) < tol(1e-6, 2e-5)
 
 
 def test_shuffled_edge_order_gives_same_answer():
@@ -176,8 +186,8 @@ def test_shuffled_edge_order_gives_same_answer():
         ds[k] = d[k][p]
     a = HipProblem(d).raw_step("weights_pose", 1)
     b = HipProblem(ds).raw_step("weights_pose", 1)
-    assert rel(b["poses_out"], a["poses_out"]) < 2e-6
-    assert rel(b["patches_out"], a["patches_out"]) < 2e-6
+    assert rel(b["poses_out"], a["poses_out"]) < tol(1e-7, 2e-6)
+    assert rel(b["patches_out"], a["patches_out"]) < tol(1e-7, 2e-6)
 
 
 def test_real_shape_window_graph_vs_oracle():
@@ -191,7 +201,10 @@ def test_real_shape_window_graph_vs_oracle():
                          d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=fixedp, want_system=True)
     o = HipProblem(d).raw_step("weights_pose", fixedp)
     assert o["plan"].n == 15
-    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-6
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-6)
+    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < DX_TOL
+    assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(fixedp, fixedp + 15)) < UPD_POSE_TOL
+    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], np.unique(d["kk"])) < UPD_DISP_TOL
     assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL
     assert rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
 
@@ -213,7 +226,7 @@ def test_convergence_full_ba_c3():
                            d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, structure_only=True)
         po, pa = r["poses_out"], r["patches_out"]
     hip_pose = Gs.data[0].cpu().numpy()
-    assert rel(hip_pose, po) < 5e-5
+    assert rel(hip_pose, po) < tol(2e-6, 5e-5)
     e0 = np.linalg.norm(d["poses"][:, :3] - g.poses_gt[:, :3])
     e1 = np.linalg.norm(hip_pose[:, :3] - g.poses_gt[:, :3])
     assert e1 < 0.5 * e0
@@ -271,7 +284,7 @@ def test_reduced_system_is_reproducible_step_after_step():
         if ref is None:
             ref = sysv
             D = 6 * plan.n
-            assert rel(np.diag(sysv[:D * D].reshape(D, D)), load("c3")["ps.f64.S_diag"]) < 2e-6
+            assert rel(np.diag(sysv[:D * D].reshape(D, D)), load("c3")["ps.f64.S_diag"]) < tol(1e-10, 2e-6)
         else:
             assert rel(sysv, ref) < 1e-9, it
 
@@ -292,12 +305,12 @@ def test_random_covisibility_graphs_vs_oracle(seed, N, M, fixedp, far, groups):
                          d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=fixedp, want_system=True)
     o = HipProblem(d).raw_step("weights_pose", fixedp)
     assert o["status"] == 0
-    # (fp32 per-edge residuals feed the robust weights; with a few hundred edges there is less averaging
-    #  than in the fixtures, so S gets 2e-5 here; the state keeps the north-star tolerance)
-    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
-    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < 1e-3       # (a few hundred edges: the float32 residuals average less)
-    assert rel(o["poses_out"], ref["poses_out"]) < 1e-5
-    assert rel(o["patches_out"], ref["patches_out"]) < 1e-5
+    # (float32 per edge: the residuals feed the robust weights; with a few hundred edges there is less averaging than in
+    #  the fixtures, so S gets 2e-5 and dX 1e-3 there)
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-5)
+    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < tol(DX_TOL, 1e-3)
+    assert rel(o["poses_out"], ref["poses_out"]) < tol(STATE_TOL, 1e-5)
+    assert rel(o["patches_out"], ref["patches_out"]) < tol(STATE_TOL, 1e-5)
 
 
 def test_largest_supported_system_vs_oracle():
@@ -312,7 +325,7 @@ def test_largest_supported_system_vs_oracle():
                          d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, want_system=True)
     o = HipProblem(d).raw_step("weights_pose", 1)
     assert o["plan"].n == 255 and o["status"] == 0
-    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-5)
     # (float32 factor for a system this size, brought back inside the contract by one step of iterative refinement)
     assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < DX_TOL
     assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL
@@ -411,7 +424,7 @@ def test_track_seen_by_many_cameras_vs_oracle():
                          d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, want_system=True)
     o = HipProblem(d).raw_step("weights_pose", 1)
     assert o["plan"].max_tile_cams >= 38 and o["status"] == 0
-    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-5)
     assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL         # a 47-pose dense system: float32 factor + one refinement step
     assert rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
 
@@ -497,7 +510,7 @@ def test_random_graph_sweep():
         o = HipProblem(d).raw_step("weights_pose", fixedp, so=so)
         for name in ("poses_out", "patches_out"):
             err, own = rel(o[name], r64[name]), rel(r32[name], r64[name])
-            assert err < max(1e-5, 3.0 * own), (t, N, M, far, groups, fixedp, so, name, err, own)
+            assert err < tol(STATE_TOL, max(1e-5, 3.0 * own)), (t, N, M, far, groups, fixedp, so, name, err, own)
             worst = max(worst, err)
         assert so or o["status"] == 0
-    assert worst < 1e-4
+    assert worst < tol(STATE_TOL, 1e-4)

@@ -43,19 +43,20 @@ out["c3"] = dict(dX=rel(o["dX"].reshape(-1), gd["ps.f64.dX"].reshape(-1)), poses
 print("RESULT " + json.dumps(out))
 """
 
-# (environment, tolerance on dX, tolerance on the new poses).  The float variants factor in fp32 like
-# the reference itself (its own float32 run is 5e-3 off in dX on these fixtures).
+# (environment, tolerance on dX, tolerance on the new poses).  Float64 per-edge maths and a float64 factor in LDS: dX is
+# inside north_star's 1e-5 (measured 2.6e-8 — it is stored as float32).  The float variants of the solver factor in
+# float32 and refine once; BT_EDGE_PREC=0 is the float32 per-edge path of round 2 (the reference's own precision: its
+# float32 run is 5e-3 off in dX on these fixtures).
 VARIANTS = [
-    ({}, 2e-3, 1e-5),
-    ({"BT_SOLVER_PIPE": "0"}, 2e-3, 1e-5),
-    ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0"}, 2e-3, 1e-5),
-    ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0", "BT_SOLVER_ORDER": "0"}, 2e-3, 1e-5),
-    ({"BT_TILE_MAX_WGS": "16"}, 2e-3, 1e-5),         # persistent k_tile: 16 tiles per workgroup at C3 (graphs > 1024 tiles use it)
-    ({"BT_TILE_MAX_WGS": "3"}, 2e-3, 1e-5),          # ... with uneven tile ranges
-    ({"BT_TILE_WIDE": "1"}, 2e-3, 1e-5),             # 16-wave k_tile (chosen by itself for <= 128 tiles with >= 24 slots)
-    ({"BT_TILE_WIDE": "0"}, 2e-3, 1e-5),
-    ({"BT_SOLVER_MODE": "1"}, 2e-2, 1e-4),
-    ({"BT_SOLVER_MODE": "2"}, 2e-2, 1e-4),
+    ({}, 1e-5, 2e-7),
+    ({"BT_SOLVER_PIPE": "0"}, 1e-5, 2e-7),
+    ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0"}, 1e-5, 2e-7),
+    ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0", "BT_SOLVER_ORDER": "0"}, 1e-5, 2e-7),
+    ({"BT_EDGE_PREC": "0"}, 2e-3, 1e-5),                          # float32 per edge, 8 / 16 waves per tile as the plan picks
+    ({"BT_EDGE_PREC": "0", "BT_TILE_WIDE": "1"}, 2e-3, 1e-5),     # 16-wave float32 k_tile forced
+    ({"BT_EDGE_PREC": "0", "BT_TILE_WIDE": "0"}, 2e-3, 1e-5),
+    ({"BT_SOLVER_MODE": "1"}, 5e-5, 1e-6),
+    ({"BT_SOLVER_MODE": "2"}, 5e-5, 1e-6),
 ]
 
 

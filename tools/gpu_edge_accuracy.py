@@ -13,6 +13,9 @@ from gpu_util import HipProblem, rel, update_err  # noqa: E402
 for M in [int(x) for x in (sys.argv[1:] or ["64", "256"])]:
     for frames, fixedp in ((16, 1), (64, 1), (64, 2)):
         g = graphgen.make_graph(frames, M, 8, seed=3)
+        f = lambda a: np.asarray(a, np.float32).astype(np.float64)      # the oracle sees the float32 inputs the kernels see
+        g.poses, g.patches, g.mono_disp, g.intrinsics, g.targets3, g.weights, g.weights_pose = (
+            f(a) for a in (g.poses, g.patches, g.mono_disp, g.intrinsics, g.targets3, g.weights, g.weights_pose))
         d = dict(poses=g.poses, patches=g.patches, mono=g.mono_disp, intrinsics=g.intrinsics, targets3=g.targets3,
                  weights=g.weights, weights_pose=g.weights_pose, ii=g.ii, jj=g.jj, kk=g.kk, bounds=g.bounds)
         o = HipProblem(d).raw_step("weights_pose", fixedp, False, "huber")
