@@ -122,6 +122,8 @@ def lib():
     L.bt_version.restype = i32
     L.bt_plan_jacobian_kernel.restype = i32
     L.bt_plan_jacobian_kernel.argtypes = [vp]
+    L.bt_plan_edge_precision.restype = i32
+    L.bt_plan_edge_precision.argtypes = [vp]
     L.bt_target_arch.restype = ctypes.c_char_p
     L.bt_plan_create.restype = i32
     L.bt_plan_create.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, ctypes.POINTER(vp)]

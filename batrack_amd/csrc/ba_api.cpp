@@ -313,6 +313,10 @@ int bt_plan_jacobian_kernel(const bt_plan *pl) {
     if (!pl || !pl->dev_base) return -1;
     return edge_applies(pl->dev) ? 2 : stream_applies(pl->dev) ? 1 : 0;
 }
+int bt_plan_edge_precision(const bt_plan *pl) {
+    if (!pl || !pl->dev_base) return -1;
+    return edge_precision(pl->dev) ? 8 : 4;
+}
 const char *bt_target_arch(void) { return "gfx950"; }
 
 int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf,

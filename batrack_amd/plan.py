@@ -98,6 +98,11 @@ class Plan:
         """'k_tile' | 'k_stream' | 'k_edge': what the steps of this plan launch (bt_plan_jacobian_kernel)."""
         return {0: "k_tile", 1: "k_stream", 2: "k_edge"}.get(self._lib.bt_plan_jacobian_kernel(self._h), "host-only")
 
+    @property
+    def edge_precision(self):
+        """8 | 4: bytes of the floating-point type of the per-edge maths of this plan's steps (bt_plan_edge_precision)."""
+        return self._lib.bt_plan_edge_precision(self._h)
+
     def array(self, name):
         """Host copy of a plan array (tests / tooling)."""
         p = ctypes.c_void_p()

@@ -175,6 +175,12 @@ int bt_ba_status(const bt_plan *plan, void *workspace, void *stream, int32_t *st
  * waves per tile, tiles streamed), 2 = k_edge (edge-major, one wave per tile) — chosen from the plan's size and shape
  * (DESIGN.md §4); -1 for a host-only plan.  For tests and tooling. */
 int bt_plan_jacobian_kernel(const bt_plan *plan);
+/* Precision of the per-edge maths (reprojection, Jacobians, robust weights, the products they enter, E) of this plan's
+ * steps: 8 = float64 on the float32 inputs — every plan that takes k_tile and whose tiles' E fits LDS as double (up to
+ * about 30 free cameras per tile: every window of the real pipeline, which has 15) — 4 = float32 like the reference's
+ * own run (k_stream / k_edge, i.e. graphs of >= 2048 tiles; hub tracks seen by more than about 30 free cameras;
+ * BT_EDGE_PREC=0).  Sums across edges, the reduced system and its factorisation are float64 either way. */
+int bt_plan_edge_precision(const bt_plan *plan);
 
 /* Library/ABI version and the gfx target the kernels were compiled for. */
 int bt_version(void);

@@ -200,7 +200,7 @@ def test_real_shape_window_graph_vs_oracle():
     ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"],
                          d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=fixedp, want_system=True)
     o = HipProblem(d).raw_step("weights_pose", fixedp)
-    assert o["plan"].n == 15
+    assert o["plan"].n == 15 and (F32_EDGE or o["plan"].edge_precision == 8)
     assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-6)
     assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < DX_TOL
     assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(fixedp, fixedp + 15)) < UPD_POSE_TOL
@@ -424,9 +424,11 @@ def test_track_seen_by_many_cameras_vs_oracle():
                          d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, want_system=True)
     o = HipProblem(d).raw_step("weights_pose", 1)
     assert o["plan"].max_tile_cams >= 38 and o["status"] == 0
-    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-5)
-    assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL         # a 47-pose dense system: float32 factor + one refinement step
-    assert rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
+    # E of a tile with 38 cameras does not fit LDS as double: this plan's per-edge maths is float32 (bt_plan_edge_precision)
+    assert o["plan"].edge_precision == 4
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
+    assert rel(o["poses_out"], ref["poses_out"]) < 5e-6             # a 47-pose dense system: float32 factor + one refinement step
+    assert rel(o["patches_out"], ref["patches_out"]) < 5e-6
 
 
 def test_nan_in_solution_retries_with_larger_damping():

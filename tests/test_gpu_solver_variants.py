@@ -63,6 +63,8 @@ VARIANTS = [
 @pytest.mark.parametrize("env,tol_dx,tol_pose", VARIANTS, ids=lambda v: "-".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else None)
 def test_solver_variant(env, tol_dx, tol_pose):
     e = dict(os.environ, **env)
+    if e.get("BT_EDGE_PREC") == "0" or e.get("BT_STREAM_MIN_TILES") == "1" or e.get("BT_EDGE_MIN_TILES") == "1":
+        tol_dx, tol_pose = max(tol_dx, 2e-3), max(tol_pose, 1e-5)         # float32 per-edge maths (forced by the environment)
     r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + SCRIPT], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
