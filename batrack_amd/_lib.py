@@ -88,18 +88,36 @@ def build_torch_ops(force=False, verbose=False):
 
 
 _torch_ops = None
+_torch_ops_failed = False
 
 
-def torch_ops():
-    """torch.ops.batrack_hip (loads libbatrack_torch.so once).  No fallback: raises if the library is missing."""
-    global _torch_ops
-    if _torch_ops is None:
+def torch_ops(strict=False):
+    """torch.ops.batrack_hip (loads libbatrack_torch.so once), or None when that library is absent or was built against a
+    different copy of the C library (BT_LIB_PATH set): the callers then take the ctypes route to the same C ABI — still the
+    HIP path, never a CPU fallback.  strict=True raises instead."""
+    global _torch_ops, _torch_ops_failed
+    if _torch_ops is None and not _torch_ops_failed:
         lib()                                           # the C ABI library first: the registration links against it
-        if not os.path.exists(TORCH_LIB_PATH):
-            raise RuntimeError(f"batrack_amd: {TORCH_LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'`")
-        import torch
-        torch.ops.load_library(TORCH_LIB_PATH)
-        _torch_ops = torch.ops.batrack_hip
+        why = None
+        if os.environ.get("BT_LIB_PATH"):
+            why = "BT_LIB_PATH is set (libbatrack_torch.so links the default libbatrack_ba.so: two copies of the C library would be loaded)"
+        elif not os.path.exists(TORCH_LIB_PATH):
+            why = f"{TORCH_LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'`"
+        else:
+            try:
+                import torch
+                torch.ops.load_library(TORCH_LIB_PATH)
+                _torch_ops = torch.ops.batrack_hip
+            except OSError as e:
+                why = f"{TORCH_LIB_PATH} failed to load: {e}"
+        if why is not None:
+            _torch_ops_failed = True
+            if strict:
+                raise RuntimeError("batrack_amd: " + why)
+            import warnings
+            warnings.warn("batrack_amd: torch.ops.batrack_hip unavailable, using the ctypes binding of the same C ABI: " + why)
+    if _torch_ops is None and strict:
+        raise RuntimeError("batrack_amd: torch.ops.batrack_hip is unavailable")
     return _torch_ops
 
 

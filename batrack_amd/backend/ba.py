@@ -75,7 +75,11 @@ def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync):
     """A new plan: first as a shifted copy of one of the most recent plans (the caller's window in steady state repeats its
     edge list with all frame / patch indices moved up, batrack.py:189-212 — ~0.1 ms on the device), else from scratch
     (host analysis, ~1 ms for the 138k-edge window)."""
-    tried = 0
+    if sync:
+        # once, here: the index tensors must be complete before any of the builds below reads them on the plan stream
+        # (Plan.shifted may return before it gets to synchronise, so nothing below relies on it having done so)
+        torch.cuda.current_stream(ii.device).synchronize()
+        sync = False
     if os.environ.get("BT_PLAN_SHIFT", "1") != "0":
         E = ii.numel()
         try:
@@ -87,12 +91,11 @@ def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync):
         # (with a keyframe stride of 2 the match is two updates back: the frame shift that worked last time is tried first)
         cands.sort(key=lambda pl: int(fixedp) - pl.fixedp != _LAST_SHIFT[0])
         for src in cands[:3]:                          # (each comparison is ~40 us; a list that matches none is built the ordinary way)
-            pl = Plan.shifted(src, ii, jj, kk, n_buf, p_tot, fixedp, sync=sync and tried == 0)
-            tried += 1
+            pl = Plan.shifted(src, ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
             if pl is not None:
                 _LAST_SHIFT[0] = int(fixedp) - src.fixedp
                 return pl
-    return Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=sync and tried == 0)      # (the stream was synchronised by the first comparison)
+    return Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
 
 
 def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True):
@@ -178,8 +181,12 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     mono = _f32c(patches_monodisp, "patches_monodisp")
     if mono.numel() == p_tot and not mono.is_contiguous() and p_tot > 1:
         # the caller's prior is a strided view (patches_local[:, :, mid, 2:], batrack.py:866): used in place through mono_stride
+        # (only a genuine stride >= 1: an expanded tensor — stride 0 — or a negative stride is materialised instead)
         d = [i for i, n in enumerate(mono.shape) if n == p_tot]
-        mono = torch.as_strided(mono, (p_tot,), (mono.stride(d[0]),), mono.storage_offset()) if len(d) == 1 else mono.reshape(-1).contiguous()
+        if len(d) == 1 and mono.stride(d[0]) >= 1:
+            mono = torch.as_strided(mono, (p_tot,), (mono.stride(d[0]),), mono.storage_offset())
+        else:
+            mono = mono.reshape(-1).contiguous()
     else:
         mono = mono.reshape(-1)
     intr = _f32c(intrinsics, "intrinsics").reshape(-1, 4).contiguous()

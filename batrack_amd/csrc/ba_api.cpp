@@ -295,6 +295,7 @@ static int check(const bt_plan *pl, const bt_ba_args *a, const void *ws) {
     if (!a->poses || !a->patches || !a->mono_disp || !a->intrinsics || !a->patches_out) return BT_EINVAL;
     if (pl->info.E > 0 && (!a->targets || !a->weights || a->target_stride < 2)) return BT_EINVAL;
     if (a->loss < BT_LOSS_TRIVIAL || a->loss > BT_LOSS_CAUCHY) return BT_EINVAL;
+    if (a->mono_stride < 0) return BT_EINVAL;                 // 0 and 1 both mean contiguous; a prior of one repeated element must be materialised
     if (a->lmbda_per_track && pl->info.E != pl->e_all) return BT_EUNSUPPORTED;      // sharded plan: track numbers are per rank
     return BT_OK;
 }
@@ -328,7 +329,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
     ApiTick tick;
     if (on_device && E > 0) {
         // packed and range-checked on the device (8 of the 24 bytes per edge cross PCIe), into a pinned host buffer
-        if (n_buf >= 65536 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;
+        if (n_buf > 32768 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;      // tile_ij packs two frame numbers into a signed 32-bit word
         PackBuffers &pb = pack_buffers();
         if (!pb.ensure((size_t)E)) return BT_ENOMEM;
         hipStream_t cs = copy_stream();
@@ -364,7 +365,7 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
     if (!src || !ii || !jj || !kk || E <= 0) return BT_EINVAL;
     if (!src->dev_base || !src->pk_off || src->e_all != E || src->info.E != E || src->info.n_buf != n_buf || src->info.p_tot != p_tot)
         return BT_NO_MATCH;
-    if (n_buf >= 65536 || p_tot > (int64_t)0x7fffffff) return BT_NO_MATCH;
+    if (n_buf > 32768 || p_tot > (int64_t)0x7fffffff) return BT_NO_MATCH;
     PackBuffers &pb = pack_buffers();
     if (!pb.ensure((size_t)E)) return BT_ENOMEM;
     if (!pb.d_cmp && (hipMalloc(reinterpret_cast<void **>(&pb.d_cmp), 4 * sizeof(int)) != hipSuccess ||

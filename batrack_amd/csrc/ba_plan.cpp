@@ -57,7 +57,7 @@ static void layout_workspace(bt_plan *pl) {
     pl->info.workspace_bytes = (int64_t)w.total;
 }
 
-// Edges as the planner reads them: one 8-byte word per edge, kk << 32 | ii << 16 | jj (n_buf < 65536, p_tot < 2^31).
+// Edges as the planner reads them: one 8-byte word per edge, kk << 32 | ii << 16 | jj (n_buf <= 32768, p_tot < 2^31).
 // For index tensors on the device the words are packed (and range-checked) by a kernel and copied back in one piece —
 // a third of the bytes of the three int64 arrays (ba_api.cpp); host arrays are packed here.
 int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot, uint64_t *out) {
@@ -74,7 +74,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                     int64_t own_lo, int64_t own_hi, bt_plan *pl, const uint64_t *packed) {
     if (E < 0 || n_buf <= 0 || p_tot <= 0 || fixedp < 0 || n_all_min < 0 || n_all_min > n_buf) return BT_EINVAL;
     if (E > (int64_t)0x7fffffff / 2 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;
-    if (n_buf >= 65536) return BT_EUNSUPPORTED;
+    if (n_buf > 32768) return BT_EUNSUPPORTED;             // frame numbers are packed in pairs into signed 32-bit words (tile_ij)
     bt_plan_info &I = pl->info;
     I = bt_plan_info{};
     I.n_buf = n_buf; I.p_tot = p_tot; I.fixedp = fixedp;

@@ -201,7 +201,7 @@ class Stepper:
         """One BA_rgbd_droid call (or one of its multi-GPU phases) on PyTorch's current stream, through
         torch.ops.batrack_hip.ba_step — the operator registered over the C ABI (csrc/torch_ops.cpp).  `stream` (a raw
         hipStream_t) selects the ctypes route instead (tools that launch on a stream of their own)."""
-        if stream is not None or _USE_CTYPES:
+        if stream is not None or self._ops is None:
             a = self._fill(poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
                            bounds, lmbda, ep, alpha, loss, structure_only)
             a.lmbda_per_track = lmbda_per_track.data_ptr() if lmbda_per_track is not None else None

@@ -128,6 +128,23 @@ def test_strided_depth_prior_is_used_in_place():
     assert rel(c[1].cpu().numpy(), a[1].cpu().numpy()) > 1e-4
 
 
+def test_expanded_depth_prior_is_materialised():
+    """A prior that is one element expanded over all patches (stride 0) holds p_tot values in one float of storage: it must
+    not be walked with a stride (round-2 advisor finding) — same result as the contiguous tensor of that value."""
+    d = load("c1_rough")
+    hp = HipProblem(d)
+    P = hp.mono.shape[1]
+    keep = hp.mono
+    hp.mono = torch.full((1, P, 1), 0.37, device=keep.device)
+    a = hp.api_step("weights_pose", 2, False)
+    hp.mono = torch.full((1, 1, 1), 0.37, device=keep.device).expand(1, P, 1)
+    assert hp.mono.stride(1) == 0
+    b = hp.api_step("weights_pose", 2, False)
+    hp.mono = keep
+    torch.cuda.synchronize()
+    assert rel(b[0].data.cpu().numpy(), a[0].data.cpu().numpy()) < 1e-6 and rel(b[1].cpu().numpy(), a[1].cpu().numpy()) < 1e-6
+
+
 def test_per_track_lmbda_tensor():
     """ba.py:299-300: `lmbda` may be a tensor shaped like C — one damping value per distinct track, ascending patch order."""
     from oracle import refseq

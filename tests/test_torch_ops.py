@@ -7,7 +7,7 @@ from batrack_amd import _lib
 
 
 def test_operators_are_registered_with_their_schemas():
-    ops = _lib.torch_ops()
+    ops = _lib.torch_ops(strict=True)
     for name in ("plan_create", "plan_destroy", "plan_info", "ba_step"):
         assert hasattr(ops, name)
     s = str(torch.ops.batrack_hip.ba_step.default._schema)
@@ -17,7 +17,7 @@ def test_operators_are_registered_with_their_schemas():
 
 
 def test_argument_checks_raise():
-    ops = _lib.torch_ops()
+    ops = _lib.torch_ops(strict=True)
     i32 = torch.zeros(4, dtype=torch.int32)
     with pytest.raises(RuntimeError, match="int64"):
         ops.plan_create(i32, i32, i32, 2, 8, 1, 0, 0)
