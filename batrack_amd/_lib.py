@@ -48,6 +48,10 @@ class GaArgs(ctypes.Structure):                       # == bt_ga_args in include
                 [("pw_break", ctypes.c_float), ("half_disp", ctypes.c_int32)])
 
 
+class GaWeights(ctypes.Structure):                    # == bt_ga_weights
+    _fields_ = [(n, ctypes.c_float) for n in ("spatial", "rigid", "pts3d", "cam_smooth", "scale_smooth")] + [("smooth_mode", ctypes.c_int32)]
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
@@ -184,6 +188,8 @@ def lib():
     L.bt_ga_forward.argtypes = [vp, vp, vp, i32, vp]
     L.bt_ga_backward.restype = i32
     L.bt_ga_backward.argtypes = [vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
+    L.bt_ga_backward_total.restype = i32
+    L.bt_ga_backward_total.argtypes = [vp, vp, ctypes.POINTER(GaWeights), vp, vp, vp, vp, vp, vp]
     L.bt_patchify.restype = i32
     L.bt_patchify.argtypes = [vp, i64, i64, i64, i64, vp, i64, i32, i32, vp, vp]
     _lib = L

@@ -234,8 +234,9 @@ __global__ __launch_bounds__(256) void k_ga_bwd_spatial(bt_ga_args a, const floa
     for (int n = threadIdx.x; n < N; n += blockDim.x) g_ts[((size_t)t * N + n) * S + s] -= gmean;
 }
 
-__global__ __launch_bounds__(kGaStrip) void k_ga_bwd_pairwise(bt_ga_args a, const float *mono_scaled, float w_rg, float *g_ms) {
+__global__ __launch_bounds__(kGaStrip) void k_ga_bwd_pairwise(bt_ga_args a, const float *mono_scaled, float w_rg, float *g_ms, float *g_intr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[16];
     const int T = (int)a.T, N = (int)a.N, S = (int)a.S, mid = S / 2;
     const int qi = blockIdx.x / S, s = blockIdx.x % S, n0 = blockIdx.y * kGaStrip;
     const int i = (int)a.query[qi];
@@ -259,12 +260,13 @@ __global__ __launch_bounds__(kGaStrip) void k_ga_bwd_pairwise(bt_ga_args a, cons
     }
     __syncthreads();
     const int n = n0 + threadIdx.x;
-    if (n >= N) return;
-    const float4 ps = Ps[n], pm = Pm[n];
-    const float2 vn = Vs[n];
+    if (n >= N && !g_intr) return;
+    const int nn = n < N ? n : N - 1;                        // (threads past N stay for the workgroup sums of the intrinsics' gradient)
+    const float4 ps = Ps[nn], pm = Pm[nn];
+    const float2 vn = Vs[nn];
     float gs0 = 0.0f, gs1 = 0.0f, gs2 = 0.0f, gm0 = 0.0f, gm1 = 0.0f, gm2 = 0.0f;
 #pragma unroll 4
-    for (int m = 0; m < N; ++m) {
+    for (int m = 0; m < (n < N ? N : 0); ++m) {
         const float4 qs = Ps[m], qm = Pm[m];
         const float2 vm = Vs[m];
         const float dxs = ps.x - qs.x, dys = ps.y - qs.y, dzs = ps.z - qs.z;
@@ -280,16 +282,31 @@ __global__ __launch_bounds__(kGaStrip) void k_ga_bwd_pairwise(bt_ga_args a, cons
     }
     // each pair sits twice in the mean over [S, N, N]; a point is its ray times the depth, depth = 1 / max(disparity, 1e-2)
     const float c = 2.0f * w_rg / (float)((double)a.Q * S * N * N);
-    const size_t es = ((size_t)i * N + n) * S + s, em = ((size_t)i * N + n) * S + mid;
-    if (mono_scaled[es] > 1e-2f) atomicAdd(&g_ms[es], -c * (gs0 * ps.x + gs1 * ps.y + gs2 * ps.z) * ps.z);
-    if (mono_scaled[em] > 1e-2f) atomicAdd(&g_ms[em], -c * (gm0 * pm.x + gm1 * pm.y + gm2 * pm.z) * pm.z);
+    const size_t es = ((size_t)i * N + nn) * S + s, em = ((size_t)i * N + nn) * S + mid;
+    if (n < N) {
+        if (mono_scaled[es] > 1e-2f) atomicAdd(&g_ms[es], -c * (gs0 * ps.x + gs1 * ps.y + gs2 * ps.z) * ps.z);
+        if (mono_scaled[em] > 1e-2f) atomicAdd(&g_ms[em], -c * (gm0 * pm.x + gm1 * pm.y + gm2 * pm.z) * pm.z);
+    }
+    if (g_intr) {
+        // the points' gradients through iproj to the intrinsics of the slot's frame and of the centre slot's frame
+        // (refine_intrinsics: RefineNet.intrinsics is K * K_scale for every frame, refine_net.py:131-136): dX/dfx = -X / fx,
+        // dX/dcx = -D / fx, dY/dfy = -Y / fy, dY/dcy = -D / fy
+        const float v[8] = { -c * gs0 * ps.x / Ks[0], -c * gs1 * ps.y / Ks[1], -c * gs0 * ps.z / Ks[0], -c * gs1 * ps.z / Ks[1],
+                             -c * gm0 * pm.x / Km[0], -c * gm1 * pm.y / Km[1], -c * gm0 * pm.z / Km[0], -c * gm1 * pm.z / Km[1] };
+        const size_t js = (size_t)jraw, jmc = (size_t)(jm < 0 ? 0 : (jm > T - 1 ? T - 1 : jm));
+        for (int k = 0; k < 8; ++k) {
+            const float tsum = block_sum(n < N ? v[k] : 0.0f, red);
+            if (threadIdx.x == 0) atomicAdd(&g_intr[4 * (k < 4 ? js : jmc) + (k & 3)], tsum);
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void k_ga_bwd_grid(bt_ga_args a, const float *g_ms, float *g_fs) {
+__global__ __launch_bounds__(256) void k_ga_bwd_grid(bt_ga_args a, const float *g_ms, float *g_fs, int all_frames) {
     extern __shared__ __attribute__((aligned(16))) float cells[];
     const int S = (int)a.S, N = (int)a.N, T = (int)a.T, gh = (int)a.gh, gw = (int)a.gw;
+    // all_frames: one workgroup per (t, s) of every frame (pts_3d_loss reaches them all), else per (query frame, s)
     const int qi = blockIdx.x / S, s = blockIdx.x % S;
-    const int t = (int)a.query[qi];
+    const int t = all_frames ? qi : (int)a.query[qi];
     const long long jraw = a.jj[(size_t)t * S + s];
     const int jc = (int)(jraw < 0 ? 0 : (jraw > T - 1 ? T - 1 : jraw));
     const float *grid = a.frame_scales + (size_t)jc * gh * gw;
@@ -321,33 +338,192 @@ __global__ __launch_bounds__(256) void k_ga_bwd_grid(bt_ga_args a, const float *
     }
 }
 
+
+// ------------------------------------------------------------------ the terms loss_weight_dict adds (refine_net.py:274-297)
+// cam_smooth_vec_loss (:356-360): mean_t |t_t - t_{t+1}| + 0.3 mean_t |q_t - q_{t+1}| over the RAW pose components;
+// scale_grid_smoothness_loss (:362-392): mean over horizontal neighbours of f(s_a - s_b) + the same over vertical ones,
+// s = exp(grid / 10), f = | | (l1), square (l2) or smooth-L1 (huber).  One workgroup: T is a few hundred, the grid 4..10 wide.
+__device__ __forceinline__ float ga_smooth_f(float d, int mode) {
+    const float ad = fabsf(d);
+    if (mode == BT_GA_SMOOTH_L2) return d * d;
+    if (mode == BT_GA_SMOOTH_HUBER) return ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
+    return ad;
+}
+__device__ __forceinline__ float ga_smooth_df(float d, int mode) {
+    if (mode == BT_GA_SMOOTH_L2) return 2.0f * d;
+    if (mode == BT_GA_SMOOTH_HUBER) return fminf(fmaxf(d, -1.0f), 1.0f);
+    return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+}
+
+// G = false: losses[3] (camera smoothness), losses[4] (scale-grid smoothness).  G = true: their gradients, weighted, ADDED to
+// g_pose [T,7] and g_fs [T,gh,gw] (plain adds: one workgroup, every element has one writer per phase).
+template <bool G>
+__global__ __launch_bounds__(256) void k_ga_smooth(bt_ga_args a, int mode, double *losses, float w_cam, float w_ss, float *g_pose, float *g_fs) {
+    __shared__ float red[16];
+    const int T = (int)a.T, gh = (int)a.gh, gw = (int)a.gw;
+    // ---- camera smoothness
+    if (!G || w_cam != 0.0f) {
+        float lt = 0.0f, lr = 0.0f;
+        for (int t = threadIdx.x; t + 1 < T; t += blockDim.x) {
+            const float *p = a.pose + 7 * (size_t)t, *q = p + 7;
+            float dt[3], dr[4], nt = 0.0f, nr = 0.0f;
+            for (int c = 0; c < 3; ++c) { dt[c] = p[c] - q[c]; nt += dt[c] * dt[c]; }
+            for (int c = 0; c < 4; ++c) { dr[c] = p[3 + c] - q[3 + c]; nr += dr[c] * dr[c]; }
+            nt = sqrtf(nt); nr = sqrtf(nr);
+            lt += nt; lr += nr;
+            if (G) {                                             // d |v| / d v = v / |v| (0 at 0, as torch.norm)
+                const float ct = nt > 0.0f ? w_cam / ((float)(T - 1) * nt) : 0.0f, cr = nr > 0.0f ? 0.3f * w_cam / ((float)(T - 1) * nr) : 0.0f;
+                for (int c = 0; c < 3; ++c) { atomicAdd(&g_pose[7 * (size_t)t + c], ct * dt[c]); atomicAdd(&g_pose[7 * (size_t)(t + 1) + c], -ct * dt[c]); }
+                for (int c = 0; c < 4; ++c) { atomicAdd(&g_pose[7 * (size_t)t + 3 + c], cr * dr[c]); atomicAdd(&g_pose[7 * (size_t)(t + 1) + 3 + c], -cr * dr[c]); }
+            }
+        }
+        if (!G) {
+            const float st = block_sum(lt, red), sr = block_sum(lr, red);
+            if (threadIdx.x == 0 && T > 1) losses[3] = (double)st / (T - 1) + 0.3 * (double)sr / (T - 1);
+        }
+    }
+    // ---- scale-grid smoothness
+    if (!G || w_ss != 0.0f) {
+        const int nh = T * gh * (gw - 1), nv = T * (gh - 1) * gw;
+        float lh = 0.0f, lv = 0.0f;
+        for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+            const int x = k % (gw - 1), y = (k / (gw - 1)) % gh, t = k / ((gw - 1) * gh);
+            const size_t i0 = ((size_t)t * gh + y) * gw + x, i1 = i0 + 1;
+            const float s0 = expf(a.frame_scales[i0] / 10.0f), s1 = expf(a.frame_scales[i1] / 10.0f), d = s0 - s1;
+            lh += ga_smooth_f(d, mode);
+            if (G) { const float g = w_ss * ga_smooth_df(d, mode) / (float)nh; atomicAdd(&g_fs[i0], g * s0 / 10.0f); atomicAdd(&g_fs[i1], -g * s1 / 10.0f); }
+        }
+        for (int k = threadIdx.x; k < nv; k += blockDim.x) {
+            const int x = k % gw, y = (k / gw) % (gh - 1), t = k / (gw * (gh - 1));
+            const size_t i0 = ((size_t)t * gh + y) * gw + x, i1 = i0 + gw;
+            const float s0 = expf(a.frame_scales[i0] / 10.0f), s1 = expf(a.frame_scales[i1] / 10.0f), d = s0 - s1;
+            lv += ga_smooth_f(d, mode);
+            if (G) { const float g = w_ss * ga_smooth_df(d, mode) / (float)nv; atomicAdd(&g_fs[i0], g * s0 / 10.0f); atomicAdd(&g_fs[i1], -g * s1 / 10.0f); }
+        }
+        if (!G) {
+            const float sh = block_sum(lh, red), sv = block_sum(lv, red);
+            if (threadIdx.x == 0) losses[4] = (nh > 0 ? (double)sh / nh : 0.0) + (nv > 0 ? (double)sv / nv : 0.0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward of pts_3d_loss (refine_net.py:314-354)
+// One workgroup per (frame t, slot s), threads over the tracks n: the frame pair (t, j), its poses and intrinsics are
+// workgroup-uniform, so their gradients are summed in the workgroup and leave as one atomic each.
+//   q = R_j^T (R_t p_src + t_t - t_j),  loss += w |q - p_trg| / (T N S)
+// Gradients: d/d mono_scaled of the source (centre-slot) and of the target disparity (into g_ms, then through k_ga_bwd_grid
+// to frame_scales_), d/d intrinsics of frames t and j (g_intr [T,4]), and d/d pose in the convention of pypose's own
+// backward (pypose/lietensor/operation.py: SE3_Act / SE3_Mul / SE3_Inv return the gradient of the LEFT perturbation
+// Exp(delta) X, order (tau, phi), padded with a zero to the 7 stored numbers): with Z = T_j^-1 T_t and g the gradient at q,
+//   g_Z = (g, q x g),   g_{T_t} = g_Z Ad(T_j^-1) = -g_{T_j}.
+__global__ __launch_bounds__(256) void k_ga_bwd_pts3d(bt_ga_args a, const float *mono_scaled, float w, float *g_ms, float *g_pose, float *g_intr) {
+    __shared__ float red[16];
+    const int T = (int)a.T, N = (int)a.N, S = (int)a.S, mid = S / 2;
+    const int t = blockIdx.x / S, s = blockIdx.x % S;
+    const long long jraw = a.jj[(size_t)t * S + s];
+    if (jraw < 0 || jraw >= T) return;                              // patch_mask
+    const int jc = (int)jraw;
+    const bool half = a.half_disp != 0;
+    const float *Kt = a.intrinsics + 4 * (size_t)t, *Kj = a.intrinsics + 4 * (size_t)jc;
+    const float *pt = a.pose + 7 * (size_t)t, *pj = a.pose + 7 * (size_t)jc;
+    const float qji[4] = {-pj[3], -pj[4], -pj[5], pj[6]};
+    const float c = w / (float)((double)T * N * S);
+    float gz[6] = {0, 0, 0, 0, 0, 0}, gkt[4] = {0, 0, 0, 0}, gkj[4] = {0, 0, 0, 0};
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const size_t e = ((size_t)t * N + n) * S + s, em = ((size_t)t * N + n) * S + mid;
+        const bool m = a.trajs_vis[e] > 0.9f && ga_disp(a.trajs_disp, e, half) > 1e-2f && a.trajs_static[e] > 0.3f;
+        if (!m) continue;
+        float src[3], trg[3], tmp[3], rel_t[3], q[3];
+        const float xs = a.trajs_2d[2 * em], ys = a.trajs_2d[2 * em + 1], xt = a.trajs_2d[2 * e], yt = a.trajs_2d[2 * e + 1];
+        const float ds = mono_scaled[em], dt = mono_scaled[e];
+        ga_iproj(xs, ys, ds, Kt, src);
+        ga_iproj(xt, yt, dt, Kj, trg);
+        ga_qrot(pt + 3, src, tmp);
+        for (int k = 0; k < 3; ++k) rel_t[k] = tmp[k] + pt[k] - pj[k];
+        ga_qrot(qji, rel_t, q);
+        const float dx = q[0] - trg[0], dy = q[1] - trg[1], dz = q[2] - trg[2];
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (!(nrm > 0.0f)) continue;
+        const float g[3] = {c * dx / nrm, c * dy / nrm, c * dz / nrm};               // d loss / d q = - d loss / d p_trg
+        // pose (tangent of Z): (g, q x g)
+        gz[0] += g[0]; gz[1] += g[1]; gz[2] += g[2];
+        gz[3] += q[1] * g[2] - q[2] * g[1]; gz[4] += q[2] * g[0] - q[0] * g[2]; gz[5] += q[0] * g[1] - q[1] * g[0];
+        // source point: d q / d p_src = R_j^T R_t  ->  g_src = R_t^T R_j g
+        float gs[3], t1[3];
+        ga_qrot(pj + 3, g, t1);
+        const float qti[4] = {-pt[3], -pt[4], -pt[5], pt[6]};
+        ga_qrot(qti, t1, gs);
+        // a point is (X, Y, D) = ((x - cx) / fx D, (y - cy) / fy D, D), D = 1 / max(d, 1e-2): d P / d d = -P D for d > 1e-2
+        if (ds > 1e-2f) atomicAdd(&g_ms[em], -(gs[0] * src[0] + gs[1] * src[1] + gs[2] * src[2]) * src[2]);
+        if (dt > 1e-2f) atomicAdd(&g_ms[e], (g[0] * trg[0] + g[1] * trg[1] + g[2] * trg[2]) * trg[2]);
+        // intrinsics: dX/dfx = -X / fx, dX/dcx = -D / fx, dY/dfy = -Y / fy, dY/dcy = -D / fy
+        gkt[0] += -gs[0] * src[0] / Kt[0]; gkt[1] += -gs[1] * src[1] / Kt[1]; gkt[2] += -gs[0] * src[2] / Kt[0]; gkt[3] += -gs[1] * src[2] / Kt[1];
+        gkj[0] += g[0] * trg[0] / Kj[0];   gkj[1] += g[1] * trg[1] / Kj[1];   gkj[2] += g[0] * trg[2] / Kj[0];   gkj[3] += g[1] * trg[2] / Kj[1];
+    }
+    float tot[14];
+    for (int k = 0; k < 6; ++k) tot[k] = block_sum(gz[k], red);
+    for (int k = 0; k < 4; ++k) { tot[6 + k] = block_sum(gkt[k], red); tot[10 + k] = block_sum(gkj[k], red); }
+    if (threadIdx.x == 0) {
+        if (g_intr) for (int k = 0; k < 4; ++k) { atomicAdd(&g_intr[4 * (size_t)t + k], tot[6 + k]); atomicAdd(&g_intr[4 * (size_t)jc + k], tot[10 + k]); }
+        if (g_pose && jc != t) {
+            // g_Z Ad(A), A = T_j^-1 = (R_j^T, -R_j^T t_j):  (g_tau R_A, g_tau [t_A]x R_A + g_phi R_A);  v R_A = R_A^T v = R_j v
+            float tA[3], gt[3], u[3], gp[3];
+            const float ntj[3] = {-pj[0], -pj[1], -pj[2]};
+            ga_qrot(qji, ntj, tA);                                   // t_A = -R_j^T t_j
+            ga_qrot(pj + 3, tot, gt);                                // g_tau R_A
+            // the row vector g_tau [t_A]x is (g_tau x t_A)^T  (v^T [t]x = ([t]x^T v)^T = (-t x v)^T = (v x t)^T)
+            u[0] = tot[1] * tA[2] - tot[2] * tA[1]; u[1] = tot[2] * tA[0] - tot[0] * tA[2]; u[2] = tot[0] * tA[1] - tot[1] * tA[0];
+            for (int k = 0; k < 3; ++k) u[k] += tot[3 + k];          // g_tau [t_A]x + g_phi
+            ga_qrot(pj + 3, u, gp);
+            for (int k = 0; k < 3; ++k) { atomicAdd(&g_pose[7 * (size_t)t + k], gt[k]); atomicAdd(&g_pose[7 * (size_t)jc + k], -gt[k]); }
+            for (int k = 0; k < 3; ++k) { atomicAdd(&g_pose[7 * (size_t)t + 3 + k], gp[k]); atomicAdd(&g_pose[7 * (size_t)jc + 3 + k], -gp[k]); }
+        }
+    }
+}
 }  // namespace bt
 
-extern "C" int bt_ga_backward(const bt_ga_args *a, const float *mono_scaled, float w_spatial, float w_rigid, float *g_mono_scaled,
-                              float *grad_trajs_scales, float *grad_frame_scales, void *stream) {
-    if (!a || !mono_scaled || !g_mono_scaled || !grad_trajs_scales || !grad_frame_scales) return BT_EINVAL;
+extern "C" int bt_ga_backward_total(const bt_ga_args *a, const float *mono_scaled, const bt_ga_weights *w, float *g_mono_scaled,
+                                    float *grad_trajs_scales, float *grad_frame_scales, float *grad_pose, float *grad_intrinsics, void *stream) {
+    if (!a || !w || !mono_scaled || !g_mono_scaled || !grad_trajs_scales || !grad_frame_scales) return BT_EINVAL;
     if (a->T <= 0 || a->N <= 0 || a->S <= 0 || a->gh <= 0 || a->gw <= 0 || a->H <= 1 || a->W <= 1 || a->Q <= 0) return BT_EINVAL;
     if (!a->trajs_2d || !a->trajs_disp || !a->trajs_disp_mono || !a->trajs_vis || !a->trajs_static || !a->jj || !a->intrinsics ||
         !a->query || !a->trajs_scales || !a->frame_scales || !a->frame_shifts) return BT_EINVAL;
+    if ((w->pts3d != 0.0f || w->cam_smooth != 0.0f) && !a->pose) return BT_EINVAL;
+    if (w->smooth_mode < BT_GA_SMOOTH_L1 || w->smooth_mode > BT_GA_SMOOTH_HUBER) return BT_EINVAL;
     if (a->T * a->S > 0x7fffffff || a->T * a->N * a->S > ((int64_t)1 << 40) || a->gh * a->gw > 12 * 1024) return BT_EUNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t tns = (size_t)(a->T * a->N * a->S);
     if (hipMemsetAsync(g_mono_scaled, 0, tns * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(grad_trajs_scales, 0, tns * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(grad_frame_scales, 0, (size_t)(a->T * a->gh * a->gw) * sizeof(float), st) != hipSuccess) return BT_EHIP;
-    const dim3 qs((unsigned)(a->Q * a->S));
-    hipLaunchKernelGGL(bt::k_ga_bwd_spatial, qs, dim3(256), 0, st, *a, mono_scaled, w_spatial, g_mono_scaled, grad_trajs_scales);
-    if (w_rigid != 0.0f) {
+        hipMemsetAsync(grad_frame_scales, 0, (size_t)(a->T * a->gh * a->gw) * sizeof(float), st) != hipSuccess ||
+        (grad_pose && hipMemsetAsync(grad_pose, 0, (size_t)a->T * 7 * sizeof(float), st) != hipSuccess) ||
+        (grad_intrinsics && hipMemsetAsync(grad_intrinsics, 0, (size_t)a->T * 4 * sizeof(float), st) != hipSuccess)) return BT_EHIP;
+    const dim3 qs((unsigned)(a->Q * a->S)), ts((unsigned)(a->T * a->S));
+    hipLaunchKernelGGL(bt::k_ga_bwd_spatial, qs, dim3(256), 0, st, *a, mono_scaled, w->spatial, g_mono_scaled, grad_trajs_scales);
+    if (w->rigid != 0.0f) {
         const size_t lds = (size_t)a->N * (2 * sizeof(float4) + sizeof(float2));
         if (lds > 64 * 1024) return BT_EUNSUPPORTED;
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void *>(&bt::k_ga_bwd_pairwise), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
             return BT_EHIP;
         hipLaunchKernelGGL(bt::k_ga_bwd_pairwise, dim3((unsigned)(a->Q * a->S), (unsigned)((a->N + bt::kGaStrip - 1) / bt::kGaStrip)), dim3(bt::kGaStrip),
-                           lds, st, *a, mono_scaled, w_rigid, g_mono_scaled);
+                           lds, st, *a, mono_scaled, w->rigid, g_mono_scaled, grad_intrinsics);
     }
-    hipLaunchKernelGGL(bt::k_ga_bwd_grid, qs, dim3(256), (size_t)(a->gh * a->gw) * sizeof(float), st, *a, g_mono_scaled, grad_frame_scales);
+    if (w->pts3d != 0.0f)
+        hipLaunchKernelGGL(bt::k_ga_bwd_pts3d, ts, dim3(256), 0, st, *a, mono_scaled, w->pts3d, g_mono_scaled, grad_pose, grad_intrinsics);
+    // d total / d mono_scaled -> frame_scales_: over the query frames, or over every frame when the 3-D point term is in
+    hipLaunchKernelGGL(bt::k_ga_bwd_grid, w->pts3d != 0.0f ? ts : qs, dim3(256), (size_t)(a->gh * a->gw) * sizeof(float), st, *a, g_mono_scaled,
+                       grad_frame_scales, w->pts3d != 0.0f ? 1 : 0);
+    if ((w->cam_smooth != 0.0f && grad_pose) || w->scale_smooth != 0.0f)
+        hipLaunchKernelGGL(bt::k_ga_smooth<true>, dim3(1), dim3(256), 0, st, *a, w->smooth_mode, (double *)nullptr, grad_pose ? w->cam_smooth : 0.0f,
+                           w->scale_smooth, grad_pose, grad_frame_scales);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+extern "C" int bt_ga_backward(const bt_ga_args *a, const float *mono_scaled, float w_spatial, float w_rigid, float *g_mono_scaled,
+                              float *grad_trajs_scales, float *grad_frame_scales, void *stream) {
+    const bt_ga_weights w = {w_spatial, w_rigid, 0.0f, 0.0f, 0.0f, BT_GA_SMOOTH_L1};
+    return bt_ga_backward_total(a, mono_scaled, &w, g_mono_scaled, grad_trajs_scales, grad_frame_scales, nullptr, nullptr, stream);
 }
 
 extern "C" int bt_ga_forward(const bt_ga_args *a, float *mono_scaled_out, double *losses, int32_t which, void *stream) {
@@ -357,7 +533,7 @@ extern "C" int bt_ga_forward(const bt_ga_args *a, float *mono_scaled_out, double
         !a->pose || !a->query || !a->trajs_scales || !a->frame_scales || !a->frame_shifts) return BT_EINVAL;
     if (a->T * a->S > 0x7fffffff || a->T * a->N * a->S > ((int64_t)1 << 40)) return BT_EUNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(losses, 0, 3 * sizeof(double), st) != hipSuccess) return BT_EHIP;
+    if (hipMemsetAsync(losses, 0, 5 * sizeof(double), st) != hipSuccess) return BT_EHIP;
     hipLaunchKernelGGL(bt::k_ga_scale, dim3((unsigned)(a->T * a->S)), dim3(256), 0, st, *a, mono_scaled_out, losses);
     if (which & 2) {
         const size_t lds = (size_t)a->N * (2 * sizeof(float4) + sizeof(float2));
@@ -371,6 +547,11 @@ extern "C" int bt_ga_forward(const bt_ga_args *a, float *mono_scaled_out, double
     if (which & 4) {
         const size_t total = (size_t)(a->T * a->N * a->S);
         hipLaunchKernelGGL(bt::k_ga_pts3d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *a, mono_scaled_out, losses);
+    }
+    if (which & 8) {
+        const int mode = (which >> 8) & 3;
+        if (mode > BT_GA_SMOOTH_HUBER) return BT_EINVAL;
+        hipLaunchKernelGGL(bt::k_ga_smooth<false>, dim3(1), dim3(256), 0, st, *a, mode, losses, 0.0f, 0.0f, (float *)nullptr, (float *)nullptr);
     }
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }

@@ -2,18 +2,24 @@
 
 `RefineLosses` holds what `RefineNet` (/root/reference/main/global_refine/model/refine_net.py) holds after its
 `_init_from_ba` — same attribute names (`trajs_2d`, `trajs_disp`, `trajs_disp_mono`, `trajs_vis`, `trajs_static`, `jj`,
-`intrinsics`, `grid_query_frames`, parameters `trajs_scales`, `frame_scales_`, `frame_shifts_`, `pose`) — and evaluates
-  get_frame_scaled_depth()   refine_net.py:148-174
-  spatial_loss()             the huber depth term of forward(), refine_net.py:252-268
-  inter_frame_loss()         refine_net.py:199-225 (the O(Q S N^2) rigidity term)
-  pts_3d_loss()              refine_net.py:300-345
-  forward(alpha)             total of refine_net.py:291-293 (loss_weight_dict = None, no scale-grid smoothness)
-  backward(alpha) / loss(alpha)   gradients of forward(alpha) w.r.t. `trajs_scales` and `frame_scales_` (what the reference
-                             gets from autograd and steps with Adam, trainer.py:23-77): explicit, or as a torch.autograd
-                             node so that `net.loss(alpha).backward()` fills `.grad` of the two parameters
-through include/batrack_ga.h.  pts_3d_loss (poses, intrinsics) is forward only.
-`half_disp=True` keeps the two disparity arrays in float16 and forms the depth residual in float16 (BASELINE.json
-configs[4]).  GPU tensors only; there is no CPU fallback.
+`intrinsics`, `grid_query_frames`, parameters `trajs_scales`, `frame_scales_`, `frame_shifts_`, `pose`, `K`; settings
+`loss_weight_dict`, `alpha`, `scale_smoothness_weight`, `refine_intrinsics`, `K_scale`) — and evaluates
+  get_frame_scaled_depth()          refine_net.py:148-174
+  spatial_loss()                    the huber depth term of forward(), refine_net.py:252-268
+  inter_frame_loss()                refine_net.py:199-225 (the O(Q S N^2) rigidity term)
+  pts_3d_loss()                     refine_net.py:314-354
+  cam_smooth_vec_loss()             refine_net.py:356-360
+  scale_grid_smoothness_loss(mode)  refine_net.py:362-392 ('l1' | 'l2' | 'huber')
+  forward()                         the total the reference optimises: the `loss_weight_dict` branch (refine_net.py:274-297;
+                                    run_global_refine.py:61-67 always passes one) or, with `loss_weight_dict = None`,
+                                    spatial + alpha * rigid + scale_smoothness_weight * smoothness('l1') (:299-301)
+  backward()                        its gradients w.r.t. every parameter the reference's Adam loop steps (trainer.py:33-43):
+                                    `trajs_scales`, `frame_scales_`, `pose` (pypose's left-perturbation convention, see
+                                    include/batrack_ga.h) and `K`
+  loss()                            forward() as a torch.autograd node, so that the reference's loop body
+                                    `loss = net.loss(); loss.backward(); optimizer.step()` fills `.grad` of the parameters
+through include/batrack_ga.h.  `half_disp=True` keeps the two disparity arrays in float16 and forms the depth residual in
+float16 (BASELINE.json configs[4]).  GPU tensors only; there is no CPU fallback.
 """
 import ctypes
 
@@ -21,10 +27,14 @@ import torch
 
 from . import _lib
 
+_SMOOTH = {"l1": 0, "l2": 1, "huber": 2}
+
 
 class RefineLosses:
     def __init__(self, trajs_2d, trajs_disp, trajs_disp_mono, trajs_vis, trajs_static, jj, intrinsics, grid_query_frames,
-                 trajs_scales, frame_scales_, frame_shifts_, pose, H, W, pw_break=20.0, half_disp=False):
+                 trajs_scales, frame_scales_, frame_shifts_, pose, H, W, pw_break=20.0, half_disp=False,
+                 loss_weight_dict=None, alpha=0.5, scale_smoothness_weight=0.1, scale_smoothness_mode="l2",
+                 refine_intrinsics=False, K=None, K_scale=20.0):
         dev = trajs_2d.device
         if dev.type != "cuda":
             raise RuntimeError("RefineLosses: tensors must be on the GPU (no CPU fallback in batrack_amd)")
@@ -37,24 +47,42 @@ class RefineLosses:
         self.trajs_disp_mono = trajs_disp_mono.to(device=dev, dtype=dd).contiguous()
         self.trajs_vis, self.trajs_static = f(trajs_vis), f(trajs_static)
         self.jj = jj.to(device=dev, dtype=torch.int64).contiguous()
-        self.intrinsics = f(intrinsics)
+        self.intrinsics_raw = f(intrinsics)
         self.grid_query_frames = grid_query_frames.to(device=dev, dtype=torch.int64).contiguous()
+        q = self.grid_query_frames
+        if q.numel() == 0 or q.unique().numel() != q.numel() or int(q.min()) < 0 or int(q.max()) >= self.T:
+            # (the kernels count a query frame once; `loss[grid_query_frames].mean()` would count a repeated one twice)
+            raise ValueError("grid_query_frames must be distinct frame numbers in [0, T)")
         self.trajs_scales, self.frame_scales_, self.frame_shifts_, self.pose = f(trajs_scales), f(frame_scales_), f(frame_shifts_), f(pose)
         self.H, self.W, self.pw_break = int(H), int(W), float(pw_break)
         if tuple(self.trajs_2d.shape) != (self.T, self.N, self.S_local, 2) or tuple(self.jj.shape) != (self.T, self.S_local):
             raise ValueError("trajs_2d must be [T,N,S,2] and jj [T,S]")
+        # what RefineNet.__init__ takes (refine_net.py:16-48)
+        self.loss_weight_dict = None if loss_weight_dict is None else dict(loss_weight_dict)
+        self.alpha, self.scale_smoothness_weight, self.scale_smoothness_mode = float(alpha), float(scale_smoothness_weight), scale_smoothness_mode
+        self.refine_intrinsics, self.K_scale = bool(refine_intrinsics), float(K_scale)
+        self.K = f(K) if K is not None else (torch.median(self.intrinsics_raw, dim=0)[0] / self.K_scale).clone()   # K_init, refine_net.py:77
         self._lib = _lib.lib()
+        self._intr = torch.empty(self.T, 4, device=dev, dtype=torch.float32)
         self._mono_scaled = torch.empty(self.T, self.N, self.S_local, device=dev, dtype=torch.float32)
-        self._losses = torch.zeros(3, device=dev, dtype=torch.float64)
+        self._losses = torch.zeros(5, device=dev, dtype=torch.float64)
         self._g_ms = None
+
+    @property
+    def intrinsics(self):
+        """refine_net.py:131-136: K * K_scale for every frame when the intrinsics are refined, else the per-frame input."""
+        if self.refine_intrinsics:
+            return (self.K.detach() * self.K_scale).expand(self.T, 4)
+        return self.intrinsics_raw
 
     def _args(self):
         a = _lib.GaArgs()
         a.T, a.N, a.S = self.T, self.N, self.S_local
         a.gh, a.gw = self.frame_scales_.shape[1:]
         a.H, a.W, a.Q = self.H, self.W, self.grid_query_frames.numel()
+        self._intr.copy_(self.intrinsics)
         for n, t in (("trajs_2d", self.trajs_2d), ("trajs_disp", self.trajs_disp), ("trajs_disp_mono", self.trajs_disp_mono),
-                     ("trajs_vis", self.trajs_vis), ("trajs_static", self.trajs_static), ("jj", self.jj), ("intrinsics", self.intrinsics),
+                     ("trajs_vis", self.trajs_vis), ("trajs_static", self.trajs_static), ("jj", self.jj), ("intrinsics", self._intr),
                      ("pose", self.pose), ("query", self.grid_query_frames), ("trajs_scales", self.trajs_scales),
                      ("frame_scales", self.frame_scales_), ("frame_shifts", self.frame_shifts_)):
             if not (t.is_cuda and t.is_contiguous()):
@@ -63,23 +91,64 @@ class RefineLosses:
         a.pw_break, a.half_disp = self.pw_break, 1 if self.half_disp else 0
         return a
 
-    def backward(self, alpha=0.5):
-        """(d forward(alpha) / d trajs_scales [T,N,S], d forward(alpha) / d frame_scales_ [T,gh,gw]) as new float32 tensors."""
+    # ------------------------------------------------------------------ the total and its weights
+    def weights(self, alpha=None):
+        """(spatial, rigid, pts3d, cam_smooth, scale_smooth) of forward()'s total and the mode of the smoothness term — 'l1'
+        in both branches of forward(), whatever `scale_smoothness_mode` says (refine_net.py:289,299)."""
+        if self.loss_weight_dict is not None:
+            d = self.loss_weight_dict
+            w = [d.get("spatial_loss", 0.0), d.get("inter_frame_loss", 0.0), d.get("pts_3d_loss", 0.0),
+                 d.get("cam_smooth_vec_loss", 0.0), d.get("scale_smoothness_loss", 0.0)]
+            if self.alpha <= 0:                       # (loss_rigid is the constant 0.0 then, refine_net.py:270-273)
+                w[1] = 0.0
+        else:
+            al = self.alpha if alpha is None else float(alpha)
+            w = [1.0, al if al > 0 else 0.0, 0.0, 0.0, self.scale_smoothness_weight if self.scale_smoothness_weight > 0 else 0.0]
+        return [float(x) for x in w], "l1"
+
+    def _which(self, w, mode):
+        return 1 | (2 if w[1] else 0) | (4 if w[2] else 0) | ((8 | (_SMOOTH[mode] << 8)) if (w[3] or w[4]) else 0)
+
+    def forward(self, alpha=None):
+        """RefineNet.forward(): the weighted total as a float64 scalar tensor.  `alpha` overrides `self.alpha` in the
+        `loss_weight_dict = None` branch (kept from round 2's interface)."""
+        w, mode = self.weights(alpha)
+        l = self._run(self._which(w, mode))
+        return sum(wi * l[i] for i, wi in enumerate(w) if wi)
+
+    def backward(self, alpha=None, want=("trajs_scales", "frame_scales_", "pose", "K")):
+        """Gradients of forward() as a dict of new float32 tensors: `trajs_scales` [T,N,S], `frame_scales_` [T,gh,gw],
+        `pose` [T,7] (pypose's convention: left-perturbation gradient in the first six numbers, plus the plain derivative of
+        the camera-smoothness term), `intrinsics` [T,4] per frame and `K` [4] = K_scale * their sum (refine_net.py:131-136)."""
+        w, mode = self.weights(alpha)
         self._run(1)                                                      # mono_scaled for the current parameters
         if self._g_ms is None:
             self._g_ms = torch.empty_like(self._mono_scaled)
+        dev = self.trajs_2d.device
         g_ts, g_fs = torch.empty_like(self._mono_scaled), torch.empty_like(self.frame_scales_, dtype=torch.float32)
+        need_pose = (w[2] or w[3]) and "pose" in want
+        need_k = (w[1] or w[2]) and ("K" in want or "intrinsics" in want)
+        g_pose = torch.empty(self.T, 7, device=dev, dtype=torch.float32) if need_pose else None
+        g_intr = torch.empty(self.T, 4, device=dev, dtype=torch.float32) if need_k else None
         a = self._args()
-        st = torch.cuda.current_stream(self.trajs_2d.device).cuda_stream
-        _lib.check(self._lib.bt_ga_backward(ctypes.byref(a), self._mono_scaled.data_ptr(), 1.0, float(alpha), self._g_ms.data_ptr(),
-                                            g_ts.data_ptr(), g_fs.data_ptr(), st), "bt_ga_backward")
-        return g_ts, g_fs
+        gw = _lib.GaWeights(*w, _SMOOTH[mode])
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self._lib.bt_ga_backward_total(ctypes.byref(a), self._mono_scaled.data_ptr(), ctypes.byref(gw), self._g_ms.data_ptr(),
+                                                  g_ts.data_ptr(), g_fs.data_ptr(), g_pose.data_ptr() if need_pose else None,
+                                                  g_intr.data_ptr() if need_k else None, st), "bt_ga_backward_total")
+        out = {"trajs_scales": g_ts, "frame_scales_": g_fs}
+        out["pose"] = g_pose if need_pose else torch.zeros(self.T, 7, device=dev)
+        out["intrinsics"] = g_intr if need_k else torch.zeros(self.T, 4, device=dev)
+        out["K"] = out["intrinsics"].sum(0) * self.K_scale if self.refine_intrinsics else torch.zeros(4, device=dev)
+        return out
 
-    def loss(self, alpha=0.5):
-        """forward(alpha) as a float32 scalar attached to autograd: `.backward()` fills `.grad` of `self.trajs_scales` and
-        `self.frame_scales_` when they are leaves that require grad (the reference's nn.Parameters)."""
-        return _TotalLoss.apply(self.trajs_scales, self.frame_scales_, self, float(alpha))
+    def loss(self, alpha=None):
+        """forward() as a float32 scalar attached to autograd: `.backward()` fills `.grad` of `self.trajs_scales`,
+        `self.frame_scales_`, `self.pose` and `self.K` where they are leaves that require grad (the reference's
+        nn.Parameters / pp.Parameter, refine_net.py:42-48)."""
+        return _TotalLoss.apply(self.trajs_scales, self.frame_scales_, self.pose, self.K, self, alpha)
 
+    # ------------------------------------------------------------------ the terms
     def _run(self, which):
         a = self._args()
         st = torch.cuda.current_stream(self.trajs_2d.device).cuda_stream
@@ -100,24 +169,30 @@ class RefineLosses:
     def pts_3d_loss(self):
         return self._run(5)[2].clone()
 
-    def losses(self):
-        """(spatial, inter-frame, 3-D points) in one pass, as a float64 tensor of 3."""
-        return self._run(7).clone()
+    def cam_smooth_vec_loss(self):
+        return self._run(9)[3].clone()
 
-    def forward(self, alpha=0.5):
-        l = self._run(3 if alpha > 0 else 1)
-        return l[0] + alpha * l[1] if alpha > 0 else l[0].clone()
+    def scale_grid_smoothness_loss(self, mode="l2"):
+        if mode not in _SMOOTH:
+            raise ValueError(f"Unknown smoothness loss mode: {mode}")        # refine_net.py:387
+        return self._run(9 | (_SMOOTH[mode] << 8))[4].clone()
+
+    def losses(self, smooth_mode="l1"):
+        """(spatial, inter-frame, 3-D points, camera smoothness, scale-grid smoothness) in one pass, as a float64 tensor of 5."""
+        return self._run(15 | (_SMOOTH[smooth_mode] << 8)).clone()
 
 
 class _TotalLoss(torch.autograd.Function):
-    """spatial + alpha * inter-frame as one autograd node over bt_ga_forward / bt_ga_backward."""
+    """forward()'s weighted total as one autograd node over bt_ga_forward / bt_ga_backward_total."""
 
     @staticmethod
-    def forward(ctx, trajs_scales, frame_scales_, net, alpha):
+    def forward(ctx, trajs_scales, frame_scales_, pose, K, net, alpha):
         ctx.net, ctx.alpha = net, alpha
         return net.forward(alpha).to(torch.float32)
 
     @staticmethod
     def backward(ctx, gout):
-        g_ts, g_fs = ctx.net.backward(ctx.alpha)
-        return g_ts * gout, g_fs * gout, None, None
+        g = ctx.net.backward(ctx.alpha)
+        need = ctx.needs_input_grad
+        return (g["trajs_scales"] * gout if need[0] else None, g["frame_scales_"] * gout if need[1] else None,
+                g["pose"] * gout if need[2] else None, g["K"] * gout if need[3] else None, None, None)

@@ -5,7 +5,8 @@
  *   :252-268 (spatial huber term), :199-225 (inter_frame_loss, O(Q S N^2)), :300-345 (pts_3d_loss),
  * driven by the Adam loop of model/trainer.py:23-77.  The reference is a Python/autograd module (pypose for the poses);
  * it has no FFI.  This header is what a binding of those forward computations binds; batrack_amd/global_refine.py does
- * so.  bt_ga_forward gives the values, bt_ga_backward the gradients of the default total (spatial + alpha * rigid).  Device pointers, sizes, integer status
+ * so.  bt_ga_forward gives the values (all five terms of refine_net.py:252-392), bt_ga_backward_total the gradients of their
+ * weighted total with respect to every parameter of the Adam loop.  Device pointers, sizes, integer status
  * codes (include/batrack_ba.h); nothing allocates or synchronises.
  */
 #ifndef BATRACK_GA_H
@@ -38,18 +39,41 @@ typedef struct {
                                       float16 (BASELINE.json configs[4]); everything else stays float32 */
 } bt_ga_args;
 
-/* mono_scaled_out [T,N,S] float32 = get_frame_scaled_depth(); losses[3] (device, float64) = spatial huber term,
- * inter_frame_loss, pts_3d_loss — each the reference's mean.  `which` selects: bit 0 spatial (always computes
- * mono_scaled_out), bit 1 inter-frame, bit 2 3-D points.  Enqueued on `stream`. */
+/* mono_scaled_out [T,N,S] float32 = get_frame_scaled_depth(); losses[5] (device, float64) = spatial huber term,
+ * inter_frame_loss, pts_3d_loss, cam_smooth_vec_loss (refine_net.py:356-360), scale_grid_smoothness_loss (:362-392) — each
+ * the reference's mean.  `which` selects: bit 0 spatial (always computes mono_scaled_out), bit 1 inter-frame, bit 2 3-D
+ * points, bit 3 the two smoothness terms, with the mode of the scale-grid term in bits 8-9 (BT_GA_SMOOTH_*; forward() itself
+ * always passes 'l1', refine_net.py:289,299).  Entries not selected read 0.  Enqueued on `stream`. */
+#define BT_GA_SMOOTH_L1 0
+#define BT_GA_SMOOTH_L2 1
+#define BT_GA_SMOOTH_HUBER 2
 int bt_ga_forward(const bt_ga_args *args, float *mono_scaled_out, double *losses, int32_t which, void *stream);
 
-/* Gradient of  w_spatial * (spatial huber term) + w_rigid * inter_frame_loss  — RefineNet.forward's total with
- * loss_weight_dict = None is that with w_spatial = 1, w_rigid = alpha (refine_net.py:252-293) — with respect to the two
- * parameters it reaches: grad_trajs_scales [T,N,S] (through exp((p - mean_n p) / pw_break), refine_net.py:123-127) and
- * grad_frame_scales [T,gh,gw] (through exp(g / 10) and the bilinear sample, :139-174), what the reference obtains from
- * autograd (trainer.py:23-77).  `mono_scaled` is the [T,N,S] output of bt_ga_forward for the same arguments;
- * `g_mono_scaled` is [T,N,S] float scratch (on return: d total / d mono_scaled).  Query frames must be distinct.  The three
- * outputs are overwritten.  pts_3d_loss (poses, intrinsics) has no backward here.  Enqueued on `stream`. */
+/* Weights of RefineNet.forward's total: with loss_weight_dict (refine_net.py:274-297; run_global_refine.py:61-67 passes
+ * {spatial 5.0, inter_frame 0.3, pts_3d 1.0, cam_smooth_vec 1.0, scale_smoothness 0.3}) the entries of the dict; with
+ * loss_weight_dict = None (:299-301) {1, alpha, 0, 0, scale_smoothness_weight (default 0.1)}. */
+typedef struct {
+    float spatial, rigid, pts3d, cam_smooth, scale_smooth;
+    int32_t smooth_mode;            /* BT_GA_SMOOTH_* of the scale-grid term */
+} bt_ga_weights;
+
+/* Gradient of the weighted total with respect to every parameter the reference's Adam loop steps (trainer.py:33-43):
+ *   grad_trajs_scales [T,N,S]   through exp((p - mean_n p) / pw_break)                  (refine_net.py:123-127)
+ *   grad_frame_scales [T,gh,gw] through exp(g / 10), the bilinear sample (:139-174) and the smoothness term
+ *   grad_pose [T,7]             pts_3d_loss in the convention of pypose's backward — the gradient of the LEFT perturbation
+ *                               Exp(delta) X in the first six numbers (tau, phi), 0 in the seventh — plus the plain
+ *                               derivative of cam_smooth_vec_loss with respect to the seven stored numbers (it reads them
+ *                               through .tensor()); NULL: not wanted
+ *   grad_intrinsics [T,4]       per frame (fx fy cx cy), inter_frame_loss and pts_3d_loss through iproj; the reference's K
+ *                               (refine_intrinsics: intrinsics = K * K_scale for every frame, :131-136) gets
+ *                               K_scale * sum_t of it; NULL: not wanted
+ * `mono_scaled` is the [T,N,S] output of bt_ga_forward for the same arguments; `g_mono_scaled` is [T,N,S] float scratch (on
+ * return: d total / d mono_scaled).  Query frames must be distinct (bt_ga_forward too).  All outputs are overwritten.
+ * Enqueued on `stream`. */
+int bt_ga_backward_total(const bt_ga_args *args, const float *mono_scaled, const bt_ga_weights *weights, float *g_mono_scaled,
+                         float *grad_trajs_scales, float *grad_frame_scales, float *grad_pose, float *grad_intrinsics, void *stream);
+
+/* The same for  w_spatial * spatial + w_rigid * inter_frame  and the two parameters that total reaches. */
 int bt_ga_backward(const bt_ga_args *args, const float *mono_scaled, float w_spatial, float w_rigid, float *g_mono_scaled,
                    float *grad_trajs_scales, float *grad_frame_scales, void *stream);
 
