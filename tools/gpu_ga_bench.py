@@ -39,5 +39,25 @@ for T, N, S in ((50, 400, 12), (50, 1024, 12)):
         it()
     torch.cuda.synchronize()
     print(f"T={T} N={N} S={S} one Adam iteration (loss, backward, step): {(time.perf_counter() - t0) / 20 * 1e6:9.1f} us", flush=True)
+    # the total run_global_refine.py optimises (weights of :61-67, pose and K free): loss, backward, Adam step
+    from test_gpu_global_refine import _settings
+    net = build(d, **_settings("A"))
+    for p_ in (net.trajs_scales, net.frame_scales_, net.pose, net.K):
+        p_.requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [p_], "lr": 1e-2} for p_ in (net.trajs_scales, net.frame_scales_, net.pose, net.K)], lr=1e-2, betas=(0.9, 0.9))
+    def itf():
+        opt.zero_grad(); net.loss().backward(); opt.step()
+    itf(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        itf()
+    torch.cuda.synchronize()
+    print(f"T={T} N={N} S={S} one Adam iteration of the FULL total (5 terms; trajs_scales, frame_scales_, pose, K): {(time.perf_counter() - t0) / 20 * 1e6:9.1f} us", flush=True)
+    net.backward(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        net.backward()
+    torch.cuda.synchronize()
+    print(f"T={T} N={N} S={S} backward of the full total: {(time.perf_counter() - t0) / 30 * 1e6:9.1f} us (incl. the forward pass of the scaled depth)", flush=True)
     pairs = T * (S - 1) * N * N
     print(f"  pairwise work: {pairs/1e6:.1f} M pairs x ~20 flop = {pairs*20/1e9:.2f} GFLOP")
