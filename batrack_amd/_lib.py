@@ -165,6 +165,26 @@ def lib():
         f = getattr(L, name)
         f.restype = i32
         f.argtypes = [vp, ctypes.POINTER(BaArgs), vp, vp]
+    for name in ("bt_ba_reduce_pack", "bt_ba_unpack_solve_update"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, ctypes.POINTER(BaArgs), vp, vp]
+    L.bt_xchg_bytes.restype = ctypes.c_size_t
+    L.bt_xchg_bytes.argtypes = [vp, i32]
+    L.bt_xchg_alloc.restype = i32
+    L.bt_xchg_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp), ctypes.c_char_p]
+    L.bt_xchg_open.restype = i32
+    L.bt_xchg_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.bt_xchg_close.restype = i32
+    L.bt_xchg_close.argtypes = [vp]
+    L.bt_xchg_free.restype = i32
+    L.bt_xchg_free.argtypes = [vp]
+    L.bt_ba_reduce_push.restype = i32
+    L.bt_ba_reduce_push.argtypes = [vp, ctypes.POINTER(BaArgs), vp, ctypes.POINTER(vp), i32, i32, i64, vp]
+    L.bt_ba_pull_solve_update.restype = i32
+    L.bt_ba_pull_solve_update.argtypes = [vp, ctypes.POINTER(BaArgs), vp, vp, i32, i64, vp]
+    L.bt_ba_xchg_status.restype = i32
+    L.bt_ba_xchg_status.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_int32)]
     L.bt_ba_workspace_init.restype = i32
     L.bt_ba_workspace_init.argtypes = [vp, vp, vp]
     L.bt_ba_step_timed.restype = i32

@@ -542,6 +542,73 @@ int bt_ba_unpack(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream)
     return launch_pack(pl->dev, make_args(pl, a, ws), true, static_cast<hipStream_t>(stream));
 }
 
+int bt_ba_reduce_pack(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
+    const int rc = bt_ba_reduce(pl, a, ws, stream);
+    return rc != BT_OK ? rc : bt_ba_pack(pl, a, ws, stream);
+}
+
+int bt_ba_unpack_solve_update(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
+    const int rc = bt_ba_unpack(pl, a, ws, stream);
+    return rc != BT_OK ? rc : bt_ba_solve_update(pl, a, ws, stream);
+}
+
+size_t bt_xchg_bytes(const bt_plan *pl, int world) {
+    return (pl && pl->dev_base && world > 0 && world <= kMaxRanks) ? xchg_bytes(pl->dev, world) : 0;
+}
+
+int bt_xchg_alloc(size_t bytes, void **buf, unsigned char handle[64]) {
+    if (!buf || !handle || bytes == 0) return BT_EINVAL;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    void *d = nullptr;
+    // uncached: the peers' stores and this rank's loads meet in memory, not in caches that are not coherent across dies / devices
+    if (hipExtMallocWithFlags(&d, bytes, hipDeviceMallocUncached) != hipSuccess) return BT_ENOMEM;
+    hipIpcMemHandle_t h;
+    if (hipMemset(d, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, d) != hipSuccess) {
+        (void)hipFree(d);
+        return BT_EHIP;
+    }
+    std::memcpy(handle, &h, 64);
+    *buf = d;
+    return BT_OK;
+}
+
+int bt_xchg_open(const unsigned char handle[64], void **peer) {
+    if (!handle || !peer) return BT_EINVAL;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, 64);
+    return hipIpcOpenMemHandle(peer, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+int bt_xchg_close(void *peer) { return (!peer || hipIpcCloseMemHandle(peer) == hipSuccess) ? BT_OK : BT_EHIP; }
+int bt_xchg_free(void *buf) { return (!buf || hipFree(buf) == hipSuccess) ? BT_OK : BT_EHIP; }
+
+int bt_ba_reduce_push(const bt_plan *pl, const bt_ba_args *a, void *ws, void *const *bufs, int world, int rank, int64_t epoch, void *stream) {
+    const int rc = bt_ba_reduce(pl, a, ws, stream);
+    if (rc != BT_OK || is_so(pl, a)) return rc;
+    if (!bufs || world < 1 || world > kMaxRanks || rank < 0 || rank >= world || epoch < 1) return BT_EINVAL;
+    for (int q = 0; q < world; ++q) if (!bufs[q]) return BT_EINVAL;
+    return launch_xchg_push(pl->dev, make_args(pl, a, ws), bufs, world, rank, epoch, static_cast<hipStream_t>(stream));
+}
+
+int bt_ba_pull_solve_update(const bt_plan *pl, const bt_ba_args *a, void *ws, void *own, int world, int64_t epoch, void *stream) {
+    const int rc = check(pl, a, ws);
+    if (rc != BT_OK) return rc;
+    if (!is_so(pl, a)) {
+        if (!own || world < 1 || world > kMaxRanks || epoch < 1) return BT_EINVAL;
+        const int r2 = launch_xchg_pull(pl->dev, make_args(pl, a, ws), own, world, epoch, static_cast<hipStream_t>(stream));
+        if (r2 != BT_OK) return r2;
+    }
+    return bt_ba_solve_update(pl, a, ws, stream);
+}
+
+int bt_ba_xchg_status(const bt_plan *pl, void *ws, void *stream, int32_t *status) {
+    if (!pl || !ws || !status) return BT_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(status, static_cast<char *>(ws) + pl->ws.status + sizeof(int32_t), sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return BT_EHIP;
+    return hipStreamSynchronize(st) == hipSuccess ? BT_OK : BT_EHIP;
+}
+
 double *bt_ba_packed(const bt_plan *pl, void *ws, int64_t *count) {
     if (!pl || !ws) return nullptr;
     if (count) *count = pl->info.nnz_blocks * 36 + 6 * pl->info.n;

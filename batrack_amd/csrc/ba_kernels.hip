@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 #include <utility>
@@ -2139,6 +2140,109 @@ __global__ __launch_bounds__(256) void k_pack_system(PlanDev pd, StepArgs a) {
         double *p = a.y + 6 * pd.perm[k / 6] + k % 6;
         if (UNPACK) *p = a.packed[i]; else a.packed[i] = *p;
     }
+}
+
+// ------------------------------------------------------------------ one-shot exchange of [S | y] between the ranks' GPUs
+// The reduced system in its packed form is ~140 KB at 64 keyframes, ~33 KB for the 15-pose window: an all-reduce of that
+// size is pure latency, and xGMI is a full mesh of point-to-point links — so every rank WRITES its packed partial system
+// straight into a slot of every peer's exchange buffer (hipIpc-mapped, uncached device memory) and raises a flag there;
+// every rank then sums the `world` slots of its own buffer in rank order (bitwise the same sum everywhere, so every rank
+// solves the identical system) while unpacking into [S | y].  No collective library, no host round trip, nothing but two
+// kernels on the compute stream.  Buffer layout (bt_xchg_bytes): [2 parities][world slots][slot doubles] | flags [2][world]
+// int64 | a ticket counter.  Epoch e uses parity e & 1: a rank cannot start epoch e + 2 before it has seen every peer's flag
+// of epoch e + 1, which a peer raises only after it has consumed epoch e.
+__device__ __forceinline__ double *packed_elem(const PlanDev &pd, const StepArgs &a, int i, bool &zero) {
+    const int nb = pd.nnzb * 36;
+    zero = false;
+    if (i < nb) {
+        const int b = i / 36, e = i - 36 * b, r = e / 6, c = e - 6 * r, src = pd.blk_src[b];
+        const int rn = src >> 9, cn = (src >> 1) & 255;
+        if (rn == cn && c > r) { zero = true; return nullptr; }              // S holds the lower triangle only
+        return (src & 1) ? a.S + (size_t)(6 * rn + c) * pd.D + 6 * cn + r : a.S + (size_t)(6 * rn + r) * pd.D + 6 * cn + c;
+    }
+    const int k = i - nb;
+    return a.y + 6 * pd.perm[k / 6] + k % 6;
+}
+
+struct XchgPeers { double *buf[kMaxRanks]; };
+
+__device__ __forceinline__ size_t xchg_slot_doubles(const PlanDev &pd) { return ((size_t)pd.nnzb * 36 + pd.D + 1) & ~(size_t)1; }
+
+__global__ __launch_bounds__(256) void k_xchg_push(PlanDev pd, StepArgs a, XchgPeers peers, int world, int rank, long long epoch) {
+    const int total = pd.nnzb * 36 + pd.D;
+    const size_t slot = xchg_slot_doubles(pd), off = ((size_t)(epoch & 1) * world + rank) * slot;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        bool zero;
+        double *p = packed_elem(pd, a, i, zero);
+        const double v = zero ? 0.0 : *p;
+        for (int q = 0; q < world; ++q) __builtin_nontemporal_store(v, peers.buf[q] + off + i);
+    }
+    // every block: its stores out to the fabric, then a ticket; the last block raises this rank's flag in every peer's buffer
+    __threadfence_system();
+    __syncthreads();
+    __shared__ int last;
+    long long *own_flags = reinterpret_cast<long long *>(peers.buf[rank] + 2 * (size_t)world * slot);
+    int *ticket = reinterpret_cast<int *>(own_flags + 2 * world);
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    if ((int)threadIdx.x < world) {
+        long long *f = reinterpret_cast<long long *>(peers.buf[threadIdx.x] + 2 * (size_t)world * slot) + (size_t)(epoch & 1) * world + rank;
+        __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Waits for the flags of epoch `epoch` from all ranks (bounded: a peer that never arrives must not hang the GPU — status
+// word 1 is then set to BT_XCHG_TIMEOUT and the step continues on whatever the slots hold), then [S | y] = sum over the
+// ranks' slots, in rank order.
+__global__ __launch_bounds__(256) void k_xchg_pull(PlanDev pd, StepArgs a, double *own, int world, long long epoch, long long spin_limit) {
+    const size_t slot = xchg_slot_doubles(pd);
+    const long long *flags = reinterpret_cast<const long long *>(own + 2 * (size_t)world * slot) + (size_t)(epoch & 1) * world;
+    if ((int)threadIdx.x < world) {
+        long long it = 0;
+        while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++it > spin_limit) { a.status[1] = BT_XCHG_TIMEOUT; break; }
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    const int total = pd.nnzb * 36 + pd.D;
+    const double *base = own + (size_t)(epoch & 1) * world * slot;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        bool zero;
+        double *p = packed_elem(pd, a, i, zero);
+        if (zero) continue;
+        double v = 0.0;
+        for (int q = 0; q < world; ++q) v += __builtin_nontemporal_load(base + (size_t)q * slot + i);
+        *p = v;
+    }
+}
+
+size_t xchg_bytes(const PlanDev &pd, int world) {
+    const size_t slot = (((size_t)pd.nnzb * 36 + pd.D + 1) & ~(size_t)1) * sizeof(double);
+    return 2 * (size_t)world * slot + 2 * (size_t)world * sizeof(long long) + 64;
+}
+
+int launch_xchg_push(const PlanDev &pd, const StepArgs &a, void *const *bufs, int world, int rank, long long epoch, hipStream_t st) {
+    const int total = pd.nnzb * 36 + pd.D;
+    if (total <= 0) return BT_OK;
+    XchgPeers P{};
+    for (int q = 0; q < world; ++q) P.buf[q] = static_cast<double *>(bufs[q]);
+    const int nb = std::min(64, (total + 255) / 256);
+    hipLaunchKernelGGL(k_xchg_push, dim3(nb), dim3(256), 0, st, pd, a, P, world, rank, epoch);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+int launch_xchg_pull(const PlanDev &pd, const StepArgs &a, void *own, int world, long long epoch, hipStream_t st) {
+    const int total = pd.nnzb * 36 + pd.D;
+    if (total <= 0) return BT_OK;
+    static const long long limit = std::getenv("BT_XCHG_SPIN_LIMIT") ? std::atoll(std::getenv("BT_XCHG_SPIN_LIMIT")) : 20000000ll;   // ~10 s of s_sleep(8) polls
+    const int nb = std::min(64, (total + 255) / 256);
+    hipLaunchKernelGGL(k_xchg_pull, dim3(nb), dim3(256), 0, st, pd, a, static_cast<double *>(own), world, epoch, limit);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 
 // ------------------------------------------------------------------ launchers

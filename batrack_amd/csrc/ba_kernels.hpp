@@ -42,6 +42,11 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
                   int fuse_so_poses = -1, bool *fused = nullptr);
 // dense [S | y] <-> its non-zero blocks in factor order (bt_ba_pack / bt_ba_unpack)
 int launch_pack(const PlanDev &pd, const StepArgs &a, bool unpack, hipStream_t st);
+// one-shot peer-write exchange of the packed [S | y] (ba_kernels.hip: k_xchg_push / k_xchg_pull)
+constexpr int kMaxRanks = 16;
+size_t xchg_bytes(const PlanDev &pd, int world);
+int launch_xchg_push(const PlanDev &pd, const StepArgs &a, void *const *bufs, int world, int rank, long long epoch, hipStream_t st);
+int launch_xchg_pull(const PlanDev &pd, const StepArgs &a, void *own, int world, long long epoch, hipStream_t st);
 int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
 
 }  // namespace bt

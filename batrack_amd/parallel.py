@@ -3,13 +3,19 @@ reference is single-GPU, main/batrack.py:73-104).
 
 One process per GPU.  Tracks are split into `world` contiguous ranges of the
 sorted track list, balanced by edge count; a rank owns the edges, disparities
-and priors of its tracks; poses and intrinsics are replicated.  Per step:
+and priors of its tracks; poses and intrinsics are replicated.  Per step, two
+calls into the C ABI around ONE exchange of the packed reduced system (140 KB at
+64 keyframes instead of the dense 1.15 MB), selectable per engine:
 
-    bt_ba_reduce        partial reduced system [S | y] of the rank's tracks
-    bt_ba_pack          its non-zero blocks, contiguous (140 KB instead of 1.15 MB at 64 keyframes)
-    all_reduce(SUM)     the ONE exchange, float64 (RCCL over xGMI)
-    bt_ba_unpack        back into [S | y]
-    bt_ba_solve_update  identical solve on every rank, own depths, all poses
+  exchange="rccl"   bt_ba_reduce_pack -> dist.all_reduce(SUM, float64; backend nccl = RCCL over xGMI) ->
+                    bt_ba_unpack_solve_update
+  exchange="ipc"    bt_ba_reduce_push -> bt_ba_pull_solve_update: every rank writes its packed partial system
+                    straight into a slot of every peer's hipIpc-mapped exchange buffer and raises a flag; every
+                    rank sums the slots of its own buffer in rank order while unpacking.  No collective library,
+                    no host round trip: two kernels on the compute stream (include/batrack_ba.h).  The only
+                    collective is the one-time swap of the 64-byte buffer handles at construction.
+
+Every rank then runs the identical solve, updates its own depths and all poses.
 
 No second exchange inside the iteration; `gather_patches` merges the ranks'
 disparities when the caller wants the full buffer back.
@@ -73,9 +79,11 @@ class ShardedBA:
     per-edge inputs (targets, weights) stay the full tensors on every rank — a rank's plan
     only touches the edges of its own track range."""
 
-    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, device, world=None, rank=None, group=None):
+    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, device, world=None, rank=None, group=None, exchange="rccl"):
         from .plan import Plan, Stepper
-        self.group = group
+        if exchange not in ("rccl", "ipc"):
+            raise ValueError("exchange must be 'rccl' or 'ipc'")
+        self.group, self.exchange = group, exchange
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
         self.device = torch.device(device)
@@ -86,6 +94,49 @@ class ShardedBA:
         self.plan = Plan(ii, jj, kk, n_buf, p_tot, fixedp, own=plan_range(self.owned, p_tot) if self.world > 1 else (0, 0))
         self.stepper = Stepper(self.plan, self.device)
         self._covered = None
+        self._xbuf, self._peers, self._epoch = None, None, 0
+        if exchange == "ipc" and self.world > 1 and self.plan.n > 0:
+            self._open_exchange()
+
+    def _open_exchange(self):
+        """The rank's exchange buffer and the peers' buffers mapped into this process (once per engine)."""
+        import ctypes
+        from . import _lib
+        L = self.stepper._lib
+        if self.world > 16:
+            raise RuntimeError("exchange='ipc' supports up to 16 ranks")
+        with torch.cuda.device(self.device):
+            nbytes = L.bt_xchg_bytes(self.plan.handle, self.world)
+            buf, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+            _lib.check(L.bt_xchg_alloc(nbytes, ctypes.byref(buf), handle), "bt_xchg_alloc")
+            mine = torch.frombuffer(bytearray(handle.raw), dtype=torch.uint8).clone()
+            # the one collective of this path: 64 bytes per rank, once (on the host for a gloo group, on the device for nccl)
+            on_dev = dist.get_backend(self.group) != "gloo"
+            mine = mine.to(self.device) if on_dev else mine
+            allh = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(allh, mine, group=self.group)
+            ptrs = (ctypes.c_void_p * self.world)()
+            opened = []
+            for r in range(self.world):
+                if r == self.rank:
+                    ptrs[r] = buf.value
+                else:
+                    p = ctypes.c_void_p()
+                    _lib.check(L.bt_xchg_open(bytes(allh[r].cpu().numpy().tobytes()), ctypes.byref(p)), f"bt_xchg_open (rank {r})")
+                    ptrs[r] = p.value
+                    opened.append(p)
+            dist.barrier(group=self.group)            # nobody pushes before everybody has mapped
+        self._xbuf, self._peers, self._opened = buf, ptrs, opened
+
+    def close(self):
+        if self._xbuf is not None:
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)            # no peer may still be writing into a buffer that is about to go
+            L = self.stepper._lib
+            for p in self._opened:
+                L.bt_xchg_close(p)
+            L.bt_xchg_free(self._xbuf)
+            self._xbuf = self._peers = None
 
     def step(self, poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
              bounds, lmbda, ep, alpha, loss, structure_only):
@@ -97,17 +148,28 @@ class ShardedBA:
         if so or self.world == 1:
             st.step(*args)
             return
-        # one argument block, five enqueues on the current stream (the all-reduce is enqueued by torch on the same stream)
+        # one argument block, two enqueues on the current stream around the exchange
         import ctypes
         from . import _lib
         a = st._fill(*args)
         L, h, ws = st._lib, self.plan.handle, st.ws.data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
-        _lib.check(L.bt_ba_reduce(h, ctypes.byref(a), ws, stream), "bt_ba_reduce")
-        _lib.check(L.bt_ba_pack(h, ctypes.byref(a), ws, stream), "bt_ba_pack")
-        allreduce_system(st.packed, self.group)
-        _lib.check(L.bt_ba_unpack(h, ctypes.byref(a), ws, stream), "bt_ba_unpack")
-        _lib.check(L.bt_ba_solve_update(h, ctypes.byref(a), ws, stream), "bt_ba_solve_update")
+        if self._xbuf is not None:
+            self._epoch += 1
+            _lib.check(L.bt_ba_reduce_push(h, ctypes.byref(a), ws, self._peers, self.world, self.rank, self._epoch, stream), "bt_ba_reduce_push")
+            _lib.check(L.bt_ba_pull_solve_update(h, ctypes.byref(a), ws, self._xbuf, self.world, self._epoch, stream), "bt_ba_pull_solve_update")
+            return
+        _lib.check(L.bt_ba_reduce_pack(h, ctypes.byref(a), ws, stream), "bt_ba_reduce_pack")
+        allreduce_system(st.packed, self.group)          # (enqueued by torch on the same stream under nccl = RCCL)
+        _lib.check(L.bt_ba_unpack_solve_update(h, ctypes.byref(a), ws, stream), "bt_ba_unpack_solve_update")
+
+    def exchange_status(self):
+        """0, or BT_XCHG_TIMEOUT (1) once a pull gave up waiting for a peer (exchange='ipc')."""
+        import ctypes
+        s = ctypes.c_int32()
+        self.stepper._lib.bt_ba_xchg_status(self.plan.handle, self.stepper.ws.data_ptr(),
+                                            torch.cuda.current_stream(self.device).cuda_stream, ctypes.byref(s))
+        return int(s.value)
 
     def gather_patches(self, patches_out):
         """Merge disparities: every patch slot is owned by exactly one rank (its track range); slots outside every

@@ -166,6 +166,37 @@ double *bt_ba_system(const bt_plan *plan, void *workspace, int64_t *count);
 int bt_ba_pack(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
 int bt_ba_unpack(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
 double *bt_ba_packed(const bt_plan *plan, void *workspace, int64_t *count);
+/* The step in TWO calls around a collective (RCCL over xGMI: all-reduce bt_ba_packed(), sum, float64):
+ *   bt_ba_reduce_pack           = bt_ba_reduce + bt_ba_pack
+ *   bt_ba_unpack_solve_update   = bt_ba_unpack + bt_ba_solve_update  */
+int bt_ba_reduce_pack(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
+int bt_ba_unpack_solve_update(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
+
+/* ... or with NO collective library: a one-shot exchange over peer-mapped buffers (the message is
+ * latency-bound and xGMI is a full mesh).  Every rank allocates an exchange buffer (bt_xchg_alloc: uncached device memory
+ * plus its 64-byte hipIpc handle), the ranks swap handles once (any transport) and map each other's buffers (bt_xchg_open).
+ * Per step, on the compute stream:
+ *   bt_ba_reduce_push          reduce, then write the packed partial system into slot `rank` of EVERY rank's buffer
+ *                              (bufs[world], bufs[rank] = the rank's own) and raise this rank's flag there
+ *   bt_ba_pull_solve_update    wait for all `world` flags of this epoch in the own buffer, sum the slots in rank order
+ *                              (bitwise the same system on every rank), solve, back-substitute, retract
+ * `epoch` is 1, 2, 3, ... and must advance by one per step on every rank (two parities of slots: a rank may run one
+ * step ahead of a peer, not two — guaranteed by the flags themselves).  A peer that never arrives makes the pull give up
+ * after a bounded wait and sets BT_XCHG_TIMEOUT in the second status word (bt_ba_xchg_status); it never hangs the GPU.
+ * world <= 16.  Structure-only steps exchange nothing: both calls then behave like bt_ba_reduce / bt_ba_solve_update. */
+#define BT_XCHG_TIMEOUT 1
+size_t bt_xchg_bytes(const bt_plan *plan, int world);
+int bt_xchg_alloc(size_t bytes, void **buf, unsigned char handle[64]);
+int bt_xchg_open(const unsigned char handle[64], void **peer);
+int bt_xchg_close(void *peer);
+int bt_xchg_free(void *buf);
+int bt_ba_reduce_push(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *const *bufs, int world, int rank,
+                      int64_t epoch, void *stream);
+int bt_ba_pull_solve_update(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *own_buf, int world,
+                            int64_t epoch, void *stream);
+/* Synchronous read-back of the exchange status word (0, or BT_XCHG_TIMEOUT once a pull gave up). */
+int bt_ba_xchg_status(const bt_plan *plan, void *workspace, void *stream, int32_t *status);
+
 /* Device pointer to dX [n,6] floats inside `workspace`. */
 float *bt_ba_dx(const bt_plan *plan, void *workspace);
 /* Synchronous read-back of the solver status word (BT_SOLVE_*). */

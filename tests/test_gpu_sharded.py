@@ -1,7 +1,11 @@
-"""-m gpu: the track-sharded step end to end on the device.  Two ranks share cuda:0 (the
-GPU box has one GPU); the all-reduce of [S|y] is staged through gloo for this test only —
-everything else (per-shard plans with the global n_all, bt_ba_reduce, bt_ba_solve_update,
-gather of the disparities) is the production path.  Result must equal the 1-GPU step."""
+"""-m gpu: the track-sharded step end to end on the device, through BOTH exchange paths.  Two or four ranks share
+cuda:0 (the GPU box has one GPU):
+  exchange="rccl"  bt_ba_reduce_pack -> all-reduce -> bt_ba_unpack_solve_update; the all-reduce is staged through gloo for
+                   this test only (RCCL needs one GPU per rank)
+  exchange="ipc"   bt_ba_reduce_push -> bt_ba_pull_solve_update: the production one-shot exchange as it is — hipIpc-mapped
+                   buffers, peer writes and flags on the compute stream — with the peers' buffers living on the same GPU.
+Everything else (per-shard plans with the global n_all, the kernels, the gather of the disparities) is the production path.
+The result is compared with the float64 ORACLE (two chained steps) and with the 1-GPU HIP step."""
 import os
 import sys
 
@@ -32,7 +36,7 @@ def _inputs(seed=3, shape="band"):
                    t3=f(g.targets3), w=f(g.weights_pose), ii=g.ii, jj=g.jj, kk=g.kk)
 
 
-def _worker(rank, world, port, out, shape, fixedp):
+def _worker(rank, world, port, out, shape, fixedp, exchange="rccl"):
     sys.path[:0] = [os.path.dirname(HERE), HERE]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -44,7 +48,7 @@ def _worker(rank, world, port, out, shape, fixedp):
         T = lambda a: torch.as_tensor(a, device=dev)
         poses, patches, mono, intr, t3, w = (T(d[k]) for k in ("poses", "patches", "mono", "intr", "t3", "w"))
         ii, jj, kk = T(d["ii"]), T(d["jj"]), T(d["kk"])
-        eng = ShardedBA(ii, jj, kk, poses.shape[0], patches.shape[0], fixedp, dev)
+        eng = ShardedBA(ii, jj, kk, poses.shape[0], patches.shape[0], fixedp, dev, exchange=exchange)
         tg, wl = t3, w
         scal = (list(g.bounds), 1e-4, 10.0, 0.05, "huber")
         P, X = [poses, torch.empty_like(poses)], [patches, torch.empty_like(patches)]
@@ -52,13 +56,16 @@ def _worker(rank, world, port, out, shape, fixedp):
             eng.step(P[k & 1], X[k & 1], mono, intr, tg, tg.stride(0), wl, P[(k + 1) & 1], X[(k + 1) & 1], *scal, False)
         full = eng.gather_patches(X[0])
         torch.cuda.synchronize()
-        out[rank] = (P[0].cpu().numpy(), full.cpu().numpy(), int(eng.plan.E), eng.stepper.status())
+        out[rank] = (P[0].cpu().numpy(), full.cpu().numpy(), int(eng.plan.E), eng.stepper.status(), eng.exchange_status())
+        eng.close()
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "ipc"])
 @pytest.mark.parametrize("shape,fixedp,world", [("band", 1, 2), ("shibuya", 9, 2), ("band", 1, 4), ("few", 1, 4)])
-def test_sharded_step_equals_single_gpu(shape, fixedp, world):
+def test_sharded_step_equals_oracle_and_single_gpu(shape, fixedp, world, exchange):
+    import oracle
     from batrack_amd.plan import Plan, Stepper
     g, d = _inputs(shape=shape)
     dev = "cuda:0"
@@ -76,15 +83,24 @@ def test_sharded_step_equals_single_gpu(shape, fixedp, world):
     port = 29700 + (os.getpid() % 1000)
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out, shape, fixedp), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, shape, fixedp, exchange), nprocs=world, join=True)
+    # the float64 oracle on the same float32 inputs, two chained pose+structure steps
+    f64 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    op, ox = f64(d["poses"]), f64(d["patches"])
+    for _ in range(2):
+        r = oracle.ba_step(op, ox, f64(d["mono"]), f64(d["intr"]), f64(d["t3"]), f64(d["w"]), d["ii"], d["jj"], d["kk"], g.bounds, fixedp=fixedp)
+        op, ox = r["poses_out"], r["patches_out"]
     assert len(out) == world and sum(out[r][2] for r in range(world)) == len(d["ii"])
     rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b)
     for r in range(world):
-        pose, pat, _, status = out[r]
-        assert status == 0
+        pose, pat, _, status, xstatus = out[r]
+        assert status == 0 and xstatus == 0
         ep, ex = rel(pose, ref_pose), rel(pat, ref_pat)
         tol = 1e-5 if shape == "few" else 2e-6       # three tracks barely constrain the poses: rounding of the sums is amplified
         assert ep < tol and ex < tol, (r, ep, ex)     # summation order differs (atomics, shard split)
+        # against the oracle: float64 per-edge maths, float32 state written twice
+        eo, exo = rel(pose, op), rel(pat, ox)
+        assert eo < 1e-6 and exo < 1e-6, (r, eo, exo)
     for r in range(1, world):
         assert np.array_equal(out[0][0], out[r][0])    # identical solve on every rank after the all-reduce
     if shape == "few":
