@@ -206,6 +206,7 @@ static void bind_pointers(bt_plan *pl, const void *d) {
     P.tile_pair0 = BT_I32(O.tp0); P.tile_npair = BT_I32(O.tnp); P.tile_pairs = BT_I32(O.tps);
     P.slot_lp = reinterpret_cast<const uint8_t *>(b + O.slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams; P.e_all = pl->e_all;
     P.slot_code = reinterpret_cast<const uint16_t *>(b + O.sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + O.tla); P.tile_rec = BT_I32(O.trec); P.it_edge = BT_I32(O.ite); P.tile_sinfo = reinterpret_cast<const uint32_t *>(b + O.tsi); P.em_ok = pl->em_ok; P.em_its = (int)pl->em_its; P.em_lgs = pl->em_lgs; P.em_self = pl->em_self;
+    P.pm_edge = BT_I32(O.pme); P.pm_rec = BT_I32(O.pmr); P.pm_lb = reinterpret_cast<const uint8_t *>(b + O.pmb); P.pm_la = reinterpret_cast<const uint8_t *>(b + O.pml); P.pm_ok = pl->pm_ok; P.sp_ok = pl->sp_ok; P.pp_ptr = BT_I32(O.ppp); P.pp_idx = BT_I32(O.ppi);
 #undef BT_I32
 }
 
@@ -234,6 +235,8 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
     O.fy = put(buf, pl->fz_yurg), O.fm = put(buf, pl->fz_meta), O.fpm = put(buf, pl->fz_pmeta), O.bss = put(buf, pl->bs_sync), O.fri = put(buf, pl->fz_rowinfo), O.fpf = put(buf, pl->fz_pfirst), O.fps = put(buf, pl->fz_psecond), O.tij = put(buf, pl->tile_ij), O.tkx = put(buf, pl->tile_kx);
     O.tc8 = put(buf, pl->tile_cut8), O.tc16 = put(buf, pl->tile_cut16);
     O.sc = put(buf, pl->slot_code), O.tla = put(buf, pl->tile_la), O.trec = put(buf, pl->tile_rec), O.ite = put(buf, pl->it_edge), O.tsi = put(buf, pl->tile_sinfo);
+    O.pme = put(buf, pl->pm_edge), O.pmr = put(buf, pl->pm_rec), O.pmb = put(buf, pl->pm_lb), O.pml = put(buf, pl->pm_la);
+    O.ppp = put(buf, pl->pp_ptr), O.ppi = put(buf, pl->pp_idx);
     tick("pack arrays");
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
@@ -284,6 +287,7 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     s.lfac = reinterpret_cast<float *>(w + L.lfac);
     s.linv = reinterpret_cast<float *>(w + L.linv); s.zvec = reinterpret_cast<float *>(w + L.zvec);
     s.dx = reinterpret_cast<float *>(w + L.dx); s.dx0 = reinterpret_cast<float *>(w + L.dx0); s.status = reinterpret_cast<int *>(w + L.status);
+    s.spart = reinterpret_cast<double *>(w + L.spart);
     static const int dbg = std::getenv("BT_DEBUG_MODE") ? std::atoi(std::getenv("BT_DEBUG_MODE")) : 0;
     s.dbg = dbg;
     s.prec = edge_precision(pl->dev);
@@ -312,7 +316,7 @@ extern "C" {
 int bt_version(void) { return BT_VERSION; }
 int bt_plan_jacobian_kernel(const bt_plan *pl) {
     if (!pl || !pl->dev_base) return -1;
-    return edge_applies(pl->dev) ? 2 : stream_applies(pl->dev) ? 1 : 0;
+    return edge_applies(pl->dev) ? 2 : stream_applies(pl->dev) ? 1 : etile_precision_bytes(pl->dev) ? 3 : 0;
 }
 int bt_plan_edge_precision(const bt_plan *pl) {
     if (!pl || !pl->dev_base) return -1;
@@ -394,7 +398,7 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
     pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
     pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
     pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
-    pl->em_self = src->em_self; pl->e_all = src->e_all;
+    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->pm_rounds = src->pm_rounds;
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
     void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);
@@ -457,7 +461,7 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
     BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next) BT_ARR(perm) BT_ARR(blk_src) BT_ARR(lvl_ptr) BT_ARR(lvl_cols)
     BT_ARR(col_lvl) BT_ARR(dp_ptr) BT_ARR(dp) BT_ARR(tile_pair0) BT_ARR(tile_npair) BT_ARR(tile_pairs) BT_ARR(slot_lp) BT_ARR(tile_flags)
-    BT_ARR(fz_pend_ptr) BT_ARR(fz_pend) BT_ARR(fz_lazy_ptr) BT_ARR(fz_lazy) BT_ARR(fz_yurg) BT_ARR(fz_meta) BT_ARR(fz_pmeta) BT_ARR(bs_sync) BT_ARR(fz_rowinfo) BT_ARR(fz_pfirst) BT_ARR(fz_psecond) BT_ARR(act_bits) BT_ARR(act_rank) BT_ARR(tile_ij) BT_ARR(tile_kx) BT_ARR(lvl_meta) BT_ARR(slot_code) BT_ARR(tile_la) BT_ARR(tile_rec) BT_ARR(it_edge) BT_ARR(tile_sinfo) BT_ARR(tile_cut8) BT_ARR(tile_cut16)
+    BT_ARR(fz_pend_ptr) BT_ARR(fz_pend) BT_ARR(fz_lazy_ptr) BT_ARR(fz_lazy) BT_ARR(fz_yurg) BT_ARR(fz_meta) BT_ARR(fz_pmeta) BT_ARR(bs_sync) BT_ARR(fz_rowinfo) BT_ARR(fz_pfirst) BT_ARR(fz_psecond) BT_ARR(act_bits) BT_ARR(act_rank) BT_ARR(tile_ij) BT_ARR(tile_kx) BT_ARR(lvl_meta) BT_ARR(slot_code) BT_ARR(tile_la) BT_ARR(tile_rec) BT_ARR(it_edge) BT_ARR(tile_sinfo) BT_ARR(tile_cut8) BT_ARR(tile_cut16) BT_ARR(pm_edge) BT_ARR(pm_rec) BT_ARR(pm_lb) BT_ARR(pm_la)
 #undef BT_ARR
     return -1;
 }

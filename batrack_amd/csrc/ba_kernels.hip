@@ -30,6 +30,7 @@
 
 #include "ba_kernels.hpp"
 #include "ba_edge.hpp"
+#include "ba_update.hpp"
 
 namespace bt {
 
@@ -56,9 +57,6 @@ namespace bt {
 // TRACKS_ELSEWHERE: patches that carry a track are written by the tile blocks and skipped here, else — the unfused
 // structure-only update — their dZ = Q w' is applied here, ba.py:316-317), then one thread per buffer pose: Exp(dX) * G in
 // double (groups.py:153-156) or, structure-only, a plain copy.
-template <bool SO, bool TRACKS_ELSEWHERE>
-__device__ __forceinline__ void update_rest(const PlanDev &pd, const StepArgs &a, int gid, int do_poses);
-
 // FUSE (structure-only steps): the workgroups behind the pd.T tile workgroups do update_rest, and every tile writes its
 // tracks' new disparities itself: the whole structure-only step is ONE launch instead of k_tile<SO> + k_update<SO>.
 // R: float or double — the precision of the per-edge maths, of E in LDS and of the (Q, w') it leaves for k_update (float64 is
@@ -409,7 +407,38 @@ __device__ __forceinline__ int sym21(int p, int q) {
     return p * 6 - p * (p - 1) / 2 + (q - p);
 }
 
-__global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
+// sp_blocks > 0 (plans whose tiles share their cameras, Jacobian kernel k_etile): the blocks behind the pair blocks add up the
+// tiles' Schur products E Q E^T (one block per 16x16 output tile, its 256 threads one element each over all tiles) and E Q w'
+// (the last block) and subtract them from [S | y] — a few thousand atomics instead of tiles x that many.
+__global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a, int pair_blocks) {
+    if ((int)blockIdx.x >= pair_blocks) {
+        const int b = (int)blockIdx.x - pair_blocks, R16 = pd.max_rows16, nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
+        const size_t per_tile = sp_tile_doubles(pd.max_rows16, pd.max_tile_pairs);
+        const int *cams = pd.tile_cams + pd.tile_cam0[0];            // the cameras of every tile
+        const int Rw = 6 * pd.tile_ncam[0];
+        auto grow = [&](int r) { return 6 * cams[r / 6] + r % 6; };
+        if (b < ntl) {
+            int ti = 0, base = 0;
+            while (base + ti + 1 <= b) { base += ti + 1; ++ti; }
+            const int tj = b - base, j = threadIdx.x, r = j >> 6, lane = j & 63;
+            double sum = 0.0;
+            const double *src = a.spart + (size_t)b * 256 + j;
+            for (int t = 0; t < pd.T; ++t) sum += src[(size_t)t * per_tile];
+            const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
+            if (row < Rw && col < Rw) {
+                const int gr = grow(row), gc = grow(col);
+                if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -sum);
+            }
+        } else {
+            for (int row = threadIdx.x; row < Rw; row += blockDim.x) {
+                double sum = 0.0;
+                const double *src = a.spart + (size_t)ntl * 256 + row;
+                for (int t = 0; t < pd.T; ++t) sum += src[(size_t)t * per_tile];
+                atomicAdd(&a.y[grow(row)], -sum);
+            }
+        }
+        return;
+    }
     __shared__ double sB[4][36], sAd[4][36], sM[4][36], sg[4][6];
     __shared__ double sgeo[4][kPairGeomFloats];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -421,7 +450,19 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
         double *acc = a.pairacc + (size_t)p * kPairAccStride;
         double *g = sgeo[w];
         // the sums first (they need only the pair index), so their latency runs under the pose loads and the geometry
-        const double accv = lane < 36 ? acc[sym21(lane / 6, lane % 6)] : lane < 42 ? acc[21 + lane - 36] : 0.0;
+        double accv = 0.0;
+        const int vi_ld = lane < 36 ? sym21(lane / 6, lane % 6) : lane < 42 ? 21 + lane - 36 : -1;
+        if (pair_blocks < (int)gridDim.x) {
+            // (k_etile left the tiles' sums side by side: added up here, in the order of the plan's list)
+            if (vi_ld >= 0) {
+                const int R16 = pd.max_rows16, nt = R16 >> 4;
+                const size_t per_tile = sp_tile_doubles(pd.max_rows16, pd.max_tile_pairs), off = (size_t)nt * (nt + 1) / 2 * 256 + R16;
+                for (int q = pd.pp_ptr[p]; q < pd.pp_ptr[p + 1]; ++q) {
+                    const int e = pd.pp_idx[q];
+                    accv += a.spart[(size_t)(e >> 6) * per_tile + off + (size_t)(e & 63) * 32 + vi_ld];
+                }
+            }
+        } else if (vi_ld >= 0) accv = acc[vi_ld];
         if (lane < kPairGeomFloats)                                                              // computed by the Jacobian kernel
             g[lane] = a.prec ? reinterpret_cast<const double *>(a.pairgeo)[(size_t)p * kPairGeomFloats + lane]
                              : (double)a.pairgeo[(size_t)p * kPairGeomFloats + lane];
@@ -444,7 +485,7 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a) {
             sg[w][lane - 36] = accv;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (lane < 27) acc[lane] = 0.0;                 // leave the per-pair sums clear for the next step
+        if (lane < 27 && pair_blocks == (int)gridDim.x) acc[lane] = 0.0;       // leave the per-pair sums clear for the next step
     }
     __syncthreads();
     if (live && lane < 36) {
@@ -1921,47 +1962,6 @@ __global__ __launch_bounds__(256) void k_refine_add(PlanDev pd, StepArgs a) {
 }
 
 // ------------------------------------------------------------------ k_update
-__device__ inline void retract_pose(const float *pin, const float *xi, float *pout) {
-    // poses' = Exp(xi) * G  (groups.py:153-156; so3.h:153-190; se3.h:134-142), in double
-    const double tau[3] = {xi[0], xi[1], xi[2]}, phi[3] = {xi[3], xi[4], xi[5]};
-    const double th2 = phi[0]*phi[0] + phi[1]*phi[1] + phi[2]*phi[2], th = sqrt(th2);
-    double imag, real, c1, c2;
-    if (th < 1e-6) {
-        const double th4 = th2 * th2;
-        imag = 0.5 - th2 / 48.0 + th4 / 3840.0;
-        real = 1.0 - th2 / 8.0 + th4 / 384.0;
-        c1 = 0.5 - th2 / 24.0;
-        c2 = 1.0 / 6.0 - th2 / 120.0;
-    } else {
-        imag = sin(0.5 * th) / th;
-        real = cos(0.5 * th);
-        c1 = (1.0 - cos(th)) / th2;
-        c2 = (th - sin(th)) / (th2 * th);
-    }
-    double qe[4] = {imag * phi[0], imag * phi[1], imag * phi[2], real};
-    double nq = 1.0 / sqrt(qe[0]*qe[0] + qe[1]*qe[1] + qe[2]*qe[2] + qe[3]*qe[3]);
-    for (int c = 0; c < 4; ++c) qe[c] *= nq;
-    const double pxt[3] = {phi[1]*tau[2] - phi[2]*tau[1], phi[2]*tau[0] - phi[0]*tau[2], phi[0]*tau[1] - phi[1]*tau[0]};
-    const double ppt[3] = {phi[1]*pxt[2] - phi[2]*pxt[1], phi[2]*pxt[0] - phi[0]*pxt[2], phi[0]*pxt[1] - phi[1]*pxt[0]};
-    double te[3];
-    for (int c = 0; c < 3; ++c) te[c] = tau[c] + c1 * pxt[c] + c2 * ppt[c];
-    double q[4] = {pin[3], pin[4], pin[5], pin[6]};
-    nq = 1.0 / sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
-    for (int c = 0; c < 4; ++c) q[c] *= nq;
-    const double t[3] = {pin[0], pin[1], pin[2]};
-    double qo[4] = { qe[3]*q[0] + qe[0]*q[3] + qe[1]*q[2] - qe[2]*q[1],
-                     qe[3]*q[1] - qe[0]*q[2] + qe[1]*q[3] + qe[2]*q[0],
-                     qe[3]*q[2] + qe[0]*q[1] - qe[1]*q[0] + qe[2]*q[3],
-                     qe[3]*q[3] - qe[0]*q[0] - qe[1]*q[1] - qe[2]*q[2] };
-    nq = 1.0 / sqrt(qo[0]*qo[0] + qo[1]*qo[1] + qo[2]*qo[2] + qo[3]*qo[3]);
-    double ux = qe[1]*t[2] - qe[2]*t[1], uy = qe[2]*t[0] - qe[0]*t[2], uz = qe[0]*t[1] - qe[1]*t[0];
-    ux += ux; uy += uy; uz += uz;
-    pout[0] = (float)(te[0] + t[0] + qe[3]*ux + (qe[1]*uz - qe[2]*uy));
-    pout[1] = (float)(te[1] + t[1] + qe[3]*uy + (qe[2]*ux - qe[0]*uz));
-    pout[2] = (float)(te[2] + t[2] + qe[3]*uz + (qe[0]*uy - qe[1]*ux));
-    for (int c = 0; c < 4; ++c) pout[3 + c] = (float)(qo[c] * nq);
-}
-
 // One BA step's last kernel.  Block ranges (512 threads each):
 //   [0, tile_blocks)         pose+structure steps only: one block per tile of tracks.  The depth update
 //                            dZ_k = Q_k (w'_k - sum_c E[c,k]^T dX_c) (ba.py:328) is evaluated WITHOUT a stored E:
@@ -2090,36 +2090,6 @@ __global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int 
         return;
     }
     update_rest<SO, !SO>(pd, a, (int)(blockIdx.x - (SO ? 0 : tile_blocks)) * (int)blockDim.x + (int)threadIdx.x, do_poses);
-}
-
-template <bool SO, bool TRACKS_ELSEWHERE>
-__device__ __forceinline__ void update_rest(const PlanDev &pd, const StepArgs &a, int gid, int do_poses) {
-    if (gid < pd.p_tot) {
-        // track of this patch, or -1: bitmap + rank (most of the buffer's patches are not in the window)
-        const unsigned aw = pd.act_bits[gid >> 5], ab = (unsigned)gid & 31u;
-        const bool has = (aw >> ab) & 1u;
-        if (TRACKS_ELSEWHERE && has) return;                            // written by its tile's block
-        const float x = a.patches[3*gid], y = a.patches[3*gid + 1], d = a.patches[3*gid + 2];
-        float dd = d;                                                   // ba.py:333 (whole buffer)
-        if (SO && has) {                                                // ba.py:316-317
-            const int trk = pd.act_rank[gid >> 5] + __popc(aw & ((1u << ab) - 1u));
-            if (a.prec) { const double2 qw = reinterpret_cast<const double2 *>(a.qw)[trk]; dd = (float)((double)d + qw.x * qw.y); }
-            else { const float2 qw = a.qw[trk]; dd = d + qw.x * qw.y; }
-        }
-        dd = dd < 1e-3f ? 1e-3f : dd;
-        dd = dd > 10.0f ? 10.0f : dd;
-        a.patches_out[3*gid] = x; a.patches_out[3*gid + 1] = y; a.patches_out[3*gid + 2] = dd;
-    } else if (do_poses && gid < pd.p_tot + pd.n_buf) {
-        const int p = gid - pd.p_tot;
-        if (SO) {
-            for (int c = 0; c < 7; ++c) a.poses_out[7*p + c] = a.poses[7*p + c];
-        } else {
-            float xi[6] = {0, 0, 0, 0, 0, 0};
-            if (p >= pd.fixedp && p < pd.fixedp + pd.n)
-                for (int c = 0; c < 6; ++c) xi[c] = a.dx[6 * (p - pd.fixedp) + c];
-            retract_pose(a.poses + 7*p, xi, a.poses_out + 7*p);
-        }
-    }
 }
 
 // ------------------------------------------------------------------ k_pack_system
@@ -2270,8 +2240,13 @@ static inline size_t tile_lds_bytes_r(const PlanDev &pd, bool so, size_t rsz, si
 int edge_precision(const PlanDev &pd) {
     static const int env = std::getenv("BT_EDGE_PREC") ? std::atoi(std::getenv("BT_EDGE_PREC")) : 1;   // 0: measurement only
     if (env == 0 || pd.T <= 0 || edge_applies(pd) || stream_applies(pd)) return 0;
+    const int eb = etile_precision_bytes(pd);
+    if (eb) return eb == 8 ? 1 : 0;
     return tile_lds_bytes_r(pd, false, sizeof(double), 8) <= kLdsBudget ? 1 : 0;
 }
+
+// the pair-major tile kernel takes the plan (ba_etile.hip)
+static bool etile_applies(const PlanDev &pd) { return etile_precision_bytes(pd) != 0; }
 
 static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     return tile_lds_bytes_r(pd, so, edge_precision(pd) ? sizeof(double) : sizeof(float), (size_t)tile_threads(pd) / 64);
@@ -2328,7 +2303,7 @@ static int raise_lds_limit(const void *fn, size_t need) {
 }
 
 int configure_kernels(const PlanDev &pd) {
-    const size_t need = tile_lds_bytes(pd, false);
+    const size_t need = etile_applies(pd) ? 0 : tile_lds_bytes(pd, false);
     if (need > kLdsBudget) return BT_EUNSUPPORTED;
     const void *tiles[6] = { reinterpret_cast<const void *>(&k_tile<false, false>), reinterpret_cast<const void *>(&k_tile<false, false, true>),
                              reinterpret_cast<const void *>(&k_tile<false, true>), reinterpret_cast<const void *>(&k_tile<false, true, true>),
@@ -2336,7 +2311,7 @@ int configure_kernels(const PlanDev &pd) {
                              reinterpret_cast<const void *>(&k_tile<false, true, false, false, double>) };
     const bool dbl = edge_precision(pd) != 0;
     for (int i = dbl ? 4 : 0; i < (dbl ? 6 : 4); ++i) if (raise_lds_limit(tiles[i], need) != BT_OK) return BT_EHIP;
-    if (dbl) {
+    if (dbl && !etile_applies(pd)) {
         const size_t nu = ((size_t)pd.max_tile_pairs * kUpdGeo + kUpdThreads) * sizeof(double);
         if (nu > kLdsBudget) return BT_EUNSUPPORTED;
         if (raise_lds_limit(reinterpret_cast<const void *>(&k_update<false, kUpdThreads, double>), nu) != BT_OK) return BT_EHIP;
@@ -2385,6 +2360,21 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         if (ran) *ran |= 1u << 1;
         const int rc = launch_stream(pd, a, so ? 1 : 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
         if (rc != BT_OK) return rc;
+    } else if (pd.T > 0 && etile_applies(pd)) {
+        if (ran) *ran |= 1u << 1;
+        int rc;
+        if (so && fuse_so_poses >= 0 && fused) {
+            const int total = pd.p_tot + (fuse_so_poses ? pd.n_buf : 0), nbr = (total + 511) / 512;
+            rc = launch_etile(pd, a, 1, fuse_so_poses, nbr, 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+            *fused = true;
+        } else if (so) {
+            // split structure-only step (multi-GPU phases, the timed path): the tile blocks only — they leave (Q, w') for the
+            // k_update<true> that follows
+            rc = launch_etile(pd, a, 1, 0, 0, 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+        } else {
+            rc = launch_etile(pd, a, 0, 0, 0, 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
+        }
+        if (rc != BT_OK) return rc;
     } else if (pd.T > 0) {
         const bool wide = tile_wide(pd);
         const dim3 blk(tile_threads(pd)), grid(pd.T);
@@ -2413,8 +2403,11 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         else if (wide)         BT_LAUNCH(1, (k_tile<false, false, true>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
         else                   BT_LAUNCH(1, (k_tile<false, false>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
     }
-    if (!so && pd.P > 0)
-        BT_LAUNCH(2, k_pair_finalize, dim3((pd.P + 3) / 4), dim3(256), 0, pd, a);
+    if (!so && pd.P > 0) {
+        const int pb = (pd.P + 3) / 4, nt16 = pd.max_rows16 >> 4;
+        const int sp_blocks = (pd.T > 0 && etile_applies(pd) && pd.sp_ok) ? nt16 * (nt16 + 1) / 2 + 1 : 0;
+        BT_LAUNCH(2, k_pair_finalize, dim3(pb + sp_blocks), dim3(256), 0, pd, a, pb);
+    }
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 
@@ -2473,6 +2466,12 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int rc = launch_stream(pd, a, 2, st, nullptr, nullptr);
         if (rc != BT_OK) return rc;
         BT_LAUNCH(4, k_update<false>, dim3(nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, 0, nb);
+    }
+    else if (pd.T > 0 && etile_applies(pd)) {
+        if (ran) *ran |= 1u << 4;
+        const int nbe = (total + 511) / 512, zbe = (int)((nz + 4 * 512 - 1) / (4 * 512));
+        const int rc = launch_etile(pd, a, 2, do_poses, nbe, zbe, st, ev ? ev[8] : nullptr, ev ? ev[9] : nullptr);
+        if (rc != BT_OK) return rc;
     }
     else if (a.prec)
         BT_LAUNCH(4, (k_update<false, kUpdThreads, double>), dim3(pd.T + nb + zb), dim3(kUpdThreads), ((size_t)pd.max_tile_pairs * kUpdGeo + kUpdThreads) * sizeof(double), pd, a, do_poses, pd.T, pd.T + nb);

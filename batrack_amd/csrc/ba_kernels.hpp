@@ -20,6 +20,7 @@ struct StepArgs {
     float *lfac, *linv, *zvec, *dx, *dx0;
     float *pairgeo;               // [pairs][kPairGeomFloats]: relative pose of every camera pair, left by k_tile for k_pair_finalize
     int *status;
+    double *spart;                // [tiles][ntl * 256 + max_rows16]: per-tile Schur products of k_etile when the plan's sp_ok (else unused)
     int prec;                     // 1: the per-edge maths, E, pairgeo and qw are float64 (k_tile path, the default there); 0: float32
     int dbg;                      // env BT_DEBUG_MODE, 0 in production: 16 / 32 launch the cycle-counting variants of the solver / k_tile
 };
@@ -35,6 +36,11 @@ int launch_stream(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st
 // the same for slot-uniform graphs in the edge-major layout (ba_stream3.hip)
 bool edge_applies(const PlanDev &pd);
 int launch_edge(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+// the pair-major tile kernel (ba_etile.hip) for the graphs k_tile would take, whenever the plan has the pair-major tables
+// (every tile <= 64 camera pairs) and the tile's E fits LDS: 8 / 4 = as double / only as float, 0 = k_tile takes the plan.
+// launch_etile: mode 0 = pose+structure reduce, 1 = the whole structure-only step, 2 = a pose+structure step's last kernel
+int etile_precision_bytes(const PlanDev &pd);
+int launch_etile(const PlanDev &pd, const StepArgs &a, int mode, int do_poses, int extra_blocks, int zero_blocks, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 // ev != nullptr: a (start, stop) event pair per kernel; *ran gets bit k set for every kernel k that was launched
 // fuse_so_poses >= 0 (and `fused` given): a structure-only step on the k_tile path also does the step's update in the same
 // launch (fuse_so_poses = 1: copy the poses too) and sets *fused; the caller then skips launch_solve_update

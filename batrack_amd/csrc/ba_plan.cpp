@@ -52,6 +52,8 @@ static void layout_workspace(bt_plan *pl) {
     w.dx = off;       off = align_up(off + D * sizeof(float) + 64, 256);
     w.dx0 = off;      off = align_up(off + D * sizeof(float) + 64, 256);     // first solution of a refined solve (float32-factor systems)
     w.status = off;   off = align_up(off + 1024, 256);
+    w.spart = off;
+    if (pl->sp_ok) off = align_up(off + (size_t)I.tiles * sp_tile_doubles(pl->max_rows16, pl->max_tile_pairs) * sizeof(double), 256);
     w.total = off;
     pl->ws = w;
     pl->info.workspace_bytes = (int64_t)w.total;
@@ -240,6 +242,19 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         max_cams = std::max(max_cams, (int)tile_set.size());
         tile_set.clear(); ++epoch; trk0 = trk_end;
     };
+    // Tracks per tile: 64 (one per lane of k_tile), or 16 for the graphs of FEW tiles with DEEP edge lists per track — a sliding
+    // window (batrack.py:399-410: ~2,500 tracks x ~54 edges) is 40 tiles of 64 tracks on a 256-CU part; the pair-major kernel
+    // (k_etile) does not tie a lane to a track, so the same graph is spread over four times as many workgroups.  Plans whose
+    // tiles turn out not to fit that kernel are rebuilt with 64 (tcap_retry).
+    static thread_local int tcap_retry = 0;
+    int tcap = kLanes;
+    {
+        static const int env = std::getenv("BT_TILE_TRACKS") ? std::atoi(std::getenv("BT_TILE_TRACKS")) : 0;     // measurement only
+        static const int pm_env = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;
+        const int64_t t64 = (m + kLanes - 1) / kLanes;
+        if (env > 0) tcap = std::min<int>(kLanes, env);
+        else if (pm_env && !tcap_retry && t64 > 0 && t64 <= 96 && E_own >= 24 * (int64_t)m && t64 < std::min(edge_min_tiles(), stream_min_tiles()) / 4) tcap = 16;
+    }
     for (int32_t k = 0; k < m; ++k) {
         trk_set.clear();
         if (masks_ok) {
@@ -263,7 +278,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         int add = 0;
         for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) ++add;
         const int limit = std::max<int>(kTileCamSoft, (int)trk_set.size());
-        if (k - trk0 >= kLanes || (k > trk0 && (int)tile_set.size() + add > limit)) close_tile(k);
+        if (k - trk0 >= tcap || (k > trk0 && (int)tile_set.size() + add > limit)) close_tile(k);
         for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) { stamp[(size_t)c] = epoch; tile_set.push_back(c); }
     }
     close_tile(m);
@@ -866,6 +881,96 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             pl->em_lgs = lgS[0];
             for (int64_t t = 1; t < I.tiles; ++t) if (lgS[(size_t)t] != pl->em_lgs) { pl->em_lgs = -1; break; }
         }
+    }
+
+    // ---- pair-major layout of the same tiles (k_etile, ba_etile.hip): lane = track_in_iteration * S + s, where s is the LOCAL
+    // PAIR of the tile (S = its pair count padded to a power of two, an iteration = 64 / S consecutive tracks) and the edges a
+    // track has with that pair — repeated observations (batrack.py:399-410 appends a window's factors again every keyframe
+    // step) — are the lane's D ROUNDS.  A lane then keeps one camera pair for the whole tile (the 27 per-pair products are
+    // summed per lane in registers), owns its (track, target camera) element of the local E exclusively (plain store of the
+    // sum over its rounds), and a track's own sums (C, w, source-camera E) are reductions over S adjacent lanes.  Any tile of
+    // at most 64 pairs can be laid out this way (a track that lacks a pair has no edge in that lane).
+    //   pm_edge[(round0 + it * D + d) * 64 + lane]   edge of (tile, iteration it, round d, lane), -1 = none
+    //   pm_rec[t * 4]   = round0, log2 S | D << 8, iterations, 0
+    //   pm_lb[t * 64 + s]   local target camera of local pair s (0xff: fixed, or s >= npair)
+    //   pm_la[t * 64 + l]   local source camera of track l of the tile (0xff: fixed / no track)
+    // pm_ok: 2 = the plan was tiled FOR the pair-major kernel (small tiles) or BT_ETILE=2 forces it, 1 = the tables exist but
+    // k_tile keeps the plan (at one tile per CU, e.g. the 64-keyframe benchmark, k_tile measured 12.7 us against 15.0)
+    pl->pm_ok = I.tiles > 0 ? 1 : 0; pl->pm_rounds = 0;
+    pl->pm_edge.clear(); pl->pm_rec.clear(); pl->pm_lb.clear(); pl->pm_la.clear();
+    {
+        static const int pm_env = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;     // 0: measurement / tests (forces k_tile)
+        if (!pm_env || (pm_env != 2 && tcap == kLanes)) pl->pm_ok = 0;      // (tables only for the plans that will use them)
+        for (int64_t t = 0; t < I.tiles && pl->pm_ok; ++t) if (pl->tile_npair[(size_t)t] > kLanes) pl->pm_ok = 0;
+        if (pl->pm_ok) {
+            pl->pm_rec.assign((size_t)I.tiles * 4, 0);
+            pl->pm_lb.assign((size_t)I.tiles * kLanes, 0xff);
+            pl->pm_la.assign((size_t)I.tiles * kLanes, 0xff);
+            std::vector<int32_t> cnt;                              // edges of (track, local pair) placed so far
+            int64_t rounds = 0;
+            for (int64_t t = 0; t < I.tiles && pl->pm_ok; ++t) {
+                const size_t b0 = (size_t)pl->tile_slot0[(size_t)t] * kLanes;
+                const int32_t ns = pl->tile_nslot[(size_t)t], nt = pl->tile_ntrk[(size_t)t], np = pl->tile_npair[(size_t)t];
+                int lg = 0;
+                while ((1 << lg) < np) ++lg;
+                const int32_t S = 1 << lg, G = kLanes >> lg, nit = (nt + G - 1) / G;
+                // multiplicities
+                cnt.assign((size_t)nt * (size_t)S, 0);
+                int32_t D = 1;
+                for (int32_t k = 0; k < nt; ++k)
+                    for (int32_t sl = 0; sl < ns; ++sl) {
+                        const size_t i = b0 + (size_t)sl * kLanes + (size_t)k;
+                        if (pl->slot_edge[i] < 0) continue;
+                        D = std::max(D, ++cnt[(size_t)k * S + pl->slot_lp[i]]);
+                    }
+                if (D > 255) { pl->pm_ok = 0; break; }
+                pl->pm_rec[(size_t)t * 4] = (int32_t)rounds;
+                pl->pm_rec[(size_t)t * 4 + 1] = lg | (D << 8);
+                pl->pm_rec[(size_t)t * 4 + 2] = nit;
+                pl->pm_edge.resize((size_t)(rounds + (int64_t)nit * D) * kLanes, -1);
+                std::fill(cnt.begin(), cnt.end(), 0);
+                for (int32_t k = 0; k < nt; ++k)
+                    for (int32_t sl = 0; sl < ns; ++sl) {
+                        const size_t i = b0 + (size_t)sl * kLanes + (size_t)k;
+                        if (pl->slot_edge[i] < 0) continue;
+                        const int32_t lp = pl->slot_lp[i], d = cnt[(size_t)k * S + lp]++;
+                        pl->pm_edge[((size_t)rounds + (size_t)(k / G) * D + (size_t)d) * kLanes + (size_t)((k % G) << lg) + (size_t)lp] = pl->slot_edge[i];
+                        pl->pm_lb[(size_t)t * kLanes + (size_t)lp] = (uint8_t)(pl->slot_lab[i] >> 8);
+                        pl->pm_la[(size_t)t * kLanes + (size_t)k] = (uint8_t)(pl->slot_lab[i] & 0xff);
+                    }
+                rounds += (int64_t)nit * D;
+            }
+            pl->pm_rounds = rounds;
+            if (pl->pm_ok && (tcap < kLanes || pm_env == 2)) pl->pm_ok = 2;
+            if (!pl->pm_ok) { pl->pm_edge.clear(); pl->pm_rec.clear(); pl->pm_lb.clear(); pl->pm_la.clear(); }
+        }
+        if (!pl->pm_ok && tcap < kLanes && !tcap_retry) {          // small tiles are for k_etile only: lay the plan out again for k_tile
+            tcap_retry = 1;
+            const int rc = build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed);
+            tcap_retry = 0;
+            return rc;
+        }
+    }
+    // ---- partial Schur sums instead of atomics: when every tile sees the SAME cameras (a sliding window: all tiles' blocks of
+    // E Q E^T land on the same few thousand elements of S, and hundreds of workgroups' float64 atomics on them serialise in the
+    // L2) the pair-major kernel stores its tile's product and k_pair_finalize adds the tiles' products up.
+    pl->sp_ok = 0;
+    if (pl->pm_ok && I.tiles >= 8) {
+        bool same = true;
+        for (int64_t t = 1; t < I.tiles && same; ++t) same = (pl->tile_flags[(size_t)t] & 1) != 0;
+        const int64_t per_tile = (int64_t)sp_tile_doubles(pl->max_rows16, pl->max_tile_pairs);
+        if (same && per_tile * I.tiles * 8 <= ((int64_t)64 << 20)) pl->sp_ok = 1;
+    }
+    pl->pp_ptr.clear(); pl->pp_idx.clear();
+    if (pl->sp_ok) {                                               // which tiles hold sums of which camera pair
+        pl->pp_ptr.assign((size_t)I.pairs + 1, 0);
+        for (size_t q = 0; q < pl->tile_pairs.size(); ++q) pl->pp_ptr[(size_t)pl->tile_pairs[q] + 1]++;
+        for (int64_t p = 0; p < I.pairs; ++p) pl->pp_ptr[(size_t)p + 1] += pl->pp_ptr[(size_t)p];
+        pl->pp_idx.assign(pl->tile_pairs.size(), 0);
+        std::vector<int32_t> cur(pl->pp_ptr.begin(), pl->pp_ptr.end() - 1);
+        for (int64_t t = 0; t < I.tiles; ++t)
+            for (int32_t q = 0; q < pl->tile_npair[(size_t)t]; ++q)
+                pl->pp_idx[(size_t)cur[(size_t)pl->tile_pairs[(size_t)(pl->tile_pair0[(size_t)t] + q)]]++] = (int32_t)(t << 6) | q;
     }
 
     BT_TICK("14");

@@ -20,6 +20,18 @@ constexpr int kLdsRowStride = 66;
 constexpr int kMaxLevelCols = 4;
 constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geometry is kept in LDS    // columns of the reduced system factored concurrently (one critical wave each)   // floats per local E row (bank-conflict-free)
 
+// doubles per tile of StepArgs::spart (plans with sp_ok): the tile's Schur product (ntl lower 16x16 tiles of 256), E Q w'
+// (max_rows16) and its per-pair sums (max_tile_pairs x 32: 27 used)
+#ifdef __HIPCC__
+#define BT_HD __host__ __device__
+#else
+#define BT_HD
+#endif
+BT_HD inline size_t sp_tile_doubles(int max_rows16, int max_tile_pairs) {
+    const size_t nt = (size_t)max_rows16 / 16;
+    return nt * (nt + 1) / 2 * 256 + (size_t)max_rows16 + (size_t)(max_tile_pairs > 0 ? max_tile_pairs : 1) * 32;
+}
+
 // Device-side view: raw pointers into one device allocation + sizes.
 struct PlanDev {
     int E, n_buf, p_tot, fixedp, n_all, n, D, m, P, T, slots, erows, nnzb, nupd, max_rows16;
@@ -43,6 +55,11 @@ struct PlanDev {
     const int32_t *tile_rec;                                 // 8 ints per tile (ba_plan.cpp)
     const int32_t *it_edge;                                  // edge-major layout (ba_plan.cpp): [iterations][64]
     const uint32_t *tile_sinfo;                              // [tiles][64]
+    const int32_t *pm_edge, *pm_rec;                         // pair-major layout (ba_plan.cpp): [rounds][64], [tiles][4]
+    const uint8_t *pm_lb, *pm_la;                            // [tiles][64]: target camera of local pair s / source camera of track l
+    const int32_t *pp_ptr, *pp_idx;                          // sp_ok: the (tile << 6 | local pair) entries of every camera pair, CSR over the pairs
+    int sp_ok;                                               // every tile has the same cameras: k_etile leaves per-tile Schur products (StepArgs::spart)
+    int pm_ok;                                               // the pair-major tables exist (every tile has at most 64 camera pairs)
     int em_self;                                             // some edge has ii == jj (its source-camera E lands on a target row)
     int em_ok, em_its, em_lgs;                               // every tile slot-uniform; total iterations; log2 S if the same for all tiles, else -1
     const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
@@ -59,12 +76,12 @@ struct PlanDev {
 // Byte offsets of the regions inside the caller's workspace.
 struct WsLayout {
     size_t sys, pairacc, zero_bytes;   // [sys, sys+zero_bytes) is cleared every reduce
-    size_t packed, pairgeo, qw, lfac, linv, zvec, dx, dx0, status, total;
+    size_t packed, pairgeo, qw, lfac, linv, zvec, dx, dx0, status, spart, total;
 };
 
 }  // namespace bt
 
-namespace bt { struct PlanOffsets { size_t ab, ar, bc, bs, bss, c0, cams, cl, cp, dp, dpp, e0, fl, flp, fm, fp, fpf, fpm, fpp, fps, fri, fy, ite, kx, lc, lm, lp, pi, pj, pm, ri, s0, sc, se, sl, slp, sn, sp, t0, tc, tc16, tc8, tf, tij, tkx, tla, tn, tnp, tp0, tps, trec, tsi, u, un, up; }; }
+namespace bt { struct PlanOffsets { size_t ab, ar, bc, pme, pmr, pmb, pml, ppp, ppi, bs, bss, c0, cams, cl, cp, dp, dpp, e0, fl, flp, fm, fp, fpf, fpm, fpp, fps, fri, fy, ite, kx, lc, lm, lp, pi, pj, pm, ri, s0, sc, se, sl, slp, sn, sp, t0, tc, tc16, tc8, tf, tij, tkx, tla, tn, tnp, tp0, tps, trec, tsi, u, un, up; }; }
 
 struct bt_plan {
     bt_plan_info info{};
@@ -91,6 +108,11 @@ struct bt_plan {
     std::vector<int32_t> tile_rec, it_edge;
     std::vector<uint32_t> tile_sinfo;
     int em_ok = 0, em_lgs = -1, em_self = 0;
+    std::vector<int32_t> pm_edge, pm_rec;
+    std::vector<uint8_t> pm_lb, pm_la;
+    std::vector<int32_t> pp_ptr, pp_idx;
+    int pm_ok = 0, sp_ok = 0;
+    long long pm_rounds = 0;
     long long em_its = 0;
     int max_tile_pairs = 0, max_tile_slots = 0;
     std::vector<int32_t> col_ptr, row_idx, upd_ptr, upd, blk_col, upd_next;
@@ -120,6 +142,7 @@ struct bt_plan {
                         &bs_sync, &fz_rowinfo, &fz_pfirst, &fz_psecond})
             v->clear();
         tile_cut8.clear(); tile_cut16.clear();
+        pm_edge.clear(); pm_rec.clear(); pm_lb.clear(); pm_la.clear(); pp_ptr.clear(); pp_idx.clear(); pm_ok = 0; sp_ok = 0; pm_rounds = 0;
         slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); it_edge.clear(); tile_sinfo.clear(); em_ok = 0; em_its = 0; em_lgs = -1; act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;
         fz_ok = fzp_ok = 0;

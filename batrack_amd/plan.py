@@ -14,12 +14,12 @@ from . import _lib
 
 _USE_CTYPES = os.environ.get("BT_PY_BINDING", "") == "ctypes"      # measurement only: the ctypes route for every step
 
-_NP_TYPES = {"slot_lab": np.uint16, "slot_lp": np.uint8, "act_bits": np.uint32, "slot_code": np.uint16, "tile_la": np.uint8, "tile_sinfo": np.uint32, "tile_cut8": np.uint16, "tile_cut16": np.uint16}
+_NP_TYPES = {"slot_lab": np.uint16, "slot_lp": np.uint8, "act_bits": np.uint32, "slot_code": np.uint16, "tile_la": np.uint8, "tile_sinfo": np.uint32, "tile_cut8": np.uint16, "tile_cut16": np.uint16, "pm_lb": np.uint8, "pm_la": np.uint8}
 PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0", "tile_ntrk", "tile_ncam",
                "tile_cam0", "tile_slot0", "tile_nslot", "tile_erow0", "tile_cams", "slot_edge", "slot_pair",
                "slot_lab", "col_ptr", "row_idx", "upd_ptr", "upd", "blk_col", "upd_next", "perm", "blk_src",
                "lvl_ptr", "lvl_cols", "col_lvl", "dp_ptr", "dp", "tile_pair0", "tile_npair", "tile_pairs", "slot_lp", "tile_flags",
-               "fz_pend_ptr", "fz_pend", "fz_lazy_ptr", "fz_lazy", "fz_yurg", "fz_meta", "fz_pmeta", "bs_sync", "fz_rowinfo", "fz_pfirst", "fz_psecond", "act_bits", "act_rank", "tile_ij", "tile_kx", "lvl_meta", "slot_code", "tile_la", "tile_rec", "it_edge", "tile_sinfo", "tile_cut8", "tile_cut16")
+               "fz_pend_ptr", "fz_pend", "fz_lazy_ptr", "fz_lazy", "fz_yurg", "fz_meta", "fz_pmeta", "bs_sync", "fz_rowinfo", "fz_pfirst", "fz_psecond", "act_bits", "act_rank", "tile_ij", "tile_kx", "lvl_meta", "slot_code", "tile_la", "tile_rec", "it_edge", "tile_sinfo", "tile_cut8", "tile_cut16", "pm_edge", "pm_rec", "pm_lb", "pm_la")
 
 
 class Plan:
@@ -95,8 +95,8 @@ class Plan:
 
     @property
     def jacobian_kernel(self):
-        """'k_tile' | 'k_stream' | 'k_edge': what the steps of this plan launch (bt_plan_jacobian_kernel)."""
-        return {0: "k_tile", 1: "k_stream", 2: "k_edge"}.get(self._lib.bt_plan_jacobian_kernel(self._h), "host-only")
+        """'k_tile' | 'k_stream' | 'k_edge' | 'k_etile': what the steps of this plan launch (bt_plan_jacobian_kernel)."""
+        return {0: "k_tile", 1: "k_stream", 2: "k_edge", 3: "k_etile"}.get(self._lib.bt_plan_jacobian_kernel(self._h), "host-only")
 
     @property
     def edge_precision(self):

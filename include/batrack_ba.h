@@ -203,8 +203,9 @@ float *bt_ba_dx(const bt_plan *plan, void *workspace);
 int bt_ba_status(const bt_plan *plan, void *workspace, void *stream, int32_t *status);
 
 /* Which Jacobian kernel the steps of this (uploaded) plan launch: 0 = k_tile (one tile per workgroup), 1 = k_stream (two
- * waves per tile, tiles streamed), 2 = k_edge (edge-major, one wave per tile) — chosen from the plan's size and shape
- * (DESIGN.md §4); -1 for a host-only plan.  For tests and tooling. */
+ * waves per tile, tiles streamed), 2 = k_edge (edge-major, one wave per tile), 3 = k_etile (pair-major lanes, one tile of 16
+ * tracks per workgroup: sliding-window graphs) — chosen from the plan's size and shape; -1 for a host-only
+ * plan.  For tests and tooling. */
 int bt_plan_jacobian_kernel(const bt_plan *plan);
 /* Precision of the per-edge maths (reprojection, Jacobians, robust weights, the products they enter, E) of this plan's
  * steps: 8 = float64 on the float32 inputs — every plan that takes k_tile and whose tiles' E fits LDS as double (up to

@@ -45,10 +45,11 @@ def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so):
 
 FORCED = {"k_edge": dict(BT_EDGE_MIN_TILES="1", BT_EDGE_PREF_TILES="1", BT_STREAM_MIN_TILES="1"),      # wherever the tiles are slot-uniform
           "k_stream": dict(BT_EDGE_OFF="1", BT_STREAM_MIN_TILES="1"),
-          "k_tile": dict(BT_EDGE_OFF="1", BT_STREAM_MIN_TILES="100000000")}
+          "k_tile": dict(BT_EDGE_OFF="1", BT_STREAM_MIN_TILES="100000000", BT_ETILE="0"),
+          "k_etile": dict(BT_EDGE_OFF="1", BT_STREAM_MIN_TILES="100000000", BT_ETILE="2")}       # the pair-major tile kernel for every plan
 
 
-@pytest.mark.parametrize("kernel", ["k_edge", "k_stream", "k_tile"])
+@pytest.mark.parametrize("kernel", ["k_edge", "k_stream", "k_tile", "k_etile"])
 def test_parity_suite_with_the_selection_forced(kernel):
     env = dict(os.environ, **FORCED[kernel])
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_solver_variants.py", "-x", "-q", "-m", "gpu",

@@ -289,3 +289,74 @@ def test_wave_cuts_partition_the_slots_and_avoid_runs(name):
                     lo, hi = max(cut[w - 1], min(ns, w * chunk) - chunk), min(ns, min(ns, w * chunk) + chunk)
                     assert crossed[max(lo, 1):hi].all() or c == cut[w - 1], (t, W, w, c)     # nothing better was in reach
     assert total_cuts > 0
+
+
+PM_SCRIPT = r"""
+import sys
+import numpy as np
+from batrack_amd import graphgen
+from batrack_amd.plan import Plan
+kind = sys.argv[1]
+if kind == "c1":
+    g, fixedp = graphgen.make_config("C1", seed=0), 1
+elif kind == "c3":
+    g, fixedp = graphgen.make_config("C3", seed=0), 1
+elif kind == "window":
+    g, fixedp = graphgen.make_window_graph(n_frames=30, M=48, seed=2)
+else:
+    g, fixedp = graphgen.make_random_graph(20, 30, seed=4, far_frac=0.3, groups=2), 2
+pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], fixedp, upload=False)
+A = pl.arrays()
+rec = A["pm_rec"].reshape(-1, 4)
+assert rec.shape[0] == pl.tiles and A["pm_edge"].size % 64 == 0
+pm_edge = A["pm_edge"].reshape(-1, 64)
+seen = np.zeros(len(g.ii), np.int64)
+lp_of, lab_of = {}, {}
+se, lab, slp = A["slot_edge"], A["slot_lab"], A["slot_lp"]
+for i in np.flatnonzero(se >= 0):
+    lp_of[int(se[i])] = int(slp[i]); lab_of[int(se[i])] = int(lab[i])
+for t in range(pl.tiles):
+    r0, lg, D, nit = int(rec[t, 0]), int(rec[t, 1]) & 0xff, int(rec[t, 1]) >> 8, int(rec[t, 2])
+    S, G = 1 << lg, 64 >> lg
+    assert S >= int(A["tile_npair"][t]) and nit == (int(A["tile_ntrk"][t]) + G - 1) // G
+    mult = {}
+    for it in range(nit):
+        for d in range(D):
+            row = pm_edge[r0 + it * D + d]
+            for lane in np.flatnonzero(row >= 0):
+                e = int(row[lane])
+                s, track = lane & (S - 1), it * G + (lane >> lg)
+                seen[e] += 1
+                assert lp_of[e] == s
+                assert int(A["kx"][int(A["tile_trk0"][t]) + track]) == int(g.kk[e])
+                assert int(A["pm_lb"][t * 64 + s]) == lab_of[e] >> 8 and int(A["pm_la"][t * 64 + track]) == lab_of[e] & 0xff
+                mult[(track, s)] = mult.get((track, s), 0) + 1
+    assert D == max(max(mult.values(), default=1), 1)
+assert np.all(seen == 1)
+print("PM_OK", pl.tiles)
+"""
+
+
+@pytest.mark.parametrize("kind", ["c1", "window", "random", "c3"])
+def test_pair_major_tables_cover_every_edge_once(kind):
+    """The pair-major layout of k_etile (ba_plan.cpp; BT_ETILE=2 builds it for every plan, read once per process): every edge
+    of the list sits in exactly one (tile, iteration, round, lane); the lane's local pair is the edge's pair, its track the
+    edge's track; pm_lb / pm_la are the local target / source cameras the track-major tables give the same edge; the number
+    of rounds is the largest multiplicity of a (track, pair)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", PM_SCRIPT, kind], cwd=root, env=dict(os.environ, BT_ETILE="2", PYTHONPATH=root),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_window_plans_are_tiled_for_the_pair_major_kernel():
+    """A sliding-window edge list (few tiles of 64 tracks, deep edge lists) is laid out in tiles of 16 tracks with the
+    pair-major tables; the 64-keyframe benchmark graph keeps its 64-track tiles."""
+    g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
+    pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], fixedp, upload=False)
+    assert int(pl.array("tile_ntrk").max()) == 16 and pl.tiles == 160 and pl.array("pm_rec").size == 4 * pl.tiles
+    g = graphgen.make_config("C3", seed=0)
+    pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
+    assert int(pl.array("tile_ntrk").max()) == 64 and pl.tiles == 256 and pl.array("pm_rec").size == 0
