@@ -351,7 +351,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
     if (!pl) return BT_ENOMEM;
     int rc = BT_OK;
     try {
-        rc = build_plan_host(packed ? nullptr : ii, packed ? nullptr : jj, packed ? nullptr : kk, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed);
+        rc = build_plan_host(packed ? nullptr : ii, packed ? nullptr : jj, packed ? nullptr : kk, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, /*keep_slots=*/!upload);
         tick("host analysis");
         if (rc == BT_OK && upload) rc = upload_plan(pl, packed ? pack_buffers().d_words : nullptr);
     } catch (const std::bad_alloc &) {

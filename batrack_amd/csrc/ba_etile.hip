@@ -494,13 +494,10 @@ static size_t etile_lds_bytes(const PlanDev &pd, int mode, size_t rsz) {
     const size_t mtp = (size_t)(pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1);
     if (mode == kEtUpd) return mtp * kEtGeoUpd * rsz + 64;
     if (mode == kEtSO) return mtp * kPairGeomFloats * rsz + 64;
-    const size_t rows = (size_t)pd.max_rows16;
-    size_t smax = 1;
-    while (smax < mtp) smax <<= 1;
-    return (size_t)(kEtWaves / 2) * 26 * smax * sizeof(double) + (rows * kLdsRowStride + 128 + mtp * kPairGeomFloats) * rsz + rows * sizeof(int) + 64;
+    return etile_full_lds_bytes(pd.max_rows16, pd.max_tile_pairs, rsz);
 }
 
-constexpr size_t kEtLdsBudget = 160 * 1024 - 512;
+constexpr size_t kEtLdsBudget = kEtileLdsBudget;
 
 // 8: the tiles' E fits LDS as double, 4: only as float, 0: k_etile does not take this plan
 int etile_precision_bytes(const PlanDev &pd) {

@@ -73,7 +73,7 @@ int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
 int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk64, int64_t E,
                     int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
-                    int64_t own_lo, int64_t own_hi, bt_plan *pl, const uint64_t *packed) {
+                    int64_t own_lo, int64_t own_hi, bt_plan *pl, const uint64_t *packed, bool keep_slots) {
     if (E < 0 || n_buf <= 0 || p_tot <= 0 || fixedp < 0 || n_all_min < 0 || n_all_min > n_buf) return BT_EINVAL;
     if (E > (int64_t)0x7fffffff / 2 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;
     if (n_buf > 32768) return BT_EUNSUPPORTED;             // frame numbers are packed in pairs into signed 32-bit words (tile_ij)
@@ -289,10 +289,25 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     BT_TICK("6");
     // ---- per tile: its distinct camera pairs (their relative pose is computed once per tile), then the slot arrays
     // [slots][64] with the local pair index of every edge, in one walk over the tile's edges
-    pl->slot_edge.assign((size_t)slots * kLanes, -1);
-    pl->slot_pair.assign((size_t)slots * kLanes, 0);
-    pl->slot_lab.assign((size_t)slots * kLanes, 0xffff);
-    pl->slot_lp.assign((size_t)slots * kLanes, 0);
+    // (a plan tiled for k_etile — tcap < 64 — gets its pair-major tables straight from the tracks' edge lists here; the
+    //  [slots][64] arrays of k_tile, three quarters of them padding at 16 tracks per tile, are then built only on request:
+    //  host-only plans, which the tests' emulator executes)
+    const bool want_slots = tcap == kLanes || keep_slots;
+    const bool pm_direct = tcap < kLanes;
+    bool pm_fail = false;
+    int64_t pm_rounds_acc = 0;
+    std::vector<int32_t> pm_cnt;
+    if (pm_direct) {
+        pl->pm_rec.assign((size_t)T * 4, 0);
+        pl->pm_lb.assign((size_t)T * kLanes, 0xff);
+        pl->pm_la.assign((size_t)T * kLanes, 0xff);
+        pl->pm_edge.clear();
+        pl->pm_edge.reserve((size_t)E_own * 2 + (size_t)T * kLanes * 4);      // (one allocation: the table grows tile by tile)
+    }
+    pl->slot_edge.assign(want_slots ? (size_t)slots * kLanes : 0, -1);
+    pl->slot_pair.assign(want_slots ? (size_t)slots * kLanes : 0, 0);
+    pl->slot_lab.assign(want_slots ? (size_t)slots * kLanes : 0, 0xffff);
+    pl->slot_lp.assign(want_slots ? (size_t)slots * kLanes : 0, 0);
     pl->tile_pair0.assign((size_t)T, 0); pl->tile_npair.assign((size_t)T, 0);
     pl->tile_pairs.clear();
     pl->max_tile_pairs = 0;
@@ -331,7 +346,40 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             std::sort(mine.begin(), mine.end());
             if ((int)mine.size() > kMaxTilePairs) return BT_EUNSUPPORTED;
             for (size_t q = 0; q < mine.size(); ++q) lp_of[(size_t)mine[q]] = (int32_t)q;
-            for (int32_t l = 0; l < nt; ++l) {
+            if (pm_direct && !pm_fail) {
+                // pair-major tables of this tile (layout: the block further down that builds them from the slot arrays)
+                const int32_t np = (int32_t)mine.size();
+                if (np > kLanes) pm_fail = true;
+                else {
+                    int lg = 0;
+                    while ((1 << lg) < np) ++lg;
+                    const int32_t S = 1 << lg, G = kLanes >> lg, nit = (nt + G - 1) / G;
+                    pm_cnt.assign((size_t)nt * (size_t)S, 0);
+                    int32_t D = 1;
+                    for (int32_t l = 0; l < nt; ++l)
+                        for (int32_t sidx = off[(size_t)(t0 + l)]; sidx < off[(size_t)(t0 + l) + 1]; ++sidx)
+                            D = std::max(D, ++pm_cnt[(size_t)l * S + lp_of[(size_t)pair_id(ord[(size_t)sidx])]]);
+                    if (D > 255) pm_fail = true;
+                    else {
+                        pl->pm_rec[(size_t)t * 4] = (int32_t)pm_rounds_acc;
+                        pl->pm_rec[(size_t)t * 4 + 1] = lg | (D << 8);
+                        pl->pm_rec[(size_t)t * 4 + 2] = nit;
+                        pl->pm_edge.resize((size_t)(pm_rounds_acc + (int64_t)nit * D) * kLanes, -1);
+                        std::fill(pm_cnt.begin(), pm_cnt.end(), 0);
+                        for (int32_t l = 0; l < nt; ++l)
+                            for (int32_t sidx = off[(size_t)(t0 + l)]; sidx < off[(size_t)(t0 + l) + 1]; ++sidx) {
+                                const int32_t e = ord[(size_t)sidx];
+                                const int64_t a2 = II(e) - fixedp, b2 = JJ(e) - fixedp;
+                                const int32_t lp = lp_of[(size_t)pair_id(e)], d = pm_cnt[(size_t)l * S + lp]++;
+                                pl->pm_edge[((size_t)pm_rounds_acc + (size_t)(l / G) * D + (size_t)d) * kLanes + (size_t)((l % G) << lg) + (size_t)lp] = e;
+                                pl->pm_lb[(size_t)t * kLanes + (size_t)lp] = b2 >= 0 ? (uint8_t)local[(size_t)b2] : 0xff;
+                                pl->pm_la[(size_t)t * kLanes + (size_t)l] = a2 >= 0 ? (uint8_t)local[(size_t)a2] : 0xff;
+                            }
+                        pm_rounds_acc += (int64_t)nit * D;
+                    }
+                }
+            }
+            for (int32_t l = 0; l < nt && want_slots; ++l) {
                 const int32_t k = t0 + l;
                 uint16_t lb_before = 0xff;
                 for (int32_t sidx = off[(size_t)k]; sidx < off[(size_t)k + 1]; ++sidx) {
@@ -350,7 +398,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                     lb_before = lb;
                 }
             }
-            for (int W = 8; W <= 16; W += 8) {
+            for (int W = 8; W <= 16 && want_slots; W += 8) {
                 uint16_t *cut = (W == 8 ? pl->tile_cut8.data() + (size_t)t * 9 : pl->tile_cut16.data() + (size_t)t * 17);
                 const int32_t chunk = (ns_t + W - 1) / W;
                 int32_t prev = 0;
@@ -897,8 +945,19 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // pm_ok: 2 = the plan was tiled FOR the pair-major kernel (small tiles) or BT_ETILE=2 forces it, 1 = the tables exist but
     // k_tile keeps the plan (at one tile per CU, e.g. the 64-keyframe benchmark, k_tile measured 12.7 us against 15.0)
     pl->pm_ok = I.tiles > 0 ? 1 : 0; pl->pm_rounds = 0;
-    pl->pm_edge.clear(); pl->pm_rec.clear(); pl->pm_lb.clear(); pl->pm_la.clear();
-    {
+    if (pm_direct) {
+        // (built tile by tile above) — the plan stays with k_etile only if that kernel's LDS need fits in float64
+        if (pm_fail || I.tiles <= 0 || etile_full_lds_bytes(pl->max_rows16, pl->max_tile_pairs, sizeof(double)) > kEtileLdsBudget) {
+            pl->pm_ok = 0;
+            pl->pm_edge.clear(); pl->pm_rec.clear(); pl->pm_lb.clear(); pl->pm_la.clear();
+        } else {
+            pl->pm_ok = 2;
+            pl->pm_rounds = pm_rounds_acc;
+        }
+    } else {
+        pl->pm_edge.clear(); pl->pm_rec.clear(); pl->pm_lb.clear(); pl->pm_la.clear();
+    }
+    if (!pm_direct) {
         static const int pm_env = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;     // 0: measurement / tests (forces k_tile)
         if (!pm_env || (pm_env != 2 && tcap == kLanes)) pl->pm_ok = 0;      // (tables only for the plans that will use them)
         for (int64_t t = 0; t < I.tiles && pl->pm_ok; ++t) if (pl->tile_npair[(size_t)t] > kLanes) pl->pm_ok = 0;
@@ -944,9 +1003,11 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             if (pl->pm_ok && (tcap < kLanes || pm_env == 2)) pl->pm_ok = 2;
             if (!pl->pm_ok) { pl->pm_edge.clear(); pl->pm_rec.clear(); pl->pm_lb.clear(); pl->pm_la.clear(); }
         }
+    }
+    {
         if (!pl->pm_ok && tcap < kLanes && !tcap_retry) {          // small tiles are for k_etile only: lay the plan out again for k_tile
             tcap_retry = 1;
-            const int rc = build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed);
+            const int rc = build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots);
             tcap_retry = 0;
             return rc;
         }

@@ -32,6 +32,17 @@ BT_HD inline size_t sp_tile_doubles(int max_rows16, int max_tile_pairs) {
     return nt * (nt + 1) / 2 * 256 + (size_t)max_rows16 + (size_t)(max_tile_pairs > 0 ? max_tile_pairs : 1) * 32;
 }
 
+// LDS bytes of k_etile's pose+structure instantiation (ba_etile.hip) for a plan whose largest tile has max_rows16 rows of E
+// and max_tile_pairs camera pairs, with per-edge numbers of rsz bytes: the planner lays a plan out for that kernel only if
+// this fits (kEtileLdsBudget)
+constexpr size_t kEtileLdsBudget = 160 * 1024 - 512;
+BT_HD inline size_t etile_full_lds_bytes(int max_rows16, int max_tile_pairs, size_t rsz) {
+    const size_t mtp = (size_t)(max_tile_pairs > 0 ? max_tile_pairs : 1), rows = (size_t)max_rows16;
+    size_t smax = 1;
+    while (smax < mtp) smax <<= 1;
+    return (size_t)4 * 26 * smax * sizeof(double) + (rows * kLdsRowStride + 128 + mtp * kPairGeomFloats) * rsz + rows * sizeof(int) + 64;
+}
+
 // Device-side view: raw pointers into one device allocation + sizes.
 struct PlanDev {
     int E, n_buf, p_tot, fixedp, n_all, n, D, m, P, T, slots, erows, nnzb, nupd, max_rows16;
@@ -163,7 +174,7 @@ int stream_min_tiles();
 // `packed` (optional): the edges as 8-byte words kk << 32 | ii << 16 | jj, already range-checked (ii / jj / kk are then not read)
 int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
                     int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
-                    int64_t own_lo, int64_t own_hi, bt_plan *plan, const uint64_t *packed = nullptr);
+                    int64_t own_lo, int64_t own_hi, bt_plan *plan, const uint64_t *packed = nullptr, bool keep_slots = false);
 // the same packing on the device (plan_pack.hip): `out` E words and `bad` one int (set to 1 on an index out of range), device memory
 int launch_shift_match(const uint64_t *nw, const uint64_t *ow, int64_t E, int *out, void *stream);
 int launch_plan_shift(int32_t *kx, int m, int32_t *tile_kx, int nkx, int32_t *tile_ij, int nij, int32_t *pair_i, int32_t *pair_j, int P,
