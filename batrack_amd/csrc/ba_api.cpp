@@ -13,7 +13,7 @@
 
 #include "ba_kernels.hpp"
 
-#define BT_VERSION 202
+#define BT_VERSION 203
 
 namespace bt {
 

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
                 R Ca = sv[0] + pm * (R)a.alpha;
                 Ca = Ca + (R)(a.lmbda_trk ? a.lmbda_trk[trk] : a.lmbda);
                 const R wp = sv[1] - pm * (R)a.alpha * (pdisp - mono_v);
-                const R Q = (R)1 / Ca;
+                const R Q = sizeof(R) == 8 ? (R)frcp((double)Ca) : (R)1 / Ca;      // (float64: seed + two Newton steps, < 1e-15; the IEEE divide is ~30 instructions)
                 if constexpr (MODE == kEtSO) {                                        // ba.py:316-317, :333
                     R2 qw2; qw2.x = Q; qw2.y = wp;
                     reinterpret_cast<R2 *>(a.qw)[trk] = qw2;                          // (for a k_update<true> behind a split step)

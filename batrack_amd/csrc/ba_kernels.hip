@@ -34,6 +34,8 @@
 
 namespace bt {
 
+__device__ __forceinline__ double dpp_add8(double v);     // (defined with the solver's helpers below)
+
 // ------------------------------------------------------------------ k_tile
 // One workgroup of 8 waves per tile of <= 64 tracks; lane l of every wave owns track l.
 // Wave w takes a contiguous chunk of the tile's edge slots (one slot each on the
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? 2 :
                 R Ca = C + pm * (R)a.alpha;
                 Ca = Ca + (R)(a.lmbda_trk ? a.lmbda_trk[trk] : a.lmbda);
                 wp = wv - pm * (R)a.alpha * (pdisp - mono);
-                Q = (R)1 / Ca;
+                Q = sizeof(R) == 8 ? (R)frcp((double)Ca) : (R)1 / Ca;      // (float64: seed + two Newton steps, < 1e-15; the IEEE divide is ~30 instructions)
                 if (FUSE) {                                                // ba.py:316-317, :333
                     float dd = (float)(pdisp + Q * wp);
                     dd = dd < 1e-3f ? 1e-3f : dd;
@@ -350,6 +352,18 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? 2 :
         // its atomics — and 8x the dX error on the reference's ill-conditioned 8-frame case, for S and for y alike).
         // The wave of a diagonal tile has the rows of E it needs for E (Q w'), the Schur term of y (ba.py:311), in
         // registers: one more product with beta = Q w' in every column of B, column 0 of the result emitted.
+        // E (Q w'), the Schur term of y (ba.py:311): every row of E against beta = Q w', eight threads per row on the vector
+        // pipe, float64 (it used to be a second product of the diagonal tiles' waves on the matrix pipe: 16 more f64 MFMAs on
+        // three of the eight waves — the tile's critical path at one tile per CU)
+        for (int row = tid >> 3; row < Rw; row += nthr >> 3) {
+            const int part = tid & 7;
+            const R *er = Eh + row * kLdsRowStride + part;
+            double s8 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s8 += (double)er[8 * k] * (double)Qs[64 + part + 8 * k];
+            s8 = dpp_add8(s8);
+            if (part == 0) atomicAdd(&a.y[gidx[row]], -s8);
+        }
         const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
         for (int t = wave; t < ntl; t += kTileWaves) {
             int ti = 0, base = 0;
@@ -372,17 +386,6 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? 2 :
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + kq + 4 * r;
                 if (gc >= 0 && row < Rw) { const int gr = gidx[row]; if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -acc[r]); }
-            }
-            if (ti == tj) {
-                double4_t yt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks)
-                    yt = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[ks], (double)qr[64 + 4 * ks], yt, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + kq + 4 * r;
-                    if (li == 0 && row < Rw) atomicAdd(&a.y[gidx[row]], -yt[r]);
-                }
             }
         }
         BT_PF(6);

@@ -297,6 +297,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     bool pm_fail = false;
     int64_t pm_rounds_acc = 0;
     std::vector<int32_t> pm_cnt;
+    static thread_local std::vector<uint32_t> pm_code;
     if (pm_direct) {
         pl->pm_rec.assign((size_t)T * 4, 0);
         pl->pm_lb.assign((size_t)T * kLanes, 0xff);
@@ -355,25 +356,34 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                     while ((1 << lg) < np) ++lg;
                     const int32_t S = 1 << lg, G = kLanes >> lg, nit = (nt + G - 1) / G;
                     pm_cnt.assign((size_t)nt * (size_t)S, 0);
+                    // one walk over the tile's edges (each a random access into the packed edge list): local pair, local
+                    // cameras and the round of every edge; the table is filled from these codes
+                    const int32_t q0 = off[(size_t)t0], q1 = off[(size_t)(t0 + nt)];
+                    pm_code.resize((size_t)(q1 - q0));
                     int32_t D = 1;
                     for (int32_t l = 0; l < nt; ++l)
-                        for (int32_t sidx = off[(size_t)(t0 + l)]; sidx < off[(size_t)(t0 + l) + 1]; ++sidx)
-                            D = std::max(D, ++pm_cnt[(size_t)l * S + lp_of[(size_t)pair_id(ord[(size_t)sidx])]]);
+                        for (int32_t sidx = off[(size_t)(t0 + l)]; sidx < off[(size_t)(t0 + l) + 1]; ++sidx) {
+                            const int32_t e = ord[(size_t)sidx];
+                            const int64_t i = II(e), j = JJ(e), a2 = i - fixedp, b2 = j - fixedp;
+                            const int32_t lp = lp_of[(size_t)pair_of[(size_t)((i - f_lo) * nw + (j - f_lo))]];
+                            const int32_t d = pm_cnt[(size_t)l * S + lp]++;
+                            D = std::max(D, d + 1);
+                            const uint32_t la = a2 >= 0 ? (uint32_t)local[(size_t)a2] : 0xffu, lb = b2 >= 0 ? (uint32_t)local[(size_t)b2] : 0xffu;
+                            pm_code[(size_t)(sidx - q0)] = (uint32_t)lp | (la << 8) | (lb << 16) | ((uint32_t)std::min(d, 255) << 24);
+                        }
                     if (D > 255) pm_fail = true;
                     else {
                         pl->pm_rec[(size_t)t * 4] = (int32_t)pm_rounds_acc;
                         pl->pm_rec[(size_t)t * 4 + 1] = lg | (D << 8);
                         pl->pm_rec[(size_t)t * 4 + 2] = nit;
                         pl->pm_edge.resize((size_t)(pm_rounds_acc + (int64_t)nit * D) * kLanes, -1);
-                        std::fill(pm_cnt.begin(), pm_cnt.end(), 0);
                         for (int32_t l = 0; l < nt; ++l)
                             for (int32_t sidx = off[(size_t)(t0 + l)]; sidx < off[(size_t)(t0 + l) + 1]; ++sidx) {
-                                const int32_t e = ord[(size_t)sidx];
-                                const int64_t a2 = II(e) - fixedp, b2 = JJ(e) - fixedp;
-                                const int32_t lp = lp_of[(size_t)pair_id(e)], d = pm_cnt[(size_t)l * S + lp]++;
-                                pl->pm_edge[((size_t)pm_rounds_acc + (size_t)(l / G) * D + (size_t)d) * kLanes + (size_t)((l % G) << lg) + (size_t)lp] = e;
-                                pl->pm_lb[(size_t)t * kLanes + (size_t)lp] = b2 >= 0 ? (uint8_t)local[(size_t)b2] : 0xff;
-                                pl->pm_la[(size_t)t * kLanes + (size_t)l] = a2 >= 0 ? (uint8_t)local[(size_t)a2] : 0xff;
+                                const uint32_t c = pm_code[(size_t)(sidx - q0)];
+                                const int32_t lp = (int32_t)(c & 0xffu), d = (int32_t)(c >> 24);
+                                pl->pm_edge[((size_t)pm_rounds_acc + (size_t)(l / G) * D + (size_t)d) * kLanes + (size_t)((l % G) << lg) + (size_t)lp] = ord[(size_t)sidx];
+                                pl->pm_lb[(size_t)t * kLanes + (size_t)lp] = (uint8_t)((c >> 16) & 0xffu);
+                                pl->pm_la[(size_t)t * kLanes + (size_t)l] = (uint8_t)((c >> 8) & 0xffu);
                             }
                         pm_rounds_acc += (int64_t)nit * D;
                     }

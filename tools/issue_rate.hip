@@ -44,9 +44,8 @@ int main() {
     const int iters = 4096;
     const char *names[4] = {"v_fma_f32", "v_fma_f64", "v_pk_fma_f32", "v_add_f32_dpp"};
     for (int kind = 0; kind < 4; ++kind)
-        for (int cfg = 0; cfg < 5; ++cfg) {
-            // the last configuration fills every CU with two 1024-thread workgroups: 8 waves per SIMD
-            const int threads = cfg == 0 ? 64 : cfg == 1 ? 256 : cfg == 2 ? 512 : 1024, grid = cfg == 4 ? 512 : 1;
+        for (int cfg = 0; cfg < 4; ++cfg) {
+            const int threads = cfg == 0 ? 64 : cfg == 1 ? 256 : cfg == 2 ? 512 : 1024, grid = 1;
             long long hc = 0;
             for (int rep = 0; rep < 3; ++rep) {
                 if (kind == 0) hipLaunchKernelGGL(k_issue<0>, dim3(grid), dim3(threads), 0, 0, dout, dcyc, iters);
@@ -57,7 +56,7 @@ int main() {
                 CK(hipMemcpy(&hc, dcyc, 8, hipMemcpyDeviceToHost));
             }
             const double per = (double)hc / ((double)iters * 16.0);
-            const int wps = cfg == 4 ? 8 : threads <= 256 ? 1 : threads / 256;
+            const int wps = threads <= 256 ? 1 : threads / 256;
             printf("%-14s %4d threads (%d wave%s per SIMD): %.2f cycles per wave64 instruction as seen by one wave -> %.2f cycles of SIMD time per instruction\n",
                    names[kind], threads, wps, wps > 1 ? "s" : "", per, per / wps);
         }
