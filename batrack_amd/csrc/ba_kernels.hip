@@ -2212,7 +2212,7 @@ int launch_xchg_push(const PlanDev &pd, const StepArgs &a, void *const *bufs, in
 int launch_xchg_pull(const PlanDev &pd, const StepArgs &a, void *own, int world, long long epoch, hipStream_t st) {
     const int total = pd.nnzb * 36 + pd.D;
     if (total <= 0) return BT_OK;
-    static const long long limit = std::getenv("BT_XCHG_SPIN_LIMIT") ? std::atoll(std::getenv("BT_XCHG_SPIN_LIMIT")) : 20000000ll;   // ~10 s of s_sleep(8) polls
+    static const long long limit = std::getenv("BT_XCHG_SPIN_LIMIT") ? std::atoll(std::getenv("BT_XCHG_SPIN_LIMIT")) : 2000000ll;   // a few seconds of polls (each an uncached load + s_sleep)
     const int nb = std::min(64, (total + 255) / 256);
     hipLaunchKernelGGL(k_xchg_pull, dim3(nb), dim3(256), 0, st, pd, a, static_cast<double *>(own), world, epoch, limit);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;

@@ -99,33 +99,49 @@ class ShardedBA:
             self._open_exchange()
 
     def _open_exchange(self):
-        """The rank's exchange buffer and the peers' buffers mapped into this process (once per engine)."""
+        """The rank's exchange buffer and the peers' buffers mapped into this process (once per engine).  Every rank runs
+        the same collectives whatever happens locally (a rank that cannot allocate or map still takes part in the
+        all-gather and in the verdict), so a failure raises on ALL ranks together instead of leaving the others waiting."""
         import ctypes
         from . import _lib
         L = self.stepper._lib
         if self.world > 16:
             raise RuntimeError("exchange='ipc' supports up to 16 ranks")
+        on_dev = dist.get_backend(self.group) != "gloo"
+        err = None
+        buf, handle, opened = ctypes.c_void_p(), ctypes.create_string_buffer(64), []
+        ptrs = (ctypes.c_void_p * self.world)()
         with torch.cuda.device(self.device):
-            nbytes = L.bt_xchg_bytes(self.plan.handle, self.world)
-            buf, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
-            _lib.check(L.bt_xchg_alloc(nbytes, ctypes.byref(buf), handle), "bt_xchg_alloc")
+            try:
+                nbytes = L.bt_xchg_bytes(self.plan.handle, self.world)
+                _lib.check(L.bt_xchg_alloc(nbytes, ctypes.byref(buf), handle), "bt_xchg_alloc")
+            except Exception as e:                                        # noqa: BLE001
+                err = e
             mine = torch.frombuffer(bytearray(handle.raw), dtype=torch.uint8).clone()
-            # the one collective of this path: 64 bytes per rank, once (on the host for a gloo group, on the device for nccl)
-            on_dev = dist.get_backend(self.group) != "gloo"
+            # the one data collective of this path: 64 bytes per rank, once (on the host for a gloo group, on the device for nccl)
             mine = mine.to(self.device) if on_dev else mine
             allh = [torch.empty_like(mine) for _ in range(self.world)]
             dist.all_gather(allh, mine, group=self.group)
-            ptrs = (ctypes.c_void_p * self.world)()
-            opened = []
-            for r in range(self.world):
-                if r == self.rank:
-                    ptrs[r] = buf.value
-                else:
-                    p = ctypes.c_void_p()
-                    _lib.check(L.bt_xchg_open(bytes(allh[r].cpu().numpy().tobytes()), ctypes.byref(p)), f"bt_xchg_open (rank {r})")
-                    ptrs[r] = p.value
-                    opened.append(p)
-            dist.barrier(group=self.group)            # nobody pushes before everybody has mapped
+            if err is None:
+                try:
+                    for r in range(self.world):
+                        if r == self.rank:
+                            ptrs[r] = buf.value
+                        else:
+                            p = ctypes.c_void_p()
+                            _lib.check(L.bt_xchg_open(bytes(allh[r].cpu().numpy().tobytes()), ctypes.byref(p)), f"bt_xchg_open (rank {r})")
+                            ptrs[r] = p.value
+                            opened.append(p)
+                except Exception as e:                                    # noqa: BLE001
+                    err = e
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=self.device if on_dev else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)  # (also the barrier: nobody pushes before everybody has mapped)
+        if int(ok.item()) == 0:
+            for p in opened:
+                L.bt_xchg_close(p)
+            if buf.value:
+                L.bt_xchg_free(buf)
+            raise RuntimeError(f"exchange='ipc' could not be set up on every rank (this rank: {err!r})")
         self._xbuf, self._peers, self._opened = buf, ptrs, opened
 
     def close(self):

@@ -12,7 +12,7 @@ from batrack_amd.plan import Plan, Stepper
 
 dev = "cuda:0"
 for M in [int(x) for x in (sys.argv[1:] or ["256", "1024", "4096", "16384"])]:
-    g = graphgen.make_graph(64, M, 8, seed=0)
+    g = graphgen.make_graph(64, M, int(os.environ.get("BT_SWEEP_K", "8")), seed=0)      # BT_SWEEP_K: observations per track (default 8)
     f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
     poses, patches, mono, intr, t3, w = f32(g.poses), f32(g.patches), f32(g.mono_disp), f32(g.intrinsics), f32(g.targets3), f32(g.weights_pose)
     ii, jj, kk = (torch.as_tensor(a, device=dev) for a in (g.ii, g.jj, g.kk))
