@@ -206,7 +206,7 @@ static void bind_pointers(bt_plan *pl, const void *d) {
     P.tile_pair0 = BT_I32(O.tp0); P.tile_npair = BT_I32(O.tnp); P.tile_pairs = BT_I32(O.tps);
     P.slot_lp = reinterpret_cast<const uint8_t *>(b + O.slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams; P.e_all = pl->e_all;
     P.slot_code = reinterpret_cast<const uint16_t *>(b + O.sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + O.tla); P.tile_rec = BT_I32(O.trec); P.it_edge = BT_I32(O.ite); P.tile_sinfo = reinterpret_cast<const uint32_t *>(b + O.tsi); P.em_ok = pl->em_ok; P.em_its = (int)pl->em_its; P.em_lgs = pl->em_lgs; P.em_self = pl->em_self;
-    P.pm_edge = BT_I32(O.pme); P.pm_rec = BT_I32(O.pmr); P.pm_lb = reinterpret_cast<const uint8_t *>(b + O.pmb); P.pm_la = reinterpret_cast<const uint8_t *>(b + O.pml); P.pm_ok = pl->pm_ok; P.sp_ok = pl->sp_ok; P.pp_ptr = BT_I32(O.ppp); P.pp_idx = BT_I32(O.ppi);
+    P.pm_edge = BT_I32(O.pme); P.pm_rec = BT_I32(O.pmr); P.pm_lb = reinterpret_cast<const uint8_t *>(b + O.pmb); P.pm_la = reinterpret_cast<const uint8_t *>(b + O.pml); P.pm_ok = pl->pm_ok; P.sp_ok = pl->sp_ok; P.trk_off = pl->trk_off; P.pp_ptr = BT_I32(O.ppp); P.pp_idx = BT_I32(O.ppi);
 #undef BT_I32
 }
 
@@ -300,7 +300,6 @@ static int check(const bt_plan *pl, const bt_ba_args *a, const void *ws) {
     if (pl->info.E > 0 && (!a->targets || !a->weights || a->target_stride < 2)) return BT_EINVAL;
     if (a->loss < BT_LOSS_TRIVIAL || a->loss > BT_LOSS_CAUCHY) return BT_EINVAL;
     if (a->mono_stride < 0) return BT_EINVAL;                 // 0 and 1 both mean contiguous; a prior of one repeated element must be materialised
-    if (a->lmbda_per_track && pl->info.E != pl->e_all) return BT_EUNSUPPORTED;      // sharded plan: track numbers are per rank
     return BT_OK;
 }
 
@@ -398,7 +397,7 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
     pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
     pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
     pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
-    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->pm_rounds = src->pm_rounds;
+    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
     void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);

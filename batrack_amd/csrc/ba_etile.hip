@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
                 const int trk = pd.tile_trk0[tile] + track;
                 const R pm = mono_v > (R)1e-2f ? (R)1 : (R)0;                         // (the prior is float32 data: compared as such)
                 R Ca = sv[0] + pm * (R)a.alpha;
-                Ca = Ca + (R)(a.lmbda_trk ? a.lmbda_trk[trk] : a.lmbda);
+                Ca = Ca + (R)(a.lmbda_trk ? a.lmbda_trk[pd.trk_off + trk] : a.lmbda);
                 const R wp = sv[1] - pm * (R)a.alpha * (pdisp - mono_v);
                 const R Q = sizeof(R) == 8 ? (R)frcp((double)Ca) : (R)1 / Ca;      // (float64: seed + two Newton steps, < 1e-15; the IEEE divide is ~30 instructions)
                 if constexpr (MODE == kEtSO) {                                        // ba.py:316-317, :333

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? 2 :
                 const R mono = mono_v;
                 const R pm = mono > (R)1e-2f ? (R)1 : (R)0;               // (the prior is float32 data: compared as such)
                 R Ca = C + pm * (R)a.alpha;
-                Ca = Ca + (R)(a.lmbda_trk ? a.lmbda_trk[trk] : a.lmbda);
+                Ca = Ca + (R)(a.lmbda_trk ? a.lmbda_trk[pd.trk_off + trk] : a.lmbda);
                 wp = wv - pm * (R)a.alpha * (pdisp - mono);
                 Q = sizeof(R) == 8 ? (R)frcp((double)Ca) : (R)1 / Ca;      // (float64: seed + two Newton steps, < 1e-15; the IEEE divide is ~30 instructions)
                 if (FUSE) {                                                // ba.py:316-317, :333

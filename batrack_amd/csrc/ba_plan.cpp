@@ -135,6 +135,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         if (bit < 0 || bit >= 64) masks_ok = false; else t.mask |= 1ull << bit;
     }
     pp_lo = kmin; pp_hi = kmax;
+    // sharded plan: the number of distinct tracks in front of this rank's range — a per-track lmbda tensor (ba.py:299-300) is
+    // indexed by the GLOBAL track number, the kernels count from the rank's first track
+    pl->trk_off = 0;
+    if (E_own != E && own_lo > 0) {
+        std::vector<uint8_t> seen((size_t)own_lo, 0);
+        for (int64_t e = 0; e < E; ++e) { const int64_t k = KK(e); if (k < own_lo && !seen[(size_t)k]) { seen[(size_t)k] = 1; ++pl->trk_off; } }
+    }
     pl->em_self = any_self ? 1 : 0;
     if (E == 0) f_lo = 0;
     I.n_all = n_all;

@@ -71,6 +71,7 @@ struct PlanDev {
     const int32_t *pp_ptr, *pp_idx;                          // sp_ok: the (tile << 6 | local pair) entries of every camera pair, CSR over the pairs
     int sp_ok;                                               // every tile has the same cameras: k_etile leaves per-tile Schur products (StepArgs::spart)
     int pm_ok;                                               // the pair-major tables exist (every tile has at most 64 camera pairs)
+    int trk_off;                                             // sharded plan: distinct tracks of the full edge list in front of this rank's first
     int em_self;                                             // some edge has ii == jj (its source-camera E lands on a target row)
     int em_ok, em_its, em_lgs;                               // every tile slot-uniform; total iterations; log2 S if the same for all tiles, else -1
     const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
@@ -122,7 +123,7 @@ struct bt_plan {
     std::vector<int32_t> pm_edge, pm_rec;
     std::vector<uint8_t> pm_lb, pm_la;
     std::vector<int32_t> pp_ptr, pp_idx;
-    int pm_ok = 0, sp_ok = 0;
+    int pm_ok = 0, sp_ok = 0, trk_off = 0;
     long long pm_rounds = 0;
     long long em_its = 0;
     int max_tile_pairs = 0, max_tile_slots = 0;

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(128, MODE == kModeFull ? BT_STREAM_FULL_WAVES : 4) 
             if (has_trk) {
                 const float pm = mono_v > 1e-2f ? 1.0f : 0.0f;
                 float Ca = C + pm * a.alpha;
-                Ca = Ca + (a.lmbda_trk ? a.lmbda_trk[(unsigned)rec.trk0 + (unsigned)lane] : a.lmbda);
+                Ca = Ca + (a.lmbda_trk ? a.lmbda_trk[(unsigned)pd.trk_off + (unsigned)rec.trk0 + (unsigned)lane] : a.lmbda);
                 wp = wv - pm * a.alpha * (pdisp - mono_v);
                 Q = 1.0f / Ca;
                 if (wave == 0) a.qw[(unsigned)rec.trk0 + (unsigned)lane] = make_float2(Q, wp);

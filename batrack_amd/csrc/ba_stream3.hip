@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
                 const float C = cw[lane], wv = cw[64 + lane];
                 const float pm = mono_v > 1e-2f ? 1.0f : 0.0f;
                 float Ca = C + pm * a.alpha;
-                Ca = Ca + (a.lmbda_trk ? a.lmbda_trk[(unsigned)rec.trk0 + (unsigned)lane] : a.lmbda);
+                Ca = Ca + (a.lmbda_trk ? a.lmbda_trk[(unsigned)pd.trk_off + (unsigned)rec.trk0 + (unsigned)lane] : a.lmbda);
                 wp = wv - pm * a.alpha * (pdisp - mono_v);
                 Q = 1.0f / Ca;
                 a.qw[(unsigned)rec.trk0 + (unsigned)lane] = make_float2(Q, wp);

@@ -155,19 +155,21 @@ class ShardedBA:
             self._xbuf = self._peers = None
 
     def step(self, poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
-             bounds, lmbda, ep, alpha, loss, structure_only):
-        """Same argument order as Stepper.step; per-edge tensors are the full ones on every rank."""
+             bounds, lmbda, ep, alpha, loss, structure_only, lmbda_per_track=None):
+        """Same argument order as Stepper.step; per-edge tensors are the full ones on every rank.  `lmbda_per_track`: the
+        reference's lmbda tensor (ba.py:299-300), one float32 per distinct track of the FULL edge list on every rank."""
         args = (poses, patches, mono, intrinsics, targets, tstride, weights, poses_out, patches_out,
                 bounds, lmbda, ep, alpha, loss, structure_only)
         so = bool(structure_only) or self.plan.n == 0
         st = self.stepper
         if so or self.world == 1:
-            st.step(*args)
+            st.step(*args, lmbda_per_track=lmbda_per_track)
             return
         # one argument block, two enqueues on the current stream around the exchange
         import ctypes
         from . import _lib
         a = st._fill(*args)
+        a.lmbda_per_track = lmbda_per_track.data_ptr() if lmbda_per_track is not None else None
         L, h, ws = st._lib, self.plan.handle, st.ws.data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
         if self._xbuf is not None:

@@ -130,9 +130,9 @@ typedef struct {
     int32_t structure_only;    /* ba.py:316                                           */
     int64_t mono_stride;       /* in floats between consecutive patches of mono_disp: the caller's prior is the
                                   strided view patches_local[:, :, mid, 2:] (batrack.py:866); 0 or 1 = contiguous */
-    const float *lmbda_per_track; /* NULL, or [m] device floats: the reference also accepts a lmbda TENSOR shaped like C, one
-                                  value per distinct track in ascending patch order (ba.py:299-300); `lmbda` is then ignored.
-                                  Not with sharded plans (own_lo / own_hi): BT_EUNSUPPORTED */
+    const float *lmbda_per_track; /* NULL, or device floats, one per distinct track of the FULL edge list in ascending patch order:
+                                  the reference also accepts a lmbda TENSOR shaped like C (ba.py:299-300); `lmbda` is then ignored.
+                                  A sharded plan (own_lo / own_hi) reads the entries of its own tracks from the same full array */
 } bt_ba_args;
 
 /* Clears the accumulators ([S | y] and the per-pair sums) inside `workspace`.  Call once

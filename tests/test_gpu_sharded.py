@@ -36,7 +36,13 @@ def _inputs(seed=3, shape="band"):
                    t3=f(g.targets3), w=f(g.weights_pose), ii=g.ii, jj=g.jj, kk=g.kk)
 
 
-def _worker(rank, world, port, out, shape, fixedp, exchange="rccl"):
+def _lmbda_vector(kk):
+    """One damping value per distinct track of the full edge list, ascending patch order (ba.py:299-300)."""
+    m = len(np.unique(kk))
+    return np.random.default_rng(11).uniform(1e-4, 0.5, m).astype(np.float32)
+
+
+def _worker(rank, world, port, out, shape, fixedp, exchange="rccl", per_track_lmbda=False):
     sys.path[:0] = [os.path.dirname(HERE), HERE]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -52,8 +58,9 @@ def _worker(rank, world, port, out, shape, fixedp, exchange="rccl"):
         tg, wl = t3, w
         scal = (list(g.bounds), 1e-4, 10.0, 0.05, "huber")
         P, X = [poses, torch.empty_like(poses)], [patches, torch.empty_like(patches)]
+        lm = T(_lmbda_vector(d["kk"])) if per_track_lmbda else None
         for k in range(2):                                     # two chained pose+structure steps
-            eng.step(P[k & 1], X[k & 1], mono, intr, tg, tg.stride(0), wl, P[(k + 1) & 1], X[(k + 1) & 1], *scal, False)
+            eng.step(P[k & 1], X[k & 1], mono, intr, tg, tg.stride(0), wl, P[(k + 1) & 1], X[(k + 1) & 1], *scal, False, lmbda_per_track=lm)
         full = eng.gather_patches(X[0])
         torch.cuda.synchronize()
         out[rank] = (P[0].cpu().numpy(), full.cpu().numpy(), int(eng.plan.E), eng.stepper.status(), eng.exchange_status())
@@ -105,3 +112,33 @@ def test_sharded_step_equals_oracle_and_single_gpu(shape, fixedp, world, exchang
         assert np.array_equal(out[0][0], out[r][0])    # identical solve on every rank after the all-reduce
     if shape == "few":
         assert sum(1 for r in range(world) if out[r][2] == 0) >= 1     # a rank without a single edge took part
+
+
+def test_per_track_lmbda_on_a_sharded_plan():
+    """The reference's lmbda TENSOR (one value per distinct track, ba.py:299-300) with the tracks split over two ranks: every
+    rank reads its own tracks' entries of the full array (plan field trk_off).  Equal to the 1-GPU step with the same tensor."""
+    from batrack_amd.plan import Plan, Stepper
+    g, d = _inputs(shape="band")
+    dev = "cuda:0"
+    T = lambda a: torch.as_tensor(a, device=dev)
+    poses, patches, mono, intr, t3, w = (T(d[k]) for k in ("poses", "patches", "mono", "intr", "t3", "w"))
+    ii, jj, kk = T(d["ii"]), T(d["jj"]), T(d["kk"])
+    st = Stepper(Plan(ii, jj, kk, poses.shape[0], patches.shape[0], 1), dev)
+    lm = T(_lmbda_vector(d["kk"]))
+    scal = (list(g.bounds), 1e-4, 10.0, 0.05, "huber")
+    P, X = [poses, torch.empty_like(poses)], [patches, torch.empty_like(patches)]
+    for k in range(2):
+        st.step(P[k & 1], X[k & 1], mono, intr, t3, 3, w, P[(k + 1) & 1], X[(k + 1) & 1], *scal, False, lmbda_per_track=lm)
+    plain = [poses, torch.empty_like(poses)], [patches, torch.empty_like(patches)]
+    st.step(poses, patches, mono, intr, t3, 3, w, plain[0][1], plain[1][1], *scal, False)
+    torch.cuda.synchronize()
+    ref_pose, ref_pat = P[0].cpu().numpy(), X[0].cpu().numpy()
+    port = 29900 + (os.getpid() % 1000)
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out, "band", 1, "ipc", True), nprocs=2, join=True)
+    rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b)
+    for r in range(2):
+        assert out[r][3] == 0 and out[r][4] == 0
+        assert rel(out[r][0], ref_pose) < 2e-6 and rel(out[r][1], ref_pat) < 2e-6, (r, rel(out[r][0], ref_pose), rel(out[r][1], ref_pat))
+    assert rel(plain[1][1].cpu().numpy(), X[1].cpu().numpy()) > 1e-5          # and the tensor is not the scalar
