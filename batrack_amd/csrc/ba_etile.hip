@@ -386,7 +386,9 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
     if (MODE != kEtFull) return;
 
     // ---- the lanes' pair sums: over the lanes with the same pair, then lane s (< S) adds them to the workgroup's float64 sums
+    const int gp_l = (!pd.sp_ok && lane < np) ? pd.tile_pairs[pd.tile_pair0[tile] + lane] : 0;       // (np <= 64: one pair per lane)
     et_stride_sum(pa, lgS);
+    BT_PF(6);
     {
         double *dst = ppart + (size_t)(wave & 3) * 26 * Smax + s;
         if (lane <= S1 && wave < 4) {
@@ -405,18 +407,28 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
     // per-pair sums of the tile -> the workspace (k_pair_finalize turns them into B and v): atomics, or — sp_ok, where many
     // tiles share each pair — stored per tile for k_pair_finalize to add up
     const int nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
+    // (the tile's record in StepArgs::spart: products of the 16x16 tiles t = ti (ti + 1) / 2 + tj | E Q w' | pair sums [27][pairs]
+    //  — at offsets fixed by the plan's largest tile, so that k_pair_finalize finds them without the tile's own sizes)
+    const size_t sp_y = (size_t)(pd.max_rows16 >> 4) * ((pd.max_rows16 >> 4) + 1) / 2 * 256, sp_p = sp_y + pd.max_rows16;
     double *sp_t = a.spart + (size_t)tile * sp_tile_doubles(pd.max_rows16, pd.max_tile_pairs);
-    for (int idx = tid; idx < np * 27; idx += kEtThreads) {
-        const int vi = idx / np, p = idx - vi * np;
+    // (element vi of all pairs by one wave: consecutive lanes read consecutive LDS words and store consecutive doubles —
+    //  layout [vi][pair] inside the tile's record.  The atomics' pair index was loaded before the merge: a load inside this
+    //  loop would wait, on the in-order counter, for the previous atomic's round trip as well)
+    const int mtp_s = pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1;
+    double *spp = sp_t + sp_p + lane;
+    double *pacc = a.pairacc + (size_t)gp_l * kPairAccStride;
+    for (int vi = wave; vi < 27; vi += kEtWaves) {
+        if (lane >= np) break;
         const int i = vi == 0 ? 0 : vi - 1;        // element order of the 27-vector: Bjj row-major upper triangle with its structural zero at [0][1]
         double val = 0.0;
         if (vi != 1) {
 #pragma unroll
-            for (int w = 0; w < kEtWaves / 2; ++w) val += ppart[((size_t)w * 26 + i) * Smax + p];
+            for (int w = 0; w < kEtWaves / 2; ++w) val += ppart[((size_t)w * 26 + i) * Smax + lane];
         }
-        if (pd.sp_ok) sp_t[(size_t)ntl * 256 + R16 + p * 32 + vi] = val;
-        else if (val != 0.0) atomicAdd(&a.pairacc[(size_t)pd.tile_pairs[pd.tile_pair0[tile] + p] * kPairAccStride + vi], val);
+        if (pd.sp_ok) spp[(size_t)vi * mtp_s] = val;
+        else if (val != 0.0) atomicAdd(&pacc[vi], val);
     }
+    BT_PF(5);
 
     // ---- Schur product of the tile on the matrix cores (as k_tile): out[i][j] += sum_k Q_k Eh[i][k] Eh[j][k] over the 64
     // tracks, one 16x16 output tile per wave on v_mfma_f64_16x16x4_f64; the diagonal tiles' waves also emit E (Q w')
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + kq + 4 * r;
-                if (pd.sp_ok) { if (li == 0) sp_t[(size_t)ntl * 256 + row] = yt[r]; }
+                if (pd.sp_ok) { if (li == 0) sp_t[sp_y + row] = yt[r]; }
                 else if (li == 0 && row < Rw) atomicAdd(&a.y[gidx[row]], -yt[r]);
             }
         }

@@ -410,35 +410,42 @@ __device__ __forceinline__ int sym21(int p, int q) {
     return p * 6 - p * (p - 1) / 2 + (q - p);
 }
 
-// sp_blocks > 0 (plans whose tiles share their cameras, Jacobian kernel k_etile): the blocks behind the pair blocks add up the
-// tiles' Schur products E Q E^T (one block per 16x16 output tile, its 256 threads one element each over all tiles) and E Q w'
-// (the last block) and subtract them from [S | y] — a few thousand atomics instead of tiles x that many.
+// Blocks behind the pair blocks (plans with sp_ok, Jacobian kernel k_etile): per group of consecutive same-camera tiles, one
+// block per 16x16 tile of the Schur product E Q E^T (its 256 threads one element each, summed over the group's tiles in
+// tile order: independent loads, eight in flight) and one for E Q w'; subtracted from [S | y] — a few atomics per element
+// and step instead of one per element and TILE.
 __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a, int pair_blocks) {
     if ((int)blockIdx.x >= pair_blocks) {
-        const int b = (int)blockIdx.x - pair_blocks, R16 = pd.max_rows16, nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
+        const int R16 = pd.max_rows16, nt = R16 >> 4, ntl = nt * (nt + 1) / 2;
+        const int g = ((int)blockIdx.x - pair_blocks) / (ntl + 1), b = ((int)blockIdx.x - pair_blocks) - g * (ntl + 1);
         const size_t per_tile = sp_tile_doubles(pd.max_rows16, pd.max_tile_pairs);
-        const int *cams = pd.tile_cams + pd.tile_cam0[0];            // the cameras of every tile
-        const int Rw = 6 * pd.tile_ncam[0];
+        const int t0 = pd.sg_ptr[g], t1 = pd.sg_ptr[g + 1];
+        const int *cams = pd.tile_cams + pd.tile_cam0[t0];           // the cameras of every tile of the group
+        const int Rw = 6 * pd.tile_ncam[t0];
         auto grow = [&](int r) { return 6 * cams[r / 6] + r % 6; };
+        auto group_sum = [&](const double *src) {
+            double sum = 0.0;
+            for (int t = t0; t < t1; t += 8) {
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = t + k < t1 ? src[(size_t)(t + k) * per_tile] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += v[k];
+            }
+            return sum;
+        };
         if (b < ntl) {
             int ti = 0, base = 0;
             while (base + ti + 1 <= b) { base += ti + 1; ++ti; }
             const int tj = b - base, j = threadIdx.x, r = j >> 6, lane = j & 63;
-            double sum = 0.0;
-            const double *src = a.spart + (size_t)b * 256 + j;
-            for (int t = 0; t < pd.T; ++t) sum += src[(size_t)t * per_tile];
             const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
             if (row < Rw && col < Rw) {
                 const int gr = grow(row), gc = grow(col);
-                if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -sum);
+                if (gr >= gc) atomicAdd(&a.S[(size_t)gr * pd.D + gc], -group_sum(a.spart + (size_t)b * 256 + j));
             }
         } else {
-            for (int row = threadIdx.x; row < Rw; row += blockDim.x) {
-                double sum = 0.0;
-                const double *src = a.spart + (size_t)ntl * 256 + row;
-                for (int t = 0; t < pd.T; ++t) sum += src[(size_t)t * per_tile];
-                atomicAdd(&a.y[grow(row)], -sum);
-            }
+            for (int row = threadIdx.x; row < Rw; row += blockDim.x)
+                atomicAdd(&a.y[grow(row)], -group_sum(a.spart + (size_t)ntl * 256 + row));
         }
         return;
     }
@@ -456,13 +463,24 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a, i
         double accv = 0.0;
         const int vi_ld = lane < 36 ? sym21(lane / 6, lane % 6) : lane < 42 ? 21 + lane - 36 : -1;
         if (pair_blocks < (int)gridDim.x) {
-            // (k_etile left the tiles' sums side by side: added up here, in the order of the plan's list)
-            if (vi_ld >= 0) {
-                const int R16 = pd.max_rows16, nt = R16 >> 4;
-                const size_t per_tile = sp_tile_doubles(pd.max_rows16, pd.max_tile_pairs), off = (size_t)nt * (nt + 1) / 2 * 256 + R16;
-                for (int q = pd.pp_ptr[p]; q < pd.pp_ptr[p + 1]; ++q) {
-                    const int e = pd.pp_idx[q];
-                    accv += a.spart[(size_t)(e >> 6) * per_tile + off + (size_t)(e & 63) * 32 + vi_ld];
+            // (k_etile left the tiles' sums side by side: added up here in the order of the plan's list — the list entries
+            //  through the lanes, then independent loads, eight in flight)
+            const int R16 = pd.max_rows16, nt = R16 >> 4;
+            const size_t per_tile = sp_tile_doubles(pd.max_rows16, pd.max_tile_pairs), off = (size_t)nt * (nt + 1) / 2 * 256 + R16;
+            const size_t mtp_s = (size_t)(pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1);
+            const int q0 = pd.pp_ptr[p], q1 = pd.pp_ptr[p + 1];
+            const double *src = a.spart + off + (size_t)(vi_ld >= 0 ? vi_ld : 0) * mtp_s;
+            for (int qb = q0; qb < q1; qb += 64) {
+                const int e_l = qb + lane < q1 ? pd.pp_idx[qb + lane] : 0, cnt = min(64, q1 - qb);
+                for (int k0 = 0; k0 < cnt; k0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = __shfl(e_l, k0 + k);
+                        v[k] = (k0 + k < cnt && vi_ld >= 0) ? src[(size_t)(e >> 6) * per_tile + (size_t)(e & 63)] : 0.0;      // [vi][pair] per tile
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) accv += v[k];
                 }
             }
         } else if (vi_ld >= 0) accv = acc[vi_ld];
@@ -2408,7 +2426,7 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
     }
     if (!so && pd.P > 0) {
         const int pb = (pd.P + 3) / 4, nt16 = pd.max_rows16 >> 4;
-        const int sp_blocks = (pd.T > 0 && etile_applies(pd) && pd.sp_ok) ? nt16 * (nt16 + 1) / 2 + 1 : 0;
+        const int sp_blocks = (pd.T > 0 && etile_applies(pd) && pd.sp_ok) ? pd.sg_n * (nt16 * (nt16 + 1) / 2 + 1) : 0;
         BT_LAUNCH(2, k_pair_finalize, dim3(pb + sp_blocks), dim3(256), 0, pd, a, pb);
     }
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;

@@ -1029,15 +1029,19 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             return rc;
         }
     }
-    // ---- partial Schur sums instead of atomics: when every tile sees the SAME cameras (a sliding window: all tiles' blocks of
-    // E Q E^T land on the same few thousand elements of S, and hundreds of workgroups' float64 atomics on them serialise in the
-    // L2) the pair-major kernel stores its tile's product and k_pair_finalize adds the tiles' products up.
+    // ---- partial sums instead of atomics for the pair-major kernel: hundreds of workgroups' float64 atomics on the same few
+    // thousand elements of [S | y] and of the per-pair sums queue up in the L2 (measured on the 160-tile window: half of the
+    // kernel).  Every tile stores its Schur product, E Q w' and pair sums (StepArgs::spart); k_pair_finalize adds them up —
+    // the products by position over each GROUP of consecutive tiles with the same cameras (a sliding window: the tiles of one
+    // source frame; at most kSpGroupMax tiles, so that the sum is one round of independent loads), the pair sums over the
+    // plan's list of every pair's (tile, local pair) entries.
     pl->sp_ok = 0;
-    if (pl->pm_ok && I.tiles >= 8) {
-        bool same = true;
-        for (int64_t t = 1; t < I.tiles && same; ++t) same = (pl->tile_flags[(size_t)t] & 1) != 0;
-        const int64_t per_tile = (int64_t)sp_tile_doubles(pl->max_rows16, pl->max_tile_pairs);
-        if (same && per_tile * I.tiles * 8 <= ((int64_t)64 << 20)) pl->sp_ok = 1;
+    if (pl->pm_ok == 2 && (int64_t)sp_tile_doubles(pl->max_rows16, pl->max_tile_pairs) * I.tiles * 8 <= ((int64_t)64 << 20)) pl->sp_ok = 1;
+    pl->sg_ptr.clear();
+    if (pl->sp_ok) {
+        for (int64_t t = 0; t < I.tiles; ++t)
+            if (t == 0 || !(pl->tile_flags[(size_t)t] & 1) || t - pl->sg_ptr.back() >= kSpGroupMax) pl->sg_ptr.push_back((int32_t)t);
+        pl->sg_ptr.push_back((int32_t)I.tiles);
     }
     pl->pp_ptr.clear(); pl->pp_idx.clear();
     if (pl->sp_ok) {                                               // which tiles hold sums of which camera pair

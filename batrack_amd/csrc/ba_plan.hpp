@@ -18,6 +18,7 @@ constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj 
 constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
 constexpr int kLdsRowStride = 66;
 constexpr int kMaxLevelCols = 4;
+constexpr int kSpGroupMax = 32;     // tiles per group of k_pair_finalize's positional sums of the tiles' Schur products
 constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geometry is kept in LDS    // columns of the reduced system factored concurrently (one critical wave each)   // floats per local E row (bank-conflict-free)
 
 // doubles per tile of StepArgs::spart (plans with sp_ok): the tile's Schur product (ntl lower 16x16 tiles of 256), E Q w'
@@ -69,7 +70,8 @@ struct PlanDev {
     const int32_t *pm_edge, *pm_rec;                         // pair-major layout (ba_plan.cpp): [rounds][64], [tiles][4]
     const uint8_t *pm_lb, *pm_la;                            // [tiles][64]: target camera of local pair s / source camera of track l
     const int32_t *pp_ptr, *pp_idx;                          // sp_ok: the (tile << 6 | local pair) entries of every camera pair, CSR over the pairs
-    int sp_ok;                                               // every tile has the same cameras: k_etile leaves per-tile Schur products (StepArgs::spart)
+    const int32_t *sg_ptr; int sg_n;                         // sp_ok: first tile of every group of consecutive same-camera tiles (sg_n + 1 entries)
+    int sp_ok;                                               // k_etile leaves per-tile Schur products and pair sums (StepArgs::spart) instead of atomics
     int pm_ok;                                               // the pair-major tables exist (every tile has at most 64 camera pairs)
     int trk_off;                                             // sharded plan: distinct tracks of the full edge list in front of this rank's first
     int em_self;                                             // some edge has ii == jj (its source-camera E lands on a target row)
@@ -93,7 +95,7 @@ struct WsLayout {
 
 }  // namespace bt
 
-namespace bt { struct PlanOffsets { size_t ab, ar, bc, pme, pmr, pmb, pml, ppp, ppi, bs, bss, c0, cams, cl, cp, dp, dpp, e0, fl, flp, fm, fp, fpf, fpm, fpp, fps, fri, fy, ite, kx, lc, lm, lp, pi, pj, pm, ri, s0, sc, se, sl, slp, sn, sp, t0, tc, tc16, tc8, tf, tij, tkx, tla, tn, tnp, tp0, tps, trec, tsi, u, un, up; }; }
+namespace bt { struct PlanOffsets { size_t ab, ar, bc, pme, pmr, pmb, pml, ppp, ppi, sgp, bs, bss, c0, cams, cl, cp, dp, dpp, e0, fl, flp, fm, fp, fpf, fpm, fpp, fps, fri, fy, ite, kx, lc, lm, lp, pi, pj, pm, ri, s0, sc, se, sl, slp, sn, sp, t0, tc, tc16, tc8, tf, tij, tkx, tla, tn, tnp, tp0, tps, trec, tsi, u, un, up; }; }
 
 struct bt_plan {
     bt_plan_info info{};
@@ -122,8 +124,8 @@ struct bt_plan {
     int em_ok = 0, em_lgs = -1, em_self = 0;
     std::vector<int32_t> pm_edge, pm_rec;
     std::vector<uint8_t> pm_lb, pm_la;
-    std::vector<int32_t> pp_ptr, pp_idx;
-    int pm_ok = 0, sp_ok = 0, trk_off = 0;
+    std::vector<int32_t> pp_ptr, pp_idx, sg_ptr;
+    int pm_ok = 0, sp_ok = 0, sg_n = 0, trk_off = 0;
     long long pm_rounds = 0;
     long long em_its = 0;
     int max_tile_pairs = 0, max_tile_slots = 0;
@@ -154,7 +156,7 @@ struct bt_plan {
                         &bs_sync, &fz_rowinfo, &fz_pfirst, &fz_psecond})
             v->clear();
         tile_cut8.clear(); tile_cut16.clear();
-        pm_edge.clear(); pm_rec.clear(); pm_lb.clear(); pm_la.clear(); pp_ptr.clear(); pp_idx.clear(); pm_ok = 0; sp_ok = 0; pm_rounds = 0;
+        pm_edge.clear(); pm_rec.clear(); pm_lb.clear(); pm_la.clear(); pp_ptr.clear(); pp_idx.clear(); sg_ptr.clear(); pm_ok = 0; sp_ok = 0; pm_rounds = 0;
         slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); it_edge.clear(); tile_sinfo.clear(); em_ok = 0; em_its = 0; em_lgs = -1; act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;
         fz_ok = fzp_ok = 0;

@@ -43,6 +43,8 @@ if int(os.environ.get("BT_DEBUG_MODE", "0")) & 32:
     stat_off = off + 2 * (((6 * plan.n * 4 + 64 + 255) // 256) * 256)            # dx, dx0, then the status block
     pf = np.frombuffer(raw[stat_off + 16 + 160: stat_off + 16 + 320].tobytes(), dtype=np.int64).reshape(2, 10)
     names = ["prologue", "loadwait", "math+E", "pairreduce", "CwQ", "Esave", "mfma", "epilogue", "drain", "-"]
+    if plan.jacobian_kernel == "k_etile":
+        names = ["prologue", "rounds", "pair-sum merge (2 barriers)", "Schur + stores", "drain", "pair sums -> workspace", "stride_sum", "-", "-", "-"]
     for w, nm in enumerate(("tile0", "tileMid")):
         print(f"  k_tile {nm} wave0 cycles: " + " ".join(f"{n}={v}" for n, v in zip(names, pf[w])) + f" total={pf[w].sum()}")
 if int(os.environ.get("BT_DEBUG_MODE", "0")) & 16:
