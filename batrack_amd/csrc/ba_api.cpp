@@ -206,7 +206,7 @@ static void bind_pointers(bt_plan *pl, const void *d) {
     P.tile_pair0 = BT_I32(O.tp0); P.tile_npair = BT_I32(O.tnp); P.tile_pairs = BT_I32(O.tps);
     P.slot_lp = reinterpret_cast<const uint8_t *>(b + O.slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams; P.e_all = pl->e_all;
     P.slot_code = reinterpret_cast<const uint16_t *>(b + O.sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + O.tla); P.tile_rec = BT_I32(O.trec); P.it_edge = BT_I32(O.ite); P.tile_sinfo = reinterpret_cast<const uint32_t *>(b + O.tsi); P.em_ok = pl->em_ok; P.em_its = (int)pl->em_its; P.em_lgs = pl->em_lgs; P.em_self = pl->em_self;
-    P.pm_edge = BT_I32(O.pme); P.pm_rec = BT_I32(O.pmr); P.pm_lb = reinterpret_cast<const uint8_t *>(b + O.pmb); P.pm_la = reinterpret_cast<const uint8_t *>(b + O.pml); P.pm_ok = pl->pm_ok; P.sp_ok = pl->sp_ok; P.trk_off = pl->trk_off; P.pp_ptr = BT_I32(O.ppp); P.pp_idx = BT_I32(O.ppi); P.sg_ptr = BT_I32(O.sgp); P.sg_n = pl->sg_n;
+    P.pm_edge = BT_I32(O.pme); P.pm_rec = BT_I32(O.pmr); P.pm_lb = reinterpret_cast<const uint8_t *>(b + O.pmb); P.pm_la = reinterpret_cast<const uint8_t *>(b + O.pml); P.pm_ok = pl->pm_ok; P.sp_ok = pl->sp_ok; P.trk_off = pl->trk_off; P.pp_ptr = BT_I32(O.ppp); P.pp_idx = BT_I32(O.ppi); P.sg_ptr = BT_I32(O.sgp); P.sg_n = pl->sg_n; P.et_lgts = pl->et_lgts;
 #undef BT_I32
 }
 
@@ -289,6 +289,7 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     s.linv = reinterpret_cast<float *>(w + L.linv); s.zvec = reinterpret_cast<float *>(w + L.zvec);
     s.dx = reinterpret_cast<float *>(w + L.dx); s.dx0 = reinterpret_cast<float *>(w + L.dx0); s.status = reinterpret_cast<int *>(w + L.status);
     s.spart = reinterpret_cast<double *>(w + L.spart);
+    s.esave = reinterpret_cast<double *>(w + L.esave);
     static const int dbg = std::getenv("BT_DEBUG_MODE") ? std::atoi(std::getenv("BT_DEBUG_MODE")) : 0;
     s.dbg = dbg;
     s.prec = edge_precision(pl->dev);
@@ -398,7 +399,7 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
     pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
     pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
     pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
-    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
+    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
     void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);

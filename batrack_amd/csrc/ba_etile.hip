@@ -415,6 +415,13 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
     //  layout [vi][pair] inside the tile's record.  The atomics' pair index was loaded before the merge: a load inside this
     //  loop would wait, on the in-order counter, for the previous atomic's round trip as well)
     const int mtp_s = pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1;
+    if (pd.sp_ok) {
+        // the tile's E for the step's last kernel (k_etile_upd: dZ = Q (w' - E^T dX), ba.py:328, without the edges)
+        double *es = a.esave + (((size_t)tile * pd.max_rows16) << pd.et_lgts);
+        const int ts1 = (1 << pd.et_lgts) - 1;
+        for (int idx = tid; idx < (Rw << pd.et_lgts); idx += kEtThreads)
+            es[idx] = (double)Eh[(idx >> pd.et_lgts) * kLdsRowStride + (idx & ts1)];
+    }
     double *spp = sp_t + sp_p + lane;
     double *pacc = a.pairacc + (size_t)gp_l * kPairAccStride;
     for (int vi = wave; vi < 27; vi += kEtWaves) {
@@ -501,6 +508,62 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
 #undef BT_PF
 }
 
+// ------------------------------------------------------------------ k_etile_upd
+// Last kernel of a pose+structure step on plans with sp_ok: one wave per tile reads the E its k_etile<kEtFull> left
+// (StepArgs::esave) and applies dZ = Q (w' - E^T dX) (ba.py:328, :333) — 6 ncam x ntrk products per tile instead of the
+// tile's edges again.  Lanes = (row slice, track); behind the tile blocks the blocks of update_rest and of the clearing
+// of [S | y], as k_update.
+constexpr int kEuThreads = 256, kEuRows = 6 * kTileCamHard;
+__global__ __launch_bounds__(kEuThreads) void k_etile_upd(PlanDev pd, StepArgs a, int do_poses, int tile_blocks, int first_zero_block) {
+    if ((int)blockIdx.x >= first_zero_block) {
+        const size_t nz = (size_t)pd.D * pd.D + pd.D;
+        const size_t i0 = ((size_t)(blockIdx.x - first_zero_block) * blockDim.x + threadIdx.x) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i0 + k < nz) a.S[i0 + k] = 0.0;
+        return;
+    }
+    if ((int)blockIdx.x >= tile_blocks) {
+        update_rest<false, true>(pd, a, ((int)blockIdx.x - tile_blocks) * (int)blockDim.x + (int)threadIdx.x, do_poses);
+        return;
+    }
+    __shared__ float sdx[kEuThreads / 64][kEuRows];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = (int)blockIdx.x * (kEuThreads / 64) + wave;
+    if (tile >= pd.T) return;
+    const int ntrk = pd.tile_ntrk[tile], Rw = 6 * pd.tile_ncam[tile];
+    const int lgts = pd.et_lgts, k = lane & ((1 << lgts) - 1), sl = lane >> lgts, nsl = 64 >> lgts;
+    // the track's numbers first: their latency runs under the rows
+    int patch = -1;
+    float px = 0.f, py = 0.f, pdisp = 0.f;
+    double2 qw = {0.0, 0.0};
+    if (sl == 0 && k < ntrk) {
+        patch = pd.tile_kx[(size_t)tile * kLanes + k];
+        px = a.patches[3 * (size_t)patch]; py = a.patches[3 * (size_t)patch + 1]; pdisp = a.patches[3 * (size_t)patch + 2];
+        qw = reinterpret_cast<const double2 *>(a.qw)[pd.tile_trk0[tile] + k];
+    }
+    const int *cams = pd.tile_cams + pd.tile_cam0[tile];
+    for (int r = lane; r < Rw; r += 64) sdx[wave][r] = a.dx[6 * cams[r / 6] + r % 6];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double *E = a.esave + (((size_t)tile * pd.max_rows16) << lgts) + k;
+    double acc = 0.0;
+    for (int r0 = sl; r0 < Rw; r0 += 8 * nsl) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int r = r0 + u * nsl; v[u] = r < Rw ? E[(size_t)r << lgts] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int r = r0 + u * nsl; if (r < Rw) acc = fma(v[u], (double)sdx[wave][r], acc); }
+    }
+    // over the row slices: lanes with the same track are 1 << lgts apart
+    for (int m = 32; m >= (1 << lgts); m >>= 1) acc += __shfl_xor(acc, m);
+    if (patch >= 0) {
+        float dd = (float)((double)pdisp + qw.x * (qw.y - acc));                  // ba.py:328, :333
+        dd = dd < 1e-3f ? 1e-3f : dd;
+        dd = dd > 10.0f ? 10.0f : dd;
+        a.patches_out[3 * (size_t)patch] = px; a.patches_out[3 * (size_t)patch + 1] = py; a.patches_out[3 * (size_t)patch + 2] = dd;
+    }
+}
+
 // ------------------------------------------------------------------ dispatch
 static size_t etile_lds_bytes(const PlanDev &pd, int mode, size_t rsz) {
     const size_t mtp = (size_t)(pd.max_tile_pairs > 0 ? pd.max_tile_pairs : 1);
@@ -536,6 +599,14 @@ static int launch_etile_t(const PlanDev &pd, const StepArgs &a, int do_poses, in
 // last kernel.  extra_blocks / zero_blocks: the blocks of update_rest / of the clearing of [S | y] behind the tile blocks.
 int launch_etile(const PlanDev &pd, const StepArgs &a, int mode, int do_poses, int extra_blocks, int zero_blocks, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const bool dbl = a.prec != 0;
+    if (mode == kEtUpd && dbl && pd.sp_ok && 6 * pd.max_cams <= kEuRows) {
+        // (extra_blocks / zero_blocks were counted in blocks of kEtThreads threads)
+        const int per = kEtThreads / kEuThreads, tb = (pd.T + kEuThreads / 64 - 1) / (kEuThreads / 64);
+        const dim3 grid((unsigned)(tb + per * (extra_blocks + zero_blocks))), blk(kEuThreads);
+        if (ev0) hipExtLaunchKernelGGL(k_etile_upd, grid, blk, 0, st, ev0, ev1, 0, pd, a, do_poses, tb, tb + per * extra_blocks);
+        else hipLaunchKernelGGL(k_etile_upd, grid, blk, 0, st, pd, a, do_poses, tb, tb + per * extra_blocks);
+        return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+    }
     if (mode == kEtSO) return dbl ? launch_etile_t<kEtSO, double>(pd, a, do_poses, extra_blocks, 0, st, ev0, ev1) : launch_etile_t<kEtSO, float>(pd, a, do_poses, extra_blocks, 0, st, ev0, ev1);
     if (mode == kEtUpd) return dbl ? launch_etile_t<kEtUpd, double>(pd, a, do_poses, extra_blocks, zero_blocks, st, ev0, ev1) : launch_etile_t<kEtUpd, float>(pd, a, do_poses, extra_blocks, zero_blocks, st, ev0, ev1);
     if (a.dbg & 32) return dbl ? launch_etile_t<kEtFull, double, true>(pd, a, 0, 0, 0, st, ev0, ev1) : launch_etile_t<kEtFull, float, true>(pd, a, 0, 0, 0, st, ev0, ev1);

@@ -21,6 +21,7 @@ struct StepArgs {
     float *pairgeo;               // [pairs][kPairGeomFloats]: relative pose of every camera pair, left by k_tile for k_pair_finalize
     int *status;
     double *spart;                // [tiles][ntl * 256 + max_rows16]: per-tile Schur products of k_etile when the plan's sp_ok (else unused)
+    double *esave;                // [tiles][max_rows16][1 << et_lgts]: the tiles' E (rows of the tile's cameras x its tracks), k_etile -> k_etile_upd
     int prec;                     // 1: the per-edge maths, E, pairgeo and qw are float64 (k_tile path, the default there); 0: float32
     int dbg;                      // env BT_DEBUG_MODE, 0 in production: 16 / 32 launch the cycle-counting variants of the solver / k_tile
 };

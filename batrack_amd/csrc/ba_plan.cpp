@@ -54,6 +54,8 @@ static void layout_workspace(bt_plan *pl) {
     w.status = off;   off = align_up(off + 1024, 256);
     w.spart = off;
     if (pl->sp_ok) off = align_up(off + (size_t)I.tiles * sp_tile_doubles(pl->max_rows16, pl->max_tile_pairs) * sizeof(double), 256);
+    w.esave = off;                                                 // k_etile -> k_etile_upd: the tiles' E, [tile][max_rows16][1 << et_lgts]
+    if (pl->sp_ok) off = align_up(off + (((size_t)I.tiles * pl->max_rows16) << pl->et_lgts) * sizeof(double), 256);
     w.total = off;
     pl->ws = w;
     pl->info.workspace_bytes = (int64_t)w.total;
@@ -1035,8 +1037,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // the products by position over each GROUP of consecutive tiles with the same cameras (a sliding window: the tiles of one
     // source frame; at most kSpGroupMax tiles, so that the sum is one round of independent loads), the pair sums over the
     // plan's list of every pair's (tile, local pair) entries.
-    pl->sp_ok = 0;
-    if (pl->pm_ok == 2 && (int64_t)sp_tile_doubles(pl->max_rows16, pl->max_tile_pairs) * I.tiles * 8 <= ((int64_t)64 << 20)) pl->sp_ok = 1;
+    pl->sp_ok = 0; pl->et_lgts = 0;
+    {
+        int mt = 1;
+        for (int64_t t = 0; t < I.tiles; ++t) mt = std::max(mt, (int)pl->tile_ntrk[(size_t)t]);
+        while ((1 << pl->et_lgts) < mt) ++pl->et_lgts;
+    }
+    if (pl->pm_ok == 2 && ((int64_t)sp_tile_doubles(pl->max_rows16, pl->max_tile_pairs) + ((int64_t)pl->max_rows16 << pl->et_lgts)) * I.tiles * 8 <= ((int64_t)96 << 20)) pl->sp_ok = 1;
     pl->sg_ptr.clear();
     if (pl->sp_ok) {
         for (int64_t t = 0; t < I.tiles; ++t)

@@ -71,6 +71,7 @@ struct PlanDev {
     const uint8_t *pm_lb, *pm_la;                            // [tiles][64]: target camera of local pair s / source camera of track l
     const int32_t *pp_ptr, *pp_idx;                          // sp_ok: the (tile << 6 | local pair) entries of every camera pair, CSR over the pairs
     const int32_t *sg_ptr; int sg_n;                         // sp_ok: first tile of every group of consecutive same-camera tiles (sg_n + 1 entries)
+    int et_lgts;                                             // sp_ok: log2 of the track stride of StepArgs::esave (>= the largest tile's tracks)
     int sp_ok;                                               // k_etile leaves per-tile Schur products and pair sums (StepArgs::spart) instead of atomics
     int pm_ok;                                               // the pair-major tables exist (every tile has at most 64 camera pairs)
     int trk_off;                                             // sharded plan: distinct tracks of the full edge list in front of this rank's first
@@ -90,7 +91,7 @@ struct PlanDev {
 // Byte offsets of the regions inside the caller's workspace.
 struct WsLayout {
     size_t sys, pairacc, zero_bytes;   // [sys, sys+zero_bytes) is cleared every reduce
-    size_t packed, pairgeo, qw, lfac, linv, zvec, dx, dx0, status, spart, total;
+    size_t packed, pairgeo, qw, lfac, linv, zvec, dx, dx0, status, spart, esave, total;
 };
 
 }  // namespace bt
@@ -125,7 +126,7 @@ struct bt_plan {
     std::vector<int32_t> pm_edge, pm_rec;
     std::vector<uint8_t> pm_lb, pm_la;
     std::vector<int32_t> pp_ptr, pp_idx, sg_ptr;
-    int pm_ok = 0, sp_ok = 0, sg_n = 0, trk_off = 0;
+    int pm_ok = 0, sp_ok = 0, sg_n = 0, et_lgts = 0, trk_off = 0;
     long long pm_rounds = 0;
     long long em_its = 0;
     int max_tile_pairs = 0, max_tile_slots = 0;
