@@ -457,7 +457,7 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
         *data = pl->trk_of_patch.data();
         return (int64_t)pl->trk_of_patch.size();
     }
-    BT_ARR(kx) BT_ARR(trk_loc) BT_ARR(pair_i) BT_ARR(pair_j)
+    BT_ARR(kx) BT_ARR(trk_loc) BT_ARR(pair_i) BT_ARR(pair_j) BT_ARR(pp_ptr) BT_ARR(pp_idx) BT_ARR(sg_ptr)
     BT_ARR(tile_trk0) BT_ARR(tile_ntrk) BT_ARR(tile_ncam) BT_ARR(tile_cam0) BT_ARR(tile_slot0)
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)
     BT_ARR(slot_lab) BT_ARR(col_ptr) BT_ARR(row_idx) BT_ARR(upd_ptr) BT_ARR(upd) BT_ARR(blk_col) BT_ARR(upd_next) BT_ARR(perm) BT_ARR(blk_src) BT_ARR(lvl_ptr) BT_ARR(lvl_cols)

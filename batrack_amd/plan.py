@@ -19,7 +19,7 @@ PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0",
                "tile_cam0", "tile_slot0", "tile_nslot", "tile_erow0", "tile_cams", "slot_edge", "slot_pair",
                "slot_lab", "col_ptr", "row_idx", "upd_ptr", "upd", "blk_col", "upd_next", "perm", "blk_src",
                "lvl_ptr", "lvl_cols", "col_lvl", "dp_ptr", "dp", "tile_pair0", "tile_npair", "tile_pairs", "slot_lp", "tile_flags",
-               "fz_pend_ptr", "fz_pend", "fz_lazy_ptr", "fz_lazy", "fz_yurg", "fz_meta", "fz_pmeta", "bs_sync", "fz_rowinfo", "fz_pfirst", "fz_psecond", "act_bits", "act_rank", "tile_ij", "tile_kx", "lvl_meta", "slot_code", "tile_la", "tile_rec", "it_edge", "tile_sinfo", "tile_cut8", "tile_cut16", "pm_edge", "pm_rec", "pm_lb", "pm_la")
+               "fz_pend_ptr", "fz_pend", "fz_lazy_ptr", "fz_lazy", "fz_yurg", "fz_meta", "fz_pmeta", "bs_sync", "fz_rowinfo", "fz_pfirst", "fz_psecond", "act_bits", "act_rank", "tile_ij", "tile_kx", "lvl_meta", "slot_code", "tile_la", "tile_rec", "it_edge", "tile_sinfo", "tile_cut8", "tile_cut16", "pm_edge", "pm_rec", "pm_lb", "pm_la", "pp_ptr", "pp_idx", "sg_ptr")
 
 
 class Plan:

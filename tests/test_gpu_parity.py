@@ -207,9 +207,11 @@ def test_shuffled_edge_order_gives_same_answer():
     assert rel(b["patches_out"], a["patches_out"]) < tol(1e-7, 2e-6)
 
 
-def test_real_shape_window_graph_vs_oracle():
-    """Sliding-window graph laid out by the reference's edge rules: duplicates, 15 free poses."""
-    g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
+@pytest.mark.parametrize("M", [256, 576])
+def test_real_shape_window_graph_vs_oracle(M):
+    """Sliding-window graph laid out by the reference's edge rules: duplicates, 15 free poses.  M = 576: 36 tiles of 16 tracks
+    per source frame, i.e. groups of same-camera tiles beyond the 32 that k_pair_finalize adds up in one go."""
+    g, fixedp = graphgen.make_window_graph(n_frames=50, M=M, seed=4)
     f = lambda a: np.asarray(a, np.float32).astype(np.float64)
     d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics),
              targets3=f(g.targets3), weights=f(g.weights), weights_pose=f(g.weights_pose),
@@ -218,6 +220,9 @@ def test_real_shape_window_graph_vs_oracle():
                          d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=fixedp, want_system=True)
     o = HipProblem(d).raw_step("weights_pose", fixedp)
     assert o["plan"].n == 15 and (F32_EDGE or o["plan"].edge_precision == 8)
+    if o["plan"].jacobian_kernel == "k_etile":
+        sizes = np.diff(o["plan"].array("sg_ptr"))
+        assert sizes.max() <= 32 and ((sizes == 4).any() == (M == 576))        # (36 tiles of a frame = 32 + 4)
     assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-6)
     assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < DX_TOL
     assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(fixedp, fixedp + 15)) < UPD_POSE_TOL

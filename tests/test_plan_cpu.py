@@ -357,6 +357,23 @@ def test_window_plans_are_tiled_for_the_pair_major_kernel():
     g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
     pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], fixedp, upload=False)
     assert int(pl.array("tile_ntrk").max()) == 16 and pl.tiles == 160 and pl.array("pm_rec").size == 4 * pl.tiles
+    # the tables behind the tiles' partial sums (k_pair_finalize): groups of consecutive tiles with the same cameras (at most 32
+    # tiles each) partition the tiles, and every pair's list holds each (tile, local pair) that carries the pair exactly once
+    sg, cam0, ncam, cams = pl.array("sg_ptr"), pl.array("tile_cam0"), pl.array("tile_ncam"), pl.array("tile_cams")
+    assert sg[0] == 0 and sg[-1] == pl.tiles and (np.diff(sg) > 0).all() and (np.diff(sg) <= 32).all()
+    for a, b in zip(sg[:-1], sg[1:]):
+        ref = cams[cam0[a]:cam0[a] + ncam[a]]
+        assert all(ncam[t] == ncam[a] and (cams[cam0[t]:cam0[t] + ncam[t]] == ref).all() for t in range(a, b))
+    assert len(sg) - 1 < pl.tiles                      # (a window: the tiles of one source frame share their cameras)
+    pp, pi, tp0, tnp, tps = pl.array("pp_ptr"), pl.array("pp_idx"), pl.array("tile_pair0"), pl.array("tile_npair"), pl.array("tile_pairs")
+    assert pp[0] == 0 and pp[-1] == tps.size == pi.size
+    seen = set()
+    for p in range(pp.size - 1):
+        for e in pi[pp[p]:pp[p + 1]]:
+            t, q = int(e) >> 6, int(e) & 63
+            assert q < tnp[t] and tps[tp0[t] + q] == p and (t, q) not in seen
+            seen.add((t, q))
+    assert len(seen) == tps.size
     g = graphgen.make_config("C3", seed=0)
     pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
-    assert int(pl.array("tile_ntrk").max()) == 64 and pl.tiles == 256 and pl.array("pm_rec").size == 0
+    assert int(pl.array("tile_ntrk").max()) == 64 and pl.tiles == 256 and pl.array("pm_rec").size == 0 and pl.array("sg_ptr").size == 0
