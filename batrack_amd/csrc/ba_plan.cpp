@@ -200,13 +200,18 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // pair id, and stability keeps the original index as the tie-break (duplicates are normal, batrack.py:399-410).
     // (edge-sized temporaries persist per thread: the caller builds one plan per frame, and fresh pages cost more
     // than the passes over them)
+    // (the packed words travel with the order — pks[q] = pk[ord[q]] — so that the per-tile walks below read the edges' frames
+    //  in sequence instead of through ord into the caller's order: those random reads were most of the 0.9 ms of the walks)
     static thread_local std::vector<int32_t> ord_scratch, byj_scratch;
+    static thread_local std::vector<uint64_t> pks_scratch;
     std::vector<int32_t> &ord = ord_scratch, &byj = byj_scratch;
-    ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1);
+    std::vector<uint64_t> &pks = pks_scratch;
+    ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1); pks.resize((size_t)E_own + 1);
     std::vector<int32_t> cur(off.begin(), off.end() - 1);
     if (mono_j) {
         // every track's edges already come in (target frame, index) order: one stable scatter by track
-        for (int64_t e = 0; e < E; ++e) if (E_own == E || owned(e)) ord[(size_t)cur[(size_t)trk_of(KK(e))]++] = (int32_t)e;
+        for (int64_t e = 0; e < E; ++e)
+            if (E_own == E || owned(e)) { const int32_t q = cur[(size_t)trk_of(KK(e))]++; ord[(size_t)q] = (int32_t)e; pks[(size_t)q] = pk[e]; }
     } else {
         for (int64_t j = 0; j < n_all; ++j) cj[(size_t)j + 1] += cj[(size_t)j];
         if (E_own == E) {
@@ -216,10 +221,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         }
         for (int64_t q = 0; q < E_own; ++q) {
             const int32_t e = byj[(size_t)q];
-            ord[(size_t)cur[(size_t)trk_of(KK(e))]++] = e;
+            const int32_t pos = cur[(size_t)trk_of(KK(e))]++;
+            ord[(size_t)pos] = e; pks[(size_t)pos] = pk[e];
         }
     }
-    auto pair_id = [&](int32_t e) { return pair_of[(size_t)((II(e) - f_lo) * nw + (JJ(e) - f_lo))]; };
+    auto IQ = [&](int64_t q) { return (int64_t)((pks[(size_t)q] >> 16) & 0xffff); };      // frames of the q-th edge of the grouped order
+    auto JQ = [&](int64_t q) { return (int64_t)(pks[(size_t)q] & 0xffff); };
+    auto pair_q = [&](int64_t q) { return pair_of[(size_t)((IQ(q) - f_lo) * nw + (JQ(q) - f_lo))]; };
 
     BT_TICK("4");
     // ---- tiles: greedy over sorted tracks ----------------------------------
@@ -277,8 +285,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             }
         } else {
             for (int32_t sidx = off[(size_t)k]; sidx < off[(size_t)k + 1]; ++sidx) {
-                const int32_t e = ord[(size_t)sidx];
-                const int64_t cams[2] = { II(e) - fixedp, JJ(e) - fixedp };
+                const int64_t cams[2] = { IQ(sidx) - fixedp, JQ(sidx) - fixedp };
                 for (int64_t c : cams)
                     if (c >= 0 && tstamp[(size_t)c] != k) { tstamp[(size_t)c] = k; trk_set.push_back((int32_t)c); }
             }
@@ -349,7 +356,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                 }
             } else {
                 for (int32_t q = off[(size_t)t0]; q < off[(size_t)(t0 + nt)]; ++q) {
-                    const int32_t gp = pair_id(ord[(size_t)q]);
+                    const int32_t gp = pair_q(q);
                     if (lp_of[(size_t)gp] < 0) { lp_of[(size_t)gp] = 0; mine.push_back(gp); }
                 }
             }
@@ -372,8 +379,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                     int32_t D = 1;
                     for (int32_t l = 0; l < nt; ++l)
                         for (int32_t sidx = off[(size_t)(t0 + l)]; sidx < off[(size_t)(t0 + l) + 1]; ++sidx) {
-                            const int32_t e = ord[(size_t)sidx];
-                            const int64_t i = II(e), j = JJ(e), a2 = i - fixedp, b2 = j - fixedp;
+                            const int64_t i = IQ(sidx), j = JQ(sidx), a2 = i - fixedp, b2 = j - fixedp;
                             const int32_t lp = lp_of[(size_t)pair_of[(size_t)((i - f_lo) * nw + (j - f_lo))]];
                             const int32_t d = pm_cnt[(size_t)l * S + lp]++;
                             D = std::max(D, d + 1);
@@ -404,7 +410,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                 for (int32_t sidx = off[(size_t)k]; sidx < off[(size_t)k + 1]; ++sidx) {
                     const int32_t e = ord[(size_t)sidx];
                     const size_t idx = ((size_t)pl->tile_slot0[(size_t)t] + (size_t)(sidx - off[(size_t)k])) * kLanes + (size_t)l;
-                    const int64_t i = II(e), j = JJ(e);
+                    const int64_t i = IQ(sidx), j = JQ(sidx);
                     const int64_t a = i - fixedp, b = j - fixedp;
                     const uint16_t la = a >= 0 ? (uint16_t)local[(size_t)a] : 0xff;
                     const uint16_t lb = b >= 0 ? (uint16_t)local[(size_t)b] : 0xff;
