@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(_HERE, "lib", "libbatrack_ba.so")   # BT_LIB_PATH: measurement builds only
-SOURCES = ["ba_kernels.hip", "ba_etile.hip", "ba_stream.hip", "ba_stream3.hip", "plan_pack.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip", "ga_kernels.hip"]
+SOURCES = ["ba_kernels.hip", "ba_etile.hip", "ba_stream.hip", "ba_stream3.hip", "plan_pack.hip", "plan_device.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip", "ga_kernels.hip"]
 HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", "ba_edge.hpp", "ba_update.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
            os.path.join("..", "..", "include", "batrack_se3.h"), os.path.join("..", "..", "include", "batrack_patchify.h"),
            os.path.join("..", "..", "include", "batrack_projective.h"), os.path.join("..", "..", "include", "batrack_ga.h")]
@@ -146,6 +146,8 @@ def lib():
     L.bt_plan_jacobian_kernel.argtypes = [vp]
     L.bt_plan_edge_precision.restype = i32
     L.bt_plan_edge_precision.argtypes = [vp]
+    L.bt_plan_built_on_device.restype = i32
+    L.bt_plan_built_on_device.argtypes = [vp]
     L.bt_target_arch.restype = ctypes.c_char_p
     L.bt_plan_create.restype = i32
     L.bt_plan_create.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, ctypes.POINTER(vp)]

@@ -13,7 +13,7 @@
 
 #include "ba_kernels.hpp"
 
-#define BT_VERSION 203
+#define BT_VERSION 204
 
 namespace bt {
 
@@ -242,7 +242,10 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
     const bool keep_pk = d_packed && pl->e_all > 0 && pl->e_all <= kKeepPackedMaxEdges && pl->info.E == pl->e_all;
-    const size_t pk_off = (buf.size() + 255) / 256 * 256, total = keep_pk ? pk_off + (size_t)pl->e_all * sizeof(uint64_t) : buf.size();
+    // (a plan whose pm_edge is written on the device: the table lies behind the staged bytes, nothing of it crosses PCIe)
+    size_t tables_end = buf.size();
+    if (pl->dev_pm) { O.pme = (buf.size() + 255) / 256 * 256; tables_end = O.pme + (size_t)pl->pm_rounds * kLanes * sizeof(int32_t); }
+    const size_t pk_off = (tables_end + 255) / 256 * 256, total = keep_pk ? pk_off + (size_t)pl->e_all * sizeof(uint64_t) : tables_end;
     void *d = dev_pool().acquire(total + 256, &cap, &reuse_after);
     if (!d) return BT_ENOMEM;
     tick("device buffer");
@@ -252,9 +255,14 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
     const bool waited = !reuse_after || hipStreamWaitEvent(cs, reuse_after, 0) == hipSuccess;
     if (!waited) (void)hipEventSynchronize(reuse_after);
     dev_pool().give_event(reuse_after);
-    if (hipMemcpyAsync(d, buf.data(), buf.size(), hipMemcpyHostToDevice, cs) != hipSuccess ||
-        (keep_pk && hipMemcpyAsync(static_cast<char *>(d) + pk_off, d_packed, (size_t)pl->e_all * sizeof(uint64_t), hipMemcpyDeviceToDevice, cs) != hipSuccess) ||
-        hipStreamSynchronize(cs) != hipSuccess) { dev_pool().release(d, cap, false, nullptr); return BT_EHIP; }
+    bool ok = hipMemcpyAsync(d, buf.data(), buf.size(), hipMemcpyHostToDevice, cs) == hipSuccess &&
+              (!keep_pk || hipMemcpyAsync(static_cast<char *>(d) + pk_off, d_packed, (size_t)pl->e_all * sizeof(uint64_t), hipMemcpyDeviceToDevice, cs) == hipSuccess);
+    if (ok && pl->dev_pm) {
+        bind_pointers(pl, d);                          // (the fill kernel reads the plan's tile tables in the buffer)
+        ok = plan_device_fill(pl, pl->e_all, reinterpret_cast<int32_t *>(static_cast<char *>(d) + O.pmr),
+                              reinterpret_cast<int32_t *>(static_cast<char *>(d) + O.pme), pl->pm_rounds, cs) == BT_OK;
+    }
+    if (!ok || hipStreamSynchronize(cs) != hipSuccess) { dev_pool().release(d, cap, false, nullptr); return BT_EHIP; }
     tick("H2D copy");
     pl->dev_base = d;
     pl->dev_cap = cap;
@@ -319,6 +327,8 @@ int bt_plan_jacobian_kernel(const bt_plan *pl) {
     if (!pl || !pl->dev_base) return -1;
     return edge_applies(pl->dev) ? 2 : stream_applies(pl->dev) ? 1 : etile_precision_bytes(pl->dev) ? 3 : 0;
 }
+int bt_plan_built_on_device(const bt_plan *pl) { return pl && pl->dev_pm ? 1 : 0; }
+
 int bt_plan_edge_precision(const bt_plan *pl) {
     if (!pl || !pl->dev_base) return -1;
     return edge_precision(pl->dev) ? 8 : 4;
@@ -339,8 +349,37 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
         if (!pb.ensure((size_t)E)) return BT_ENOMEM;
         hipStream_t cs = copy_stream();
         if (hipMemsetAsync(pb.d_bad, 0, sizeof(int), cs) != hipSuccess ||
-            launch_pack_edges(ii, jj, kk, E, n_buf, p_tot, pb.d_words, pb.d_bad, cs) != BT_OK ||
-            hipMemcpyAsync(pb.h_words, pb.d_words, (size_t)E * sizeof(uint64_t), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+            launch_pack_edges(ii, jj, kk, E, n_buf, p_tot, pb.d_words, pb.d_bad, cs) != BT_OK)
+            return BT_EHIP;
+        // window plans: the passes over the edges stay on the device (plan_device.hip), the host lays out what is small
+        static const bool dev_planner = !(std::getenv("BT_PLAN_DEVICE") && std::atoi(std::getenv("BT_PLAN_DEVICE")) == 0);
+        if (dev_planner && upload && own_hi <= 0 && E >= 4096) {
+            if (hipMemcpyAsync(pb.h_bad, pb.d_bad, sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess) return BT_EHIP;
+            DevPlanStats st{};
+            int64_t tracks = 0;
+            int rc = plan_device_stats(pb.d_words, E, p_tot, cs, &st, &tracks);       // (synchronises: h_bad is in as well)
+            if (rc != BT_OK && rc != BT_NEED_EDGES) return rc;
+            if (*pb.h_bad) return BT_EINVAL;
+            tick("device: per-track figures");
+            if (rc == BT_OK) {
+                bt_plan *pl = plan_pool().take();
+                if (!pl) return BT_ENOMEM;
+                try {
+                    rc = build_plan_host(nullptr, nullptr, nullptr, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, nullptr, false, &st);
+                    tick("host analysis (no edges)");
+                    int64_t rounds = 0;
+                    if (rc == BT_OK) rc = plan_device_rounds(pl, E, cs, &rounds);
+                    tick("device: rounds");
+                    if (rc == BT_OK) { pl->pm_rounds = rounds; rc = upload_plan(pl, pb.d_words); }
+                } catch (const std::bad_alloc &) {
+                    rc = BT_ENOMEM;
+                }
+                if (rc == BT_OK) { *out = pl; return BT_OK; }
+                bt_plan_destroy(pl);
+                if (rc != BT_NEED_EDGES) return rc;
+            }
+        }
+        if (hipMemcpyAsync(pb.h_words, pb.d_words, (size_t)E * sizeof(uint64_t), hipMemcpyDeviceToHost, cs) != hipSuccess ||
             hipMemcpyAsync(pb.h_bad, pb.d_bad, sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess ||
             hipStreamSynchronize(cs) != hipSuccess)
             return BT_EHIP;
@@ -399,7 +438,7 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
     pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
     pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
     pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
-    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
+    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
     void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);

@@ -75,7 +75,7 @@ int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
 int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk64, int64_t E,
                     int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
-                    int64_t own_lo, int64_t own_hi, bt_plan *pl, const uint64_t *packed, bool keep_slots) {
+                    int64_t own_lo, int64_t own_hi, bt_plan *pl, const uint64_t *packed, bool keep_slots, const DevPlanStats *dstats) {
     if (E < 0 || n_buf <= 0 || p_tot <= 0 || fixedp < 0 || n_all_min < 0 || n_all_min > n_buf) return BT_EINVAL;
     if (E > (int64_t)0x7fffffff / 2 || p_tot > (int64_t)0x7fffffff) return BT_EUNSUPPORTED;
     if (n_buf > 32768) return BT_EUNSUPPORTED;             // frame numbers are packed in pairs into signed 32-bit words (tile_ij)
@@ -92,7 +92,9 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     BT_TICK("0");
     static thread_local std::vector<uint64_t> pk_scratch;
     const uint64_t *pk = packed;
-    if (!pk) {
+    pl->dev_pm = 0;
+    if (dstats && (keep_slots || own_lo != 0 || own_hi != p_tot || E <= 0)) return BT_NEED_EDGES;
+    if (!pk && !dstats) {
         pk_scratch.resize((size_t)E + 1);
         const int rc = pack_edges_host(ii64, jj64, kk64, E, n_buf, p_tot, pk_scratch.data());
         if (rc != BT_OK) return rc;
@@ -118,6 +120,16 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     std::vector<int32_t> cj((size_t)n_buf + 2, 0);
     int64_t E_own = 0, k_prev = -1;
     bool src_ok = true, any_self = false;
+    if (dstats) {
+        // the same figures from the device's table (bit b of a mask: target frame src - 32 + b)
+        n_all = std::max(n_all, dstats->n_all); f_lo = dstats->f_lo; kmin = dstats->kmin; kmax = dstats->kmax;
+        any_self = dstats->any_self != 0; sorted = false; E_own = E;
+        for (int64_t k = kmin; k <= kmax; ++k) {
+            const PatchStat &d = dstats->tab[(size_t)(k - kmin)];
+            PerPatch &t = pp[k];
+            t.cnt = d.cnt; t.src = d.src; t.base = d.src - 32; t.last_j = 0; t.mask = d.mask;
+        }
+    } else
     for (int64_t e = 0; e < E; ++e) {
         const int64_t k = KK(e), i = II(e), j = JJ(e);
         any_self |= i == j;
@@ -208,7 +220,9 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     std::vector<uint64_t> &pks = pks_scratch;
     ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1); pks.resize((size_t)E_own + 1);
     std::vector<int32_t> cur(off.begin(), off.end() - 1);
-    if (mono_j) {
+    if (dstats) {
+        // (no edge is read: the order of a track's edges is the device's sort)
+    } else if (mono_j) {
         // every track's edges already come in (target frame, index) order: one stable scatter by track
         for (int64_t e = 0; e < E; ++e)
             if (E_own == E || owned(e)) { const int32_t q = cur[(size_t)trk_of(KK(e))]++; ord[(size_t)q] = (int32_t)e; pks[(size_t)q] = pk[e]; }
@@ -272,6 +286,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         if (env > 0) tcap = std::min<int>(kLanes, env);
         else if (pm_env && !tcap_retry && t64 > 0 && t64 <= 96 && E_own >= 24 * (int64_t)m && t64 < std::min(edge_min_tiles(), stream_min_tiles()) / 4) tcap = 16;
     }
+    if (dstats && tcap == kLanes) return BT_NEED_EDGES;            // (the device writes the pair-major table of window plans only)
     for (int32_t k = 0; k < m; ++k) {
         trk_set.clear();
         if (masks_ok) {
@@ -367,6 +382,23 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                 // pair-major tables of this tile (layout: the block further down that builds them from the slot arrays)
                 const int32_t np = (int32_t)mine.size();
                 if (np > kLanes) pm_fail = true;
+                else if (dstats) {
+                    // the tile's record but for its rounds, the local target camera of its pairs and the local source camera
+                    // of its tracks; the table itself and the rounds come from the device
+                    int lg = 0;
+                    while ((1 << lg) < np) ++lg;
+                    const int32_t G = kLanes >> lg;
+                    pl->pm_rec[(size_t)t * 4 + 1] = lg;
+                    pl->pm_rec[(size_t)t * 4 + 2] = (nt + G - 1) / G;
+                    for (int32_t q = 0; q < np; ++q) {
+                        const int64_t b2 = (int64_t)pl->pair_j[(size_t)mine[(size_t)q]] - fixedp;
+                        pl->pm_lb[(size_t)t * kLanes + (size_t)q] = b2 >= 0 ? (uint8_t)local[(size_t)b2] : (uint8_t)0xff;
+                    }
+                    for (int32_t l = 0; l < nt; ++l) {
+                        const int64_t a2 = (int64_t)pp[pl->kx[(size_t)(t0 + l)]].src - fixedp;
+                        pl->pm_la[(size_t)t * kLanes + (size_t)l] = a2 >= 0 ? (uint8_t)local[(size_t)a2] : (uint8_t)0xff;
+                    }
+                }
                 else {
                     int lg = 0;
                     while ((1 << lg) < np) ++lg;
@@ -970,6 +1002,11 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // pm_ok: 2 = the plan was tiled FOR the pair-major kernel (small tiles) or BT_ETILE=2 forces it, 1 = the tables exist but
     // k_tile keeps the plan (at one tile per CU, e.g. the 64-keyframe benchmark, k_tile measured 12.7 us against 15.0)
     pl->pm_ok = I.tiles > 0 ? 1 : 0; pl->pm_rounds = 0;
+    if (dstats) {
+        if (pm_fail || I.tiles <= 0 || etile_full_lds_bytes(pl->max_rows16, pl->max_tile_pairs, sizeof(double)) > kEtileLdsBudget) return BT_NEED_EDGES;
+        pl->pm_ok = 2; pl->dev_pm = 1;
+        pl->dev_pair_of = pair_of; pl->dev_f_lo = f_lo; pl->dev_nw = nw;
+    } else
     if (pm_direct) {
         // (built tile by tile above) — the plan stays with k_etile only if that kernel's LDS need fits in float64
         if (pm_fail || I.tiles <= 0 || etile_full_lds_bytes(pl->max_rows16, pl->max_tile_pairs, sizeof(double)) > kEtileLdsBudget) {

@@ -127,6 +127,10 @@ struct bt_plan {
     std::vector<uint8_t> pm_lb, pm_la;
     std::vector<int32_t> pp_ptr, pp_idx, sg_ptr;
     int pm_ok = 0, sp_ok = 0, sg_n = 0, et_lgts = 0, trk_off = 0;
+    // plans whose pm_edge is written on the device (plan_device.hip): the table's rounds, and what the kernels need of the host's analysis
+    int dev_pm = 0;
+    std::vector<int32_t> dev_pair_of;                         // [nw * nw]: pair index of (i - f_lo, j - f_lo) or -1
+    int64_t dev_f_lo = 0, dev_nw = 0;
     long long pm_rounds = 0;
     long long em_its = 0;
     int max_tile_pairs = 0, max_tile_slots = 0;
@@ -176,9 +180,21 @@ int edge_min_tiles();
 int stream_min_tiles();
 // Pure host analysis (no HIP).  Returns BT_OK or an error code.
 // `packed` (optional): the edges as 8-byte words kk << 32 | ii << 16 | jj, already range-checked (ii / jj / kk are then not read)
+// `dstats` (optional; plan_device.hip): the per-track figures of the edge list as a kernel gathered them — the analysis then
+// reads NO edge: it lays out tracks, pairs, tiles and the reduced system from the tracks' (source frame, target mask), and
+// leaves the one edge-sized table of a window plan (pm_edge) and the tiles' round counts to the device
+// (bt_plan::dev_pm).  Returns BT_NEED_EDGES where that does not apply (the caller then runs the analysis on the edges).
+struct PatchStat { int32_t cnt, src; unsigned long long mask; };      // mask bit b: an edge into frame src - 32 + b
+struct DevPlanStats {
+    const PatchStat *tab;          // [kmax - kmin + 1], the patches kmin .. kmax
+    int64_t kmin, kmax, n_all, f_lo;
+    int any_self;
+};
+enum { BT_NEED_EDGES = 2 };
 int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
                     int64_t n_buf, int64_t p_tot, int64_t fixedp, int64_t n_all_min,
-                    int64_t own_lo, int64_t own_hi, bt_plan *plan, const uint64_t *packed = nullptr, bool keep_slots = false);
+                    int64_t own_lo, int64_t own_hi, bt_plan *plan, const uint64_t *packed = nullptr, bool keep_slots = false,
+                    const DevPlanStats *dstats = nullptr);
 // the same packing on the device (plan_pack.hip): `out` E words and `bad` one int (set to 1 on an index out of range), device memory
 int launch_shift_match(const uint64_t *nw, const uint64_t *ow, int64_t E, int *out, void *stream);
 int launch_plan_shift(int32_t *kx, int m, int32_t *tile_kx, int nkx, int32_t *tile_ij, int nij, int32_t *pair_i, int32_t *pair_j, int P,
@@ -186,6 +202,10 @@ int launch_plan_shift(int32_t *kx, int m, int32_t *tile_kx, int nkx, int32_t *ti
 int launch_pack_edges(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
                       uint64_t *out, int *bad, void *stream);
 int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot, uint64_t *out);
+// the passes over the edges on the device (plan_device.hip; bt_plan_create)
+int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *stream, DevPlanStats *st, int64_t *tracks);
+int plan_device_rounds(const bt_plan *pl, int64_t E, void *stream, int64_t *rounds);
+int plan_device_fill(const bt_plan *pl, int64_t E, int32_t *d_rec, int32_t *d_pm_edge, int64_t rounds, void *stream);
 // Copies the arrays to the device and fills plan->dev (ba_api.cpp).
 int upload_plan(bt_plan *plan);
 }  // namespace bt

@@ -1,0 +1,279 @@
+// plan_device.hip — the planner's passes over the EDGES on the device (window plans: the pair-major layout of k_etile).
+//
+// A plan from scratch cost ~1.4 ms of host analysis for the 138k-edge window (ba_plan.cpp), nearly all of it in three passes
+// that touch every edge: the per-track figures (count, source frame, set of target frames), the grouping of the edges by
+// track, and the walk that writes the one edge-sized table of such a plan (pm_edge).  The caller's sliding window changes its
+// edge list every frame (batrack.py:189-212) and the list is a shifted copy of an earlier one only in steady state: while the
+// window fills, every update() pays a plan from scratch.  Here the three passes run where the edge list already is:
+//   k_plan_stats    one thread per edge: atomics into a per-patch table (count, source frame, mask of target frames around the
+//                   source frame) and the figures of the whole list (frames and patches named, self edges)
+//   radix sort      of (patch - first patch) << bits | (target frame - first frame), some 18 bits, with the edge index as value
+//                   (hipcub / rocPRIM, stable): a track's edges in (target frame, index) order — the order the host's stable
+//                   counting passes produce.  Runs while the host lays out the small tables.
+//   k_plan_rounds   the round of every edge = its rank among the edges of the same (track, pair), the tiles' round counts
+//   k_plan_prefix   first round of every tile, the records' final words, the table's size
+//   k_plan_fill     writes pm_edge into the uploaded plan
+// The host keeps what is small: tracks, pairs, tiles, the reduced system's symbolic factorisation (ba_plan.cpp reads the
+// per-patch table instead of the edges).  Anything that does not fit — a track whose target frames are not within 32 of its
+// source frame, two source frames for one track, 64-track tiles, sharded plans — falls back to the analysis on the edges.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "ba_plan.hpp"
+
+namespace bt {
+
+// glob: 0 n_all, 1 f_lo, 2 kmin, 3 kmax, 4 any_self, 5 two source frames for a track, 6 a target outside the mask, 7 tracks
+__global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *words, long long E, PatchStat *stat, int *glob, int *vals) {
+    __shared__ int s_max_f, s_min_f, s_kmin, s_kmax, s_flags, s_trk;
+    if (threadIdx.x == 0) { s_max_f = 0; s_min_f = 0x7fffffff; s_kmin = 0x7fffffff; s_kmax = -1; s_flags = 0; s_trk = 0; }
+    __syncthreads();
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) {
+        const unsigned long long w = words[e];
+        const int k = (int)(w >> 32), i = (int)((w >> 16) & 0xffff), j = (int)(w & 0xffff);
+        vals[e] = (int)e;
+        int fl = i == j ? 1 : 0;
+        PatchStat *t = stat + k;
+        if (atomicAdd(&t->cnt, 1) == 0) atomicAdd(&s_trk, 1);
+        const int prev = atomicCAS(&t->src, -1, i);
+        if (prev != -1 && prev != i) fl |= 2;
+        const int bit = j - (i - 32);
+        if (bit < 0 || bit >= 64) fl |= 4;
+        else atomicOr(&t->mask, 1ull << bit);
+        atomicMax(&s_max_f, max(i, j) + 1); atomicMin(&s_min_f, min(i, j));
+        atomicMin(&s_kmin, k); atomicMax(&s_kmax, k);
+        if (fl) atomicOr(&s_flags, fl);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(&glob[0], s_max_f); atomicMin(&glob[1], s_min_f); atomicMin(&glob[2], s_kmin); atomicMax(&glob[3], s_kmax);
+        if (s_flags & 1) glob[4] = 1;
+        if (s_flags & 2) glob[5] = 1;
+        if (s_flags & 4) glob[6] = 1;
+        if (s_trk) atomicAdd(&glob[7], s_trk);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_plan_stat_clear(PatchStat *stat, long long lo, long long hi) {
+    const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= hi) { stat[p].cnt = 0; stat[p].src = -1; stat[p].mask = 0ull; }
+}
+
+// The sort key of an edge: (patch - kmin) << jbits | (target frame - f_lo) — some 18 bits for a window instead of the 50 of
+// the packed word (a track has ONE source frame, so the word's middle field orders nothing): three radix passes, not seven.
+__global__ __launch_bounds__(256) void k_plan_keys(const unsigned long long *words, long long E, int kmin, int f_lo, int jbits, unsigned *keys) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const unsigned long long w = words[e];
+    keys[e] = ((unsigned)((int)(w >> 32) - kmin) << jbits) | (unsigned)((int)(w & 0xffff) - f_lo);
+}
+
+struct PlanFillArgs {
+    const unsigned *keys;                  // the sorted keys
+    const int *vals;                       // their edge indices
+    const unsigned long long *words;       // the packed edge list (caller's order)
+    int jbits;
+    long long E;
+    const int *trk_win;                    // patch - kmin -> track
+    const int *trk_loc;                    // track -> tile << 6 | lane
+    const int *pair_of; int f_lo, nw;      // (i - f_lo) * nw + (j - f_lo) -> pair
+    const int *tile_pair0, *tile_npair, *tile_pairs;
+    int *rec;                              // pm_rec [tiles][4]
+    unsigned char *dcode;                  // [E]: the round of every sorted edge
+    int *dmax;                             // [tiles]
+    int *out;                              // 0: rounds of the whole table, 1: some (track, pair) has more than 255 edges
+    int *pm_edge;
+};
+
+__global__ __launch_bounds__(256) void k_plan_rounds(PlanFillArgs a) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = q < a.E;                              // (the grid's last wave is partial: its idle lanes take part in the votes below)
+    if ((long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63) >= a.E) return;
+    const unsigned key = valid ? a.keys[q] : 0u;
+    int d = 0;
+    if (valid) {
+        while (d < 256 && q - d - 1 >= 0 && a.keys[q - d - 1] == key) ++d;
+        if (d > 255) { a.out[1] = 1; d = 255; }
+        a.dcode[q] = (unsigned char)d;
+    }
+    // one atomic per wave where the wave's edges are all of one tile — the sorted order keeps a tile's ~900 edges together
+    // (138k atomics on the tiles' 160 counters were 0.3 ms of this kernel)
+    const int t = valid ? a.trk_loc[a.trk_win[key >> a.jbits]] >> 6 : -1;
+    const int t0 = __builtin_amdgcn_readfirstlane(t);           // (lane 0 of a wave that got here is valid)
+    if (__all(!valid || t == t0)) {
+        int mx = valid ? d + 1 : 0;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = max(mx, __shfl_xor(mx, m));
+        if ((threadIdx.x & 63) == 0) atomicMax(&a.dmax[t0], mx);
+    } else if (valid && (q + 1 == a.E || a.keys[q + 1] != key)) atomicMax(&a.dmax[t], d + 1);
+}
+
+__global__ void k_plan_prefix(int *rec, const int *dmax, int T, int *out) {
+    if (threadIdx.x || blockIdx.x) return;
+    long long acc = 0;
+    for (int t = 0; t < T; ++t) {
+        const int D = max(dmax[t], 1);
+        rec[4 * t] = (int)acc;
+        rec[4 * t + 1] = (rec[4 * t + 1] & 0xff) | (D << 8);
+        acc += (long long)rec[4 * t + 2] * D;
+    }
+    out[0] = acc > 0x7fffffffll / 64 ? -1 : (int)acc;
+}
+
+__global__ __launch_bounds__(256) void k_plan_fill(PlanFillArgs a) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.E) return;
+    const unsigned key = a.keys[q];
+    const int e = a.vals[q];
+    const unsigned long long w = a.words[e];
+    const int i = (int)((w >> 16) & 0xffff), j = (int)(w & 0xffff);
+    const int loc = a.trk_loc[a.trk_win[key >> a.jbits]], t = loc >> 6, l = loc & 63;
+    const int gp = a.pair_of[(i - a.f_lo) * a.nw + (j - a.f_lo)];
+    const int *tp = a.tile_pairs + a.tile_pair0[t];
+    int lo = 0, hi = a.tile_npair[t] - 1;                       // (the tile's pairs are ascending)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tp[mid] < gp) lo = mid + 1; else hi = mid; }
+    const int round0 = a.rec[4 * t], lg = a.rec[4 * t + 1] & 0xff, D = a.rec[4 * t + 1] >> 8, G = 64 >> lg;
+    a.pm_edge[((size_t)round0 + (size_t)(l / G) * D + a.dcode[q]) * 64 + (size_t)((l % G) << lg) + (size_t)lo] = e;
+}
+
+// ------------------------------------------------------------------ host side of the passes
+namespace {
+struct DevPlanBuffers {
+    PatchStat *stat = nullptr; size_t stat_cap = 0; long long dirty_lo = 0, dirty_hi = -1;
+    int *glob = nullptr, *h_glob = nullptr;                       // 8 + 2 ints (device, pinned host)
+    unsigned *keys_in = nullptr, *keys = nullptr; int *vals_in = nullptr, *vals = nullptr; unsigned char *dcode = nullptr; size_t e_cap = 0;
+    const unsigned long long *words = nullptr; int jbits = 0;
+    void *temp = nullptr; size_t temp_cap = 0;
+    PatchStat *h_tab = nullptr; size_t tab_cap = 0;              // pinned: the window's slice of the table
+    int *small = nullptr, *h_small = nullptr; size_t small_cap = 0;   // trk_win | trk_loc | pair_of | rec | dmax (device, pinned staging)
+    bool grow_edges(size_t E) {
+        if (E <= e_cap) return true;
+        (void)hipFree(keys_in); (void)hipFree(keys); (void)hipFree(vals_in); (void)hipFree(vals); (void)hipFree(dcode);
+        const size_t want = E + E / 4 + 4096;
+        if (hipMalloc(reinterpret_cast<void **>(&keys_in), want * 4) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&keys), want * 4) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&vals_in), want * 4) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&vals), want * 4) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&dcode), want) != hipSuccess) { e_cap = 0; return false; }
+        e_cap = want;
+        return true;
+    }
+};
+DevPlanBuffers &bufs() { static thread_local DevPlanBuffers b; return b; }
+}  // namespace
+
+// Pass 1: the per-patch table and the list's figures.  On BT_OK *st describes the table slice (pinned host memory, valid until
+// the thread's next call) and the sort of the words has been queued behind it on `stream`.  BT_NEED_EDGES: not a list this
+// path takes.
+int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *stream, DevPlanStats *st, int64_t *tracks) {
+    hipStream_t cs = static_cast<hipStream_t>(stream);
+    DevPlanBuffers &b = bufs();
+    if (!b.glob) {
+        if (hipMalloc(reinterpret_cast<void **>(&b.glob), 16 * sizeof(int)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&b.h_glob), 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) return BT_ENOMEM;
+    }
+    if ((size_t)p_tot > b.stat_cap) {
+        (void)hipFree(b.stat);
+        if (hipMalloc(reinterpret_cast<void **>(&b.stat), (size_t)p_tot * sizeof(PatchStat)) != hipSuccess) { b.stat_cap = 0; return BT_ENOMEM; }
+        b.stat_cap = (size_t)p_tot; b.dirty_lo = 0; b.dirty_hi = p_tot - 1;
+    }
+    if (!b.grow_edges((size_t)E)) return BT_ENOMEM;
+    if (b.dirty_hi >= b.dirty_lo)
+        hipLaunchKernelGGL(k_plan_stat_clear, dim3((unsigned)((b.dirty_hi - b.dirty_lo + 256) / 256)), dim3(256), 0, cs, b.stat, b.dirty_lo, b.dirty_hi);
+    b.h_glob[0] = 0; b.h_glob[1] = 0x7fffffff; b.h_glob[2] = 0x7fffffff; b.h_glob[3] = -1;
+    for (int c = 4; c < 10; ++c) b.h_glob[c] = 0;
+    if (hipMemcpyAsync(b.glob, b.h_glob, 10 * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess) return BT_EHIP;
+    hipLaunchKernelGGL(k_plan_stats, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, reinterpret_cast<const unsigned long long *>(d_words),
+                       (long long)E, b.stat, b.glob, b.vals_in);
+    if (hipMemcpyAsync(b.h_glob, b.glob, 8 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
+    const int *g = b.h_glob;
+    b.dirty_lo = g[2]; b.dirty_hi = g[3];
+    *tracks = g[7];
+    if (g[5] || g[6] || g[3] < g[2]) return BT_NEED_EDGES;
+    // (window plans only: the same test as the planner's choice of 16-track tiles, before anything else is copied)
+    const int64_t t64 = ((int64_t)g[7] + kLanes - 1) / kLanes;
+    if (!(t64 > 0 && t64 <= 96 && E >= 24 * (int64_t)g[7])) return BT_NEED_EDGES;
+    const size_t nt = (size_t)(g[3] - g[2] + 1);
+    if (nt > b.tab_cap) {
+        (void)hipHostFree(b.h_tab);
+        if (hipHostMalloc(reinterpret_cast<void **>(&b.h_tab), (nt + nt / 4 + 1024) * sizeof(PatchStat), hipHostMallocDefault) != hipSuccess) { b.tab_cap = 0; return BT_ENOMEM; }
+        b.tab_cap = nt + nt / 4 + 1024;
+    }
+    hipEvent_t ev = nullptr;
+    if (hipMemcpyAsync(b.h_tab, b.stat + g[2], nt * sizeof(PatchStat), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, cs) != hipSuccess) return BT_EHIP;
+    // the sort runs while the host lays out tracks, pairs and tiles
+    int jbits = 1, kbits = 1;
+    while ((1 << jbits) < g[0] - g[1]) ++jbits;
+    while (kbits < 31 && ((int64_t)1 << kbits) < (int64_t)g[3] - g[2] + 1) ++kbits;
+    if (jbits + kbits > 32) { (void)hipEventDestroy(ev); return BT_NEED_EDGES; }
+    b.words = reinterpret_cast<const unsigned long long *>(d_words); b.jbits = jbits;
+    hipLaunchKernelGGL(k_plan_keys, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, b.words, (long long)E, g[2], g[1], jbits, b.keys_in);
+    size_t need = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, need, b.keys_in, b.keys, b.vals_in, b.vals, (int)E, 0, jbits + kbits, cs);
+    if (need > b.temp_cap) {
+        (void)hipFree(b.temp);
+        if (hipMalloc(&b.temp, need + need / 4 + 4096) != hipSuccess) { b.temp_cap = 0; (void)hipEventDestroy(ev); return BT_ENOMEM; }
+        b.temp_cap = need + need / 4 + 4096;
+    }
+    size_t tb = b.temp_cap;
+    const bool sorted_ok = hipcub::DeviceRadixSort::SortPairs(b.temp, tb, b.keys_in, b.keys, b.vals_in, b.vals, (int)E, 0, jbits + kbits, cs) == hipSuccess;
+    const bool waited = hipEventSynchronize(ev) == hipSuccess;
+    (void)hipEventDestroy(ev);
+    if (!sorted_ok || !waited) return BT_EHIP;
+    st->tab = b.h_tab; st->kmin = g[2]; st->kmax = g[3]; st->n_all = g[0]; st->f_lo = g[1]; st->any_self = g[4];
+    return BT_OK;
+}
+
+// Pass 2 (after the host analysis): the rounds.  Leaves the final tile records and the staged tables on the device for
+// plan_device_fill; *rounds = the table's rounds.  BT_NEED_EDGES if some (track, pair) has more than 255 edges.
+int plan_device_rounds(const bt_plan *pl, int64_t E, void *stream, int64_t *rounds) {
+    hipStream_t cs = static_cast<hipStream_t>(stream);
+    DevPlanBuffers &b = bufs();
+    const size_t T = (size_t)pl->info.tiles, nwin = pl->trk_win.size(), m = pl->trk_loc.size(), npo = pl->dev_pair_of.size();
+    const size_t n_small = nwin + m + npo + 4 * T + T + 2;
+    if (n_small > b.small_cap) {
+        (void)hipFree(b.small); (void)hipHostFree(b.h_small);
+        const size_t want = n_small + n_small / 4 + 4096;
+        if (hipMalloc(reinterpret_cast<void **>(&b.small), want * sizeof(int)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&b.h_small), want * sizeof(int), hipHostMallocDefault) != hipSuccess) { b.small_cap = 0; return BT_ENOMEM; }
+        b.small_cap = want;
+    }
+    int *h = b.h_small;
+    std::copy(pl->trk_win.begin(), pl->trk_win.end(), h);
+    std::copy(pl->trk_loc.begin(), pl->trk_loc.end(), h + nwin);
+    std::copy(pl->dev_pair_of.begin(), pl->dev_pair_of.end(), h + nwin + m);
+    std::copy(pl->pm_rec.begin(), pl->pm_rec.end(), h + nwin + m + npo);
+    std::fill(h + nwin + m + npo + 4 * T, h + n_small, 0);
+    if (hipMemcpyAsync(b.small, h, n_small * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess) return BT_EHIP;
+    PlanFillArgs a{};
+    a.keys = b.keys; a.vals = b.vals; a.words = b.words; a.jbits = b.jbits; a.E = E;
+    a.trk_win = b.small; a.trk_loc = b.small + nwin;
+    a.pair_of = b.small + nwin + m; a.f_lo = (int)pl->dev_f_lo; a.nw = (int)pl->dev_nw;
+    a.rec = b.small + nwin + m + npo; a.dmax = a.rec + 4 * T; a.out = a.dmax + T; a.dcode = b.dcode;
+    hipLaunchKernelGGL(k_plan_rounds, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, a);
+    hipLaunchKernelGGL(k_plan_prefix, dim3(1), dim3(64), 0, cs, a.rec, a.dmax, (int)T, a.out);
+    if (hipMemcpyAsync(b.h_glob + 10, a.out, 2 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
+    if (b.h_glob[11] || b.h_glob[10] < 0) return BT_NEED_EDGES;
+    *rounds = b.h_glob[10];
+    return BT_OK;
+}
+
+// Pass 3 (queued behind the upload of the plan's tables on `stream`): the tile records and pm_edge in the plan's buffer.
+int plan_device_fill(const bt_plan *pl, int64_t E, int32_t *d_rec, int32_t *d_pm_edge, int64_t rounds, void *stream) {
+    hipStream_t cs = static_cast<hipStream_t>(stream);
+    DevPlanBuffers &b = bufs();
+    const size_t T = (size_t)pl->info.tiles, nwin = pl->trk_win.size(), m = pl->trk_loc.size(), npo = pl->dev_pair_of.size();
+    PlanFillArgs a{};
+    a.keys = b.keys; a.vals = b.vals; a.words = b.words; a.jbits = b.jbits; a.E = E;
+    a.trk_win = b.small; a.trk_loc = b.small + nwin;
+    a.pair_of = b.small + nwin + m; a.f_lo = (int)pl->dev_f_lo; a.nw = (int)pl->dev_nw;
+    a.tile_pair0 = pl->dev.tile_pair0; a.tile_npair = pl->dev.tile_npair; a.tile_pairs = pl->dev.tile_pairs;
+    a.rec = d_rec; a.dcode = b.dcode; a.pm_edge = d_pm_edge;
+    if (hipMemcpyAsync(d_rec, b.small + nwin + m + npo, 4 * T * sizeof(int), hipMemcpyDeviceToDevice, cs) != hipSuccess ||
+        hipMemsetAsync(d_pm_edge, 0xff, (size_t)rounds * kLanes * sizeof(int32_t), cs) != hipSuccess) return BT_EHIP;
+    hipLaunchKernelGGL(k_plan_fill, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, a);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+}  // namespace bt

@@ -103,6 +103,11 @@ class Plan:
         """8 | 4: bytes of the floating-point type of the per-edge maths of this plan's steps (bt_plan_edge_precision)."""
         return self._lib.bt_plan_edge_precision(self._h)
 
+    @property
+    def built_on_device(self):
+        """True if the planner's passes over the edges ran on the device (bt_plan_built_on_device)."""
+        return bool(self._lib.bt_plan_built_on_device(self._h))
+
     def array(self, name):
         """Host copy of a plan array (tests / tooling)."""
         p = ctypes.c_void_p()

@@ -538,3 +538,37 @@ def test_random_graph_sweep():
             worst = max(worst, err)
         assert so or o["status"] == 0
     assert worst < tol(STATE_TOL, 1e-4)
+
+
+def test_device_planned_window_plan_equals_the_host_planned_one():
+    """bt_plan_create with DEVICE index tensors plans a sliding-window list on the device (per-track figures, radix sort, the
+    pair-major table by kernels; the host lays out tracks, pairs, tiles and the reduced system without reading an edge); with
+    host arrays the host analyses the edges.  Same tables either way: the two plans' steps agree to the last bits (the few
+    float64 atomics of k_pair_finalize are the only order-dependent sums), and a list the device path does not take — target
+    frames 40 away from the source frame — still gets its plan."""
+    from batrack_amd.plan import Plan, Stepper
+    dev = "cuda:0"
+    g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
+    f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
+    poses, patches, mono, intr, t3, w = f32(g.poses), f32(g.patches), f32(g.mono_disp), f32(g.intrinsics), f32(g.targets3), f32(g.weights_pose)
+    outs = []
+    forced = any(v in os.environ for v in ("BT_ETILE", "BT_EDGE_MIN_TILES", "BT_STREAM_MIN_TILES", "BT_EDGE_OFF", "BT_TILE_TRACKS"))   # (the suites of test_gpu_jacobian_kernels.py)
+    for on_dev in (True, False):
+        idx = [torch.as_tensor(a, device=dev) for a in (g.ii, g.jj, g.kk)] if on_dev else [np.asarray(a) for a in (g.ii, g.jj, g.kk)]
+        plan = Plan(*idx, poses.shape[0], patches.shape[0], fixedp)
+        if not forced:
+            assert plan.jacobian_kernel == "k_etile" and plan.built_on_device == (on_dev and os.environ.get("BT_PLAN_DEVICE", "1") != "0")
+        st = Stepper(plan, dev)
+        Po, Xo = torch.empty_like(poses), torch.empty_like(patches)
+        st.step(poses, patches, mono, intr, t3, 3, w, Po, Xo, list(g.bounds), 1e-4, 10.0, 0.05, "huber", False)
+        torch.cuda.synchronize()
+        outs.append((Po.cpu().numpy().astype(np.float64), Xo.cpu().numpy().astype(np.float64), plan.tiles, plan.m, plan.pairs))
+    a, b = outs
+    assert a[2:] == b[2:]
+    assert rel(a[0], b[0]) < 1e-7 and rel(a[1], b[1]) < 1e-7          # (float32 outputs of float64 sums that differ in their last bits)
+    # a window whose tracks reach 40 frames back: outside the device path's 64-frame mask around the source frame
+    g2, fp2 = graphgen.make_window_graph(n_frames=60, M=64, seed=5, window=40, removal=45)
+    idx = [torch.as_tensor(a, device=dev) for a in (g2.ii, g2.jj, g2.kk)]
+    p2 = Plan(*idx, g2.poses.shape[0], g2.patches.shape[0], fp2)
+    ref = Plan(np.asarray(g2.ii), np.asarray(g2.jj), np.asarray(g2.kk), g2.poses.shape[0], g2.patches.shape[0], fp2, upload=False)
+    assert not p2.built_on_device and (p2.tiles, p2.m, p2.pairs, p2.n) == (ref.tiles, ref.m, ref.pairs, ref.n)
