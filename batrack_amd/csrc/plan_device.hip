@@ -26,9 +26,10 @@
 namespace bt {
 
 // glob: 0 n_all, 1 f_lo, 2 kmin, 3 kmax, 4 any_self, 5 two source frames for a track, 6 a target outside the mask, 7 tracks
+// (no atomic here returns a value: 415k returning atomics on the per-patch records were 85 us of a 138k-edge list)
 __global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *words, long long E, PatchStat *stat, int *glob, int *vals) {
-    __shared__ int s_max_f, s_min_f, s_kmin, s_kmax, s_flags, s_trk;
-    if (threadIdx.x == 0) { s_max_f = 0; s_min_f = 0x7fffffff; s_kmin = 0x7fffffff; s_kmax = -1; s_flags = 0; s_trk = 0; }
+    __shared__ int s_max_f, s_min_f, s_kmin, s_kmax, s_flags;
+    if (threadIdx.x == 0) { s_max_f = 0; s_min_f = 0x7fffffff; s_kmin = 0x7fffffff; s_kmax = -1; s_flags = 0; }
     __syncthreads();
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < E) {
@@ -37,9 +38,9 @@ __global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *wo
         vals[e] = (int)e;
         int fl = i == j ? 1 : 0;
         PatchStat *t = stat + k;
-        if (atomicAdd(&t->cnt, 1) == 0) atomicAdd(&s_trk, 1);
-        const int prev = atomicCAS(&t->src, -1, i);
-        if (prev != -1 && prev != i) fl |= 2;
+        atomicAdd(&t->cnt, 1);
+        atomicMax(&t->src, i);                      // (one source frame per track is checked below: min == max)
+        atomicMin(&t->src_min, i);
         const int bit = j - (i - 32);
         if (bit < 0 || bit >= 64) fl |= 4;
         else atomicOr(&t->mask, 1ull << bit);
@@ -51,15 +52,26 @@ __global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *wo
     if (threadIdx.x == 0) {
         atomicMax(&glob[0], s_max_f); atomicMin(&glob[1], s_min_f); atomicMin(&glob[2], s_kmin); atomicMax(&glob[3], s_kmax);
         if (s_flags & 1) glob[4] = 1;
-        if (s_flags & 2) glob[5] = 1;
         if (s_flags & 4) glob[6] = 1;
-        if (s_trk) atomicAdd(&glob[7], s_trk);
     }
+}
+
+// tracks (patches with an edge) and the one-source-frame check over the window's slice of the table
+__global__ __launch_bounds__(256) void k_plan_count(const PatchStat *stat, int *glob) {
+    const int kmin = glob[2], kmax = glob[3];
+    int n = 0, bad = 0;
+    for (int p = kmin + (int)(blockIdx.x * blockDim.x + threadIdx.x); p <= kmax; p += (int)(gridDim.x * blockDim.x)) {
+        const PatchStat t = stat[p];
+        if (t.cnt > 0) { ++n; bad |= t.src != t.src_min; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { n += __shfl_xor(n, m); bad |= __shfl_xor(bad, m); }
+    if ((threadIdx.x & 63) == 0) { if (n) atomicAdd(&glob[7], n); if (bad) glob[5] = 1; }
 }
 
 __global__ __launch_bounds__(256) void k_plan_stat_clear(PatchStat *stat, long long lo, long long hi) {
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p <= hi) { stat[p].cnt = 0; stat[p].src = -1; stat[p].mask = 0ull; }
+    if (p <= hi) { stat[p].cnt = 0; stat[p].src = -1; stat[p].src_min = 0x7fffffff; stat[p].mask = 0ull; }
 }
 
 // The sort key of an edge: (patch - kmin) << jbits | (target frame - f_lo) — some 18 bits for a window instead of the 50 of
@@ -111,16 +123,28 @@ __global__ __launch_bounds__(256) void k_plan_rounds(PlanFillArgs a) {
     } else if (valid && (q + 1 == a.E || a.keys[q + 1] != key)) atomicMax(&a.dmax[t], d + 1);
 }
 
-__global__ void k_plan_prefix(int *rec, const int *dmax, int T, int *out) {
-    if (threadIdx.x || blockIdx.x) return;
-    long long acc = 0;
-    for (int t = 0; t < T; ++t) {
+// first round of every tile (exclusive prefix of iterations x rounds), the records' final words, the table's rounds
+__global__ __launch_bounds__(256) void k_plan_prefix(int *rec, const int *dmax, int T, int *out) {
+    __shared__ long long part[256];
+    const int tid = threadIdx.x, per = (T + 255) / 256, t0 = tid * per, t1 = min(T, t0 + per);
+    long long sum = 0;
+    for (int t = t0; t < t1; ++t) sum += (long long)rec[4 * t + 2] * max(dmax[t], 1);
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const long long v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    long long acc = tid ? part[tid - 1] : 0;
+    for (int t = t0; t < t1; ++t) {
         const int D = max(dmax[t], 1);
         rec[4 * t] = (int)acc;
         rec[4 * t + 1] = (rec[4 * t + 1] & 0xff) | (D << 8);
         acc += (long long)rec[4 * t + 2] * D;
     }
-    out[0] = acc > 0x7fffffffll / 64 ? -1 : (int)acc;
+    if (tid == 255) out[0] = part[255] > 0x7fffffffll / 64 ? -1 : (int)part[255];
 }
 
 __global__ __launch_bounds__(256) void k_plan_fill(PlanFillArgs a) {
@@ -185,6 +209,7 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
     if (hipMemcpyAsync(b.glob, b.h_glob, 10 * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess) return BT_EHIP;
     hipLaunchKernelGGL(k_plan_stats, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, reinterpret_cast<const unsigned long long *>(d_words),
                        (long long)E, b.stat, b.glob, b.vals_in);
+    hipLaunchKernelGGL(k_plan_count, dim3(16), dim3(256), 0, cs, b.stat, b.glob);
     if (hipMemcpyAsync(b.h_glob, b.glob, 8 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
     const int *g = b.h_glob;
     b.dirty_lo = g[2]; b.dirty_hi = g[3];
@@ -252,7 +277,7 @@ int plan_device_rounds(const bt_plan *pl, int64_t E, void *stream, int64_t *roun
     a.pair_of = b.small + nwin + m; a.f_lo = (int)pl->dev_f_lo; a.nw = (int)pl->dev_nw;
     a.rec = b.small + nwin + m + npo; a.dmax = a.rec + 4 * T; a.out = a.dmax + T; a.dcode = b.dcode;
     hipLaunchKernelGGL(k_plan_rounds, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, a);
-    hipLaunchKernelGGL(k_plan_prefix, dim3(1), dim3(64), 0, cs, a.rec, a.dmax, (int)T, a.out);
+    hipLaunchKernelGGL(k_plan_prefix, dim3(1), dim3(256), 0, cs, a.rec, a.dmax, (int)T, a.out);
     if (hipMemcpyAsync(b.h_glob + 10, a.out, 2 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
     if (b.h_glob[11] || b.h_glob[10] < 0) return BT_NEED_EDGES;
     *rounds = b.h_glob[10];

@@ -276,7 +276,7 @@ def main():
                 oracle.ba_step(*cin, fixedp=1, dtype=np.float32)
                 nc += 1
             c_rate = nc / (time.perf_counter() - t0)
-            cpu_baseline = {"value": round(1.0 / runs[best][0], 3), "unit": "BA iterations/s", "cores": best, "kind": "refseq",
+            cpu_baseline = {"value": round(1.0 / runs[best][0], 3), "unit": "BA iterations/s", "cores": best, "kind": "port", "port_of": "refseq: the reference's operator sequence (ba.py:253-337) on torch-CPU, oracle/refseq.py",
                             "host_cores": os.cpu_count(), "cpu_quota": quota,
                             "by_threads": {str(k): {"iterations_per_s": round(1.0 / v[0], 3), "median_ms": round(1e3 * v[0], 2), "calls": v[1]}
                                            for k, v in runs.items()},
