@@ -496,6 +496,15 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
         *data = pl->trk_of_patch.data();
         return (int64_t)pl->trk_of_patch.size();
     }
+    if (pl->dev_pm && pl->dev_base && (std::strcmp(name, "pm_edge") == 0 || std::strcmp(name, "pm_rec") == 0)) {
+        // a plan whose pair-major table was written on the device: read back on request (tests, tooling)
+        const bool edge = name[3] == 'e';
+        std::vector<int32_t> &v = pl->dev_readback;
+        v.assign(edge ? (size_t)pl->pm_rounds * kLanes : (size_t)pl->info.tiles * 4, 0);
+        if (hipMemcpy(v.data(), static_cast<const char *>(pl->dev_base) + (edge ? pl->off.pme : pl->off.pmr), v.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        *data = v.data();
+        return (int64_t)v.size();
+    }
     BT_ARR(kx) BT_ARR(trk_loc) BT_ARR(pair_i) BT_ARR(pair_j) BT_ARR(pp_ptr) BT_ARR(pp_idx) BT_ARR(sg_ptr)
     BT_ARR(tile_trk0) BT_ARR(tile_ntrk) BT_ARR(tile_ncam) BT_ARR(tile_cam0) BT_ARR(tile_slot0)
     BT_ARR(tile_nslot) BT_ARR(tile_erow0) BT_ARR(tile_cams) BT_ARR(slot_edge) BT_ARR(slot_pair)

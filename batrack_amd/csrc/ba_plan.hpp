@@ -129,6 +129,7 @@ struct bt_plan {
     int pm_ok = 0, sp_ok = 0, sg_n = 0, et_lgts = 0, trk_off = 0;
     // plans whose pm_edge is written on the device (plan_device.hip): the table's rounds, and what the kernels need of the host's analysis
     int dev_pm = 0;
+    mutable std::vector<int32_t> dev_readback;                // bt_plan_array(pm_edge / pm_rec) of such a plan
     std::vector<int32_t> dev_pair_of;                         // [nw * nw]: pair index of (i - f_lo, j - f_lo) or -1
     int64_t dev_f_lo = 0, dev_nw = 0;
     long long pm_rounds = 0;

@@ -1,0 +1,79 @@
+"""The device-side planner (csrc/plan_device.hip) against the host's analysis of the same edge lists: the pair-major table,
+the tile records and every host-side table of the two plans are IDENTICAL — for regular windows, windows with edges removed
+at random, shuffled edge order (the radix sort must reproduce the host's (target frame, original index) order of a track's
+repeated observations) and several keyframe strides — and lists the device path does not take come back planned by the host."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from batrack_amd import graphgen  # noqa: E402
+from batrack_amd.plan import Plan  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FORCED = any(v in os.environ for v in ("BT_ETILE", "BT_EDGE_MIN_TILES", "BT_STREAM_MIN_TILES", "BT_EDGE_OFF", "BT_TILE_TRACKS", "BT_PLAN_DEVICE"))
+TABLES = ("pm_edge", "pm_rec", "pm_lb", "pm_la", "kx", "pair_i", "pair_j", "tile_trk0", "tile_ntrk", "tile_ncam", "tile_cams", "tile_pair0",
+          "tile_npair", "tile_pairs", "tile_flags", "tile_ij", "tile_kx", "pp_ptr", "pp_idx", "sg_ptr", "col_ptr", "row_idx", "perm", "act_bits", "act_rank")
+
+
+def both_plans(ii, jj, kk, n_buf, p_tot, fixedp):
+    dev = Plan(*(torch.as_tensor(a, device=DEV) for a in (ii, jj, kk)), n_buf, p_tot, fixedp)
+    host = Plan(np.asarray(ii), np.asarray(jj), np.asarray(kk), n_buf, p_tot, fixedp)
+    return dev, host
+
+
+@pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
+@pytest.mark.parametrize("variant", ["regular", "M64_stride1", "M128_stride3", "thinned", "shuffled", "thinned_shuffled"])
+def test_device_planned_tables_equal_the_hosts(variant):
+    kw = dict(n_frames=50, M=256, seed=4)
+    if variant == "M64_stride1":
+        kw = dict(n_frames=40, M=64, seed=7, kf_stride=1, window=10)
+    if variant == "M128_stride3":
+        kw = dict(n_frames=45, M=128, seed=9, kf_stride=3, window=14)
+    g, fixedp = graphgen.make_window_graph(**kw)
+    ii, jj, kk = (np.asarray(a) for a in (g.ii, g.jj, g.kk))
+    rng = np.random.default_rng(11)
+    if "thinned" in variant:                    # irregular: a fifth of the observations gone, some tracks short
+        keep = rng.random(ii.size) > 0.2
+        ii, jj, kk = ii[keep], jj[keep], kk[keep]
+    if "shuffled" in variant:
+        p = rng.permutation(ii.size)
+        ii, jj, kk = ii[p], jj[p], kk[p]
+    dev, host = both_plans(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], fixedp)
+    assert dev.built_on_device and not host.built_on_device
+    assert dev.jacobian_kernel == host.jacobian_kernel == "k_etile"
+    for f in ("E", "m", "n", "tiles", "pairs", "nnz_blocks", "workspace_bytes"):
+        assert getattr(dev, f) == getattr(host, f), f
+    for name in TABLES:
+        a, b = dev.array(name), host.array(name)
+        assert a.shape == b.shape and (a == b).all(), name
+
+
+@pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
+def test_lists_outside_the_device_path_are_planned_by_the_host():
+    # (a) the 64-keyframe benchmark graph: 64-track tiles; (b) a short list; (c) a track with two source frames is refused by
+    # both paths alike; (d) an index out of range is reported, not planned
+    g = graphgen.make_config("C3", seed=0)
+    p = Plan(*(torch.as_tensor(a, device=DEV) for a in (g.ii, g.jj, g.kk)), g.poses.shape[0], g.patches.shape[0], 1)
+    assert not p.built_on_device and p.jacobian_kernel == "k_tile" and p.tiles == 256
+    g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
+    ii, jj, kk = (np.asarray(a).copy() for a in (g.ii, g.jj, g.kk))
+    p = Plan(*(torch.as_tensor(a[:2000], device=DEV) for a in (ii, jj, kk)), g.poses.shape[0], g.patches.shape[0], fixedp)
+    assert not p.built_on_device
+    bad = ii.copy()
+    bad[5] = bad[5] + 1 if bad[5] + 1 < g.poses.shape[0] else bad[5] - 1           # a second source frame for that edge's track
+    for idx in ((torch.as_tensor(bad, device=DEV), torch.as_tensor(jj, device=DEV), torch.as_tensor(kk, device=DEV)), (bad, jj, kk)):
+        with pytest.raises(Exception):
+            Plan(*idx, g.poses.shape[0], g.patches.shape[0], fixedp)
+    oob = kk.copy()
+    oob[7] = g.patches.shape[0]
+    with pytest.raises(Exception):
+        Plan(torch.as_tensor(ii, device=DEV), torch.as_tensor(jj, device=DEV), torch.as_tensor(oob, device=DEV), g.poses.shape[0], g.patches.shape[0], fixedp)
+    # and the next list after the refused ones is planned on the device again (the per-patch table was left clean)
+    dev, host = both_plans(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], fixedp)
+    assert dev.built_on_device and (dev.array("pm_edge") == host.array("pm_edge")).all()
