@@ -245,6 +245,11 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
     // (a plan whose pm_edge is written on the device: the table lies behind the staged bytes, nothing of it crosses PCIe)
     size_t tables_end = buf.size();
     if (pl->dev_pm) { O.pme = (buf.size() + 255) / 256 * 256; tables_end = O.pme + (size_t)pl->pm_rounds * kLanes * sizeof(int32_t); }
+    if (pl->dev_slots) {                                   // likewise the [slots][64] arrays of a 64-track layout
+        const size_t ns = (size_t)pl->info.slots * kLanes;
+        auto take = [&](size_t bytes) { const size_t o = (tables_end + 255) / 256 * 256; tables_end = o + bytes; return o; };
+        O.se = take(ns * sizeof(int32_t)); O.sp = take(ns * sizeof(int32_t)); O.sl = take(ns * sizeof(uint16_t)); O.slp = take(ns);
+    }
     const size_t pk_off = (tables_end + 255) / 256 * 256, total = keep_pk ? pk_off + (size_t)pl->e_all * sizeof(uint64_t) : tables_end;
     void *d = dev_pool().acquire(total + 256, &cap, &reuse_after);
     if (!d) return BT_ENOMEM;
@@ -257,10 +262,15 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
     dev_pool().give_event(reuse_after);
     bool ok = hipMemcpyAsync(d, buf.data(), buf.size(), hipMemcpyHostToDevice, cs) == hipSuccess &&
               (!keep_pk || hipMemcpyAsync(static_cast<char *>(d) + pk_off, d_packed, (size_t)pl->e_all * sizeof(uint64_t), hipMemcpyDeviceToDevice, cs) == hipSuccess);
-    if (ok && pl->dev_pm) {
-        bind_pointers(pl, d);                          // (the fill kernel reads the plan's tile tables in the buffer)
-        ok = plan_device_fill(pl, pl->e_all, reinterpret_cast<int32_t *>(static_cast<char *>(d) + O.pmr),
-                              reinterpret_cast<int32_t *>(static_cast<char *>(d) + O.pme), pl->pm_rounds, cs) == BT_OK;
+    if (ok && (pl->dev_pm || pl->dev_slots)) {
+        bind_pointers(pl, d);                          // (the fill kernels read the plan's tile tables in the buffer)
+        char *db = static_cast<char *>(d);
+        if (pl->dev_pm)
+            ok = plan_device_fill(pl, pl->e_all, reinterpret_cast<int32_t *>(db + O.pmr), reinterpret_cast<int32_t *>(db + O.pme), pl->pm_rounds, cs) == BT_OK;
+        else
+            ok = plan_device_slots_fill(pl, pl->e_all, reinterpret_cast<int32_t *>(db + O.se), reinterpret_cast<int32_t *>(db + O.sp),
+                                        reinterpret_cast<uint16_t *>(db + O.sl), reinterpret_cast<uint8_t *>(db + O.slp),
+                                        reinterpret_cast<uint16_t *>(db + O.tc8), reinterpret_cast<uint16_t *>(db + O.tc16), cs) == BT_OK;
     }
     if (!ok || hipStreamSynchronize(cs) != hipSuccess) { dev_pool().release(d, cap, false, nullptr); return BT_EHIP; }
     tick("H2D copy");
@@ -327,7 +337,7 @@ int bt_plan_jacobian_kernel(const bt_plan *pl) {
     if (!pl || !pl->dev_base) return -1;
     return edge_applies(pl->dev) ? 2 : stream_applies(pl->dev) ? 1 : etile_precision_bytes(pl->dev) ? 3 : 0;
 }
-int bt_plan_built_on_device(const bt_plan *pl) { return pl && pl->dev_pm ? 1 : 0; }
+int bt_plan_built_on_device(const bt_plan *pl) { return pl && (pl->dev_pm || pl->dev_slots) ? 1 : 0; }
 
 int bt_plan_edge_precision(const bt_plan *pl) {
     if (!pl || !pl->dev_base) return -1;
@@ -368,7 +378,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
                     rc = build_plan_host(nullptr, nullptr, nullptr, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, nullptr, false, &st);
                     tick("host analysis (no edges)");
                     int64_t rounds = 0;
-                    if (rc == BT_OK) rc = plan_device_rounds(pl, E, cs, &rounds);
+                    if (rc == BT_OK) rc = pl->dev_pm ? plan_device_rounds(pl, E, cs, &rounds) : plan_device_slots_stage(pl, cs);
                     tick("device: rounds");
                     if (rc == BT_OK) { pl->pm_rounds = rounds; rc = upload_plan(pl, pb.d_words); }
                 } catch (const std::bad_alloc &) {
@@ -438,7 +448,7 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
     pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
     pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
     pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
-    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
+    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->dev_slots = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
     void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);
@@ -495,6 +505,24 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
         for (size_t i = 0; i < pl->trk_win.size(); ++i) pl->trk_of_patch[(size_t)pl->trk_win_lo + i] = pl->trk_win[i];
         *data = pl->trk_of_patch.data();
         return (int64_t)pl->trk_of_patch.size();
+    }
+    if (pl->dev_slots && pl->dev_base) {
+        // a 64-track plan whose slot arrays and wave cuts were written on the device: read back on request (tests, tooling)
+        const size_t ns = (size_t)pl->info.slots * kLanes, T = (size_t)pl->info.tiles;
+        size_t off = 0, bytes = 0, esz = 4;
+        if (std::strcmp(name, "slot_edge") == 0) { off = pl->off.se; bytes = ns * 4; }
+        else if (std::strcmp(name, "slot_pair") == 0) { off = pl->off.sp; bytes = ns * 4; }
+        else if (std::strcmp(name, "slot_lab") == 0) { off = pl->off.sl; bytes = ns * 2; esz = 2; }
+        else if (std::strcmp(name, "slot_lp") == 0) { off = pl->off.slp; bytes = ns; esz = 1; }
+        else if (std::strcmp(name, "tile_cut8") == 0) { off = pl->off.tc8; bytes = T * 9 * 2; esz = 2; }
+        else if (std::strcmp(name, "tile_cut16") == 0) { off = pl->off.tc16; bytes = T * 17 * 2; esz = 2; }
+        if (bytes) {
+            std::vector<int32_t> &v = pl->dev_readback;
+            v.assign((bytes + 3) / 4, 0);
+            if (hipMemcpy(v.data(), static_cast<const char *>(pl->dev_base) + off, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            *data = v.data();
+            return (int64_t)(bytes / esz);
+        }
     }
     if (pl->dev_pm && pl->dev_base && (std::strcmp(name, "pm_edge") == 0 || std::strcmp(name, "pm_rec") == 0)) {
         // a plan whose pair-major table was written on the device: read back on request (tests, tooling)

@@ -92,7 +92,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     BT_TICK("0");
     static thread_local std::vector<uint64_t> pk_scratch;
     const uint64_t *pk = packed;
-    pl->dev_pm = 0;
+    pl->dev_pm = 0; pl->dev_slots = 0;
     if (dstats && (keep_slots || own_lo != 0 || own_hi != p_tot || E <= 0)) return BT_NEED_EDGES;
     if (!pk && !dstats) {
         pk_scratch.resize((size_t)E + 1);
@@ -286,7 +286,10 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         if (env > 0) tcap = std::min<int>(kLanes, env);
         else if (pm_env && !tcap_retry && t64 > 0 && t64 <= 96 && E_own >= 24 * (int64_t)m && t64 < std::min(edge_min_tiles(), stream_min_tiles()) / 4) tcap = 16;
     }
-    if (dstats && tcap == kLanes) return BT_NEED_EDGES;            // (the device writes the pair-major table of window plans only)
+    if (dstats && tcap == kLanes) {                                // the device then writes the [slots][64] arrays and the wave cuts
+        static const int pm_env2 = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;
+        if (pm_env2 == 2) return BT_NEED_EDGES;                    // (pair-major tables of 64-track tiles are made from the host's slot arrays)
+    }
     for (int32_t k = 0; k < m; ++k) {
         trk_set.clear();
         if (masks_ok) {
@@ -316,6 +319,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     const int32_t T = (int32_t)pl->tile_trk0.size();
     I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
     pl->max_rows16 = (int)((6 * max_cams + 15) / 16 * 16);
+    if (dstats && tcap == kLanes && T >= std::min(edge_min_tiles(), stream_min_tiles())) return BT_NEED_EDGES;   // (k_stream / k_edge tables come from the host's slot arrays)
 
     BT_TICK("6");
     // ---- per tile: its distinct camera pairs (their relative pose is computed once per tile), then the slot arrays
@@ -323,7 +327,8 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // (a plan tiled for k_etile — tcap < 64 — gets its pair-major tables straight from the tracks' edge lists here; the
     //  [slots][64] arrays of k_tile, three quarters of them padding at 16 tracks per tile, are then built only on request:
     //  host-only plans, which the tests' emulator executes)
-    const bool want_slots = tcap == kLanes || keep_slots;
+    const bool dev_slots = dstats && tcap == kLanes;            // the slot arrays are written on the device (plan_device.hip)
+    const bool want_slots = (tcap == kLanes || keep_slots) && !dev_slots;
     const bool pm_direct = tcap < kLanes;
     bool pm_fail = false;
     int64_t pm_rounds_acc = 0;
@@ -1003,8 +1008,15 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // k_tile keeps the plan (at one tile per CU, e.g. the 64-keyframe benchmark, k_tile measured 12.7 us against 15.0)
     pl->pm_ok = I.tiles > 0 ? 1 : 0; pl->pm_rounds = 0;
     if (dstats) {
-        if (pm_fail || I.tiles <= 0 || etile_full_lds_bytes(pl->max_rows16, pl->max_tile_pairs, sizeof(double)) > kEtileLdsBudget) return BT_NEED_EDGES;
-        pl->pm_ok = 2; pl->dev_pm = 1;
+        if (I.tiles <= 0) return BT_NEED_EDGES;
+        if (pm_direct) {
+            if (pm_fail || etile_full_lds_bytes(pl->max_rows16, pl->max_tile_pairs, sizeof(double)) > kEtileLdsBudget) return BT_NEED_EDGES;
+            pl->pm_ok = 2; pl->dev_pm = 1;
+        } else {
+            pl->pm_ok = 0; pl->dev_slots = 1;
+            pl->pm_edge.clear(); pl->pm_rec.clear(); pl->pm_lb.clear(); pl->pm_la.clear();
+            pl->dev_off = off;
+        }
         pl->dev_pair_of = pair_of; pl->dev_f_lo = f_lo; pl->dev_nw = nw;
     } else
     if (pm_direct) {

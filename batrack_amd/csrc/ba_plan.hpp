@@ -129,6 +129,8 @@ struct bt_plan {
     int pm_ok = 0, sp_ok = 0, sg_n = 0, et_lgts = 0, trk_off = 0;
     // plans whose pm_edge is written on the device (plan_device.hip): the table's rounds, and what the kernels need of the host's analysis
     int dev_pm = 0;
+    int dev_slots = 0;                                        // likewise the [slots][64] arrays and the wave cuts of a 64-track layout
+    std::vector<int32_t> dev_off;                             // [m + 1]: first position of every track's edges in the grouped order
     mutable std::vector<int32_t> dev_readback;                // bt_plan_array(pm_edge / pm_rec) of such a plan
     std::vector<int32_t> dev_pair_of;                         // [nw * nw]: pair index of (i - f_lo, j - f_lo) or -1
     int64_t dev_f_lo = 0, dev_nw = 0;
@@ -207,6 +209,9 @@ int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *stream, DevPlanStats *st, int64_t *tracks);
 int plan_device_rounds(const bt_plan *pl, int64_t E, void *stream, int64_t *rounds);
 int plan_device_fill(const bt_plan *pl, int64_t E, int32_t *d_rec, int32_t *d_pm_edge, int64_t rounds, void *stream);
+int plan_device_slots_stage(const bt_plan *pl, void *stream);
+int plan_device_slots_fill(const bt_plan *pl, int64_t E, int32_t *d_slot_edge, int32_t *d_slot_pair, uint16_t *d_slot_lab, uint8_t *d_slot_lp,
+                           uint16_t *d_cut8, uint16_t *d_cut16, void *stream);
 // Copies the arrays to the device and fills plan->dev (ba_api.cpp).
 int upload_plan(bt_plan *plan);
 }  // namespace bt

@@ -1,4 +1,4 @@
-// plan_device.hip — the planner's passes over the EDGES on the device (window plans: the pair-major layout of k_etile).
+// plan_device.hip — the planner's passes over the EDGES on the device (the layouts of k_etile and k_tile: graphs below 2048 tiles).
 //
 // A plan from scratch cost ~1.4 ms of host analysis for the 138k-edge window (ba_plan.cpp), nearly all of it in three passes
 // that touch every edge: the per-track figures (count, source frame, set of target frames), the grouping of the edges by
@@ -14,8 +14,9 @@
 //   k_plan_prefix   first round of every tile, the records' final words, the table's size
 //   k_plan_fill     writes pm_edge into the uploaded plan
 // The host keeps what is small: tracks, pairs, tiles, the reduced system's symbolic factorisation (ba_plan.cpp reads the
-// per-patch table instead of the edges).  Anything that does not fit — a track whose target frames are not within 32 of its
-// source frame, two source frames for one track, 64-track tiles, sharded plans — falls back to the analysis on the edges.
+// per-patch table instead of the edges).  64-track layouts: k_plan_slots / k_plan_cuts instead of the last three.  Anything that
+// does not fit — a track whose target frames are not within 32 of its source frame, two source frames for one track, graphs of
+// the wave-per-tile kernels, sharded plans — falls back to the analysis on the edges.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -163,6 +164,71 @@ __global__ __launch_bounds__(256) void k_plan_fill(PlanFillArgs a) {
     a.pm_edge[((size_t)round0 + (size_t)(l / G) * D + a.dcode[q]) * 64 + (size_t)((l % G) << lg) + (size_t)lo] = e;
 }
 
+// ---- 64-track layouts (k_tile): the [slots][64] arrays and the waves' slot cuts (ba_plan.cpp describes them)
+struct PlanSlotArgs {
+    const unsigned *keys; const int *vals; const unsigned long long *words; int jbits; long long E;
+    const int *trk_win, *trk_loc, *pair_of, *off; int f_lo, nw, fixedp;
+    const int *tile_slot0, *tile_cam0, *tile_ncam, *tile_cams, *tile_pair0, *tile_npair, *tile_pairs, *tile_nslot;
+    int *slot_edge, *slot_pair; unsigned short *slot_lab; unsigned char *slot_lp;
+    unsigned char *crossed;                 // [slots + 1], by global slot: some track's run of one target camera spans slots s - 1 and s
+    unsigned short *cut8, *cut16; int T;
+};
+
+__device__ __forceinline__ int local_cam(const int *cams, int nc, int c) {      // position of free camera c in the tile's ascending list, 0xff: fixed
+    if (c < 0) return 0xff;
+    int lo = 0, hi = nc - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cams[mid] < c) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_plan_slots(PlanSlotArgs a) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.E) return;
+    const unsigned key = a.keys[q];
+    const int e = a.vals[q];
+    const unsigned long long w = a.words[e];
+    const int i = (int)((w >> 16) & 0xffff), j = (int)(w & 0xffff);
+    const int trk = a.trk_win[key >> a.jbits], loc = a.trk_loc[trk], t = loc >> 6, l = loc & 63;
+    const int s = (int)(q - a.off[trk]);
+    const int *cams = a.tile_cams + a.tile_cam0[t];
+    const int nc = a.tile_ncam[t];
+    const int la = local_cam(cams, nc, i - a.fixedp), lb = local_cam(cams, nc, j - a.fixedp);
+    const int gp = a.pair_of[(i - a.f_lo) * a.nw + (j - a.f_lo)];
+    const int *tp = a.tile_pairs + a.tile_pair0[t];
+    int lo = 0, hi = a.tile_npair[t] - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tp[mid] < gp) lo = mid + 1; else hi = mid; }
+    const size_t idx = ((size_t)a.tile_slot0[t] + (size_t)s) * 64 + (size_t)l;
+    a.slot_edge[idx] = e; a.slot_pair[idx] = gp; a.slot_lab[idx] = (unsigned short)(la | (lb << 8)); a.slot_lp[idx] = (unsigned char)lo;
+    // the previous edge of the track has the same target frame (its key is the same): a run that continues into this slot
+    if (s > 0 && lb != 0xff && a.keys[q - 1] == key) a.crossed[a.tile_slot0[t] + s] = 1;
+}
+
+// one thread per (tile, 8 or 16 waves): the nearest slot boundary to the even split that no run crosses (ba_plan.cpp)
+__global__ __launch_bounds__(256) void k_plan_cuts(PlanSlotArgs a) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x, t = id >> 1, W = (id & 1) ? 16 : 8;
+    if (t >= a.T) return;
+    const int ns = a.tile_nslot[t];
+    const unsigned char *crossed = a.crossed + a.tile_slot0[t];
+    unsigned short *cut = W == 8 ? a.cut8 + (size_t)t * 9 : a.cut16 + (size_t)t * 17;
+    const int chunk = (ns + W - 1) / W;
+    int prev = 0;
+    cut[0] = 0;
+    for (int w = 1; w < W; ++w) {
+        const int ideal = min(ns, w * chunk);
+        int best = ideal;
+        if (ideal < ns && crossed[ideal]) {
+            for (int d = 1; d <= chunk; ++d) {
+                if (ideal - d >= prev && !crossed[ideal - d]) { best = ideal - d; break; }
+                if (ideal + d <= ns && (ideal + d == ns || !crossed[ideal + d])) { best = ideal + d; break; }
+            }
+        }
+        best = max(best, prev);
+        cut[w] = (unsigned short)best;
+        prev = best;
+    }
+    cut[W] = (unsigned short)ns;
+}
+
 // ------------------------------------------------------------------ host side of the passes
 namespace {
 struct DevPlanBuffers {
@@ -172,6 +238,7 @@ struct DevPlanBuffers {
     const unsigned long long *words = nullptr; int jbits = 0;
     void *temp = nullptr; size_t temp_cap = 0;
     PatchStat *h_tab = nullptr; size_t tab_cap = 0;              // pinned: the window's slice of the table
+    unsigned char *crossed = nullptr; size_t crossed_cap = 0;
     int *small = nullptr, *h_small = nullptr; size_t small_cap = 0;   // trk_win | trk_loc | pair_of | rec | dmax (device, pinned staging)
     bool grow_edges(size_t E) {
         if (E <= e_cap) return true;
@@ -215,10 +282,11 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
     b.dirty_lo = g[2]; b.dirty_hi = g[3];
     *tracks = g[7];
     if (g[5] || g[6] || g[3] < g[2]) return BT_NEED_EDGES;
-    // (window plans only: the same test as the planner's choice of 16-track tiles, before anything else is copied)
+    // (not the graphs of the wave-per-tile kernels — their tables are made from the host's slot arrays — and not a patch range
+    //  mostly empty: the table's slice would be a larger copy than the edges)
     const int64_t t64 = ((int64_t)g[7] + kLanes - 1) / kLanes;
-    if (!(t64 > 0 && t64 <= 96 && E >= 24 * (int64_t)g[7])) return BT_NEED_EDGES;
     const size_t nt = (size_t)(g[3] - g[2] + 1);
+    if (t64 <= 0 || t64 >= std::min(edge_min_tiles(), stream_min_tiles()) || nt > 4 * (size_t)g[7] + 65536) return BT_NEED_EDGES;
     if (nt > b.tab_cap) {
         (void)hipHostFree(b.h_tab);
         if (hipHostMalloc(reinterpret_cast<void **>(&b.h_tab), (nt + nt / 4 + 1024) * sizeof(PatchStat), hipHostMallocDefault) != hipSuccess) { b.tab_cap = 0; return BT_ENOMEM; }
@@ -298,6 +366,57 @@ int plan_device_fill(const bt_plan *pl, int64_t E, int32_t *d_rec, int32_t *d_pm
     if (hipMemcpyAsync(d_rec, b.small + nwin + m + npo, 4 * T * sizeof(int), hipMemcpyDeviceToDevice, cs) != hipSuccess ||
         hipMemsetAsync(d_pm_edge, 0xff, (size_t)rounds * kLanes * sizeof(int32_t), cs) != hipSuccess) return BT_EHIP;
     hipLaunchKernelGGL(k_plan_fill, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, a);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+// 64-track layouts: the small tables the slot kernels read (queued on `stream`; no synchronisation: the plan's upload follows)
+int plan_device_slots_stage(const bt_plan *pl, void *stream) {
+    hipStream_t cs = static_cast<hipStream_t>(stream);
+    DevPlanBuffers &b = bufs();
+    const size_t nwin = pl->trk_win.size(), m = pl->trk_loc.size(), npo = pl->dev_pair_of.size(), noff = pl->dev_off.size();
+    const size_t n_small = nwin + m + npo + noff;
+    if (n_small > b.small_cap) {
+        (void)hipFree(b.small); (void)hipHostFree(b.h_small);
+        const size_t want = n_small + n_small / 4 + 4096;
+        if (hipMalloc(reinterpret_cast<void **>(&b.small), want * sizeof(int)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&b.h_small), want * sizeof(int), hipHostMallocDefault) != hipSuccess) { b.small_cap = 0; return BT_ENOMEM; }
+        b.small_cap = want;
+    }
+    const size_t ncr = (size_t)pl->info.slots + 2;
+    if (ncr > b.crossed_cap) {
+        (void)hipFree(b.crossed);
+        if (hipMalloc(reinterpret_cast<void **>(&b.crossed), ncr + ncr / 4 + 4096) != hipSuccess) { b.crossed_cap = 0; return BT_ENOMEM; }
+        b.crossed_cap = ncr + ncr / 4 + 4096;
+    }
+    int *h = b.h_small;
+    std::copy(pl->trk_win.begin(), pl->trk_win.end(), h);
+    std::copy(pl->trk_loc.begin(), pl->trk_loc.end(), h + nwin);
+    std::copy(pl->dev_pair_of.begin(), pl->dev_pair_of.end(), h + nwin + m);
+    std::copy(pl->dev_off.begin(), pl->dev_off.end(), h + nwin + m + npo);
+    if (hipMemcpyAsync(b.small, h, n_small * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess ||
+        hipMemsetAsync(b.crossed, 0, ncr, cs) != hipSuccess) return BT_EHIP;
+    return BT_OK;
+}
+
+// ... and the arrays themselves, in the plan's buffer (queued behind the upload of its tables)
+int plan_device_slots_fill(const bt_plan *pl, int64_t E, int32_t *d_slot_edge, int32_t *d_slot_pair, uint16_t *d_slot_lab, uint8_t *d_slot_lp,
+                           uint16_t *d_cut8, uint16_t *d_cut16, void *stream) {
+    hipStream_t cs = static_cast<hipStream_t>(stream);
+    DevPlanBuffers &b = bufs();
+    const size_t nwin = pl->trk_win.size(), m = pl->trk_loc.size(), npo = pl->dev_pair_of.size(), n = (size_t)pl->info.slots * kLanes;
+    PlanSlotArgs a{};
+    a.keys = b.keys; a.vals = b.vals; a.words = b.words; a.jbits = b.jbits; a.E = E;
+    a.trk_win = b.small; a.trk_loc = b.small + nwin; a.pair_of = b.small + nwin + m; a.off = b.small + nwin + m + npo;
+    a.f_lo = (int)pl->dev_f_lo; a.nw = (int)pl->dev_nw; a.fixedp = (int)pl->info.fixedp;
+    const PlanDev &P = pl->dev;
+    a.tile_slot0 = P.tile_slot0; a.tile_cam0 = P.tile_cam0; a.tile_ncam = P.tile_ncam; a.tile_cams = P.tile_cams;
+    a.tile_pair0 = P.tile_pair0; a.tile_npair = P.tile_npair; a.tile_pairs = P.tile_pairs; a.tile_nslot = P.tile_nslot;
+    a.slot_edge = d_slot_edge; a.slot_pair = d_slot_pair; a.slot_lab = d_slot_lab; a.slot_lp = d_slot_lp;
+    a.crossed = b.crossed; a.cut8 = d_cut8; a.cut16 = d_cut16; a.T = (int)pl->info.tiles;
+    if (hipMemsetAsync(d_slot_edge, 0xff, n * sizeof(int32_t), cs) != hipSuccess || hipMemsetAsync(d_slot_pair, 0, n * sizeof(int32_t), cs) != hipSuccess ||
+        hipMemsetAsync(d_slot_lab, 0xff, n * sizeof(uint16_t), cs) != hipSuccess || hipMemsetAsync(d_slot_lp, 0, n, cs) != hipSuccess) return BT_EHIP;
+    hipLaunchKernelGGL(k_plan_slots, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, a);
+    hipLaunchKernelGGL(k_plan_cuts, dim3((unsigned)((2 * a.T + 255) / 256)), dim3(256), 0, cs, a);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 

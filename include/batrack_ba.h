@@ -220,8 +220,9 @@ int bt_plan_jacobian_kernel(const bt_plan *plan);
  * BT_EDGE_PREC=0).  Sums across edges, the reduced system and its factorisation are float64 either way. */
 int bt_plan_edge_precision(const bt_plan *plan);
 /* 1 if the passes over the edges of this plan ran on the device (bt_plan_create with device index tensors on a sliding-window
- * edge list: per-track figures, a radix sort and the pair-major table by kernels, the host laid out tracks, pairs, tiles and
- * the reduced system from the per-track figures), 0 if the host analysed the edges (any other list; BT_PLAN_DEVICE=0), also
+ * or 64-keyframe-sized edge list, i.e. below 2048 tiles: per-track figures, a radix sort and the edge-sized tables by kernels,
+ * the host laid out tracks, pairs, tiles and the reduced system from the per-track figures), 0 if the host analysed the edges
+ * (larger graphs, sharded plans, host arrays, BT_PLAN_DEVICE=0), also
  * for a shifted copy (its tables are its source's).  For tests and tooling. */
 int bt_plan_built_on_device(const bt_plan *plan);
 

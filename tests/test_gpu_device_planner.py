@@ -56,11 +56,11 @@ def test_device_planned_tables_equal_the_hosts(variant):
 
 @pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
 def test_lists_outside_the_device_path_are_planned_by_the_host():
-    # (a) the 64-keyframe benchmark graph: 64-track tiles; (b) a short list; (c) a track with two source frames is refused by
+    # (a) a graph of the wave-per-tile kernels (2048 tiles); (b) a short list; (c) a track with two source frames is refused by
     # both paths alike; (d) an index out of range is reported, not planned
-    g = graphgen.make_config("C3", seed=0)
+    g = graphgen.make_graph(64, 2048, 8, seed=0)
     p = Plan(*(torch.as_tensor(a, device=DEV) for a in (g.ii, g.jj, g.kk)), g.poses.shape[0], g.patches.shape[0], 1)
-    assert not p.built_on_device and p.jacobian_kernel == "k_tile" and p.tiles == 256
+    assert not p.built_on_device and p.jacobian_kernel == "k_stream" and p.tiles == 2048
     g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
     ii, jj, kk = (np.asarray(a).copy() for a in (g.ii, g.jj, g.kk))
     p = Plan(*(torch.as_tensor(a[:2000], device=DEV) for a in (ii, jj, kk)), g.poses.shape[0], g.patches.shape[0], fixedp)
@@ -77,3 +77,38 @@ def test_lists_outside_the_device_path_are_planned_by_the_host():
     # and the next list after the refused ones is planned on the device again (the per-patch table was left clean)
     dev, host = both_plans(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], fixedp)
     assert dev.built_on_device and (dev.array("pm_edge") == host.array("pm_edge")).all()
+
+
+SLOT_TABLES = ("slot_edge", "slot_pair", "slot_lab", "slot_lp", "tile_cut8", "tile_cut16", "kx", "pair_i", "pair_j", "tile_trk0", "tile_ntrk", "tile_ncam",
+               "tile_cams", "tile_slot0", "tile_nslot", "tile_pair0", "tile_npair", "tile_pairs", "tile_flags", "tile_ij", "tile_kx", "col_ptr", "row_idx",
+               "perm", "act_bits", "act_rank")
+
+
+@pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
+@pytest.mark.parametrize("variant", ["C3", "C3_shuffled", "small", "repeats", "thinned"])
+def test_device_planned_slot_arrays_equal_the_hosts(variant):
+    """64-track layouts (k_tile): the [slots][64] arrays and the waves' slot cuts written by kernels."""
+    rng = np.random.default_rng(3)
+    if variant.startswith("C3"):
+        g, fixedp = graphgen.make_config("C3", seed=0), 1
+    elif variant == "small":
+        g, fixedp = graphgen.make_graph(16, 128, 6, seed=2), 2
+    else:
+        g, fixedp = graphgen.make_graph(32, 256, 8, seed=5), 1
+    ii, jj, kk = (np.asarray(a) for a in (g.ii, g.jj, g.kk))
+    if variant == "repeats":                    # repeated observations: runs of one target camera inside a track (the cuts avoid them)
+        extra = rng.integers(0, ii.size, ii.size // 2)
+        ii, jj, kk = np.concatenate([ii, ii[extra]]), np.concatenate([jj, jj[extra]]), np.concatenate([kk, kk[extra]])
+    if variant == "thinned":
+        keep = rng.random(ii.size) > 0.3
+        ii, jj, kk = ii[keep], jj[keep], kk[keep]
+    if variant in ("C3_shuffled", "repeats"):
+        p = rng.permutation(ii.size)
+        ii, jj, kk = ii[p], jj[p], kk[p]
+    dev, host = both_plans(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], fixedp)
+    assert dev.built_on_device and not host.built_on_device and dev.jacobian_kernel == host.jacobian_kernel == "k_tile"
+    for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
+        assert getattr(dev, f) == getattr(host, f), f
+    for name in SLOT_TABLES:
+        a, b = dev.array(name), host.array(name)
+        assert a.shape == b.shape and (a == b).all(), name
