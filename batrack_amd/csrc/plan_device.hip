@@ -263,6 +263,7 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
         if (hipMalloc(reinterpret_cast<void **>(&b.glob), 16 * sizeof(int)) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&b.h_glob), 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) return BT_ENOMEM;
     }
+    if (p_tot > ((int64_t)8 << 20) || E > (int64_t)0x7fffffff / 2) return BT_NEED_EDGES;      // (a per-patch table of 24 B per slot of the buffer: 6 MB for the reference's 1024 x 256 slots)
     if ((size_t)p_tot > b.stat_cap) {
         (void)hipFree(b.stat);
         if (hipMalloc(reinterpret_cast<void **>(&b.stat), (size_t)p_tot * sizeof(PatchStat)) != hipSuccess) { b.stat_cap = 0; return BT_ENOMEM; }
