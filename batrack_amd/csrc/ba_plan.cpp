@@ -1010,7 +1010,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     if (dstats) {
         if (I.tiles <= 0) return BT_NEED_EDGES;
         if (pm_direct) {
-            if (pm_fail || etile_full_lds_bytes(pl->max_rows16, pl->max_tile_pairs, sizeof(double)) > kEtileLdsBudget) return BT_NEED_EDGES;
+            if (pm_fail || etile_full_lds_bytes(pl->max_rows16, pl->max_tile_pairs, sizeof(double)) > kEtileLdsBudget) {
+                if (tcap_retry) return BT_NEED_EDGES;
+                tcap_retry = 1;                                    // small tiles are for k_etile only: lay the plan out again for k_tile
+                const int rc = build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots, dstats);
+                tcap_retry = 0;
+                return rc;
+            }
             pl->pm_ok = 2; pl->dev_pm = 1;
         } else {
             pl->pm_ok = 0; pl->dev_slots = 1;

@@ -112,3 +112,46 @@ def test_device_planned_slot_arrays_equal_the_hosts(variant):
     for name in SLOT_TABLES:
         a, b = dev.array(name), host.array(name)
         assert a.shape == b.shape and (a == b).all(), name
+
+
+@pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
+@pytest.mark.parametrize("seed", range(12))
+def test_random_edge_lists_plan_alike_on_device_and_host(seed):
+    """Random edge lists (frames, tracks per frame, targets within +-20 frames of the source, repeats, self edges, gaps in the
+    patch range, any fixedp, shuffled): whichever layout the planner picks, the device-planned plan has the host's tables."""
+    rng = np.random.default_rng(100 + seed)
+    n_frames, M = int(rng.integers(8, 48)), int(rng.choice([8, 16, 64, 128]))
+    n_buf, p_tot = n_frames + int(rng.integers(0, 8)), (n_frames + 2) * M
+    lo = int(rng.integers(0, max(1, n_frames // 3)))                       # the frames before `lo` carry no track
+    src = np.repeat(np.arange(lo, n_frames), M)
+    pat = src * M + np.tile(np.arange(M), n_frames - lo)
+    alive = rng.random(pat.size) < rng.uniform(0.5, 1.0)                  # gaps in the patch range
+    src, pat = src[alive], pat[alive]
+    span = int(rng.integers(2, 21))
+    ii, jj, kk = [], [], []
+    for s, p in zip(src, pat):
+        tg = np.arange(max(0, s - span), min(n_frames, s + span + 1))
+        tg = tg[rng.random(tg.size) < rng.uniform(0.3, 1.0)]
+        if seed % 3 and tg.size:
+            tg = tg[tg != s] if tg.size > 1 else tg                       # (self edges only in every third list)
+        if tg.size == 0:
+            continue
+        rep = rng.integers(1, 4, tg.size) if seed % 2 else np.ones(tg.size, np.int64)
+        tg = np.repeat(tg, rep)
+        ii.append(np.full(tg.size, s)); jj.append(tg); kk.append(np.full(tg.size, p))
+    ii, jj, kk = (np.concatenate(a).astype(np.int64) for a in (ii, jj, kk))
+    while ii.size < 4200:                                                 # (the device path starts at 4096 edges)
+        ii, jj, kk = np.concatenate([ii, ii]), np.concatenate([jj, jj]), np.concatenate([kk, kk])
+    p = rng.permutation(ii.size)
+    ii, jj, kk = ii[p], jj[p], kk[p]
+    fixedp = int(rng.integers(0, max(1, int(max(ii.max(), jj.max())))))
+    dev, host = both_plans(ii, jj, kk, n_buf, p_tot, fixedp)
+    # (graphs of 2048 tiles and more — many cameras per track: a tile per track — keep the host's analysis: the tables of the
+    #  wave-per-tile kernels are derived from its slot arrays)
+    assert dev.jacobian_kernel == host.jacobian_kernel and dev.built_on_device == (host.tiles < 2048)
+    for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
+        assert getattr(dev, f) == getattr(host, f), f
+    names = TABLES if dev.jacobian_kernel == "k_etile" else SLOT_TABLES
+    for name in names:
+        a, b = dev.array(name), host.array(name)
+        assert a.shape == b.shape and (a == b).all(), (name, dev.jacobian_kernel)
