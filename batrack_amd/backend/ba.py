@@ -168,7 +168,7 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     P = _f32c(poses.data, "poses")
     if P.dim() != 3 or P.shape[0] != 1 or P.shape[-1] != 7:
         raise ValueError("poses must wrap a [1, N, 7] tensor (batch b = 1, ba.py:218)")
-    if patches.shape[0] != 1 or patches.shape[2] != 3 or patches[0, 0, 0].numel() != 1:
+    if patches.dim() < 3 or patches.shape[0] != 1 or patches.shape[2] != 3 or patches.numel() != 3 * patches.shape[1]:
         raise ValueError("patches must be [1, P_tot, 3, 1, 1] (patch size 1, batrack.py:45)")
     if loss not in _lib.LOSS:
         raise NotImplementedError(loss)              # ba.py:98-99
@@ -176,29 +176,12 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     if E == 0:
         raise ValueError("empty edge list")
     dev = P.device
-    Pc = P.contiguous()
-    pat = _f32c(patches, "patches").reshape(p_tot, 3).contiguous()
-    mono = _f32c(patches_monodisp, "patches_monodisp")
-    if mono.numel() == p_tot and not mono.is_contiguous() and p_tot > 1:
-        # the caller's prior is a strided view (patches_local[:, :, mid, 2:], batrack.py:866): used in place through mono_stride
-        # (only a genuine stride >= 1: an expanded tensor — stride 0 — or a negative stride is materialised instead)
-        d = [i for i, n in enumerate(mono.shape) if n == p_tot]
-        if len(d) == 1 and mono.stride(d[0]) >= 1:
-            mono = torch.as_strided(mono, (p_tot,), (mono.stride(d[0]),), mono.storage_offset())
-        else:
-            mono = mono.reshape(-1).contiguous()
-    else:
-        mono = mono.reshape(-1)
-    intr = _f32c(intrinsics, "intrinsics").reshape(-1, 4).contiguous()
-    if mono.numel() != p_tot or intr.shape[0] != n_buf:
+    for t, what in ((patches, "patches"), (patches_monodisp, "patches_monodisp"), (intrinsics, "intrinsics"), (targets_2d, "targets_2d"), (weights, "weights")):
+        _f32c(t, what)
+    if patches_monodisp.numel() != p_tot or intrinsics.numel() != 4 * n_buf:
         raise ValueError("patches_monodisp / intrinsics do not match the patch / pose buffers")
-    tg = _f32c(targets_2d, "targets_2d")
-    if tg.shape[-1] != 2 or tg.numel() != 2 * E:
+    if targets_2d.shape[-1] != 2 or targets_2d.numel() != 2 * E:
         raise ValueError("targets_2d must be [1, E, 2]")
-    tg = tg.reshape(E, 2) if tg.is_contiguous() else tg[0]
-    if tg.stride(1) != 1:                          # the caller's view has strides (3, 1): used in place
-        tg = tg.contiguous()
-    w = _f32c(weights, "weights").reshape(E, 2).contiguous()
     stepper = _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, dev)
     lm_trk = None
     if isinstance(lmbda, torch.Tensor):
@@ -210,6 +193,34 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
         else:
             raise ValueError(f"a lmbda tensor must hold 1 or m = {stepper.plan.m} values (ba.py:299-300), got {lmbda.numel()}")
     so = bool(structure_only) or stepper.plan.n == 0
+    if stepper._ops is not None:
+        # the whole call in ONE operator (csrc/torch_ops.cpp ba_droid: the views the ABI needs, the output tensors, the step):
+        # the tensor operations below cost 28 us of host time a call, more than a structure-only step takes on the GPU
+        poses_out, out_patches = stepper._ops.ba_droid(stepper.plan.handle.value, stepper.ws, P, patches, patches_monodisp, intrinsics,
+                                                       targets_2d, weights, [float(b) for b in bounds], float(lmbda), float(ep),
+                                                       float(alpha), _lib.LOSS[loss], so, lm_trk)
+        if PRINT:
+            print("BA_rgbd_droid: PRINT is not implemented in batrack_amd (debug only, ba.py:244-245)")
+        return (poses, out_patches) if so else (SE3(poses_out), out_patches)
+    Pc = P.contiguous()
+    pat = patches.reshape(p_tot, 3).contiguous()
+    mono = patches_monodisp
+    if mono.numel() == p_tot and not mono.is_contiguous() and p_tot > 1:
+        # the caller's prior is a strided view (patches_local[:, :, mid, 2:], batrack.py:866): used in place through mono_stride
+        # (only a genuine stride >= 1: an expanded tensor — stride 0 — or a negative stride is materialised instead)
+        d = [i for i, n in enumerate(mono.shape) if n == p_tot]
+        if len(d) == 1 and mono.stride(d[0]) >= 1:
+            mono = torch.as_strided(mono, (p_tot,), (mono.stride(d[0]),), mono.storage_offset())
+        else:
+            mono = mono.reshape(-1).contiguous()
+    else:
+        mono = mono.reshape(-1)
+    intr = intrinsics.reshape(-1, 4).contiguous()
+    tg = targets_2d
+    tg = tg.reshape(E, 2) if tg.is_contiguous() else tg[0]
+    if tg.stride(1) != 1:                          # the caller's view has strides (3, 1): used in place
+        tg = tg.contiguous()
+    w = weights.reshape(E, 2).contiguous()
     patches_out = torch.empty_like(pat)
     poses_out = Pc if so else torch.empty_like(Pc)
     stepper.step(Pc, pat, mono, intr, tg, tg.stride(0), w, poses_out, patches_out,
