@@ -46,10 +46,23 @@ def _store(key, stepper, ii, jj, kk):
     _CACHE[key] = (stepper, tuple(weakref.ref(t) for t in (ii, jj, kk)))
 
 
+_LAST = [None]       # (ii, jj, kk, versions, fixedp, n_buf, p_tot, device, stepper) of the last call: an update() makes 2*ITER calls on one list
+
+
 def _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, device):
     """One plan per (edge list, fixedp): the caller keeps self.ii/jj/kk alive and
     unmodified across the 2*ITER calls of an update() (batrack.py:869-875) and
     replaces the tensors when edges are appended/removed (batrack.py:189-204)."""
+    last = _LAST[0]
+    if (last is not None and last[0] is ii and last[1] is jj and last[2] is kk and last[3] == (ii._version, jj._version, kk._version, ii.data_ptr(), jj.data_ptr(), kk.data_ptr())
+            and last[4] == fixedp and last[5] == n_buf and last[6] == p_tot and last[7] == device):
+        return last[8]
+    stepper = _plan_lookup(ii, jj, kk, n_buf, p_tot, fixedp, device)
+    _LAST[0] = (ii, jj, kk, (ii._version, jj._version, kk._version, ii.data_ptr(), jj.data_ptr(), kk.data_ptr()), fixedp, n_buf, p_tot, device, stepper)
+    return stepper
+
+
+def _plan_lookup(ii, jj, kk, n_buf, p_tot, fixedp, device):
     key = _key(ii, jj, kk, n_buf, p_tot, fixedp, device)
     hit = _CACHE.get(key)
     if hit is not None:
@@ -151,6 +164,7 @@ def clear_plan_cache():
         fut.result()
     _PENDING.clear()
     _CACHE.clear()
+    _LAST[0] = None
 
 
 def _f32c(t, what):
@@ -196,7 +210,7 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     if stepper._ops is not None:
         # the whole call in ONE operator (csrc/torch_ops.cpp ba_droid: the views the ABI needs, the output tensors, the step):
         # the tensor operations below cost 28 us of host time a call, more than a structure-only step takes on the GPU
-        poses_out, out_patches = stepper._ops.ba_droid(stepper.plan.handle.value, stepper.ws, P, patches, patches_monodisp, intrinsics,
+        poses_out, out_patches = stepper._ops.ba_droid.default(stepper.plan.handle.value, stepper.ws, P, patches, patches_monodisp, intrinsics,
                                                        targets_2d, weights, [float(b) for b in bounds], float(lmbda), float(ep),
                                                        float(alpha), _lib.LOSS[loss], so, lm_trk)
         if PRINT:
