@@ -59,11 +59,29 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def _obj_path(src):
+    return os.path.join(os.path.dirname(LIB_PATH), "obj", os.path.splitext(src)[0] + ".o")
+
+
 def build(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 without a GPU present; then the torch.ops registration (host code, g++)."""
+    """hipcc cross-compiles for gfx950 without a GPU present (one object per source, stale ones only, in parallel);
+    then the torch.ops registration (host code, g++)."""
     if force or needs_build():
-        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-        cmd = ["hipcc"] + HIPCC_FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB_PATH]
+        from concurrent.futures import ThreadPoolExecutor
+        os.makedirs(os.path.join(os.path.dirname(LIB_PATH), "obj"), exist_ok=True)
+        th = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+        stale = [f for f in SOURCES if force or not os.path.exists(_obj_path(f))
+                 or os.path.getmtime(_obj_path(f)) < max(th, os.path.getmtime(os.path.join(CSRC, f)))]
+        flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+        def compile_one(f):
+            cmd = ["hipcc"] + flags + (["-x", "hip"] if f.endswith(".hip") else []) + ["-c", os.path.join(CSRC, f), "-o", _obj_path(f)]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(len(stale), os.cpu_count() or 4) or 1) as ex:
+            list(ex.map(compile_one, stale))
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj_path(f) for f in SOURCES] + ["-o", LIB_PATH]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -664,10 +664,11 @@ int bt_xchg_close(void *peer) { return (!peer || hipIpcCloseMemHandle(peer) == h
 int bt_xchg_free(void *buf) { return (!buf || hipFree(buf) == hipSuccess) ? BT_OK : BT_EHIP; }
 
 int bt_ba_reduce_push(const bt_plan *pl, const bt_ba_args *a, void *ws, void *const *bufs, int world, int rank, int64_t epoch, void *stream) {
-    const int rc = bt_ba_reduce(pl, a, ws, stream);
-    if (rc != BT_OK || is_so(pl, a)) return rc;
+    // (validated BEFORE anything is enqueued: an EINVAL must not leave half a step on the stream)
     if (!bufs || world < 1 || world > kMaxRanks || rank < 0 || rank >= world || epoch < 1) return BT_EINVAL;
     for (int q = 0; q < world; ++q) if (!bufs[q]) return BT_EINVAL;
+    const int rc = bt_ba_reduce(pl, a, ws, stream);
+    if (rc != BT_OK || is_so(pl, a)) return rc;
     return launch_xchg_push(pl->dev, make_args(pl, a, ws), bufs, world, rank, epoch, static_cast<hipStream_t>(stream));
 }
 

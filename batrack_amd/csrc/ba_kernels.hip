@@ -2185,9 +2185,12 @@ __global__ __launch_bounds__(256) void k_xchg_push(PlanDev pd, StepArgs a, XchgP
     }
 }
 
-// Waits for the flags of epoch `epoch` from all ranks (bounded: a peer that never arrives must not hang the GPU — status
-// word 1 is then set to BT_XCHG_TIMEOUT and the step continues on whatever the slots hold), then [S | y] = sum over the
-// ranks' slots, in rank order.
+// Waits for the flags of epoch `epoch` from all ranks, then [S | y] = sum over the ranks' slots, in rank order.  The wait is
+// bounded (a peer that never arrives must not hang the GPU).  A time-out is FATAL for the step, never a silent wrong answer:
+// status word 1 is set to BT_XCHG_TIMEOUT (sticky until bt_ba_workspace_init), and the last block to finish plants a
+// non-positive pivot in S, so that the solver that follows reports a failed factorisation and the step leaves the poses
+// where they were (dX = 0, the reference's own reaction to a failed Cholesky, ba.py:9-13) instead of solving a partial system;
+// the depths then move by their rank-local Q w' only.  The caller polls bt_ba_xchg_status and raises (parallel.py).
 __global__ __launch_bounds__(256) void k_xchg_pull(PlanDev pd, StepArgs a, double *own, int world, long long epoch, long long spin_limit) {
     const size_t slot = xchg_slot_doubles(pd);
     const long long *flags = reinterpret_cast<const long long *>(own + 2 * (size_t)world * slot) + (size_t)(epoch & 1) * world;
@@ -2195,7 +2198,7 @@ __global__ __launch_bounds__(256) void k_xchg_pull(PlanDev pd, StepArgs a, doubl
         long long it = 0;
         while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
             __builtin_amdgcn_s_sleep(8);
-            if (++it > spin_limit) { a.status[1] = BT_XCHG_TIMEOUT; break; }
+            if (++it > spin_limit) { __hip_atomic_store(a.status + 1, (int)BT_XCHG_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
     }
     __syncthreads();
@@ -2209,6 +2212,18 @@ __global__ __launch_bounds__(256) void k_xchg_pull(PlanDev pd, StepArgs a, doubl
         double v = 0.0;
         for (int q = 0; q < world; ++q) v += __builtin_nontemporal_load(base + (size_t)q * slot + i);
         *p = v;
+    }
+    // the last block (a ticket in the rank's own buffer: the push of this step left it at 0) checks the verdict of ALL blocks
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long *own_flags = reinterpret_cast<long long *>(own + 2 * (size_t)world * slot);
+        int *ticket = reinterpret_cast<int *>(own_flags + 2 * world) + 1;
+        if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_load(a.status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)BT_XCHG_TIMEOUT)
+                for (int d = 0; d < pd.D; ++d) a.S[(size_t)d * pd.D + d] = -1e300;      // every pivot fails whatever the elimination order
+        }
     }
 }
 
@@ -2230,7 +2245,7 @@ int launch_xchg_push(const PlanDev &pd, const StepArgs &a, void *const *bufs, in
 int launch_xchg_pull(const PlanDev &pd, const StepArgs &a, void *own, int world, long long epoch, hipStream_t st) {
     const int total = pd.nnzb * 36 + pd.D;
     if (total <= 0) return BT_OK;
-    static const long long limit = std::getenv("BT_XCHG_SPIN_LIMIT") ? std::atoll(std::getenv("BT_XCHG_SPIN_LIMIT")) : 2000000ll;   // a few seconds of polls (each an uncached load + s_sleep)
+    static const long long limit = std::getenv("BT_XCHG_SPIN_LIMIT") ? std::atoll(std::getenv("BT_XCHG_SPIN_LIMIT")) : 20000000ll;   // tens of seconds of polls (each an uncached load + s_sleep): first-launch code loading and host stalls must not trip it
     const int nb = std::min(64, (total + 255) / 256);
     hipLaunchKernelGGL(k_xchg_pull, dim3(nb), dim3(256), 0, st, pd, a, static_cast<double *>(own), world, epoch, limit);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;

@@ -278,6 +278,9 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // (k_etile) does not tie a lane to a track, so the same graph is spread over four times as many workgroups.  Plans whose
     // tiles turn out not to fit that kernel are rebuilt with 64 (tcap_retry).
     static thread_local int tcap_retry = 0;
+    struct RetryScope {                                            // sets the flag for a nested layout pass; unwinds with it (bad_alloc)
+        int &f; explicit RetryScope(int &x) : f(x) { f = 1; } ~RetryScope() { f = 0; }
+    };
     int tcap = kLanes;
     {
         static const int env = std::getenv("BT_TILE_TRACKS") ? std::atoi(std::getenv("BT_TILE_TRACKS")) : 0;     // measurement only
@@ -320,6 +323,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
     pl->max_rows16 = (int)((6 * max_cams + 15) / 16 * 16);
     if (dstats && tcap == kLanes && T >= std::min(edge_min_tiles(), stream_min_tiles())) return BT_NEED_EDGES;   // (k_stream / k_edge tables come from the host's slot arrays)
+    if (tcap < kLanes && T >= std::min(edge_min_tiles(), stream_min_tiles())) {
+        // the camera limit closed 16-track tiles early and the plan reached the tile count of the wave-per-tile kernels, whose
+        // tables come from the [slots][64] arrays a small-tile plan does not have: lay it out again with 64 tracks per tile
+        if (tcap_retry) return dstats ? (int)BT_NEED_EDGES : (int)BT_EUNSUPPORTED;
+        RetryScope guard(tcap_retry);
+        return build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots, dstats);
+    }
 
     BT_TICK("6");
     // ---- per tile: its distinct camera pairs (their relative pose is computed once per tile), then the slot arrays
@@ -895,7 +905,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // (local target camera | local pair << 8; the global pair id is tile_pairs[pair0 + local pair]); per (tile,
     // lane) the local source camera (one per track: ii = ix[kk], checked above); per tile one 32-byte record
     //   [0] ntrk | ncam << 8 | npair << 16 | flags << 24   [1] slot0  [2] nslot  [3] cam0  [4] pair0  [5] trk0
-    const bool want_stream_tables = I.tiles >= std::min(edge_min_tiles(), stream_min_tiles());
+    const bool want_stream_tables = want_slots && I.tiles >= std::min(edge_min_tiles(), stream_min_tiles());   // (they are made from the slot arrays)
     if (want_stream_tables) {
         pl->slot_code.assign((size_t)slots * kLanes, 0xffff);
         pl->tile_la.assign((size_t)I.tiles * kLanes, 0xff);
@@ -1012,10 +1022,8 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         if (pm_direct) {
             if (pm_fail || etile_full_lds_bytes(pl->max_rows16, pl->max_tile_pairs, sizeof(double)) > kEtileLdsBudget) {
                 if (tcap_retry) return BT_NEED_EDGES;
-                tcap_retry = 1;                                    // small tiles are for k_etile only: lay the plan out again for k_tile
-                const int rc = build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots, dstats);
-                tcap_retry = 0;
-                return rc;
+                RetryScope guard(tcap_retry);                      // small tiles are for k_etile only: lay the plan out again for k_tile
+                return build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots, dstats);
             }
             pl->pm_ok = 2; pl->dev_pm = 1;
         } else {
@@ -1086,10 +1094,8 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     }
     {
         if (!pl->pm_ok && tcap < kLanes && !tcap_retry) {          // small tiles are for k_etile only: lay the plan out again for k_tile
-            tcap_retry = 1;
-            const int rc = build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots);
-            tcap_retry = 0;
-            return rc;
+            RetryScope guard(tcap_retry);
+            return build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots);
         }
     }
     // ---- partial sums instead of atomics for the pair-major kernel: hundreds of workgroups' float64 atomics on the same few

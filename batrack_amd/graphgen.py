@@ -23,6 +23,7 @@ import numpy as np
 
 SINTEL = dict(wd=1024, ht=436, fx=500.0, fy=500.0, cx=512.0, cy=218.0)
 SHIBUYA = dict(wd=640, ht=360, fx=772.548, fy=772.548, cx=320.0, cy=180.0)
+SHIBUYA_CROP = dict(SHIBUYA, ht=352)      # as the pipeline sees it: frames cropped to multiples of 16 (stream.py:156-157, 270-271)
 DAVIS = dict(wd=848, ht=480, fx=600.0, fy=600.0, cx=424.0, cy=240.0)
 
 # name -> (N, M, K)

@@ -95,6 +95,10 @@ class ShardedBA:
         self.stepper = Stepper(self.plan, self.device)
         self._covered = None
         self._xbuf, self._peers, self._epoch = None, None, 0
+        # exchange='ipc': a pull that gave up waiting for a peer makes its step a no-op for the poses (the solver sees a failed
+        # factorisation) and leaves BT_XCHG_TIMEOUT in the workspace; the status word is read back every `status_every` steps
+        # (one stream synchronisation) and in gather_patches, and a time-out raises on this rank
+        self.status_every = 16
         if exchange == "ipc" and self.world > 1 and self.plan.n > 0:
             self._open_exchange()
 
@@ -176,6 +180,8 @@ class ShardedBA:
             self._epoch += 1
             _lib.check(L.bt_ba_reduce_push(h, ctypes.byref(a), ws, self._peers, self.world, self.rank, self._epoch, stream), "bt_ba_reduce_push")
             _lib.check(L.bt_ba_pull_solve_update(h, ctypes.byref(a), ws, self._xbuf, self.world, self._epoch, stream), "bt_ba_pull_solve_update")
+            if self.status_every and self._epoch % self.status_every == 0:
+                self.check_exchange()
             return
         _lib.check(L.bt_ba_reduce_pack(h, ctypes.byref(a), ws, stream), "bt_ba_reduce_pack")
         allreduce_system(st.packed, self.group)          # (enqueued by torch on the same stream under nccl = RCCL)
@@ -189,12 +195,19 @@ class ShardedBA:
                                             torch.cuda.current_stream(self.device).cuda_stream, ctypes.byref(s))
         return int(s.value)
 
+    def check_exchange(self):
+        """Raises if a pull of this engine ever timed out (the steps since then did not move the poses)."""
+        if self._xbuf is not None and self.exchange_status() != 0:
+            raise RuntimeError(f"rank {self.rank}: exchange='ipc' timed out waiting for a peer's partial system (BT_XCHG_TIMEOUT); "
+                               "the affected steps left the poses unchanged — a rank is hung or was delayed beyond BT_XCHG_SPIN_LIMIT polls")
+
     def gather_patches(self, patches_out):
         """Merge disparities: every patch slot is owned by exactly one rank (its track range); slots outside every
         range are identical on all ranks.  One fixed-shape all-reduce over the span of the ranges (a sum of disjoint
         pieces); no Python objects are exchanged."""
         if self.world == 1:
             return patches_out
+        self.check_exchange()
         span_lo = min(a for a, b in self.ranges if b > a)
         span_hi = max(b for a, b in self.ranges if b > a)
         lo, hi = self.owned

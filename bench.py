@@ -47,11 +47,69 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
+    ap.add_argument("--probe-ipc", action="store_true", help="internal: child process of an N > 1 run (see ipc_probe)")
+    ap.add_argument("--no-large", action="store_true", help="skip the 2.1M-edge sharded workload reported beside the headline")
     return ap.parse_args()
+
+
+def ipc_probe(world, local, timeout=240.0):
+    """exchange='ipc' writes into peers' memory through hipIpc mappings: a fault there kills the process and a torchrun job
+    with it.  So before the bench's own ranks touch that path, every rank runs it once in a CHILD process (this script with
+    --probe-ipc: gloo rendezvous on a neighbouring port, the rank's own GPU, one sharded step through both exchanges, poses
+    compared across ranks bit for bit).  A child that crashes, hangs (killed after `timeout`) or disagrees returns non-zero and
+    the bench stays on the RCCL all-reduce — the first multi-GPU run still prints its line."""
+    import subprocess
+    env = dict(os.environ, BT_BENCH_BACKEND="gloo", BT_PROBE_DEVICE=str(local),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23))
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+        del env[k]
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-ipc", "--gpus", str(world)], env=env, timeout=timeout,
+                           capture_output=True, text=True)
+    except subprocess.TimeoutExpired:
+        return False, "probe timed out"
+    return r.returncode == 0, (r.stderr or r.stdout)[-400:]
+
+
+def probe_main(args):
+    import torch
+    import torch.distributed as dist
+    from batrack_amd import graphgen
+    from batrack_amd.parallel import ShardedBA
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dev = torch.device("cuda", int(os.environ.get("BT_PROBE_DEVICE", "0")) % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo")
+    g = graphgen.make_config("C3", seed=args.seed)
+    f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
+    poses, patches, mono, intr, t3, w = f32(g.poses), f32(g.patches), f32(g.mono_disp), f32(g.intrinsics), f32(g.targets3), f32(g.weights_pose)
+    ii, jj, kk = (torch.as_tensor(a, device=dev) for a in (g.ii, g.jj, g.kk))
+    scal = (list(g.bounds), 1e-4, 10.0, 0.05, "huber")
+    ok = True
+    ea = ShardedBA(ii, jj, kk, poses.shape[0], patches.shape[0], 1, dev, exchange="rccl")      # (host-staged sum under gloo)
+    eb = ShardedBA(ii, jj, kk, poses.shape[0], patches.shape[0], 1, dev, exchange="ipc")
+    Pa, Xa, Pb, Xb = torch.empty_like(poses), torch.empty_like(patches), torch.empty_like(poses), torch.empty_like(patches)
+    ea.step(poses, patches, mono, intr, t3, 3, w, Pa, Xa, *scal, False)
+    for _ in range(3):                                                                       # both parities of the exchange buffer
+        eb.step(poses, patches, mono, intr, t3, 3, w, Pb, Xb, *scal, False)
+    torch.cuda.synchronize()
+    ok = ok and eb.exchange_status() == 0 and eb.stepper.status() == 0 and bool(torch.isfinite(Pb).all())
+    ok = ok and float((Pa - Pb).abs().max()) <= 5e-7
+    allp = [torch.empty_like(Pb, device="cpu") for _ in range(world)]
+    dist.all_gather(allp, Pb.cpu())
+    ok = ok and all(torch.equal(allp[0], q) for q in allp)           # rank-ordered sums: the same bits on every rank
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    eb.close()
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag.item()) == 1 else 1)
 
 
 def main():
     args = parse()
+    if args.probe_ipc:
+        probe_main(args)
+        return
     import torch
     import torch.distributed as dist
     from batrack_amd import graphgen
@@ -90,32 +148,48 @@ def main():
 
     t0 = time.perf_counter()
     exchange = None
+    engines = {}
+    xnote = None
     if world > 1:
-        # The exchange of the packed [S | y]: the one-shot peer-write path over hipIpc-mapped buffers (BT_BENCH_EXCHANGE=ipc,
-        # the default) is checked against the RCCL all-reduce on one step first and dropped for RCCL if it cannot be set
-        # up, times out or disagrees — nothing is assumed about a topology this code has not run on.
-        eng = ShardedBA(ii, jj, kk, n_buf, p_tot, fixedp, dev, exchange="rccl")
+        # The exchange of the packed [S | y].  "rccl": dist.all_reduce on the compute stream.  "ipc": the one-shot peer-write
+        # path over hipIpc-mapped buffers (BT_BENCH_EXCHANGE=ipc, the default) — probed in child processes first
+        # (ipc_probe), then checked here on one step: finite, no time-out, the same bits on every rank (the slots are summed
+        # in rank order) and within float32 rounding of the RCCL result (whose summation order is RCCL's own).  Dropped for
+        # RCCL if anything fails — nothing is assumed about a topology this code has not run on.
+        engines["rccl"] = ShardedBA(ii, jj, kk, n_buf, p_tot, fixedp, dev, exchange="rccl")
         exchange = "rccl"
         if os.environ.get("BT_BENCH_EXCHANGE", "ipc") == "ipc":
-            ok = 1
-            eng2 = None
-            try:
-                eng2 = ShardedBA(ii, jj, kk, n_buf, p_tot, fixedp, dev, exchange="ipc")
-                Pa, Xa, Pb, Xb = (torch.empty_like(poses), torch.empty_like(patches), torch.empty_like(poses), torch.empty_like(patches))
-                eng.step(poses, patches, mono, intr, t3, t3.stride(0), w_pose, Pa, Xa, *scal, False)
-                eng2.step(poses, patches, mono, intr, t3, t3.stride(0), w_pose, Pb, Xb, *scal, False)
-                torch.cuda.synchronize()
-                if eng2.exchange_status() != 0 or not bool(torch.isfinite(Pb).all()) or float((Pa - Pb).abs().max()) > 1e-5:
-                    ok = 0
-            except Exception as e:                                       # noqa: BLE001  (reported, not swallowed)
-                print(f"bench.py rank {rank}: exchange='ipc' unavailable ({e}); using the RCCL all-reduce", file=sys.stderr, flush=True)
-                ok = 0
-            flag = torch.tensor([ok], device=dev if backend == "nccl" else "cpu", dtype=torch.int32)
+            ok, why = (True, "") if os.environ.get("BT_BENCH_IPC_PROBE", "1") == "0" else ipc_probe(world, local)
+            flag = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu", dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                eng, exchange = eng2, "ipc"
-            elif eng2 is not None and ok:
-                pass                                                       # (another rank failed: everyone stays on RCCL)
+            if int(flag.item()) == 0:
+                xnote = "exchange='ipc' failed its child-process probe on some rank; RCCL all-reduce only" + (f" (rank {rank}: {why.strip()[-200:]})" if not ok else "")
+                if not ok:
+                    print(f"bench.py rank {rank}: {xnote}", file=sys.stderr, flush=True)
+            else:
+                eng2, ok = None, 1
+                try:
+                    eng2 = ShardedBA(ii, jj, kk, n_buf, p_tot, fixedp, dev, exchange="ipc")
+                    Pa, Xa, Pb, Xb = (torch.empty_like(poses), torch.empty_like(patches), torch.empty_like(poses), torch.empty_like(patches))
+                    engines["rccl"].step(poses, patches, mono, intr, t3, t3.stride(0), w_pose, Pa, Xa, *scal, False)
+                    eng2.step(poses, patches, mono, intr, t3, t3.stride(0), w_pose, Pb, Xb, *scal, False)
+                    torch.cuda.synchronize()
+                    if eng2.exchange_status() != 0 or not bool(torch.isfinite(Pb).all()) or float((Pa - Pb).abs().max()) > 5e-7:
+                        ok = 0
+                    same = [torch.empty_like(Pb) for _ in range(world)] if backend == "nccl" else [torch.empty_like(Pb, device="cpu") for _ in range(world)]
+                    dist.all_gather(same, Pb if backend == "nccl" else Pb.cpu())
+                    if not all(torch.equal(same[0], q) for q in same):
+                        ok = 0                                                   # the ranks' poses must agree bit for bit
+                except Exception as e:                                       # noqa: BLE001  (reported, not swallowed)
+                    print(f"bench.py rank {rank}: exchange='ipc' unavailable ({e}); using the RCCL all-reduce", file=sys.stderr, flush=True)
+                    ok = 0
+                flag = torch.tensor([ok], device=dev if backend == "nccl" else "cpu", dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    engines["ipc"], exchange = eng2, "ipc"
+                else:
+                    xnote = "exchange='ipc' disagreed with the RCCL all-reduce, timed out or could not be set up; RCCL all-reduce only"
+        eng = engines[exchange]
         plan, stepper = eng.plan, eng.stepper
         tg, wp_l, wa_l = t3, w_pose, w_all
         step = eng.step
@@ -148,23 +222,39 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        ba_iter(k)
-    steps = args.steps
-    while True:
-        fence()
-        t0 = time.perf_counter()
-        for k in range(args.warmup, args.warmup + steps):
-            ba_iter(k)
-        fence()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
-        if elapsed >= 0.05:
-            break
-        steps = int(steps * max(2.0, 0.06 / max(elapsed, 1e-6))) + 1      # too short to mean anything: time more steps (same on every rank)
+    def timed(fn, warmup, steps):
+        """`steps` calls of fn(k) between fences (barrier + synchronize on both sides), MAX over ranks; extended until the
+        region is at least 50 ms (the same decision on every rank: it is taken on the reduced time)."""
+        for k in range(warmup):
+            fn(k)
+        while True:
+            fence()
+            t0 = time.perf_counter()
+            for k in range(warmup, warmup + steps):
+                fn(k)
+            fence()
+            el = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            if el >= 0.05:
+                return steps, el
+            steps = int(steps * max(2.0, 0.06 / max(el, 1e-6))) + 1      # too short to mean anything: time more steps
+
+    steps, elapsed = timed(ba_iter, args.warmup, args.steps)
+    xrates = None
+    if world > 1:
+        # both exchanges for the record (the headline `value` is the one named in config.parallelism)
+        xrates = {exchange: round(steps / elapsed, 2)}
+        for name, e2 in engines.items():
+            if name != exchange:
+                def other(k, e2=e2):
+                    a, b = k & 1, (k + 1) & 1
+                    e2.step(P[a], X[a], mono, intr, tg, tg.stride(0), wp_l, P[b], X[b], *scal, False)
+                s2, el2 = timed(other, min(args.warmup, 5), args.steps)
+                xrates[name] = round(s2 / el2, 2)
+        eng.check_exchange()
     status = stepper.status()
 
     extra = {}
@@ -315,6 +405,40 @@ def main():
                                       "reference's operator sequence (oracle/refseq.py: block materialisation, 12 scatter-adds, dense E, GEMM Schur, "
                                       "cholesky_ex), 3 warm-up calls"}
 
+    # A sharded workload whose edge work dominates (the headline graph's step is mostly the replicated 378 x 378 solve, which
+    # no rank count shortens): 64 keyframes x 4096 tracks per frame x 8 observations = 2.1M edges, the same generator.
+    large = None
+    if not args.no_large:
+        try:
+            gl = graphgen.make_graph(64, 4096, 8, seed=args.seed)
+            Lp, Lx, Lm, Li, Lt, Lw = (f32(a_) for a_ in (gl.poses, gl.patches, gl.mono_disp, gl.intrinsics, gl.targets3, gl.weights_pose))
+            lidx = [torch.as_tensor(a_, device=dev) for a_ in (gl.ii, gl.jj, gl.kk)]
+            lscal = (list(gl.bounds), 1e-4, 10.0, 0.05, "huber")
+            if world > 1:
+                leng = ShardedBA(*lidx, Lp.shape[0], Lx.shape[0], 1, dev, exchange=exchange)
+                lstep, lplan = leng.step, leng.plan
+            else:
+                lplan = Plan(*lidx, Lp.shape[0], Lx.shape[0], 1)
+                lstep = Stepper(lplan, dev).step
+            LP, LX = [Lp.clone(), torch.empty_like(Lp)], [Lx.clone(), torch.empty_like(Lx)]
+
+            def large_iter(k):
+                a, b = k & 1, (k + 1) & 1
+                lstep(LP[a], LX[a], Lm, Li, Lt, 3, Lw, LP[b], LX[b], *lscal, False)
+            ls, lel = timed(large_iter, 5, 50)
+            large = {"workload": f"64 keyframes, {len(gl.ii)} edges, {len(np.unique(gl.kk))} tracks, 63 free poses (make_graph(64, 4096, 8), seed {args.seed})",
+                     "iterations_per_s": round(ls / lel, 2), "ms_per_step": round(1e3 * lel / ls, 4), "steps": ls,
+                     "edges_this_rank": int(lplan.E), "jacobian_kernel_this_rank": lplan.jacobian_kernel,
+                     "edge_precision_this_rank": "float64 per edge" if lplan.edge_precision == 8 else "float32 per edge"}
+            if world > 1:
+                leng.check_exchange()
+                leng.close()
+            del LP, LX, Lp, Lx, Lt, Lw
+        except Exception as e:                                   # (a record beside the headline number: never its failure)
+            large = {"error": repr(e)}
+            if world > 1:
+                raise                                            # (but under N > 1 a rank that dropped out would leave the others waiting)
+
     if rank == 0:
         out = {
             "metric": "BA iterations/s on 64-KF/128k-edge graph",
@@ -332,6 +456,14 @@ def main():
                        "plan_build_ms_cold": round(plan_ms, 2), "edge_precision": "float64 per edge" if plan.edge_precision == 8 else "float32 per edge",
                        "solver_status": status, **extra},
         }
+        if large is not None:
+            out["config"]["sharded_large" if world > 1 else "large_graph"] = large
+        if xrates is not None:
+            out["config"]["exchange"] = exchange
+            out["config"]["exchange_iterations_per_s"] = xrates
+            out["config"]["exchange_note"] = xnote
+            out["config"]["what_this_line_shows"] = ("strong scaling of ONE fixed 131k-edge graph: the 378 x 378 solve is replicated on every rank and is most of the "
+                                                     "step, so `value` is not expected to grow with N; the edge work that shards is in config.sharded_large")
         if roofline is None:
             # N > 1: the Jacobian kernel of rank 0's shard (its own plan: this rank's tracks), same definition
             acc = []
@@ -349,6 +481,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline
         print(json.dumps(out), flush=True)
     if world > 1:
+        for e in engines.values():
+            e.close()
         dist.destroy_process_group()
 
 

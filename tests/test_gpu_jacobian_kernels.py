@@ -60,3 +60,19 @@ def test_parity_suite_with_the_selection_forced(kernel):
             "T = lambda a: torch.as_tensor(a, device='cuda:0'); p = Plan(T(g.ii), T(g.jj), T(g.kk), g.poses.shape[0], g.patches.shape[0], 1); print(p.jacobian_kernel)")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == kernel, r.stdout + r.stderr[-2000:]
+
+
+def test_uploaded_plan_of_many_one_track_tiles_steps_like_the_oracle():
+    """The advisor's round-3 crash case on the device path: 3000 tracks x 26 observations with random source frames — first
+    tiled for k_etile, 2967 tiles of one track each, laid out again with 64-track tiles and stepped by a wave-per-tile kernel."""
+    from test_plan_cpu import _many_small_tiles_graph
+    from edge_problems import problem
+    ii, jj, kk, n_buf, m = _many_small_tiles_graph(m=3000)
+    d = problem(ii, jj, kk, n_buf, m, seed=3)
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"], d["ii"], d["jj"], d["kk"],
+                         d["bounds"], fixedp=1, want_system=True)
+    o = HipProblem(d).raw_step("weights_pose", 1)
+    assert o["plan"].tiles >= 2048 and o["plan"].jacobian_kernel in ("k_stream", "k_edge", "k_tile")
+    assert o["status"] == 0
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 5e-6 and rel(o["y"], ref["y"]) < 5e-6
+    assert rel(o["poses_out"], ref["poses_out"]) < 5e-6 and rel(o["patches_out"], ref["patches_out"]) < 5e-6

@@ -29,6 +29,8 @@ def _inputs(seed=3, shape="band"):
                        weights_pose=np.ones_like(g.weights_pose[keep]))
     elif shape == "shibuya":      # BASELINE.json configs[3] stand-in: Shibuya camera, sliding-window edge list
         g, _ = graphgen.make_window_graph(n_frames=24, M=64, seed=seed, cam=graphgen.SHIBUYA)
+    elif shape == "shibuya_full":  # the same at FULL size: 50 frames, M = 256 (shibuya.yaml:10), 640 x 352 (calibs/tartan_shibuya.txt:1 after the crop)
+        g, _ = graphgen.make_window_graph(n_frames=50, M=256, seed=seed, cam=graphgen.SHIBUYA_CROP)
     else:
         g = graphgen.make_graph(16, 64, 8, seed=seed)
     f = lambda a: np.asarray(a, np.float32)
@@ -42,7 +44,7 @@ def _lmbda_vector(kk):
     return np.random.default_rng(11).uniform(1e-4, 0.5, m).astype(np.float32)
 
 
-def _worker(rank, world, port, out, shape, fixedp, exchange="rccl", per_track_lmbda=False):
+def _worker(rank, world, port, out, shape, fixedp, exchange="rccl", per_track_lmbda=False, absent=-1):
     sys.path[:0] = [os.path.dirname(HERE), HERE]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -55,6 +57,22 @@ def _worker(rank, world, port, out, shape, fixedp, exchange="rccl", per_track_lm
         poses, patches, mono, intr, t3, w = (T(d[k]) for k in ("poses", "patches", "mono", "intr", "t3", "w"))
         ii, jj, kk = T(d["ii"]), T(d["jj"]), T(d["kk"])
         eng = ShardedBA(ii, jj, kk, poses.shape[0], patches.shape[0], fixedp, dev, exchange=exchange)
+        if absent >= 0:
+            # a peer that never arrives: rank `absent` builds its engine (the set-up collectives) and then does not step
+            res = None
+            if rank != absent:
+                Pn, Xn = torch.empty_like(poses), torch.empty_like(patches)
+                eng.step(poses, patches, mono, intr, t3, t3.stride(0), w, Pn, Xn, list(g.bounds), 1e-4, 10.0, 0.05, "huber", False)
+                torch.cuda.synchronize()
+                raised = False
+                try:
+                    eng.check_exchange()
+                except RuntimeError as e:
+                    raised = "BT_XCHG_TIMEOUT" in str(e)
+                res = (Pn.cpu().numpy(), Xn.cpu().numpy(), eng.stepper.status(), eng.exchange_status(), raised)
+            out[rank] = res
+            eng.close()
+            return
         tg, wl = t3, w
         scal = (list(g.bounds), 1e-4, 10.0, 0.05, "huber")
         P, X = [poses, torch.empty_like(poses)], [patches, torch.empty_like(patches)]
@@ -69,8 +87,9 @@ def _worker(rank, world, port, out, shape, fixedp, exchange="rccl", per_track_lm
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["rccl", "ipc"])
-@pytest.mark.parametrize("shape,fixedp,world", [("band", 1, 2), ("shibuya", 9, 2), ("band", 1, 4), ("few", 1, 4)])
+@pytest.mark.parametrize("shape,fixedp,world,exchange", [(s, f, w, x) for x in ("rccl", "ipc") for (s, f, w) in
+                                                         [("band", 1, 2), ("shibuya", 9, 2), ("band", 1, 4), ("few", 1, 4)]] +
+                         [("band", 1, 8, "ipc"), ("shibuya_full", 35, 8, "ipc"), ("shibuya_full", 35, 8, "rccl")])    # BASELINE.json configs[3]: eight ranks
 def test_sharded_step_equals_oracle_and_single_gpu(shape, fixedp, world, exchange):
     import oracle
     from batrack_amd.plan import Plan, Stepper
@@ -142,3 +161,28 @@ def test_per_track_lmbda_on_a_sharded_plan():
         assert out[r][3] == 0 and out[r][4] == 0
         assert rel(out[r][0], ref_pose) < 2e-6 and rel(out[r][1], ref_pat) < 2e-6, (r, rel(out[r][0], ref_pose), rel(out[r][1], ref_pat))
     assert rel(plain[1][1].cpu().numpy(), X[1].cpu().numpy()) > 1e-5          # and the tensor is not the scalar
+
+
+def test_a_peer_that_never_arrives_fails_the_step_instead_of_solving_garbage():
+    """exchange='ipc' with rank 1 absent from the step: rank 0's pull gives up after BT_XCHG_SPIN_LIMIT polls, the solver that
+    follows sees a failed factorisation — the poses stay where they were (dX = 0, the reference's reaction to a failed
+    Cholesky, ba.py:9-13), never the solution of a partial system — and ShardedBA.check_exchange raises."""
+    g, d = _inputs(shape="band")
+    port = 30100 + (os.getpid() % 1000)
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    old = os.environ.get("BT_XCHG_SPIN_LIMIT")
+    os.environ["BT_XCHG_SPIN_LIMIT"] = "20000"          # (read once per process by the spawned workers)
+    try:
+        mp.spawn(_worker, args=(2, port, out, "band", 1, "ipc", False, 1), nprocs=2, join=True)
+    finally:
+        if old is None:
+            del os.environ["BT_XCHG_SPIN_LIMIT"]
+        else:
+            os.environ["BT_XCHG_SPIN_LIMIT"] = old
+    assert out[1] is None
+    pose, pat, status, xstatus, raised = out[0]
+    assert xstatus == 1 and raised                      # BT_XCHG_TIMEOUT, reported
+    assert status == 1                                  # BT_SOLVE_CHOL_FAILED: pose update skipped
+    assert np.abs(pose - d["poses"]).max() < 1e-6       # Exp(0) * G (the quaternion is renormalised)
+    assert np.isfinite(pat).all()

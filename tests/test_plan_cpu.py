@@ -377,3 +377,29 @@ def test_window_plans_are_tiled_for_the_pair_major_kernel():
     g = graphgen.make_config("C3", seed=0)
     pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
     assert int(pl.array("tile_ntrk").max()) == 64 and pl.tiles == 256 and pl.array("pm_rec").size == 0 and pl.array("sg_ptr").size == 0
+
+
+def _many_small_tiles_graph(m=3000, K=26, n_buf=120, seed=0):
+    """Tracks with random source frames and 26 observations each: every track closes its own tile (the 16-camera limit), so
+    a plan first tiled for k_etile (16 tracks per tile) reaches the tile count of the wave-per-tile kernels."""
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n_buf - K - 4, m)
+    kk = np.repeat(np.arange(m), K).astype(np.int64)
+    ii = np.repeat(src, K).astype(np.int64)
+    jj = (ii + np.tile(np.arange(K), m)).astype(np.int64)
+    return ii, jj, kk, n_buf, m
+
+
+def test_small_tile_plan_that_reaches_the_stream_tile_count_does_not_crash():
+    """Round-3 advisor finding: an UPLOADED plan (no host slot arrays) tiled with 16 tracks per tile whose tile count reached
+    stream_min_tiles() read the empty slot arrays (SIGSEGV at ba_plan.cpp want_stream_tables).  Without a GPU the upload
+    itself fails AFTER the host analysis: an error return, not a crash; on a GPU box the plan is created."""
+    ii, jj, kk, n_buf, m = _many_small_tiles_graph()
+    host = Plan(ii, jj, kk, n_buf, m, 1, upload=False)
+    assert host.tiles >= 2048 and host.arrays()["tile_ntrk"].max() <= 64
+    try:
+        up = Plan(ii, jj, kk, n_buf, m, 1, upload=True)
+    except RuntimeError as e:                      # no device here: out of memory / HIP error from the upload
+        assert "bt_plan_create failed" in str(e)
+    else:
+        assert up.tiles == host.tiles
