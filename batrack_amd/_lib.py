@@ -230,6 +230,10 @@ def lib():
     L.bt_ga_backward.argtypes = [vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
     L.bt_ga_backward_total.restype = i32
     L.bt_ga_backward_total.argtypes = [vp, vp, ctypes.POINTER(GaWeights), vp, vp, vp, vp, vp, vp]
+    L.bt_ga_mat_to_se3.restype = i32
+    L.bt_ga_mat_to_se3.argtypes = [vp, vp, i64, vp]
+    L.bt_ga_sample_disp_mono.restype = i32
+    L.bt_ga_sample_disp_mono.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, vp]
     L.bt_patchify.restype = i32
     L.bt_patchify.argtypes = [vp, i64, i64, i64, i64, vp, i64, i32, i32, vp, vp]
     _lib = L

@@ -526,6 +526,65 @@ extern "C" int bt_ga_backward(const bt_ga_args *a, const float *mono_scaled, flo
     return bt_ga_backward_total(a, mono_scaled, &w, g_mono_scaled, grad_trajs_scales, grad_frame_scales, nullptr, nullptr, stream);
 }
 
+// ------------------------------------------------------------------ hand-off from the sparse-SLAM stage (refine_net.py:53-121)
+__global__ __launch_bounds__(256) void k_ga_mat_to_se3(const float *mats, float *poses, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const float *m = mats + (size_t)t * 16;
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[4], m11 = m[5], m12 = m[6], m20 = m[8], m21 = m[9], m22 = m[10];
+    const float tr = m00 + m11 + m22;
+    float qx, qy, qz, qw;
+    if (tr > 0.0f) {
+        const float sq = sqrtf(tr + 1.0f) * 2.0f;
+        qw = 0.25f * sq; qx = (m21 - m12) / sq; qy = (m02 - m20) / sq; qz = (m10 - m01) / sq;
+    } else if (m00 > m11 && m00 > m22) {
+        const float sq = sqrtf(1.0f + m00 - m11 - m22) * 2.0f;
+        qw = (m21 - m12) / sq; qx = 0.25f * sq; qy = (m01 + m10) / sq; qz = (m02 + m20) / sq;
+    } else if (m11 > m22) {
+        const float sq = sqrtf(1.0f + m11 - m00 - m22) * 2.0f;
+        qw = (m02 - m20) / sq; qx = (m01 + m10) / sq; qy = 0.25f * sq; qz = (m12 + m21) / sq;
+    } else {
+        const float sq = sqrtf(1.0f + m22 - m00 - m11) * 2.0f;
+        qw = (m10 - m01) / sq; qx = (m02 + m20) / sq; qy = (m12 + m21) / sq; qz = 0.25f * sq;
+    }
+    const float inv = 1.0f / sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
+    float *o = poses + (size_t)t * 7;
+    o[0] = m[3]; o[1] = m[7]; o[2] = m[11];
+    o[3] = qx * inv; o[4] = qy * inv; o[5] = qz * inv; o[6] = qw * inv;
+}
+
+__global__ __launch_bounds__(256) void k_ga_sample_disp_mono(const float *dmaps, const float *trajs_2d, float *out, int T, int N, int S, int H, int W) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)T * N * S) return;
+    const int s = (int)(idx % S), t = (int)(idx / ((long long)N * S));
+    int f = t + s - S / 2;
+    f = f < 0 ? 0 : (f > T - 1 ? T - 1 : f);
+    const float x = trajs_2d[2 * idx], y = trajs_2d[2 * idx + 1];
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = x0 + 1, y1 = y0 + 1;
+    const int x0c = min(max(x0, 0), W - 1), x1c = min(max(x1, 0), W - 1), y0c = min(max(y0, 0), H - 1), y1c = min(max(y1, 0), H - 1);
+    const float *im = dmaps + (size_t)f * H * W;
+    const float i00 = im[(size_t)y0c * W + x0c], i01 = im[(size_t)y0c * W + x1c], i10 = im[(size_t)y1c * W + x0c], i11 = im[(size_t)y1c * W + x1c];
+    const float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
+    const float w00 = (x1f - x) * (y1f - y), w01 = (x - x0f) * (y1f - y), w10 = (x1f - x) * (y - y0f), w11 = (x - x0f) * (y - y0f);
+    const float depth = w00 * i00 + w01 * i01 + w10 * i10 + w11 * i11;
+    out[idx] = 1.0f / fmaxf(depth, 1e-2f);
+}
+
+extern "C" int bt_ga_mat_to_se3(const float *mats, float *poses, int64_t T, void *stream) {
+    if (!mats || !poses || T < 0 || T > (1 << 24)) return BT_EINVAL;
+    if (T == 0) return BT_OK;
+    hipLaunchKernelGGL(k_ga_mat_to_se3, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), mats, poses, (int)T);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+extern "C" int bt_ga_sample_disp_mono(const float *dmaps, const float *trajs_2d, float *out, int64_t T, int64_t N, int64_t S, int64_t H, int64_t W, void *stream) {
+    if (!dmaps || !trajs_2d || !out || T < 1 || N < 1 || S < 1 || H < 1 || W < 1 || T > (1 << 24) || (double)T * (double)N * (double)S > 4e11) return BT_EINVAL;
+    const long long total = (long long)T * N * S;
+    hipLaunchKernelGGL(k_ga_sample_disp_mono, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dmaps, trajs_2d, out, (int)T, (int)N, (int)S, (int)H, (int)W);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
 extern "C" int bt_ga_forward(const bt_ga_args *a, float *mono_scaled_out, double *losses, int32_t which, void *stream) {
     if (!a || !mono_scaled_out || !losses) return BT_EINVAL;
     if (a->T <= 0 || a->N <= 0 || a->S <= 0 || a->gh <= 0 || a->gw <= 0 || a->H <= 1 || a->W <= 1 || a->Q <= 0) return BT_EINVAL;

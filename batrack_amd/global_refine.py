@@ -30,6 +30,29 @@ from . import _lib
 _SMOOTH = {"l1": 0, "l2": 1, "huber": 2}
 
 
+def _align_depth_maps(depth_maps):
+    """model/utils.py:268-312 (`align_depth_maps`, used when RefineNet is built with align_depth=True): every depth map is
+    scaled so that its median over the overlap with its aligned predecessor matches the median of the previous (two) aligned
+    maps.  A one-off pass over numpy arrays at construction, on the host as in the reference."""
+    import numpy as np
+    S = depth_maps.shape[0]
+    out = np.zeros_like(depth_maps)
+    out[0] = depth_maps[0]
+    for i in range(1, S):
+        prev, cur = out[i - 1, ..., 0], depth_maps[i, ..., 0]
+        mask = (prev > 0) & (cur > 0)
+        if mask.sum() < 100:                                   # min_overlap_threshold
+            out[i, ..., 0] = cur
+            continue
+        if i == 1:
+            med_prev = np.median(prev[mask])
+        else:
+            past = out[i - 2, ..., 0]
+            med_prev = np.median(np.concatenate((past[(past > 0) & (prev > 0)], prev[mask])))
+        out[i, ..., 0] = med_prev / np.median(cur[mask]) * cur
+    return out
+
+
 class RefineLosses:
     def __init__(self, trajs_2d, trajs_disp, trajs_disp_mono, trajs_vis, trajs_static, jj, intrinsics, grid_query_frames,
                  trajs_scales, frame_scales_, frame_shifts_, pose, H, W, pw_break=20.0, half_disp=False,
@@ -67,6 +90,67 @@ class RefineLosses:
         self._mono_scaled = torch.empty(self.T, self.N, self.S_local, device=dev, dtype=torch.float32)
         self._losses = torch.zeros(5, device=dev, dtype=torch.float64)
         self._g_ms = None
+
+    # ------------------------------------------------------------------ the hand-off from the sparse-SLAM stage
+    @classmethod
+    def from_results(cls, results, device="cuda:0", grid_size=4, pw_break=20.0, align_depth=False, loss_weight_dict=None,
+                     refine_intrinsics=False, alpha=0.5, scale_smoothness_weight=0.1, scale_smoothness_mode="l2", half_disp=False,
+                     K_scale=20.0):
+        """What `RefineNet.__init__` + `_init_from_ba` do with a results.pkl (refine_net.py:16-121), on the GPU.  `results`: the
+        dictionary `BATRACK.get_results` / `batrack_amd.sequence.WindowedBA.get_results` returns, or the path of its pickle.
+          cams_T_world [T,4,4] -> `pose` by bt_ga_mat_to_se3 (`pp.mat2SE3`, refine_net.py:61)
+          intrinsics [T,4] -> `intrinsics_raw`; `K` = their (lower) median / K_scale (refine_net.py:77)
+          trajs_2d_disp [T,N,S,3] -> `trajs_2d`, `trajs_disp`; trajs_static, trajs_vis, grid_query_frames as they are
+          jj = t + s - S // 2 (refine_net.py:92-97)
+          dmaps [T,H,W,1] -> `trajs_disp_mono` [T,N,S] = 1 / max(bilinear sample of frame clamp(jj) at the track, 1e-2) by
+                             bt_ga_sample_disp_mono (refine_net.py:99-110); `align_depth=True` first rescales the maps by
+                             their running medians as model/utils.py:268-312 does (on the host, where the reference does it)
+          parameters at the reference's initial values: trajs_scales = 1, frame_scales_ = 1 [T,gh,gw], frame_shifts_ = 0.
+        `trajs_valid` is kept as an attribute (the reference reads it into `self.trajs_valid` and never uses it in a loss)."""
+        import numpy as np
+        if isinstance(results, (str, bytes)) or hasattr(results, "__fspath__"):
+            import pickle
+            with open(results, "rb") as f:
+                results = pickle.load(f)
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("RefineLosses.from_results: the target device must be a GPU (no CPU fallback in batrack_amd)")
+        if results.get("dmaps") is None:
+            raise ValueError("results['dmaps'] is required: the mono-depth maps the tracks' prior disparities are sampled from")
+        L = _lib.lib()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        dm = np.asarray(results["dmaps"])
+        if dm.ndim != 4 or dm.shape[-1] < 1:
+            raise ValueError("results['dmaps'] must be [T,H,W,C]")
+        if align_depth:
+            dm = _align_depth_maps(dm)
+        t2d = torch.as_tensor(np.ascontiguousarray(results["trajs_2d_disp"]), dtype=torch.float32, device=dev)
+        if t2d.dim() != 4 or t2d.shape[-1] != 3:
+            raise ValueError("results['trajs_2d_disp'] must be [T,N,S_local,3]")
+        T, N, S, _ = t2d.shape
+        if dm.shape[0] != T:
+            raise ValueError("results['dmaps'] and results['trajs_2d_disp'] disagree about the number of frames")
+        H, W = int(dm.shape[1]), int(dm.shape[2])
+        dmaps = torch.as_tensor(np.ascontiguousarray(dm[..., 0]), dtype=torch.float32, device=dev)
+        trajs_2d = t2d[..., :2].contiguous()
+        mono = torch.empty(T, N, S, device=dev, dtype=torch.float32)
+        _lib.check(L.bt_ga_sample_disp_mono(dmaps.data_ptr(), trajs_2d.data_ptr(), mono.data_ptr(), T, N, S, H, W, st), "bt_ga_sample_disp_mono")
+        cams = torch.as_tensor(np.ascontiguousarray(results["cams_T_world"]), dtype=torch.float32, device=dev).reshape(-1, 16)
+        if cams.shape[0] != T:
+            raise ValueError("results['cams_T_world'] must be [T,4,4]")
+        pose = torch.empty(T, 7, device=dev, dtype=torch.float32)
+        _lib.check(L.bt_ga_mat_to_se3(cams.data_ptr(), pose.data_ptr(), T, st), "bt_ga_mat_to_se3")
+        gh, gw = (grid_size if isinstance(grid_size, (list, tuple)) else (grid_size, grid_size))
+        jj = torch.arange(T, device=dev)[:, None] + torch.arange(S, device=dev)[None] - S // 2
+        f = lambda k: torch.as_tensor(np.ascontiguousarray(results[k]), device=dev)
+        net = cls(trajs_2d, t2d[..., 2].contiguous(), mono, f("trajs_vis"), f("trajs_static"), jj, f("intrinsics"),
+                  f("grid_query_frames"), torch.ones(T, N, S, device=dev), torch.ones(T, int(gh), int(gw), device=dev),
+                  torch.zeros(T, device=dev), pose, H, W, pw_break=pw_break, half_disp=half_disp, loss_weight_dict=loss_weight_dict,
+                  alpha=alpha, scale_smoothness_weight=scale_smoothness_weight, scale_smoothness_mode=scale_smoothness_mode,
+                  refine_intrinsics=refine_intrinsics, K_scale=K_scale)
+        net.trajs_valid = f("trajs_valid")
+        net.results = results
+        return net
 
     @property
     def intrinsics(self):

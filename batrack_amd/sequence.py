@@ -86,9 +86,19 @@ class SyntheticObservations:
         dt = (jj - ii).astype(np.float64)
         t3 = np.stack([u + self.velocity[kk, 0] * dt + self._rng.normal(0.0, self.px_noise, E),
                        v + self.velocity[kk, 1] * dt + self._rng.normal(0.0, self.px_noise, E),
-                       self.disp_gt[kk] / np.maximum(Z, 1e-2)], 1)
+                       self.disp_prior[kk] / np.maximum(Z, 1e-2)], 1)          # (the tracker's depth: in the track's own frame, Z = 1, its prior)
         vis = (Z > 0.2) & (self._rng.random(E) >= self.drop_frac)
         return t3, vis, ~self.dynamic[kk]
+
+    def depth_map(self, f):
+        """Stand-in for the mono-depth network's map of frame f (`depth` of BATRACK.__call__, batrack.py:937; what
+        `get_results(dmaps=...)` stores): a smooth positive field [ht, wd, 1], float32.  It is not the surface the tracks lie
+        on — the hand-off to the global-alignment stage only samples it."""
+        ht, wd = int(self.ht), int(self.wd)
+        y, x = np.mgrid[0:ht, 0:wd].astype(np.float64)
+        ph = 0.37 * f
+        d = 2.5 + 1.2 * np.sin(2.0 * np.pi * x / wd + ph) * np.cos(2.0 * np.pi * y / ht - 0.5 * ph) + 0.4 * np.sin(6.0 * np.pi * (x + y) / (wd + ht) + ph)
+        return d.astype(np.float32)[..., None]
 
     def centres_gt(self):
         from .evaluation import camera_centres
@@ -120,8 +130,17 @@ class WindowedBA:
         self.poses_ = torch.zeros(self.N, 7, **f32)
         self.poses_[:, 6] = 1.0                                                    # batrack.py:84
         self.patches_ = torch.zeros(self.N, self.M, 3, 1, 1, **f32)
-        self.monodisp_ = torch.zeros(self.N, self.M, 1, **f32)
         self.intrinsics_ = torch.as_tensor(obs.intrinsics, **f32).repeat(self.N, 1)
+        # the per-track window buffers the tracker side keeps and results.pkl is cut from (batrack.py:66,78-93): a track's
+        # targets / visibility / static label / weight in the S_local = 2 S_slam - 1 frames around its own frame
+        self.S_local = 2 * c.S_slam - 1
+        self.patches_local_ = torch.zeros(self.N, self.M, self.S_local, 3, **f32)
+        self.patches_local_vis_ = torch.zeros(self.N, self.M, self.S_local, 1, **f32)
+        self.patches_local_static_ = torch.ones(self.N, self.M, self.S_local, 1, **f32)
+        self.patches_local_weights_ = torch.zeros(self.N, self.M, self.S_local, 1, **f32)
+        self.patches_valid_ = torch.zeros(self.N, self.M, **f32)
+        self.tstamps_ = torch.zeros(self.N, **i64)
+        self.tlist, self.counter = [], 0
         self.ii, self.jj, self.kk = (torch.zeros(0, **i64) for _ in range(3))
         self.targets_3d = torch.zeros(1, 0, 3, **f32)
         self.weights = torch.zeros(1, 0, 2, **f32)
@@ -189,15 +208,31 @@ class WindowedBA:
         pad = 20
         inside = (t3[:, 0] >= pad) & (t3[:, 0] < self.wd - pad) & (t3[:, 1] >= pad) & (t3[:, 1] < self.ht - pad)
         w[~inside] = 0.0
+        f32 = dict(dtype=torch.float32, device=self.device)
         if self.n >= self.cfg.MIN_TRACK_LEN:
             seen = (w > 0).any(1).reshape(-1, S).sum(1) >= self.cfg.MIN_TRACK_LEN     # per track of the window
+            self.patches_valid_[self.n - S:self.n:self.cfg.kf_stride] = torch.as_tensor(seen.reshape(-1, self.M), **f32)   # batrack.py:783
             w[~np.repeat(seen, S)] = 0.0
         wp = w.copy()
         wp[~static] = 0.0
-        f32 = dict(dtype=torch.float32, device=self.device)
-        self.targets_3d = torch.cat([self.targets_3d, torch.as_tensor(t3, **f32)[None]], 1)
-        self.weights = torch.cat([self.weights, torch.as_tensor(w, **f32)[None]], 1)
+        t3_t, w_t = torch.as_tensor(t3, **f32)[None], torch.as_tensor(w, **f32)[None]
+        self.targets_3d = torch.cat([self.targets_3d, t3_t], 1)
+        self.weights = torch.cat([self.weights, w_t], 1)
         self.weights_pose = torch.cat([self.weights_pose, torch.as_tensor(wp, **f32)[None]], 1)
+        self.update_local(t3_t, w_t, torch.as_tensor(vis, device=self.device)[None], torch.as_tensor(static, device=self.device)[None])
+
+    # ---- batrack.py:632-663
+    def update_local(self, target_3d, weights, vis_e, static_e):
+        """The new edges' targets, visibility, static label and weight into the tracks' window buffers, slot
+        (jj - ii) + (S_local + 1) // 2 - 1 of the track."""
+        ii, jj, kk = self._kk_new // self.M, self._jj_new, self._kk_new
+        local_id = (jj - ii) + (self.S_local + 1) // 2 - 1
+        ok = (local_id >= 0) & (local_id < self.S_local)
+        kv, lv = kk[ok], local_id[ok]
+        self.patches_local_.view(self.N * self.M, self.S_local, 3)[kv, lv] = target_3d[0, ok]
+        self.patches_local_vis_.view(self.N * self.M, self.S_local, 1)[kv, lv] = vis_e[0, ok][:, None].float()
+        self.patches_local_static_.view(self.N * self.M, self.S_local, 1)[kv, lv] = static_e[0, ok][:, None].float()
+        self.patches_local_weights_.view(self.N * self.M, self.S_local, 1)[kv, lv] = weights[0, ok][:, :1]
 
     # ---- batrack.py:327-338
     def map_point_filtering(self):
@@ -216,7 +251,8 @@ class WindowedBA:
         bounds = [0, 0, self.wd, self.ht]
         Gs = self.SE3(self.poses)
         patches = self.patches
-        mono = self.monodisp_.view(1, self.N * self.M, 1)
+        # the depth prior is the track's own slot of its window buffer, a strided view consumed in place (batrack.py:866)
+        mono = self.patches_local_.view(1, self.N * self.M, self.S_local, 3)[:, :, (self.S_local + 1) // 2 - 1, 2:]
         self._sync()
         tic = time.perf_counter()
         for _ in range(c.ITER):
@@ -258,8 +294,12 @@ class WindowedBA:
         pat, prior = self.obs.frame_patches(self.n)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.patches_[self.n] = torch.as_tensor(pat, **f32).view(self.M, 3, 1, 1)
-        self.monodisp_[self.n] = torch.as_tensor(prior, **f32).view(self.M, 1)
+        if self.n % c.kf_stride == 0 and not self.is_initialized:
+            self.patches_valid_[self.n] = 1                                       # batrack.py:968-969
         self.init_motion()
+        self.tlist.append(float(self.n))
+        self.tstamps_[self.n] = self.counter
+        self.counter += 1
         self.n += 1
         self.m += self.M
         if (self.n - 1) % c.kf_stride == 0:
@@ -276,15 +316,37 @@ class WindowedBA:
             if self.n % c.kf_stride != 0:                       # the next frame appends nothing: its edge list is final now
                 self._prefetch(self.n + 1)
 
-    # ---- batrack.py:1080-1135, the BA-owned part of the hand-off to the next stage
-    def get_results(self):
-        """`cams_T_world` [n,4,4] (inverse pose matrices), `intrinsics` [n,4], `tstamps` [n] with the reference's
-        keys and layout.  The tracker-owned entries of results.pkl (`trajs_2d_disp`, `trajs_valid`, `trajs_static`,
-        `trajs_vis`, `grid_query_frames`, `dmaps`, `rgbs`) have no counterpart in this replay and are not emitted."""
-        G = self.SE3(self.poses_[:self.n])
-        return {"cams_T_world": G.inv().matrix().detach().cpu().numpy(),
-                "intrinsics": self.intrinsics_[:self.n].detach().cpu().numpy(),
-                "tstamps": np.arange(self.n, dtype=float)}
+    # ---- batrack.py:1080-1135: the hand-off to the global-alignment stage (results.pkl)
+    def get_results(self, rgbs=None, dmaps=None, dmaps_gt=None, save_path=None):
+        """The reference's results dictionary, all eleven keys with its shapes and dtypes (batrack.py:1113-1125):
+        `cams_T_world` [T,4,4] float32 (inverse pose matrices), `intrinsics` [T,4] float32, `tstamps` [T] float64,
+        `trajs_2d_disp` [T,M,S_local,3] float32 (a track's (u, v, disparity) targets in the S_local frames around its own),
+        `trajs_valid` [T,M] bool (some weight > 0 in the window), `trajs_static`, `trajs_vis` [T,M,S_local] float32,
+        `grid_query_frames` (the frames with a valid patch), `dmaps` / `rgbs` / `dmaps_gt` as float64 arrays of what the caller
+        hands in (None stays None).  T = frames seen; no frame is ever dropped from the buffer by `keyframe_simple`, so the
+        reference's per-time-stamp pose lookup (`get_pose`) is the buffer itself.  Pickled to `save_path` if given."""
+        T = self.counter
+        G = self.SE3(self.poses_[:T])
+        pts_valid = self.patches_valid_[:T].detach().cpu().numpy()
+        trajs_valid = self.patches_local_weights_[:T, ..., 0]
+        results = {
+            "cams_T_world": G.inv().matrix().detach().cpu().numpy(),
+            "intrinsics": self.intrinsics_[:T].detach().cpu().numpy(),
+            "tstamps": np.array(self.tlist, dtype=float),
+            "trajs_2d_disp": self.patches_local_[:T].detach().cpu().numpy(),
+            "trajs_valid": (trajs_valid.sum(dim=2) > 0).detach().cpu().numpy(),
+            "trajs_static": self.patches_local_static_[:T, ..., 0].detach().cpu().numpy(),
+            "trajs_vis": self.patches_local_vis_[:T, ..., 0].detach().cpu().numpy(),
+            "grid_query_frames": np.arange(T)[pts_valid.sum(axis=1) > 0],
+            "dmaps": None if dmaps is None else np.array(dmaps, dtype=float),
+            "rgbs": None if rgbs is None else np.array(rgbs, dtype=float),
+            "dmaps_gt": None if dmaps_gt is None else np.array(dmaps_gt, dtype=float),
+        }
+        if save_path is not None:
+            import pickle
+            with open(save_path, "wb+") as f:
+                pickle.dump(results, f)
+        return results
 
     def run(self, n_frames=None):
         for _ in range(self.obs.n_frames if n_frames is None else n_frames):

@@ -77,6 +77,20 @@ int bt_ga_backward_total(const bt_ga_args *args, const float *mono_scaled, const
 int bt_ga_backward(const bt_ga_args *args, const float *mono_scaled, float w_spatial, float w_rigid, float *g_mono_scaled,
                    float *grad_trajs_scales, float *grad_frame_scales, void *stream);
 
+/* ---- the hand-off from the sparse-SLAM stage: RefineNet._init_from_ba, refine_net.py:53-121
+ *
+ * bt_ga_mat_to_se3: `pp.mat2SE3(cams_T_world)` (refine_net.py:61): T row-major 4x4 matrices [T,16] -> poses [T,7]
+ * (tx ty tz qx qy qz qw).  The quaternion by the trace / largest-diagonal-entry rule, normalised; its SIGN is whatever the
+ * branch gives (q and -q are the same pose; pypose is not in the image, see tests/golden/refstubs/pypose).
+ *
+ * bt_ga_sample_disp_mono: the loop refine_net.py:99-110 — for every frame t, slot s and track n the depth map of frame
+ * clamp(t + s - S / 2, 0, T - 1) is sampled bilinearly at trajs_2d[t, n, s] exactly as model/utils.py:bilinear_sample2d does
+ * (corner indices floor(x), floor(x) + 1 clamped to the image, weights from the UNclamped corners), and the result is
+ * 1 / max(depth, 1e-2).  dmaps [T,H,W] float32 (channel 0 of results['dmaps']), out [T,N,S] float32. */
+int bt_ga_mat_to_se3(const float *mats, float *poses, int64_t T, void *stream);
+int bt_ga_sample_disp_mono(const float *dmaps, const float *trajs_2d, float *disp_mono_out,
+                           int64_t T, int64_t N, int64_t S, int64_t H, int64_t W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,9 +120,33 @@ def SE3(data):
 
 
 def Parameter(x):
-    """pp.Parameter: a leaf LieTensor that requires grad (refine_net.py:45)."""
-    return torch.as_tensor(x).as_subclass(torch.Tensor).detach().clone().requires_grad_(True).as_subclass(LieTensor)
+    """pp.Parameter: a LEAF LieTensor that requires grad (refine_net.py:45), so that `net.pose.grad` is filled."""
+    return torch.Tensor._make_subclass(LieTensor, torch.as_tensor(x).as_subclass(torch.Tensor).detach().clone(), True)
 
 
 def mat2SE3(m):
-    raise NotImplementedError("stand-in: construct poses as [.., 7] tensors")
+    """pp.mat2SE3 (refine_net.py:61): [..,4,4] (or [..,3,4]) matrices -> SE3 LieTensor [..,7] = (t, q_xyzw).  Stand-in: the
+    quaternion by the trace / largest-diagonal-entry rule, normalised.  q and -q are the same pose; which of the two (and
+    which branch near the switch-over) real pypose returns is NOT pinned by this stand-in."""
+    m = torch.as_tensor(m)
+    R, t = m[..., :3, :3], m[..., :3, 3]
+    m00, m01, m02 = R[..., 0, 0], R[..., 0, 1], R[..., 0, 2]
+    m10, m11, m12 = R[..., 1, 0], R[..., 1, 1], R[..., 1, 2]
+    m20, m21, m22 = R[..., 2, 0], R[..., 2, 1], R[..., 2, 2]
+    tr = m00 + m11 + m22
+
+    def case(w, x, y, z, sq):
+        return torch.stack([x, y, z, w], -1) / sq[..., None]
+    s0 = torch.sqrt(torch.clamp(tr + 1.0, min=1e-30)) * 2.0
+    q0 = case(0.25 * s0 * s0, m21 - m12, m02 - m20, m10 - m01, s0)
+    s1 = torch.sqrt(torch.clamp(1.0 + m00 - m11 - m22, min=1e-30)) * 2.0
+    q1 = case(m21 - m12, 0.25 * s1 * s1, m01 + m10, m02 + m20, s1)
+    s2 = torch.sqrt(torch.clamp(1.0 + m11 - m00 - m22, min=1e-30)) * 2.0
+    q2 = case(m02 - m20, m01 + m10, 0.25 * s2 * s2, m12 + m21, s2)
+    s3 = torch.sqrt(torch.clamp(1.0 + m22 - m00 - m11, min=1e-30)) * 2.0
+    q3 = case(m10 - m01, m02 + m20, m12 + m21, 0.25 * s3 * s3, s3)
+    c1 = ((m00 > m11) & (m00 > m22))[..., None]
+    c2 = (m11 > m22)[..., None]
+    q = torch.where((tr > 0)[..., None], q0, torch.where(c1, q1, torch.where(c2, q2, q3)))
+    q = q / q.norm(dim=-1, keepdim=True)
+    return SE3(torch.cat([t, q], -1))

@@ -1,0 +1,114 @@
+"""-m gpu: the hand-off from the sparse-SLAM stage to the dense global alignment, end to end.
+  (a) tests/golden/ga_init.npz — a results.pkl and what the reference's UNMODIFIED RefineNet.__init__ / _init_from_ba /
+      forward() / autograd made of it — through RefineLosses.from_results (bt_ga_mat_to_se3, bt_ga_sample_disp_mono) and the
+      HIP losses: derived tensors, the total right after construction, the total and every gradient at perturbed parameters.
+  (b) the replayed sequence on the HIP BA -> WindowedBA.get_results (all eleven keys, the reference's shapes and dtypes) ->
+      pickle -> RefineLosses.from_results -> forward() / backward(), against the float64 oracle (oracle/ga_init.py +
+      oracle/ga_torch.py, themselves pinned by (a)'s fixture in tests/test_ga_init_oracle.py) on the same dictionary."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ga_init.npz"), allow_pickle=False))
+RES = {k[3:]: v for k, v in G.items() if k.startswith("in.")}
+RES.update(rgbs=None, dmaps_gt=None)
+WEIGHTS = dict(zip(("spatial_loss", "inter_frame_loss", "pts_3d_loss", "cam_smooth_vec_loss", "scale_smoothness_loss"), (float(x) for x in G["weights"])))
+
+
+def same_rotation(p, q):
+    s = np.sign(np.sum(p[:, 3:] * q[:, 3:], axis=1, keepdims=True))
+    return max(np.abs(p[:, :3] - q[:, :3]).max(), np.abs(p[:, 3:] * s - q[:, 3:]).max())
+
+
+@pytest.mark.parametrize("tag,align", [("plain", False), ("aligned", True)])
+def test_from_results_derives_what_the_reference_derives(tag, align):
+    from batrack_amd.global_refine import RefineLosses
+    net = RefineLosses.from_results(RES, "cuda:0", grid_size=4, align_depth=align, loss_weight_dict=WEIGHTS, refine_intrinsics=True)
+    T, N, S, H, W = (int(x) for x in G[f"{tag}.T_N_S_H_W"])
+    assert (net.T, net.N, net.S_local, net.H, net.W) == (T, N, S, H, W)
+    assert np.array_equal(net.jj.cpu().numpy(), G[f"{tag}.jj"])
+    assert np.array_equal(net.trajs_2d.cpu().numpy(), G[f"{tag}.trajs_2d"]) and np.array_equal(net.trajs_disp.cpu().numpy(), G[f"{tag}.trajs_disp"])
+    assert np.abs(net.K.cpu().numpy() - G[f"{tag}.K_init"]).max() < 1e-6
+    assert same_rotation(net.pose.cpu().numpy().astype(np.float64), G[f"{tag}.pose_init"].astype(np.float64)) < 2e-6
+    ref = G[f"{tag}.trajs_disp_mono"]
+    assert np.abs(net.trajs_disp_mono.cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+    assert (net.trajs_disp_mono == 100.0).any()                                   # the 1e-2 clamp of the sampled depth
+    assert np.array_equal(net.trajs_valid.cpu().numpy(), RES["trajs_valid"])
+
+
+def test_total_and_gradients_from_a_results_dictionary_match_the_reference():
+    from batrack_amd.global_refine import RefineLosses
+    net = RefineLosses.from_results(RES, "cuda:0", grid_size=4, loss_weight_dict=WEIGHTS, refine_intrinsics=True)
+    assert torch.equal(net.trajs_scales.cpu(), torch.as_tensor(G["init.trajs_scales"])) and torch.equal(net.frame_scales_.cpu(), torch.as_tensor(G["init.frame_scales_"]))
+    assert abs(float(net.forward()) / float(G["init.total"]) - 1) < 1e-5
+    net.trajs_scales.copy_(torch.as_tensor(G["pert.trajs_scales"]))
+    net.frame_scales_.copy_(torch.as_tensor(G["pert.frame_scales_"]))
+    assert abs(float(net.forward()) / float(G["pert.total"]) - 1) < 1e-5
+    g = net.backward()
+    # the quaternion's sign is the stand-in's choice on both sides (fixture and kernel restate the same rule); a flipped
+    # sign would flip nothing in the gradient's first six numbers (left-perturbation gradient), so they are compared as is
+    for key, name in (("trajs_scales", "grad_trajs_scales"), ("frame_scales_", "grad_frame_scales"), ("pose", "grad_pose"), ("K", "grad_K")):
+        ref = G[f"pert.{name}"].astype(np.float64)
+        err = np.abs(g[key].cpu().numpy().astype(np.float64) - ref).max()
+        assert err < 5e-5 * np.abs(ref).max(), (name, err, np.abs(ref).max())
+
+
+def test_replay_to_results_to_global_alignment(tmp_path):
+    from batrack_amd import graphgen
+    from batrack_amd.backend.ba import BA_rgbd_droid
+    from batrack_amd.global_refine import RefineLosses
+    from batrack_amd.sequence import SlamConfig, SyntheticObservations, WindowedBA
+    from oracle import ga_init, ga_torch
+    cam = dict(graphgen.SINTEL, wd=256, ht=112, cx=128.0, cy=56.0, fx=125.0, fy=125.0)
+    n_frames, M = 26, 48
+    obs = SyntheticObservations(n_frames=n_frames, M=M, seed=9, cam=cam)
+    cfg = SlamConfig(PATCHES_PER_FRAME=M, BUFFER_SIZE=n_frames + 1, num_init=6, init_updates=6, ITER=2, OPTIMIZATION_WINDOW=8, REMOVAL_WINDOW=10, S_slam=6)
+    trk = WindowedBA(obs, BA_rgbd_droid, cfg, device="cuda:0")
+    trk.run()
+    path = str(tmp_path / "results.pkl")
+    res = trk.get_results(dmaps=[obs.depth_map(f) for f in range(n_frames)], save_path=path)
+    # the reference's keys, shapes and dtypes (batrack.py:1086-1125)
+    S_local = 2 * cfg.S_slam - 1
+    assert list(res) == ["cams_T_world", "intrinsics", "tstamps", "trajs_2d_disp", "trajs_valid", "trajs_static", "trajs_vis",
+                         "grid_query_frames", "dmaps", "rgbs", "dmaps_gt"]
+    want = dict(cams_T_world=((n_frames, 4, 4), np.float32), intrinsics=((n_frames, 4), np.float32), tstamps=((n_frames,), np.float64),
+                trajs_2d_disp=((n_frames, M, S_local, 3), np.float32), trajs_valid=((n_frames, M), np.bool_),
+                trajs_static=((n_frames, M, S_local), np.float32), trajs_vis=((n_frames, M, S_local), np.float32),
+                dmaps=((n_frames, 112, 256, 1), np.float64))
+    for k, (shape, dt) in want.items():
+        assert res[k].shape == shape and res[k].dtype == dt, (k, res[k].shape, res[k].dtype)
+    assert res["rgbs"] is None and res["dmaps_gt"] is None and res["grid_query_frames"].dtype.kind == "i"
+    q = res["grid_query_frames"]
+    assert 0 < len(q) < n_frames                                                 # only the window's keyframes carry tracks (batrack.py:399-410)
+    mid = (S_local + 1) // 2 - 1
+    kf = res["trajs_valid"].any(axis=1)
+    assert kf.any() and set(np.nonzero(kf)[0]) <= set(q)                         # a frame with a weighted track is a query frame
+    # a keyframe's own slot holds its patches' pixel position (+ noise) and prior disparity; tracks of keyframes are seen
+    own = res["trajs_2d_disp"][q[0], :, mid]
+    assert np.abs(own[:, :2] - obs.xy[q[0] * M:(q[0] + 1) * M]).max() < 5.0 and np.allclose(own[:, 2], obs.disp_prior[q[0] * M:(q[0] + 1) * M], rtol=1e-6)
+    assert res["trajs_vis"][q].max() == 1.0 and set(np.unique(res["trajs_static"])) <= {0.0, 1.0}
+
+    net = RefineLosses.from_results(path, "cuda:0", grid_size=4, loss_weight_dict=WEIGHTS, refine_intrinsics=True)     # from the pickle, as run_global_refine.py does
+    o = ga_init.init_from_ba(res)
+    assert np.abs(net.trajs_disp_mono.cpu().numpy() - o["trajs_disp_mono"]).max() < 1e-5 * np.abs(o["trajs_disp_mono"]).max()
+    assert same_rotation(net.pose.cpu().numpy().astype(np.float64), o["pose_init"]) < 2e-6
+    rng = np.random.default_rng(3)
+    ts, fs = 1.0 + 0.3 * rng.standard_normal((net.T, net.N, net.S_local)), 1.0 + 2.0 * rng.standard_normal((net.T, 4, 4))
+    net.trajs_scales.copy_(torch.as_tensor(ts, dtype=torch.float32))
+    net.frame_scales_.copy_(torch.as_tensor(fs, dtype=torch.float32))
+    f64 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    d = dict(trajs_2d=f64(o["trajs_2d"]), trajs_disp=f64(o["trajs_disp"]), trajs_disp_mono=f64(o["trajs_disp_mono"]), trajs_vis=f64(o["trajs_vis"]),
+             trajs_static=f64(o["trajs_static"]), jj=o["jj"], intrinsics=f64(o["intrinsics_raw"]), pose=net.pose.cpu().numpy().astype(np.float64),
+             grid_query_frames=o["grid_query_frames"], frame_shifts=np.zeros(o["T"]), H=np.int64(o["H"]), W=np.int64(o["W"]), pw_break=np.float64(20.0),
+             trajs_scales=f64(ts), frame_scales_=f64(fs))
+    r = ga_torch.full_total_and_grads(d, [WEIGHTS[k] for k in ("spatial_loss", "inter_frame_loss", "pts_3d_loss", "cam_smooth_vec_loss", "scale_smoothness_loss")], "l1", refine_intrinsics=True)
+    assert abs(float(net.forward()) / r["total"] - 1) < 1e-5, (float(net.forward()), r["total"])
+    g = net.backward()
+    for key, name in (("trajs_scales", "grad_trajs_scales"), ("frame_scales_", "grad_frame_scales"), ("pose", "grad_pose"), ("K", "grad_K")):
+        ref = np.asarray(r[name], np.float64)
+        err = np.abs(g[key].cpu().numpy().astype(np.float64) - ref).max()
+        assert err < 1e-4 * np.abs(ref).max(), (name, err, np.abs(ref).max())
