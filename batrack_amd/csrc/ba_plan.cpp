@@ -15,6 +15,7 @@
 #include "ba_plan.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -24,13 +25,32 @@ namespace bt {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Tile counts from which a plan is laid out for the wave-per-tile kernels k_stream / k_edge.  Those kernels do the per-edge
+// maths in FLOAT32 (update 1e-5 .. 5e-5 off the reference's float64 run on the benchmark graphs: outside north_star's 1e-5),
+// so since round 4 they are an explicit choice of the caller — bt_config_float32_kernels(1), or BT_FLOAT32_KERNELS=1 in the
+// environment — and every plan otherwise takes the float64-per-edge tile kernels whatever its size.  BT_EDGE_MIN_TILES /
+// BT_STREAM_MIN_TILES set the thresholds outright (tests, measurement).  A plan records what it was laid out for (st_ok,
+// em_ok): the launch-time choice never depends on a later change of this setting.
+static std::atomic<int> g_float32_kernels{-1};       // -1: not set by the caller -> the environment decides
+int config_float32_kernels(int enable) {
+    const int prev = g_float32_kernels.load();
+    if (enable >= 0) g_float32_kernels.store(enable ? 1 : 0);
+    return prev < 0 ? (std::getenv("BT_FLOAT32_KERNELS") && std::atoi(std::getenv("BT_FLOAT32_KERNELS")) ? 1 : 0) : prev;
+}
+static int float32_kernels_on() {
+    const int v = g_float32_kernels.load();
+    if (v >= 0) return v;
+    static const int env = std::getenv("BT_FLOAT32_KERNELS") ? std::atoi(std::getenv("BT_FLOAT32_KERNELS")) : 0;
+    return env ? 1 : 0;
+}
+constexpr int kNever = 1 << 30;
 int edge_min_tiles() {
-    static const int t = std::getenv("BT_EDGE_MIN_TILES") ? std::atoi(std::getenv("BT_EDGE_MIN_TILES")) : 2048;
-    return t;
+    static const int t = std::getenv("BT_EDGE_MIN_TILES") ? std::atoi(std::getenv("BT_EDGE_MIN_TILES")) : -1;
+    return t >= 0 ? t : (float32_kernels_on() ? 2048 : kNever);
 }
 int stream_min_tiles() {
-    static const int t = std::getenv("BT_STREAM_MIN_TILES") ? std::atoi(std::getenv("BT_STREAM_MIN_TILES")) : 2048;
-    return t;
+    static const int t = std::getenv("BT_STREAM_MIN_TILES") ? std::atoi(std::getenv("BT_STREAM_MIN_TILES")) : -1;
+    return t >= 0 ? t : (float32_kernels_on() ? 2048 : kNever);
 }
 
 static void layout_workspace(bt_plan *pl) {
@@ -323,9 +343,10 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
     pl->max_rows16 = (int)((6 * max_cams + 15) / 16 * 16);
     if (dstats && tcap == kLanes && T >= std::min(edge_min_tiles(), stream_min_tiles())) return BT_NEED_EDGES;   // (k_stream / k_edge tables come from the host's slot arrays)
-    if (tcap < kLanes && T >= std::min(edge_min_tiles(), stream_min_tiles())) {
-        // the camera limit closed 16-track tiles early and the plan reached the tile count of the wave-per-tile kernels, whose
-        // tables come from the [slots][64] arrays a small-tile plan does not have: lay it out again with 64 tracks per tile
+    if (tcap < kLanes && T >= std::min(std::min(edge_min_tiles(), stream_min_tiles()), 1024)) {
+        // the camera limit closed 16-track tiles early: the plan reached the tile count of the wave-per-tile kernels, whose
+        // tables come from the [slots][64] arrays a small-tile plan does not have — or simply four times the CUs, where
+        // spreading a graph over more workgroups has lost its point: lay it out again with 64 tracks per tile
         if (tcap_retry) return dstats ? (int)BT_NEED_EDGES : (int)BT_EUNSUPPORTED;
         RetryScope guard(tcap_retry);
         return build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots, dstats);
@@ -910,6 +931,8 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // lane) the local source camera (one per track: ii = ix[kk], checked above); per tile one 32-byte record
     //   [0] ntrk | ncam << 8 | npair << 16 | flags << 24   [1] slot0  [2] nslot  [3] cam0  [4] pair0  [5] trk0
     const bool want_stream_tables = want_slots && I.tiles >= std::min(edge_min_tiles(), stream_min_tiles());   // (they are made from the slot arrays)
+    pl->st_ok = want_stream_tables ? 1 : 0;
+    pl->st_min = stream_min_tiles(); pl->em_min = edge_min_tiles();
     if (want_stream_tables) {
         pl->slot_code.assign((size_t)slots * kLanes, 0xffff);
         pl->tile_la.assign((size_t)I.tiles * kLanes, 0xff);

@@ -77,6 +77,8 @@ struct PlanDev {
     int trk_off;                                             // sharded plan: distinct tracks of the full edge list in front of this rank's first
     int em_self;                                             // some edge has ii == jj (its source-camera E lands on a target row)
     int em_ok, em_its, em_lgs;                               // every tile slot-uniform; total iterations; log2 S if the same for all tiles, else -1
+    int st_ok;                                               // the compact tables of k_stream exist (the plan was laid out for the wave-per-tile kernels)
+    int st_min, em_min;                                      // stream_min_tiles() / edge_min_tiles() when the plan was built: the launch-time choice is the plan's own
     const int32_t *col_ptr, *row_idx, *upd_ptr, *upd, *blk_col, *upd_next;
     // elimination order and level schedule of the reduced solver
     int nlev, ndp;
@@ -122,7 +124,7 @@ struct bt_plan {
     std::vector<uint16_t> slot_code;
     std::vector<int32_t> tile_rec, it_edge;
     std::vector<uint32_t> tile_sinfo;
-    int em_ok = 0, em_lgs = -1, em_self = 0;
+    int em_ok = 0, em_lgs = -1, em_self = 0, st_ok = 0, st_min = 1 << 30, em_min = 1 << 30;
     std::vector<int32_t> pm_edge, pm_rec;
     std::vector<uint8_t> pm_lb, pm_la;
     std::vector<int32_t> pp_ptr, pp_idx, sg_ptr;
@@ -165,7 +167,7 @@ struct bt_plan {
             v->clear();
         tile_cut8.clear(); tile_cut16.clear();
         pm_edge.clear(); pm_rec.clear(); pm_lb.clear(); pm_la.clear(); pp_ptr.clear(); pp_idx.clear(); sg_ptr.clear(); pm_ok = 0; sp_ok = 0; pm_rounds = 0;
-        slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); it_edge.clear(); tile_sinfo.clear(); em_ok = 0; em_its = 0; em_lgs = -1; act_bits.clear(); act_rank.clear(); stage.clear();
+        slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); it_edge.clear(); tile_sinfo.clear(); em_ok = 0; st_ok = 0; em_its = 0; em_lgs = -1; act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;
         fz_ok = fzp_ok = 0;
         max_rows16 = 16;
@@ -181,6 +183,8 @@ namespace bt {
 // measurement and tests).  The planner lays out their tables only for plans that will use them.
 int edge_min_tiles();
 int stream_min_tiles();
+// the caller's choice of the float32 wave-per-tile kernels for large graphs (bt_config_float32_kernels); returns the previous setting
+int config_float32_kernels(int enable);
 // Pure host analysis (no HIP).  Returns BT_OK or an error code.
 // `packed` (optional): the edges as 8-byte words kk << 32 | ii << 16 | jj, already range-checked (ii / jj / kk are then not read)
 // `dstats` (optional; plan_device.hip): the per-track figures of the edge list as a kernel gathered them — the analysis then

@@ -547,7 +547,7 @@ static size_t stream_lds_bytes(const PlanDev &pd, int mode) {
 // The streaming kernels take graphs of many tiles whose tiles see at most 10 cameras (row tiles of the register
 // accumulators) and 32 camera pairs (one lane per pair in the prologue, LDS of the per-pair sums).
 bool stream_applies(const PlanDev &pd) {
-    return pd.T >= stream_min_tiles() && pd.max_cams <= 10 && pd.max_tile_pairs <= 32 && pd.max_tile_pairs > 0;
+    return pd.st_ok != 0 && pd.T >= pd.st_min && pd.max_cams <= 10 && pd.max_tile_pairs <= 32 && pd.max_tile_pairs > 0;
 }
 
 template <int MODE, int NT, bool PROF = false>

@@ -575,7 +575,7 @@ static size_t edge_lds_bytes(const PlanDev &pd, int mode) {
 bool edge_applies(const PlanDev &pd) {
     static const int off = std::getenv("BT_EDGE_OFF") ? std::atoi(std::getenv("BT_EDGE_OFF")) : 0;   // measurement only
     static const int pref = std::getenv("BT_EDGE_PREF_TILES") ? std::atoi(std::getenv("BT_EDGE_PREF_TILES")) : 6144;
-    if (off || !pd.em_ok || pd.T < edge_min_tiles() || pd.max_cams > 10 || pd.max_cams <= 0 || pd.max_tile_pairs > 64 || pd.max_tile_pairs <= 0)
+    if (off || !pd.em_ok || pd.T < pd.em_min || pd.max_cams > 10 || pd.max_cams <= 0 || pd.max_tile_pairs > 64 || pd.max_tile_pairs <= 0)
         return false;
     return pd.T >= pref || !stream_applies(pd);
 }

@@ -409,35 +409,48 @@ def main():
     # no rank count shortens): 64 keyframes x 4096 tracks per frame x 8 observations = 2.1M edges, the same generator.
     large = None
     if not args.no_large:
-        try:
-            gl = graphgen.make_graph(64, 4096, 8, seed=args.seed)
-            Lp, Lx, Lm, Li, Lt, Lw = (f32(a_) for a_ in (gl.poses, gl.patches, gl.mono_disp, gl.intrinsics, gl.targets3, gl.weights_pose))
-            lidx = [torch.as_tensor(a_, device=dev) for a_ in (gl.ii, gl.jj, gl.kk)]
-            lscal = (list(gl.bounds), 1e-4, 10.0, 0.05, "huber")
-            if world > 1:
-                leng = ShardedBA(*lidx, Lp.shape[0], Lx.shape[0], 1, dev, exchange=exchange)
-                lstep, lplan = leng.step, leng.plan
-            else:
-                lplan = Plan(*lidx, Lp.shape[0], Lx.shape[0], 1)
-                lstep = Stepper(lplan, dev).step
+        from batrack_amd.plan import float32_kernels
+        gl = graphgen.make_graph(64, 4096, 8, seed=args.seed)
+        Lp, Lx, Lm, Li, Lt, Lw = (f32(a_) for a_ in (gl.poses, gl.patches, gl.mono_disp, gl.intrinsics, gl.targets3, gl.weights_pose))
+        lidx = [torch.as_tensor(a_, device=dev) for a_ in (gl.ii, gl.jj, gl.kk)]
+        lscal = (list(gl.bounds), 1e-4, 10.0, 0.05, "huber")
+
+        def measure_large(use_f32):
+            """The default (float64 per edge: inside the 1e-5 bar) and, beside it, the caller's opt-in float32 wave-per-tile kernels."""
+            prev = float32_kernels(use_f32)
+            try:
+                if world > 1:
+                    leng = ShardedBA(*lidx, Lp.shape[0], Lx.shape[0], 1, dev, exchange=exchange)
+                    lstep, lplan = leng.step, leng.plan
+                else:
+                    leng = None
+                    lplan = Plan(*lidx, Lp.shape[0], Lx.shape[0], 1)
+                    lstep = Stepper(lplan, dev).step
+            finally:
+                float32_kernels(prev)
             LP, LX = [Lp.clone(), torch.empty_like(Lp)], [Lx.clone(), torch.empty_like(Lx)]
 
             def large_iter(k):
                 a, b = k & 1, (k + 1) & 1
                 lstep(LP[a], LX[a], Lm, Li, Lt, 3, Lw, LP[b], LX[b], *lscal, False)
             ls, lel = timed(large_iter, 5, 50)
-            large = {"workload": f"64 keyframes, {len(gl.ii)} edges, {len(np.unique(gl.kk))} tracks, 63 free poses (make_graph(64, 4096, 8), seed {args.seed})",
-                     "iterations_per_s": round(ls / lel, 2), "ms_per_step": round(1e3 * lel / ls, 4), "steps": ls,
-                     "edges_this_rank": int(lplan.E), "jacobian_kernel_this_rank": lplan.jacobian_kernel,
-                     "edge_precision_this_rank": "float64 per edge" if lplan.edge_precision == 8 else "float32 per edge"}
-            if world > 1:
+            r = {"iterations_per_s": round(ls / lel, 2), "ms_per_step": round(1e3 * lel / ls, 4), "steps": ls,
+                 "edges_this_rank": int(lplan.E), "jacobian_kernel_this_rank": lplan.jacobian_kernel,
+                 "edge_precision_this_rank": "float64 per edge" if lplan.edge_precision == 8 else "float32 per edge",
+                 "planned_on_device": bool(lplan.built_on_device)}
+            if leng is not None:
                 leng.check_exchange()
                 leng.close()
-            del LP, LX, Lp, Lx, Lt, Lw
+            return r
+        try:
+            large = {"workload": f"64 keyframes, {len(gl.ii)} edges, {len(np.unique(gl.kk))} tracks, 63 free poses (make_graph(64, 4096, 8), seed {args.seed})"}
+            large.update(measure_large(False))
+            large["float32_kernels_opt_in"] = measure_large(True)
         except Exception as e:                                   # (a record beside the headline number: never its failure)
             large = {"error": repr(e)}
             if world > 1:
                 raise                                            # (but under N > 1 a rank that dropped out would leave the others waiting)
+        del Lp, Lx, Lt, Lw
 
     if rank == 0:
         out = {

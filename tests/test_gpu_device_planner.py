@@ -56,10 +56,19 @@ def test_device_planned_tables_equal_the_hosts(variant):
 
 @pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
 def test_lists_outside_the_device_path_are_planned_by_the_host():
-    # (a) a graph of the wave-per-tile kernels (2048 tiles); (b) a short list; (c) a track with two source frames is refused by
-    # both paths alike; (d) an index out of range is reported, not planned
+    # (a) a graph laid out for the float32 wave-per-tile kernels (the caller's choice; 2048 tiles) — by default the same list is
+    # planned on the device for k_tile; (b) a short list; (c) a track with two source frames is refused by both paths alike;
+    # (d) an index out of range is reported, not planned
+    from batrack_amd.plan import float32_kernels
     g = graphgen.make_graph(64, 2048, 8, seed=0)
-    p = Plan(*(torch.as_tensor(a, device=DEV) for a in (g.ii, g.jj, g.kk)), g.poses.shape[0], g.patches.shape[0], 1)
+    idx = [torch.as_tensor(a, device=DEV) for a in (g.ii, g.jj, g.kk)]
+    p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
+    assert p.built_on_device and p.jacobian_kernel == "k_tile" and p.tiles == 2048
+    prev = float32_kernels(True)
+    try:
+        p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
+    finally:
+        float32_kernels(prev)
     assert not p.built_on_device and p.jacobian_kernel == "k_stream" and p.tiles == 2048
     g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
     ii, jj, kk = (np.asarray(a).copy() for a in (g.ii, g.jj, g.kk))
@@ -85,12 +94,15 @@ SLOT_TABLES = ("slot_edge", "slot_pair", "slot_lab", "slot_lp", "tile_cut8", "ti
 
 
 @pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
-@pytest.mark.parametrize("variant", ["C3", "C3_shuffled", "small", "repeats", "thinned"])
+@pytest.mark.parametrize("variant", ["C3", "C3_shuffled", "small", "repeats", "thinned", "large2048", "large8192_shuffled"])
 def test_device_planned_slot_arrays_equal_the_hosts(variant):
-    """64-track layouts (k_tile): the [slots][64] arrays and the waves' slot cuts written by kernels."""
+    """64-track layouts (k_tile): the [slots][64] arrays and the waves' slot cuts written by kernels — since round 4 for graphs
+    of any tile count (2048 and 8192 tiles: the sizes the host used to analyse for the float32 wave-per-tile kernels)."""
     rng = np.random.default_rng(3)
     if variant.startswith("C3"):
         g, fixedp = graphgen.make_config("C3", seed=0), 1
+    elif variant.startswith("large"):
+        g, fixedp = graphgen.make_graph(64, 2048 if "2048" in variant else 8192, 8, seed=6), 1
     elif variant == "small":
         g, fixedp = graphgen.make_graph(16, 128, 6, seed=2), 2
     else:
@@ -102,7 +114,7 @@ def test_device_planned_slot_arrays_equal_the_hosts(variant):
     if variant == "thinned":
         keep = rng.random(ii.size) > 0.3
         ii, jj, kk = ii[keep], jj[keep], kk[keep]
-    if variant in ("C3_shuffled", "repeats"):
+    if variant in ("C3_shuffled", "repeats", "large8192_shuffled"):
         p = rng.permutation(ii.size)
         ii, jj, kk = ii[p], jj[p], kk[p]
     dev, host = both_plans(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], fixedp)
@@ -146,9 +158,8 @@ def test_random_edge_lists_plan_alike_on_device_and_host(seed):
     ii, jj, kk = ii[p], jj[p], kk[p]
     fixedp = int(rng.integers(0, max(1, int(max(ii.max(), jj.max())))))
     dev, host = both_plans(ii, jj, kk, n_buf, p_tot, fixedp)
-    # (graphs of 2048 tiles and more — many cameras per track: a tile per track — keep the host's analysis: the tables of the
-    #  wave-per-tile kernels are derived from its slot arrays)
-    assert dev.jacobian_kernel == host.jacobian_kernel and dev.built_on_device == (host.tiles < 2048)
+    # (since round 4 also the graphs of 2048 tiles and more — many cameras per track: a tile per track)
+    assert dev.jacobian_kernel == host.jacobian_kernel and dev.built_on_device
     for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
         assert getattr(dev, f) == getattr(host, f), f
     names = TABLES if dev.jacobian_kernel == "k_etile" else SLOT_TABLES
