@@ -52,6 +52,17 @@ class GaWeights(ctypes.Structure):                    # == bt_ga_weights
     _fields_ = [(n, ctypes.c_float) for n in ("spatial", "rigid", "pts3d", "cam_smooth", "scale_smooth")] + [("smooth_mode", ctypes.c_int32)]
 
 
+def kernel_sources_sha16():
+    """sha256 (16 hex digits) over the sources and headers the HIP library is built from: what a measurement of the kernels
+    (profiles/pmc_k_tile.json) is valid for.  bench.py quotes PMC traffic only from a file whose hash equals this."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True

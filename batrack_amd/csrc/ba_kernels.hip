@@ -64,7 +64,10 @@ __device__ __forceinline__ double dpp_add8(double v);     // (defined with the s
 // R: float or double — the precision of the per-edge maths, of E in LDS and of the (Q, w') it leaves for k_update (float64 is
 // the default of this kernel: StepArgs::prec).  The float64 variant is allowed 256 registers (two 8-wave tiles per CU).
 template <bool SO, bool PROF, bool WIDE = false, bool FUSE = false, typename R = float>
-__global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? 2 : 4)) void k_tile(PlanDev pd, StepArgs a, int do_poses) {
+#ifndef BT_TILE64_WAVES
+#define BT_TILE64_WAVES 2
+#endif
+__global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? BT_TILE64_WAVES : 4)) void k_tile(PlanDev pd, StepArgs a, int do_poses) {
     if (FUSE && (int)blockIdx.x >= pd.T) {
         update_rest<true, true>(pd, a, ((int)blockIdx.x - pd.T) * (int)blockDim.x + (int)threadIdx.x, do_poses);
         return;

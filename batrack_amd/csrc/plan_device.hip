@@ -295,7 +295,8 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
     }
     hipEvent_t ev = nullptr;
     if (hipMemcpyAsync(b.h_tab, b.stat + g[2], nt * sizeof(PatchStat), hipMemcpyDeviceToHost, cs) != hipSuccess ||
-        hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, cs) != hipSuccess) return BT_EHIP;
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return BT_EHIP;
+    if (hipEventRecord(ev, cs) != hipSuccess) { (void)hipEventDestroy(ev); return BT_EHIP; }
     // the sort runs while the host lays out tracks, pairs and tiles
     int jbits = 1, kbits = 1;
     while ((1 << jbits) < g[0] - g[1]) ++jbits;

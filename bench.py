@@ -350,15 +350,21 @@ def main():
         alg_bytes = 40 * plan.E + 20 * plan.m + 72 * plan.n_all        # SURVEY.md §8d, Jacobian kernel only
         tile_s = kern_us["tile"] * 1e-6
         achieved = alg_bytes / tile_s / 1e9 if tile_s > 0 else 0.0
-        # HBM bytes per launch from the PMC passes (their own rocprofv3 runs, committed under profiles/)
+        # HBM bytes per launch from the PMC passes (their own rocprofv3 runs of tools/gpu_profile_round.sh, committed under
+        # profiles/): quoted only if the file was made from the kernel sources this run was built from
         traffic, traffic_source = None, None
         try:
+            from batrack_amd import _lib as _bl
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_k_tile.json")))
-            if pmc.get(args.workload, {}).get("edges") == plan.E:
+            if pmc.get("kernel_sources_sha16") != _bl.kernel_sources_sha16():
+                traffic_source = ("profiles/pmc_k_tile.json was measured on other kernel sources (sha16 "
+                                  f"{pmc.get('kernel_sources_sha16')} != {_bl.kernel_sources_sha16()}): not quoted")
+            elif pmc.get(args.workload, {}).get("edges") == plan.E:
                 traffic = pmc[args.workload]["traffic_bytes"]
-                traffic_source = "profiles/pmc_k_tile.json (separate rocprofv3 --pmc passes of this workload, not measured in this run)"
-        except Exception:
-            traffic = None
+                traffic_source = ("profiles/pmc_k_tile.json: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this workload on "
+                                  "these kernel sources, not measured in this run")
+        except Exception as e:
+            traffic, traffic_source = None, f"profiles/pmc_k_tile.json unreadable ({e!r})"
         roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes": alg_bytes, "kernel_us": round(kern_us["tile"], 3)}

@@ -10,6 +10,9 @@ from batrack_amd.plan import Plan
 
 if len(sys.argv) > 1 and sys.argv[1] == "window":
     g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
+elif len(sys.argv) > 1 and sys.argv[1] == "large":          # 8.4M edges, 16384 tiles: planned on the device since round 4
+    g, fixedp = graphgen.make_graph(64, 16384, 8, seed=0), 1
+    print("# 64 keyframes x 16384 tracks per frame x 8 observations = 8.4M edges")
 else:
     g, fixedp = graphgen.make_config("C3", seed=0), 1
 n_buf, p_tot = g.poses.shape[0], g.patches.shape[0]

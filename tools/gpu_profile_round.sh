@@ -1,9 +1,11 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): rocprofv3 kernel traces and PMC passes of the round, summaries under gpurun_out/prof_r03/.
-# PMC passes are their own runs with --kernel-trace only (no other trace domain beside --pmc).
+# Runs on the GPU box (gpurun): rocprofv3 kernel traces and PMC passes of the round, summaries under gpurun_out/prof_r04/
+# (copied into profiles/r04_* afterwards).  PMC passes are their own runs with --kernel-trace only (no other trace domain
+# beside --pmc).  profiles/pmc_k_tile.json is rewritten from the FETCH_SIZE / WRITE_SIZE passes of THIS build
+# (tools/pmc_to_json.py: it carries the hash of the kernel sources; bench.py refuses it when the sources change).
 set -u
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r03
+OUT=$R/gpurun_out/prof_r04
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 trace() {   # name, command...
@@ -12,30 +14,49 @@ trace() {   # name, command...
     rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o runc -- "$@" > $OUT/$name.stdout 2> $OUT/$name.stderr
     python $R/tools/prof_summary.py $(find /tmp/prof_$name -name "*results.db" | head -1) > $OUT/kernel_trace_stats_$name.txt 2>&1
 }
-pmc() {     # counter, M
+pmc() {     # counter, tag, M  (environment of the caller selects the kernels)
     rm -rf /tmp/pmc_$1_$2
-    rocprofv3 --kernel-trace --pmc $1 -d /tmp/pmc_$1_$2 -o runc -- python $R/tools/gpu_pmc_run.py $2 4 > /dev/null 2> $OUT/pmc_$1_$2.stderr
-    python $R/tools/pmc_summary.py $(find /tmp/pmc_$1_$2 -name "*results.db" | head -1) >> $OUT/pmc_fetch_write.txt 2>&1
+    rocprofv3 --kernel-trace --pmc $1 -d /tmp/pmc_$1_$2 -o runc -- python $R/tools/gpu_pmc_run.py $3 4 > /dev/null 2> $OUT/pmc_$1_$2.stderr
+    cp $(find /tmp/pmc_$1_$2 -name "*results.db" | head -1) /tmp/pmc_$1_$2.db
+    python $R/tools/pmc_summary.py /tmp/pmc_$1_$2.db >> $OUT/pmc_fetch_write.txt 2>&1
 }
-trace c3 python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline
+# ---- headline bench first (fresh clocks), then the traces
+python $R/bench.py --steps 200 --warmup 20 > $OUT/bench_n1.json 2> $OUT/bench_n1.stderr
+trace c3 python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-large
 trace window python $R/tools/gpu_timing.py --workload window
-trace e8m python $R/tools/gpu_pmc_run.py 16384 6
+trace e2m_f64 python $R/tools/gpu_pmc_run.py 4096 6
+trace e8m_f64 python $R/tools/gpu_pmc_run.py 16384 6
+BT_FLOAT32_KERNELS=1 trace e8m_f32 python $R/tools/gpu_pmc_run.py 16384 6
+trace ga python $R/tools/gpu_ga_bench.py
+# ---- HBM traffic of the Jacobian kernel: C3 and 8.4M edges in the default (float64) kernels, 8.4M in the opt-in float32 kernel
 : > $OUT/pmc_fetch_write.txt
-for M in 256 16384; do for C in FETCH_SIZE WRITE_SIZE; do pmc $C $M; done; done
-$R/tools/gpu_pmc_sq.sh 16384 $OUT/pmc_sq_e8m.txt > /dev/null 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do pmc $C c3 256; pmc $C e8m 16384; BT_FLOAT32_KERNELS=1 pmc $C e8mf32 16384; done
+python $R/tools/pmc_to_json.py $OUT/pmc_k_tile.json \
+    C3:131072:16384:64:/tmp/pmc_FETCH_SIZE_c3.db:/tmp/pmc_WRITE_SIZE_c3.db \
+    E8M:8388608:1048576:64:/tmp/pmc_FETCH_SIZE_e8m.db:/tmp/pmc_WRITE_SIZE_e8m.db \
+    E8M_float32_kernels:8388608:1048576:64:/tmp/pmc_FETCH_SIZE_e8mf32.db:/tmp/pmc_WRITE_SIZE_e8mf32.db > $OUT/pmc_to_json.stdout 2>&1
 $R/tools/gpu_pmc_sq.sh 256 $OUT/pmc_sq_c3.txt > /dev/null 2>&1
+$R/tools/gpu_pmc_sq.sh 16384 $OUT/pmc_sq_e8m_f64.txt > /dev/null 2>&1
 cd $R
-hipcc --offload-arch=gfx950 -O3 tools/issue_rate.hip -o /tmp/issue_rate && /tmp/issue_rate > $OUT/valu_issue_rate.txt 2>&1
-python tools/gpu_sweep.py 256 1024 4096 16384 32768 > $OUT/edge_sweep.txt 2>&1
-(echo "# k_stream (float32 per edge, the default from 2048 tiles) against k_tile (float64 per edge) forced on the same graphs"; for M in 512 1024; do python tools/gpu_sweep.py $M; BT_STREAM_MIN_TILES=100000000 BT_EDGE_MIN_TILES=100000000 python tools/gpu_sweep.py $M; done) > $OUT/kernel_choice_f64.txt 2>&1
-(for w in 2 4 6 8; do echo "== BT_EDGE_WAVES_PER_CU=$w"; BT_EDGE_WAVES_PER_CU=$w python tools/gpu_sweep.py 16384; done) > $OUT/edge_occupancy.txt 2>&1
-python bench.py --steps 200 --warmup 20 > $OUT/bench_n1.json 2> $OUT/bench_n1.stderr
+# ---- the edge sweep in both precisions (the roofline table of DESIGN.md §6)
+(echo "# default: float64 per edge (k_tile), every size"; python tools/gpu_sweep.py 256 1024 4096 16384 32768;
+ echo "# BT_FLOAT32_KERNELS=1: the caller's opt-in float32 wave-per-tile kernels from 2048 tiles"; BT_FLOAT32_KERNELS=1 python tools/gpu_sweep.py 4096 16384 32768) > $OUT/edge_sweep.txt 2>&1
+# ---- solver variants: k_solve_pipe (default) against k_solve_chain, with their in-kernel cycle counters
+(for w in C3 window; do python tools/gpu_timing.py --workload $w; BT_SOLVER_CHAIN=1 python tools/gpu_timing.py --workload $w; done;
+ BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver"; BT_SOLVER_CHAIN=1 BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver";
+ BT_DEBUG_MODE=16 python tools/gpu_timing.py --workload window | grep -A2 "solver") > $OUT/solver_variants.txt 2>&1
 python tests/sequence_report.py > $OUT/sequence_ate.txt 2>&1
-(echo "# 200 frames, steady state of the window"; python tests/sequence_report.py --frames 200 --skip-oracle; echo "# the same with BT_PLAN_SHIFT=0 (every plan from scratch)"; BT_PLAN_SHIFT=0 python tests/sequence_report.py --frames 200 --skip-oracle) >> $OUT/sequence_ate.txt 2>&1
-(python tools/gpu_plan_time.py; python tools/gpu_plan_time.py window; BT_PLAN_PROF=1 python tools/gpu_plan_time.py window 2>&1 | tail -40) > $OUT/plan_time.txt 2>&1
+(echo "# 200 frames, steady state of the window"; python tests/sequence_report.py --frames 200 --skip-oracle) >> $OUT/sequence_ate.txt 2>&1
+(python tools/gpu_plan_time.py; python tools/gpu_plan_time.py window; python tools/gpu_plan_time.py large) > $OUT/plan_time.txt 2>&1
 python tools/gpu_check.py > $OUT/parity_numbers.txt 2>&1
 python tools/gpu_refine_check.py >> $OUT/parity_numbers.txt 2>&1
 python tools/gpu_edge_accuracy.py 64 256 >> $OUT/parity_numbers.txt 2>&1
-(echo "# the float32 per-edge kernels (k_edge forced) on the same generated graphs"; BT_EDGE_MIN_TILES=1 python tools/gpu_edge_accuracy.py) >> $OUT/parity_numbers.txt 2>&1
+(echo "# graphs of 2048 .. 16384 tiles, default (float64 per edge, k_tile)"; python tools/gpu_edge_accuracy.py 64 2048; python tools/gpu_edge_accuracy.py 64 8192;
+ echo "# the same with the caller's opt-in float32 kernels (BT_FLOAT32_KERNELS=1)"; BT_FLOAT32_KERNELS=1 python tools/gpu_edge_accuracy.py 64 2048; BT_FLOAT32_KERNELS=1 python tools/gpu_edge_accuracy.py 64 8192) >> $OUT/parity_numbers.txt 2>&1
 (for w in C3 window; do python tools/gpu_timing.py --workload $w; BT_EDGE_PREC=0 BT_ETILE=0 python tools/gpu_timing.py --workload $w; BT_ETILE=0 python tools/gpu_timing.py --workload $w; done) > $OUT/timing_variants.txt 2>&1
+python tools/gpu_ga_bench.py > $OUT/global_refine_losses.txt 2>&1
+# ---- N > 1 plumbing on the one GPU (ranks share it; gloo rendezvous): not a scaling measurement
+for n in 2 4 8; do
+  BT_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29820 + n)) bench.py --gpus $n --steps 50 --warmup 5 2> $OUT/bench_plumbing_n$n.stderr | tail -1 > $OUT/bench_plumbing_n$n.json
+done
 ls -la $OUT
