@@ -175,8 +175,8 @@ def lib():
     L.bt_plan_jacobian_kernel.argtypes = [vp]
     L.bt_plan_edge_precision.restype = i32
     L.bt_plan_edge_precision.argtypes = [vp]
-    L.bt_config_float32_kernels.restype = i32
-    L.bt_config_float32_kernels.argtypes = [i32]
+    L.bt_config_wave_per_tile_kernels.restype = i32
+    L.bt_config_wave_per_tile_kernels.argtypes = [i32]
     L.bt_plan_built_on_device.restype = i32
     L.bt_plan_built_on_device.argtypes = [vp]
     L.bt_target_arch.restype = ctypes.c_char_p

@@ -341,7 +341,8 @@ int bt_plan_built_on_device(const bt_plan *pl) { return pl && (pl->dev_pm || pl-
 
 int bt_plan_edge_precision(const bt_plan *pl) {
     if (!pl || !pl->dev_base) return -1;
-    return edge_precision(pl->dev) ? 8 : 4;
+    if (edge_precision(pl->dev)) return 8;
+    return (pl->dev.T > 0 && (edge_applies(pl->dev) || stream_applies(pl->dev))) ? 6 : 4;     // 6: mixed (ba_edge.hpp: edge_eval_mixed)
 }
 const char *bt_target_arch(void) { return "gfx950"; }
 
@@ -655,7 +656,7 @@ int bt_xchg_alloc(size_t bytes, void **buf, unsigned char handle[64]) {
     return BT_OK;
 }
 
-int bt_config_float32_kernels(int enable) { return bt::config_float32_kernels(enable); }
+int bt_config_wave_per_tile_kernels(int enable) { return bt::config_wave_per_tile_kernels(enable); }
 
 int bt_xchg_open(const unsigned char handle[64], void **peer) {
     if (!handle || !peer) return BT_EINVAL;

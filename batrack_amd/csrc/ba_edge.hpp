@@ -37,7 +37,10 @@ __device__ inline void quat_to_rot(const double *q, double R[9]) {
 // R_ij (9, row-major), t_ij (3), (1/fx_i, 1/fy_i, cx_i, cy_i), (fx_j, fy_j, cx_j, cy_j).
 // Gij = Gj * Gi^-1 (projective_ops.py:61) in double; a self edge is exactly the identity.
 // T = float: rounded to float32 (the float32 per-edge path, k_stream / k_edge); T = double: kept (the float64 per-edge path).
-template <typename T>
+// RAWK: g[12], g[13] hold fx_i, fy_i themselves instead of their reciprocals (edge_eval_mixed divides in double: a float32
+// reciprocal of the one focal length every camera shares is the SAME 6e-8 off for every edge of the graph — a bias along the
+// weakly constrained directions of the reduced system, which it took to find: dX 3e-5 with it, 2e-6 without).
+template <typename T, bool RAWK = false>
 __device__ inline void pair_geometry(const float *poses, const float *intr, int i, int j, T *g) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
     if (i != j) {
@@ -54,7 +57,9 @@ __device__ inline void pair_geometry(const float *poses, const float *intr, int 
     for (int c = 0; c < 9; ++c) g[c] = (T)R[c];
     for (int c = 0; c < 3; ++c) g[9 + c] = (T)t[c];
     // source intrinsics as (1/fx, 1/fy, cx, cy): iproj divides (projective_ops.py:25-26)
-    g[12] = (T)1 / (T)intr[4*i]; g[13] = (T)1 / (T)intr[4*i + 1]; g[14] = intr[4*i + 2]; g[15] = intr[4*i + 3];
+    if (RAWK) { g[12] = (T)intr[4*i]; g[13] = (T)intr[4*i + 1]; }
+    else { g[12] = (T)1 / (T)intr[4*i]; g[13] = (T)1 / (T)intr[4*i + 1]; }
+    g[14] = intr[4*i + 2]; g[15] = intr[4*i + 3];
     for (int c = 0; c < 4; ++c) g[16 + c] = intr[4*j + c];
 }
 
@@ -127,6 +132,56 @@ __device__ __forceinline__ void edge_eval(const T *g, T x, T y, T d, T tu, T tv,
     o.W1 = vld * (w1 * robust_weight(r1, a.loss));
     o.r0 = vld * r0; o.r1 = vld * r1;
 }
+
+// MIXED precision (the wave-per-tile kernels of large graphs, round 4): the reprojection and the residual in float64 on the
+// float32 inputs and on the pair's float32 geometry — u = fx X / Z + cx is ~500 px and r = target - u ~0.5 px, so a float32
+// u (3e-5 px) costs r five digits, and that, not the Jacobians' rounding, is what put the float32 kernels' update at
+// 1e-5 .. 5e-5 from the reference's float64 run on the benchmark graphs (measured stage by stage on the host: projection in
+// float32 alone dX 3.3e-5; geometry, Jacobians and their products in float32 with the projection in float64: 2e-6) —,
+// validity and bounds decided on those float64 values, then Jacobians, robust weights and every product in float32.
+__device__ __forceinline__ void edge_eval_mixed(const float *g, float x, float y, float d, float tu, float tv,
+                                                float w0, float w1, const StepArgs &a, EdgeQT<float> &o) {
+    // projective_ops.py:19-29 (iproj), :61-66 (act4), :43-45 (proj) in double
+    // (g[12], g[13] = fx_i, fy_i: pair_geometry<float, true>) the quotient to double precision from the float32 hardware
+    // reciprocal: q = fl32(n * rcp), X0 = q + (n - q fx) rcp
+    const double nx = (double)x - (double)g[14], ny = (double)y - (double)g[15];
+    const float rfx = frcp(g[12]), rfy = frcp(g[13]);
+    const float qx = (float)nx * rfx, qy = (float)ny * rfy;
+    const double X0 = fma(fma(-(double)qx, (double)g[12], nx), (double)rfx, (double)qx);
+    const double Y0 = fma(fma(-(double)qy, (double)g[13], ny), (double)rfy, (double)qy);
+    const double dd = (double)d;
+    const double Xd = fma((double)g[0], X0, fma((double)g[1], Y0, (double)g[2])) + (double)g[9] * dd;
+    const double Yd = fma((double)g[3], X0, fma((double)g[4], Y0, (double)g[5])) + (double)g[10] * dd;
+    const double Zd = fma((double)g[6], X0, fma((double)g[7], Y0, (double)g[8])) + (double)g[11] * dd;
+    const double izd = frcp(fmax(Zd, 1e-2));
+    const double ud = fma((double)g[16], izd * Xd, (double)g[18]), vd = fma((double)g[17], izd * Yd, (double)g[19]);
+    const double r0d = (double)tu - ud, r1d = (double)tv - vd;
+    float vld = Zd > 0.2 ? 1.0f : 0.0f;
+    vld *= r0d * r0d + r1d * r1d < 62500.0 ? 1.0f : 0.0f;               // |r| < 250 (ba.py:233), compared squared
+    vld *= (ud > (double)a.b0 && vd > (double)a.b1 && ud < (double)a.b2 && vd < (double)a.b3) ? 1.0f : 0.0f;
+    // projective_ops.py:80-98 in float on the rounded point
+    const float X = (float)Xd, Y = (float)Yd, Z = (float)Zd, fx = g[16], fy = g[17];
+    const float dj = fabsf(Z) > 0.2f ? frcp(Z) : 0.0f;
+    const float A = fx * dj, B = -fx * X * dj * dj, C = fy * dj, Dd = -fy * Y * dj * dj;
+    o.a0 = d * A;  o.a2 = d * B;  o.a3 = B * Y;            o.a4 = A * Z - B * X;  o.a5 = -A * Y;
+    o.b1 = d * C;  o.b2 = d * Dd; o.b3 = Dd * Y - C * Z;   o.b4 = -Dd * X;        o.b5 = C * X;
+    o.jz0 = fmaf(A, g[9], B * g[11]);
+    o.jz1 = fmaf(C, g[10], Dd * g[11]);
+    const float r0 = (float)r0d, r1 = (float)r1d;
+    o.W0 = vld * (w0 * robust_weight(r0, a.loss));
+    o.W1 = vld * (w1 * robust_weight(r1, a.loss));
+    o.r0 = vld * r0; o.r1 = vld * r1;
+}
+
+// what the wave-per-tile kernels (k_stream, k_edge) evaluate an edge with; -DBT_WPT_MIXED=0: plain float32 (measurement builds)
+#ifndef BT_WPT_MIXED
+#define BT_WPT_MIXED 1
+#endif
+#if BT_WPT_MIXED
+#define BT_WPT_EDGE_EVAL edge_eval_mixed
+#else
+#define BT_WPT_EDGE_EVAL edge_eval<float>
+#endif
 
 // Sum v[0..31] over the 64 lanes of a wave; afterwards every lane holds, in v[0], the
 // total of element ((lane >> 1) & 31).  Halving exchange: 16 + 8 lane-swap instructions

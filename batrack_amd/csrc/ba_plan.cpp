@@ -25,32 +25,36 @@ namespace bt {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Tile counts from which a plan is laid out for the wave-per-tile kernels k_stream / k_edge.  Those kernels do the per-edge
-// maths in FLOAT32 (update 1e-5 .. 5e-5 off the reference's float64 run on the benchmark graphs: outside north_star's 1e-5),
-// so since round 4 they are an explicit choice of the caller — bt_config_float32_kernels(1), or BT_FLOAT32_KERNELS=1 in the
-// environment — and every plan otherwise takes the float64-per-edge tile kernels whatever its size.  BT_EDGE_MIN_TILES /
+// Tile counts from which a plan is laid out for the wave-per-tile kernels k_stream / k_edge (2048: profiles/r02_kernel_choice.txt).
+// Those kernels evaluate an edge in MIXED precision since round 4 (reprojection and residual in float64, Jacobians and their
+// products in float32: ba_edge.hpp edge_eval_mixed) and keep the update within north_star's 1e-5 of the reference's float64
+// run (measured 1e-6 .. 5e-6 on the benchmark graphs; S and y 1e-7).  A caller who wants the reduced system itself to 1e-10
+// at every size switches them off — bt_config_wave_per_tile_kernels(0), or BT_WPT_KERNELS=0 in the environment — and every
+// plan then takes the float64-per-edge tile kernels (a third of the throughput from 2048 tiles on).  BT_EDGE_MIN_TILES /
 // BT_STREAM_MIN_TILES set the thresholds outright (tests, measurement).  A plan records what it was laid out for (st_ok,
-// em_ok): the launch-time choice never depends on a later change of this setting.
-static std::atomic<int> g_float32_kernels{-1};       // -1: not set by the caller -> the environment decides
-int config_float32_kernels(int enable) {
-    const int prev = g_float32_kernels.load();
-    if (enable >= 0) g_float32_kernels.store(enable ? 1 : 0);
-    return prev < 0 ? (std::getenv("BT_FLOAT32_KERNELS") && std::atoi(std::getenv("BT_FLOAT32_KERNELS")) ? 1 : 0) : prev;
-}
-static int float32_kernels_on() {
-    const int v = g_float32_kernels.load();
-    if (v >= 0) return v;
-    static const int env = std::getenv("BT_FLOAT32_KERNELS") ? std::atoi(std::getenv("BT_FLOAT32_KERNELS")) : 0;
+// em_ok, st_min, em_min): the launch-time choice never depends on a later change of this setting.
+static std::atomic<int> g_wpt_kernels{-1};           // -1: not set by the caller -> the environment decides (default on)
+static int wpt_env() {
+    static const int env = std::getenv("BT_WPT_KERNELS") ? std::atoi(std::getenv("BT_WPT_KERNELS")) : 1;
     return env ? 1 : 0;
+}
+int config_wave_per_tile_kernels(int enable) {
+    const int prev = g_wpt_kernels.load();
+    if (enable >= 0) g_wpt_kernels.store(enable ? 1 : 0);
+    return prev < 0 ? wpt_env() : prev;
+}
+static int wpt_kernels_on() {
+    const int v = g_wpt_kernels.load();
+    return v >= 0 ? v : wpt_env();
 }
 constexpr int kNever = 1 << 30;
 int edge_min_tiles() {
     static const int t = std::getenv("BT_EDGE_MIN_TILES") ? std::atoi(std::getenv("BT_EDGE_MIN_TILES")) : -1;
-    return t >= 0 ? t : (float32_kernels_on() ? 2048 : kNever);
+    return t >= 0 ? t : (wpt_kernels_on() ? 2048 : kNever);
 }
 int stream_min_tiles() {
     static const int t = std::getenv("BT_STREAM_MIN_TILES") ? std::atoi(std::getenv("BT_STREAM_MIN_TILES")) : -1;
-    return t >= 0 ? t : (float32_kernels_on() ? 2048 : kNever);
+    return t >= 0 ? t : (wpt_kernels_on() ? 2048 : kNever);
 }
 
 static void layout_workspace(bt_plan *pl) {

@@ -183,8 +183,8 @@ namespace bt {
 // measurement and tests).  The planner lays out their tables only for plans that will use them.
 int edge_min_tiles();
 int stream_min_tiles();
-// the caller's choice of the float32 wave-per-tile kernels for large graphs (bt_config_float32_kernels); returns the previous setting
-int config_float32_kernels(int enable);
+// the wave-per-tile kernels for graphs of >= 2048 tiles, on by default (bt_config_wave_per_tile_kernels); returns the previous setting
+int config_wave_per_tile_kernels(int enable);
 // Pure host analysis (no HIP).  Returns BT_OK or an error code.
 // `packed` (optional): the edges as 8-byte words kk << 32 | ii << 16 | jj, already range-checked (ii / jj / kk are then not read)
 // `dstats` (optional; plan_device.hip): the per-track figures of the edge list as a kernel gathered them — the analysis then

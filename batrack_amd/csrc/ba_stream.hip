@@ -281,7 +281,7 @@ __global__ __launch_bounds__(128, MODE == kModeFull ? BT_STREAM_FULL_WAVES : 4) 
                     g[26] = 0.0f; g[27] = 0.0f;
                 } else {
                     const int ij = pd.tile_ij[(unsigned)tile * (unsigned)mtp + (unsigned)p];
-                    pair_geometry(a.poses, a.intr, ij & 0xffff, ij >> 16, g);
+                    pair_geometry<float, BT_WPT_MIXED != 0>(a.poses, a.intr, ij & 0xffff, ij >> 16, g);
                     if (MODE == kModeFull) {
                         gpl[p] = gp;
                         float4 *dst = reinterpret_cast<float4 *>(a.pairgeo + (size_t)gp * kPairGeomFloats);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(128, MODE == kModeFull ? BT_STREAM_FULL_WAVES : 4) 
                     }
                 }
                 EdgeQ q;
-                edge_eval(g, px, py, pdisp, grp.tu[s], grp.tv[s], grp.w0[s], grp.w1[s], a, q);
+                BT_WPT_EDGE_EVAL(g, px, py, pdisp, grp.tu[s], grp.tv[s], grp.w0[s], grp.w1[s], a, q);
                 if (!act) { q.W0 = 0.0f; q.W1 = 0.0f; q.r0 = 0.0f; q.r1 = 0.0f; }
                 if (MODE == kModeUpd) {
                     if (act) {

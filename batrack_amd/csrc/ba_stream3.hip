@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
                     g[26] = 0.0f; g[27] = 0.0f;
                 } else {
                     const int ij = pd.tile_ij[(unsigned)tile * (unsigned)mtp + (unsigned)p];
-                    pair_geometry(a.poses, a.intr, ij & 0xffff, ij >> 16, g);
+                    pair_geometry<float, BT_WPT_MIXED != 0>(a.poses, a.intr, ij & 0xffff, ij >> 16, g);
                     if (MODE == kEmFull) {
                         gpl[p] = gp;
                         float4 *dst = reinterpret_cast<float4 *>(a.pairgeo + (size_t)gp * kPairGeomFloats);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(64, MODE == kEmFull ? BT_EDGE_FULL_WAVES : 4) void 
             }
             BT_PF(9);
             EdgeQ q;
-            edge_eval(g, pt.x, pt.y, pt.z, tu, tv, w0, w1, a, q);
+            BT_WPT_EDGE_EVAL(g, pt.x, pt.y, pt.z, tu, tv, w0, w1, a, q);
             if (!act) { q.W0 = 0.0f; q.W1 = 0.0f; q.r0 = 0.0f; q.r1 = 0.0f; }
             BT_PF(10);
             if (MODE == kEmUpd) {

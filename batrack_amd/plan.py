@@ -22,12 +22,13 @@ PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0",
                "fz_pend_ptr", "fz_pend", "fz_lazy_ptr", "fz_lazy", "fz_yurg", "fz_meta", "fz_pmeta", "bs_sync", "fz_rowinfo", "fz_pfirst", "fz_psecond", "act_bits", "act_rank", "tile_ij", "tile_kx", "lvl_meta", "slot_code", "tile_la", "tile_rec", "it_edge", "tile_sinfo", "tile_cut8", "tile_cut16", "pm_edge", "pm_rec", "pm_lb", "pm_la", "pp_ptr", "pp_idx", "sg_ptr")
 
 
-def float32_kernels(enable=None):
-    """The float32 per-edge kernels (k_stream, k_edge) for graphs of >= 2048 tiles: off by default — every plan runs the
-    float64-per-edge tile kernels and stays inside the 1e-5 bar on the update —, `float32_kernels(True)` trades that for two to
-    four times the throughput on such graphs (plans created afterwards; include/batrack_ba.h: bt_config_float32_kernels).
-    Returns the previous setting; no argument only queries."""
-    return bool(_lib.lib().bt_config_float32_kernels(-1 if enable is None else int(bool(enable))))
+def wave_per_tile_kernels(enable=None):
+    """The wave-per-tile kernels (k_stream, k_edge) for graphs of >= 2048 tiles, on by default: mixed precision (float64
+    reprojection and residual, float32 Jacobians), update within 1e-5 of the reference's float64 run, about three times the
+    float64 tile kernels' throughput.  `wave_per_tile_kernels(False)` lays the plans created afterwards out for the float64
+    tile kernels whatever their size (include/batrack_ba.h: bt_config_wave_per_tile_kernels).  Returns the previous setting; no
+    argument only queries."""
+    return bool(_lib.lib().bt_config_wave_per_tile_kernels(-1 if enable is None else int(bool(enable))))
 
 
 class Plan:
@@ -108,7 +109,8 @@ class Plan:
 
     @property
     def edge_precision(self):
-        """8 | 4: bytes of the floating-point type of the per-edge maths of this plan's steps (bt_plan_edge_precision)."""
+        """8 | 6 | 4: float64 per edge, mixed (float64 reprojection and residual, float32 Jacobians: k_stream / k_edge), float32
+        (bt_plan_edge_precision)."""
         return self._lib.bt_plan_edge_precision(self._h)
 
     @property

@@ -415,15 +415,16 @@ def main():
     # no rank count shortens): 64 keyframes x 4096 tracks per frame x 8 observations = 2.1M edges, the same generator.
     large = None
     if not args.no_large:
-        from batrack_amd.plan import float32_kernels
+        from batrack_amd.plan import wave_per_tile_kernels
         gl = graphgen.make_graph(64, 4096, 8, seed=args.seed)
         Lp, Lx, Lm, Li, Lt, Lw = (f32(a_) for a_ in (gl.poses, gl.patches, gl.mono_disp, gl.intrinsics, gl.targets3, gl.weights_pose))
         lidx = [torch.as_tensor(a_, device=dev) for a_ in (gl.ii, gl.jj, gl.kk)]
         lscal = (list(gl.bounds), 1e-4, 10.0, 0.05, "huber")
 
-        def measure_large(use_f32):
-            """The default (float64 per edge: inside the 1e-5 bar) and, beside it, the caller's opt-in float32 wave-per-tile kernels."""
-            prev = float32_kernels(use_f32)
+        def measure_large(wpt):
+            """The default (from 2048 tiles the wave-per-tile kernels, mixed precision: inside the 1e-5 bar) and, beside it, the
+            float64 tile kernels at every size (bt_config_wave_per_tile_kernels(0))."""
+            prev = wave_per_tile_kernels(wpt)
             try:
                 if world > 1:
                     leng = ShardedBA(*lidx, Lp.shape[0], Lx.shape[0], 1, dev, exchange=exchange)
@@ -433,7 +434,7 @@ def main():
                     lplan = Plan(*lidx, Lp.shape[0], Lx.shape[0], 1)
                     lstep = Stepper(lplan, dev).step
             finally:
-                float32_kernels(prev)
+                wave_per_tile_kernels(prev)
             LP, LX = [Lp.clone(), torch.empty_like(Lp)], [Lx.clone(), torch.empty_like(Lx)]
 
             def large_iter(k):
@@ -442,7 +443,7 @@ def main():
             ls, lel = timed(large_iter, 5, 50)
             r = {"iterations_per_s": round(ls / lel, 2), "ms_per_step": round(1e3 * lel / ls, 4), "steps": ls,
                  "edges_this_rank": int(lplan.E), "jacobian_kernel_this_rank": lplan.jacobian_kernel,
-                 "edge_precision_this_rank": "float64 per edge" if lplan.edge_precision == 8 else "float32 per edge",
+                 "edge_precision_this_rank": {8: "float64 per edge", 6: "mixed: float64 reprojection and residual, float32 Jacobians", 4: "float32 per edge"}[lplan.edge_precision],
                  "planned_on_device": bool(lplan.built_on_device)}
             if leng is not None:
                 leng.check_exchange()
@@ -450,8 +451,8 @@ def main():
             return r
         try:
             large = {"workload": f"64 keyframes, {len(gl.ii)} edges, {len(np.unique(gl.kk))} tracks, 63 free poses (make_graph(64, 4096, 8), seed {args.seed})"}
-            large.update(measure_large(False))
-            large["float32_kernels_opt_in"] = measure_large(True)
+            large.update(measure_large(True))
+            large["float64_tile_kernels_only"] = measure_large(False)
         except Exception as e:                                   # (a record beside the headline number: never its failure)
             large = {"error": repr(e)}
             if world > 1:

@@ -24,9 +24,11 @@
  *   workspace caller-owned device scratch of bt_plan_workspace_bytes() bytes.
  *
  * Arithmetic: inputs and outputs are float32 as the reference's (batrack.py:74-91).  The per-edge maths (reprojection,
- * Jacobians, robust weights, ba.py:228-266 / projective_ops.py:54-100) is float64 on those inputs for every plan, whatever its
- * size (bt_plan_edge_precision() == 8), unless the caller asks for the float32 wave-per-tile kernels of large graphs
- * (bt_config_float32_kernels) or a tile's E does not fit LDS as double (a track seen by more than about 30 free cameras);
+ * Jacobians, robust weights, ba.py:228-266 / projective_ops.py:54-100) is float64 on those inputs for every plan of fewer than
+ * 2048 tiles (bt_plan_edge_precision() == 8: every window of the real pipeline); beyond, the wave-per-tile kernels keep the
+ * reprojection and the residual in float64 and do the Jacobians and their products in float32 (== 6; switched off by
+ * bt_config_wave_per_tile_kernels(0)); float32 throughout (== 4) only where a tile's E does not fit LDS as double (a track
+ * seen by more than about 30 free cameras);
  * sums across edges, the reduced system, its factorisation and the retraction are float64 always.  The update agrees with
  * the reference's float64 run to ~1e-6 (north_star: 1e-5).
  */
@@ -217,15 +219,17 @@ int bt_plan_jacobian_kernel(const bt_plan *plan);
 /* Precision of the per-edge maths (reprojection, Jacobians, robust weights, the products they enter, E) of this plan's
  * steps: 8 = float64 on the float32 inputs — every plan that takes k_tile and whose tiles' E fits LDS as double (up to
  * about 30 free cameras per tile: every window of the real pipeline, which has 15) — 4 = float32 like the reference's
- * own run (k_stream / k_edge when the caller enabled them with bt_config_float32_kernels, graphs of >= 2048 tiles; hub
- * tracks seen by more than about 30 free cameras; BT_EDGE_PREC=0).  Sums across edges, the reduced system and its factorisation are float64 either way. */
+ * own run (hub tracks seen by more than about 30 free cameras; BT_EDGE_PREC=0), 6 = mixed: float64 reprojection and residual,
+ * float32 Jacobians and products (k_stream / k_edge, graphs of >= 2048 tiles; update within 1e-5 like 8, S and y 1e-7).  Sums across edges, the reduced system and its factorisation are float64 either way. */
 int bt_plan_edge_precision(const bt_plan *plan);
-/* The float32 per-edge kernels for graphs of >= 2048 tiles (k_stream, k_edge: two to four times the float64 tile kernels'
- * throughput there; S 4e-7..8e-7 and the update 1e-5..5e-5 off the reference's float64 run on the benchmark graphs, i.e.
- * OUTSIDE the 1e-5 this library otherwise keeps — the reference's own float32 run is no closer).  Off by default since
- * round 4; enable >= 0 sets it for the plans created afterwards (a plan keeps the layout it was built with), enable < 0 only
- * queries.  Returns the previous setting.  BT_FLOAT32_KERNELS=1 in the environment is the same switch for a whole process. */
-int bt_config_float32_kernels(int enable);
+/* The wave-per-tile kernels for graphs of >= 2048 tiles (k_stream, k_edge: about three times the float64 tile kernels'
+ * throughput there).  They evaluate an edge in MIXED precision — reprojection and residual in float64 on the float32 inputs,
+ * Jacobians and their products in float32 — which keeps the pose / depth update within the 1e-5 of the reference's float64
+ * run this library promises (measured 1e-6 .. 5e-6 on the benchmark graphs; S and y themselves 1e-7 instead of the tile
+ * kernels' 1e-13).  On by default; enable = 0 lays out the plans created afterwards for the float64 tile kernels whatever
+ * their size (a plan keeps the layout it was built with), enable < 0 only queries.  Returns the previous setting.
+ * BT_WPT_KERNELS=0 in the environment is the same switch for a whole process. */
+int bt_config_wave_per_tile_kernels(int enable);
 /* 1 if the passes over the edges of this plan ran on the device (bt_plan_create with device index tensors on a sliding-window
  * or 64-keyframe-sized edge list, i.e. below 2048 tiles: per-track figures, a radix sort and the edge-sized tables by kernels,
  * the host laid out tracks, pairs, tiles and the reduced system from the per-track figures), 0 if the host analysed the edges

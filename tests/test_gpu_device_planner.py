@@ -56,20 +56,20 @@ def test_device_planned_tables_equal_the_hosts(variant):
 
 @pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
 def test_lists_outside_the_device_path_are_planned_by_the_host():
-    # (a) a graph laid out for the float32 wave-per-tile kernels (the caller's choice; 2048 tiles) — by default the same list is
-    # planned on the device for k_tile; (b) a short list; (c) a track with two source frames is refused by both paths alike;
-    # (d) an index out of range is reported, not planned
-    from batrack_amd.plan import float32_kernels
+    # (a) a graph laid out for the wave-per-tile kernels (2048 tiles: their tables are derived from the host's slot arrays) — with
+    # those kernels switched off the same list is planned on the device for k_tile; (b) a short list; (c) a track with two source
+    # frames is refused by both paths alike; (d) an index out of range is reported, not planned
+    from batrack_amd.plan import wave_per_tile_kernels
     g = graphgen.make_graph(64, 2048, 8, seed=0)
     idx = [torch.as_tensor(a, device=DEV) for a in (g.ii, g.jj, g.kk)]
     p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
-    assert p.built_on_device and p.jacobian_kernel == "k_tile" and p.tiles == 2048
-    prev = float32_kernels(True)
+    assert not p.built_on_device and p.jacobian_kernel == "k_stream" and p.tiles == 2048
+    prev = wave_per_tile_kernels(False)
     try:
         p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
     finally:
-        float32_kernels(prev)
-    assert not p.built_on_device and p.jacobian_kernel == "k_stream" and p.tiles == 2048
+        wave_per_tile_kernels(prev)
+    assert p.built_on_device and p.jacobian_kernel == "k_tile" and p.tiles == 2048
     g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
     ii, jj, kk = (np.asarray(a).copy() for a in (g.ii, g.jj, g.kk))
     p = Plan(*(torch.as_tensor(a[:2000], device=DEV) for a in (ii, jj, kk)), g.poses.shape[0], g.patches.shape[0], fixedp)
@@ -117,7 +117,13 @@ def test_device_planned_slot_arrays_equal_the_hosts(variant):
     if variant in ("C3_shuffled", "repeats", "large8192_shuffled"):
         p = rng.permutation(ii.size)
         ii, jj, kk = ii[p], jj[p], kk[p]
-    dev, host = both_plans(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], fixedp)
+    from batrack_amd.plan import wave_per_tile_kernels
+    prev = wave_per_tile_kernels(False) if variant.startswith("large") else None      # (the float64 tile layout at every size)
+    try:
+        dev, host = both_plans(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], fixedp)
+    finally:
+        if prev is not None:
+            wave_per_tile_kernels(prev)
     assert dev.built_on_device and not host.built_on_device and dev.jacobian_kernel == host.jacobian_kernel == "k_tile"
     for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
         assert getattr(dev, f) == getattr(host, f), f
@@ -158,8 +164,9 @@ def test_random_edge_lists_plan_alike_on_device_and_host(seed):
     ii, jj, kk = ii[p], jj[p], kk[p]
     fixedp = int(rng.integers(0, max(1, int(max(ii.max(), jj.max())))))
     dev, host = both_plans(ii, jj, kk, n_buf, p_tot, fixedp)
-    # (since round 4 also the graphs of 2048 tiles and more — many cameras per track: a tile per track)
-    assert dev.jacobian_kernel == host.jacobian_kernel and dev.built_on_device
+    # (graphs of 2048 tiles and more — many cameras per track: a tile per track — keep the host's analysis: the tables of the
+    #  wave-per-tile kernels are derived from its slot arrays)
+    assert dev.jacobian_kernel == host.jacobian_kernel and dev.built_on_device == (host.tiles < 2048)
     for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
         assert getattr(dev, f) == getattr(host, f), f
     names = TABLES if dev.jacobian_kernel == "k_etile" else SLOT_TABLES

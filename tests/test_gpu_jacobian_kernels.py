@@ -17,14 +17,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("frames,M,kernel,so,f32", [(16, 16, "k_tile", False, False), (64, 1024, "k_tile", False, False),
-                                                  # since round 4 the float64-per-edge tile kernel whatever the size ...
-                                                  (64, 2048, "k_tile", False, False), (64, 2048, "k_tile", True, False), (64, 6144, "k_tile", False, False),
-                                                  # ... and the float32 wave-per-tile kernels where the caller asks for them
+# gates (state, S and y, dX, update poses, update disparities) by the plan's precision of the per-edge maths: 8 float64, 6 mixed
+# (k_stream / k_edge: float64 reprojection and residual, float32 Jacobians), 4 float32 (BT_EDGE_PREC=0: measurement)
+GATES = {8: (2e-7, 1e-10, 1e-5, 1e-5, 1e-5), 6: (2e-7, 1e-6, 1e-5, 1e-5, 1e-5), 4: (5e-6, 5e-6, 3e-4, 3e-4, 1e-4)}
+
+
+@pytest.mark.parametrize("frames,M,kernel,so,wpt", [(16, 16, "k_tile", False, True), (64, 1024, "k_tile", False, True),
+                                                  # from 2048 tiles the wave-per-tile kernels, mixed precision: inside the 1e-5 bar ...
                                                   (64, 2048, "k_stream", False, True), (64, 2048, "k_stream", True, True),
-                                                  (64, 6144, "k_edge", False, True), (64, 6144, "k_edge", True, True)])
-def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, f32):
-    from batrack_amd.plan import float32_kernels
+                                                  (64, 6144, "k_edge", False, True), (64, 6144, "k_edge", True, True),
+                                                  # ... or, switched off by the caller, the float64 tile kernel at every size
+                                                  (64, 2048, "k_tile", False, False), (64, 2048, "k_tile", True, False), (64, 6144, "k_tile", False, False)])
+def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, wpt):
+    from batrack_amd.plan import wave_per_tile_kernels
     g = graphgen.make_graph(frames, M, 8, seed=5)
     f = lambda a: np.asarray(a, np.float32).astype(np.float64)
     d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics), targets3=f(g.targets3),
@@ -32,17 +37,16 @@ def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, f32):
     wkey = "weights" if so else "weights_pose"
     ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"],
                          d["bounds"], fixedp=1, structure_only=so, want_system=not so)
-    prev = float32_kernels(f32)
+    prev = wave_per_tile_kernels(wpt)
     try:
         o = HipProblem(d).raw_step(wkey, 1, so)
     finally:
-        float32_kernels(prev)
+        wave_per_tile_kernels(prev)
     assert o["plan"].jacobian_kernel == kernel, (o["plan"].jacobian_kernel, o["plan"].tiles)
-    assert o["plan"].edge_precision == (4 if f32 or os.environ.get("BT_EDGE_PREC") == "0" else 8)
+    prec = o["plan"].edge_precision
+    assert prec == (4 if os.environ.get("BT_EDGE_PREC") == "0" and kernel == "k_tile" else 6 if kernel in ("k_stream", "k_edge") else 8)
     act = np.unique(g.kk)
-    # float64 per edge: north_star's 1e-5 on the update; the float32 kernels (k_stream / k_edge): the reference's own precision
-    f64 = o["plan"].edge_precision == 8
-    t_upd_d, t_upd_p, t_state, t_sys, t_dx = (1e-5, 1e-5, 2e-7, 1e-10, 1e-5) if f64 else (1e-4, 3e-4, 5e-6, 5e-6, 3e-4)
+    t_state, t_sys, t_dx, t_upd_p, t_upd_d = GATES[prec]
     assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], act) < t_upd_d
     assert rel(o["patches_out"], ref["patches_out"]) < t_state
     if not so:
@@ -53,22 +57,23 @@ def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, f32):
         assert rel(o["poses_out"], ref["poses_out"]) < t_state
 
 
-def test_the_float32_kernels_setting_is_the_plans_own():
+def test_the_kernel_choice_is_the_plans_own():
     """A plan keeps the layout it was built with: switching the setting afterwards changes neither its kernel nor its tables."""
     import torch
-    from batrack_amd.plan import Plan, float32_kernels
+    from batrack_amd.plan import Plan, wave_per_tile_kernels
     g = graphgen.make_graph(64, 2048, 8, seed=2)
     T = lambda a: torch.as_tensor(a, device="cuda:0")
     ii, jj, kk = T(g.ii), T(g.jj), T(g.kk)
-    assert float32_kernels() is False                                  # the default
-    p64 = Plan(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], 1)
-    prev = float32_kernels(True)
+    assert wave_per_tile_kernels() is True                              # the default
+    pw = Plan(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], 1)
+    prev = wave_per_tile_kernels(False)
     try:
-        p32 = Plan(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], 1)
-        assert (p64.jacobian_kernel, p64.edge_precision) == ("k_tile", 8) and (p32.jacobian_kernel, p32.edge_precision) == ("k_stream", 4)
+        pt = Plan(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], 1)
+        assert (pw.jacobian_kernel, pw.edge_precision) == ("k_stream", 6) and (pt.jacobian_kernel, pt.edge_precision) == ("k_tile", 8)
     finally:
-        float32_kernels(prev)
-    assert (p32.jacobian_kernel, p32.edge_precision) == ("k_stream", 4) and float32_kernels() is False
+        wave_per_tile_kernels(prev)
+    assert (pt.jacobian_kernel, pt.edge_precision) == ("k_tile", 8) and (pw.jacobian_kernel, pw.edge_precision) == ("k_stream", 6)
+    assert wave_per_tile_kernels() is True
 
 
 FORCED = {"k_edge": dict(BT_EDGE_MIN_TILES="1", BT_EDGE_PREF_TILES="1", BT_STREAM_MIN_TILES="1"),      # wherever the tiles are slot-uniform

@@ -24,23 +24,24 @@ pmc() {     # counter, tag, M  (environment of the caller selects the kernels)
 python $R/bench.py --steps 200 --warmup 20 > $OUT/bench_n1.json 2> $OUT/bench_n1.stderr
 trace c3 python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-large
 trace window python $R/tools/gpu_timing.py --workload window
-trace e2m_f64 python $R/tools/gpu_pmc_run.py 4096 6
-trace e8m_f64 python $R/tools/gpu_pmc_run.py 16384 6
-BT_FLOAT32_KERNELS=1 trace e8m_f32 python $R/tools/gpu_pmc_run.py 16384 6
+trace e2m python $R/tools/gpu_pmc_run.py 4096 6
+trace e8m python $R/tools/gpu_pmc_run.py 16384 6
+BT_WPT_KERNELS=0 trace e8m_f64tile python $R/tools/gpu_pmc_run.py 16384 6
 trace ga python $R/tools/gpu_ga_bench.py
-# ---- HBM traffic of the Jacobian kernel: C3 and 8.4M edges in the default (float64) kernels, 8.4M in the opt-in float32 kernel
+# ---- HBM traffic of the Jacobian kernel: C3 (k_tile, float64) and 8.4M edges (k_edge, mixed precision: the default there; and the
+# float64 tile kernel the caller can have instead)
 : > $OUT/pmc_fetch_write.txt
-for C in FETCH_SIZE WRITE_SIZE; do pmc $C c3 256; pmc $C e8m 16384; BT_FLOAT32_KERNELS=1 pmc $C e8mf32 16384; done
+for C in FETCH_SIZE WRITE_SIZE; do pmc $C c3 256; pmc $C e8m 16384; BT_WPT_KERNELS=0 pmc $C e8mf64 16384; done
 python $R/tools/pmc_to_json.py $OUT/pmc_k_tile.json \
     C3:131072:16384:64:/tmp/pmc_FETCH_SIZE_c3.db:/tmp/pmc_WRITE_SIZE_c3.db \
     E8M:8388608:1048576:64:/tmp/pmc_FETCH_SIZE_e8m.db:/tmp/pmc_WRITE_SIZE_e8m.db \
-    E8M_float32_kernels:8388608:1048576:64:/tmp/pmc_FETCH_SIZE_e8mf32.db:/tmp/pmc_WRITE_SIZE_e8mf32.db > $OUT/pmc_to_json.stdout 2>&1
+    E8M_float64_tile_kernels:8388608:1048576:64:/tmp/pmc_FETCH_SIZE_e8mf64.db:/tmp/pmc_WRITE_SIZE_e8mf64.db > $OUT/pmc_to_json.stdout 2>&1
 $R/tools/gpu_pmc_sq.sh 256 $OUT/pmc_sq_c3.txt > /dev/null 2>&1
-$R/tools/gpu_pmc_sq.sh 16384 $OUT/pmc_sq_e8m_f64.txt > /dev/null 2>&1
+$R/tools/gpu_pmc_sq.sh 16384 $OUT/pmc_sq_e8m.txt > /dev/null 2>&1
 cd $R
 # ---- the edge sweep in both precisions (the roofline table of DESIGN.md §6)
-(echo "# default: float64 per edge (k_tile), every size"; python tools/gpu_sweep.py 256 1024 4096 16384 32768;
- echo "# BT_FLOAT32_KERNELS=1: the caller's opt-in float32 wave-per-tile kernels from 2048 tiles"; BT_FLOAT32_KERNELS=1 python tools/gpu_sweep.py 4096 16384 32768) > $OUT/edge_sweep.txt 2>&1
+(echo "# default: k_tile (float64 per edge) below 2048 tiles, k_stream / k_edge (mixed precision) from there: every row inside the 1e-5 bar on the update"; python tools/gpu_sweep.py 256 1024 4096 16384 32768;
+ echo "# BT_WPT_KERNELS=0: the float64 tile kernel at every size"; BT_WPT_KERNELS=0 python tools/gpu_sweep.py 4096 16384 32768) > $OUT/edge_sweep.txt 2>&1
 # ---- solver variants: k_solve_pipe (default) against k_solve_chain, with their in-kernel cycle counters
 (for w in C3 window; do python tools/gpu_timing.py --workload $w; BT_SOLVER_CHAIN=1 python tools/gpu_timing.py --workload $w; done;
  BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver"; BT_SOLVER_CHAIN=1 BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver";
@@ -51,8 +52,8 @@ python tests/sequence_report.py > $OUT/sequence_ate.txt 2>&1
 python tools/gpu_check.py > $OUT/parity_numbers.txt 2>&1
 python tools/gpu_refine_check.py >> $OUT/parity_numbers.txt 2>&1
 python tools/gpu_edge_accuracy.py 64 256 >> $OUT/parity_numbers.txt 2>&1
-(echo "# graphs of 2048 .. 16384 tiles, default (float64 per edge, k_tile)"; python tools/gpu_edge_accuracy.py 64 2048; python tools/gpu_edge_accuracy.py 64 8192;
- echo "# the same with the caller's opt-in float32 kernels (BT_FLOAT32_KERNELS=1)"; BT_FLOAT32_KERNELS=1 python tools/gpu_edge_accuracy.py 64 2048; BT_FLOAT32_KERNELS=1 python tools/gpu_edge_accuracy.py 64 8192) >> $OUT/parity_numbers.txt 2>&1
+(echo "# graphs of 2048 .. 8192 tiles, default (k_stream / k_edge, mixed precision)"; python tools/gpu_edge_accuracy.py 2048 8192;
+ echo "# the same with the float64 tile kernel (BT_WPT_KERNELS=0)"; BT_WPT_KERNELS=0 python tools/gpu_edge_accuracy.py 2048 8192) >> $OUT/parity_numbers.txt 2>&1
 (for w in C3 window; do python tools/gpu_timing.py --workload $w; BT_EDGE_PREC=0 BT_ETILE=0 python tools/gpu_timing.py --workload $w; BT_ETILE=0 python tools/gpu_timing.py --workload $w; done) > $OUT/timing_variants.txt 2>&1
 python tools/gpu_ga_bench.py > $OUT/global_refine_losses.txt 2>&1
 # ---- N > 1 plumbing on the one GPU (ranks share it; gloo rendezvous): not a scaling measurement
