@@ -73,9 +73,14 @@ class RefineLosses:
         self.intrinsics_raw = f(intrinsics)
         self.grid_query_frames = grid_query_frames.to(device=dev, dtype=torch.int64).contiguous()
         q = self.grid_query_frames
-        if q.numel() == 0 or q.unique().numel() != q.numel() or int(q.min()) < 0 or int(q.max()) >= self.T:
-            # (the kernels count a query frame once; `loss[grid_query_frames].mean()` would count a repeated one twice)
-            raise ValueError("grid_query_frames must be distinct frame numbers in [0, T)")
+        if q.numel() == 0 or int(q.min()) < 0 or int(q.max()) >= self.T:
+            raise ValueError("grid_query_frames must be frame numbers in [0, T)")
+        # `loss[grid_query_frames].mean()` (refine_net.py:265,223) counts a frame that is listed twice twice.  The kernels take
+        # lists of DISTINCT frames, so a list with repeats is split into layers — layer k = the frames listed more than k times —
+        # and the query-dependent terms (spatial, inter-frame) are the layers' means weighted by Q_k / Q.  BATRACK.get_results
+        # never produces a repeat (batrack.py:1095); one layer, weight 1, is the usual case.
+        frames, counts = torch.unique(q, return_counts=True)
+        self._query_layers = [(frames[counts > k].contiguous(), float((counts > k).sum()) / q.numel()) for k in range(int(counts.max()))]
         self.trajs_scales, self.frame_scales_, self.frame_shifts_, self.pose = f(trajs_scales), f(frame_scales_), f(frame_shifts_), f(pose)
         self.H, self.W, self.pw_break = int(H), int(W), float(pw_break)
         if tuple(self.trajs_2d.shape) != (self.T, self.N, self.S_local, 2) or tuple(self.jj.shape) != (self.T, self.S_local):
@@ -159,15 +164,16 @@ class RefineLosses:
             return (self.K.detach() * self.K_scale).expand(self.T, 4)
         return self.intrinsics_raw
 
-    def _args(self):
+    def _args(self, layer=0):
         a = _lib.GaArgs()
         a.T, a.N, a.S = self.T, self.N, self.S_local
         a.gh, a.gw = self.frame_scales_.shape[1:]
-        a.H, a.W, a.Q = self.H, self.W, self.grid_query_frames.numel()
+        query = self._query_layers[layer][0]
+        a.H, a.W, a.Q = self.H, self.W, query.numel()
         self._intr.copy_(self.intrinsics)
         for n, t in (("trajs_2d", self.trajs_2d), ("trajs_disp", self.trajs_disp), ("trajs_disp_mono", self.trajs_disp_mono),
                      ("trajs_vis", self.trajs_vis), ("trajs_static", self.trajs_static), ("jj", self.jj), ("intrinsics", self._intr),
-                     ("pose", self.pose), ("query", self.grid_query_frames), ("trajs_scales", self.trajs_scales),
+                     ("pose", self.pose), ("query", query), ("trajs_scales", self.trajs_scales),
                      ("frame_scales", self.frame_scales_), ("frame_shifts", self.frame_shifts_)):
             if not (t.is_cuda and t.is_contiguous()):
                 raise RuntimeError(f"RefineLosses: `{n}` must be a contiguous GPU tensor")
@@ -214,12 +220,20 @@ class RefineLosses:
         need_k = (w[1] or w[2]) and ("K" in want or "intrinsics" in want)
         g_pose = torch.empty(self.T, 7, device=dev, dtype=torch.float32) if need_pose else None
         g_intr = torch.empty(self.T, 4, device=dev, dtype=torch.float32) if need_k else None
-        a = self._args()
-        gw = _lib.GaWeights(*w, _SMOOTH[mode])
         st = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(self._lib.bt_ga_backward_total(ctypes.byref(a), self._mono_scaled.data_ptr(), ctypes.byref(gw), self._g_ms.data_ptr(),
-                                                  g_ts.data_ptr(), g_fs.data_ptr(), g_pose.data_ptr() if need_pose else None,
-                                                  g_intr.data_ptr() if need_k else None, st), "bt_ga_backward_total")
+        for k, (_, frac) in enumerate(self._query_layers):
+            # (a list with repeated frames: the query-dependent terms once per layer at Q_k / Q of their weight, the rest with layer 0)
+            wk = [w[0] * frac, w[1] * frac] + (list(w[2:]) if k == 0 else [0.0, 0.0, 0.0])
+            tgt = (g_ts, g_fs, g_pose, g_intr) if k == 0 else tuple(None if t is None else torch.empty_like(t) for t in (g_ts, g_fs, g_pose, g_intr))
+            a = self._args(k)
+            gw = _lib.GaWeights(*wk, _SMOOTH[mode])
+            _lib.check(self._lib.bt_ga_backward_total(ctypes.byref(a), self._mono_scaled.data_ptr(), ctypes.byref(gw), self._g_ms.data_ptr(),
+                                                      tgt[0].data_ptr(), tgt[1].data_ptr(), tgt[2].data_ptr() if need_pose else None,
+                                                      tgt[3].data_ptr() if need_k else None, st), "bt_ga_backward_total")
+            if k > 0:
+                for acc, t in zip((g_ts, g_fs, g_pose, g_intr), tgt):
+                    if acc is not None:
+                        acc += t
         out = {"trajs_scales": g_ts, "frame_scales_": g_fs}
         out["pose"] = g_pose if need_pose else torch.zeros(self.T, 7, device=dev)
         out["intrinsics"] = g_intr if need_k else torch.zeros(self.T, 4, device=dev)
@@ -234,11 +248,20 @@ class RefineLosses:
 
     # ------------------------------------------------------------------ the terms
     def _run(self, which):
-        a = self._args()
         st = torch.cuda.current_stream(self.trajs_2d.device).cuda_stream
-        _lib.check(self._lib.bt_ga_forward(ctypes.byref(a), self._mono_scaled.data_ptr(), self._losses.data_ptr(), int(which), st),
-                   "bt_ga_forward")
-        return self._losses
+        total = None
+        for k, (_, frac) in enumerate(self._query_layers):
+            a = self._args(k)
+            _lib.check(self._lib.bt_ga_forward(ctypes.byref(a), self._mono_scaled.data_ptr(), self._losses.data_ptr(),
+                                               int(which if k == 0 else which & 3), st), "bt_ga_forward")
+            if len(self._query_layers) == 1:
+                return self._losses
+            if k == 0:
+                total = self._losses.clone()
+                total[:2] *= frac
+            else:
+                total[:2] += frac * self._losses[:2]
+        return total
 
     def get_frame_scaled_depth(self):
         self._run(1)

@@ -239,8 +239,21 @@ def test_float16_depth_residual_backward():
     assert _gerr(g["frame_scales_"].cpu().numpy(), r["grad_frame_scales"]) < 2e-3
 
 
-def test_repeated_query_frames_are_refused():
+def test_repeated_query_frames_count_as_often_as_they_are_listed():
+    """`loss[self.grid_query_frames.long()].mean()` (refine_net.py:223,265) counts a frame that is listed twice twice; the
+    oracle indexes the same way.  Total and every gradient with the full weight set, against the float64 oracle."""
+    from oracle import ga_torch
     d = dict(GD)
-    d["grid_query_frames"] = np.array([0, 2, 2, 7], np.int64)
+    d["grid_query_frames"] = np.array([0, 2, 2, 7, 2, 9, 7], np.int64)
+    w = [RUN_WEIGHTS[k] for k in ("spatial_loss", "inter_frame_loss", "pts_3d_loss", "cam_smooth_vec_loss", "scale_smoothness_loss")]
+    net = build(d, **_settings("A"))
+    r = ga_torch.full_total_and_grads(d, w, "l1", refine_intrinsics=True)
+    assert abs(float(net.forward()) / r["total"] - 1) < 1e-5
+    l = net.losses().cpu().numpy()
+    for i, k in enumerate(("spatial", "rigid", "pts3d", "cam_smooth", "scale_smooth")):
+        assert abs(l[i] / r[k] - 1) < 1e-5, (k, l[i], r[k])
+    g = net.backward()
+    for key, name in (("trajs_scales", "grad_trajs_scales"), ("frame_scales_", "grad_frame_scales"), ("pose", "grad_pose"), ("K", "grad_K")):
+        assert _gerr(g[key].cpu().numpy(), np.asarray(r[name])) < 5e-5, name
     with pytest.raises(ValueError):
-        build(d)
+        build(dict(GD, grid_query_frames=np.array([0, 99], np.int64)))          # out of range is still refused
