@@ -266,9 +266,9 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
         bind_pointers(pl, d);                          // (the fill kernels read the plan's tile tables in the buffer)
         char *db = static_cast<char *>(d);
         if (pl->dev_pm)
-            ok = plan_device_fill(pl, pl->e_all, reinterpret_cast<int32_t *>(db + O.pmr), reinterpret_cast<int32_t *>(db + O.pme), pl->pm_rounds, cs) == BT_OK;
+            ok = plan_device_fill(pl, pl->info.E, reinterpret_cast<int32_t *>(db + O.pmr), reinterpret_cast<int32_t *>(db + O.pme), pl->pm_rounds, cs) == BT_OK;
         else
-            ok = plan_device_slots_fill(pl, pl->e_all, reinterpret_cast<int32_t *>(db + O.se), reinterpret_cast<int32_t *>(db + O.sp),
+            ok = plan_device_slots_fill(pl, pl->info.E, reinterpret_cast<int32_t *>(db + O.se), reinterpret_cast<int32_t *>(db + O.sp),
                                         reinterpret_cast<uint16_t *>(db + O.sl), reinterpret_cast<uint8_t *>(db + O.slp),
                                         reinterpret_cast<uint16_t *>(db + O.tc8), reinterpret_cast<uint16_t *>(db + O.tc16), cs) == BT_OK;
     }
@@ -364,7 +364,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
             return BT_EHIP;
         // window plans: the passes over the edges stay on the device (plan_device.hip), the host lays out what is small
         static const bool dev_planner = !(std::getenv("BT_PLAN_DEVICE") && std::atoi(std::getenv("BT_PLAN_DEVICE")) == 0);
-        if (dev_planner && upload && own_hi <= 0 && E >= 4096) {
+        if (dev_planner && upload && E >= 4096) {
             if (hipMemcpyAsync(pb.h_bad, pb.d_bad, sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess) return BT_EHIP;
             DevPlanStats st{};
             int64_t tracks = 0;
@@ -381,7 +381,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
                     rc = build_plan_host(nullptr, nullptr, nullptr, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, nullptr, false, &st);
                     tick("host analysis (no edges)");
                     int64_t rounds = 0;
-                    if (rc == BT_OK) rc = pl->dev_pm ? plan_device_rounds(pl, E, cs, &rounds) : plan_device_slots_stage(pl, cs);
+                    if (rc == BT_OK) rc = pl->dev_pm ? plan_device_rounds(pl, pl->info.E, cs, &rounds) : plan_device_slots_stage(pl, cs);
                     tick("device: rounds");
                     if (rc == BT_OK) { pl->pm_rounds = rounds; rc = upload_plan(pl, pb.d_words); }
                 } catch (const std::bad_alloc &) {
@@ -508,6 +508,11 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
         for (size_t i = 0; i < pl->trk_win.size(); ++i) pl->trk_of_patch[(size_t)pl->trk_win_lo + i] = pl->trk_win[i];
         *data = pl->trk_of_patch.data();
         return (int64_t)pl->trk_of_patch.size();
+    }
+    if (std::strcmp(name, "trk_off") == 0) {                  // sharded: distinct tracks in front of the rank's range (one element)
+        pl->dev_readback.assign(1, (int32_t)pl->trk_off);
+        *data = pl->dev_readback.data();
+        return 1;
     }
     if (pl->dev_slots && pl->dev_base) {
         // a 64-track plan whose slot arrays and wave cuts were written on the device: read back on request (tests, tooling)

@@ -117,7 +117,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     static thread_local std::vector<uint64_t> pk_scratch;
     const uint64_t *pk = packed;
     pl->dev_pm = 0; pl->dev_slots = 0;
-    if (dstats && (keep_slots || own_lo != 0 || own_hi != p_tot || E <= 0)) return BT_NEED_EDGES;
+    if (dstats && (keep_slots || E <= 0)) return BT_NEED_EDGES;
     if (!pk && !dstats) {
         pk_scratch.resize((size_t)E + 1);
         const int rc = pack_edges_host(ii64, jj64, kk64, E, n_buf, p_tot, pk_scratch.data());
@@ -147,12 +147,19 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     if (dstats) {
         // the same figures from the device's table (bit b of a mask: target frame src - 32 + b)
         n_all = std::max(n_all, dstats->n_all); f_lo = dstats->f_lo; kmin = dstats->kmin; kmax = dstats->kmax;
-        any_self = dstats->any_self != 0; sorted = false; E_own = E;
+        any_self = dstats->any_self != 0; sorted = false;
+        // a sharded plan lays out the tracks of [own_lo, own_hi) only: the device's sort keeps a patch's edges together in
+        // patch order, so the rank's edges are ONE segment of the sorted list — it starts behind the edges of the patches in
+        // front of the range (dev_q0).  The other ranks' tracks keep their (source frame, mask) for the pattern of S below.
+        pl->dev_q0 = 0;
         for (int64_t k = kmin; k <= kmax; ++k) {
             const PatchStat &d = dstats->tab[(size_t)(k - kmin)];
             PerPatch &t = pp[k];
-            t.cnt = d.cnt; t.src = d.src; t.base = d.src - 32; t.last_j = 0; t.mask = d.mask;
+            t.src = d.src; t.base = d.src - 32; t.last_j = 0; t.mask = d.mask;
+            if (k >= own_lo && k < own_hi) { t.cnt = d.cnt; E_own += d.cnt; }
+            else { t.cnt = 0; if (k < own_lo) pl->dev_q0 += d.cnt; }
         }
+        if (E_own == 0) return BT_NEED_EDGES;                  // (a rank without tracks: nothing for the device passes to lay out)
     } else
     for (int64_t e = 0; e < E; ++e) {
         const int64_t k = KK(e), i = II(e), j = JJ(e);
@@ -176,7 +183,9 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // sharded plan: the number of distinct tracks in front of this rank's range — a per-track lmbda tensor (ba.py:299-300) is
     // indexed by the GLOBAL track number, the kernels count from the rank's first track
     pl->trk_off = 0;
-    if (E_own != E && own_lo > 0) {
+    if (dstats) {
+        for (int64_t k = kmin; k < std::min(own_lo, kmax + 1); ++k) pl->trk_off += dstats->tab[(size_t)(k - kmin)].cnt > 0 ? 1 : 0;
+    } else if (E_own != E && own_lo > 0) {
         std::vector<uint8_t> seen((size_t)own_lo, 0);
         for (int64_t e = 0; e < E; ++e) { const int64_t k = KK(e); if (k < own_lo && !seen[(size_t)k]) { seen[(size_t)k] = 1; ++pl->trk_off; } }
     }
@@ -554,7 +563,25 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         const int64_t a = pl->pair_i[p] - fixedp, b = pl->pair_j[p] - fixedp;
         if (a >= 0 && b >= 0) nz[(size_t)std::max(a, b)][(size_t)std::min(a, b)] = 1;
     }
-    if (E_own != E) {
+    if (E_own != E && dstats) {
+        // (the same from the device's table: a track's cameras are its source frame and the frames of its mask)
+        std::vector<int32_t> cset;
+        for (int64_t p = kmin; p <= kmax; ++p) {
+            if (p >= own_lo && p < own_hi) continue;
+            const PatchStat &d = dstats->tab[(size_t)(p - kmin)];
+            if (d.cnt <= 0) continue;
+            cset.clear();
+            if (d.src >= fixedp) cset.push_back((int32_t)(d.src - fixedp));
+            for (uint64_t mk = d.mask; mk; mk &= mk - 1) {
+                const int64_t c = (int64_t)d.src - 32 + __builtin_ctzll(mk) - fixedp;
+                if (c >= 0) cset.push_back((int32_t)c);
+            }
+            std::sort(cset.begin(), cset.end());
+            cset.erase(std::unique(cset.begin(), cset.end()), cset.end());
+            for (size_t u = 0; u < cset.size(); ++u)
+                for (size_t v = 0; v <= u; ++v) nz[(size_t)cset[u]][(size_t)cset[v]] = 1;
+        }
+    } else if (E_own != E) {
         // sharded: tracks owned by other ranks contribute blocks to the all-reduced system too.
         // Their pattern: every camera pair of an edge, and all pairs among the free cameras of a track.
         std::vector<int32_t> toff((size_t)p_tot + 1, 0);

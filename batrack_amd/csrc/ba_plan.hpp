@@ -136,6 +136,7 @@ struct bt_plan {
     mutable std::vector<int32_t> dev_readback;                // bt_plan_array(pm_edge / pm_rec) of such a plan
     std::vector<int32_t> dev_pair_of;                         // [nw * nw]: pair index of (i - f_lo, j - f_lo) or -1
     int64_t dev_f_lo = 0, dev_nw = 0;
+    int64_t dev_q0 = 0;                                       // sharded: position of the rank's first edge in the device's sorted list
     long long pm_rounds = 0;
     long long em_its = 0;
     int max_tile_pairs = 0, max_tile_slots = 0;

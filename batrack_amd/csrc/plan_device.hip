@@ -342,7 +342,7 @@ int plan_device_rounds(const bt_plan *pl, int64_t E, void *stream, int64_t *roun
     std::fill(h + nwin + m + npo + 4 * T, h + n_small, 0);
     if (hipMemcpyAsync(b.small, h, n_small * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess) return BT_EHIP;
     PlanFillArgs a{};
-    a.keys = b.keys; a.vals = b.vals; a.words = b.words; a.jbits = b.jbits; a.E = E;
+    a.keys = b.keys + pl->dev_q0; a.vals = b.vals + pl->dev_q0; a.words = b.words; a.jbits = b.jbits; a.E = E;
     a.trk_win = b.small; a.trk_loc = b.small + nwin;
     a.pair_of = b.small + nwin + m; a.f_lo = (int)pl->dev_f_lo; a.nw = (int)pl->dev_nw;
     a.rec = b.small + nwin + m + npo; a.dmax = a.rec + 4 * T; a.out = a.dmax + T; a.dcode = b.dcode;
@@ -360,7 +360,7 @@ int plan_device_fill(const bt_plan *pl, int64_t E, int32_t *d_rec, int32_t *d_pm
     DevPlanBuffers &b = bufs();
     const size_t T = (size_t)pl->info.tiles, nwin = pl->trk_win.size(), m = pl->trk_loc.size(), npo = pl->dev_pair_of.size();
     PlanFillArgs a{};
-    a.keys = b.keys; a.vals = b.vals; a.words = b.words; a.jbits = b.jbits; a.E = E;
+    a.keys = b.keys + pl->dev_q0; a.vals = b.vals + pl->dev_q0; a.words = b.words; a.jbits = b.jbits; a.E = E;
     a.trk_win = b.small; a.trk_loc = b.small + nwin;
     a.pair_of = b.small + nwin + m; a.f_lo = (int)pl->dev_f_lo; a.nw = (int)pl->dev_nw;
     a.tile_pair0 = pl->dev.tile_pair0; a.tile_npair = pl->dev.tile_npair; a.tile_pairs = pl->dev.tile_pairs;
@@ -407,7 +407,7 @@ int plan_device_slots_fill(const bt_plan *pl, int64_t E, int32_t *d_slot_edge, i
     DevPlanBuffers &b = bufs();
     const size_t nwin = pl->trk_win.size(), m = pl->trk_loc.size(), npo = pl->dev_pair_of.size(), n = (size_t)pl->info.slots * kLanes;
     PlanSlotArgs a{};
-    a.keys = b.keys; a.vals = b.vals; a.words = b.words; a.jbits = b.jbits; a.E = E;
+    a.keys = b.keys + pl->dev_q0; a.vals = b.vals + pl->dev_q0; a.words = b.words; a.jbits = b.jbits; a.E = E;
     a.trk_win = b.small; a.trk_loc = b.small + nwin; a.pair_of = b.small + nwin + m; a.off = b.small + nwin + m + npo;
     a.f_lo = (int)pl->dev_f_lo; a.nw = (int)pl->dev_nw; a.fixedp = (int)pl->info.fixedp;
     const PlanDev &P = pl->dev;

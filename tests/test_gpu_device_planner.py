@@ -173,3 +173,40 @@ def test_random_edge_lists_plan_alike_on_device_and_host(seed):
     for name in names:
         a, b = dev.array(name), host.array(name)
         assert a.shape == b.shape and (a == b).all(), (name, dev.jacobian_kernel)
+
+
+@pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
+@pytest.mark.parametrize("graph", ["window", "window_shuffled", "C3", "random"])
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_plans_are_laid_out_on_the_device_too(graph, world):
+    """A rank's plan of a sharded solve (own = its range of the patch buffer, parallel.py: plan_range): the device's sort keeps
+    the rank's edges in one segment of the sorted list, the passes run on that segment, and the pattern of the all-reduced system
+    comes from the other ranks' (source frame, target mask) — every table equals the host's analysis of the same list and range."""
+    from batrack_amd.parallel import partition_tracks, plan_range
+    rng = np.random.default_rng(17)
+    if graph.startswith("window"):
+        g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
+    elif graph == "C3":
+        g, fixedp = graphgen.make_config("C3", seed=0), 1
+    else:
+        g, fixedp = graphgen.make_graph(24, 512, 7, seed=8), 2
+    ii, jj, kk = (np.asarray(a) for a in (g.ii, g.jj, g.kk))
+    if graph in ("window_shuffled", "random"):
+        p = rng.permutation(ii.size)
+        ii, jj, kk = ii[p], jj[p], kk[p]
+    n_buf, p_tot = g.poses.shape[0], g.patches.shape[0]
+    ranges = partition_tracks(kk, world)
+    built = 0
+    for r in range(world):
+        own = plan_range(ranges[r], p_tot)
+        dev = Plan(*(torch.as_tensor(a, device=DEV) for a in (ii, jj, kk)), n_buf, p_tot, fixedp, own=own)
+        host = Plan(ii, jj, kk, n_buf, p_tot, fixedp, own=own)
+        assert not host.built_on_device and dev.jacobian_kernel == host.jacobian_kernel
+        built += int(dev.built_on_device)
+        for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
+            assert getattr(dev, f) == getattr(host, f), (f, r)
+        names = (TABLES if dev.jacobian_kernel == "k_etile" else SLOT_TABLES) + ("trk_off",)
+        for name in names:
+            a, b = dev.array(name), host.array(name)
+            assert a.shape == b.shape and (a == b).all(), (name, r, dev.jacobian_kernel)
+    assert built == world                       # (every rank of these lists holds 4096 edges or more in total and has tracks)

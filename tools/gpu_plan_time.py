@@ -31,6 +31,22 @@ for name, args, kw in (("host arrays, no upload", (g.ii, g.jj, g.kk), dict(uploa
         pl.close()
     print(f"{name:26s}: first {ts[0]:.2f} ms, then median {np.median(ts[1:]):.2f} ms")
 
+if len(sys.argv) > 1 and sys.argv[1] in ("window", "large"):
+    # a rank's plan of a sharded solve (world 8, rank 3): the device's passes run on the rank's segment of the sorted list
+    from batrack_amd.parallel import partition_tracks, plan_range
+    own = plan_range(partition_tracks(g.kk, 8)[3], p_tot)
+    for name, args in (("sharded 3/8, host arrays", (g.ii, g.jj, g.kk)), ("sharded 3/8, device tensors", (ii, jj, kk))):
+        ts = []
+        for _ in range(8):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pl = Plan(*args, n_buf, p_tot, fixedp, own=own)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            note = f"  ({pl.jacobian_kernel}, {pl.tiles} tiles, built on device: {bool(pl.built_on_device)})"
+            pl.close()
+        print(f"{name:26s}: first {ts[0]:.2f} ms, then median {np.median(ts[1:]):.2f} ms" + note)
+
 from batrack_amd.plan import Stepper
 ts = []
 for _ in range(6):
