@@ -249,6 +249,10 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
         const size_t ns = (size_t)pl->info.slots * kLanes;
         auto take = [&](size_t bytes) { const size_t o = (tables_end + 255) / 256 * 256; tables_end = o + bytes; return o; };
         O.se = take(ns * sizeof(int32_t)); O.sp = take(ns * sizeof(int32_t)); O.sl = take(ns * sizeof(uint16_t)); O.slp = take(ns);
+        if (pl->dev_wpt) {                                 // ... and the tables of the wave-per-tile kernels
+            O.sc = take(ns * sizeof(uint16_t)); O.tla = take((size_t)pl->info.tiles * kLanes);
+            if (pl->em_ok) { O.ite = take((size_t)pl->em_its * kLanes * sizeof(int32_t)); O.tsi = take((size_t)pl->info.tiles * kLanes * sizeof(uint32_t)); }
+        }
     }
     const size_t pk_off = (tables_end + 255) / 256 * 256, total = keep_pk ? pk_off + (size_t)pl->e_all * sizeof(uint64_t) : tables_end;
     void *d = dev_pool().acquire(total + 256, &cap, &reuse_after);
@@ -267,12 +271,20 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
         char *db = static_cast<char *>(d);
         if (pl->dev_pm)
             ok = plan_device_fill(pl, pl->info.E, reinterpret_cast<int32_t *>(db + O.pmr), reinterpret_cast<int32_t *>(db + O.pme), pl->pm_rounds, cs) == BT_OK;
-        else
+        else {
+            DevWptOut w{};
+            if (pl->dev_wpt) {
+                w.slot_code = reinterpret_cast<uint16_t *>(db + O.sc); w.tile_la = reinterpret_cast<uint8_t *>(db + O.tla); w.tile_rec = reinterpret_cast<int32_t *>(db + O.trec);
+                if (pl->em_ok) { w.it_edge = reinterpret_cast<int32_t *>(db + O.ite); w.tile_sinfo = reinterpret_cast<uint32_t *>(db + O.tsi); w.its = pl->em_its; }
+            }
             ok = plan_device_slots_fill(pl, pl->info.E, reinterpret_cast<int32_t *>(db + O.se), reinterpret_cast<int32_t *>(db + O.sp),
                                         reinterpret_cast<uint16_t *>(db + O.sl), reinterpret_cast<uint8_t *>(db + O.slp),
-                                        reinterpret_cast<uint16_t *>(db + O.tc8), reinterpret_cast<uint16_t *>(db + O.tc16), cs) == BT_OK;
+                                        reinterpret_cast<uint16_t *>(db + O.tc8), reinterpret_cast<uint16_t *>(db + O.tc16), cs, pl->dev_wpt ? &w : nullptr) == BT_OK;
+        }
     }
     if (!ok || hipStreamSynchronize(cs) != hipSuccess) { dev_pool().release(d, cap, false, nullptr); return BT_EHIP; }
+    // (k_plan_sinfo's verdict: a tile whose tracks do not share their slots' pairs leaves the plan with k_stream)
+    if (pl->dev_slots && pl->dev_wpt && pl->em_ok && plan_device_em_verdict()) { pl->em_ok = 0; pl->em_its = 0; pl->em_lgs = -1; }
     tick("H2D copy");
     pl->dev_base = d;
     pl->dev_cap = cap;
@@ -451,7 +463,7 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
     pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
     pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
     pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->st_ok = src->st_ok; pl->st_min = src->st_min; pl->em_min = src->em_min; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
-    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->dev_slots = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
+    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->dev_slots = 0; pl->dev_wpt = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
     void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);
@@ -524,6 +536,11 @@ int64_t bt_plan_array(const bt_plan *pl, const char *name, const void **data) {
         else if (std::strcmp(name, "slot_lp") == 0) { off = pl->off.slp; bytes = ns; esz = 1; }
         else if (std::strcmp(name, "tile_cut8") == 0) { off = pl->off.tc8; bytes = T * 9 * 2; esz = 2; }
         else if (std::strcmp(name, "tile_cut16") == 0) { off = pl->off.tc16; bytes = T * 17 * 2; esz = 2; }
+        else if (pl->dev_wpt && std::strcmp(name, "slot_code") == 0) { off = pl->off.sc; bytes = ns * 2; esz = 2; }
+        else if (pl->dev_wpt && std::strcmp(name, "tile_la") == 0) { off = pl->off.tla; bytes = T * kLanes; esz = 1; }
+        else if (pl->dev_wpt && std::strcmp(name, "tile_rec") == 0) { off = pl->off.trec; bytes = T * 8 * 4; }
+        else if (pl->dev_wpt && pl->em_ok && std::strcmp(name, "it_edge") == 0) { off = pl->off.ite; bytes = (size_t)pl->em_its * kLanes * 4; }
+        else if (pl->dev_wpt && pl->em_ok && std::strcmp(name, "tile_sinfo") == 0) { off = pl->off.tsi; bytes = T * kLanes * 4; }
         if (bytes) {
             std::vector<int32_t> &v = pl->dev_readback;
             v.assign((bytes + 3) / 4, 0);

@@ -116,7 +116,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     BT_TICK("0");
     static thread_local std::vector<uint64_t> pk_scratch;
     const uint64_t *pk = packed;
-    pl->dev_pm = 0; pl->dev_slots = 0;
+    pl->dev_pm = 0; pl->dev_slots = 0; pl->dev_wpt = 0;
     if (dstats && (keep_slots || E <= 0)) return BT_NEED_EDGES;
     if (!pk && !dstats) {
         pk_scratch.resize((size_t)E + 1);
@@ -206,7 +206,9 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     pl->kx.clear();
     pl->trk_win_lo = kmin <= kmax ? kmin : 0;
     pl->trk_win.assign(kmin <= kmax ? (size_t)(kmax - kmin + 1) : 0, -1);
-    std::vector<int32_t> off(1, 0);
+    static thread_local std::vector<int32_t> off_scratch;        // (a million tracks: no fresh pages per plan)
+    std::vector<int32_t> &off = off_scratch;
+    off.assign(1, 0);
     for (int64_t p = kmin; p <= kmax; ++p) {
         const int32_t c = pp[p].cnt;
         if (c > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + c); pl->trk_win[(size_t)(p - kmin)] = m++; }
@@ -221,8 +223,12 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     std::vector<int32_t> pair_of((size_t)(nw * nw), -1);
     if (masks_ok) {
         // from the tracks' (source frame, target mask): a few thousand tracks instead of every edge
+        // (neighbouring tracks mostly share their source frame and targets — the tracks of one frame: such a track adds nothing)
+        int32_t src_b = -1, base_b = 0; uint64_t mask_b = 0;
         for (int32_t k = 0; k < m; ++k) {
             const PerPatch &t = pp[pl->kx[(size_t)k]];
+            if (t.src == src_b && t.base == base_b && t.mask == mask_b) continue;
+            src_b = t.src; base_b = t.base; mask_b = t.mask;
             int32_t *row = pair_of.data() + (size_t)(t.src - f_lo) * nw - f_lo;
             for (uint64_t mk = t.mask; mk; mk &= mk - 1) row[t.base + __builtin_ctzll(mk)] = 0;
         }
@@ -251,8 +257,9 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     static thread_local std::vector<uint64_t> pks_scratch;
     std::vector<int32_t> &ord = ord_scratch, &byj = byj_scratch;
     std::vector<uint64_t> &pks = pks_scratch;
-    ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1); pks.resize((size_t)E_own + 1);
-    std::vector<int32_t> cur(off.begin(), off.end() - 1);
+    if (!dstats) { ord.resize((size_t)E_own + 1); byj.resize((size_t)E_own + 1); pks.resize((size_t)E_own + 1); }
+    std::vector<int32_t> cur;
+    if (!dstats) cur.assign(off.begin(), off.end() - 1);
     if (dstats) {
         // (no edge is read: the order of a track's edges is the device's sort)
     } else if (mono_j) {
@@ -326,11 +333,17 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         static const int pm_env2 = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;
         if (pm_env2 == 2) return BT_NEED_EDGES;                    // (pair-major tables of 64-track tiles are made from the host's slot arrays)
     }
+    int32_t src_p = -1, base_p = 0, set_epoch = -1; uint64_t mask_p = 0;         // the previous track's figures: the same again = the same cameras
     for (int32_t k = 0; k < m; ++k) {
+        if (masks_ok && k > 0 && pp[pl->kx[(size_t)k]].src == src_p && pp[pl->kx[(size_t)k]].base == base_p && pp[pl->kx[(size_t)k]].mask == mask_p) {
+            // (trk_set is the previous track's and still right; in the tile it went into, it adds nothing)
+            if (set_epoch == epoch && k - trk0 < tcap) continue;
+        } else {
         trk_set.clear();
         if (masks_ok) {
             // the track's free cameras from its source frame and target mask (no walk over its edges)
             const PerPatch &t = pp[pl->kx[(size_t)k]];
+            src_p = t.src; base_p = t.base; mask_p = t.mask;
             const int64_t cs = (int64_t)t.src - fixedp;
             if (cs >= 0) { tstamp[(size_t)cs] = k; trk_set.push_back((int32_t)cs); }
             for (uint64_t mk = t.mask; mk; mk &= mk - 1) {
@@ -344,18 +357,19 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                     if (c >= 0 && tstamp[(size_t)c] != k) { tstamp[(size_t)c] = k; trk_set.push_back((int32_t)c); }
             }
         }
+        }
         if ((int)trk_set.size() > kTileCamHard) return BT_EUNSUPPORTED;
         int add = 0;
         for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) ++add;
         const int limit = std::max<int>(kTileCamSoft, (int)trk_set.size());
         if (k - trk0 >= tcap || (k > trk0 && (int)tile_set.size() + add > limit)) close_tile(k);
         for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) { stamp[(size_t)c] = epoch; tile_set.push_back(c); }
+        set_epoch = epoch;
     }
     close_tile(m);
     const int32_t T = (int32_t)pl->tile_trk0.size();
     I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
     pl->max_rows16 = (int)((6 * max_cams + 15) / 16 * 16);
-    if (dstats && tcap == kLanes && T >= std::min(edge_min_tiles(), stream_min_tiles())) return BT_NEED_EDGES;   // (k_stream / k_edge tables come from the host's slot arrays)
     if (tcap < kLanes && T >= std::min(std::min(edge_min_tiles(), stream_min_tiles()), 1024)) {
         // the camera limit closed 16-track tiles early: the plan reached the tile count of the wave-per-tile kernels, whose
         // tables come from the [slots][64] arrays a small-tile plan does not have — or simply four times the CUs, where
@@ -410,8 +424,11 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             for (int32_t c = 0; c < nc; ++c) local[(size_t)pl->tile_cams[(size_t)(c0 + c)]] = c;
             mine.clear();
             if (masks_ok) {
+                int32_t src_b = -1, base_b = 0; uint64_t mask_b = 0;
                 for (int32_t l = 0; l < nt; ++l) {
                     const PerPatch &tp = pp[pl->kx[(size_t)(t0 + l)]];
+                    if (tp.src == src_b && tp.base == base_b && tp.mask == mask_b) continue;       // (the same pairs as the track before)
+                    src_b = tp.src; base_b = tp.base; mask_b = tp.mask;
                     const int32_t *row = pair_of.data() + (size_t)(tp.src - f_lo) * nw - f_lo;
                     for (uint64_t mk = tp.mask; mk; mk &= mk - 1) {
                         const int32_t gp = row[tp.base + __builtin_ctzll(mk)];
@@ -566,10 +583,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     if (E_own != E && dstats) {
         // (the same from the device's table: a track's cameras are its source frame and the frames of its mask)
         std::vector<int32_t> cset;
+        int32_t src_b = -1; uint64_t mask_b = 0;
         for (int64_t p = kmin; p <= kmax; ++p) {
             if (p >= own_lo && p < own_hi) continue;
             const PatchStat &d = dstats->tab[(size_t)(p - kmin)];
             if (d.cnt <= 0) continue;
+            if (d.src == src_b && d.mask == mask_b) continue;          // (the same cameras as the track before: nothing new)
+            src_b = d.src; mask_b = d.mask;
             cset.clear();
             if (d.src >= fixedp) cset.push_back((int32_t)(d.src - fixedp));
             for (uint64_t mk = d.mask; mk; mk &= mk - 1) {
@@ -962,8 +982,22 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // lane) the local source camera (one per track: ii = ix[kk], checked above); per tile one 32-byte record
     //   [0] ntrk | ncam << 8 | npair << 16 | flags << 24   [1] slot0  [2] nslot  [3] cam0  [4] pair0  [5] trk0
     const bool want_stream_tables = want_slots && I.tiles >= std::min(edge_min_tiles(), stream_min_tiles());   // (they are made from the slot arrays)
-    pl->st_ok = want_stream_tables ? 1 : 0;
+    const bool dev_wpt = dev_slots && I.tiles >= std::min(edge_min_tiles(), stream_min_tiles());               // (... where those are: on the device)
+    pl->st_ok = want_stream_tables || dev_wpt ? 1 : 0;
     pl->st_min = stream_min_tiles(); pl->em_min = edge_min_tiles();
+    pl->dev_wpt = dev_wpt ? 1 : 0;
+    if (dev_wpt) {
+        // the records but for the straddle flag (k_plan_slots adds it); slot_code, tile_la, it_edge and tile_sinfo are written
+        // by the device's passes into the plan's buffer (plan_device.hip)
+        pl->slot_code.clear(); pl->tile_la.clear(); pl->it_edge.clear(); pl->tile_sinfo.clear();
+        pl->tile_rec.assign((size_t)I.tiles * 8, 0);
+        for (int64_t t = 0; t < I.tiles; ++t) {
+            int32_t *r = pl->tile_rec.data() + (size_t)t * 8;
+            r[0] = pl->tile_ntrk[(size_t)t] | (pl->tile_ncam[(size_t)t] << 8) | (pl->tile_npair[(size_t)t] << 16) | (pl->tile_flags[(size_t)t] << 24);
+            r[1] = pl->tile_slot0[(size_t)t]; r[2] = pl->tile_nslot[(size_t)t]; r[3] = pl->tile_cam0[(size_t)t];
+            r[4] = pl->tile_pair0[(size_t)t]; r[5] = pl->tile_trk0[(size_t)t];
+        }
+    }
     if (want_stream_tables) {
         pl->slot_code.assign((size_t)slots * kLanes, 0xffff);
         pl->tile_la.assign((size_t)I.tiles * kLanes, 0xff);
@@ -1006,6 +1040,25 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     //                                    repeat: this slot or a neighbour holds the same pair again (repeated observation)
     //   tile_rec[6] = it0, tile_rec[7] = log2 S | iterations << 8
     pl->em_ok = 0; pl->em_its = 0; pl->em_lgs = -1;
+    if (dev_wpt && I.tiles >= edge_min_tiles()) {
+        // (the iteration counts follow from the tiles' slot and track counts; whether every tile is slot-uniform is k_plan_sinfo's
+        //  verdict, read back by upload_plan: em_ok here is "as far as the host can tell")
+        pl->em_ok = 1;
+        int64_t its = 0;
+        for (int64_t t = 0; t < I.tiles; ++t) {
+            const int32_t ns = pl->tile_nslot[(size_t)t], nt = pl->tile_ntrk[(size_t)t];
+            int lg = 0;
+            while ((1 << lg) < ns) ++lg;
+            if (lg > 6) { pl->em_ok = 0; break; }
+            const int32_t G = kLanes >> lg;
+            pl->tile_rec[(size_t)t * 8 + 6] = (int32_t)its;
+            pl->tile_rec[(size_t)t * 8 + 7] = lg | (((nt + G - 1) / G) << 8);
+            its += (nt + G - 1) / G;
+            if (t == 0) pl->em_lgs = lg; else if (pl->em_lgs != lg) pl->em_lgs = -1;
+        }
+        if (!pl->em_ok) { for (int64_t t = 0; t < I.tiles; ++t) pl->tile_rec[(size_t)t * 8 + 6] = pl->tile_rec[(size_t)t * 8 + 7] = 0; pl->em_lgs = -1; }
+        pl->em_its = pl->em_ok ? its : 0;
+    }
     if (want_stream_tables && I.tiles >= edge_min_tiles()) {
         pl->em_ok = 1;
         int64_t its = 0;

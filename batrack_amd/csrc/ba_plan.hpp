@@ -132,6 +132,7 @@ struct bt_plan {
     // plans whose pm_edge is written on the device (plan_device.hip): the table's rounds, and what the kernels need of the host's analysis
     int dev_pm = 0;
     int dev_slots = 0;                                        // likewise the [slots][64] arrays and the wave cuts of a 64-track layout
+    int dev_wpt = 0;                                          // ... and with them the tables of the wave-per-tile kernels (slot_code, tile_la, it_edge, tile_sinfo)
     std::vector<int32_t> dev_off;                             // [m + 1]: first position of every track's edges in the grouped order
     mutable std::vector<int32_t> dev_readback;                // bt_plan_array(pm_edge / pm_rec) of such a plan
     std::vector<int32_t> dev_pair_of;                         // [nw * nw]: pair index of (i - f_lo, j - f_lo) or -1
@@ -215,8 +216,13 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
 int plan_device_rounds(const bt_plan *pl, int64_t E, void *stream, int64_t *rounds);
 int plan_device_fill(const bt_plan *pl, int64_t E, int32_t *d_rec, int32_t *d_pm_edge, int64_t rounds, void *stream);
 int plan_device_slots_stage(const bt_plan *pl, void *stream);
+// the tables of the wave-per-tile kernels, written by the same passes (device pointers into the plan's buffer; tile_rec is the
+// host's upload, the passes add the straddle flag; it_edge / tile_sinfo null: the layout of k_edge does not apply)
+struct DevWptOut { uint16_t *slot_code; uint8_t *tile_la; int32_t *tile_rec; int32_t *it_edge; uint32_t *tile_sinfo; int64_t its; };
 int plan_device_slots_fill(const bt_plan *pl, int64_t E, int32_t *d_slot_edge, int32_t *d_slot_pair, uint16_t *d_slot_lab, uint8_t *d_slot_lp,
-                           uint16_t *d_cut8, uint16_t *d_cut16, void *stream);
+                           uint16_t *d_cut8, uint16_t *d_cut16, void *stream, const DevWptOut *wpt = nullptr);
+// after the stream of plan_device_slots_fill has been waited for: 1 = some tile is not slot-uniform (no k_edge for this plan)
+int plan_device_em_verdict();
 // Copies the arrays to the device and fills plan->dev (ba_api.cpp).
 int upload_plan(bt_plan *plan);
 }  // namespace bt

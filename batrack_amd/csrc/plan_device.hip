@@ -14,9 +14,11 @@
 //   k_plan_prefix   first round of every tile, the records' final words, the table's size
 //   k_plan_fill     writes pm_edge into the uploaded plan
 // The host keeps what is small: tracks, pairs, tiles, the reduced system's symbolic factorisation (ba_plan.cpp reads the
-// per-patch table instead of the edges).  64-track layouts: k_plan_slots / k_plan_cuts instead of the last three.  Anything that
-// does not fit — a track whose target frames are not within 32 of its source frame, two source frames for one track, graphs of
-// the wave-per-tile kernels, sharded plans — falls back to the analysis on the edges.
+// per-patch table instead of the edges).  64-track layouts: k_plan_slots / k_plan_cuts instead of the last three — and, for the
+// graphs of the wave-per-tile kernels (2048 tiles and more), k_plan_slots writes their compact tables as well and k_plan_sinfo
+// decides whether the edge-major layout of k_edge applies (every tile slot-uniform).  A sharded plan runs the passes on the
+// rank's segment of the sorted list.  Anything that does not fit — a track whose target frames are not within 32 of its source
+// frame, two source frames for one track — falls back to the analysis on the edges.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -172,6 +174,9 @@ struct PlanSlotArgs {
     int *slot_edge, *slot_pair; unsigned short *slot_lab; unsigned char *slot_lp;
     unsigned char *crossed;                 // [slots + 1], by global slot: some track's run of one target camera spans slots s - 1 and s
     unsigned short *cut8, *cut16; int T;
+    // tables of the wave-per-tile kernels (ba_plan.cpp: slot_code, tile_la, tile_rec, it_edge, tile_sinfo), null: not wanted
+    unsigned short *slot_code; unsigned char *tile_la; int *tile_rec; int *it_edge; unsigned *tile_sinfo; int *em_bad;
+    const int *tile_ntrk;
 };
 
 __device__ __forceinline__ int local_cam(const int *cams, int nc, int c) {      // position of free camera c in the tile's ascending list, 0xff: fixed
@@ -200,7 +205,45 @@ __global__ __launch_bounds__(256) void k_plan_slots(PlanSlotArgs a) {
     const size_t idx = ((size_t)a.tile_slot0[t] + (size_t)s) * 64 + (size_t)l;
     a.slot_edge[idx] = e; a.slot_pair[idx] = gp; a.slot_lab[idx] = (unsigned short)(la | (lb << 8)); a.slot_lp[idx] = (unsigned char)lo;
     // the previous edge of the track has the same target frame (its key is the same): a run that continues into this slot
-    if (s > 0 && lb != 0xff && a.keys[q - 1] == key) a.crossed[a.tile_slot0[t] + s] = 1;
+    const bool run = s > 0 && lb != 0xff && a.keys[q - 1] == key;
+    if (run) a.crossed[a.tile_slot0[t] + s] = 1;
+    if (a.slot_code) {
+        a.slot_code[idx] = (unsigned short)(lb | (lo << 8));
+        if (s == 0) a.tile_la[(size_t)t * 64 + (size_t)l] = (unsigned char)la;
+        // (flag bit 2 of the tile's record: a run spans the boundary of the two half-chunks of slots of k_stream's two waves)
+        const int ns = a.tile_nslot[t], ch = (ns + 1) >> 1;
+        if (run && s == ch && ch < ns) atomicOr(&a.tile_rec[(size_t)t * 8], 4 << 24);
+        if (a.it_edge) {
+            const int it0 = a.tile_rec[(size_t)t * 8 + 6], lg = a.tile_rec[(size_t)t * 8 + 7] & 0xff, G = 64 >> lg;
+            a.it_edge[((size_t)it0 + (size_t)(l / G)) * 64 + (size_t)((l % G) << lg) + (size_t)s] = e;
+        }
+    }
+}
+
+// one wave per tile: is every slot of the tile the same (target camera, pair) for all of its tracks?  tile_sinfo as ba_plan.cpp
+// describes it (lane = slot: at most 64 slots per tile where this layout is considered at all)
+__global__ __launch_bounds__(256) void k_plan_sinfo(PlanSlotArgs a) {
+    const int t = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (t >= a.T) return;
+    const int ns = a.tile_nslot[t], nt = a.tile_ntrk[t];
+    const size_t b0 = (size_t)a.tile_slot0[t] * 64;
+    unsigned mine = 0;
+    bool bad = false;
+    for (int sl = 0; sl < ns; ++sl) {
+        const size_t i = b0 + (size_t)sl * 64 + (size_t)lane;
+        const int c = (lane < nt && a.slot_edge[i] >= 0) ? (int)a.slot_code[i] : -1;
+        const unsigned long long valid = __ballot(c >= 0);
+        if (!valid) continue;
+        const int first = __shfl(c, __ffsll((long long)valid) - 1);
+        if (__any(c >= 0 && c != first)) bad = true;
+        if (lane == sl) mine = (unsigned)first | (1u << 17);
+    }
+    const unsigned up = __shfl_down(mine, 1), dn = __shfl_up(mine, 1);
+    const bool used = (mine >> 17) & 1u;
+    const bool rep = used && ((lane + 1 < ns && ((up >> 17) & 1u) && ((up >> 8) & 0xffu) == ((mine >> 8) & 0xffu)) ||
+                              (lane > 0 && ((dn >> 17) & 1u) && ((dn >> 8) & 0xffu) == ((mine >> 8) & 0xffu)));
+    a.tile_sinfo[(size_t)t * 64 + (size_t)lane] = lane < ns ? (mine | (rep ? 1u << 16 : 0u)) : 0u;
+    if (bad && lane == 0) *a.em_bad = 1;
 }
 
 // one thread per (tile, 8 or 16 waves): the nearest slot boundary to the even split that no run crosses (ba_plan.cpp)
@@ -283,11 +326,10 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
     b.dirty_lo = g[2]; b.dirty_hi = g[3];
     *tracks = g[7];
     if (g[5] || g[6] || g[3] < g[2]) return BT_NEED_EDGES;
-    // (not the graphs of the wave-per-tile kernels — their tables are made from the host's slot arrays — and not a patch range
-    //  mostly empty: the table's slice would be a larger copy than the edges)
+    // (not a patch range mostly empty: the table's slice would be a larger copy than the edges)
     const int64_t t64 = ((int64_t)g[7] + kLanes - 1) / kLanes;
     const size_t nt = (size_t)(g[3] - g[2] + 1);
-    if (t64 <= 0 || t64 >= std::min(edge_min_tiles(), stream_min_tiles()) || nt > 4 * (size_t)g[7] + 65536) return BT_NEED_EDGES;
+    if (t64 <= 0 || nt > 4 * (size_t)g[7] + 65536) return BT_NEED_EDGES;
     if (nt > b.tab_cap) {
         (void)hipHostFree(b.h_tab);
         if (hipHostMalloc(reinterpret_cast<void **>(&b.h_tab), (nt + nt / 4 + 1024) * sizeof(PatchStat), hipHostMallocDefault) != hipSuccess) { b.tab_cap = 0; return BT_ENOMEM; }
@@ -401,8 +443,10 @@ int plan_device_slots_stage(const bt_plan *pl, void *stream) {
 }
 
 // ... and the arrays themselves, in the plan's buffer (queued behind the upload of its tables)
+int plan_device_em_verdict() { return bufs().h_glob ? bufs().h_glob[12] : 1; }
+
 int plan_device_slots_fill(const bt_plan *pl, int64_t E, int32_t *d_slot_edge, int32_t *d_slot_pair, uint16_t *d_slot_lab, uint8_t *d_slot_lp,
-                           uint16_t *d_cut8, uint16_t *d_cut16, void *stream) {
+                           uint16_t *d_cut8, uint16_t *d_cut16, void *stream, const DevWptOut *wpt) {
     hipStream_t cs = static_cast<hipStream_t>(stream);
     DevPlanBuffers &b = bufs();
     const size_t nwin = pl->trk_win.size(), m = pl->trk_loc.size(), npo = pl->dev_pair_of.size(), n = (size_t)pl->info.slots * kLanes;
@@ -417,8 +461,20 @@ int plan_device_slots_fill(const bt_plan *pl, int64_t E, int32_t *d_slot_edge, i
     a.crossed = b.crossed; a.cut8 = d_cut8; a.cut16 = d_cut16; a.T = (int)pl->info.tiles;
     if (hipMemsetAsync(d_slot_edge, 0xff, n * sizeof(int32_t), cs) != hipSuccess || hipMemsetAsync(d_slot_pair, 0, n * sizeof(int32_t), cs) != hipSuccess ||
         hipMemsetAsync(d_slot_lab, 0xff, n * sizeof(uint16_t), cs) != hipSuccess || hipMemsetAsync(d_slot_lp, 0, n, cs) != hipSuccess) return BT_EHIP;
+    if (wpt) {
+        a.slot_code = wpt->slot_code; a.tile_la = wpt->tile_la; a.tile_rec = wpt->tile_rec; a.it_edge = wpt->it_edge; a.tile_sinfo = wpt->tile_sinfo;
+        a.em_bad = b.glob + 12; a.tile_ntrk = P.tile_ntrk;
+        b.h_glob[12] = 0;
+        if (hipMemsetAsync(a.slot_code, 0xff, n * sizeof(uint16_t), cs) != hipSuccess || hipMemsetAsync(a.tile_la, 0xff, (size_t)a.T * kLanes, cs) != hipSuccess ||
+            hipMemsetAsync(a.em_bad, 0, sizeof(int), cs) != hipSuccess ||
+            (a.it_edge && hipMemsetAsync(a.it_edge, 0xff, (size_t)wpt->its * kLanes * sizeof(int32_t), cs) != hipSuccess)) return BT_EHIP;
+    }
     hipLaunchKernelGGL(k_plan_slots, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, a);
     hipLaunchKernelGGL(k_plan_cuts, dim3((unsigned)((2 * a.T + 255) / 256)), dim3(256), 0, cs, a);
+    if (wpt && a.tile_sinfo) {
+        hipLaunchKernelGGL(k_plan_sinfo, dim3((unsigned)((a.T + 3) / 4)), dim3(256), 0, cs, a);
+        if (hipMemcpyAsync(b.h_glob + 12, a.em_bad, sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess) return BT_EHIP;
+    }
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 

@@ -56,14 +56,14 @@ def test_device_planned_tables_equal_the_hosts(variant):
 
 @pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
 def test_lists_outside_the_device_path_are_planned_by_the_host():
-    # (a) a graph laid out for the wave-per-tile kernels (2048 tiles: their tables are derived from the host's slot arrays) — with
-    # those kernels switched off the same list is planned on the device for k_tile; (b) a short list; (c) a track with two source
-    # frames is refused by both paths alike; (d) an index out of range is reported, not planned
+    # (a) a graph laid out for the wave-per-tile kernels (2048 tiles) is planned on the device whichever kernels it is laid out
+    # for; (b) a short list is not; (c) a track with two source frames is refused by both paths alike; (d) an index out of range
+    # is reported, not planned
     from batrack_amd.plan import wave_per_tile_kernels
     g = graphgen.make_graph(64, 2048, 8, seed=0)
     idx = [torch.as_tensor(a, device=DEV) for a in (g.ii, g.jj, g.kk)]
     p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
-    assert not p.built_on_device and p.jacobian_kernel == "k_stream" and p.tiles == 2048
+    assert p.built_on_device and p.jacobian_kernel == "k_stream" and p.tiles == 2048
     prev = wave_per_tile_kernels(False)
     try:
         p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
@@ -86,6 +86,23 @@ def test_lists_outside_the_device_path_are_planned_by_the_host():
     # and the next list after the refused ones is planned on the device again (the per-patch table was left clean)
     dev, host = both_plans(ii, jj, kk, g.poses.shape[0], g.patches.shape[0], fixedp)
     assert dev.built_on_device and (dev.array("pm_edge") == host.array("pm_edge")).all()
+
+
+WPT_TABLES = ("slot_code", "tile_la", "tile_rec", "it_edge", "tile_sinfo")
+
+
+def compare_wave_per_tile_tables(dev, host):
+    """slot_code, tile_la, tile_rec always; the edge-major tables of k_edge where the host found every tile slot-uniform (and
+    the device must have reached the same verdict: the two plans launch the same kernel)."""
+    assert dev.jacobian_kernel == host.jacobian_kernel
+    uniform = host.array("it_edge").size > 0
+    for name in WPT_TABLES:
+        if name in ("it_edge", "tile_sinfo") and not uniform:
+            continue
+        a, b = dev.array(name), host.array(name)
+        if name == "tile_rec" and not uniform:
+            a, b = a.reshape(-1, 8)[:, :6], b.reshape(-1, 8)[:, :6]      # (words 6 and 7 belong to the edge-major layout)
+        assert a.shape == b.shape and (a == b).all(), name
 
 
 SLOT_TABLES = ("slot_edge", "slot_pair", "slot_lab", "slot_lp", "tile_cut8", "tile_cut16", "kx", "pair_i", "pair_j", "tile_trk0", "tile_ntrk", "tile_ncam",
@@ -164,15 +181,15 @@ def test_random_edge_lists_plan_alike_on_device_and_host(seed):
     ii, jj, kk = ii[p], jj[p], kk[p]
     fixedp = int(rng.integers(0, max(1, int(max(ii.max(), jj.max())))))
     dev, host = both_plans(ii, jj, kk, n_buf, p_tot, fixedp)
-    # (graphs of 2048 tiles and more — many cameras per track: a tile per track — keep the host's analysis: the tables of the
-    #  wave-per-tile kernels are derived from its slot arrays)
-    assert dev.jacobian_kernel == host.jacobian_kernel and dev.built_on_device == (host.tiles < 2048)
+    assert dev.jacobian_kernel == host.jacobian_kernel and dev.built_on_device
     for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
         assert getattr(dev, f) == getattr(host, f), f
     names = TABLES if dev.jacobian_kernel == "k_etile" else SLOT_TABLES
     for name in names:
         a, b = dev.array(name), host.array(name)
         assert a.shape == b.shape and (a == b).all(), (name, dev.jacobian_kernel)
+    if host.tiles >= 2048:
+        compare_wave_per_tile_tables(dev, host)
 
 
 @pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
@@ -210,3 +227,41 @@ def test_sharded_plans_are_laid_out_on_the_device_too(graph, world):
             a, b = dev.array(name), host.array(name)
             assert a.shape == b.shape and (a == b).all(), (name, r, dev.jacobian_kernel)
     assert built == world                       # (every rank of these lists holds 4096 edges or more in total and has tracks)
+
+
+@pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
+@pytest.mark.parametrize("variant", ["k_stream_2048", "k_edge_8192", "k_edge_8192_shuffled", "repeats", "ragged", "sharded"])
+def test_device_planned_tables_of_the_wave_per_tile_kernels_equal_the_hosts(variant):
+    """Graphs of 2048 tiles and more (k_stream, k_edge): slot_code, tile_la, the tile records with their straddle flag, and — where
+    every tile is slot-uniform — it_edge and tile_sinfo come from kernels (plan_device.hip) and equal the host's."""
+    rng = np.random.default_rng(23)
+    g, fixedp = graphgen.make_graph(64, 2048 if variant == "k_stream_2048" else 8192 if "8192" in variant else 4096, 8, seed=6), 1
+    ii, jj, kk = (np.asarray(a) for a in (g.ii, g.jj, g.kk))
+    if variant == "repeats":                    # repeated observations: runs across the half-chunk boundary (straddle flags), repeat bits
+        extra = rng.integers(0, ii.size, ii.size // 2)
+        ii, jj, kk = np.concatenate([ii, ii[extra]]), np.concatenate([jj, jj[extra]]), np.concatenate([kk, kk[extra]])
+    if variant == "ragged":                     # tracks of different lengths: tiles that are not slot-uniform (no k_edge for the plan)
+        keep = rng.random(ii.size) > 0.15
+        ii, jj, kk = ii[keep], jj[keep], kk[keep]
+    if variant in ("k_edge_8192_shuffled", "repeats"):
+        p = rng.permutation(ii.size)
+        ii, jj, kk = ii[p], jj[p], kk[p]
+    n_buf, p_tot = g.poses.shape[0], g.patches.shape[0]
+    own = (0, 0)
+    if variant == "sharded":
+        from batrack_amd.parallel import partition_tracks, plan_range
+        own = plan_range(partition_tracks(kk, 2)[1], p_tot)
+    dev = Plan(*(torch.as_tensor(a, device=DEV) for a in (ii, jj, kk)), n_buf, p_tot, fixedp, own=own)
+    host = Plan(ii, jj, kk, n_buf, p_tot, fixedp, own=own)
+    assert dev.built_on_device and not host.built_on_device and host.tiles >= 2048
+    assert dev.jacobian_kernel == host.jacobian_kernel and host.jacobian_kernel in ("k_stream", "k_edge")
+    if variant.startswith("k_"):
+        assert host.jacobian_kernel == variant[:variant.index("_", 2)]
+    if variant == "ragged":
+        assert host.jacobian_kernel == "k_stream"          # (tiles that are not slot-uniform: the device's verdict must be the host's)
+    for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
+        assert getattr(dev, f) == getattr(host, f), f
+    for name in SLOT_TABLES + ("trk_off",):
+        a, b = dev.array(name), host.array(name)
+        assert a.shape == b.shape and (a == b).all(), name
+    compare_wave_per_tile_tables(dev, host)
