@@ -29,17 +29,20 @@
 namespace bt {
 
 // glob: 0 n_all, 1 f_lo, 2 kmin, 3 kmax, 4 any_self, 5 two source frames for a track, 6 a target outside the mask, 7 tracks
-// (no atomic here returns a value: 415k returning atomics on the per-patch records were 85 us of a 138k-edge list)
-__global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *words, long long E, PatchStat *stat, int *glob, int *vals) {
+// (no atomic here returns a value: 415k returning atomics on the per-patch records were 85 us of a 138k-edge list; and the list's
+//  figures leave a workgroup as ONE record of partials, reduced by k_plan_count: four atomics per workgroup on the same four words
+//  — 131k of them for 8.4M edges — are served one after the other, 25 ns each: 3.3 ms of such a plan)
+constexpr int kStatBlocks = 1024;                 // workgroups of k_plan_stats (grid-stride), = records of partials
+__global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *words, long long E, PatchStat *stat, int *part, int *vals) {
     __shared__ int s_max_f, s_min_f, s_kmin, s_kmax, s_flags;
     if (threadIdx.x == 0) { s_max_f = 0; s_min_f = 0x7fffffff; s_kmin = 0x7fffffff; s_kmax = -1; s_flags = 0; }
     __syncthreads();
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < E) {
+    int max_f = 0, min_f = 0x7fffffff, kmin = 0x7fffffff, kmax = -1, fl = 0;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
         const unsigned long long w = words[e];
         const int k = (int)(w >> 32), i = (int)((w >> 16) & 0xffff), j = (int)(w & 0xffff);
         vals[e] = (int)e;
-        int fl = i == j ? 1 : 0;
+        if (i == j) fl |= 1;
         PatchStat *t = stat + k;
         atomicAdd(&t->cnt, 1);
         atomicMax(&t->src, i);                      // (one source frame per track is checked below: min == max)
@@ -47,13 +50,38 @@ __global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *wo
         const int bit = j - (i - 32);
         if (bit < 0 || bit >= 64) fl |= 4;
         else atomicOr(&t->mask, 1ull << bit);
-        atomicMax(&s_max_f, max(i, j) + 1); atomicMin(&s_min_f, min(i, j));
-        atomicMin(&s_kmin, k); atomicMax(&s_kmax, k);
+        max_f = max(max_f, max(i, j) + 1); min_f = min(min_f, min(i, j));
+        kmin = min(kmin, k); kmax = max(kmax, k);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        max_f = max(max_f, __shfl_xor(max_f, m)); min_f = min(min_f, __shfl_xor(min_f, m));
+        kmin = min(kmin, __shfl_xor(kmin, m)); kmax = max(kmax, __shfl_xor(kmax, m)); fl |= __shfl_xor(fl, m);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&s_max_f, max_f); atomicMin(&s_min_f, min_f); atomicMin(&s_kmin, kmin); atomicMax(&s_kmax, kmax);
         if (fl) atomicOr(&s_flags, fl);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicMax(&glob[0], s_max_f); atomicMin(&glob[1], s_min_f); atomicMin(&glob[2], s_kmin); atomicMax(&glob[3], s_kmax);
+        int *o = part + 8 * blockIdx.x;
+        o[0] = s_max_f; o[1] = s_min_f; o[2] = s_kmin; o[3] = s_kmax; o[4] = s_flags;
+    }
+}
+
+// the workgroups' partials into glob[0..6] (one workgroup), ahead of k_plan_count on the same stream
+__global__ __launch_bounds__(256) void k_plan_glob(const int *part, int nblk, int *glob) {
+    __shared__ int s_max_f, s_min_f, s_kmin, s_kmax, s_flags;
+    if (threadIdx.x == 0) { s_max_f = 0; s_min_f = 0x7fffffff; s_kmin = 0x7fffffff; s_kmax = -1; s_flags = 0; }
+    __syncthreads();
+    for (int r = threadIdx.x; r < nblk; r += blockDim.x) {
+        const int *o = part + 8 * r;
+        atomicMax(&s_max_f, o[0]); atomicMin(&s_min_f, o[1]); atomicMin(&s_kmin, o[2]); atomicMax(&s_kmax, o[3]);
+        if (o[4]) atomicOr(&s_flags, o[4]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        glob[0] = max(glob[0], s_max_f); glob[1] = min(glob[1], s_min_f); glob[2] = min(glob[2], s_kmin); glob[3] = max(glob[3], s_kmax);
         if (s_flags & 1) glob[4] = 1;
         if (s_flags & 4) glob[6] = 1;
     }
@@ -277,6 +305,7 @@ namespace {
 struct DevPlanBuffers {
     PatchStat *stat = nullptr; size_t stat_cap = 0; long long dirty_lo = 0, dirty_hi = -1;
     int *glob = nullptr, *h_glob = nullptr;                       // 8 + 2 ints (device, pinned host)
+    int *part = nullptr;                                          // [kStatBlocks][8]: the workgroups' partials of k_plan_stats
     unsigned *keys_in = nullptr, *keys = nullptr; int *vals_in = nullptr, *vals = nullptr; unsigned char *dcode = nullptr; size_t e_cap = 0;
     const unsigned long long *words = nullptr; int jbits = 0;
     void *temp = nullptr; size_t temp_cap = 0;
@@ -303,7 +332,7 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
     hipStream_t cs = static_cast<hipStream_t>(stream);
     DevPlanBuffers &b = bufs();
     if (!b.glob) {
-        if (hipMalloc(reinterpret_cast<void **>(&b.glob), 16 * sizeof(int)) != hipSuccess ||
+        if (hipMalloc(reinterpret_cast<void **>(&b.glob), 16 * sizeof(int)) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&b.part), kStatBlocks * 8 * sizeof(int)) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&b.h_glob), 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) return BT_ENOMEM;
     }
     if (p_tot > ((int64_t)8 << 20) || E > (int64_t)0x7fffffff / 2) return BT_NEED_EDGES;      // (a per-patch table of 24 B per slot of the buffer: 6 MB for the reference's 1024 x 256 slots)
@@ -318,9 +347,11 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
     b.h_glob[0] = 0; b.h_glob[1] = 0x7fffffff; b.h_glob[2] = 0x7fffffff; b.h_glob[3] = -1;
     for (int c = 4; c < 10; ++c) b.h_glob[c] = 0;
     if (hipMemcpyAsync(b.glob, b.h_glob, 10 * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess) return BT_EHIP;
-    hipLaunchKernelGGL(k_plan_stats, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, cs, reinterpret_cast<const unsigned long long *>(d_words),
-                       (long long)E, b.stat, b.glob, b.vals_in);
-    hipLaunchKernelGGL(k_plan_count, dim3(16), dim3(256), 0, cs, b.stat, b.glob);
+    const int nblk = (int)std::min<int64_t>(kStatBlocks, (E + 255) / 256);
+    hipLaunchKernelGGL(k_plan_stats, dim3((unsigned)nblk), dim3(256), 0, cs, reinterpret_cast<const unsigned long long *>(d_words),
+                       (long long)E, b.stat, b.part, b.vals_in);
+    hipLaunchKernelGGL(k_plan_glob, dim3(1), dim3(256), 0, cs, b.part, nblk, b.glob);
+    hipLaunchKernelGGL(k_plan_count, dim3(64), dim3(256), 0, cs, b.stat, b.glob);
     if (hipMemcpyAsync(b.h_glob, b.glob, 8 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
     const int *g = b.h_glob;
     b.dirty_lo = g[2]; b.dirty_hi = g[3];
