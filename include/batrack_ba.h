@@ -230,11 +230,11 @@ int bt_plan_edge_precision(const bt_plan *plan);
  * their size (a plan keeps the layout it was built with), enable < 0 only queries.  Returns the previous setting.
  * BT_WPT_KERNELS=0 in the environment is the same switch for a whole process. */
 int bt_config_wave_per_tile_kernels(int enable);
-/* 1 if the passes over the edges of this plan ran on the device (bt_plan_create with device index tensors on a sliding-window
- * or 64-keyframe-sized edge list, i.e. below 2048 tiles: per-track figures, a radix sort and the edge-sized tables by kernels,
- * the host laid out tracks, pairs, tiles and the reduced system from the per-track figures), 0 if the host analysed the edges
- * (larger graphs, sharded plans, host arrays, BT_PLAN_DEVICE=0), also
- * for a shifted copy (its tables are its source's).  For tests and tooling. */
+/* 1 if the passes over the edges of this plan ran on the device (bt_plan_create with device index tensors and 4096 edges or
+ * more, any layout, whole or sharded: per-track figures, a radix sort and the edge-sized tables by kernels, the host laid out
+ * tracks, pairs, tiles and the reduced system from the per-track figures), 0 if the host analysed the edges (host arrays,
+ * BT_PLAN_DEVICE=0, a target frame 32 or more away from its track's source frame, a rank without tracks), also for a shifted
+ * copy (its tables are its source's).  For tests and tooling. */
 int bt_plan_built_on_device(const bt_plan *plan);
 
 /* Library/ABI version and the gfx target the kernels were compiled for. */
