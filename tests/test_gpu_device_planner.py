@@ -265,3 +265,51 @@ def test_device_planned_tables_of_the_wave_per_tile_kernels_equal_the_hosts(vari
         a, b = dev.array(name), host.array(name)
         assert a.shape == b.shape and (a == b).all(), name
     compare_wave_per_tile_tables(dev, host)
+
+
+@pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
+@pytest.mark.parametrize("seed", range(4))
+def test_random_many_tile_lists_plan_alike_on_device_and_host(seed):
+    """Random lists of 2048 tiles and more (tracks per frame in the thousands, 2..9 targets per track within +-12 frames, repeats
+    in every second list, shuffled, any fixedp; odd seeds: a rank's range of a sharded solve): whichever wave-per-tile kernel the
+    planner picks, every table of the device-planned plan is the host's."""
+    rng = np.random.default_rng(900 + seed)
+    n_frames, M = int(rng.integers(28, 40)), int(rng.choice([6144, 8192])) * (2 if seed % 2 else 1)     # (a rank of two keeps 2048 tiles)
+    n_buf, p_tot = n_frames + 2, (n_frames + 1) * M
+    src = np.repeat(np.arange(n_frames), M)
+    pat = src * M + np.tile(np.arange(M), n_frames)
+    alive = rng.random(pat.size) < (2.0 if seed == 0 else 0.97)          # (seed 0: no gaps, tiles inside a frame: slot-uniform, k_edge)
+    src, pat = src[alive], pat[alive]
+    # per track: a window of targets around the source frame, the same for the tracks of a frame in even seeds (slot-uniform
+    # tiles: k_edge), thinned per track in odd ones (k_stream)
+    span = int(rng.integers(2, 5))                                       # (at most 10 cameras per tile: the wave-per-tile kernels' limit)
+    off = np.arange(-span, span + 1)
+    off = off[off != 0]
+    tg = src[:, None] + off[None, :]
+    ok = (tg >= 0) & (tg < n_frames)
+    if seed % 2:
+        ok &= rng.random(tg.shape) < 0.8
+    ii = np.broadcast_to(src[:, None], tg.shape)[ok]
+    kk = np.broadcast_to(pat[:, None], tg.shape)[ok]
+    jj = tg[ok]
+    if seed >= 2:                                                        # repeated observations
+        extra = rng.integers(0, ii.size, ii.size // 3)
+        ii, jj, kk = np.concatenate([ii, ii[extra]]), np.concatenate([jj, jj[extra]]), np.concatenate([kk, kk[extra]])
+    p = rng.permutation(ii.size)
+    ii, jj, kk = (a[p].astype(np.int64) for a in (ii, jj, kk))
+    fixedp = int(rng.integers(1, 4))
+    own = (0, 0)
+    if seed % 2:
+        from batrack_amd.parallel import partition_tracks, plan_range
+        own = plan_range(partition_tracks(kk, 2)[seed // 2 % 2], p_tot)
+    dev = Plan(*(torch.as_tensor(a, device=DEV) for a in (ii, jj, kk)), n_buf, p_tot, fixedp, own=own)
+    host = Plan(ii, jj, kk, n_buf, p_tot, fixedp, own=own)
+    assert dev.built_on_device and not host.built_on_device and host.tiles >= 2048, host.tiles
+    assert dev.jacobian_kernel == host.jacobian_kernel
+    for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
+        assert getattr(dev, f) == getattr(host, f), f
+    for name in SLOT_TABLES + ("trk_off",):
+        a, b = dev.array(name), host.array(name)
+        assert a.shape == b.shape and (a == b).all(), name
+    compare_wave_per_tile_tables(dev, host)            # (the tables exist whichever kernel the tiles' camera counts admit)
+    assert seed != 0 or host.jacobian_kernel == "k_edge"
