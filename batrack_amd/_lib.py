@@ -184,6 +184,8 @@ def lib():
     L.bt_plan_create.argtypes = [vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, ctypes.POINTER(vp)]
     L.bt_plan_create_shifted.restype = i32
     L.bt_plan_create_shifted.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ctypes.POINTER(vp)]
+    L.bt_plan_create_shifted_any.restype = i32
+    L.bt_plan_create_shifted_any.argtypes = [ctypes.POINTER(vp), i32, vp, vp, vp, i64, i64, i64, i64, ctypes.POINTER(i32), ctypes.POINTER(vp)]
     L.bt_plan_destroy.restype = None
     L.bt_plan_destroy.argtypes = [vp]
     L.bt_plan_pool_trim.restype = None

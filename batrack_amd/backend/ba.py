@@ -99,14 +99,18 @@ def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync):
             cached = list(_CACHE.values())             # (prefetch_plan calls this from its worker thread while the cache may change)
         except RuntimeError:
             cached = []
-        cands = [st.plan for st, _ in reversed(cached)  # most recent first
-                 if st.plan.E == E and st.plan.n_buf == int(n_buf) and st.plan.p_tot == int(p_tot) and st.plan.fixedp < int(fixedp)]
+        nb, pt, fp = int(n_buf), int(p_tot), int(fixedp)
+        cands = []
+        for st, _ in reversed(cached):                 # most recent first (the figures straight from the plans' dicts: every frame passes here)
+            inf = st.plan.info
+            if inf["E"] == E and inf["n_buf"] == nb and inf["p_tot"] == pt and inf["fixedp"] < fp:
+                cands.append(st.plan)
         # (with a keyframe stride of 2 the match is two updates back: the frame shift that worked last time is tried first)
-        cands.sort(key=lambda pl: int(fixedp) - pl.fixedp != _LAST_SHIFT[0])
-        for src in cands[:3]:                          # (each comparison is ~40 us; a list that matches none is built the ordinary way)
-            pl = Plan.shifted(src, ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
+        cands.sort(key=lambda pl: fp - pl.info["fixedp"] != _LAST_SHIFT[0])
+        if cands:                                      # (one comparison pass and one host wait for all of them; a list that matches none is built the ordinary way)
+            pl, which = Plan.shifted_any(cands[:3], ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
             if pl is not None:
-                _LAST_SHIFT[0] = int(fixedp) - src.fixedp
+                _LAST_SHIFT[0] = fp - cands[which].info["fixedp"]
                 return pl
     return Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
 

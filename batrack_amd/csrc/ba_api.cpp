@@ -63,6 +63,14 @@ struct DevPool {
     }
     std::vector<hipEvent_t> spare;                 // events not attached to a buffer (guarded by mu)
     void give_event(hipEvent_t ev) { if (ev) { std::lock_guard<std::mutex> lk(mu); spare.push_back(ev); } }
+    hipEvent_t take_event() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!spare.empty()) { hipEvent_t ev = spare.back(); spare.pop_back(); return ev; }
+        }
+        hipEvent_t ev = nullptr;
+        return hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess ? ev : nullptr;
+    }
     // last_stream != nullptr / launched: kernels reading the buffer may still be queued there
     void release(void *p, size_t cap, bool launched, hipStream_t last_stream) {
         Entry e{p, cap, nullptr, false};
@@ -326,6 +334,17 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     return s;
 }
 
+// Every entry point that launches a plan's kernels passes here first: the stream is remembered for bt_plan_destroy, and a clone
+// whose tables are still being copied on the plan stream (bt_plan_create_shifted_any) gets its launches ordered behind them.
+static void mark_launch(const bt_plan *pl, void *stream) {
+    pl->last_stream = stream; pl->launched = true;
+    if (pl->ready) {
+        hipEvent_t ev = static_cast<hipEvent_t>(pl->ready);
+        if (hipEventQuery(ev) == hipSuccess) { dev_pool().give_event(ev); pl->ready = nullptr; }
+        else if (hipStreamWaitEvent(static_cast<hipStream_t>(stream), ev, 0) != hipSuccess) (void)hipEventSynchronize(ev);
+    }
+}
+
 static int check(const bt_plan *pl, const bt_ba_args *a, const void *ws) {
     if (!pl || !a || !ws || !pl->dev_base) return BT_EINVAL;
     if (!a->poses || !a->patches || !a->mono_disp || !a->intrinsics || !a->patches_out) return BT_EINVAL;
@@ -427,34 +446,62 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
     return BT_OK;
 }
 
-int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
-                           int64_t n_buf, int64_t p_tot, int64_t fixedp, bt_plan **out) {
+// The plan of a list that is a shifted copy of ONE of up to four earlier plans' lists (the caller's cache, most likely first):
+// packed once, compared with every candidate in the same queue, one synchronisation for all of them (a candidate that does not
+// match used to cost a round trip of its own: with a keyframe stride of 2 every other update of the replay paid one).  The clone's
+// tables are copied and shifted on the plan stream WITHOUT a host wait: the plan carries an event (`ready`) that its first
+// launches are ordered behind (mark_launch).
+constexpr int kMaxShiftSources = 4;
+int bt_plan_create_shifted_any(const bt_plan *const *srcs, int nsrc, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                               int64_t n_buf, int64_t p_tot, int64_t fixedp, int *which, bt_plan **out) {
     if (!out) return BT_EINVAL;
     *out = nullptr;
-    if (!src || !ii || !jj || !kk || E <= 0) return BT_EINVAL;
-    if (!src->dev_base || !src->pk_off || src->e_all != E || src->info.E != E || src->info.n_buf != n_buf || src->info.p_tot != p_tot)
-        return BT_NO_MATCH;
+    if (which) *which = -1;
+    if (!srcs || nsrc <= 0 || !ii || !jj || !kk || E <= 0) return BT_EINVAL;
     if (n_buf > 32768 || p_tot > (int64_t)0x7fffffff) return BT_NO_MATCH;
+    const bt_plan *cand[kMaxShiftSources];
+    int idx[kMaxShiftSources], nc = 0;
+    for (int q = 0; q < nsrc && nc < kMaxShiftSources; ++q) {
+        const bt_plan *src = srcs[q];
+        if (!src) return BT_EINVAL;
+        if (!src->dev_base || !src->pk_off || src->e_all != E || src->info.E != E || src->info.n_buf != n_buf || src->info.p_tot != p_tot) continue;
+        cand[nc] = src; idx[nc++] = q;
+    }
+    if (nc == 0) return BT_NO_MATCH;
+    ApiTick tick;
     PackBuffers &pb = pack_buffers();
     if (!pb.ensure((size_t)E)) return BT_ENOMEM;
-    if (!pb.d_cmp && (hipMalloc(reinterpret_cast<void **>(&pb.d_cmp), 4 * sizeof(int)) != hipSuccess ||
-                      hipHostMalloc(reinterpret_cast<void **>(&pb.h_cmp), 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)) return BT_ENOMEM;
+    constexpr int kCmpInts = 4 * kMaxShiftSources + 4;            // per candidate: mismatch, -, shift lo, shift hi; then the range check's verdict
+    if (!pb.d_cmp && (hipMalloc(reinterpret_cast<void **>(&pb.d_cmp), kCmpInts * sizeof(int)) != hipSuccess ||
+                      hipHostMalloc(reinterpret_cast<void **>(&pb.h_cmp), kCmpInts * sizeof(int), hipHostMallocDefault) != hipSuccess)) return BT_ENOMEM;
     hipStream_t cs = copy_stream();
-    const uint64_t *old_words = reinterpret_cast<const uint64_t *>(static_cast<const char *>(src->dev_base) + src->pk_off);
-    if (hipMemsetAsync(pb.d_bad, 0, sizeof(int), cs) != hipSuccess || hipMemsetAsync(pb.d_cmp, 0, 4 * sizeof(int), cs) != hipSuccess ||
-        launch_pack_edges(ii, jj, kk, E, n_buf, p_tot, pb.d_words, pb.d_bad, cs) != BT_OK ||
-        launch_shift_match(pb.d_words, old_words, E, pb.d_cmp, cs) != BT_OK ||
-        hipMemcpyAsync(pb.h_cmp, pb.d_cmp, 4 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess ||
-        hipMemcpyAsync(pb.h_bad, pb.d_bad, sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+    int *d_bad = pb.d_cmp + 4 * kMaxShiftSources;
+    bool ok = hipMemsetAsync(pb.d_cmp, 0, kCmpInts * sizeof(int), cs) == hipSuccess &&
+              launch_pack_edges(ii, jj, kk, E, n_buf, p_tot, pb.d_words, d_bad, cs) == BT_OK;
+    for (int q = 0; ok && q < nc; ++q) {
+        const uint64_t *old_words = reinterpret_cast<const uint64_t *>(static_cast<const char *>(cand[q]->dev_base) + cand[q]->pk_off);
+        ok = launch_shift_match(pb.d_words, old_words, E, pb.d_cmp + 4 * q, cs) == BT_OK;
+    }
+    if (!ok || hipMemcpyAsync(pb.h_cmp, pb.d_cmp, kCmpInts * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess ||
         hipStreamSynchronize(cs) != hipSuccess)
         return BT_EHIP;
-    if (*pb.h_bad) return BT_EINVAL;
-    if (pb.h_cmp[0]) return BT_NO_MATCH;
-    const uint64_t d0 = (uint64_t)(uint32_t)pb.h_cmp[2] | ((uint64_t)(uint32_t)pb.h_cmp[3] << 32);
-    const int64_t dj = (int64_t)(d0 & 0xffff), di = (int64_t)((d0 >> 16) & 0xffff), dk = (int64_t)(d0 >> 32);
-    // (shifts forward in time only; both frame fields by the same amount; the fixed prefix moves along)
-    if (di != dj || dk >= ((int64_t)1 << 31) || fixedp != src->info.fixedp + di || src->info.n_all + di > n_buf) return BT_NO_MATCH;
-    if (di == 0 && dk == 0) return BT_NO_MATCH;                      // the same list: the caller's cache has that plan already
+    tick("shifted: pack + match (synchronised)");
+    if (pb.h_cmp[4 * kMaxShiftSources]) return BT_EINVAL;
+    const bt_plan *src = nullptr;
+    int64_t di = 0, dk = 0;
+    for (int q = 0; q < nc && !src; ++q) {
+        const int *c = pb.h_cmp + 4 * q;
+        if (c[0]) continue;
+        const uint64_t d0 = (uint64_t)(uint32_t)c[2] | ((uint64_t)(uint32_t)c[3] << 32);
+        const int64_t dj = (int64_t)(d0 & 0xffff);
+        di = (int64_t)((d0 >> 16) & 0xffff); dk = (int64_t)(d0 >> 32);
+        // (shifts forward in time only; both frame fields by the same amount; the fixed prefix moves along)
+        if (di != dj || dk >= ((int64_t)1 << 31) || fixedp != cand[q]->info.fixedp + di || cand[q]->info.n_all + di > n_buf) continue;
+        if (di == 0 && dk == 0) continue;                           // the same list: the caller's cache has that plan already
+        src = cand[q];
+        if (which) *which = idx[q];
+    }
+    if (!src) return BT_NO_MATCH;
     bt_plan *pl = plan_pool().take();
     if (!pl) return BT_ENOMEM;
     pl->info = src->info; pl->info.fixedp = fixedp; pl->info.n_all = src->info.n_all + di;
@@ -484,19 +531,41 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
         rc = launch_plan_shift(I32(O.kx), (int)pl->info.m, I32(O.tkx), (int)pl->info.tiles * kLanes, I32(O.tij), pl->n_tile_ij, I32(O.pi), I32(O.pj),
                                (int)pl->info.pairs, reinterpret_cast<const uint32_t *>(ob + O.ab), reinterpret_cast<uint32_t *>(nb + O.ab), I32(O.ar),
                                pl->n_act_words, (int)di, (int)dk, cs);
-    if (rc == BT_OK && hipStreamSynchronize(cs) != hipSuccess) rc = BT_EHIP;
-    if (rc != BT_OK) { dev_pool().release(d, cap, false, nullptr); plan_pool().give(pl); return rc; }
+    // no host wait for the copies: the plan's first launches are ordered behind this event on whatever stream they use
+    hipEvent_t ready = rc == BT_OK ? dev_pool().take_event() : nullptr;
+    if (rc == BT_OK && (!ready || hipEventRecord(ready, cs) != hipSuccess)) {
+        dev_pool().give_event(ready); ready = nullptr;
+        if (hipStreamSynchronize(cs) != hipSuccess) rc = BT_EHIP;
+    }
+    tick("shifted: copies enqueued");
+    if (rc != BT_OK) { (void)hipStreamSynchronize(cs); dev_pool().release(d, cap, false, nullptr); plan_pool().give(pl); return rc; }
+    pl->ready = ready;
     pl->dev_base = d;
     pl->dev_cap = cap;
     bind_pointers(pl, d);
     rc = configure_kernels(pl->dev);
+    tick("shifted: configure kernels");
     if (rc != BT_OK) { bt_plan_destroy(pl); return rc; }
     *out = pl;
     return BT_OK;
 }
 
+int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                           int64_t n_buf, int64_t p_tot, int64_t fixedp, bt_plan **out) {
+    if (!out) return BT_EINVAL;
+    *out = nullptr;
+    if (!src) return BT_EINVAL;
+    return bt_plan_create_shifted_any(&src, 1, ii, jj, kk, E, n_buf, p_tot, fixedp, nullptr, out);
+}
+
 void bt_plan_destroy(bt_plan *pl) {
     if (!pl) return;
+    if (pl->ready) {
+        // (copies of a clone that was never launched may still be queued on the plan stream: the buffer's next owner writes it
+        //  on that same stream, behind them)
+        dev_pool().give_event(static_cast<hipEvent_t>(pl->ready));
+        pl->ready = nullptr;
+    }
     if (pl->dev_base) dev_pool().release(pl->dev_base, pl->dev_cap, pl->launched, static_cast<hipStream_t>(pl->last_stream));
     plan_pool().give(pl);
 }
@@ -578,7 +647,7 @@ int bt_ba_reduce(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream)
     const int rc = check(pl, a, ws);
     if (rc != BT_OK) return rc;
     const StepArgs s = make_args(pl, a, ws);
-    pl->last_stream = stream; pl->launched = true;
+    mark_launch(pl, stream);
     return launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), is_so(pl, a), static_cast<hipStream_t>(stream));
 }
 
@@ -590,7 +659,7 @@ int bt_ba_solve_update(const bt_plan *pl, const bt_ba_args *a, void *ws, void *s
     if (!so && a->poses_out == a->poses) return BT_EINVAL;
     const StepArgs s = make_args(pl, a, ws);
     const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
-    pl->last_stream = stream; pl->launched = true;
+    mark_launch(pl, stream);
     return launch_solve_update(pl->dev, s, so, copy_poses, static_cast<hipStream_t>(stream));
 }
 
@@ -600,7 +669,7 @@ int bt_ba_step(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
     const bool so = is_so(pl, a);
     if (!so && (!a->poses_out || a->poses_out == a->poses)) return BT_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    pl->last_stream = stream; pl->launched = true;
+    mark_launch(pl, stream);
     const StepArgs s = make_args(pl, a, ws);
     const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
     bool fused = false;              // (structure-only steps on the k_tile path are one launch)
@@ -615,7 +684,7 @@ int bt_ba_step_timed(const bt_plan *pl, const bt_ba_args *a, void *ws, void *str
     const bool so = is_so(pl, a);
     if (!so && (!a->poses_out || a->poses_out == a->poses)) return BT_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    pl->last_stream = stream; pl->launched = true;
+    mark_launch(pl, stream);
     hipEvent_t ev[10];
     for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return BT_EHIP;
     const StepArgs s = make_args(pl, a, ws);
@@ -636,7 +705,7 @@ int bt_ba_pack(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
     const int rc = check(pl, a, ws);
     if (rc != BT_OK) return rc;
     if (is_so(pl, a)) return BT_OK;
-    pl->last_stream = stream; pl->launched = true;
+    mark_launch(pl, stream);
     return launch_pack(pl->dev, make_args(pl, a, ws), false, static_cast<hipStream_t>(stream));
 }
 
@@ -644,7 +713,7 @@ int bt_ba_unpack(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream)
     const int rc = check(pl, a, ws);
     if (rc != BT_OK) return rc;
     if (is_so(pl, a)) return BT_OK;
-    pl->last_stream = stream; pl->launched = true;
+    mark_launch(pl, stream);
     return launch_pack(pl->dev, make_args(pl, a, ws), true, static_cast<hipStream_t>(stream));
 }
 
@@ -704,6 +773,7 @@ int bt_ba_pull_solve_update(const bt_plan *pl, const bt_ba_args *a, void *ws, vo
     if (rc != BT_OK) return rc;
     if (!is_so(pl, a)) {
         if (!own || world < 1 || world > kMaxRanks || epoch < 1) return BT_EINVAL;
+        mark_launch(pl, stream);
         const int r2 = launch_xchg_pull(pl->dev, make_args(pl, a, ws), own, world, epoch, static_cast<hipStream_t>(stream));
         if (r2 != BT_OK) return r2;
     }

@@ -153,6 +153,7 @@ struct bt_plan {
     // reuses the device buffer makes its table upload wait for it (the tables must not change under queued kernels)
     mutable void *last_stream = nullptr;
     mutable bool launched = false;
+    mutable void *ready = nullptr;                            // hipEvent_t behind a clone's copies on the plan stream (ba_api.cpp: mark_launch), else null
     size_t dev_cap = 0;
     bt::PlanDev dev{};
 
@@ -175,7 +176,7 @@ struct bt_plan {
         max_rows16 = 16;
         ws = bt::WsLayout{};
         dev_base = nullptr; dev_cap = 0;
-        last_stream = nullptr; launched = false;
+        last_stream = nullptr; launched = false; ready = nullptr;
         dev = bt::PlanDev{};
     }
 };

@@ -102,6 +102,13 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
  * The new plan has no host arrays (bt_plan_array returns empty ones). */
 int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
                            int64_t n_buf, int64_t p_tot, int64_t fixedp, bt_plan **out);
+/* The same against up to four candidate source plans at once (the caller's most recent plans, most likely first): the list is
+ * packed once and compared with every candidate in one queue — one host wait for all of them, where a candidate that does not
+ * match costs a round trip of its own through bt_plan_create_shifted.  *which (optional) = index of the source that matched.
+ * The clone's tables are copied on the library's plan stream without a host wait; the plan's first launches are ordered
+ * behind them whatever stream they are given. */
+int bt_plan_create_shifted_any(const bt_plan *const *srcs, int nsrc, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                               int64_t n_buf, int64_t p_tot, int64_t fixedp, int *which, bt_plan **out);
 
 /* The device buffer and the host arrays of a destroyed plan are kept (up to eight of each) for the next
  * bt_plan_create: the caller replaces its edge list every frame (batrack.py:189-212), and a
