@@ -313,3 +313,42 @@ def test_random_many_tile_lists_plan_alike_on_device_and_host(seed):
         assert a.shape == b.shape and (a == b).all(), name
     compare_wave_per_tile_tables(dev, host)            # (the tables exist whichever kernel the tiles' camera counts admit)
     assert seed != 0 or host.jacobian_kernel == "k_edge", (host.jacobian_kernel, host.tiles)
+
+
+@pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
+def test_small_tile_layout_that_reaches_2048_tiles_is_laid_out_again_on_the_device():
+    """The round-3 advisor's list (3000 tracks x 26 observations, random source frames: every track closes its own 16-track tile
+    at the camera limit, 2048 tiles and more) through the DEVICE planner: the second layout (64 tracks per tile) and its
+    wave-per-tile tables come from the device's passes too, and equal the host's."""
+    rng = np.random.default_rng(0)
+    m, K, n_buf = 3000, 26, 120
+    src = rng.integers(0, n_buf - K - 4, m)
+    kk = np.repeat(np.arange(m), K).astype(np.int64)
+    ii = np.repeat(src, K).astype(np.int64)
+    jj = (ii + np.tile(np.arange(K), m)).astype(np.int64)
+    dev, host = both_plans(ii, jj, kk, n_buf, m, 1)
+    assert host.tiles >= 2048 and dev.built_on_device and dev.jacobian_kernel == host.jacobian_kernel
+    for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
+        assert getattr(dev, f) == getattr(host, f), f
+    for name in SLOT_TABLES:
+        a, b = dev.array(name), host.array(name)
+        assert a.shape == b.shape and (a == b).all(), name
+    compare_wave_per_tile_tables(dev, host)
+    # and it steps like the host-planned one
+    from batrack_amd.plan import Stepper
+    g = graphgen.make_graph(8, 64, 4, seed=1)            # (only for tensors of the right kind: poses, intrinsics)
+    torch.manual_seed(0)
+    poses = torch.zeros(n_buf, 7, device=DEV); poses[:, 6] = 1; poses[:, :3] = 0.01 * torch.randn(n_buf, 3, device=DEV)
+    patches = torch.rand(m, 3, 3, 3, device=DEV) * 100 + 50; patches[:, 2] = 0.5 + torch.rand(m, 1, 1, device=DEV)
+    intr = torch.tensor([[300.0, 300.0, 320.0, 176.0]], device=DEV).repeat(n_buf, 1)
+    mono = patches[:, 2, 1, 1].contiguous()
+    targets = torch.rand(ii.size, 2, device=DEV) * 300 + 20
+    weights = torch.rand(ii.size, 2, device=DEV)
+    outs = []
+    for pl in (dev, host):
+        st = Stepper(pl, torch.device(DEV))
+        po, pa = torch.empty_like(poses), patches.clone()
+        st.step(poses, patches, mono, intr, targets, 2, weights, po, pa, (0, 0, 640, 352), 1e-4, 10.0, 0.05, "huber", False)
+        torch.cuda.synchronize()
+        outs.append((po.cpu(), pa.cpu()))
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-6, equal_nan=True) and torch.allclose(outs[0][1], outs[1][1], atol=1e-5, equal_nan=True)
