@@ -132,10 +132,17 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // ---- ONE pass over the edges: n_all (ba.py:219), the window of patches and frames they name, edges per track and per
     // target frame, the camera pairs in use, and per track its source frame and the set of its target frames (a 64-bit mask
     // around the first target seen: a track's observations span a window of frames, batrack.py:399-410)
-    struct PerPatch { int32_t cnt, src, base, last_j; uint64_t mask; };
+    // (mask, mask2: target frames base + b and base + 64 + b; the host's own pass fills 64 bits around the first target it sees,
+    //  the device's table 128 around the source frame)
+    struct PerPatch { int32_t cnt, src, base, last_j; uint64_t mask, mask2; };
+#define BT_FOR_TARGETS(T_, fr_, ...)                                                                                            \
+    do {                                                                                                                        \
+        for (uint64_t mk_ = (T_).mask; mk_; mk_ &= mk_ - 1) { const int32_t fr_ = (T_).base + __builtin_ctzll(mk_); __VA_ARGS__ }        \
+        for (uint64_t mk_ = (T_).mask2; mk_; mk_ &= mk_ - 1) { const int32_t fr_ = (T_).base + 64 + __builtin_ctzll(mk_); __VA_ARGS__ }  \
+    } while (0)
     static thread_local std::vector<PerPatch> pp_tab;            // indexed by patch; only [kmin, kmax] of the previous plan is dirty
     static thread_local int64_t pp_lo = 0, pp_hi = -1;
-    if ((int64_t)pp_tab.size() < p_tot) { pp_tab.assign((size_t)p_tot, PerPatch{0, 0, 0, 0, 0}); pp_lo = 0; pp_hi = -1; }
+    if ((int64_t)pp_tab.size() < p_tot) { pp_tab.assign((size_t)p_tot, PerPatch{0, 0, 0, 0, 0, 0}); pp_lo = 0; pp_hi = -1; }
     for (int64_t p = pp_lo; p <= pp_hi; ++p) pp_tab[(size_t)p].cnt = 0;
     PerPatch *pp = pp_tab.data();
     int64_t n_all = n_all_min, kmin = p_tot, kmax = -1;       // [kmin, kmax]: patches the edges name (a window of the buffer)
@@ -155,7 +162,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         for (int64_t k = kmin; k <= kmax; ++k) {
             const PatchStat &d = dstats->tab[(size_t)(k - kmin)];
             PerPatch &t = pp[k];
-            t.src = d.src; t.base = d.src - 32; t.last_j = 0; t.mask = d.mask;
+            t.src = d.src; t.base = d.src - 64; t.last_j = 0; t.mask = d.mask; t.mask2 = d.mask2;
             if (k >= own_lo && k < own_hi) { t.cnt = d.cnt; E_own += d.cnt; }
             else { t.cnt = 0; if (k < own_lo) pl->dev_q0 += d.cnt; }
         }
@@ -173,7 +180,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         ++E_own;
         ++cj[(size_t)j + 1];
         PerPatch &t = pp[k];
-        if (t.cnt++ == 0) { t.src = (int32_t)i; t.base = (int32_t)j - 32; t.mask = 0; }
+        if (t.cnt++ == 0) { t.src = (int32_t)i; t.base = (int32_t)j - 32; t.mask = 0; t.mask2 = 0; }
         else { if (t.src != (int32_t)i) src_ok = false; if ((int32_t)j < t.last_j) mono_j = false; }
         t.last_j = (int32_t)j;          // one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)
         const int64_t bit = j - t.base;
@@ -224,13 +231,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     if (masks_ok) {
         // from the tracks' (source frame, target mask): a few thousand tracks instead of every edge
         // (neighbouring tracks mostly share their source frame and targets — the tracks of one frame: such a track adds nothing)
-        int32_t src_b = -1, base_b = 0; uint64_t mask_b = 0;
+        int32_t src_b = -1, base_b = 0; uint64_t mask_b = 0, mask2_b = 0;
         for (int32_t k = 0; k < m; ++k) {
             const PerPatch &t = pp[pl->kx[(size_t)k]];
-            if (t.src == src_b && t.base == base_b && t.mask == mask_b) continue;
-            src_b = t.src; base_b = t.base; mask_b = t.mask;
+            if (t.src == src_b && t.base == base_b && t.mask == mask_b && t.mask2 == mask2_b) continue;
+            src_b = t.src; base_b = t.base; mask_b = t.mask; mask2_b = t.mask2;
             int32_t *row = pair_of.data() + (size_t)(t.src - f_lo) * nw - f_lo;
-            for (uint64_t mk = t.mask; mk; mk &= mk - 1) row[t.base + __builtin_ctzll(mk)] = 0;
+            BT_FOR_TARGETS(t, fr, row[fr] = 0;);
         }
     } else {
         for (int64_t e = 0; e < E; ++e) if (owned(e)) pair_of[(size_t)((II(e) - f_lo) * nw + (JJ(e) - f_lo))] = 0;
@@ -333,9 +340,10 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         static const int pm_env2 = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;
         if (pm_env2 == 2) return BT_NEED_EDGES;                    // (pair-major tables of 64-track tiles are made from the host's slot arrays)
     }
-    int32_t src_p = -1, base_p = 0, set_epoch = -1; uint64_t mask_p = 0;         // the previous track's figures: the same again = the same cameras
+    int32_t src_p = -1, base_p = 0, set_epoch = -1; uint64_t mask_p = 0, mask2_p = 0;         // the previous track's figures: the same again = the same cameras
     for (int32_t k = 0; k < m; ++k) {
-        if (masks_ok && k > 0 && pp[pl->kx[(size_t)k]].src == src_p && pp[pl->kx[(size_t)k]].base == base_p && pp[pl->kx[(size_t)k]].mask == mask_p) {
+        if (masks_ok && k > 0 && pp[pl->kx[(size_t)k]].src == src_p && pp[pl->kx[(size_t)k]].base == base_p && pp[pl->kx[(size_t)k]].mask == mask_p &&
+            pp[pl->kx[(size_t)k]].mask2 == mask2_p) {
             // (trk_set is the previous track's and still right; in the tile it went into, it adds nothing)
             if (set_epoch == epoch && k - trk0 < tcap) continue;
         } else {
@@ -343,13 +351,12 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         if (masks_ok) {
             // the track's free cameras from its source frame and target mask (no walk over its edges)
             const PerPatch &t = pp[pl->kx[(size_t)k]];
-            src_p = t.src; base_p = t.base; mask_p = t.mask;
+            src_p = t.src; base_p = t.base; mask_p = t.mask; mask2_p = t.mask2;
             const int64_t cs = (int64_t)t.src - fixedp;
             if (cs >= 0) { tstamp[(size_t)cs] = k; trk_set.push_back((int32_t)cs); }
-            for (uint64_t mk = t.mask; mk; mk &= mk - 1) {
-                const int64_t c = (int64_t)t.base + __builtin_ctzll(mk) - fixedp;
-                if (c >= 0 && tstamp[(size_t)c] != k) { tstamp[(size_t)c] = k; trk_set.push_back((int32_t)c); }
-            }
+            BT_FOR_TARGETS(t, fr,
+                const int64_t c = (int64_t)fr - fixedp;
+                if (c >= 0 && tstamp[(size_t)c] != k) { tstamp[(size_t)c] = k; trk_set.push_back((int32_t)c); });
         } else {
             for (int32_t sidx = off[(size_t)k]; sidx < off[(size_t)k + 1]; ++sidx) {
                 const int64_t cams[2] = { IQ(sidx) - fixedp, JQ(sidx) - fixedp };
@@ -424,16 +431,15 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             for (int32_t c = 0; c < nc; ++c) local[(size_t)pl->tile_cams[(size_t)(c0 + c)]] = c;
             mine.clear();
             if (masks_ok) {
-                int32_t src_b = -1, base_b = 0; uint64_t mask_b = 0;
+                int32_t src_b = -1, base_b = 0; uint64_t mask_b = 0, mask2_b = 0;
                 for (int32_t l = 0; l < nt; ++l) {
                     const PerPatch &tp = pp[pl->kx[(size_t)(t0 + l)]];
-                    if (tp.src == src_b && tp.base == base_b && tp.mask == mask_b) continue;       // (the same pairs as the track before)
-                    src_b = tp.src; base_b = tp.base; mask_b = tp.mask;
+                    if (tp.src == src_b && tp.base == base_b && tp.mask == mask_b && tp.mask2 == mask2_b) continue;       // (the same pairs as the track before)
+                    src_b = tp.src; base_b = tp.base; mask_b = tp.mask; mask2_b = tp.mask2;
                     const int32_t *row = pair_of.data() + (size_t)(tp.src - f_lo) * nw - f_lo;
-                    for (uint64_t mk = tp.mask; mk; mk &= mk - 1) {
-                        const int32_t gp = row[tp.base + __builtin_ctzll(mk)];
-                        if (lp_of[(size_t)gp] < 0) { lp_of[(size_t)gp] = 0; mine.push_back(gp); }
-                    }
+                    BT_FOR_TARGETS(tp, fr,
+                        const int32_t gp = row[fr];
+                        if (lp_of[(size_t)gp] < 0) { lp_of[(size_t)gp] = 0; mine.push_back(gp); });
                 }
             } else {
                 for (int32_t q = off[(size_t)t0]; q < off[(size_t)(t0 + nt)]; ++q) {
@@ -583,19 +589,19 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     if (E_own != E && dstats) {
         // (the same from the device's table: a track's cameras are its source frame and the frames of its mask)
         std::vector<int32_t> cset;
-        int32_t src_b = -1; uint64_t mask_b = 0;
+        int32_t src_b = -1; uint64_t mask_b = 0, mask2_b = 0;
         for (int64_t p = kmin; p <= kmax; ++p) {
             if (p >= own_lo && p < own_hi) continue;
             const PatchStat &d = dstats->tab[(size_t)(p - kmin)];
             if (d.cnt <= 0) continue;
-            if (d.src == src_b && d.mask == mask_b) continue;          // (the same cameras as the track before: nothing new)
-            src_b = d.src; mask_b = d.mask;
+            if (d.src == src_b && d.mask == mask_b && d.mask2 == mask2_b) continue;          // (the same cameras as the track before: nothing new)
+            src_b = d.src; mask_b = d.mask; mask2_b = d.mask2;
             cset.clear();
             if (d.src >= fixedp) cset.push_back((int32_t)(d.src - fixedp));
-            for (uint64_t mk = d.mask; mk; mk &= mk - 1) {
-                const int64_t c = (int64_t)d.src - 32 + __builtin_ctzll(mk) - fixedp;
-                if (c >= 0) cset.push_back((int32_t)c);
-            }
+            const PerPatch dt{d.cnt, d.src, d.src - 64, 0, d.mask, d.mask2};
+            BT_FOR_TARGETS(dt, fr,
+                const int64_t c = (int64_t)fr - fixedp;
+                if (c >= 0) cset.push_back((int32_t)c););
             std::sort(cset.begin(), cset.end());
             cset.erase(std::unique(cset.begin(), cset.end()), cset.end());
             for (size_t u = 0; u < cset.size(); ++u)

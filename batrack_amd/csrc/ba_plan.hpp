@@ -194,7 +194,7 @@ int config_wave_per_tile_kernels(int enable);
 // reads NO edge: it lays out tracks, pairs, tiles and the reduced system from the tracks' (source frame, target mask), and
 // leaves the one edge-sized table of a window plan (pm_edge) and the tiles' round counts to the device
 // (bt_plan::dev_pm).  Returns BT_NEED_EDGES where that does not apply (the caller then runs the analysis on the edges).
-struct PatchStat { int32_t cnt, src, src_min, pad; unsigned long long mask; };      // mask bit b: an edge into frame src - 32 + b
+struct PatchStat { int32_t cnt, src, src_min, pad; unsigned long long mask, mask2; };      // bit b of (mask | mask2 << 64): an edge into frame src - 64 + b
 struct DevPlanStats {
     const PatchStat *tab;          // [kmax - kmin + 1], the patches kmin .. kmax
     int64_t kmin, kmax, n_all, f_lo;

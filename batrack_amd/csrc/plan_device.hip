@@ -5,8 +5,8 @@
 // track, and the walk that writes the one edge-sized table of such a plan (pm_edge).  The caller's sliding window changes its
 // edge list every frame (batrack.py:189-212) and the list is a shifted copy of an earlier one only in steady state: while the
 // window fills, every update() pays a plan from scratch.  Here the three passes run where the edge list already is:
-//   k_plan_stats    one thread per edge: atomics into a per-patch table (count, source frame, mask of target frames around the
-//                   source frame) and the figures of the whole list (frames and patches named, self edges)
+//   k_plan_stats    one thread per edge: atomics into a per-patch table (count, source frame, 128-bit mask of target frames around
+//                   the source frame) and the figures of the whole list (frames and patches named, self edges)
 //   radix sort      of (patch - first patch) << bits | (target frame - first frame), some 18 bits, with the edge index as value
 //                   (hipcub / rocPRIM, stable): a track's edges in (target frame, index) order — the order the host's stable
 //                   counting passes produce.  Runs while the host lays out the small tables.
@@ -17,7 +17,7 @@
 // per-patch table instead of the edges).  64-track layouts: k_plan_slots / k_plan_cuts instead of the last three — and, for the
 // graphs of the wave-per-tile kernels (2048 tiles and more), k_plan_slots writes their compact tables as well and k_plan_sinfo
 // decides whether the edge-major layout of k_edge applies (every tile slot-uniform).  A sharded plan runs the passes on the
-// rank's segment of the sorted list.  Anything that does not fit — a track whose target frames are not within 32 of its source
+// rank's segment of the sorted list.  Anything that does not fit — a track whose target frames are not within 64 of its source
 // frame, two source frames for one track — falls back to the analysis on the edges.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -47,9 +47,9 @@ __global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *wo
         atomicAdd(&t->cnt, 1);
         atomicMax(&t->src, i);                      // (one source frame per track is checked below: min == max)
         atomicMin(&t->src_min, i);
-        const int bit = j - (i - 32);
-        if (bit < 0 || bit >= 64) fl |= 4;
-        else atomicOr(&t->mask, 1ull << bit);
+        const int bit = j - (i - 64);
+        if (bit < 0 || bit >= 128) fl |= 4;
+        else atomicOr(bit < 64 ? &t->mask : &t->mask2, 1ull << (bit & 63));
         max_f = max(max_f, max(i, j) + 1); min_f = min(min_f, min(i, j));
         kmin = min(kmin, k); kmax = max(kmax, k);
     }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_plan_count(const PatchStat *stat, int *
 
 __global__ __launch_bounds__(256) void k_plan_stat_clear(PatchStat *stat, long long lo, long long hi) {
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p <= hi) { stat[p].cnt = 0; stat[p].src = -1; stat[p].src_min = 0x7fffffff; stat[p].mask = 0ull; }
+    if (p <= hi) { stat[p].cnt = 0; stat[p].src = -1; stat[p].src_min = 0x7fffffff; stat[p].mask = 0ull; stat[p].mask2 = 0ull; }
 }
 
 // The sort key of an edge: (patch - kmin) << jbits | (target frame - f_lo) — some 18 bits for a window instead of the 50 of
@@ -335,7 +335,7 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
         if (hipMalloc(reinterpret_cast<void **>(&b.glob), 16 * sizeof(int)) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&b.part), kStatBlocks * 8 * sizeof(int)) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&b.h_glob), 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) return BT_ENOMEM;
     }
-    if (p_tot > ((int64_t)8 << 20) || E > (int64_t)0x7fffffff / 2) return BT_NEED_EDGES;      // (a per-patch table of 24 B per slot of the buffer: 6 MB for the reference's 1024 x 256 slots)
+    if (p_tot > ((int64_t)8 << 20) || E > (int64_t)0x7fffffff / 2) return BT_NEED_EDGES;      // (a per-patch table of 32 B per slot of the buffer: 8 MB for the reference's 1024 x 256 slots)
     if ((size_t)p_tot > b.stat_cap) {
         (void)hipFree(b.stat);
         if (hipMalloc(reinterpret_cast<void **>(&b.stat), (size_t)p_tot * sizeof(PatchStat)) != hipSuccess) { b.stat_cap = 0; return BT_ENOMEM; }

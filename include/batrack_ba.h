@@ -240,7 +240,7 @@ int bt_config_wave_per_tile_kernels(int enable);
 /* 1 if the passes over the edges of this plan ran on the device (bt_plan_create with device index tensors and 4096 edges or
  * more, any layout, whole or sharded: per-track figures, a radix sort and the edge-sized tables by kernels, the host laid out
  * tracks, pairs, tiles and the reduced system from the per-track figures), 0 if the host analysed the edges (host arrays,
- * BT_PLAN_DEVICE=0, a target frame 32 or more away from its track's source frame, a rank without tracks), also for a shifted
+ * BT_PLAN_DEVICE=0, a target frame more than 63 away from its track's source frame, a rank without tracks), also for a shifted
  * copy (its tables are its source's).  For tests and tooling. */
 int bt_plan_built_on_device(const bt_plan *plan);
 

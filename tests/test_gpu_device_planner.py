@@ -352,3 +352,31 @@ def test_small_tile_layout_that_reaches_2048_tiles_is_laid_out_again_on_the_devi
         torch.cuda.synchronize()
         outs.append((po.cpu(), pa.cpu()))
     assert torch.allclose(outs[0][0], outs[1][0], atol=1e-6, equal_nan=True) and torch.allclose(outs[0][1], outs[1][1], atol=1e-5, equal_nan=True)
+
+
+@pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
+@pytest.mark.parametrize("reach", [31, 45, 63, 64])
+def test_targets_far_from_their_source_frame(reach):
+    """A track's targets up to 63 frames from its source frame fit the device's 128-bit mask (round 3: 31); one frame more and
+    the list goes to the host's analysis.  Either way the plan's tables are the host's."""
+    rng = np.random.default_rng(reach)
+    n_frames, M = 140, 48
+    src = np.repeat(np.arange(n_frames), M)
+    pat = src * M + np.tile(np.arange(M), n_frames)
+    ii, jj, kk = [], [], []
+    for s, p in zip(src, pat):
+        near = np.arange(max(0, s - 3), min(n_frames, s + 4))
+        far = np.array([f for f in (s - reach, s + reach) if 0 <= f < n_frames], np.int64)
+        tg = np.concatenate([near[near != s], far])
+        ii.append(np.full(tg.size, s)); jj.append(tg); kk.append(np.full(tg.size, p))
+    ii, jj, kk = (np.concatenate(a).astype(np.int64) for a in (ii, jj, kk))
+    p = rng.permutation(ii.size)
+    ii, jj, kk = ii[p], jj[p], kk[p]
+    dev, host = both_plans(ii, jj, kk, n_frames + 2, (n_frames + 1) * M, 5)
+    assert dev.built_on_device == (reach <= 63) and dev.jacobian_kernel == host.jacobian_kernel
+    for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
+        assert getattr(dev, f) == getattr(host, f), f
+    names = TABLES if dev.jacobian_kernel == "k_etile" else SLOT_TABLES
+    for name in names:
+        a, b = dev.array(name), host.array(name)
+        assert a.shape == b.shape and (a == b).all(), name

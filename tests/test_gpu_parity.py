@@ -544,8 +544,8 @@ def test_device_planned_window_plan_equals_the_host_planned_one():
     """bt_plan_create with DEVICE index tensors plans a sliding-window list on the device (per-track figures, radix sort, the
     pair-major table by kernels; the host lays out tracks, pairs, tiles and the reduced system without reading an edge); with
     host arrays the host analyses the edges.  Same tables either way: the two plans' steps agree to the last bits (the few
-    float64 atomics of k_pair_finalize are the only order-dependent sums), and a list the device path does not take — target
-    frames 40 away from the source frame — still gets its plan."""
+    float64 atomics of k_pair_finalize are the only order-dependent sums), and a list with target frames 40 away from the source
+    frame (the host's analysis in round 3, the device's 128-bit mask since) gets the same plan."""
     from batrack_amd.plan import Plan, Stepper
     dev = "cuda:0"
     g, fixedp = graphgen.make_window_graph(n_frames=50, M=256, seed=4)
@@ -566,9 +566,9 @@ def test_device_planned_window_plan_equals_the_host_planned_one():
     a, b = outs
     assert a[2:] == b[2:]
     assert rel(a[0], b[0]) < 1e-7 and rel(a[1], b[1]) < 1e-7          # (float32 outputs of float64 sums that differ in their last bits)
-    # a window whose tracks reach 40 frames back: outside the device path's 64-frame mask around the source frame
+    # a window whose tracks reach 40 frames back: outside round 3's 64-frame mask around the source frame, inside round 4's 128
     g2, fp2 = graphgen.make_window_graph(n_frames=60, M=64, seed=5, window=40, removal=45)
     idx = [torch.as_tensor(a, device=dev) for a in (g2.ii, g2.jj, g2.kk)]
     p2 = Plan(*idx, g2.poses.shape[0], g2.patches.shape[0], fp2)
     ref = Plan(np.asarray(g2.ii), np.asarray(g2.jj), np.asarray(g2.kk), g2.poses.shape[0], g2.patches.shape[0], fp2, upload=False)
-    assert not p2.built_on_device and (p2.tiles, p2.m, p2.pairs, p2.n) == (ref.tiles, ref.m, ref.pairs, ref.n)
+    assert (forced or os.environ.get("BT_PLAN_DEVICE", "1") == "0" or p2.built_on_device) and (p2.tiles, p2.m, p2.pairs, p2.n) == (ref.tiles, ref.m, ref.pairs, ref.n)
