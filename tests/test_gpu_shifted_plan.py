@@ -57,6 +57,41 @@ def test_shifted_plan_equals_a_fresh_one(df, M):
     assert sh2 is not None and sh2.info["fixedp"] == fixedp + 2 * df
 
 
+def test_one_of_several_candidate_sources_matches():
+    """bt_plan_create_shifted_any: the list is compared with every candidate in one pass; the first that is a shifted copy (in
+    the order given) is cloned, `which` names it; the clone steps before any host wait for its copies (its launches are ordered
+    behind them) exactly like a fresh plan."""
+    g, fixedp = window()
+    T = lambda a: torch.as_tensor(np.asarray(a, np.int64), device=DEV)
+    n_buf, p_tot = g.poses.shape[0], g.patches.shape[0]
+    ii0, jj0, kk0 = T(g.ii), T(g.jj), T(g.kk)
+    src = Plan(ii0, jj0, kk0, n_buf, p_tot, fixedp)
+    perm = torch.randperm(ii0.numel(), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    other = Plan(ii0[perm], jj0[perm], kk0[perm], n_buf, p_tot, fixedp)          # the same size, another order: no shifted copy
+    later = Plan(ii0 + 1, jj0 + 1, kk0 + 64, n_buf, p_tot, fixedp + 1)            # a shift by one frame of the same list
+    ii2, jj2, kk2 = ii0 + 2, jj0 + 2, kk0 + 128
+    pl, which = Plan.shifted_any([other, src, later], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
+    assert pl is not None and which == 1
+    pl2, which2 = Plan.shifted_any([other, later, src], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
+    assert pl2 is not None and which2 == 1 and pl2.info == pl.info
+    assert Plan.shifted_any([other], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2) == (None, -1)
+    fresh = Plan(ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
+    assert pl.info == fresh.info
+    f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=DEV)
+    poses = f32(np.roll(g.poses, 2, axis=0)); patches = f32(np.roll(g.patches, 128, axis=0))
+    g.mono_disp_shifted = np.roll(g.mono_disp, 128, axis=0)
+    g.intrinsics = np.roll(g.intrinsics, 2, axis=0)
+    # straight into a step, several times over fresh clones: the first launch of each is the one ordered behind the copies
+    outs = []
+    for _ in range(4):
+        c, _w = Plan.shifted_any([src], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
+        outs.append(step_with(c, g, ii2, jj2, kk2, poses, patches))
+    b = step_with(fresh, g, ii2, jj2, kk2, poses, patches)
+    rel = lambda x, y: np.linalg.norm(x.astype(np.float64) - y) / np.linalg.norm(y)
+    for a in outs:
+        assert a[2] == b[2] == 0 and rel(a[0], b[0]) < 1e-6 and rel(a[1], b[1]) < 1e-6
+
+
 def test_lists_that_are_no_shift_are_refused():
     g, fixedp = window()
     T = lambda a: torch.as_tensor(np.asarray(a, np.int64), device=DEV)
