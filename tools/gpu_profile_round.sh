@@ -21,7 +21,7 @@ pmc() {     # counter, tag, M  (environment of the caller selects the kernels)
     python $R/tools/pmc_summary.py /tmp/pmc_$1_$2.db >> $OUT/pmc_fetch_write.txt 2>&1
 }
 # ---- headline bench first (fresh clocks), then the traces
-python $R/bench.py --steps 200 --warmup 20 > $OUT/bench_n1.json 2> $OUT/bench_n1.stderr
+python $R/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.stderr
 trace c3 python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-large
 trace window python $R/tools/gpu_timing.py --workload window
 trace e2m python $R/tools/gpu_pmc_run.py 4096 6
