@@ -69,27 +69,30 @@ __global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *wo
     }
 }
 
-// the workgroups' partials into glob[0..6] (one workgroup), ahead of k_plan_count on the same stream
-__global__ __launch_bounds__(256) void k_plan_glob(const int *part, int nblk, int *glob) {
-    __shared__ int s_max_f, s_min_f, s_kmin, s_kmax, s_flags;
-    if (threadIdx.x == 0) { s_max_f = 0; s_min_f = 0x7fffffff; s_kmin = 0x7fffffff; s_kmax = -1; s_flags = 0; }
-    __syncthreads();
+// tracks (patches with an edge) and the one-source-frame check over the window's slice of the table.  Every workgroup first
+// reduces the partials k_plan_stats left (shuffles, no atomics: a kernel of its own for that was another launch and ~2k
+// same-address LDS atomics); workgroup 0 writes the list's figures to glob[0..6].
+__global__ __launch_bounds__(256) void k_plan_count(const PatchStat *stat, const int *part, int nblk, int *glob) {
+    __shared__ int red[4][5];
+    int max_f = 0, min_f = 0x7fffffff, kmin = 0x7fffffff, kmax = -1, fl = 0;
     for (int r = threadIdx.x; r < nblk; r += blockDim.x) {
         const int *o = part + 8 * r;
-        atomicMax(&s_max_f, o[0]); atomicMin(&s_min_f, o[1]); atomicMin(&s_kmin, o[2]); atomicMax(&s_kmax, o[3]);
-        if (o[4]) atomicOr(&s_flags, o[4]);
+        max_f = max(max_f, o[0]); min_f = min(min_f, o[1]); kmin = min(kmin, o[2]); kmax = max(kmax, o[3]); fl |= o[4];
     }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        max_f = max(max_f, __shfl_xor(max_f, m)); min_f = min(min_f, __shfl_xor(min_f, m));
+        kmin = min(kmin, __shfl_xor(kmin, m)); kmax = max(kmax, __shfl_xor(kmax, m)); fl |= __shfl_xor(fl, m);
+    }
+    if ((threadIdx.x & 63) == 0) { int *o = red[threadIdx.x >> 6]; o[0] = max_f; o[1] = min_f; o[2] = kmin; o[3] = kmax; o[4] = fl; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        glob[0] = max(glob[0], s_max_f); glob[1] = min(glob[1], s_min_f); glob[2] = min(glob[2], s_kmin); glob[3] = max(glob[3], s_kmax);
-        if (s_flags & 1) glob[4] = 1;
-        if (s_flags & 4) glob[6] = 1;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { max_f = max(max_f, red[w][0]); min_f = min(min_f, red[w][1]); kmin = min(kmin, red[w][2]); kmax = max(kmax, red[w][3]); fl |= red[w][4]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        glob[0] = max_f; glob[1] = min_f; glob[2] = kmin; glob[3] = kmax;
+        if (fl & 1) glob[4] = 1;
+        if (fl & 4) glob[6] = 1;
     }
-}
-
-// tracks (patches with an edge) and the one-source-frame check over the window's slice of the table
-__global__ __launch_bounds__(256) void k_plan_count(const PatchStat *stat, int *glob) {
-    const int kmin = glob[2], kmax = glob[3];
     int n = 0, bad = 0;
     for (int p = kmin + (int)(blockIdx.x * blockDim.x + threadIdx.x); p <= kmax; p += (int)(gridDim.x * blockDim.x)) {
         const PatchStat t = stat[p];
@@ -350,8 +353,7 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
     const int nblk = (int)std::min<int64_t>(kStatBlocks, (E + 255) / 256);
     hipLaunchKernelGGL(k_plan_stats, dim3((unsigned)nblk), dim3(256), 0, cs, reinterpret_cast<const unsigned long long *>(d_words),
                        (long long)E, b.stat, b.part, b.vals_in);
-    hipLaunchKernelGGL(k_plan_glob, dim3(1), dim3(256), 0, cs, b.part, nblk, b.glob);
-    hipLaunchKernelGGL(k_plan_count, dim3(64), dim3(256), 0, cs, b.stat, b.glob);
+    hipLaunchKernelGGL(k_plan_count, dim3(64), dim3(256), 0, cs, b.stat, b.part, nblk, b.glob);
     if (hipMemcpyAsync(b.h_glob, b.glob, 8 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
     const int *g = b.h_glob;
     b.dirty_lo = g[2]; b.dirty_hi = g[3];
