@@ -456,6 +456,20 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a, i
     __shared__ double sgeo[4][kPairGeomFloats];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + w;
+    if (a.priv) {
+        // k_edge2's private copies of y (ba_plan.hpp: kPrivY): added up, cleared, and the sum added to y
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pd.D; i += pair_blocks * blockDim.x) {
+            double s = 0.0;
+            for (int c = 0; c < kPrivY; c += 8) {
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = a.priv[(size_t)(c + k) * pd.D + i];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s += v[k]; if (v[k] != 0.0) a.priv[(size_t)(c + k) * pd.D + i] = 0.0; }
+            }
+            if (s != 0.0) atomicAdd(&a.y[i], s);
+        }
+    }
     const bool live = p < pd.P;
     int ia = -1, ib = -1;
     if (live) {
@@ -486,7 +500,18 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a, i
                     for (int k = 0; k < 8; ++k) accv += v[k];
                 }
             }
-        } else if (vi_ld >= 0) accv = acc[vi_ld];
+        } else if (vi_ld >= 0) {
+            accv = acc[vi_ld];
+            if (a.priv) {                     // ... and of the per-pair sums (kPrivP)
+                double *pp = a.priv + (size_t)kPrivY * pd.D + (size_t)p * kPairAccStride + vi_ld;
+                const size_t cs = (size_t)pd.P * kPairAccStride;
+                double v[kPrivP];
+#pragma unroll
+                for (int c = 0; c < kPrivP; ++c) v[c] = pp[c * cs];
+#pragma unroll
+                for (int c = 0; c < kPrivP; ++c) accv += v[c];
+            }
+        }
         if (lane < kPairGeomFloats)                                                              // computed by the Jacobian kernel
             g[lane] = a.prec ? reinterpret_cast<const double *>(a.pairgeo)[(size_t)p * kPairGeomFloats + lane]
                              : (double)a.pairgeo[(size_t)p * kPairGeomFloats + lane];
@@ -510,6 +535,12 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a, i
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (lane < 27 && pair_blocks == (int)gridDim.x) acc[lane] = 0.0;       // leave the per-pair sums clear for the next step
+        if (a.priv && lane < 27 && pair_blocks == (int)gridDim.x) {
+            double *pp = a.priv + (size_t)kPrivY * pd.D + (size_t)p * kPairAccStride + lane;
+            const size_t cs = (size_t)pd.P * kPairAccStride;
+#pragma unroll
+            for (int c = 0; c < kPrivP; ++c) pp[c * cs] = 0.0;
+        }
     }
     __syncthreads();
     if (live && lane < 36) {

@@ -15,6 +15,7 @@ struct StepArgs {
     const float *lmbda_trk;       // per-track lmbda (ba.py:299-300) or nullptr
     int loss;
     double *S, *y, *pairacc;      // S, y, pairacc are contiguous (cleared together)
+    double *priv;                 // private copies of y and the per-pair sums (ba_plan.hpp: kPrivY, kPrivP) or nullptr
     double *packed;               // the non-zero blocks of [S | y] in factor order (multi-GPU exchange buffer)
     float2 *qw;
     float *lfac, *linv, *zvec, *dx, *dx0;
@@ -37,6 +38,8 @@ int launch_stream(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st
 // the same for slot-uniform graphs in the edge-major layout (ba_stream3.hip)
 bool edge_applies(const PlanDev &pd);
 int launch_edge(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+// its pose+structure reduce with two edges per lane (ba_edge2.hip)
+int launch_edge2(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 // the pair-major tile kernel (ba_etile.hip) for the graphs k_tile would take, whenever the plan has the pair-major tables
 // (every tile <= 64 camera pairs) and the tile's E fits LDS: 8 / 4 = as double / only as float, 0 = k_tile takes the plan.
 // launch_etile: mode 0 = pose+structure reduce, 1 = the whole structure-only step, 2 = a pose+structure step's last kernel

@@ -66,6 +66,12 @@ static void layout_workspace(bt_plan *pl) {
     off = align_up(off, 256);
     w.pairacc = off;  off += (size_t)I.pairs * kPairAccStride * sizeof(double);
     off = align_up(off, 256);
+    w.priv = 0;
+    if (I.tiles >= pl->em_min) {       // (plans k_edge2 can take: by the tile count alone — whether the tiles are slot-uniform is, for
+                                       //  a device-planned list, known only after the upload, and the layout must not depend on the planner)
+        w.priv = off;
+        off = align_up(off + ((size_t)kPrivY * D + (size_t)kPrivP * I.pairs * kPairAccStride) * sizeof(double), 256);
+    }
     w.zero_bytes = off - w.sys;
     w.packed = off;   off = align_up(off + ((size_t)I.nnz_blocks * 36 + D) * sizeof(double), 256);   // exchange form of [S | y]
     w.pairgeo = off;  off = align_up(off + (size_t)I.pairs * kPairGeomFloats * sizeof(double), 256);         // k_tile -> k_pair_finalize (float or double)
@@ -95,6 +101,14 @@ int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
         out[e] = ((uint64_t)kk[e] << 32) | ((uint64_t)ii[e] << 16) | (uint64_t)jj[e];
     }
     return BT_OK;
+}
+
+// Iterations of an edge-major tile (64 / S tracks each): an EVEN number (the last one empty where the tile's tracks end in an
+// odd one), so that the flat iteration stream of a wave pairs up (2J, 2J + 1) inside every tile — k_edge2 (ba_edge2.hip) takes
+// two iterations per step, one edge of each per lane.  (S = 1: one iteration is the whole tile; no second half to pair.)
+static inline int32_t em_iterations(int32_t ntrk, int32_t G) {
+    const int32_t nit = (ntrk + G - 1) / G;
+    return G < kLanes ? (nit + 1) & ~1 : nit;
 }
 
 int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk64, int64_t E,
@@ -1057,9 +1071,10 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             while ((1 << lg) < ns) ++lg;
             if (lg > 6) { pl->em_ok = 0; break; }
             const int32_t G = kLanes >> lg;
+            const int32_t nit_t = em_iterations(nt, G);
             pl->tile_rec[(size_t)t * 8 + 6] = (int32_t)its;
-            pl->tile_rec[(size_t)t * 8 + 7] = lg | (((nt + G - 1) / G) << 8);
-            its += (nt + G - 1) / G;
+            pl->tile_rec[(size_t)t * 8 + 7] = lg | (nit_t << 8);
+            its += nit_t;
             if (t == 0) pl->em_lgs = lg; else if (pl->em_lgs != lg) pl->em_lgs = -1;
         }
         if (!pl->em_ok) { for (int64_t t = 0; t < I.tiles; ++t) pl->tile_rec[(size_t)t * 8 + 6] = pl->tile_rec[(size_t)t * 8 + 7] = 0; pl->em_lgs = -1; }
@@ -1075,7 +1090,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             while ((1 << lg) < ns) ++lg;
             if (lg > 6) { pl->em_ok = 0; break; }
             const int32_t G = kLanes >> lg;
-            it0[(size_t)t] = (int32_t)its; lgS[(size_t)t] = lg; nit[(size_t)t] = (nt + G - 1) / G;
+            it0[(size_t)t] = (int32_t)its; lgS[(size_t)t] = lg; nit[(size_t)t] = em_iterations(nt, G);
             its += nit[(size_t)t];
         }
         pl->tile_sinfo.assign(pl->em_ok ? (size_t)I.tiles * kLanes : 0, 0);

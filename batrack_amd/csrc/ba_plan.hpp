@@ -15,6 +15,11 @@ constexpr int kTileCamSoft = 16;    // close a tile when its camera union would 
 constexpr int kTileCamHard = 64;    // a single track may not see more free cameras than this
 constexpr int kMaxFree = 255;       // free poses supported by the reduced solver
 constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj + 6 gj)
+// Private copies of y and of the per-pair sums for k_edge2 (ba_edge2.hip): thousands of waves end with atomics on the SAME few
+// cache lines (y is 6n doubles in all; a pair's 27 sums are hit by every wave of its source frame) and atomics on one line are
+// served one after the other — at 8.4M edges they were 35 of the kernel's 170 us.  A wave adds to copy (its index mod the count);
+// k_pair_finalize adds the copies up and clears them.
+constexpr int kPrivY = 64, kPrivP = 16;
 constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
 constexpr int kLdsRowStride = 66;
 constexpr int kMaxLevelCols = 4;
@@ -94,6 +99,7 @@ struct PlanDev {
 struct WsLayout {
     size_t sys, pairacc, zero_bytes;   // [sys, sys+zero_bytes) is cleared every reduce
     size_t packed, pairgeo, qw, lfac, linv, zvec, dx, dx0, status, spart, esave, total;
+    size_t priv;                       // inside the cleared region: [kPrivY][D] then [kPrivP][pairs][kPairAccStride] doubles; 0 = none
 };
 
 }  // namespace bt

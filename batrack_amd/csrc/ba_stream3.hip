@@ -615,6 +615,8 @@ int launch_edge(const PlanDev &pd, const StepArgs &a, int mode, hipStream_t st, 
     const bool s8 = pd.em_lgs == 3;            // the 8-observation graphs of the benchmark generator
     if (mode == kEmSO) return s8 ? launch_edge_t<kEmSO, 1, 3>(pd, a, st, ev0, ev1) : launch_edge_t<kEmSO, 1, -1>(pd, a, st, ev0, ev1);
     if (mode == kEmUpd) return s8 ? launch_edge_t<kEmUpd, 1, 3>(pd, a, st, ev0, ev1) : launch_edge_t<kEmUpd, 1, -1>(pd, a, st, ev0, ev1);
+    static const int e2 = std::getenv("BT_EDGE2") ? std::atoi(std::getenv("BT_EDGE2")) : 1;                 // measurement only
+    if (e2 && !(a.dbg & 32)) return launch_edge2(pd, a, st, ev0, ev1);
     if (pd.max_cams <= 8 && s8 && (a.dbg & 32)) return launch_edge_t<kEmFull, 3, 3, true>(pd, a, st, ev0, ev1);
     if (pd.max_cams <= 8) return s8 ? launch_edge_t<kEmFull, 3, 3>(pd, a, st, ev0, ev1) : launch_edge_t<kEmFull, 3, -1>(pd, a, st, ev0, ev1);
     return launch_edge_t<kEmFull, 4, -1>(pd, a, st, ev0, ev1);

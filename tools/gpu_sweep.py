@@ -52,5 +52,14 @@ for M in [int(x) for x in (sys.argv[1:] or ["256", "1024", "4096", "16384"])]:
         names2 = ["issue loads", "lds operands", "edge_eval", "Ej/Ei", "group_sum", "E stores", "pair fma", "rotate(prev)"]
         for w, nm in enumerate(("wave 0", "wave mid")):
             print(f"  k_edge {nm} inside the iterations: " + " ".join(f"{n}={v}" for n, v in zip(names2, pf2[w])))
+    if int(os.environ.get("BT_DEBUG_MODE", "0")) & 64:          # a -DBT_E2_PROF build of k_edge2 (tools/build_variant.sh)
+        torch.cuda.synchronize()
+        off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
+        raw = st.ws.cpu().numpy()
+        stat_off = off + 2 * (((6 * plan.n * 4 + 64 + 255) // 256) * 256)
+        names = ["tile top", "operands+project", "jacobian+W", "gather issue", "products+group_sum", "E stores+Q", "pair fma", "schur", "flush", "drain", "tiles", "tile end+rotate", "flush checks", "geometry+X0"]
+        for w, nm in enumerate(("wave 0", "wave mid")):
+            pf = np.frombuffer(raw[stat_off + 16 + 160 + 160 * w: stat_off + 16 + 160 + 160 * w + 112].tobytes(), dtype=np.int64)
+            print(f"  k_edge2 {nm} cycles: " + " ".join(f"{n}={v}" for n, v in zip(names, pf)))
     del st, plan
     torch.cuda.empty_cache()
