@@ -108,9 +108,9 @@ def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync):
         # (with a keyframe stride of 2 the match is two updates back: the frame shift that worked last time is tried first)
         cands.sort(key=lambda pl: fp - pl.info["fixedp"] != _LAST_SHIFT[0])
         if cands:                                      # (one comparison pass and one host wait for all of them; a list that matches none is built the ordinary way)
-            pl, which = Plan.shifted_any(cands[:3], ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
+            pl, matched = Plan.shifted_any(cands[:3], ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
             if pl is not None:
-                _LAST_SHIFT[0] = fp - cands[which].info["fixedp"]
+                _LAST_SHIFT[0] = fp - matched.info["fixedp"]
                 return pl
     return Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
 

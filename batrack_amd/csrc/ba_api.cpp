@@ -339,9 +339,11 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
 // whose tables are still being copied on the plan stream (bt_plan_create_shifted_any) gets its launches ordered behind them.
 static void mark_launch(const bt_plan *pl, void *stream) {
     pl->last_stream = stream; pl->launched = true;
-    if (pl->ready) {
-        hipEvent_t ev = static_cast<hipEvent_t>(pl->ready);
-        if (hipEventQuery(ev) == hipSuccess) { dev_pool().give_event(ev); pl->ready = nullptr; }
+    if (void *r = pl->ready.load(std::memory_order_acquire)) {
+        hipEvent_t ev = static_cast<hipEvent_t>(r);
+        if (hipEventQuery(ev) == hipSuccess) {
+            if (pl->ready.exchange(nullptr, std::memory_order_acq_rel) == r) dev_pool().give_event(ev);      // (one claimant)
+        }
         else if (hipStreamWaitEvent(static_cast<hipStream_t>(stream), ev, 0) != hipSuccess) (void)hipEventSynchronize(ev);
     }
 }
@@ -561,11 +563,10 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
 
 void bt_plan_destroy(bt_plan *pl) {
     if (!pl) return;
-    if (pl->ready) {
+    if (void *r = pl->ready.exchange(nullptr, std::memory_order_acq_rel)) {
         // (copies of a clone that was never launched may still be queued on the plan stream: the buffer's next owner writes it
         //  on that same stream, behind them)
-        dev_pool().give_event(static_cast<hipEvent_t>(pl->ready));
-        pl->ready = nullptr;
+        dev_pool().give_event(static_cast<hipEvent_t>(r));
     }
     if (pl->dev_base) dev_pool().release(pl->dev_base, pl->dev_cap, pl->launched, static_cast<hipStream_t>(pl->last_stream));
     plan_pool().give(pl);

@@ -43,13 +43,17 @@ constexpr int kGeoF = 16;              // floats per pair: t (3), fx_j | R (9), 
 // bytes they meet in two / four banks groups (measured: a third of the kernel's LDS cycles were bank conflicts)
 constexpr int kGeoDS = 18, kGeoFS = 20;
 #ifndef BT_EDGE2_PA_TILES
-#define BT_EDGE2_PA_TILES 4
+#define BT_EDGE2_PA_TILES 16
 #endif
-constexpr int kPaFlushTiles = BT_EDGE2_PA_TILES;         // tiles a lane's float32 pair sums run before they are added to the float64 sums
+// tiles a lane's float32 pair sums run before they are added to the float64 sums (measured on the benchmark graphs: 4 / 8 / 16
+// tiles give the same S, y and dX against the oracle; every flush is 26 wave-wide atomics on lines other waves hit as well)
+constexpr int kPaFlushTiles = BT_EDGE2_PA_TILES;
 #ifndef BT_EDGE2_SCHUR_TILES
-#define BT_EDGE2_SCHUR_TILES 8
+#define BT_EDGE2_SCHUR_TILES 4096
 #endif
-constexpr int kSchurFlushTiles = BT_EDGE2_SCHUR_TILES;   // tiles of one camera set the float32 Schur accumulators run before they go to S (float64 atomics)
+// tiles of one camera set after which the float64 Schur sums in LDS go to S (they are exact enough to run for ever; the bound
+// only keeps a flush from being the wave's very last act in graphs of one camera set)
+constexpr int kSchurFlushTiles = BT_EDGE2_SCHUR_TILES;
 
 // floats per row of the local E: the step's tracks (2G, at least the 16 of one k-sweep of the matrix pipe) + 4 (rows 16-byte
 // aligned for the b128 operand reads, neighbouring rows on different banks)

@@ -863,36 +863,6 @@ __device__ __forceinline__ void apply_update_row3(T *Lw, unsigned s1, unsigned s
     }
 }
 
-// Half a row of an update triple (outputs 3 hh .. 3 hh + 2): 12 vector loads + 3 scalar ones and 18 FMAs — k_solve_chain's
-// helpers spread a level's lazy updates over twice as many lanes, each with about two thirds of apply_update_row3's instructions.
-template <typename T>
-__device__ __forceinline__ void apply_update_half3(T *Lw, unsigned s1, unsigned s2, unsigned d, int r, int hh) {
-    T a[6], b[18], v[3];
-    T *dst = Lw + (d & 0x7fffu) * 36 + 6 * r + 3 * hh;
-    const T *bb = Lw + s2 * 36 + 18 * hh;
-    load_row6(Lw + s1 * 36 + 6 * r, a);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) load_row6(bb + 6 * c, reinterpret_cast<T (&)[6]>(b[6 * c]));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) v[c] = dst[c];
-    __builtin_amdgcn_sched_barrier(0);
-    T o[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        T acc = a[0] * b[6 * c];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) acc += a[k] * b[6 * c + k];
-        o[c] = acc;
-    }
-    if (d & 0x8000u) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(dst + c, -o[c]);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dst[c] = v[c] - o[c];
-    }
-}
-
 template <typename T, bool PROF = false>
 __device__ __forceinline__ void apply_update_row(T *Lw, const unsigned short *tr, int r, long long *pf = nullptr, long long *tcp = nullptr) {
     T a[6], b[36], o[6], v[6];
@@ -1830,7 +1800,6 @@ size_t solve_pipe_lds_bytes(const PlanDev &pd) {
            (5 * (size_t)pd.nnzb + (size_t)pd.n + 1 + (size_t)pd.nlev * 8) * sizeof(int) + 64;      // row_idx, pfirst, psecond, col_ptr, level records, bsrc, trl
 }
 
-size_t solve_chain_lds_bytes(const PlanDev &pd) { return solve_pipe_lds_bytes(pd); }
 
 __device__ __forceinline__ void wait_ge(int *flag, int target) {
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
@@ -2099,271 +2068,6 @@ __global__ __launch_bounds__(768) void k_solve_pipe(PlanDev pd, StepArgs a) {
 #undef BT_TW
 }
 
-// ------------------------------------------------------------------ k_solve_chain (round 4)
-// k_solve_pipe with the hand-overs INSIDE a level removed.  Round 3's timers put ~1.35k of a level's ~2.8k cycles on the
-// diagonal wave -> row wave hand-over (publish the updated 6x6 block, fence, flag, poll, 18 broadcast reads) and on every
-// lane of the row wave factoring that block redundantly.  Here ONE wave per column owns the whole block column, a lane per
-// row: lanes 0..5 the rows of the diagonal block, lane 6 the right-hand side y_j, lanes 7.. the panel rows.  The pending
-// update (from the level below) is the same formula for all of them, and the factorisation is the textbook right-looking
-// one ACROSS LANES: per pivot c the pivot and the multipliers l_kc (k > c) are read out of lanes c and k with v_readlane
-// (wave-uniform, so they become scalar operands of the FMAs), every lane scales its own entry and updates the entries to
-// its right.  For the diagonal rows that is the Cholesky factor, for the panel rows and y the forward substitution — the
-// same instructions.  Nothing is published inside a level; a level costs one flag round trip (to the helpers and to the
-// column's successor), not five.  Helpers (10 waves now) and the back substitution are k_solve_pipe's.
-// Requires what k_solve_pipe requires and 6 (cnt + 1) + 1 <= 64 rows per column (chain_applies).
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// 1 / x: float32 hardware seed (1 ulp) and one Newton step in double (relative error ~1e-14, as rsqrt_t<double>)
-__device__ __forceinline__ double rcp_newton(double x) {
-    const double r = (double)__builtin_amdgcn_rcpf((float)x);
-    return r + r * (1.0 - x * r);
-}
-
-// [S | y] -> LDS in factor order, damped (ba.py:67).  16-byte pieces, three lanes per 48-byte block row: a wave instruction
-// touches ~21 rows of S instead of 64 (lds_load_system reads a row per lane, 8 bytes at a time: 13.6k cycles at C3).
-static bool chain_applies(const PlanDev &pd);
-
-template <bool PROF>
-__global__ __launch_bounds__(768) void k_solve_chain(PlanDev pd, StepArgs a) {
-    typedef double T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int flags[2];
-    __shared__ int colready[2], hcnt, ntr;
-    const int tid = threadIdx.x, nth = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nth >> 6;
-    const int n = pd.n, D = pd.D, nnzb = pd.nnzb, nlev = pd.nlev;
-    T *Lw = reinterpret_cast<T *>(smem);
-    T *z = Lw + (size_t)nnzb * 36, *scr = z + D, *zt = scr;
-    unsigned short *lazy = reinterpret_cast<unsigned short *>(scr + 2 * 36);
-    int *row_idx = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(scr) + pipe_work_bytes(pd)), *pfirst = row_idx + nnzb,
-        *psecond = pfirst + nnzb, *col_ptr = psecond + nnzb, *lrec = col_ptr + n + 1, *bsrc = lrec + nlev * 8, *trl = bsrc + nnzb;
-    long long tall = PROF ? clock64() : 0, tload = 0, tsweep = 0, twait = 0, twork = 0, tq = 0, sub[3] = {0, 0, 0};
-#define BT_TW(acc) do { if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long tn = clock64(); acc += tn - tq; tq = tn; } } while (0)
-
-    int status = BT_SOLVE_OK;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const double lm = attempt == 0 ? 1e-4 : 1e-3;
-        if (tid < 2) { flags[tid] = 0; colready[tid] = 0; }
-        if (tid == 2) hcnt = 0;
-
-        if (attempt == 0) {
-            for (int i = tid; i < nnzb; i += nth) { row_idx[i] = pd.fz_rowinfo[i]; pfirst[i] = pd.fz_pfirst[i]; psecond[i] = pd.fz_psecond[i]; }
-            for (int i = tid; i <= n; i += nth) col_ptr[i] = pd.col_ptr[i];
-            for (int i = tid; i < nlev * 8; i += nth) lrec[i] = pd.fz_pmeta[i];
-        }
-        for (int i = tid; i < pd.fz_nlazy; i += nth)          // one 8-byte word per triple: src1, src2, dst | shared << 15
-            reinterpret_cast<ushort4 *>(lazy)[i] = make_ushort4((unsigned short)pd.fz_lazy[3 * i], (unsigned short)pd.fz_lazy[3 * i + 1],
-                                                               (unsigned short)pd.fz_lazy[3 * i + 2], 0);
-        lds_load_system_dma<T>(pd, a, Lw, z, bsrc, trl, &ntr, col_ptr, lm, attempt == 0, false, tid, nth);
-        __syncthreads();
-        if (PROF) { tload = clock64() - tall; tq = clock64(); }
-
-        // helper waves.  Waves w and w + 4 share a SIMD (a workgroup's waves go to the SIMDs cyclically), so the waves 4, 5, 8, 9
-        // would take issue slots from the two column waves: they sit the sweep out (bit 12 of the debug word: they help too)
-        const bool all_help = (a.dbg >> 12) & 1 || nw < 8;
-        const int hidx = all_help ? wave - 2 : (wave & 3) >= 2 ? (wave >> 2) * 2 + (wave & 1) : -1;      // 2,3,6,7,10,11 -> 0..5
-        const int nh = all_help ? nw - 2 : (nw / 4) * 2 + (nw % 4 > 2 ? nw % 4 - 2 : 0);
-        const int xsleep = (a.dbg >> 8) & 15;                  // (measurement only: longer naps between the helpers' polls)
-        if (wave < 2) {
-            // ================= column waves: one per column of the level, a lane per row of the block column
-            __builtin_amdgcn_s_setprio(3);
-            const int q = wave;
-            const int4 *lrec4 = reinterpret_cast<const int4 *>(lrec);
-            int4 vrec = lrec4[q];
-            int vnc = lrec[1];
-            // a lane's pending words (static) are read one level ahead: the row loads of a level start right behind its flags
-            auto lane_block = [&](int ma_, int mb_, bool &valid_, bool &isy_, int &r_, int &bown_) {
-                const int dpos_ = mb_ & 0xffff, cnt_ = (ma_ >> 8) & 255;
-                const bool isd_ = lane < 6;
-                isy_ = lane == 6; valid_ = lane < 7 + 6 * cnt_;
-                const int sr_ = lane - 7, sb_ = sr_ / 6;
-                r_ = isd_ ? lane : (valid_ ? sr_ - 6 * sb_ : 0);
-                bown_ = (isd_ || isy_ || !valid_) ? dpos_ : dpos_ + 1 + sb_;
-            };
-            unsigned pfo_n, ps_n;
-            {
-                bool v0, y0; int r0, b0;
-                lane_block(vrec.x, vrec.y, v0, y0, r0, b0);
-                pfo_n = (unsigned)pfirst[b0]; ps_n = (unsigned)psecond[b0];
-            }
-            for (int l = 0; l < nlev; ++l) {
-                const int ma = __builtin_amdgcn_readfirstlane(vrec.x), mb = __builtin_amdgcn_readfirstlane(vrec.y),
-                          md = __builtin_amdgcn_readfirstlane(vrec.w), ncl = (__builtin_amdgcn_readfirstlane(vnc) >> 24) & 3;
-                if (l + 1 < nlev) { vrec = lrec4[2 * (l + 1) + q]; vnc = lrec[8 * (l + 1) + 1]; }   // next level's, in flight during this one
-                if (q < ncl) {
-                    if (l > 0) {
-                        // the columns of the level below that hold pending sources of this column (the record's dependency
-                        // bits) and the helpers' batches 0 .. l - 2 (every lazy update into this column has landed)
-                        const int dep = (md >> 20) & 3;
-                        const int need0 = (dep & 1) ? l : 0, need1 = (dep & 2) ? l : 0, needh = nh * (l - 1);
-                        for (;;) {
-                            const int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const int f1 = __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const int fh = __hip_atomic_load(&hcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (f0 >= need0 && f1 >= need1 && fh >= needh) break;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    }
-                    BT_TW(twait);
-                    const int dpos = mb & 0xffff, j = ma & 255, ysrc = (ma >> 16) & 255;
-                    bool valid, isy; int r, bown;
-                    lane_block(ma, mb, valid, isy, r, bown);
-                    T *p = isy ? z + 6 * j : Lw + (size_t)bown * 36 + 6 * r;
-                    const unsigned pfo = pfo_n, ps = ps_n;
-                    const int s1 = pfo & 0x7fff, s2 = (pfo >> 15) & 0x7fff, no = valid ? (int)(pfo >> 30) : 0;
-                    T in[6], avec[6];
-                    load_row6(p, in);
-                    load_row6(isy ? z + 6 * ysrc : Lw + (size_t)s1 * 36 + 6 * r, avec);
-                    // (the 6x6 operand in two halves of three rows: 36 registers live instead of 72 — the wave's budget is 168)
-                    auto pend = [&](const T *M, bool on) {
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            T m[18];
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) load_row6(M + 6 * (3 * hh + c), reinterpret_cast<T (&)[6]>(m[6 * c]));
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                T acc = avec[0] * m[6 * c];
-#pragma unroll
-                                for (int e = 1; e < 6; ++e) acc += avec[e] * m[6 * c + e];
-                                in[3 * hh + c] -= on ? acc : (T)0;
-                            }
-                        }
-                    };
-                    pend(Lw + (size_t)(isy ? s1 : s2) * 36, no > 0);
-                    if (l + 1 < nlev) {                              // next level's pending words (its record has arrived by now)
-                        bool v1, y1; int r1, b1;
-                        lane_block(vrec.x, vrec.y, v1, y1, r1, b1);
-                        pfo_n = (unsigned)pfirst[b1]; ps_n = (unsigned)psecond[b1];
-                    }
-                    if (__builtin_amdgcn_ballot_w64(no > 1)) {       // where chains merge: a second pending pair
-                        const int t1 = ps & 0x7fff, t2 = (ps >> 15) & 0x7fff;
-                        load_row6(isy ? z + 6 * ((row_idx[t1] >> 8) & 255) : Lw + (size_t)t1 * 36 + 6 * r, avec);
-                        pend(Lw + (size_t)(isy ? t1 : t2) * 36, no > 1);
-                    }
-                    BT_TW(sub[0]);
-                    // right-looking factorisation / substitution across the lanes, in L D L^T form: the dependent chain from one
-                    // pivot to the next is pivot -> 1 / d -> t = in[c] / d -> in[c + 1] -= t u -> next pivot (7 dependent
-                    // instructions); the reciprocal square roots that turn the columns into those of the Cholesky factor, and
-                    // the read-outs of the multipliers u_k = a_kc (raw: symmetric to the pivot row), are off that chain
-                    bool ok = true;
-                    T il[6];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        const T dpiv = readlane_f64(in[c], c);
-                        ok = ok && (dpiv > (T)0);
-                        const T rd = rcp_newton(dpiv);
-                        const T t = in[c] * rd;
-#pragma unroll
-                        for (int k = c + 1; k < 6; ++k) in[k] -= t * readlane_f64(in[c], k);
-                        il[c] = rsqrt_t<T>(dpiv);
-                    }
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) in[c] = lane == c ? il[c] : in[c] * il[c];      // the diagonal block keeps 1 / l_cc (lds_back_substitute)
-                    if (valid) store_row6(p, in);
-                    if (!ok && lane == 0) flags[0] = 1;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) __hip_atomic_store(&colready[q], l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    BT_TW(sub[1]);
-                } else if (l + 1 < nlev) {                           // (idle this level: still keep the look-ahead going)
-                    bool v1, y1; int r1, b1;
-                    lane_block(vrec.x, vrec.y, v1, y1, r1, b1);
-                    pfo_n = (unsigned)pfirst[b1]; ps_n = (unsigned)psecond[b1];
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-        } else if (hidx >= 0) {
-            // ================= helper waves: batch b = lazy updates and lazy y contributions of the columns of level b
-            const int h = hidx * 64 + lane, hs = nh * 64;
-            for (int b = 0; b + 1 < nlev; ++b) {
-                const int p0a = __builtin_amdgcn_readfirstlane(lrec[8 * b]), p0b = __builtin_amdgcn_readfirstlane(lrec[8 * b + 1]),
-                          p0c = __builtin_amdgcn_readfirstlane(lrec[8 * b + 2]), p1a = __builtin_amdgcn_readfirstlane(lrec[8 * b + 4]),
-                          p1b = __builtin_amdgcn_readfirstlane(lrec[8 * b + 5]), p1c = __builtin_amdgcn_readfirstlane(lrec[8 * b + 6]);
-                const int pnc = (p0b >> 24) & 3;
-                {
-                    const int need1 = pnc > 1 ? b + 1 : 0;
-                    for (;;) {
-                        const int f0 = __hip_atomic_load(&colready[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const int f1 = __hip_atomic_load(&colready[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const int fh = __hip_atomic_load(&hcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (f0 >= b + 1 && f1 >= need1 && fh >= nh * b) break;
-                        __builtin_amdgcn_s_sleep(1);
-                        for (int sl = 0; sl < xsleep; ++sl) __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                BT_TW(twait);
-                const int rows0 = ((p0c >> 16) & 0xffff) * 12, rows1 = rows0 + (pnc > 1 ? ((p1c >> 16) & 0xffff) * 12 : 0);      // half rows
-                for (int item = h; item < rows1; item += hs) {
-                    const bool sec = item >= rows0;
-                    const int idx = item - (sec ? rows0 : 0), t = idx / 12, rr = idx - 12 * t;
-                    const ushort4 tr = reinterpret_cast<const ushort4 *>(lazy)[((sec ? p1c : p0c) & 0xffff) + t];
-                    apply_update_half3<T>(Lw, tr.x, tr.y, tr.z, rr >> 1, rr & 1);
-                }
-                {
-                    const int ys0 = ((p0a >> 8) & 255) * 6, ys1 = ys0 + (pnc > 1 ? ((p1a >> 8) & 255) * 6 : 0);
-                    const int shift = ((rows1 + 63) >> 6) << 6;
-                    int first = h - shift;                       // (no division in the usual one-round case)
-                    if (shift > hs) first = (h - shift % hs + hs) % hs; else if (first < 0) first += hs;
-                    for (int item = first; item < ys1; item += hs) {
-                        const bool sec = item >= ys0;
-                        const int qq = item - (sec ? ys0 : 0);
-                        const int pj = (sec ? p1a : p0a) & 255, dposp = (sec ? p1b : p0b) & 0xffff, sb = qq / 6, r = qq - 6 * sb;
-                        const int rcv = row_idx[dposp + 1 + sb];
-                        if (rcv & (1 << 25)) continue;            // pending: the destination column's y lane takes it
-                        T lr[6], zr[6];
-                        load_row6(Lw + (size_t)(dposp + 1 + sb) * 36 + 6 * r, lr);
-                        load_row6(z + 6 * pj, zr);
-                        T acc = lr[0] * zr[0];
-#pragma unroll
-                        for (int k = 1; k < 6; ++k) acc += lr[k] * zr[k];
-                        lds_sub(z + 6 * (rcv & 255) + r, acc, (rcv & (1 << 24)) != 0);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_fetch_add(&hcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                BT_TW(twork);
-            }
-        }
-        __syncthreads();
-        if (PROF) tsweep = clock64() - tall;
-
-        int4 *bmeta = reinterpret_cast<int4 *>(zt + ((D + 1) & ~1));          // compact level table behind zt
-        for (int i = tid; i < nlev * kMaxLevelCols; i += nth) {          // (col, diag pos, #sub-blocks, barrier before this level)
-            int4 mm = reinterpret_cast<const int4 *>(pd.fz_meta)[2 * i];
-            mm.w = pd.bs_sync[i / kMaxLevelCols];
-            bmeta[i] = mm;
-        }
-        lds_back_substitute<T, false>(pd, Lw, z, zt, row_idx, col_ptr, bmeta, 1, tid, nth, nullptr);
-        for (int i = tid; i < D; i += nth) if (zt[i] != zt[i]) flags[1] = 1;
-        __syncthreads();
-        const bool failed = flags[0] != 0, has_nan = flags[1] != 0;
-        __syncthreads();
-        if (failed) {
-            for (int i = tid; i < D; i += nth) zt[i] = (T)0;
-            status = BT_SOLVE_CHOL_FAILED;
-            break;
-        }
-        if (!has_nan) break;
-        status = BT_SOLVE_RETRIED;
-    }
-    __syncthreads();
-    for (int i = tid; i < D; i += nth) a.dx[6 * pd.perm[i / 6] + i % 6] = (float)zt[i];
-    if (tid == 0) a.status[0] = status;
-    if (PROF && lane == 0) {        // measurement only: per-wave (waiting, working) cycles of the sweep
-        long long *o = reinterpret_cast<long long *>(a.status + 4) + 40 + wave * 2;
-        o[0] = twait; o[1] = twork + sub[0] + sub[1];
-        if (wave == 0 || wave == 2) {
-            long long *g = reinterpret_cast<long long *>(a.status + 4) + (wave ? 10 : 0);
-            g[0] = tload; g[1] = tsweep; g[2] = clock64() - tall;
-            g[3] = sub[0]; g[4] = sub[1]; g[5] = sub[2]; g[6] = twait; g[7] = twork; g[8] = 0;
-        }
-    }
-#undef BT_TW
-}
 
 // ------------------------------------------------------------------ refinement of float32-factor solves
 // Systems whose factor does not fit LDS as double are factored in float32 (k_solve_lds<float>, k_solve_global): dX is then
@@ -2721,17 +2425,6 @@ static bool use_pipe_solver(const PlanDev &pd) {
     return on != 0 && pd.fzp_ok != 0 && pd.fz_ok != 0 && solve_pipe_lds_bytes(pd) <= kLdsBudget;
 }
 
-// the column-per-wave variant of k_solve_pipe (round 4); BT_SOLVER_CHAIN=0: k_solve_pipe (measurement only)
-static bool chain_applies(const PlanDev &pd) {
-    static const int on = std::getenv("BT_SOLVER_CHAIN") ? std::atoi(std::getenv("BT_SOLVER_CHAIN")) : 0;
-    return on != 0 && use_pipe_solver(pd) && pd.fzp_ok == 2 && solve_chain_lds_bytes(pd) <= kLdsBudget;
-}
-
-static int chain_threads() {
-    static const int t = std::getenv("BT_CHAIN_THREADS") ? std::atoi(std::getenv("BT_CHAIN_THREADS")) : 768;   // measurement only
-    return t >= 192 && t <= 768 ? (t / 64) * 64 : 768;
-}
-
 static int solver_threads() {
     // 12 waves: enough helper threads for one round of update rows on banded systems, and a
     // 170-register budget per thread so that a whole 6x6 operand block can be in flight from LDS
@@ -2786,10 +2479,6 @@ int configure_kernels(const PlanDev &pd) {
     if (mode == 0 && use_pipe_solver(pd))
         if (raise_lds_limit(reinterpret_cast<const void *>(&k_solve_pipe<false>), solve_pipe_lds_bytes(pd)) != BT_OK ||
             raise_lds_limit(reinterpret_cast<const void *>(&k_solve_pipe<true>), solve_pipe_lds_bytes(pd)) != BT_OK)
-            return BT_EHIP;
-    if (mode == 0 && chain_applies(pd))
-        if (raise_lds_limit(reinterpret_cast<const void *>(&k_solve_chain<false>), solve_chain_lds_bytes(pd)) != BT_OK ||
-            raise_lds_limit(reinterpret_cast<const void *>(&k_solve_chain<true>), solve_chain_lds_bytes(pd)) != BT_OK)
             return BT_EHIP;
     if (mode == 0 && use_fused_solver(pd))
         if (raise_lds_limit(reinterpret_cast<const void *>(&k_solve_fused<false>), solve_fused_lds_bytes(pd, solver_threads())) != BT_OK ||
@@ -2897,9 +2586,7 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
                 if (evp) hipExtLaunchKernelGGL(kern, grid, block, lds, st, evp[6], evp[7], 0, pd, a);                        \
                 else hipLaunchKernelGGL(kern, grid, block, lds, st, pd, a);                                                  \
             } while (0)
-            if (mode == 0 && chain_applies(pd) && !prof)    BT_LAUNCH_S(k_solve_chain<false>, dim3(1), dim3(chain_threads()), solve_chain_lds_bytes(pd));
-            else if (mode == 0 && chain_applies(pd))        BT_LAUNCH_S(k_solve_chain<true>, dim3(1), dim3(chain_threads()), solve_chain_lds_bytes(pd));
-            else if (mode == 0 && use_pipe_solver(pd) && !prof)  BT_LAUNCH_S(k_solve_pipe<false>, dim3(1), dim3(768), solve_pipe_lds_bytes(pd));
+            if (mode == 0 && use_pipe_solver(pd) && !prof)  BT_LAUNCH_S(k_solve_pipe<false>, dim3(1), dim3(768), solve_pipe_lds_bytes(pd));
             else if (mode == 0 && use_pipe_solver(pd))      BT_LAUNCH_S(k_solve_pipe<true>, dim3(1), dim3(768), solve_pipe_lds_bytes(pd));
             else if (mode == 0 && use_fused_solver(pd) && !prof) BT_LAUNCH_S(k_solve_fused<false>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr));
             else if (mode == 0 && use_fused_solver(pd))     BT_LAUNCH_S(k_solve_fused<true>, dim3(1), dim3(nthr), solve_fused_lds_bytes(pd, nthr));

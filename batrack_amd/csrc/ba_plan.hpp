@@ -1,6 +1,7 @@
 // ba_plan.hpp — structure of one BA edge list, shared by the host planner
 // (ba_plan.cpp), the kernels (ba_kernels.hip) and the C ABI (ba_api.cpp).
 #pragma once
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <string>
@@ -159,7 +160,10 @@ struct bt_plan {
     // reuses the device buffer makes its table upload wait for it (the tables must not change under queued kernels)
     mutable void *last_stream = nullptr;
     mutable bool launched = false;
-    mutable void *ready = nullptr;                            // hipEvent_t behind a clone's copies on the plan stream (ba_api.cpp: mark_launch), else null
+    // hipEvent_t behind a clone's copies on the plan stream (ba_api.cpp: mark_launch), else null.  Atomic: two host threads may
+    // launch the same fresh clone; whoever finds the event complete CLAIMS it (exchange) before handing it back to the pool —
+    // handed back twice, two later clones would share one event.
+    mutable std::atomic<void *> ready{nullptr};
     size_t dev_cap = 0;
     bt::PlanDev dev{};
 

@@ -579,6 +579,7 @@ extern "C" int bt_ga_mat_to_se3(const float *mats, float *poses, int64_t T, void
 
 extern "C" int bt_ga_sample_disp_mono(const float *dmaps, const float *trajs_2d, float *out, int64_t T, int64_t N, int64_t S, int64_t H, int64_t W, void *stream) {
     if (!dmaps || !trajs_2d || !out || T < 1 || N < 1 || S < 1 || H < 1 || W < 1 || T > (1 << 24) || (double)T * (double)N * (double)S > 4e11) return BT_EINVAL;
+    if (H > 0x7fffffffll || W > 0x7fffffffll || N > 0x7fffffffll || S > 0x7fffffffll || (double)T * (double)H * (double)W > 9e18) return BT_EINVAL;   // (the kernel's ints)
     const long long total = (long long)T * N * S;
     hipLaunchKernelGGL(k_ga_sample_disp_mono, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        dmaps, trajs_2d, out, (int)T, (int)N, (int)S, (int)H, (int)W);

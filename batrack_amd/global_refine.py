@@ -109,7 +109,14 @@ class RefineLosses:
           jj = t + s - S // 2 (refine_net.py:92-97)
           dmaps [T,H,W,1] -> `trajs_disp_mono` [T,N,S] = 1 / max(bilinear sample of frame clamp(jj) at the track, 1e-2) by
                              bt_ga_sample_disp_mono (refine_net.py:99-110); `align_depth=True` first rescales the maps by
-                             their running medians as model/utils.py:268-312 does (on the host, where the reference does it)
+                             their running medians as model/utils.py:268-312 does (on the host, where the reference does it).
+                             The maps are sampled in FLOAT32 (the reference keeps results['dmaps'] float64 and samples and
+                             inverts in float64): `trajs_disp_mono` is within ~1e-7 relative of the reference's, tested at
+                             1e-5 of its largest entry — the losses it enters are float32 anyway
+          `pose`: as a rotation and a translation it is cams_T_world's; the quaternion's SIGN is the kernel's convention (w >= 0
+                             from the trace branch, i.e. for every rotation below 180 degrees) — pypose is not in this image,
+                             so its convention is unpinned; the camera-smoothness term reads the stored numbers and is
+                             invariant under a common sign, not under the sign of one pose
           parameters at the reference's initial values: trajs_scales = 1, frame_scales_ = 1 [T,gh,gw], frame_shifts_ = 0.
         `trajs_valid` is kept as an attribute (the reference reads it into `self.trajs_valid` and never uses it in a loss)."""
         import numpy as np

@@ -79,7 +79,7 @@ class ShardedBA:
     per-edge inputs (targets, weights) stay the full tensors on every rank — a rank's plan
     only touches the edges of its own track range."""
 
-    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, device, world=None, rank=None, group=None, exchange="rccl"):
+    def __init__(self, ii, jj, kk, n_buf, p_tot, fixedp, device, world=None, rank=None, group=None, exchange="rccl", status_every=16):
         from .plan import Plan, Stepper
         if exchange not in ("rccl", "ipc"):
             raise ValueError("exchange must be 'rccl' or 'ipc'")
@@ -97,8 +97,10 @@ class ShardedBA:
         self._xbuf, self._peers, self._epoch = None, None, 0
         # exchange='ipc': a pull that gave up waiting for a peer makes its step a no-op for the poses (the solver sees a failed
         # factorisation) and leaves BT_XCHG_TIMEOUT in the workspace; the status word is read back every `status_every` steps
-        # (one stream synchronisation) and in gather_patches, and a time-out raises on this rank
-        self.status_every = 16
+        # (one stream synchronisation: 0 = never inside step) and ALWAYS in gather_patches, i.e. once per update() of the caller
+        # (batrack.py:856-895 merges the patches after its 2 x ITER calls): a time-out is reported at the end of the update() it
+        # happened in, at the latest; a caller that steps without gathering calls check_exchange() itself at that point
+        self.status_every = int(status_every)
         if exchange == "ipc" and self.world > 1 and self.plan.n > 0:
             self._open_exchange()
 

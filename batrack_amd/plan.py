@@ -95,11 +95,12 @@ class Plan:
     @classmethod
     def shifted_any(cls, srcs, ii, jj, kk, n_buf, p_tot, fixedp, sync=True):
         """`shifted` against several candidate plans at once (bt_plan_create_shifted_any: one comparison pass and one host
-        wait for all of them).  Returns (plan, index of the source that matched) or (None, -1)."""
+        wait for all of them).  Returns (plan, the source plan that matched) or (None, None) — the plan itself, not a position:
+        candidates that were never uploaded are skipped here, so a position would not be one in the caller's list."""
         import torch
         srcs = [s for s in srcs if s.uploaded][:4]
         if not srcs or not (ii.is_cuda and ii.dtype == jj.dtype == kk.dtype == torch.int64 and jj.is_cuda and kk.is_cuda):
-            return None, -1
+            return None, None
         arrs = [a if a.is_contiguous() else a.contiguous() for a in (ii, jj, kk)]
         if sync:
             torch.cuda.current_stream(arrs[0].device).synchronize()
@@ -109,15 +110,16 @@ class Plan:
         rc = lib.bt_plan_create_shifted_any(handles, len(srcs), arrs[0].data_ptr(), arrs[1].data_ptr(), arrs[2].data_ptr(), arrs[0].numel(),
                                             int(n_buf), int(p_tot), int(fixedp), ctypes.byref(which), ctypes.byref(h))
         if rc > 0:
-            return None, -1
+            return None, None
         _lib.check(rc, "bt_plan_create_shifted_any")
         self = cls.__new__(cls)
         self._lib, self._h, self._keep = lib, h, None
         # (the clone's figures are its source's but for the two the shift moves: this is on the critical path of every frame)
-        src = srcs[which.value].info
+        matched = srcs[which.value]
+        src = matched.info
         self.info = dict(src, fixedp=int(fixedp), n_all=src["n_all"] + int(fixedp) - src["fixedp"])
         self.uploaded = True
-        return self, int(which.value)
+        return self, matched
 
     def __getattr__(self, name):
         info = self.__dict__.get("info")

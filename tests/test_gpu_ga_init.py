@@ -40,6 +40,27 @@ def test_from_results_derives_what_the_reference_derives(tag, align):
     assert np.array_equal(net.trajs_valid.cpu().numpy(), RES["trajs_valid"])
 
 
+def test_pose_rotation_against_the_matrices_themselves():
+    """The `pose` fixture comes through a stand-in for pypose's mat2SE3 (pypose is not in the image: parity unpinned, DESIGN §8
+    f-3), and that stand-in uses the same branch rule as the kernel.  Independent of both: the quaternion, turned back into a
+    matrix by scipy, IS the rotation block of cams_T_world (up to the quaternion's sign), the translation its last column."""
+    from scipy.spatial.transform import Rotation
+    from batrack_amd.global_refine import RefineLosses
+    net = RefineLosses.from_results(RES, "cuda:0", grid_size=4, loss_weight_dict=WEIGHTS, refine_intrinsics=True)
+    pose = net.pose.cpu().numpy().astype(np.float64)
+    cams = np.asarray(RES["cams_T_world"], np.float64).reshape(-1, 4, 4)
+    assert np.abs(np.linalg.norm(pose[:, 3:], axis=1) - 1).max() < 1e-6
+    assert np.abs(Rotation.from_quat(pose[:, 3:]).as_matrix() - cams[:, :3, :3]).max() < 2e-6
+    assert np.abs(pose[:, :3] - cams[:, :3, 3]).max() < 1e-6
+    # the camera-smoothness term differences the STORED numbers (refine_net.py:356-360): it is invariant under flipping the sign of
+    # every quaternion together, not of one — neighbouring poses must come out on the same hemisphere, as they do (w >= 0 from the
+    # trace branch for every rotation below 180 degrees)
+    assert (np.sum(pose[:-1, 3:] * pose[1:, 3:], axis=1) > 0).all()
+    base = float(net.cam_smooth_vec_loss())
+    net.pose.mul_(torch.tensor([1, 1, 1, -1, -1, -1, -1], dtype=net.pose.dtype, device=net.pose.device))
+    assert abs(float(net.cam_smooth_vec_loss()) - base) < 1e-6 * max(1.0, abs(base))
+
+
 def test_total_and_gradients_from_a_results_dictionary_match_the_reference():
     from batrack_amd.global_refine import RefineLosses
     net = RefineLosses.from_results(RES, "cuda:0", grid_size=4, loss_weight_dict=WEIGHTS, refine_intrinsics=True)

@@ -70,11 +70,15 @@ def test_one_of_several_candidate_sources_matches():
     other = Plan(ii0[perm], jj0[perm], kk0[perm], n_buf, p_tot, fixedp)          # the same size, another order: no shifted copy
     later = Plan(ii0 + 1, jj0 + 1, kk0 + 64, n_buf, p_tot, fixedp + 1)            # a shift by one frame of the same list
     ii2, jj2, kk2 = ii0 + 2, jj0 + 2, kk0 + 128
-    pl, which = Plan.shifted_any([other, src, later], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
-    assert pl is not None and which == 1
-    pl2, which2 = Plan.shifted_any([other, later, src], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
-    assert pl2 is not None and which2 == 1 and pl2.info == pl.info
-    assert Plan.shifted_any([other], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2) == (None, -1)
+    pl, matched = Plan.shifted_any([other, src, later], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
+    assert pl is not None and matched is src
+    pl2, matched2 = Plan.shifted_any([other, later, src], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
+    assert pl2 is not None and matched2 is later and pl2.info == pl.info
+    assert Plan.shifted_any([other], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2) == (None, None)
+    # a candidate that was never uploaded is skipped, and the source is still named by identity (not by a position in a filtered list)
+    host_only = Plan(g.ii, g.jj, g.kk, n_buf, p_tot, fixedp, upload=False)
+    pl3, matched3 = Plan.shifted_any([host_only, other, src], ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
+    assert pl3 is not None and matched3 is src
     fresh = Plan(ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
     assert pl.info == fresh.info
     f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=DEV)
