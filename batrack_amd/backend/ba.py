@@ -186,8 +186,25 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     P = _f32c(poses.data, "poses")
     if P.dim() != 3 or P.shape[0] != 1 or P.shape[-1] != 7:
         raise ValueError("poses must wrap a [1, N, 7] tensor (batch b = 1, ba.py:218)")
+    if patches.dim() == 5 and patches.shape[0] == 1 and patches.shape[2] == 3 and patches.shape[3] == patches.shape[4] and patches.shape[3] > 1:
+        # Patch size p > 1 (BA-Track itself uses 1, batrack.py:45).  The reference projects the patch's CENTRE pixel (ba.py:228-230:
+        # coords[..., p//2, p//2, :]), takes the depth prior at its first pixel (disps[:, kx, 0, 0], ba.py:307) and adds dZ to the
+        # whole disparity plane of the patch (ba.py:332-334).  A patch's disparity plane holds ONE value in the reference's callers
+        # (the tracker fills it per patch); for such patches that is the p = 1 step on the centres with the result broadcast
+        # back.  Planes that are not constant are refused: the clamp of ba.py:333 would act on each pixel separately.
+        pp = patches.shape[3]
+        disps = patches[:, :, 2]
+        if not bool((disps == disps[..., :1, :1]).all()):
+            raise NotImplementedError("BA_rgbd_droid: patches of size > 1 whose disparity plane is not constant over the patch")
+        centre = patches[:, :, :, pp // 2, pp // 2].contiguous()[..., None, None]
+        new_poses, out_c = BA_rgbd_droid(poses, centre, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda,
+                                         ii, jj, kk, bounds, ep=ep, PRINT=PRINT, fixedp=fixedp, structure_only=structure_only,
+                                         loss=loss, alpha=alpha)
+        out = patches.clone()
+        out[:, :, 2] = out_c[:, :, 2].expand(-1, -1, pp, pp)
+        return new_poses, out
     if patches.dim() < 3 or patches.shape[0] != 1 or patches.shape[2] != 3 or patches.numel() != 3 * patches.shape[1]:
-        raise ValueError("patches must be [1, P_tot, 3, 1, 1] (patch size 1, batrack.py:45)")
+        raise ValueError("patches must be [1, P_tot, 3, p, p] (batrack.py:45: p = 1)")
     if loss not in _lib.LOSS:
         raise NotImplementedError(loss)              # ba.py:98-99
     n_buf, p_tot, E = P.shape[1], patches.shape[1], ii.numel()

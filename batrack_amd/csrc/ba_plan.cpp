@@ -219,6 +219,14 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     if (n > kMaxFree) return BT_EUNSUPPORTED;
     if (!src_ok) return BT_EUNSUPPORTED;
     I.E = E_own;
+    // Tile counts from which the wave-per-tile kernels take THIS plan.  A rank's plan of a sharded solve (own_lo / own_hi) holds
+    // its share of the tiles: the thresholds shrink by that share, so that all ranks of a graph large enough for those kernels use
+    // them (and the same per-edge precision), instead of a rank falling back to the float64 tile kernel because ITS shard is small.
+    const auto shard_min = [&](int thr) {
+        if (E_own >= E || thr <= 1 || thr >= (1 << 29)) return thr;
+        return (int)std::max<int64_t>(1, ((int64_t)thr * E_own + E - 1) / E);
+    };
+    const int em_min_p = shard_min(edge_min_tiles()), st_min_p = shard_min(stream_min_tiles());
 
     BT_TICK("1");
     // unique tracks, ascending (ba.py:276); off = first position of a track's edges in the grouped order.
@@ -348,7 +356,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         static const int pm_env = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;
         const int64_t t64 = (m + kLanes - 1) / kLanes;
         if (env > 0) tcap = std::min<int>(kLanes, env);
-        else if (pm_env && !tcap_retry && t64 > 0 && t64 <= 96 && E_own >= 24 * (int64_t)m && t64 < std::min(edge_min_tiles(), stream_min_tiles()) / 4) tcap = 16;
+        else if (pm_env && !tcap_retry && t64 > 0 && t64 <= 96 && E_own >= 24 * (int64_t)m && t64 < std::min(em_min_p, st_min_p) / 4) tcap = 16;
     }
     if (dstats && tcap == kLanes) {                                // the device then writes the [slots][64] arrays and the wave cuts
         static const int pm_env2 = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;
@@ -391,7 +399,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     const int32_t T = (int32_t)pl->tile_trk0.size();
     I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
     pl->max_rows16 = (int)((6 * max_cams + 15) / 16 * 16);
-    if (tcap < kLanes && T >= std::min(std::min(edge_min_tiles(), stream_min_tiles()), 1024)) {
+    if (tcap < kLanes && T >= std::min(std::min(em_min_p, st_min_p), 1024)) {
         // the camera limit closed 16-track tiles early: the plan reached the tile count of the wave-per-tile kernels, whose
         // tables come from the [slots][64] arrays a small-tile plan does not have — or simply four times the CUs, where
         // spreading a graph over more workgroups has lost its point: lay it out again with 64 tracks per tile
@@ -1001,10 +1009,10 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // (local target camera | local pair << 8; the global pair id is tile_pairs[pair0 + local pair]); per (tile,
     // lane) the local source camera (one per track: ii = ix[kk], checked above); per tile one 32-byte record
     //   [0] ntrk | ncam << 8 | npair << 16 | flags << 24   [1] slot0  [2] nslot  [3] cam0  [4] pair0  [5] trk0
-    const bool want_stream_tables = want_slots && I.tiles >= std::min(edge_min_tiles(), stream_min_tiles());   // (they are made from the slot arrays)
-    const bool dev_wpt = dev_slots && I.tiles >= std::min(edge_min_tiles(), stream_min_tiles());               // (... where those are: on the device)
+    const bool want_stream_tables = want_slots && I.tiles >= std::min(em_min_p, st_min_p);   // (they are made from the slot arrays)
+    const bool dev_wpt = dev_slots && I.tiles >= std::min(em_min_p, st_min_p);               // (... where those are: on the device)
     pl->st_ok = want_stream_tables || dev_wpt ? 1 : 0;
-    pl->st_min = stream_min_tiles(); pl->em_min = edge_min_tiles();
+    pl->st_min = st_min_p; pl->em_min = em_min_p;
     pl->dev_wpt = dev_wpt ? 1 : 0;
     if (dev_wpt) {
         // the records but for the straddle flag (k_plan_slots adds it); slot_code, tile_la, it_edge and tile_sinfo are written
@@ -1060,7 +1068,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     //                                    repeat: this slot or a neighbour holds the same pair again (repeated observation)
     //   tile_rec[6] = it0, tile_rec[7] = log2 S | iterations << 8
     pl->em_ok = 0; pl->em_its = 0; pl->em_lgs = -1;
-    if (dev_wpt && I.tiles >= edge_min_tiles()) {
+    if (dev_wpt && I.tiles >= em_min_p) {
         // (the iteration counts follow from the tiles' slot and track counts; whether every tile is slot-uniform is k_plan_sinfo's
         //  verdict, read back by upload_plan: em_ok here is "as far as the host can tell")
         pl->em_ok = 1;
@@ -1080,7 +1088,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         if (!pl->em_ok) { for (int64_t t = 0; t < I.tiles; ++t) pl->tile_rec[(size_t)t * 8 + 6] = pl->tile_rec[(size_t)t * 8 + 7] = 0; pl->em_lgs = -1; }
         pl->em_its = pl->em_ok ? its : 0;
     }
-    if (want_stream_tables && I.tiles >= edge_min_tiles()) {
+    if (want_stream_tables && I.tiles >= em_min_p) {
         pl->em_ok = 1;
         int64_t its = 0;
         std::vector<int32_t> it0((size_t)I.tiles), lgS((size_t)I.tiles), nit((size_t)I.tiles);

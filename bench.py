@@ -239,6 +239,8 @@ def main():
         return steps, el
 
     steps, elapsed = timed(ba_iter, args.warmup, args.steps)
+    # the spread of that number: the same K steps five more times (each block between its own fences; `value` stays the first)
+    blocks = [1e3 * el / st_ for st_, el in (timed(ba_iter, 0, args.steps) for _ in range(5))]
     xrates = None
     if world > 1:
         # both exchanges for the record (the headline `value` is the one named in config.parallelism)
@@ -329,7 +331,7 @@ def main():
             extra["sliding_window"] = {"edges": int(wplan.E), "free_poses": int(wplan.n), "tiles": int(wplan.tiles), "jacobian_kernel": wplan.jacobian_kernel,
                                        "planned_on_device": bool(wplan.built_on_device), "step_us": round(wus, 1),
                                        "kernel_us": {k: round(1e3 * float(np.mean(v)), 2) for k, v in wacc.items() if np.mean(v) > 0}}
-            del wst, wplan
+            wst_keep = wst
         except Exception as e:                                   # (a record beside the headline number: never its failure)
             extra["sliding_window"] = {"error": repr(e)}
 
@@ -361,9 +363,27 @@ def main():
                                   "these kernel sources, not measured in this run")
         except Exception as e:
             traffic, traffic_source = None, f"profiles/pmc_k_tile.json unreadable ({e!r})"
-        roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        # ... and COLD: the graph's 5.6 MB live in L2 / Infinity Cache between the steps of the loop above; a 512 MB sweep
+        # between launches evicts them (L2 32 MB, Infinity Cache 256 MB), so this is the kernel reading its inputs from HBM
+        flush_buf = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+
+        def cold_tile_us(stp, call, reps=12):
+            ts = []
+            for _ in range(reps):
+                flush_buf.add_(1)
+                ts.append(1e3 * call(stp)["tile"])
+            return float(np.median(ts))
+        cold_us = cold_tile_us(stepper, lambda stp: stp.step_timed(P[0], X[0], mono, intr, tg, tg.stride(0), wp_l, P[1], X[1], *scal, False))
+        roofline = {"bound": "hbm", "kernel": plan.jacobian_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                    "algorithmic_bytes": alg_bytes, "kernel_us": round(kern_us["tile"], 3)}
+                    "algorithmic_bytes": alg_bytes, "kernel_us": round(kern_us["tile"], 3),
+                    "cold_kernel_us": round(cold_us, 3), "cold_frac": round(alg_bytes / (cold_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    "cold_how": "median of 12 launches, each behind a 512 MB read-modify-write sweep (L2 + Infinity Cache evicted)"}
+        if "sliding_window" in extra and "kernel_us" in extra["sliding_window"]:
+            try:
+                extra["sliding_window"]["cold_kernel_us_tile"] = round(cold_tile_us(None, lambda _: wst_keep.step_timed(Wp, Wx, Wm, Wi, Wt, 3, Ww, Wo, Wxo, *wscal, False)), 2)
+            except Exception as e:                               # (a record beside the headline number)
+                extra["sliding_window"]["cold_kernel_us_tile"] = repr(e)
 
         if not args.no_cpu_baseline:
             import oracle
@@ -438,6 +458,7 @@ def main():
                 lstep(LP[a], LX[a], Lm, Li, Lt, 3, Lw, LP[b], LX[b], *lscal, False)
             ls, lel = timed(large_iter, 5, 50)
             r = {"iterations_per_s": round(ls / lel, 2), "ms_per_step": round(1e3 * lel / ls, 4), "steps": ls,
+                 "iterations_per_s_blocks": [round(st_ / el, 2) for st_, el in (timed(large_iter, 0, 50) for _ in range(4))],
                  "edges_this_rank": int(lplan.E), "jacobian_kernel_this_rank": lplan.jacobian_kernel,
                  "edge_precision_this_rank": {8: "float64 per edge", 6: "mixed: float64 reprojection and residual, float32 Jacobians", 4: "float32 per edge"}[lplan.edge_precision],
                  "planned_on_device": bool(lplan.built_on_device)}
@@ -455,12 +476,38 @@ def main():
                 raise                                            # (but under N > 1 a rank that dropped out would leave the others waiting)
         del Lp, Lx, Lt, Lw
 
+    # The roofline of the Jacobian kernel where it can approach it: 8.4M edges (64 keyframes x 16384 tracks per frame x 8
+    # observations, the same generator), the kernel's own duration from HIP events, warm and behind the flush
+    if world == 1 and not args.no_large and roofline is not None:
+        try:
+            gb = graphgen.make_graph(64, 16384, 8, seed=args.seed)
+            Bp, Bx, Bm, Bi, Bt, Bw = (f32(a_) for a_ in (gb.poses, gb.patches, gb.mono_disp, gb.intrinsics, gb.targets3, gb.weights_pose))
+            bplan = Plan(*(torch.as_tensor(a_, device=dev) for a_ in (gb.ii, gb.jj, gb.kk)), Bp.shape[0], Bx.shape[0], 1)
+            bst = Stepper(bplan, dev)
+            Bo, Bxo = torch.empty_like(Bp), torch.empty_like(Bx)
+            bscal = (list(gb.bounds), 1e-4, 10.0, 0.05, "huber")
+            bcall = lambda _=None: bst.step_timed(Bp, Bx, Bm, Bi, Bt, 3, Bw, Bo, Bxo, *bscal, False)
+            for _ in range(3):
+                bcall()
+            warm = float(np.median([1e3 * bcall()["tile"] for _ in range(12)]))
+            cold = cold_tile_us(None, bcall)
+            balg = 40 * bplan.E + 20 * bplan.m + 72 * bplan.n_all
+            roofline["large"] = {"workload": f"64 keyframes, {bplan.E} edges, {bplan.m} tracks (make_graph(64, 16384, 8), seed {args.seed})",
+                                 "kernel": bplan.jacobian_kernel, "edge_precision": bplan.edge_precision, "algorithmic_bytes": balg,
+                                 "kernel_us": round(warm, 2), "achieved": round(balg / (warm * 1e-6) / 1e9, 1), "frac": round(balg / (warm * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "cold_kernel_us": round(cold, 2), "cold_frac": round(balg / (cold * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            del bst, bplan, Bp, Bx, Bt, Bw
+        except Exception as e:                                   # (a record beside the headline number: never its failure)
+            roofline["large"] = {"error": repr(e)}
+
     if rank == 0:
         out = {
             "metric": "BA iterations/s on 64-KF/128k-edge graph",
             "value": round(steps / elapsed, 2), "unit": "BA iterations/s",
             "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / steps, 5),
+            "ms_per_step_blocks": {"n": len(blocks), "min": round(min(blocks), 5), "median": round(float(np.median(blocks)), 5), "max": round(max(blocks), 5),
+                                   "what": "the same K steps timed five more times behind the headline block"},
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {g.n_frames} keyframes, {plan.E if world == 1 else len(g.ii)} edges, "
@@ -474,6 +521,10 @@ def main():
         }
         if large is not None:
             out["config"]["sharded_large" if world > 1 else "large_graph"] = large
+            if "iterations_per_s" in large:
+                # the edge work that shards, beside the headline (whose step is mostly the replicated solve): first-class
+                out["value_large"] = {"value": large["iterations_per_s"], "unit": "BA iterations/s", "workload": large["workload"],
+                                      "jacobian_kernel_this_rank": large.get("jacobian_kernel_this_rank")}
         if xrates is not None:
             out["config"]["exchange"] = exchange
             out["config"]["exchange_iterations_per_s"] = xrates

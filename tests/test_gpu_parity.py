@@ -104,6 +104,33 @@ def test_api_dual_iterations(name, fixedp):
     assert np.array_equal(hp.patches[0, :, :, 0, 0].cpu().numpy(), d["patches"].astype(np.float32))
 
 
+def test_patches_of_size_three_step_like_their_centres():
+    """Patch size p = 3 (ba.py:228-230 projects the centre pixel, :307 takes the prior at pixel (0, 0), :332-334 adds dZ to the whole
+    disparity plane): the step on [1, P, 3, 3, 3] patches with per-patch-constant disparity is the p = 1 step of the fixture — the
+    reference's float64 result — at every pixel; a plane that is not constant is refused."""
+    d = load("c1_rough")
+    hp = HipProblem(d)
+    p1 = hp.patches                                                           # [1, P, 3, 1, 1]
+    off = torch.tensor([-1.0, 0.0, 1.0], device=p1.device)
+    p3 = p1.repeat(1, 1, 1, 3, 3).clone()
+    p3[:, :, 0] += off[None, None, None, :]                                    # x, y of the neighbouring pixels: never read by the step
+    p3[:, :, 1] += off[None, None, :, None]
+    Gs, pat = hp.api_step("weights_pose", 2, False, patches=p3)
+    torch.cuda.synchronize()
+    assert tuple(pat.shape) == (1, d["patches"].shape[0], 3, 3, 3)
+    ref = d["ps_fp2.f64.patches_out"] if "ps_fp2.f64.patches_out" in d else None
+    one = hp.api_step("weights_pose", 2, False)
+    assert torch.equal(pat[:, :, 2], one[1][:, :, 2].expand(-1, -1, 3, 3))     # every pixel of the plane: the centre's new disparity
+    assert torch.equal(pat[:, :, :2], p3[:, :, :2])                            # x, y untouched
+    assert rel(Gs.data.cpu().numpy(), one[0].data.cpu().numpy()) < 1e-6
+    if ref is not None:
+        assert rel(pat[0, :, :, 1, 1].cpu().numpy(), ref) < tol(1e-6, 2e-5)
+    bad = p3.clone()
+    bad[0, 0, 2, 0, 0] += 0.1
+    with pytest.raises(NotImplementedError):
+        hp.api_step("weights_pose", 2, False, patches=bad)
+
+
 def test_strided_depth_prior_is_used_in_place():
     """The caller's prior is the view patches_local[:, :, mid, 2:] (batrack.py:866): stride S_local * 3 floats between
     patches.  Same result as a contiguous copy of it, and no copy is made (ABI field mono_stride)."""
