@@ -186,6 +186,10 @@ def lib():
     L.bt_plan_create_shifted.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ctypes.POINTER(vp)]
     L.bt_plan_create_shifted_any.restype = i32
     L.bt_plan_create_shifted_any.argtypes = [ctypes.POINTER(vp), i32, vp, vp, vp, i64, i64, i64, i64, ctypes.POINTER(i32), ctypes.POINTER(vp)]
+    L.bt_plan_create_shifted_spec.restype = i32
+    L.bt_plan_create_shifted_spec.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, vp, ctypes.POINTER(vp)]
+    L.bt_plan_spec_confirm.restype = i32
+    L.bt_plan_spec_confirm.argtypes = [vp]
     L.bt_plan_destroy.restype = None
     L.bt_plan_destroy.argtypes = [vp]
     L.bt_plan_pool_trim.restype = None

@@ -79,15 +79,36 @@ def _plan_lookup(ii, jj, kk, n_buf, p_tot, fixedp, device):
             return box["stepper"]
         if "error" in box and not isinstance(box["error"], Exception):
             raise box["error"]                    # KeyboardInterrupt and the like; ordinary errors are re-raised by the build below
-    stepper = Stepper(_build_plan(ii, jj, kk, n_buf, p_tot, fixedp, True), device)
+    pl, ws = _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, True)
+    stepper = Stepper(pl, device, ws)
     _store(key, stepper, ii, jj, kk)
     return stepper
 
 
-def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync):
+def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync, speculate=True):
     """A new plan: first as a shifted copy of one of the most recent plans (the caller's window in steady state repeats its
     edge list with all frame / patch indices moved up, batrack.py:189-212 — ~0.1 ms on the device), else from scratch
-    (host analysis, ~1 ms for the 138k-edge window)."""
+    (host analysis, ~1 ms for the 138k-edge window).  Returns (plan, workspace to share or None).
+
+    Steady state of the caller's window: the list is the one of an earlier update() moved up by as many frames as `fixedp`
+    moved (batrack.py:189-212, :858).  That is ASSUMED of the most recent plan whose fixedp differs by the shift that was right
+    last time (Plan.shifted_spec: the clone is enqueued with no synchronisation and no host wait, the comparison that proves the
+    assumption runs on the GPU beside it); BA_rgbd_droid confirms after it has enqueued the call's step and repeats the call on a
+    properly built plan where the assumption was wrong."""
+    if speculate and _LAST_SHIFT[0] is not None and os.environ.get("BT_PLAN_SHIFT", "1") != "0" and os.environ.get("BT_PLAN_SPECULATE", "1") != "0":
+        E, nb, pt, fp = ii.numel(), int(n_buf), int(p_tot), int(fixedp)
+        try:
+            cached = list(_CACHE.values())
+        except RuntimeError:
+            cached = []
+        for st, _ in reversed(cached):
+            inf = st.plan.info
+            if (inf["E"] == E and inf["n_buf"] == nb and inf["p_tot"] == pt and fp - inf["fixedp"] == _LAST_SHIFT[0]
+                    and not st.plan.__dict__.get("speculative")):
+                pl = Plan.shifted_spec(st.plan, ii, jj, kk, n_buf, p_tot, fixedp)
+                if pl is not None:
+                    return pl, st.ws
+                break
     if sync:
         # once, here: the index tensors must be complete before any of the builds below reads them on the plan stream
         # (Plan.shifted may return before it gets to synchronise, so nothing below relies on it having done so)
@@ -111,8 +132,17 @@ def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync):
             pl, matched = Plan.shifted_any(cands[:3], ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
             if pl is not None:
                 _LAST_SHIFT[0] = fp - matched.info["fixedp"]
-                return pl
-    return Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=False)
+                return pl, None
+    return Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=False), None
+
+
+def _discard(stepper):
+    """A plan whose speculation failed: out of every cache (and the shift that was assumed with it)."""
+    for k in [k for k, (st, _) in list(_CACHE.items()) if st is stepper]:
+        _CACHE.pop(k, None)
+    if _LAST[0] is not None and _LAST[0][8] is stepper:
+        _LAST[0] = None
+    _LAST_SHIFT[0] = None
 
 
 def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True):
@@ -145,7 +175,7 @@ def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True
             # the current device and stream are per host thread: the workspace is allocated and zero-filled on the stream
             # the steps will run on, so its accumulators are clear before the first of them whatever stream that is
             with torch.cuda.device(dev), torch.cuda.stream(caller_stream):
-                box["stepper"] = Stepper(_build_plan(ii, jj, kk, n_buf, p_tot, fixedp, False), dev)
+                box["stepper"] = Stepper(_build_plan(ii, jj, kk, n_buf, p_tot, fixedp, False, speculate=False)[0], dev)
         except BaseException as e:                              # reported (or retried in the open) by _plan_for
             box["error"] = e
 
@@ -236,6 +266,11 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
                                                        float(alpha), _lib.LOSS[loss], so, lm_trk)
         if PRINT:
             print("BA_rgbd_droid: PRINT is not implemented in batrack_amd (debug only, ba.py:244-245)")
+        if stepper.plan.__dict__.get("speculative") and not stepper.plan.confirm():
+            # the list was no shifted copy after all: what was just enqueued is void (the inputs are untouched) — once more, properly
+            _discard(stepper)
+            return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda, ii, jj, kk, bounds,
+                                 ep=ep, PRINT=False, fixedp=fixedp, structure_only=structure_only, loss=loss, alpha=alpha)
         return (poses, out_patches) if so else (SE3(poses_out), out_patches)
     Pc = P.contiguous()
     pat = patches.reshape(p_tot, 3).contiguous()
@@ -262,6 +297,10 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
                  bounds, lmbda, ep, alpha, loss, so, lmbda_per_track=lm_trk)
     if PRINT:
         print("BA_rgbd_droid: PRINT is not implemented in batrack_amd (debug only, ba.py:244-245)")
+    if stepper.plan.__dict__.get("speculative") and not stepper.plan.confirm():
+        _discard(stepper)
+        return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda, ii, jj, kk, bounds,
+                             ep=ep, PRINT=False, fixedp=fixedp, structure_only=structure_only, loss=loss, alpha=alpha)
     out_patches = patches_out.view(1, p_tot, 3, 1, 1)
     if so:
         return poses, out_patches

@@ -449,6 +449,132 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
     return BT_OK;
 }
 
+// The clone of `src` for a list shifted by di frames / dk patches: tables copied and shifted on the plan stream `cs` (the new list's
+// packed words, d_words, behind them), no host wait — the plan carries the event its first launches are ordered behind.
+static int clone_shifted(const bt_plan *src, const uint64_t *d_words, int64_t E, int64_t fixedp, int64_t di, int64_t dk, hipStream_t cs, bt_plan **out) {
+    ApiTick tick;
+    const PackBuffers &pb_unused = pack_buffers(); (void)pb_unused;
+    bt_plan *pl = plan_pool().take();
+    if (!pl) return BT_ENOMEM;
+    pl->info = src->info; pl->info.fixedp = fixedp; pl->info.n_all = src->info.n_all + di;
+    pl->ws = src->ws; pl->off = src->off; pl->dev_bytes = src->dev_bytes; pl->pk_off = src->pk_off;
+    pl->n_act_words = src->n_act_words; pl->n_tile_ij = src->n_tile_ij;
+    pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
+    pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
+    pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->st_ok = src->st_ok; pl->st_min = src->st_min; pl->em_min = src->em_min; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
+    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->dev_slots = 0; pl->dev_wpt = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds; pl->k_hi = src->k_hi >= 0 ? src->k_hi + dk : -1;
+    size_t cap = 0;
+    hipEvent_t reuse_after = nullptr;
+    void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);
+    if (!d) { plan_pool().give(pl); return BT_ENOMEM; }
+    const bool waited = !reuse_after || hipStreamWaitEvent(cs, reuse_after, 0) == hipSuccess;
+    if (!waited) (void)hipEventSynchronize(reuse_after);
+    dev_pool().give_event(reuse_after);
+    char *nb = static_cast<char *>(d);
+    const char *ob = static_cast<const char *>(src->dev_base);
+    const PlanOffsets &O = pl->off;
+    auto I32 = [&](size_t off) { return reinterpret_cast<int32_t *>(nb + off); };
+    int rc = BT_OK;
+    // the tables as they are, the new packed edge list behind them, then the ones that hold absolute frame / patch numbers
+    if (hipMemcpyAsync(nb, ob, src->pk_off, hipMemcpyDeviceToDevice, cs) != hipSuccess ||
+        hipMemcpyAsync(nb + pl->pk_off, d_words, (size_t)E * sizeof(uint64_t), hipMemcpyDeviceToDevice, cs) != hipSuccess)
+        rc = BT_EHIP;
+    if (rc == BT_OK)
+        rc = launch_plan_shift(I32(O.kx), (int)pl->info.m, I32(O.tkx), (int)pl->info.tiles * kLanes, I32(O.tij), pl->n_tile_ij, I32(O.pi), I32(O.pj),
+                               (int)pl->info.pairs, reinterpret_cast<const uint32_t *>(ob + O.ab), reinterpret_cast<uint32_t *>(nb + O.ab), I32(O.ar),
+                               pl->n_act_words, (int)di, (int)dk, cs);
+    // no host wait for the copies: the plan's first launches are ordered behind this event on whatever stream they use
+    hipEvent_t ready = rc == BT_OK ? dev_pool().take_event() : nullptr;
+    if (rc == BT_OK && (!ready || hipEventRecord(ready, cs) != hipSuccess)) {
+        dev_pool().give_event(ready); ready = nullptr;
+        if (hipStreamSynchronize(cs) != hipSuccess) rc = BT_EHIP;
+    }
+    tick("shifted: copies enqueued");
+    if (rc != BT_OK) { (void)hipStreamSynchronize(cs); dev_pool().release(d, cap, false, nullptr); plan_pool().give(pl); return rc; }
+    pl->ready = ready;
+    pl->dev_base = d;
+    pl->dev_cap = cap;
+    bind_pointers(pl, d);
+    rc = configure_kernels(pl->dev);
+    tick("shifted: configure kernels");
+    if (rc != BT_OK) { bt_plan_destroy(pl); return rc; }
+    *out = pl;
+    return BT_OK;
+}
+
+// Verdicts of speculative clones: pinned / device int pairs handed out round robin (a plan's verdict is read by
+// bt_plan_spec_confirm right after its first step; sixteen unconfirmed speculative plans at a time are sixteen more than the
+// caller has)
+struct SpecSlots {
+    int *h = nullptr;                                                        // pinned, mapped: the comparison kernel writes its verdict there
+    hipEvent_t ev_in = nullptr;                                              // orders the plan stream behind the caller's stream
+    unsigned next = 0;
+    bool ensure() {
+        if (h && ev_in) return true;
+        return (h || hipHostMalloc(reinterpret_cast<void **>(&h), 16 * 2 * sizeof(int), hipHostMallocMapped) == hipSuccess) &&
+               (ev_in || hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess);
+    }
+};
+static SpecSlots &spec_slots() { static SpecSlots s; return s; }
+static std::mutex &spec_mutex() { static std::mutex m; return m; }
+
+int bt_plan_create_shifted_spec(const bt_plan *src, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                                int64_t n_buf, int64_t p_tot, int64_t fixedp, void *in_stream, bt_plan **out) {
+    if (!out) return BT_EINVAL;
+    *out = nullptr;
+    if (!src || !ii || !jj || !kk || E <= 0) return BT_EINVAL;
+    if (n_buf > 32768 || p_tot > (int64_t)0x7fffffff || n_buf <= 0 || p_tot % n_buf != 0) return BT_NO_MATCH;
+    if (!src->dev_base || !src->pk_off || src->e_all != E || src->info.E != E || src->info.n_buf != n_buf || src->info.p_tot != p_tot) return BT_NO_MATCH;
+    if (src->spec_ev) return BT_NO_MATCH;                                        // (an unconfirmed speculation is no source)
+    const int64_t di = fixedp - src->info.fixedp, dk = di * (p_tot / n_buf);
+    // every number the clone's tables will hold stays inside the caller's buffers, whatever the new list turns out to be
+    if (di <= 0 || di >= 32768 || src->info.n_all + di > n_buf || src->k_hi < 0 || src->k_hi + dk >= p_tot) return BT_NO_MATCH;
+    ApiTick tick;
+    PackBuffers &pb = pack_buffers();
+    if (!pb.ensure((size_t)E)) return BT_ENOMEM;
+    int *h_flag;
+    hipStream_t cs = copy_stream();
+    {
+        std::lock_guard<std::mutex> g(spec_mutex());
+        SpecSlots &ss = spec_slots();
+        if (!ss.ensure()) return BT_ENOMEM;
+        h_flag = ss.h + 2 * (ss.next++ % 16);
+        // the index tensors are complete when `in_stream` gets here: the plan stream waits for that, the host does not
+        if (hipEventRecord(ss.ev_in, static_cast<hipStream_t>(in_stream)) != hipSuccess || hipStreamWaitEvent(cs, ss.ev_in, 0) != hipSuccess) {
+            if (hipStreamSynchronize(static_cast<hipStream_t>(in_stream)) != hipSuccess) return BT_EHIP;
+        }
+    }
+    const uint64_t *old_words = reinterpret_cast<const uint64_t *>(static_cast<const char *>(src->dev_base) + src->pk_off);
+    const uint64_t delta = ((uint64_t)dk << 32) | ((uint64_t)di << 16) | (uint64_t)di;
+    h_flag[0] = 0; h_flag[1] = 0;
+    hipEvent_t spec_ev = dev_pool().take_event();
+    if (!spec_ev) return BT_ENOMEM;
+    const bool ok = launch_pack_match_expect(ii, jj, kk, E, n_buf, p_tot, old_words, delta, pb.d_words, h_flag, cs) == BT_OK &&
+                    hipEventRecord(spec_ev, cs) == hipSuccess;
+    if (!ok) { (void)hipStreamSynchronize(cs); dev_pool().give_event(spec_ev); return BT_EHIP; }
+    tick("speculative shift: pack + match enqueued");
+    bt_plan *pl = nullptr;
+    const int rc = clone_shifted(src, pb.d_words, E, fixedp, di, dk, cs, &pl);
+    if (rc != BT_OK) { (void)hipEventSynchronize(spec_ev); dev_pool().give_event(spec_ev); return rc; }
+    pl->spec_ev = spec_ev; pl->spec_flag = h_flag;
+    *out = pl;
+    return BT_OK;
+}
+
+int bt_plan_spec_confirm(bt_plan *pl) {
+    if (!pl) return BT_EINVAL;
+    if (!pl->spec_ev) return BT_OK;
+    hipEvent_t ev = static_cast<hipEvent_t>(pl->spec_ev);
+    const bool waited = hipEventSynchronize(ev) == hipSuccess;
+    dev_pool().give_event(ev);
+    pl->spec_ev = nullptr;
+    if (!waited) return BT_EHIP;
+    const int differs = pl->spec_flag[0], bad = pl->spec_flag[1];
+    pl->spec_flag = nullptr;
+    if (bad) return BT_EINVAL;
+    return differs ? BT_NO_MATCH : BT_OK;
+}
+
 // The plan of a list that is a shifted copy of ONE of up to four earlier plans' lists (the caller's cache, most likely first):
 // packed once, compared with every candidate in the same queue, one synchronisation for all of them (a candidate that does not
 // match used to cost a round trip of its own: with a keyframe stride of 2 every other update of the replay paid one).  The clone's
@@ -505,52 +631,7 @@ int bt_plan_create_shifted_any(const bt_plan *const *srcs, int nsrc, const int64
         if (which) *which = idx[q];
     }
     if (!src) return BT_NO_MATCH;
-    bt_plan *pl = plan_pool().take();
-    if (!pl) return BT_ENOMEM;
-    pl->info = src->info; pl->info.fixedp = fixedp; pl->info.n_all = src->info.n_all + di;
-    pl->ws = src->ws; pl->off = src->off; pl->dev_bytes = src->dev_bytes; pl->pk_off = src->pk_off;
-    pl->n_act_words = src->n_act_words; pl->n_tile_ij = src->n_tile_ij;
-    pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
-    pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
-    pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->st_ok = src->st_ok; pl->st_min = src->st_min; pl->em_min = src->em_min; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
-    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->dev_slots = 0; pl->dev_wpt = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds;
-    size_t cap = 0;
-    hipEvent_t reuse_after = nullptr;
-    void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);
-    if (!d) { plan_pool().give(pl); return BT_ENOMEM; }
-    const bool waited = !reuse_after || hipStreamWaitEvent(cs, reuse_after, 0) == hipSuccess;
-    if (!waited) (void)hipEventSynchronize(reuse_after);
-    dev_pool().give_event(reuse_after);
-    char *nb = static_cast<char *>(d);
-    const char *ob = static_cast<const char *>(src->dev_base);
-    const PlanOffsets &O = pl->off;
-    auto I32 = [&](size_t off) { return reinterpret_cast<int32_t *>(nb + off); };
-    int rc = BT_OK;
-    // the tables as they are, the new packed edge list behind them, then the ones that hold absolute frame / patch numbers
-    if (hipMemcpyAsync(nb, ob, src->pk_off, hipMemcpyDeviceToDevice, cs) != hipSuccess ||
-        hipMemcpyAsync(nb + pl->pk_off, pb.d_words, (size_t)E * sizeof(uint64_t), hipMemcpyDeviceToDevice, cs) != hipSuccess)
-        rc = BT_EHIP;
-    if (rc == BT_OK)
-        rc = launch_plan_shift(I32(O.kx), (int)pl->info.m, I32(O.tkx), (int)pl->info.tiles * kLanes, I32(O.tij), pl->n_tile_ij, I32(O.pi), I32(O.pj),
-                               (int)pl->info.pairs, reinterpret_cast<const uint32_t *>(ob + O.ab), reinterpret_cast<uint32_t *>(nb + O.ab), I32(O.ar),
-                               pl->n_act_words, (int)di, (int)dk, cs);
-    // no host wait for the copies: the plan's first launches are ordered behind this event on whatever stream they use
-    hipEvent_t ready = rc == BT_OK ? dev_pool().take_event() : nullptr;
-    if (rc == BT_OK && (!ready || hipEventRecord(ready, cs) != hipSuccess)) {
-        dev_pool().give_event(ready); ready = nullptr;
-        if (hipStreamSynchronize(cs) != hipSuccess) rc = BT_EHIP;
-    }
-    tick("shifted: copies enqueued");
-    if (rc != BT_OK) { (void)hipStreamSynchronize(cs); dev_pool().release(d, cap, false, nullptr); plan_pool().give(pl); return rc; }
-    pl->ready = ready;
-    pl->dev_base = d;
-    pl->dev_cap = cap;
-    bind_pointers(pl, d);
-    rc = configure_kernels(pl->dev);
-    tick("shifted: configure kernels");
-    if (rc != BT_OK) { bt_plan_destroy(pl); return rc; }
-    *out = pl;
-    return BT_OK;
+    return clone_shifted(src, pb.d_words, E, fixedp, di, dk, cs, out);
 }
 
 int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
@@ -563,6 +644,7 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
 
 void bt_plan_destroy(bt_plan *pl) {
     if (!pl) return;
+    if (pl->spec_ev) { (void)hipEventSynchronize(static_cast<hipEvent_t>(pl->spec_ev)); dev_pool().give_event(static_cast<hipEvent_t>(pl->spec_ev)); pl->spec_ev = nullptr; pl->spec_flag = nullptr; }
     if (void *r = pl->ready.exchange(nullptr, std::memory_order_acq_rel)) {
         // (copies of a clone that was never launched may still be queued on the plan stream: the buffer's next owner writes it
         //  on that same stream, behind them)

@@ -234,6 +234,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     int32_t m = 0;
     pl->kx.clear();
     pl->trk_win_lo = kmin <= kmax ? kmin : 0;
+    pl->k_hi = kmax;
     pl->trk_win.assign(kmin <= kmax ? (size_t)(kmax - kmin + 1) : 0, -1);
     static thread_local std::vector<int32_t> off_scratch;        // (a million tracks: no fresh pages per plan)
     std::vector<int32_t> &off = off_scratch;

@@ -165,6 +165,9 @@ struct bt_plan {
     // handed back twice, two later clones would share one event.
     mutable std::atomic<void *> ready{nullptr};
     size_t dev_cap = 0;
+    int64_t k_hi = -1;                                        // largest patch index the plan's tables hold (bt_plan_create_shifted_spec checks k_hi + dk < p_tot)
+    void *spec_ev = nullptr;                                  // hipEvent_t behind the verdict of a speculative clone (bt_plan_spec_confirm), else null
+    int *spec_flag = nullptr;                                 // its two pinned ints: list differs / index out of range
     bt::PlanDev dev{};
 
     // Back to the state of a new object, but with the vectors' capacity kept: destroyed plans are recycled
@@ -186,7 +189,7 @@ struct bt_plan {
         max_rows16 = 16;
         ws = bt::WsLayout{};
         dev_base = nullptr; dev_cap = 0;
-        last_stream = nullptr; launched = false; ready = nullptr;
+        last_stream = nullptr; launched = false; ready = nullptr; k_hi = -1; spec_ev = nullptr; spec_flag = nullptr;
         dev = bt::PlanDev{};
     }
 };
@@ -217,6 +220,10 @@ int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
                     const DevPlanStats *dstats = nullptr);
 // the same packing on the device (plan_pack.hip): `out` E words and `bad` one int (set to 1 on an index out of range), device memory
 int launch_shift_match(const uint64_t *nw, const uint64_t *ow, int64_t E, int *out, void *stream);
+// pack the list into `out` and set host_flags[0] unless word[e] == ow[e] + delta for every edge, host_flags[1] on an index out of
+// range (bt_plan_create_shifted_spec; host_flags: device-visible pinned memory, cleared by the caller)
+int launch_pack_match_expect(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
+                             const uint64_t *ow, uint64_t delta, uint64_t *out, int *host_flags, void *stream);
 int launch_plan_shift(int32_t *kx, int m, int32_t *tile_kx, int nkx, int32_t *tile_ij, int nij, int32_t *pair_i, int32_t *pair_j, int P,
                       const uint32_t *old_bits, uint32_t *new_bits, int32_t *new_rank, int nwords, int df, int dk, void *stream);
 int launch_pack_edges(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,

@@ -76,6 +76,29 @@ __global__ __launch_bounds__(1024) void k_act_shift(const uint32_t *old_bits, ui
     for (int w = w0; w < w1; ++w) { new_rank[w] = run; run += __popc(new_bits[w]); }
 }
 
+// Pack the new list (as k_pack_edges) and compare it with the old packed list plus `delta` in the same pass; the verdict goes
+// straight into pinned host memory (flags[0]: the lists differ, flags[1]: an index out of range) — one launch instead of
+// memset + pack + compare + copy back (each HIP call is ~8 us of host time, which is what this path is made of).
+__global__ __launch_bounds__(256) void k_pack_match_expect(const long long *ii, const long long *jj, const long long *kk, long long E, long long n_buf, long long p_tot,
+                                                           const unsigned long long *ow, unsigned long long delta, unsigned long long *out, int *flags) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long long i = ii[e], j = jj[e], k = kk[e];
+    if (i < 0 || j < 0 || i >= n_buf || j >= n_buf || k < 0 || k >= p_tot) { flags[1] = 1; flags[0] = 1; out[e] = 0; return; }
+    const unsigned long long w = ((unsigned long long)k << 32) | ((unsigned long long)i << 16) | (unsigned long long)j;
+    out[e] = w;
+    if (w - ow[e] != delta) flags[0] = 1;
+}
+
+int launch_pack_match_expect(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
+                             const uint64_t *ow, uint64_t delta, uint64_t *out, int *host_flags, void *stream) {
+    hipLaunchKernelGGL(k_pack_match_expect, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long *>(ii), reinterpret_cast<const long long *>(jj), reinterpret_cast<const long long *>(kk),
+                       (long long)E, (long long)n_buf, (long long)p_tot, reinterpret_cast<const unsigned long long *>(ow), (unsigned long long)delta,
+                       reinterpret_cast<unsigned long long *>(out), host_flags);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
 int launch_shift_match(const uint64_t *nw, const uint64_t *ow, int64_t E, int *out, void *stream) {
     hipLaunchKernelGGL(k_shift_match, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const unsigned long long *>(nw), reinterpret_cast<const unsigned long long *>(ow), (long long)E, out);

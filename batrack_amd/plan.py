@@ -121,6 +121,44 @@ class Plan:
         self.uploaded = True
         return self, matched
 
+    @classmethod
+    def shifted_spec(cls, src, ii, jj, kk, n_buf, p_tot, fixedp):
+        """The plan of a list ASSUMED to be `src`'s shifted by fixedp - src.fixedp frames (bt_plan_create_shifted_spec): no
+        synchronisation, no host wait — the comparison that proves the assumption runs on the GPU beside the clone's copies.
+        The plan can be stepped at once; `confirm()` must be called before its results are used (it returns False where the
+        assumption was wrong: discard the plan and what it computed).  None where the shift is not of that form."""
+        import torch
+        if not (src.uploaded and ii.is_cuda and jj.is_cuda and kk.is_cuda and ii.dtype == jj.dtype == kk.dtype == torch.int64
+                and ii.is_contiguous() and jj.is_contiguous() and kk.is_contiguous()):
+            return None
+        h = ctypes.c_void_p()
+        # (the raw handle of the current stream: building a torch.cuda.Stream object for it costs more than the C call's share)
+        stream = torch._C._cuda_getCurrentRawStream(ii.device.index if ii.device.index is not None else torch.cuda.current_device())
+        rc = src._lib.bt_plan_create_shifted_spec(src._h, ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii.numel(), int(n_buf), int(p_tot),
+                                                  int(fixedp), stream, ctypes.byref(h))
+        if rc > 0:
+            return None
+        _lib.check(rc, "bt_plan_create_shifted_spec")
+        self = cls.__new__(cls)
+        self._lib, self._h, self._keep = src._lib, h, (ii, jj, kk)       # (the index tensors are read by kernels still queued)
+        s = src.info
+        self.info = dict(s, fixedp=int(fixedp), n_all=s["n_all"] + int(fixedp) - s["fixedp"])
+        self.uploaded = True
+        self.speculative = True
+        return self
+
+    def confirm(self):
+        """True: the plan is the list's plan (always, unless it came from `shifted_spec`).  False: the speculation failed."""
+        if not self.__dict__.get("speculative"):
+            return True
+        rc = self._lib.bt_plan_spec_confirm(self._h)
+        self.speculative = False
+        self._keep = None
+        if rc > 0:
+            return False
+        _lib.check(rc, "bt_plan_spec_confirm")
+        return True
+
     def __getattr__(self, name):
         info = self.__dict__.get("info")
         if info is not None and name in info:
@@ -186,14 +224,19 @@ def _raw_stream(device):
 class Stepper:
     """A plan bound to a device: owns the workspace, fills bt_ba_args, launches."""
 
-    def __init__(self, plan, device):
+    def __init__(self, plan, device, ws=None):
         import torch
         if not plan.uploaded:
             raise RuntimeError("plan was built host-only")
         self.plan = plan
         self.device = torch.device(device)
-        # zero-filled: the accumulators must start clear (bt_ba_workspace_init); every step leaves them clear
-        self.ws = torch.zeros(max(plan.workspace_bytes, 256), dtype=torch.uint8, device=self.device)
+        # zero-filled: the accumulators must start clear (bt_ba_workspace_init); every step leaves them clear.  `ws`: the
+        # workspace of another stepper whose plan has the same workspace layout (a shifted clone and its source), used on the
+        # same stream: every step leaves it as it found it, so the two can take turns
+        if ws is not None and ws.numel() >= max(plan.workspace_bytes, 256) and ws.device == self.device:
+            self.ws = ws
+        else:
+            self.ws = torch.zeros(max(plan.workspace_bytes, 256), dtype=torch.uint8, device=self.device)
         self._args = _lib.BaArgs()
         self._lib = _lib.lib()
         self._ops = None if _USE_CTYPES else _lib.torch_ops()

@@ -107,6 +107,20 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
  * match costs a round trip of its own through bt_plan_create_shifted.  *which (optional) = index of the source that matched.
  * The clone's tables are copied on the library's plan stream without a host wait; the plan's first launches are ordered
  * behind them whatever stream they are given. */
+/* The same, SPECULATIVELY, with no host wait at all.  The caller's sliding window shifts its edge list by a whole number of
+ * frames and fixedp moves along (batrack.py:189-212, :858): the shift is df = fixedp - src.fixedp frames and dk = df * (p_tot /
+ * n_buf) patches.  The clone is made for THAT shift — copies and shift kernels enqueued on the plan stream behind an event
+ * recorded on `in_stream` (the stream that produced the index tensors: no synchronisation of it either) — while a kernel compares
+ * the packed list with src's under the same assumption and leaves its verdict in pinned memory.  The plan is usable at once; what it
+ * computes is meaningless (but memory-safe: every index it holds is inside the caller's buffers) unless the verdict is good, so
+ * the caller launches its first step, then calls bt_plan_spec_confirm — by then the verdict has usually arrived — and on BT_NO_MATCH
+ * destroys the plan, builds the list's plan with bt_plan_create and repeats the step (the inputs of a step are never modified).
+ * BT_NO_MATCH from the create call itself: the shift is not of that form (no speculation possible).  src as for the above. */
+int bt_plan_create_shifted_spec(const bt_plan *src, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                                int64_t n_buf, int64_t p_tot, int64_t fixedp, void *in_stream, bt_plan **out);
+/* BT_OK: the plan is what bt_plan_create would have built (or was not speculative); BT_NO_MATCH: it is not — destroy it; BT_EINVAL:
+ * the new list holds an index outside [0, n_buf) / [0, p_tot).  Waits for the verdict if it has not arrived. */
+int bt_plan_spec_confirm(bt_plan *plan);
 int bt_plan_create_shifted_any(const bt_plan *const *srcs, int nsrc, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
                                int64_t n_buf, int64_t p_tot, int64_t fixedp, int *which, bt_plan **out);
 

@@ -96,6 +96,91 @@ def test_one_of_several_candidate_sources_matches():
         assert a[2] == b[2] == 0 and rel(a[0], b[0]) < 1e-6 and rel(a[1], b[1]) < 1e-6
 
 
+def test_speculative_clone_steps_like_a_fresh_plan_and_a_wrong_guess_is_found_out():
+    """bt_plan_create_shifted_spec: the clone for the shift fixedp implies, enqueued with no host wait; the verdict of the
+    comparison arrives behind it.  Right guess: confirm() is True and the step equals a fresh plan's.  Wrong guess (the list is
+    another one of the same length): the plan is still safe to step — every index it holds is inside the buffers — and
+    confirm() says False."""
+    g, fixedp = window()
+    T = lambda a: torch.as_tensor(np.asarray(a, np.int64), device=DEV)
+    n_buf, p_tot = g.poses.shape[0], g.patches.shape[0]
+    M = p_tot // n_buf
+    ii0, jj0, kk0 = T(g.ii), T(g.jj), T(g.kk)
+    src = Plan(ii0, jj0, kk0, n_buf, p_tot, fixedp)
+    ii2, jj2, kk2 = ii0 + 2, jj0 + 2, kk0 + 2 * M
+    f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=DEV)
+    poses = f32(np.roll(g.poses, 2, axis=0)); patches = f32(np.roll(g.patches, 2 * M, axis=0))
+    g.mono_disp_shifted = np.roll(g.mono_disp, 2 * M, axis=0)
+    g.intrinsics = np.roll(g.intrinsics, 2, axis=0)
+    fresh = step_with(Plan(ii2, jj2, kk2, n_buf, p_tot, fixedp + 2), g, ii2, jj2, kk2, poses, patches)
+    rel = lambda x, y: np.linalg.norm(x.astype(np.float64) - y) / np.linalg.norm(y)
+    for _ in range(3):
+        pl = Plan.shifted_spec(src, ii2, jj2, kk2, n_buf, p_tot, fixedp + 2)
+        assert pl is not None and pl.speculative
+        out = step_with(pl, g, ii2, jj2, kk2, poses, patches)              # stepped BEFORE the verdict is asked for
+        assert pl.confirm() and not pl.speculative and pl.confirm()
+        assert out[2] == fresh[2] == 0 and rel(out[0], fresh[0]) < 1e-6 and rel(out[1], fresh[1]) < 1e-6
+    # a list of the same length that is NOT the shifted one (two edges swapped targets): found out, and harmless to have stepped
+    jj_bad = jj2.clone()
+    jj_bad[[5, 9]] = jj_bad[[9, 5]] + 0
+    if bool((jj_bad == jj2).all()):
+        jj_bad[5] = jj_bad[5] - 1 if int(jj_bad[5]) > 0 else jj_bad[5] + 1
+    pl = Plan.shifted_spec(src, ii2, jj_bad, kk2, n_buf, p_tot, fixedp + 2)
+    assert pl is not None
+    step_with(pl, g, ii2, jj_bad, kk2, poses, patches)
+    assert pl.confirm() is False
+    # shifts that are not of the assumed form are not speculated on at all
+    assert Plan.shifted_spec(src, ii0, jj0, kk0, n_buf, p_tot, fixedp) is None                 # fixedp did not move
+    assert Plan.shifted_spec(src, ii2, jj2, kk2, n_buf, p_tot, fixedp + n_buf) is None          # beyond the pose buffer
+
+
+def test_a_wrong_guess_inside_BA_rgbd_droid_is_repeated_on_a_proper_plan(monkeypatch):
+    """Forced mis-speculation through the drop-in entry point: a cached plan of the right size and fixedp distance whose list is
+    NOT the new list's shifted copy.  The call must come back with the result of a properly built plan."""
+    from batrack_amd.backend import ba as hip_ba
+    from batrack_amd.backend.lietorch import SE3
+    g, fixedp = window(seed=9)
+    T = lambda a: torch.as_tensor(np.asarray(a, np.int64), device=DEV)
+    f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=DEV)
+    n_buf, p_tot = g.poses.shape[0], g.patches.shape[0]
+    M = p_tot // n_buf
+    ii0, jj0, kk0 = T(g.ii), T(g.jj), T(g.kk)
+    perm = torch.randperm(ii0.numel(), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    iiB, jjB, kkB = (ii0[perm] + 2).contiguous(), (jj0[perm] + 2).contiguous(), (kk0[perm] + 2 * M).contiguous()     # same edges, shifted AND reordered
+    poses0, patches0 = f32(g.poses)[None], f32(g.patches)[None, :, :, None, None]
+    poses2, patches2 = f32(np.roll(g.poses, 2, axis=0))[None], f32(np.roll(g.patches, 2 * M, axis=0))[None, :, :, None, None]
+    mono0, mono2 = f32(g.mono_disp)[None, :, None], f32(np.roll(g.mono_disp, 2 * M, axis=0))[None, :, None]
+    intr0, intr2 = f32(g.intrinsics)[None], f32(np.roll(g.intrinsics, 2, axis=0))[None]
+    t3 = f32(g.targets3)[None]
+    w = f32(g.weights_pose)[None]
+    t3B, wB = t3[:, perm].contiguous(), w[:, perm].contiguous()
+    call = lambda P, X, mo, K, tg, ww, a, b, c, fp: hip_ba.BA_rgbd_droid(SE3(P), X, mo, K, tg[..., :2], tg[..., 2:], ww, 1e-4, a, b, c, list(g.bounds),
+                                                                          ep=10, fixedp=fp, structure_only=False, loss="huber", alpha=0.05)
+    monkeypatch.setenv("BT_PLAN_SPECULATE", "0")
+    hip_ba.clear_plan_cache()
+    want = call(poses2, patches2, mono2, intr2, t3B, wB, iiB, jjB, kkB, fixedp + 2)
+    torch.cuda.synchronize()
+    want = (want[0].data.clone(), want[1].clone())
+    monkeypatch.setenv("BT_PLAN_SPECULATE", "1")
+    hip_ba.clear_plan_cache()
+    call(poses0, patches0, mono0, intr0, t3, w, ii0, jj0, kk0, fixedp)        # the cached plan the guess will be made from
+    hip_ba._LAST_SHIFT[0] = 2                                                   # "the shift that was right last time"
+    tried = {"n": 0}
+    real_spec = Plan.shifted_spec.__func__
+
+    def spec(cls, *a, **k):
+        r = real_spec(cls, *a, **k)
+        tried["n"] += r is not None
+        return r
+    monkeypatch.setattr(Plan, "shifted_spec", classmethod(spec))
+    got = call(poses2, patches2, mono2, intr2, t3B, wB, iiB, jjB, kkB, fixedp + 2)
+    torch.cuda.synchronize()
+    assert tried["n"] == 1 and hip_ba._LAST_SHIFT[0] is None                    # the guess was made, found wrong, and forgotten
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    assert rel(got[0].data, want[0]) < 1e-6 and rel(got[1], want[1]) < 1e-6
+    hip_ba.clear_plan_cache()
+
+
 def test_lists_that_are_no_shift_are_refused():
     g, fixedp = window()
     T = lambda a: torch.as_tensor(np.asarray(a, np.int64), device=DEV)
@@ -121,12 +206,18 @@ def test_sequence_replay_uses_shifted_plans_and_gives_the_same_trajectory(monkey
         monkeypatch.setenv("BT_PLAN_SHIFT", mode)
         hip_ba.clear_plan_cache()
         made = {"shifted": 0, "built": 0}
-        real_shifted, real_init = Plan.shifted_any.__func__, Plan.__init__
+        real_shifted, real_spec, real_init = Plan.shifted_any.__func__, Plan.shifted_spec.__func__, Plan.__init__
 
         def shifted(cls, *a, **k):
             r = real_shifted(cls, *a, **k)
             made["shifted"] += r[0] is not None
             return r
+
+        def spec(cls, *a, **k):                                    # (steady state: the clone is made on the ASSUMPTION of the shift)
+            r = real_spec(cls, *a, **k)
+            made["shifted"] += r is not None
+            return r
+        monkeypatch.setattr(Plan, "shifted_spec", classmethod(spec))
 
         def init(self, *a, **k):
             made["built"] += 1
