@@ -93,56 +93,125 @@ __device__ __forceinline__ void ga_iproj(float x, float y, float d, const float 
     P[0] = (x - K[2]) / K[0] * depth; P[1] = (y - K[3]) / K[1] * depth; P[2] = depth;
 }
 
-constexpr int kGaStrip = 256;           // tracks n per workgroup of k_ga_pairwise
+// ---- the rigidity term's tracks, staged two by two.
+// A SUPER-TRACK p is the tracks 2p and 2p + 1 of the (query frame, slot); its numbers sit in four float4 arrays of LDS so
+// that both tracks of a partner arrive as the two halves of packed-float32 operands (v_pk_add_f32 / v_pk_fma_f32):
+//   L[5 p + 0] = (Xs0, Xs1, Ys0, Ys1)   + 1 = (Zs0, Zs1, Xm0, Xm1)   + 2 = (Ym0, Ym1, Zm0, Zm1)   + 3 = (vis0, vis1, static0, static1)
+//   + 4 = (disparity above iproj's clamp: slot 0, slot 1, centre 0, centre 1 — read by the backward only)
+// (a record is 80 B: one address per partner, the reads are immediate offsets, and 16 consecutive lanes' 16 B words fall
+//  into 16 different bank groups because 5 is odd)
+// (s: the point at the slot, m: at the centre slot; vis is zeroed where the mono disparity fails its test or the track does
+// not exist — N odd — so the pair mask min(vis vis', static static') > 0.5 is refine_net.py:213-217's three tests in one).
+// A thread owns one super-track and meets a partner super-track per step: two 4 x 16 B LDS reads feed FOUR track pairs
+// (16 B of LDS per pair instead of 40), every difference / square / sum is one packed instruction per two pairs.
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int kGaStrip = 256;           // super-tracks (2 tracks each) per workgroup of the pairwise kernels
+
+__device__ __forceinline__ f2 ga_fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+struct GaSuper { float4 *rec; };
+constexpr int kGaRec = 5;              // float4 per super-track
+
+__device__ __forceinline__ void ga_stage(const bt_ga_args &a, const float *mono_scaled, int i, int s, int mid, const float *Ks, const float *Km,
+                                         const GaSuper &L, int M) {
+    const int N = (int)a.N, S = (int)a.S;
+    const bool half = a.half_disp != 0;
+    for (int p = threadIdx.x; p < M; p += blockDim.x) {
+        float Ps[2][3] = {{0, 0, 0}, {0, 0, 0}}, Pm[2][3] = {{0, 0, 0}, {0, 0, 0}}, vis[2] = {0, 0}, sta[2] = {0, 0}, oks[2] = {0, 0}, okm[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = 2 * p + h;
+            if (n < N) {
+                const size_t es = ((size_t)i * N + n) * S + s, em = ((size_t)i * N + n) * S + mid;
+                ga_iproj(a.trajs_2d[2 * es], a.trajs_2d[2 * es + 1], mono_scaled[es], Ks, Ps[h]);
+                ga_iproj(a.trajs_2d[2 * em], a.trajs_2d[2 * em + 1], mono_scaled[em], Km, Pm[h]);
+                vis[h] = ga_disp(a.trajs_disp_mono, es, half) > 1e-2f ? a.trajs_vis[es] : 0.0f;
+                sta[h] = a.trajs_static[es];
+                oks[h] = mono_scaled[es] > 1e-2f ? 1.0f : 0.0f;       // (iproj clamps the disparity there: no gradient below)
+                okm[h] = mono_scaled[em] > 1e-2f ? 1.0f : 0.0f;
+            }
+        }
+        float4 *r = L.rec + kGaRec * p;
+        r[0] = make_float4(Ps[0][0], Ps[1][0], Ps[0][1], Ps[1][1]);
+        r[1] = make_float4(Ps[0][2], Ps[1][2], Pm[0][0], Pm[1][0]);
+        r[2] = make_float4(Pm[0][1], Pm[1][1], Pm[0][2], Pm[1][2]);
+        r[3] = make_float4(vis[0], vis[1], sta[0], sta[1]);
+        r[4] = make_float4(oks[0], oks[1], okm[0], okm[1]);
+    }
+}
+
+// one own track (its six coordinates and two mask factors) against the two tracks of a partner super-track
+struct GaOwn { float xs, ys, zs, xm, ym, zm, vis, sta; };
+struct GaPartner { f2 xs, ys, zs, xm, ym, zm, vis, sta; };
+
+__device__ __forceinline__ GaPartner ga_partner(const float4 *r) {
+    const float4 qa = r[0], qb = r[1], qc = r[2], qd = r[3];
+    GaPartner q;
+    q.xs = f2{qa.x, qa.y}; q.ys = f2{qa.z, qa.w}; q.zs = f2{qb.x, qb.y};
+    q.xm = f2{qb.z, qb.w}; q.ym = f2{qc.x, qc.y}; q.zm = f2{qc.z, qc.w};
+    q.vis = f2{qd.x, qd.y}; q.sta = f2{qd.z, qd.w};
+    return q;
+}
+template <int H>
+__device__ __forceinline__ GaOwn ga_own(const GaPartner &q) {
+    GaOwn o;
+    o.xs = q.xs[H]; o.ys = q.ys[H]; o.zs = q.zs[H]; o.xm = q.xm[H]; o.ym = q.ym[H]; o.zm = q.zm[H]; o.vis = q.vis[H]; o.sta = q.sta[H];
+    return o;
+}
+
+// masked |d_s - d_mid| of own track o with the partner's two tracks (refine_net.py:205-222).  Hardware square roots (1 ulp):
+// the IEEE-exact sequence is ten instructions per root, two roots per pair
+__device__ __forceinline__ f2 ga_pair_loss(const GaOwn &o, const GaPartner &q) {
+    const f2 dxs = q.xs - o.xs, dys = q.ys - o.ys, dzs = q.zs - o.zs;
+    const f2 dxm = q.xm - o.xm, dym = q.ym - o.ym, dzm = q.zm - o.zm;
+    const f2 ss = ga_fma2(dzs, dzs, ga_fma2(dys, dys, dxs * dxs)), sq = ga_fma2(dzm, dzm, ga_fma2(dym, dym, dxm * dxm));
+    const f2 ds = f2{__builtin_amdgcn_sqrtf(ss.x), __builtin_amdgcn_sqrtf(ss.y)}, dm = f2{__builtin_amdgcn_sqrtf(sq.x), __builtin_amdgcn_sqrtf(sq.y)};
+    const f2 df = ds - dm, pv = q.vis * o.vis, pt = q.sta * o.sta;
+    f2 r;
+    r.x = fminf(pv.x, pt.x) > 0.5f ? fabsf(df.x) : 0.0f;
+    r.y = fminf(pv.y, pt.y) > 0.5f ? fabsf(df.y) : 0.0f;
+    return r;
+}
 
 __global__ __launch_bounds__(kGaStrip) void k_ga_pairwise(bt_ga_args a, const float *mono_scaled, double *losses) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[16];
-    const int T = (int)a.T, N = (int)a.N, S = (int)a.S, mid = S / 2;
-    const int qi = blockIdx.x / S, s = blockIdx.x % S, n0 = blockIdx.y * kGaStrip;
+    const int T = (int)a.T, N = (int)a.N, S = (int)a.S, mid = S / 2, M = (N + 1) >> 1;
+    const int qi = blockIdx.x / S, s = blockIdx.x % S;
     const int i = (int)a.query[qi];
     const long long jraw = a.jj[(size_t)i * S + s];
     if (jraw < 0 || jraw >= T || s == mid) return;             // t_mask, and the centre slot's own difference is zero
-    // all N tracks of the slot and of the centre slot: point (3) | point at the centre slot (3) | vis, static, mono-ok
-    float4 *Ps = reinterpret_cast<float4 *>(sm), *Pm = Ps + N;
-    float2 *Vs = reinterpret_cast<float2 *>(Pm + N);
+    GaSuper L;
+    L.rec = reinterpret_cast<float4 *>(sm);
     const long long jm = a.jj[(size_t)i * S + mid];
-    const float *Ks = a.intrinsics + 4 * (size_t)jraw;
-    const float *Km = a.intrinsics + 4 * (size_t)(jm < 0 ? 0 : (jm > T - 1 ? T - 1 : jm));
-    const bool half = a.half_disp != 0;
-    for (int m = threadIdx.x; m < N; m += blockDim.x) {
-        const size_t es = ((size_t)i * N + m) * S + s, em = ((size_t)i * N + m) * S + mid;
-        float P[3];
-        ga_iproj(a.trajs_2d[2 * es], a.trajs_2d[2 * es + 1], mono_scaled[es], Ks, P);
-        const bool okd = ga_disp(a.trajs_disp_mono, es, half) > 1e-2f;
-        Ps[m] = make_float4(P[0], P[1], P[2], okd ? 1.0f : 0.0f);
-        ga_iproj(a.trajs_2d[2 * em], a.trajs_2d[2 * em + 1], mono_scaled[em], Km, P);
-        Pm[m] = make_float4(P[0], P[1], P[2], 0.0f);
-        Vs[m] = make_float2(a.trajs_vis[es], a.trajs_static[es]);
-    }
+    ga_stage(a, mono_scaled, i, s, mid, a.intrinsics + 4 * (size_t)jraw, a.intrinsics + 4 * (size_t)(jm < 0 ? 0 : (jm > T - 1 ? T - 1 : jm)), L, M);
     __syncthreads();
-    const int n = n0 + threadIdx.x;
+    const int j = blockIdx.y * kGaStrip + threadIdx.x;
     float acc = 0.0f;
-    if (n < N) {
-        // |d_s(n, m) - d_mid(n, m)| is symmetric in (n, m) and zero on the diagonal: thread n takes the partners
-        // m = n + 1 .. n + N / 2 (mod N) — every unordered pair once, the same trip count for every thread — and the sum
-        // counts each pair twice (for even N the antipodal partner is met from both ends: half weight).
-        const float4 ps = Ps[n], pm = Pm[n];
-        const float2 vn = Vs[n];
-        const int half_n = N >> 1;
-        int m = n + 1 >= N ? n + 1 - N : n + 1;
-#pragma unroll 4
-        for (int k = 1; k <= half_n; ++k) {
-            const float4 qs = Ps[m], qm = Pm[m];
-            const float2 vm = Vs[m];
-            const float dxs = ps.x - qs.x, dys = ps.y - qs.y, dzs = ps.z - qs.z;
-            const float dxm = pm.x - qm.x, dym = pm.y - qm.y, dzm = pm.z - qm.z;
-            // hardware square roots (1 ulp): the IEEE-exact sequence is ten instructions per root, two roots per pair
-            const float ds = __builtin_amdgcn_sqrtf(dxs * dxs + dys * dys + dzs * dzs), dm = __builtin_amdgcn_sqrtf(dxm * dxm + dym * dym + dzm * dzm);
-            const bool mk = vn.x * vm.x > 0.5f && vn.y * vm.y > 0.5f && ps.w * qs.w > 0.5f;
-            const float wgt = (2 * k == N) ? 1.0f : 2.0f;
-            acc += mk ? wgt * fabsf(ds - dm) : 0.0f;
-            m = m + 1 >= N ? 0 : m + 1;
+    if (j < M) {
+        // |d_s(n, m) - d_mid(n, m)| is symmetric in (n, m) and zero on the diagonal.  Super-track j takes the pair inside it
+        // and the partners p = j + 1 .. j + M / 2 (mod M) — every unordered pair of super-tracks once, the same trip count
+        // for every thread — and the sum counts each pair twice (for even M the antipodal partner is met from both ends:
+        // half weight).
+        const GaPartner me = ga_partner(L.rec + kGaRec * j);
+        const GaOwn oa = ga_own<0>(me), ob = ga_own<1>(me);
+        acc = 2.0f * ga_pair_loss(oa, me).y;
+        const int half_m = M >> 1, full = (M & 1) ? half_m : half_m - 1;
+        int p = j + 1 >= M ? 0 : j + 1;
+        const float4 *rp = L.rec + kGaRec * p;                 // (walked by increments: no multiply per step)
+        f2 acc2 = {0.0f, 0.0f};
+#pragma unroll 2
+        for (int k = 0; k < full; ++k) {
+            const GaPartner q = ga_partner(rp);
+            acc2 += ga_pair_loss(oa, q) + ga_pair_loss(ob, q);
+            ++p; rp += kGaRec;
+            if (p >= M) { p = 0; rp = L.rec; }
+        }
+        acc += 2.0f * (acc2.x + acc2.y);
+        if (!(M & 1) && half_m >= 1) {
+            const GaPartner q = ga_partner(rp);
+            const f2 r = ga_pair_loss(oa, q) + ga_pair_loss(ob, q);
+            acc += r.x + r.y;
         }
     }
     const float bs = block_sum(acc, red);
@@ -234,69 +303,140 @@ __global__ __launch_bounds__(256) void k_ga_bwd_spatial(bt_ga_args a, const floa
     for (int n = threadIdx.x; n < N; n += blockDim.x) g_ts[((size_t)t * N + n) * S + s] -= gmean;
 }
 
-__global__ __launch_bounds__(kGaStrip) void k_ga_bwd_pairwise(bt_ga_args a, const float *mono_scaled, float w_rg, float *g_ms, float *g_intr) {
+// d/d(points) of the masked |d_s - d_mid| of own track o with the partner's two tracks: cs = sign / d_s * (o_s - q_s) is what
+// the pair adds to o's slot point (and, negated, to the partner's), cm = -sign / d_mid * (o_m - q_m) to o's centre point.
+// 1 / distance by v_rsq on max(|.|^2, 1e-30): a zero distance has zero differences, its products vanish; sign(0) = 0 as
+// torch.sign has it
+__device__ __forceinline__ void ga_pair_grad(const GaOwn &o, const GaPartner &q, float wgt, f2 (&cs)[3], f2 (&cm)[3]) {
+    const f2 dxs = o.xs - q.xs, dys = o.ys - q.ys, dzs = o.zs - q.zs;
+    const f2 dxm = o.xm - q.xm, dym = o.ym - q.ym, dzm = o.zm - q.zm;
+    const f2 ss = ga_fma2(dzs, dzs, ga_fma2(dys, dys, dxs * dxs)), sq = ga_fma2(dzm, dzm, ga_fma2(dym, dym, dxm * dxm));
+    const f2 is = f2{__builtin_amdgcn_rsqf(fmaxf(ss.x, 1e-30f)), __builtin_amdgcn_rsqf(fmaxf(ss.y, 1e-30f))};
+    const f2 im = f2{__builtin_amdgcn_rsqf(fmaxf(sq.x, 1e-30f)), __builtin_amdgcn_rsqf(fmaxf(sq.y, 1e-30f))};
+    const f2 dd = ga_fma2(ss, is, -(sq * im));                                   // d_s - d_mid
+    const f2 pv = q.vis * o.vis, pt = q.sta * o.sta;
+    f2 sg;
+    sg.x = (fminf(pv.x, pt.x) > 0.5f && dd.x != 0.0f) ? __builtin_copysignf(wgt, dd.x) : 0.0f;
+    sg.y = (fminf(pv.y, pt.y) > 0.5f && dd.y != 0.0f) ? __builtin_copysignf(wgt, dd.y) : 0.0f;
+    const f2 as = sg * is, am = -(sg * im);
+    cs[0] = as * dxs; cs[1] = as * dys; cs[2] = as * dzs;
+    cm[0] = am * dxm; cm[1] = am * dym; cm[2] = am * dzm;
+}
+
+// lane l <- lane (l + 1) mod 64
+__device__ __forceinline__ float ga_rol1(float x) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x134 /* wave_rol:1 */, 0xf, 0xf, false));
+}
+
+// The O(Q S N^2) term's gradient, every pair of tracks ONCE: what a pair adds to one of its tracks it takes from the other.
+// A WAVE owns a block of 64 super-tracks (lane = super-track) and meets the blocks J = I + 1 .. I + Mb / 2 (mod Mb) — and its
+// own — one after the other; inside a block pair lane l meets partner (l + t) mod 64 at step t, so the 12 sums of the
+// PARTNER's tracks can live in registers too: they move one lane down per step (v_mov_b32_dpp wave_rol:1) and arrive, after
+// the block's 64 steps, complete.  Only then — and for the own sums after the walk — does a lane turn the twelve numbers into
+// d/d(mono_scaled) of the two tracks' slot and centre-slot disparities (a point is its ray times the depth: linear in the
+// sums, so partial sums may leave separately) with four global float atomics, and into its share of the intrinsics'
+// gradient.  (An LDS float atomic per step and value — the straightforward scatter — measured 25x slower than the whole
+// walk, ≈250 cycles per wave instruction; per-track sums in LDS flushed per block pair cost the second workgroup per CU.
+// Round 4: every thread walked all N partners — twice the pairs, one track pair per 40 B of LDS.)
+#ifndef BT_GA_BWD_WAVES
+#define BT_GA_BWD_WAVES 4
+#endif
+__global__ __launch_bounds__(kGaStrip, BT_GA_BWD_WAVES) void k_ga_bwd_pairwise(bt_ga_args a, const float *mono_scaled, float w_rg, float *g_ms, float *g_intr) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[16];
-    const int T = (int)a.T, N = (int)a.N, S = (int)a.S, mid = S / 2;
-    const int qi = blockIdx.x / S, s = blockIdx.x % S, n0 = blockIdx.y * kGaStrip;
+    const int T = (int)a.T, N = (int)a.N, S = (int)a.S, mid = S / 2, M = (N + 1) >> 1, Mb = (M + 63) >> 6, Mp = Mb << 6;
+    const int qi = blockIdx.x / S, s = blockIdx.x % S;
     const int i = (int)a.query[qi];
     const long long jraw = a.jj[(size_t)i * S + s];
     if (jraw < 0 || jraw >= T || s == mid) return;
-    float4 *Ps = reinterpret_cast<float4 *>(sm), *Pm = Ps + N;
-    float2 *Vs = reinterpret_cast<float2 *>(Pm + N);
+    GaSuper L;
+    L.rec = reinterpret_cast<float4 *>(sm);                      // [Mp] (super-tracks M .. Mp - 1: tracks that do not exist)
     const long long jm = a.jj[(size_t)i * S + mid];
     const float *Ks = a.intrinsics + 4 * (size_t)jraw;
     const float *Km = a.intrinsics + 4 * (size_t)(jm < 0 ? 0 : (jm > T - 1 ? T - 1 : jm));
-    const bool half = a.half_disp != 0;
-    for (int m = threadIdx.x; m < N; m += blockDim.x) {
-        const size_t es = ((size_t)i * N + m) * S + s, em = ((size_t)i * N + m) * S + mid;
-        float P[3];
-        ga_iproj(a.trajs_2d[2 * es], a.trajs_2d[2 * es + 1], mono_scaled[es], Ks, P);
-        const bool okd = ga_disp(a.trajs_disp_mono, es, half) > 1e-2f;
-        Ps[m] = make_float4(P[0], P[1], P[2], okd ? 1.0f : 0.0f);
-        ga_iproj(a.trajs_2d[2 * em], a.trajs_2d[2 * em + 1], mono_scaled[em], Km, P);
-        Pm[m] = make_float4(P[0], P[1], P[2], 0.0f);
-        Vs[m] = make_float2(a.trajs_vis[es], a.trajs_static[es]);
-    }
+    ga_stage(a, mono_scaled, i, s, mid, Ks, Km, L, Mp);
     __syncthreads();
-    const int n = n0 + threadIdx.x;
-    if (n >= N && !g_intr) return;
-    const int nn = n < N ? n : N - 1;                        // (threads past N stay for the workgroup sums of the intrinsics' gradient)
-    const float4 ps = Ps[nn], pm = Pm[nn];
-    const float2 vn = Vs[nn];
-    float gs0 = 0.0f, gs1 = 0.0f, gs2 = 0.0f, gm0 = 0.0f, gm1 = 0.0f, gm2 = 0.0f;
-#pragma unroll 4
-    for (int m = 0; m < (n < N ? N : 0); ++m) {
-        const float4 qs = Ps[m], qm = Pm[m];
-        const float2 vm = Vs[m];
-        const float dxs = ps.x - qs.x, dys = ps.y - qs.y, dzs = ps.z - qs.z;
-        const float dxm = pm.x - qm.x, dym = pm.y - qm.y, dzm = pm.z - qm.z;
-        const float ss = dxs * dxs + dys * dys + dzs * dzs, sq = dxm * dxm + dym * dym + dzm * dzm;
-        const float is = ss > 0.0f ? __builtin_amdgcn_rsqf(ss) : 0.0f, im = sq > 0.0f ? __builtin_amdgcn_rsqf(sq) : 0.0f;   // 1 / distance (0 at distance 0)
-        const float dd = ss * is - sq * im;                                      // d_s - d_mid
-        const bool mk = vn.x * vm.x > 0.5f && vn.y * vm.y > 0.5f && ps.w * qs.w > 0.5f;
-        const float sg = mk ? (dd > 0.0f ? 1.0f : (dd < 0.0f ? -1.0f : 0.0f)) : 0.0f;
-        const float as = sg * is, am = sg * im;
-        gs0 += as * dxs; gs1 += as * dys; gs2 += as * dzs;
-        gm0 -= am * dxm; gm1 -= am * dym; gm2 -= am * dzm;
-    }
-    // each pair sits twice in the mean over [S, N, N]; a point is its ray times the depth, depth = 1 / max(disparity, 1e-2)
+    // each pair sits twice in the mean over [S, N, N]
     const float c = 2.0f * w_rg / (float)((double)a.Q * S * N * N);
-    const size_t es = ((size_t)i * N + nn) * S + s, em = ((size_t)i * N + nn) * S + mid;
-    if (n < N) {
-        if (mono_scaled[es] > 1e-2f) atomicAdd(&g_ms[es], -c * (gs0 * ps.x + gs1 * ps.y + gs2 * ps.z) * ps.z);
-        if (mono_scaled[em] > 1e-2f) atomicAdd(&g_ms[em], -c * (gm0 * pm.x + gm1 * pm.y + gm2 * pm.z) * pm.z);
+    const int lane = threadIdx.x & 63, I = blockIdx.y * (kGaStrip / 64) + (threadIdx.x >> 6);
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // the sums acc (slot x y z, centre x y z, each for the two tracks) of super-track p, times sgn, leave the workgroup
+    auto emit = [&](int p, const float (&acc)[12], float sgn) {
+        const float4 *r = L.rec + kGaRec * p;
+        const float4 qa = r[0], qb = r[1], qc = r[2], ok = r[4];
+        const float k = -c * sgn;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float psx = h ? qa.y : qa.x, psy = h ? qa.w : qa.z, psz = h ? qb.y : qb.x;
+            const float pmx = h ? qb.w : qb.z, pmy = h ? qc.y : qc.x, pmz = h ? qc.w : qc.z;
+            const float gs0 = k * acc[h], gs1 = k * acc[2 + h], gs2 = k * acc[4 + h], gm0 = k * acc[6 + h], gm1 = k * acc[8 + h], gm2 = k * acc[10 + h];
+            const size_t es = ((size_t)i * N + (2 * p + h)) * S + s, em = ((size_t)i * N + (2 * p + h)) * S + mid;
+            // depth = 1 / max(disparity, 1e-2): d P / d d = -P D above the clamp (the factor -1 is in k)
+            if ((h ? ok.y : ok.x) != 0.0f) atomicAdd(&g_ms[es], (gs0 * psx + gs1 * psy + gs2 * psz) * psz);
+            if ((h ? ok.w : ok.z) != 0.0f) atomicAdd(&g_ms[em], (gm0 * pmx + gm1 * pmy + gm2 * pmz) * pmz);
+            if (g_intr) {
+                v[0] += gs0 * psx; v[1] += gs1 * psy; v[2] += gs0 * psz; v[3] += gs1 * psz;
+                v[4] += gm0 * pmx; v[5] += gm1 * pmy; v[6] += gm0 * pmz; v[7] += gm1 * pmz;
+            }
+        }
+    };
+    if (I < Mb) {
+        const GaPartner me = ga_partner(L.rec + kGaRec * (I * 64 + lane));
+        const GaOwn oa = ga_own<0>(me), ob = ga_own<1>(me);
+        f2 gas[3], gam[3], gbs[3], gbm[3], cs[3], cm[3], ds[3], dm[3];
+        float pacc[12];
+        // the pair inside the super-track (lane x of the result is the track with itself: zero)
+        ga_pair_grad(oa, me, 1.0f, cs, cm);
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            gas[c3] = cs[c3]; gam[c3] = cm[c3];
+            gbs[c3] = f2{-cs[c3].y, 0.0f}; gbm[c3] = f2{-cm[c3].y, 0.0f};
+        }
+        // block J, steps t0 .. t1 (lane l meets super-track 64 J + (l + t) mod 64), the last one with weight w_last
+        auto block_pair = [&](int J, int t0, int t1, float w_last) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) pacc[k] = 0.0f;
+            const float4 *rb = L.rec + kGaRec * 64 * J;
+#pragma unroll 1
+            for (int t = t0; t <= t1; ++t) {
+                const GaPartner q = ga_partner(rb + kGaRec * ((lane + t) & 63));
+                const float wgt = t == t1 ? w_last : 1.0f;
+                ga_pair_grad(oa, q, wgt, cs, cm);
+                ga_pair_grad(ob, q, wgt, ds, dm);
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    gas[c3] += cs[c3]; gam[c3] += cm[c3]; gbs[c3] += ds[c3]; gbm[c3] += dm[c3];
+                    const f2 ts = cs[c3] + ds[c3], tm = cm[c3] + dm[c3];
+                    // the partner's sums came from the lane above (which met this partner one step ago)
+                    pacc[2 * c3] = ga_rol1(pacc[2 * c3]) + ts.x;         pacc[2 * c3 + 1] = ga_rol1(pacc[2 * c3 + 1]) + ts.y;
+                    pacc[6 + 2 * c3] = ga_rol1(pacc[6 + 2 * c3]) + tm.x; pacc[6 + 2 * c3 + 1] = ga_rol1(pacc[6 + 2 * c3 + 1]) + tm.y;
+                }
+            }
+            emit(64 * J + ((lane + t1) & 63), pacc, -1.0f);                 // (the pair's vector, negated, is the partner's)
+        };
+        block_pair(I, 1, 32, 0.5f);                              // inside the block: the antipodal lane is met from both ends
+        const int nfull = (Mb & 1) ? Mb >> 1 : (Mb >> 1) - 1;
+        int J = I;
+        for (int d = 0; d < nfull; ++d) {
+            J = J + 1 >= Mb ? 0 : J + 1;
+            block_pair(J, 0, 63, 1.0f);
+        }
+        if (!(Mb & 1) && I < (Mb >> 1)) block_pair(I + (Mb >> 1), 0, 63, 1.0f);       // the antipodal block: by the lower wave of the two
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            pacc[2 * c3] = gas[c3].x + gas[c3].y;     pacc[2 * c3 + 1] = gbs[c3].x + gbs[c3].y;
+            pacc[6 + 2 * c3] = gam[c3].x + gam[c3].y; pacc[6 + 2 * c3 + 1] = gbm[c3].x + gbm[c3].y;
+        }
+        emit(I * 64 + lane, pacc, 1.0f);
     }
     if (g_intr) {
         // the points' gradients through iproj to the intrinsics of the slot's frame and of the centre slot's frame
         // (refine_intrinsics: RefineNet.intrinsics is K * K_scale for every frame, refine_net.py:131-136): dX/dfx = -X / fx,
-        // dX/dcx = -D / fx, dY/dfy = -Y / fy, dY/dcy = -D / fy
-        const float v[8] = { -c * gs0 * ps.x / Ks[0], -c * gs1 * ps.y / Ks[1], -c * gs0 * ps.z / Ks[0], -c * gs1 * ps.z / Ks[1],
-                             -c * gm0 * pm.x / Km[0], -c * gm1 * pm.y / Km[1], -c * gm0 * pm.z / Km[0], -c * gm1 * pm.z / Km[1] };
+        // dX/dcx = -D / fx, dY/dfy = -Y / fy, dY/dcy = -D / fy   (the factor -c is in v already)
         const size_t js = (size_t)jraw, jmc = (size_t)(jm < 0 ? 0 : (jm > T - 1 ? T - 1 : jm));
         for (int k = 0; k < 8; ++k) {
-            const float tsum = block_sum(n < N ? v[k] : 0.0f, red);
-            if (threadIdx.x == 0) atomicAdd(&g_intr[4 * (k < 4 ? js : jmc) + (k & 3)], tsum);
+            const float tsum = block_sum(v[k], red);
+            if (threadIdx.x == 0) atomicAdd(&g_intr[4 * (k < 4 ? js : jmc) + (k & 3)], tsum / (k < 4 ? Ks : Km)[k & 1]);
         }
     }
 }
@@ -501,12 +641,14 @@ extern "C" int bt_ga_backward_total(const bt_ga_args *a, const float *mono_scale
     const dim3 qs((unsigned)(a->Q * a->S)), ts((unsigned)(a->T * a->S));
     hipLaunchKernelGGL(bt::k_ga_bwd_spatial, qs, dim3(256), 0, st, *a, mono_scaled, w->spatial, g_mono_scaled, grad_trajs_scales);
     if (w->rigid != 0.0f) {
-        const size_t lds = (size_t)a->N * (2 * sizeof(float4) + sizeof(float2));
-        if (lds > 64 * 1024) return BT_EUNSUPPORTED;
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&bt::k_ga_bwd_pairwise), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
-            return BT_EHIP;
-        hipLaunchKernelGGL(bt::k_ga_bwd_pairwise, dim3((unsigned)(a->Q * a->S), (unsigned)((a->N + bt::kGaStrip - 1) / bt::kGaStrip)), dim3(bt::kGaStrip),
+        const size_t M = (size_t)(a->N + 1) / 2, Mb = (M + 63) / 64, lds = Mb * 64 * bt::kGaRec * sizeof(float4);
+        if (lds > 160 * 1024) return BT_EUNSUPPORTED;             // N <= 4096 tracks per frame
+        static size_t raised = 0;
+        if (lds > 48 * 1024 && lds > raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&bt::k_ga_bwd_pairwise), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BT_EHIP;
+            raised = lds;
+        }
+        hipLaunchKernelGGL(bt::k_ga_bwd_pairwise, dim3((unsigned)(a->Q * a->S), (unsigned)((Mb + bt::kGaStrip / 64 - 1) / (bt::kGaStrip / 64))), dim3(bt::kGaStrip),
                            lds, st, *a, mono_scaled, w->rigid, g_mono_scaled, grad_intrinsics);
     }
     if (w->pts3d != 0.0f)
@@ -596,12 +738,14 @@ extern "C" int bt_ga_forward(const bt_ga_args *a, float *mono_scaled_out, double
     if (hipMemsetAsync(losses, 0, 5 * sizeof(double), st) != hipSuccess) return BT_EHIP;
     hipLaunchKernelGGL(bt::k_ga_scale, dim3((unsigned)(a->T * a->S)), dim3(256), 0, st, *a, mono_scaled_out, losses);
     if (which & 2) {
-        const size_t lds = (size_t)a->N * (2 * sizeof(float4) + sizeof(float2));
-        if (lds > 64 * 1024) return BT_EUNSUPPORTED;              // N <= 1638 tracks per frame
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&bt::k_ga_pairwise), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
-            return BT_EHIP;
-        hipLaunchKernelGGL(bt::k_ga_pairwise, dim3((unsigned)(a->Q * a->S), (unsigned)((a->N + bt::kGaStrip - 1) / bt::kGaStrip)), dim3(bt::kGaStrip),
+        const size_t M = (size_t)(a->N + 1) / 2, lds = M * bt::kGaRec * sizeof(float4);
+        if ((M + 63) / 64 * 64 * bt::kGaRec * sizeof(float4) > 160 * 1024) return BT_EUNSUPPORTED;      // N <= 4096 tracks per frame (the backward's staging: blocks of 64 track pairs)
+        static size_t raised = 0;
+        if (lds > 48 * 1024 && lds > raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&bt::k_ga_pairwise), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BT_EHIP;
+            raised = lds;
+        }
+        hipLaunchKernelGGL(bt::k_ga_pairwise, dim3((unsigned)(a->Q * a->S), (unsigned)((M + bt::kGaStrip - 1) / bt::kGaStrip)), dim3(bt::kGaStrip),
                            lds, st, *a, mono_scaled_out, losses);
     }
     if (which & 4) {

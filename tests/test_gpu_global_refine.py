@@ -52,7 +52,8 @@ def make_case(T, N, S, seed):
     return {k: (np.asarray(v, np.float32).astype(np.float64) if np.asarray(v).dtype == np.float64 and np.ndim(v) > 0 else v) for k, v in d.items()}
 
 
-@pytest.mark.parametrize("T,N,S", [(12, 300, 7), (6, 520, 5)])
+# (the pairwise kernels walk the tracks two by two: odd N, an odd number of such pairs — 301 -> 151 — and a handful of tracks)
+@pytest.mark.parametrize("T,N,S", [(12, 300, 7), (6, 520, 5), (5, 301, 5), (4, 7, 3), (4, 2, 3), (3, 1030, 3)])
 def test_larger_cases_vs_oracle(T, N, S):
     d = make_case(T, N, S, seed=T + N)
     net = build(d)
@@ -105,7 +106,7 @@ def test_gradients_match_the_reference_autograd(alpha, key):
     assert float(g_ts[torch.as_tensor(notq, device=g_ts.device)].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("T,N,S", [(12, 300, 7), (6, 520, 5)])
+@pytest.mark.parametrize("T,N,S", [(12, 300, 7), (6, 520, 5), (5, 301, 5), (4, 7, 3), (4, 2, 3), (3, 1030, 3)])
 def test_gradients_of_larger_cases_vs_torch_oracle(T, N, S):
     from oracle import ga_torch
     d = make_case(T, N, S, seed=T + N)
