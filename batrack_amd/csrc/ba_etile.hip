@@ -105,8 +105,8 @@ __device__ __forceinline__ void et_stride_sum(T (&x)[N], int lg) {
 // ------------------------------------------------------------------ k_etile
 // Grid: kEtFull pd.T workgroups; kEtSO pd.T + the blocks of update_rest; kEtUpd tile_blocks + update_rest blocks + the
 // blocks that clear [S | y] (as k_update).
-template <int MODE, typename R, bool PROF = false>
-__global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a, int do_poses, int tile_blocks, int first_zero_block) {
+template <int MODE, typename R, bool PROF = false, bool TWO = false>
+__global__ __launch_bounds__(kEtThreads, TWO ? 1 : 2) void k_etile(PlanDev pd, StepArgs a, int do_poses, int tile_blocks, int first_zero_block) {
     if (MODE == kEtUpd && (int)blockIdx.x >= first_zero_block) {
         const size_t nz = (size_t)pd.D * pd.D + pd.D;
         const size_t i0 = ((size_t)(blockIdx.x - first_zero_block) * blockDim.x + threadIdx.x) * 4;
@@ -252,20 +252,10 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
 #pragma unroll
     for (int c = 0; c < NSV; ++c) sv[c] = (R)0;
     bool any = false;
-    int d = 0, it = wave;
+    int it = wave;
     if (nr > 0) load_track(wave + kEtWaves, patch_n, la_n, px_n, py_n, pd_n, mono_n);
-#pragma unroll 1
-    for (int k = 0; k < nr; ++k) {
-        // ---- pipeline: operands of round k were requested one round ago; request round k + 1's, and the edge ids of k + 2
-        const int e = e_cur;
-        const R tu = tu_c, tv = tv_c, w0 = w0_c, w1 = w1_c;
-        R tu_x, tv_x, w0_x, w1_x;
-        gather(e_nx, tu_x, tv_x, w0_x, w1_x);
-        const int e_nn = edge_of(k + 2);
-        const bool act = e >= 0;
-        EdgeQT<R> q;
-        edge_eval<R>(g, px, py, pdisp, tu, tv, w0, w1, a, q);
-        if (!act) { q.W0 = (R)0; q.W1 = (R)0; q.r0 = (R)0; q.r1 = (R)0; }
+    // ---- one edge of the lane's (track, pair): its share of the track's and of the pair's sums
+    auto accum = [&](const EdgeQT<R> &q, bool act) {
         if (MODE == kEtUpd) {
             if (act) {
                 const R d0 = q.a0 * g[20] + q.a2 * g[22] + q.a3 * g[23] + q.a4 * g[24] + q.a5 * g[25];
@@ -300,13 +290,9 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
             pa[22] = fma_t(wa2, q.r0, fma_t(wb2, q.r1, pa[22])); pa[23] = fma_t(wa3, q.r0, fma_t(wb3, q.r1, pa[23]));
             pa[24] = fma_t(wa4, q.r0, fma_t(wb4, q.r1, pa[24])); pa[25] = fma_t(wa5, q.r0, fma_t(wb5, q.r1, pa[25]));
         }
-        // rotate the pipeline
-        e_cur = e_nx; e_nx = e_nn;
-        tu_c = tu_x; tv_c = tv_x; w0_c = w0_x; w1_c = w1_x;
-        if (++d < D) continue;
-
-        // ---- the lane's rounds of this iteration are in: finish the iteration's tracks
-        d = 0;
+    };
+    // ---- the lane's rounds of an iteration are in: finish the iteration's tracks, take the next iteration's
+    auto finish = [&](bool more) {
         const int track = it * G + tl;
         const bool has_trk = track < ntrk;
         if (MODE == kEtUpd) {
@@ -380,7 +366,66 @@ __global__ __launch_bounds__(kEtThreads, 2) void k_etile(PlanDev pd, StepArgs a,
         // next iteration's tracks (requested one iteration ago), and the request for the one after
         it += kEtWaves;
         patch_c = patch_n; la_c = la_n; px = px_n; py = py_n; pdisp = pd_n; mono_v = mono_n;
-        if (k + 1 < nr) load_track(it + kEtWaves, patch_n, la_n, px_n, py_n, pd_n, mono_n);
+        if (more) load_track(it + kEtWaves, patch_n, la_n, px_n, py_n, pd_n, mono_n);
+    };
+    if constexpr (TWO) {
+        // ---- two rounds of the lane per trip: the two edges' dependency chains (float64: two reciprocals by Newton steps,
+        // the robust weight) run side by side in one wave — a tile of a sliding window is 8 waves x 3-4 rounds, its time is
+        // the waves' latency.  Trip j = (iteration wave + (j / D2) * kEtWaves, rounds 2 h, 2 h + 1 with h = j mod D2).
+        const int D2 = (D + 1) >> 1, ntrips = my_its * D2;
+        auto edges_of = [&](int j, int &ea, int &eb) {
+            ea = eb = -1;
+            if (j >= ntrips) return;
+            const int itx = j / D2, h = j - itx * D2, rd = round0 + (wave + itx * kEtWaves) * D + 2 * h;
+            ea = pd.pm_edge[(size_t)rd * kLanes + lane];
+            if (2 * h + 1 < D) eb = pd.pm_edge[(size_t)(rd + 1) * kLanes + lane];
+        };
+        int ea_c = e_cur, eb_c = D > 1 ? e_nx : -1, ea_n, eb_n;             // (trip 0 is rounds 0 and 1 of the first iteration)
+        R tub_c, tvb_c, w0b_c, w1b_c;
+        gather(eb_c, tub_c, tvb_c, w0b_c, w1b_c);
+        edges_of(1, ea_n, eb_n);
+        int h = 0;
+#pragma unroll 1
+        for (int j = 0; j < ntrips; ++j) {
+            const int ea = ea_c, eb = eb_c;
+            const R tua = tu_c, tva = tv_c, w0a = w0_c, w1a = w1_c, tub = tub_c, tvb = tvb_c, w0b = w0b_c, w1b = w1b_c;
+            gather(ea_n, tu_c, tv_c, w0_c, w1_c);
+            gather(eb_n, tub_c, tvb_c, w0b_c, w1b_c);
+            ea_c = ea_n; eb_c = eb_n;
+            edges_of(j + 2, ea_n, eb_n);
+            EdgeQT<R> qa, qb;
+            edge_eval<R>(g, px, py, pdisp, tua, tva, w0a, w1a, a, qa);
+            edge_eval<R>(g, px, py, pdisp, tub, tvb, w0b, w1b, a, qb);
+            if (ea < 0) { qa.W0 = (R)0; qa.W1 = (R)0; qa.r0 = (R)0; qa.r1 = (R)0; }
+            if (eb < 0) { qb.W0 = (R)0; qb.W1 = (R)0; qb.r0 = (R)0; qb.r1 = (R)0; }
+            accum(qa, ea >= 0);
+            accum(qb, eb >= 0);
+            if (++h < D2) continue;
+            h = 0;
+            finish(j + 1 < ntrips);
+        }
+    } else {
+        int d = 0;
+#pragma unroll 1
+        for (int k = 0; k < nr; ++k) {
+            // ---- pipeline: operands of round k were requested one round ago; request round k + 1's, and the edge ids of k + 2
+            const int e = e_cur;
+            const R tu = tu_c, tv = tv_c, w0 = w0_c, w1 = w1_c;
+            R tu_x, tv_x, w0_x, w1_x;
+            gather(e_nx, tu_x, tv_x, w0_x, w1_x);
+            const int e_nn = edge_of(k + 2);
+            const bool act = e >= 0;
+            EdgeQT<R> q;
+            edge_eval<R>(g, px, py, pdisp, tu, tv, w0, w1, a, q);
+            if (!act) { q.W0 = (R)0; q.W1 = (R)0; q.r0 = (R)0; q.r1 = (R)0; }
+            accum(q, act);
+            // rotate the pipeline
+            e_cur = e_nx; e_nx = e_nn;
+            tu_c = tu_x; tv_c = tv_x; w0_c = w0_x; w1_c = w1_x;
+            if (++d < D) continue;
+            d = 0;
+            finish(k + 1 < nr);
+        }
     }
     BT_PF(1);
     if (MODE != kEtFull) return;
@@ -581,17 +626,17 @@ int etile_precision_bytes(const PlanDev &pd) {
     return 0;                       // (k_tile then decides: float64 if ITS tile fits LDS as double, else float32)
 }
 
-template <int MODE, typename R, bool PROF = false>
+template <int MODE, typename R, bool PROF = false, bool TWO = false>
 static int launch_etile_t(const PlanDev &pd, const StepArgs &a, int do_poses, int extra_blocks, int zero_blocks, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const size_t lds = etile_lds_bytes(pd, MODE, sizeof(R));
     static size_t raised = 0;                      // per instantiation; only ever raised (several plans coexist)
     if (lds > 48 * 1024 && lds > raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_etile<MODE, R, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BT_EHIP;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_etile<MODE, R, PROF, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BT_EHIP;
         raised = lds;
     }
     const dim3 grid((unsigned)(pd.T + extra_blocks + zero_blocks)), blk(kEtThreads);
-    if (ev0) hipExtLaunchKernelGGL((k_etile<MODE, R, PROF>), grid, blk, lds, st, ev0, ev1, 0, pd, a, do_poses, pd.T, pd.T + extra_blocks);
-    else hipLaunchKernelGGL((k_etile<MODE, R, PROF>), grid, blk, lds, st, pd, a, do_poses, pd.T, pd.T + extra_blocks);
+    if (ev0) hipExtLaunchKernelGGL((k_etile<MODE, R, PROF, TWO>), grid, blk, lds, st, ev0, ev1, 0, pd, a, do_poses, pd.T, pd.T + extra_blocks);
+    else hipLaunchKernelGGL((k_etile<MODE, R, PROF, TWO>), grid, blk, lds, st, pd, a, do_poses, pd.T, pd.T + extra_blocks);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 
@@ -609,7 +654,11 @@ int launch_etile(const PlanDev &pd, const StepArgs &a, int mode, int do_poses, i
     }
     if (mode == kEtSO) return dbl ? launch_etile_t<kEtSO, double>(pd, a, do_poses, extra_blocks, 0, st, ev0, ev1) : launch_etile_t<kEtSO, float>(pd, a, do_poses, extra_blocks, 0, st, ev0, ev1);
     if (mode == kEtUpd) return dbl ? launch_etile_t<kEtUpd, double>(pd, a, do_poses, extra_blocks, zero_blocks, st, ev0, ev1) : launch_etile_t<kEtUpd, float>(pd, a, do_poses, extra_blocks, zero_blocks, st, ev0, ev1);
+    // float64: two rounds per trip (both variants need more than 128 registers: one workgroup per CU either way); BT_ETILE_TWO=0 for measurements
+    static const bool two = [] { const char *e = getenv("BT_ETILE_TWO"); return e ? atoi(e) != 0 : true; }();
+    if ((a.dbg & 32) && dbl && two) return launch_etile_t<kEtFull, double, true, true>(pd, a, 0, 0, 0, st, ev0, ev1);
     if (a.dbg & 32) return dbl ? launch_etile_t<kEtFull, double, true>(pd, a, 0, 0, 0, st, ev0, ev1) : launch_etile_t<kEtFull, float, true>(pd, a, 0, 0, 0, st, ev0, ev1);
+    if (dbl && two) return launch_etile_t<kEtFull, double, false, true>(pd, a, 0, 0, 0, st, ev0, ev1);
     return dbl ? launch_etile_t<kEtFull, double>(pd, a, 0, 0, 0, st, ev0, ev1) : launch_etile_t<kEtFull, float>(pd, a, 0, 0, 0, st, ev0, ev1);
 }
 

@@ -115,11 +115,11 @@ def test_patches_of_size_three_step_like_their_centres():
     p3 = p1.repeat(1, 1, 1, 3, 3).clone()
     p3[:, :, 0] += off[None, None, None, :]                                    # x, y of the neighbouring pixels: never read by the step
     p3[:, :, 1] += off[None, None, :, None]
-    Gs, pat = hp.api_step("weights_pose", 2, False, patches=p3)
+    Gs, pat = hp.api_step("weights_pose", 2, False, patches=p3, alpha=0.5, ep=100.0)      # (the settings of the fixture's ps_fp2 run)
     torch.cuda.synchronize()
     assert tuple(pat.shape) == (1, d["patches"].shape[0], 3, 3, 3)
     ref = d["ps_fp2.f64.patches_out"] if "ps_fp2.f64.patches_out" in d else None
-    one = hp.api_step("weights_pose", 2, False)
+    one = hp.api_step("weights_pose", 2, False, alpha=0.5, ep=100.0)
     assert torch.equal(pat[:, :, 2], one[1][:, :, 2].expand(-1, -1, 3, 3))     # every pixel of the plane: the centre's new disparity
     assert torch.equal(pat[:, :, :2], p3[:, :, :2])                            # x, y untouched
     assert rel(Gs.data.cpu().numpy(), one[0].data.cpu().numpy()) < 1e-6
