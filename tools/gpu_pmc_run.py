@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Tiny driver for rocprofv3 --pmc passes: a few BA steps on a workload (M tracks per frame)."""
+"""Tiny driver for rocprofv3 --pmc passes: a few BA steps on a workload (M tracks per frame).
+BT_PMC_COLD=1: a 512 MB sweep between the steps (L2 and MALL hold nothing of the graph when the Jacobian kernel starts)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,11 @@ ii, jj, kk = (torch.as_tensor(a, device=dev) for a in (g.ii, g.jj, g.kk))
 plan = Plan(ii, jj, kk, poses.shape[0], patches.shape[0], 1)
 st = Stepper(plan, dev)
 Po, Xo = torch.empty_like(poses), torch.empty_like(patches)
+cold = os.environ.get("BT_PMC_COLD", "0") != "0"
+flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev) if cold else None
 for _ in range(reps):
+    if cold:
+        flush.add_(1)
     st.step(poses, patches, mono, intr, t3, 3, w, Po, Xo, list(g.bounds), 1e-4, 10.0, 0.05, "huber", False)
 torch.cuda.synchronize()
 print(f"E={plan.E} m={plan.m} n_all={plan.n_all} algorithmic_bytes_k_tile={40*plan.E + 20*plan.m + 72*plan.n_all}")

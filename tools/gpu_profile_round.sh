@@ -1,11 +1,11 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): rocprofv3 kernel traces and PMC passes of the round, summaries under gpurun_out/prof_r04/
-# (copied into profiles/r04_* afterwards).  PMC passes are their own runs with --kernel-trace only (no other trace domain
+# Runs on the GPU box (gpurun): rocprofv3 kernel traces and PMC passes of the round, summaries under gpurun_out/prof_r05/
+# (copied into profiles/r05_* afterwards).  PMC passes are their own runs with --kernel-trace only (no other trace domain
 # beside --pmc).  profiles/pmc_k_tile.json is rewritten from the FETCH_SIZE / WRITE_SIZE passes of THIS build
 # (tools/pmc_to_json.py: it carries the hash of the kernel sources; bench.py refuses it when the sources change).
 set -u
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r04
+OUT=$R/gpurun_out/prof_r05
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 trace() {   # name, command...
@@ -28,10 +28,24 @@ trace e2m python $R/tools/gpu_pmc_run.py 4096 6
 trace e8m python $R/tools/gpu_pmc_run.py 16384 6
 BT_WPT_KERNELS=0 trace e8m_f64tile python $R/tools/gpu_pmc_run.py 16384 6
 trace ga python $R/tools/gpu_ga_bench.py
-# ---- HBM traffic of the Jacobian kernel: C3 (k_tile, float64) and 8.4M edges (k_edge, mixed precision: the default there; and the
+# ---- HBM traffic of the Jacobian kernel: C3 (k_tile, float64) and 8.4M edges (k_edge2, mixed precision: the default there; and the
 # float64 tile kernel the caller can have instead)
 : > $OUT/pmc_fetch_write.txt
 for C in FETCH_SIZE WRITE_SIZE; do pmc $C c3 256; pmc $C e8m 16384; BT_WPT_KERNELS=0 pmc $C e8mf64 16384; done
+# the same counters with L2 and MALL flushed between the steps (a 512 MB sweep: BT_PMC_COLD=1), and the kernel times warm / cold
+echo "# ---- cold: a 512 MB sweep between the steps (BT_PMC_COLD=1)" >> $OUT/pmc_fetch_write.txt
+for C in FETCH_SIZE WRITE_SIZE; do BT_PMC_COLD=1 pmc $C c3cold 256; BT_PMC_COLD=1 pmc $C e8mcold 16384; done
+python - >> $OUT/pmc_fetch_write.txt 2>&1 <<PYEOF
+import json
+b = json.loads(open("$OUT/bench_n1.json").read().strip().splitlines()[-1])
+r = b["roofline"]
+print("# ---- Jacobian kernel, warm (steps back to back) / cold (512 MB sweep between launches), HIP events (bench.py)")
+print(f"C3      {r['kernel']}: warm {r.get('kernel_us')} us, cold {r.get('cold_kernel_us')} us (frac {r.get('frac')} / {r.get('cold_frac')})")
+w = b["config"].get("sliding_window", {})
+print(f"window  {w.get('jacobian_kernel')}: warm {w.get('kernel_us', {}).get('tile')} us, cold {w.get('cold_kernel_us_tile')} us")
+l = r.get("large", {})
+print(f"8.4M    {l.get('kernel')}: warm {l.get('kernel_us')} us, cold {l.get('cold_kernel_us')} us (frac {l.get('frac')} / {l.get('cold_frac')})")
+PYEOF
 python $R/tools/pmc_to_json.py $OUT/pmc_k_tile.json \
     C3:131072:16384:64:/tmp/pmc_FETCH_SIZE_c3.db:/tmp/pmc_WRITE_SIZE_c3.db \
     E8M:8388608:1048576:64:/tmp/pmc_FETCH_SIZE_e8m.db:/tmp/pmc_WRITE_SIZE_e8m.db \
@@ -42,10 +56,15 @@ cd $R
 # ---- the edge sweep in both precisions (the roofline table of DESIGN.md §6)
 (echo "# default: k_tile (float64 per edge) below 2048 tiles, k_stream / k_edge (mixed precision) from there: every row inside the 1e-5 bar on the update"; python tools/gpu_sweep.py 256 1024 4096 16384 32768;
  echo "# BT_WPT_KERNELS=0: the float64 tile kernel at every size"; BT_WPT_KERNELS=0 python tools/gpu_sweep.py 4096 16384 32768) > $OUT/edge_sweep.txt 2>&1
-# ---- solver variants: k_solve_pipe (default) against k_solve_chain, with their in-kernel cycle counters
-(for w in C3 window; do python tools/gpu_timing.py --workload $w; BT_SOLVER_CHAIN=1 python tools/gpu_timing.py --workload $w; done;
- BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver"; BT_SOLVER_CHAIN=1 BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver";
+# ---- solver: k_solve_pipe with its in-kernel cycle counters (k_solve_chain, round 4's equal-time alternative, is deleted)
+(for w in C3 window; do python tools/gpu_timing.py --workload $w; done;
+ BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver"; BT_SOLVER_PIPE=0 BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver";
  BT_DEBUG_MODE=16 python tools/gpu_timing.py --workload window | grep -A2 "solver") > $OUT/solver_variants.txt 2>&1
+# ---- k_edge2 against round 4's k_edge on the same graphs, and the window kernel with one / two rounds per trip
+(echo "# default (k_edge2 from 2048 tiles)"; BT_EDGE_PREF_TILES=1 BT_EDGE_MIN_TILES=1 python tools/gpu_sweep.py 2048 4096 8192 16384 32768;
+ echo "# BT_EDGE2=0: round 4's k_edge"; BT_EDGE2=0 BT_EDGE_PREF_TILES=1 BT_EDGE_MIN_TILES=1 python tools/gpu_sweep.py 2048 4096 8192 16384 32768) 2>&1 | cut -c1-330 > $OUT/edge2_vs_edge.txt
+(python tools/gpu_timing.py --workload window; BT_ETILE_TWO=0 python tools/gpu_timing.py --workload window) > $OUT/window_rounds_per_trip.txt 2>&1
+python tools/gpu_spec_time.py > $OUT/plan_call_host_time.txt 2>&1
 python tests/sequence_report.py > $OUT/sequence_ate.txt 2>&1
 (echo "# 200 frames, steady state of the window"; python tests/sequence_report.py --frames 200 --skip-oracle) >> $OUT/sequence_ate.txt 2>&1
 (python tools/gpu_plan_time.py; python tools/gpu_plan_time.py window; python tools/gpu_plan_time.py large) > $OUT/plan_time.txt 2>&1

@@ -9,6 +9,7 @@ refuses the file when that differs from the sources it runs.
 """
 import json
 import os
+import re
 import sqlite3
 import sys
 
@@ -23,7 +24,8 @@ def kernel_avg(db, counter):
     """(kernel name, launches, average value per launch) of the Jacobian kernel with the most launches in this pass."""
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
-    rows = [r for r in rows if any(k in r[0] for k in JACOBIAN) and "upd" not in r[0].lower() and "<2" not in r[0]]
+    # (mode 2 of k_tile / k_etile / k_stream / k_edge is the step's last kernel; k_edge2's first template argument is a tile count)
+    rows = [r for r in rows if any(k in r[0] for k in JACOBIAN) and "upd" not in r[0].lower() and not re.search(r"k_(tile|etile|stream|edge)<2", r[0])]
     if not rows:
         raise SystemExit(f"{db}: no Jacobian kernel with counter {counter}")
     # the pose+structure instantiation: the one with the largest average (the structure-only / update modes move less)
