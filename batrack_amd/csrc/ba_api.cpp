@@ -321,7 +321,8 @@ static StepArgs make_args(const bt_plan *pl, const bt_ba_args *a, void *ws) {
     const size_t D = (size_t)(6 * pl->info.n);
     s.S = reinterpret_cast<double *>(w + L.sys); s.y = s.S + D * D;
     s.pairacc = reinterpret_cast<double *>(w + L.pairacc);
-    s.priv = L.priv ? reinterpret_cast<double *>(w + L.priv) : nullptr;
+    // (k_edge2's private copies: only where k_edge2 is the plan's Jacobian kernel — k_pair_finalize adds up what it is given)
+    s.priv = L.priv && edge_applies(pl->dev) ? reinterpret_cast<double *>(w + L.priv) : nullptr;
     s.pairgeo = reinterpret_cast<float *>(w + L.pairgeo);
     s.packed = reinterpret_cast<double *>(w + L.packed); s.qw = reinterpret_cast<float2 *>(w + L.qw);
     s.lfac = reinterpret_cast<float *>(w + L.lfac);

@@ -126,12 +126,8 @@ __device__ __forceinline__ void stride_sum(float (&x)[N], int lg) {
 // 1 / x in double from the float32 hardware seed and ONE Newton step: the seed is 1 ulp (2^-23) off, the step squares that
 // (< 1e-13 relative; u = fx X / Z + cx ~ 500 px then carries < 1e-10 px)
 __device__ __forceinline__ double rcp_nr1(double x) {
-#ifdef BT_E2_X_NR2
-    return frcp(x);
-#else
     const double y = (double)__builtin_amdgcn_rcpf((float)x);
     return fma(y, fma(-x, y, 1.0), y);
-#endif
 }
 
 // float64 part of one edge (projective_ops.py:19-66, ba.py:230-242): the point in the target frame, the residual and the
@@ -154,12 +150,8 @@ __device__ __forceinline__ Proj project(const double (&gd)[kGeoD], double X0, do
 
 // 1 / x in float32: the hardware seed (1 ulp) and a Newton step (then inside the last ulp)
 __device__ __forceinline__ float rcp_f32(float x) {
-#ifdef BT_E2_X_IEEEQ
-    return 1.0f / x;
-#else
     const float y = __builtin_amdgcn_rcpf(x);
     return fmaf(y, fmaf(-x, y, 1.0f), y);
-#endif
 }
 
 template <int LOSS>
@@ -247,11 +239,6 @@ __device__ __forceinline__ void schur_rows(const float *Eh, const float *Qs, con
     }
 }
 
-#if defined(BT_E2_X_NOATOM2)     /* measurement: no atomics at all (results wrong) */
-#define BT_E2_ATOMIC_ADD(p, v) do { if ((v) == 1.2345e300) atomicAdd((p), (v)); } while (0)
-#else
-#define BT_E2_ATOMIC_ADD(p, v) atomicAdd((p), (v))
-#endif
 template <int P> struct IC { static constexpr int value = P; };
 // -DBT_E2_PROF (measurement builds, tools/build_variant.sh): cycle counters between the phases of a step, written behind the
 // status words for tools/gpu_sweep.py (BT_DEBUG_MODE=64 prints them); every probe waits for the LDS and fences the scheduler
@@ -306,9 +293,6 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
     // add) and die there; formed from `lane` they are hoisted out of the tile loop as loop invariants, spilled for want of
     // registers, and every reload is a scratch load — a wait for everything the prefetch has in flight.
     auto olane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-#ifdef BT_E2_X_SKEW       /* measurement: the second wave of every SIMD starts late, out of phase with the first */
-    if (wv >= 4) for (int k = 0; k < BT_E2_X_SKEW; ++k) __builtin_amdgcn_s_sleep(127);
-#endif
     // (a wave without tiles — the launch's last workgroup may hold some — runs the prologue on tile 0, skips the loop, and
     //  takes part in the workgroup's barriers at the end with nothing to add)
     const bool has_work = gw * tiles_per_wave < pd.T;
@@ -320,8 +304,9 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
     // E Q E^T since the last flush lives in LDS, as float64 (schur_rows); E (Q w') of the current tile in float32 registers,
     // added to float64 sums in LDS at the tile's end
     // this wave's copies of y and of the per-pair sums (ba_plan.hpp: kPrivY)
-    double *ypriv = a.priv ? a.priv + (size_t)(gw & (kPrivY - 1)) * pd.D : a.y;
-    double *ppriv = a.priv ? a.priv + (size_t)kPrivY * pd.D + (size_t)(gw & (kPrivP - 1)) * pd.P * kPairAccStride : a.pairacc;
+    // (by workgroup: only the roots of the workgroups' trees issue atomics)
+    double *ypriv = a.priv ? a.priv + (size_t)(blockIdx.x & (kPrivY - 1)) * pd.D : a.y;
+    double *ppriv = a.priv ? a.priv + (size_t)kPrivY * pd.D + (size_t)(blockIdx.x & (kPrivP - 1)) * pd.P * kPairAccStride : a.pairacc;
     constexpr int NACC = NT * (NT + 1) / 2;
     float yacc[NT];                          // lane (li, kq) holds row 16 ti + li (all kq alike)
 #pragma unroll
@@ -357,20 +342,12 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
                 const double cr[4] = {c01.x, c01.y, c23.x, c23.y};
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-#ifndef BT_E2_X_NOATOM
-#ifdef BT_E2_X_SPREAD     /* measurement: the waves' atomics on 8 different sets of cache lines (results wrong) */
-                    if (gc[tj] >= 0 && gr[ti][r] >= gc[tj]) BT_E2_ATOMIC_ADD(&a.S[(size_t)max(gr[ti][r] - 8 * (int)(gw & 7), 0) * pd.D + gc[tj]], -cr[r]);
-#else
-                    if (gc[tj] >= 0 && gr[ti][r] >= gc[tj]) BT_E2_ATOMIC_ADD(&a.S[(size_t)gr[ti][r] * pd.D + gc[tj]], -cr[r]);
-#endif
-#else
-                    if (gc[tj] >= 0 && gr[ti][r] >= gc[tj] && cr[r] == 1.2345) atomicAdd(&a.S[(size_t)gr[ti][r] * pd.D + gc[tj]], -cr[r]);
-#endif
+                    if (gc[tj] >= 0 && gr[ti][r] >= gc[tj]) atomicAdd(&a.S[(size_t)gr[ti][r] * pd.D + gc[tj]], -cr[r]);
             }
         if (ln < Racc) {
             const double v = ysum[ln];
             ysum[ln] = 0.0;
-            BT_E2_ATOMIC_ADD(&ypriv[gidx[ln]], -v);
+            atomicAdd(&ypriv[gidx[ln]], -v);
         }
         acc_tiles = 0;
     };
@@ -392,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
 #pragma unroll
             for (int i = 0; i < 26; ++i) {
                 const int vi = i < 1 ? 0 : i + 1;        // element order of the 27-vector: the zero at [0][1] stays
-                BT_E2_ATOMIC_ADD(dst + vi, (double)f[i]);
+                atomicAdd(dst + vi, (double)f[i]);
             }
         }
         pa_tiles = 0;
@@ -417,22 +394,14 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
     int gj = rec.it0 >> 1, gj_end;
     { const Rec last = load_rec(pd, max(t_end - 1, 0)); gj_end = (last.it0 + last.nit + 1) >> 1; }
     auto load_ids = [&](int j, int &ea, int &eb) {             // (beyond the wave's last step: that step's ids again, never used)
-#ifdef BT_E2_X_FAKEMEM
-        const unsigned f = ((unsigned)min(j, gj_end - 1) & 7u) * 2u * kLanes + (unsigned)lane;
-#else
         const unsigned f = (unsigned)min(j, gj_end - 1) * 2u * kLanes + (unsigned)lane;
-#endif
         ea = pd.it_edge[f]; eb = pd.it_edge[f + kLanes];
     };
     // gather through the ids (ea, eb), then replace them by the ids of step jn.  The id loads are ISSUED FIRST (the counter of
     // outstanding loads retires in order: whoever waits for ids issued behind the gathers waits for the gathers as well), after
     // the addresses of the gathers have been formed from the old ids.
     auto gather = [&](int &ea, int &eb, int jn, f2 &tu, f2 &tv, f2 &w0, f2 &w1, int &fl) {
-#ifdef BT_E2_X_FAKEMEM        /* measurement only: every gather hits the cache */
-        const unsigned ua = (unsigned)max(ea, 0) & 1023u, ub = (unsigned)max(eb, 0) & 1023u;
-#else
         const unsigned ua = (unsigned)max(ea, 0), ub = (unsigned)max(eb, 0);
-#endif
         const unsigned ta = ua * (unsigned)a.tstride, tb = ub * (unsigned)a.tstride;     // (launch_edge2 checks that byte offsets fit 32 bits)
         const float *pa_ = a.targets + ta, *pb_ = a.targets + tb;
         const float2 *wa_ = reinterpret_cast<const float2 *>(a.weights) + ua, *wb_ = reinterpret_cast<const float2 *>(a.weights) + ub;
@@ -723,12 +692,10 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
             BT_E2_PF(6);
             // ---- E Q E^T and E (Q w') of the step's tracks (schur_rows)
             BT_E2_WAVE_SYNC();
-#ifndef BT_E2_X_NOSCHUR
             if (ntl == NT) schur_rows<NT, NT, kQn, kRow>(Eh, Qs, Bs, sacc, yacc, R, nv, lane, [] {});
             else if (NT > 1 && ntl == NT - 1) schur_rows<(NT > 1 ? NT - 1 : 1), NT, kQn, kRow>(Eh, Qs, Bs, sacc, yacc, R, nv, lane, [] {});
             else if (NT > 2 && ntl == NT - 2) schur_rows<(NT > 2 ? NT - 2 : 1), NT, kQn, kRow>(Eh, Qs, Bs, sacc, yacc, R, nv, lane, [] {});
             else schur_rows<1, NT, kQn, kRow>(Eh, Qs, Bs, sacc, yacc, R, nv, lane, [] {});
-#endif
             BT_E2_WAVE_SYNC();               // (the next step's stores into E stay behind these reads)
             BT_E2_PF(7);
             ++gj;
@@ -818,7 +785,7 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
 #pragma unroll
             for (int i = 0; i < 26; ++i) {
                 const int vi = i < 1 ? 0 : i + 1;
-                BT_E2_ATOMIC_ADD(dst + vi, pcomb ? pbuf[ln * 26 + i] : (double)f[i]);
+                atomicAdd(dst + vi, pcomb ? pbuf[ln * 26 + i] : (double)f[i]);
             }
         }
     }

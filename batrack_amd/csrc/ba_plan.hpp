@@ -20,7 +20,7 @@ constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj 
 // cache lines (y is 6n doubles in all; a pair's 27 sums are hit by every wave of its source frame) and atomics on one line are
 // served one after the other — at 8.4M edges they were 35 of the kernel's 170 us.  A wave adds to copy (its index mod the count);
 // k_pair_finalize adds the copies up and clears them.
-constexpr int kPrivY = 64, kPrivP = 16;
+constexpr int kPrivY = 16, kPrivP = 4;
 constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
 constexpr int kLdsRowStride = 66;
 constexpr int kMaxLevelCols = 4;

@@ -25,7 +25,7 @@ GATES = {8: (2e-7, 1e-10, 1e-5, 1e-5, 1e-5), 6: (2e-7, 1e-6, 1e-5, 1e-5, 1e-5), 
 @pytest.mark.parametrize("frames,M,kernel,so,wpt", [(16, 16, "k_tile", False, True), (64, 1024, "k_tile", False, True),
                                                   # from 2048 tiles the wave-per-tile kernels, mixed precision: inside the 1e-5 bar ...
                                                   (64, 2048, "k_stream", False, True), (64, 2048, "k_stream", True, True),
-                                                  (64, 6144, "k_edge", False, True), (64, 6144, "k_edge", True, True),
+                                                  (64, 4096, "k_edge", False, True), (64, 6144, "k_edge", False, True), (64, 6144, "k_edge", True, True),
                                                   # ... or, switched off by the caller, the float64 tile kernel at every size
                                                   (64, 2048, "k_tile", False, False), (64, 2048, "k_tile", True, False), (64, 6144, "k_tile", False, False)])
 def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, wpt):

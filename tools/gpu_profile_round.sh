@@ -20,6 +20,17 @@ pmc() {     # counter, tag, M  (environment of the caller selects the kernels)
     cp $(find /tmp/pmc_$1_$2 -name "*results.db" | head -1) /tmp/pmc_$1_$2.db
     python $R/tools/pmc_summary.py /tmp/pmc_$1_$2.db >> $OUT/pmc_fetch_write.txt 2>&1
 }
+# `tools/gpu_profile_round.sh pmc`: only the FETCH_SIZE / WRITE_SIZE passes and pmc_k_tile.json (after a late change of the kernel
+# sources: the JSON carries their hash)
+if [ "${1:-all}" = "pmc" ]; then
+    : > $OUT/pmc_fetch_write.txt
+    for C in FETCH_SIZE WRITE_SIZE; do pmc $C c3 256; pmc $C e8m 16384; BT_WPT_KERNELS=0 pmc $C e8mf64 16384; done
+    python $R/tools/pmc_to_json.py $OUT/pmc_k_tile.json \
+        C3:131072:16384:64:/tmp/pmc_FETCH_SIZE_c3.db:/tmp/pmc_WRITE_SIZE_c3.db \
+        E8M:8388608:1048576:64:/tmp/pmc_FETCH_SIZE_e8m.db:/tmp/pmc_WRITE_SIZE_e8m.db \
+        E8M_float64_tile_kernels:8388608:1048576:64:/tmp/pmc_FETCH_SIZE_e8mf64.db:/tmp/pmc_WRITE_SIZE_e8mf64.db > $OUT/pmc_to_json.stdout 2>&1
+    exit 0
+fi
 # ---- headline bench first (fresh clocks), then the traces
 python $R/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.stderr
 trace c3 python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-large
@@ -60,9 +71,10 @@ cd $R
 (for w in C3 window; do python tools/gpu_timing.py --workload $w; done;
  BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver"; BT_SOLVER_PIPE=0 BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver";
  BT_DEBUG_MODE=16 python tools/gpu_timing.py --workload window | grep -A2 "solver") > $OUT/solver_variants.txt 2>&1
-# ---- k_edge2 against round 4's k_edge on the same graphs, and the window kernel with one / two rounds per trip
-(echo "# default (k_edge2 from 2048 tiles)"; BT_EDGE_PREF_TILES=1 BT_EDGE_MIN_TILES=1 python tools/gpu_sweep.py 2048 4096 8192 16384 32768;
- echo "# BT_EDGE2=0: round 4's k_edge"; BT_EDGE2=0 BT_EDGE_PREF_TILES=1 BT_EDGE_MIN_TILES=1 python tools/gpu_sweep.py 2048 4096 8192 16384 32768) 2>&1 | cut -c1-330 > $OUT/edge2_vs_edge.txt
+# ---- k_edge2 forced from 2048 tiles on (default: from 4096), and the window kernel with one / two rounds per trip
+# (profiles/r05_edge2_vs_edge.txt also holds round 4's k_edge on the same graphs: measured before its pose+structure
+#  instantiation was removed, at the commit named in the file)
+(echo "# k_edge2 forced from 2048 tiles on (BT_EDGE_PREF_TILES=1 BT_EDGE_MIN_TILES=1)"; BT_EDGE_PREF_TILES=1 BT_EDGE_MIN_TILES=1 python tools/gpu_sweep.py 2048 4096 8192 16384 32768) 2>&1 | cut -c1-330 > $OUT/edge2_forced.txt
 (python tools/gpu_timing.py --workload window; BT_ETILE_TWO=0 python tools/gpu_timing.py --workload window) > $OUT/window_rounds_per_trip.txt 2>&1
 python tools/gpu_spec_time.py > $OUT/plan_call_host_time.txt 2>&1
 python tests/sequence_report.py > $OUT/sequence_ate.txt 2>&1

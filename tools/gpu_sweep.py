@@ -39,19 +39,6 @@ for M in [int(x) for x in (sys.argv[1:] or ["256", "1024", "4096", "16384"])]:
     print(f"E={plan.E:9d} tracks={plan.m:8d} tiles={plan.tiles:6d} plan={plan_ms:8.1f}ms | " +
           " ".join(f"{n}={v:9.2f}us" for n, v in med.items()) + f" step={wall:8.1f}us {plan.jacobian_kernel}" +
           f" | k_tile: {alg/1e6:8.2f} MB algorithmic -> {alg/med['tile']/1e3:8.1f} GB/s = {alg/med['tile']/1e3/8000*100:5.2f}% of 8 TB/s, {plan.E/med['tile']:.0f} edges/us", flush=True)
-    if int(os.environ.get("BT_DEBUG_MODE", "0")) & 32:
-        torch.cuda.synchronize()
-        off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
-        raw = st.ws.cpu().numpy()
-        stat_off = off + 2 * (((6 * plan.n * 4 + 64 + 255) // 256) * 256)            # dx, dx0, then the status block
-        pf = np.frombuffer(raw[stat_off + 16 + 160: stat_off + 16 + 320].tobytes(), dtype=np.int64).reshape(2, 10)
-        names = ["tile top", "iterations", "finish", "y", "schur", "flush", "drain", "-", "tiles", "-"]
-        for w, nm in enumerate(("wave 0", "wave mid")):
-            print(f"  k_edge {nm} cycles: " + " ".join(f"{n}={v}" for n, v in zip(names, pf[w])))
-        pf2 = np.frombuffer(raw[stat_off + 16 + 320: stat_off + 16 + 480].tobytes(), dtype=np.int64).reshape(2, 10)
-        names2 = ["issue loads", "lds operands", "edge_eval", "Ej/Ei", "group_sum", "E stores", "pair fma", "rotate(prev)"]
-        for w, nm in enumerate(("wave 0", "wave mid")):
-            print(f"  k_edge {nm} inside the iterations: " + " ".join(f"{n}={v}" for n, v in zip(names2, pf2[w])))
     if int(os.environ.get("BT_DEBUG_MODE", "0")) & 64:          # a -DBT_E2_PROF build of k_edge2 (tools/build_variant.sh)
         torch.cuda.synchronize()
         off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
