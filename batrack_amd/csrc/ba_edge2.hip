@@ -826,15 +826,15 @@ static int launch_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEve
     }
     // waves per workgroup = per CU: two per SIMD (the kernel's 256 registers) unless their LDS slices do not fit
     int W = (int)std::min<size_t>(8, lds_cu / lds_w);
-    static const int cap = std::getenv("BT_EDGE_WAVES_PER_CU") ? std::atoi(std::getenv("BT_EDGE_WAVES_PER_CU")) : 0;   // measurement only
-    if (cap > 0 && W > cap) W = cap;
     if (W < 1) return BT_EUNSUPPORTED;
     const int per_cu = W;                                              // waves per CU
-    // waves per workgroup: 2.  Measured at 8.4M edges / one tile per wave (profiles/r05_edge2_workgroup.txt): 1 wave 169 / 74 us,
-    // 2 waves 160 / 48, 4 waves 179 / 36, 8 waves (the whole CU) 228 / 43 — larger workgroups halve the atomics again but are not
-    // all resident from the start (the waves' lifetimes stay the same, the kernel gets longer)
-    static const int wg = std::getenv("BT_EDGE2_WG_WAVES") ? std::atoi(std::getenv("BT_EDGE2_WG_WAVES")) : 2;          // (measurement)
-    if (wg > 0 && wg < W) W = wg;
+    // waves per workgroup: 2, and 4 where every wave has a single tile (the atomics at the end are then most of a wave's life).
+    // Measured (profiles/r05_edge2_workgroup.txt; us at 2048 / 4096 / 8192 / 16384 tiles): 2 waves 48 / 60 / 89 / 160, 4 waves
+    // 36 / 56 / 95 / 179, 8 waves (the whole CU) 43 / 70 / 121 / 228, 1 wave 74 / - / - / 169 — larger workgroups halve the atomics
+    // again but are not all resident from the start (the waves' lifetimes stay the same, the kernel gets longer)
+    static const int wg_env = std::getenv("BT_EDGE2_WG_WAVES") ? std::atoi(std::getenv("BT_EDGE2_WG_WAVES")) : 0;      // (measurement)
+    const int wg = wg_env > 0 ? wg_env : (pd.T <= n_cu * per_cu ? 4 : 2);
+    if (wg < W) W = wg;
     const size_t lds = lds_w * (size_t)W;
     static size_t lds_set = 0;
     if (lds_set != lds) {

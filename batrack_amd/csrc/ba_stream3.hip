@@ -271,11 +271,11 @@ static size_t edge_lds_bytes(const PlanDev &pd, int mode) {
 // k_edge2 / k_edge take graphs of many tiles, all slot-uniform (the plan's em_ok), whose tiles see at most 10 cameras (row
 // tiles of the Schur product) and 64 camera pairs (one lane per pair in the prologue).
 // Measured on the benchmark generator (whole-step times; profiles/r02_kernel_choice.txt, r05_edge2_vs_edge.txt): k_tile is
-// fastest up to ~1500 tiles, k_stream at 2048 (two waves per tile fill the chip sooner: 130 against 140 us), k_edge2 from 4096 on
-// (151 against 160 us); where both apply, k_stream keeps the graphs below BT_EDGE_PREF_TILES.
+// fastest up to ~1500 tiles; from 2048 tiles k_edge2 where the tiles are slot-uniform (whole step 122 against k_stream's 130 us at
+// 2048 tiles, 151 against 160 at 4096), k_stream otherwise (BT_EDGE_PREF_TILES: k_stream keeps the graphs below it where both apply).
 bool edge_applies(const PlanDev &pd) {
     static const int off = std::getenv("BT_EDGE_OFF") ? std::atoi(std::getenv("BT_EDGE_OFF")) : 0;   // measurement only
-    static const int pref = std::getenv("BT_EDGE_PREF_TILES") ? std::atoi(std::getenv("BT_EDGE_PREF_TILES")) : 4096;
+    static const int pref = std::getenv("BT_EDGE_PREF_TILES") ? std::atoi(std::getenv("BT_EDGE_PREF_TILES")) : 0;
     if (off || !pd.em_ok || pd.T < pd.em_min || pd.max_cams > 10 || pd.max_cams <= 0 || pd.max_tile_pairs > 64 || pd.max_tile_pairs <= 0)
         return false;
     return pd.T >= pref || !stream_applies(pd);

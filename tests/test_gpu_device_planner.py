@@ -63,7 +63,7 @@ def test_lists_outside_the_device_path_are_planned_by_the_host():
     g = graphgen.make_graph(64, 2048, 8, seed=0)
     idx = [torch.as_tensor(a, device=DEV) for a in (g.ii, g.jj, g.kk)]
     p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
-    assert p.built_on_device and p.jacobian_kernel == "k_stream" and p.tiles == 2048
+    assert p.built_on_device and p.jacobian_kernel == "k_edge" and p.tiles == 2048      # (slot-uniform tiles: k_edge2; ragged ones: k_stream, below)
     prev = wave_per_tile_kernels(False)
     try:
         p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
@@ -230,12 +230,12 @@ def test_sharded_plans_are_laid_out_on_the_device_too(graph, world):
 
 
 @pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
-@pytest.mark.parametrize("variant", ["k_stream_2048", "k_edge_8192", "k_edge_8192_shuffled", "repeats", "ragged", "sharded"])
+@pytest.mark.parametrize("variant", ["k_edge_2048", "k_edge_8192", "k_edge_8192_shuffled", "repeats", "ragged", "sharded"])
 def test_device_planned_tables_of_the_wave_per_tile_kernels_equal_the_hosts(variant):
     """Graphs of 2048 tiles and more (k_stream, k_edge): slot_code, tile_la, the tile records with their straddle flag, and — where
     every tile is slot-uniform — it_edge and tile_sinfo come from kernels (plan_device.hip) and equal the host's."""
     rng = np.random.default_rng(23)
-    g, fixedp = graphgen.make_graph(64, 2048 if variant == "k_stream_2048" else 8192 if "8192" in variant else 4096, 8, seed=6), 1
+    g, fixedp = graphgen.make_graph(64, 2048 if variant == "k_edge_2048" else 8192 if "8192" in variant else 4096, 8, seed=6), 1
     ii, jj, kk = (np.asarray(a) for a in (g.ii, g.jj, g.kk))
     if variant == "repeats":                    # repeated observations: runs across the half-chunk boundary (straddle flags), repeat bits
         extra = rng.integers(0, ii.size, ii.size // 2)

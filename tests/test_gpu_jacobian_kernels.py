@@ -1,4 +1,4 @@
-"""-m gpu: the three Jacobian kernels.  A plan picks k_tile, k_stream or k_edge from its size and shape; the
+"""-m gpu: the Jacobian kernels.  A plan picks k_tile, k_stream or k_edge (k_edge2 + k_edge) from its size and shape; the
 fixtures are small and all take k_tile, so (a) graphs of the benchmark generator large enough for the plan to pick k_stream
 and k_edge BY ITSELF are compared with the float64 oracle, and (b) the whole parity suite is re-run in child processes with
 the selection forced (the thresholds are read once per process), so every fixture that fits a kernel's layout goes through it."""
@@ -22,15 +22,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GATES = {8: (2e-7, 1e-10, 1e-5, 1e-5, 1e-5), 6: (2e-7, 1e-6, 1e-5, 1e-5, 1e-5), 4: (5e-6, 5e-6, 3e-4, 3e-4, 1e-4)}
 
 
+def ragged(g, drop=0.15):
+    """The graph without a random 15 % of its observations: tracks of different lengths, tiles that are not slot-uniform (k_stream's
+    graphs; a missing LAST observation alone would leave the slots of a tile aligned)."""
+    keep = np.random.default_rng(11).random(np.asarray(g.kk).size) > drop
+    import copy
+    h = copy.copy(g)
+    for name in ("ii", "jj", "kk", "targets3", "weights", "weights_pose"):
+        setattr(h, name, np.ascontiguousarray(np.asarray(getattr(g, name))[keep]))
+    return h
+
+
 @pytest.mark.parametrize("frames,M,kernel,so,wpt", [(16, 16, "k_tile", False, True), (64, 1024, "k_tile", False, True),
-                                                  # from 2048 tiles the wave-per-tile kernels, mixed precision: inside the 1e-5 bar ...
+                                                  # from 2048 tiles the wave-per-tile kernels, mixed precision: inside the 1e-5 bar:
+                                                  # k_edge2 / k_edge where the tiles are slot-uniform, k_stream where they are not ...
                                                   (64, 2048, "k_stream", False, True), (64, 2048, "k_stream", True, True),
-                                                  (64, 4096, "k_edge", False, True), (64, 6144, "k_edge", False, True), (64, 6144, "k_edge", True, True),
+                                                  (64, 2048, "k_edge", False, True), (64, 4096, "k_edge", False, True),
+                                                  (64, 6144, "k_edge", False, True), (64, 6144, "k_edge", True, True),
                                                   # ... or, switched off by the caller, the float64 tile kernel at every size
                                                   (64, 2048, "k_tile", False, False), (64, 2048, "k_tile", True, False), (64, 6144, "k_tile", False, False)])
 def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, wpt):
     from batrack_amd.plan import wave_per_tile_kernels
     g = graphgen.make_graph(frames, M, 8, seed=5)
+    if kernel == "k_stream":
+        g = ragged(g)
     f = lambda a: np.asarray(a, np.float32).astype(np.float64)
     d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics), targets3=f(g.targets3),
              weights=f(g.weights), weights_pose=f(g.weights_pose), ii=g.ii, jj=g.jj, kk=g.kk, bounds=np.asarray(g.bounds))
@@ -62,7 +77,7 @@ def test_the_kernel_choice_is_the_plans_own():
     """A plan keeps the layout it was built with: switching the setting afterwards changes neither its kernel nor its tables."""
     import torch
     from batrack_amd.plan import Plan, wave_per_tile_kernels
-    g = graphgen.make_graph(64, 2048, 8, seed=2)
+    g = ragged(graphgen.make_graph(64, 2048, 8, seed=2))
     T = lambda a: torch.as_tensor(a, device="cuda:0")
     ii, jj, kk = T(g.ii), T(g.jj), T(g.kk)
     assert wave_per_tile_kernels() is True                              # the default
