@@ -33,6 +33,9 @@ namespace bt {
 namespace e2 {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+#ifndef BT_E2_PRIO_SHIFT
+#define BT_E2_PRIO_SHIFT 13        // log2 of the priority slice in shader clocks
+#endif
 #ifndef BT_E2_SB
 #define BT_E2_SB __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -295,10 +298,34 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
     auto olane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
     // (a wave without tiles — the launch's last workgroup may hold some — runs the prologue on tile 0, skips the loop, and
     //  takes part in the workgroup's barriers at the end with nothing to add)
-    const bool has_work = gw * tiles_per_wave < pd.T;
-    const int t_begin = has_work ? gw * tiles_per_wave : 0, t_end = has_work ? min(pd.T, t_begin + tiles_per_wave) : 0;
+    // Wave priority.  A SIMD holds two of these waves, and its arbiter serves the OLDER one first whenever both have an instruction
+    // ready: measured (tools/gpu_wave_times.py, 8.4M edges) the first wave of a SIMD walks its 8 tiles in 83-96 us, the second in
+    // 110-120 — and the kernel ends with the last wave.  So the two take turns: a wave learns from an arrival counter of its SIMD
+    // whether it is the first or the second, and raises its priority (s_setprio) in every other slice of the CU's clock, the slices in
+    // which its partner lowers it.
+    int arrive_rank = 0;
+    if (a.priv) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4) /* HW_ID: simd 5:4, cu 11:8, sh 12, se 15:13 */, xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) /* XCC_ID */;
+        const unsigned idx = ((xcc & 7u) << 10) | (((hw >> 13) & 7u) << 7) | (((hw >> 12) & 1u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u);
+        int *arr = reinterpret_cast<int *>(a.priv + priv_copy_doubles((size_t)pd.D, (size_t)pd.P));
+        if (lane == 0) arrive_rank = atomicAdd(arr + idx, 1);
+    }
+    // The launch's first waves take the LAST tiles: they are the first on their SIMDs and stay a few per cent ahead even with the
+    // priorities taking turns, and the tile list of a growing map ends with its newest frames — the ones whose windows are clipped
+    // (repeated and self observations: the tiles that take longest; 143 -> @@ us at 8.4M edges of the benchmark generator).
+#ifdef BT_E2_FORWARD      /* measurement */
+    const int gwt = gw;
+#else
+    const int gwt = (int)(gridDim.x * nwv) - 1 - gw;
+#endif
+    const bool has_work = gwt * tiles_per_wave < pd.T;
+    const int t_begin = has_work ? gwt * tiles_per_wave : 0, t_end = has_work ? min(pd.T, t_begin + tiles_per_wave) : 0;
 #ifdef BT_E2_PROF
     long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_c = clock64(), pf_n;
+#endif
+#ifdef BT_E2_TIMES        /* measurement (tools/gpu_wave_times.py): every wave's start, end of its tiles and end, 100 MHz clock, into patches_out */
+    const long long wt0 = wall_clock64();
+    long long wt1 = 0;
 #endif
 
     // E Q E^T since the last flush lives in LDS, as float64 (schur_rows); E (Q w') of the current tile in float32 registers,
@@ -440,6 +467,7 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
     int e_lgS = LGS >= 0 ? LGS : -1;                           // slots per track of the tiles that wrote the local E last
     const double b0 = (double)a.b0, b1 = (double)a.b1, b2 = (double)a.b2, b3 = (double)a.b3;
 
+    const int rank_s = __builtin_amdgcn_readfirstlane(arrive_rank) & 1;      // (the counter's answer has long arrived)
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int flags = tile == t_begin ? 0 : rec.flags;
@@ -509,6 +537,24 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
             e_lgS = lgS;
         }
         const bool any_rep = __builtin_amdgcn_ballot_w64(rep && lane <= S1) != 0;
+        // Repeated observations (several slots of a track with the same target camera: the slots are sorted by pair, so they are
+        // neighbours): their E entries are added up across the lanes — a segmented suffix sum over the run, distances 1, 2, 4, 8 —
+        // and the run's first lane stores the sum.  (LDS float atomics, what round 4 used, cost ~250 cycles per wave instruction:
+        // the tiles of the benchmark graphs' border frames, whose clipped targets repeat, took twice as long as the others.)
+        // (seg_dist: the largest of the distances 1, 2, 4, 8 at which some lane finds a lane of its run; 0: the repeats are all of
+        //  fixed cameras, nothing to add up)
+        int seg_dist = 0;
+        if (any_rep && lgS <= 4) {
+            const int slot = olane() & S1;
+            const int key = used && lb != 0xffu ? (int)lb : -1 - slot;
+            // (the lane moves first, with every lane active: a DPP read of a lane that a short-circuited condition has switched off
+            //  does not return that lane's value)
+            const int k1 = __builtin_amdgcn_update_dpp(-999, key, 0x101, 0xf, 0xf, false), k2 = __builtin_amdgcn_update_dpp(-999, key, 0x102, 0xf, 0xf, false);
+            const int k4 = __builtin_amdgcn_update_dpp(-999, key, 0x104, 0xf, 0xf, false), k8 = __builtin_amdgcn_update_dpp(-999, key, 0x108, 0xf, 0xf, false);
+            const bool h1 = (slot + 1 <= S1) & (k1 == key), h2 = (slot + 2 <= S1) & (k2 == key), h4 = (slot + 4 <= S1) & (k4 == key), h8 = (slot + 8 <= S1) & (k8 == key);
+            seg_dist = __builtin_amdgcn_ballot_w64(h8) ? 8 : __builtin_amdgcn_ballot_w64(h4) ? 4 : __builtin_amdgcn_ballot_w64(h2) ? 2 : __builtin_amdgcn_ballot_w64(h1) ? 1 : 0;
+        }
+        const bool seg = seg_dist > 0, rep_add = any_rep && lgS > 4;
         const unsigned la = __builtin_amdgcn_readfirstlane(la_c);          // the tile's tracks share their source camera
         const bool self_tile = la != 0xffu && __builtin_amdgcn_ballot_w64(used && lane <= S1 && lb == la) != 0;   // some slot's target IS the source (ii == jj)
         const bool hasB = G < 64;                                          // (S = 1: a step is the tile's 64 tracks, no second half)
@@ -535,6 +581,10 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
         BT_E2_PF(0);
         auto step = [&](auto pc, int it) {
             constexpr int P = decltype(pc)::value;
+#ifndef BT_E2_NO_PRIO
+            // (see "wave priority" at the top; slices of the CU's clock, so that exactly one of a SIMD's two waves is raised at any time)
+            if ((((unsigned)clock64() >> BT_E2_PRIO_SHIFT) & 1u) ^ (unsigned)rank_s) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
             const f2 tu = tu_q[P], tv = tv_q[P];
             const int fl = fl_q[P];
             const int trA = it * 2 * G + tl, trB = (trA + G) & 63;
@@ -597,7 +647,7 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
             const f2 wa0 = W0 * a0, wa2 = W0 * a2, wa3 = W0 * a3, wa4 = W0 * a4, wa5 = W0 * a5;
             const f2 wb1 = W1 * b1_, wb2 = W1 * b2_, wb3 = W1 * b3_, wb4 = W1 * b4_, wb5 = W1 * b5_;
             // Ej = Jj^T W Jz (ba.py:263)
-            const f2 Ej[6] = { wa0 * jz0, wb1 * jz1, fma2(wa2, jz0, wb2 * jz1), fma2(wa3, jz0, wb3 * jz1),
+            f2 Ej[6] = { wa0 * jz0, wb1 * jz1, fma2(wa2, jz0, wb2 * jz1), fma2(wa3, jz0, wb3 * jz1),
                                fma2(wa4, jz0, wb4 * jz1), fma2(wa5, jz0, wb5 * jz1) };
             // the tracks' sums over their S lanes: C, w (ba.py:287,292) and the source-camera E, Ei = -Ad^T Ej
             const f2 wj0 = W0 * jz0, wj1 = W1 * jz1;
@@ -632,20 +682,55 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
             }
             BT_E2_PF(4);
             // ---- the step's E.  Column of a track = its index in the step (first halves 0 .. G-1, second halves G .. 2G-1).
-            // Target-camera rows: one lane per (track, camera) — a plain store, zeros where there is no edge — unless the plan
-            // marks a repeated observation (then the step's E is cleared first and those lanes add)
-            if (any_rep) {
-                float4 *z = reinterpret_cast<float4 *>(Eh);
-                for (int i = lane; i < (R * kRow + 3) / 4; i += 64) z[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-            if (used && lb != 0xffu && lb != la) {
-                float *row = Eh + lb * 6 * kRow + tl;
-                if (rep) {
+            // Target-camera rows: one lane per (track, camera) — a plain store, zeros where there is no edge; where the plan marks
+            // repeated observations the run's first lane stores the run's sum (`seg`, at the tile's top)
+            if (seg) {
+                // bit d: the lane 2^d above belongs to this lane's run; bit 4: the lane is its run's first (formed here, per step, in
+                // the tiles that need it: a register held across the tile costs the others a spill)
+                const int slot = lane & S1;
+                const int key = used && lb != 0xffu ? (int)lb : -1 - slot;                      // (no two lanes without a camera match)
+                const int k1 = __builtin_amdgcn_update_dpp(-999, key, 0x101, 0xf, 0xf, false), k2 = __builtin_amdgcn_update_dpp(-999, key, 0x102, 0xf, 0xf, false);
+                const int k4 = __builtin_amdgcn_update_dpp(-999, key, 0x104, 0xf, 0xf, false), k8 = __builtin_amdgcn_update_dpp(-999, key, 0x108, 0xf, 0xf, false);
+                const int kp = __builtin_amdgcn_update_dpp(-999, key, 0x111, 0xf, 0xf, false);   // row_shr:1: the lane below
+                const unsigned seg_bits = (slot + 1 <= S1 && k1 == key ? 1u : 0u) | (slot + 2 <= S1 && k2 == key ? 2u : 0u) | (slot + 4 <= S1 && k4 == key ? 4u : 0u) |
+                                          (slot + 8 <= S1 && k8 == key ? 8u : 0u) | (slot == 0 || kp != key ? 16u : 0u);
+                auto shl = [&](f2 v, auto ctrl) {
+                    return f2{__uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v.x), decltype(ctrl)::value, 0xf, 0xf, true)),
+                              __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v.y), decltype(ctrl)::value, 0xf, 0xf, true))};
+                };
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) { atomicAdd(row + c * kRow, Ej[c].x); if (hasB) atomicAdd(row + c * kRow + G, Ej[c].y); }
-                } else {
+                for (int c = 0; c < 6; ++c) Ej[c] = fma2(splat(seg_bits & 1u ? 1.0f : 0.0f), shl(Ej[c], IC<0x101>()), Ej[c]);
+                if (seg_dist > 1) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) Ej[c] = fma2(splat(seg_bits & 2u ? 1.0f : 0.0f), shl(Ej[c], IC<0x102>()), Ej[c]);
+                }
+                if (seg_dist > 2) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) Ej[c] = fma2(splat(seg_bits & 4u ? 1.0f : 0.0f), shl(Ej[c], IC<0x104>()), Ej[c]);
+                }
+                if (seg_dist > 4) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) Ej[c] = fma2(splat(seg_bits & 8u ? 1.0f : 0.0f), shl(Ej[c], IC<0x108>()), Ej[c]);
+                }
+                if (used && lb != 0xffu && lb != la && (seg_bits & 16u)) {
+                    float *row = Eh + lb * 6 * kRow + tl;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) { row[c * kRow] = Ej[c].x; if (hasB) row[c * kRow + G] = Ej[c].y; }
+                }
+            } else {
+                if (rep_add) {                      // (more than 16 slots per track: the step's E is cleared first and the repeats add)
+                    float4 *z = reinterpret_cast<float4 *>(Eh);
+                    for (int i = lane; i < (R * kRow + 3) / 4; i += 64) z[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                if (used && lb != 0xffu && lb != la) {
+                    float *row = Eh + lb * 6 * kRow + tl;
+                    if (rep && rep_add) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) { atomicAdd(row + c * kRow, Ej[c].x); if (hasB) atomicAdd(row + c * kRow + G, Ej[c].y); }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) { row[c * kRow] = Ej[c].x; if (hasB) row[c * kRow + G] = Ej[c].y; }
+                    }
                 }
             }
             if (lead) {
@@ -727,6 +812,9 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
             px = px_n; py = py_n; pdisp = pd_n; mono_v = mono_n; lm_v = lm_n;
         }
     }
+#ifdef BT_E2_TIMES
+    wt1 = wall_clock64();
+#endif
     // ---- the end: the workgroup's waves add up what they hold, then the roots of the tree issue the atomics (see the top)
     {
         const int S_p = 1 << pa_lgS;
@@ -789,6 +877,13 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
             }
         }
     }
+#ifdef BT_E2_TIMES
+    if (lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long *o = reinterpret_cast<long long *>(a.patches_out) + 4 * (size_t)gw;
+        o[0] = wt0; o[1] = wt1; o[2] = wall_clock64(); o[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) /* HW_ID */ | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) /* XCC_ID */ << 32);
+    }
+#endif
 #ifdef BT_E2_PROF
     BT_E2_PF(8);
     if (lane == 0 && (gw == 0 || gw == (int)(gridDim.x * nwv) / 2)) {

@@ -469,6 +469,9 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PlanDev pd, StepArgs a, i
             }
             if (s != 0.0) atomicAdd(&a.y[i], s);
         }
+        // ... and its arrival counters cleared for the next step
+        int *arr = reinterpret_cast<int *>(a.priv + priv_copy_doubles((size_t)pd.D, (size_t)pd.P));
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kPrivArrive; i += pair_blocks * blockDim.x) if (arr[i] != 0) arr[i] = 0;
     }
     const bool live = p < pd.P;
     int ia = -1, ib = -1;

@@ -70,7 +70,7 @@ static void layout_workspace(bt_plan *pl) {
     if (I.tiles >= pl->em_min) {       // (plans k_edge2 can take: by the tile count alone — whether the tiles are slot-uniform is, for
                                        //  a device-planned list, known only after the upload, and the layout must not depend on the planner)
         w.priv = off;
-        off = align_up(off + ((size_t)kPrivY * D + (size_t)kPrivP * I.pairs * kPairAccStride) * sizeof(double), 256);
+        off = align_up(off + priv_doubles(D, (size_t)I.pairs) * sizeof(double), 256);
     }
     w.zero_bytes = off - w.sys;
     w.packed = off;   off = align_up(off + ((size_t)I.nnz_blocks * 36 + D) * sizeof(double), 256);   // exchange form of [S | y]

@@ -21,6 +21,8 @@ constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj 
 // served one after the other — at 8.4M edges they were 35 of the kernel's 170 us.  A wave adds to copy (its index mod the count);
 // k_pair_finalize adds the copies up and clears them.
 constexpr int kPrivY = 16, kPrivP = 4;
+// behind them: one arrival counter per SIMD of the chip (k_edge2: which of a SIMD's two waves am I — see "wave priority" there)
+constexpr int kPrivArrive = 8192;   // ints: xcc (3 bits) | se (3) | sh (1) | cu (4) | simd (2)
 constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
 constexpr int kLdsRowStride = 66;
 constexpr int kMaxLevelCols = 4;
@@ -34,6 +36,9 @@ constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geom
 #else
 #define BT_HD
 #endif
+// doubles of the private region (WsLayout::priv): the copies of y, of the per-pair sums, the arrival counters
+BT_HD inline size_t priv_copy_doubles(size_t D, size_t pairs) { return (size_t)kPrivY * D + (size_t)kPrivP * pairs * kPairAccStride; }
+BT_HD inline size_t priv_doubles(size_t D, size_t pairs) { return priv_copy_doubles(D, pairs) + kPrivArrive / 2; }
 BT_HD inline size_t sp_tile_doubles(int max_rows16, int max_tile_pairs) {
     const size_t nt = (size_t)max_rows16 / 16;
     return nt * (nt + 1) / 2 * 256 + (size_t)max_rows16 + (size_t)(max_tile_pairs > 0 ? max_tile_pairs : 1) * 32;
