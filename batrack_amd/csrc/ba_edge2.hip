@@ -923,12 +923,12 @@ static int launch_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEve
     int W = (int)std::min<size_t>(8, lds_cu / lds_w);
     if (W < 1) return BT_EUNSUPPORTED;
     const int per_cu = W;                                              // waves per CU
-    // waves per workgroup: 2, and 4 where every wave has a single tile (the atomics at the end are then most of a wave's life).
-    // Measured (profiles/r05_edge2_workgroup.txt; us at 2048 / 4096 / 8192 / 16384 tiles): 2 waves 48 / 60 / 89 / 160, 4 waves
-    // 36 / 56 / 95 / 179, 8 waves (the whole CU) 43 / 70 / 121 / 228, 1 wave 74 / - / - / 169 — larger workgroups halve the atomics
-    // again but are not all resident from the start (the waves' lifetimes stay the same, the kernel gets longer)
+    // waves per workgroup: 4.  The waves of a workgroup add their sums up before the atomics; larger workgroups halve the atomics
+    // again but wait for more partners.  Measured with the waves' priorities taking turns (profiles/r05_edge2_workgroup.txt; us at
+    // 8192 / 16384 / 32768 tiles): 2 waves 87 / 139 / 245, 4 waves 77 / 130 / 240, 8 waves (the whole CU) 76 / 133 / 248; at one tile
+    // per wave (2048 tiles) 48 / 36 / 43.
     static const int wg_env = std::getenv("BT_EDGE2_WG_WAVES") ? std::atoi(std::getenv("BT_EDGE2_WG_WAVES")) : 0;      // (measurement)
-    const int wg = wg_env > 0 ? wg_env : (pd.T <= n_cu * per_cu ? 4 : 2);
+    const int wg = wg_env > 0 ? wg_env : 4;
     if (wg < W) W = wg;
     const size_t lds = lds_w * (size_t)W;
     static size_t lds_set = 0;
