@@ -18,7 +18,11 @@ graph is the same, so scaling is "strong".
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel named in
 BASELINE.json (the Jacobian kernel, k_tile): algorithmic bytes (SURVEY.md §8d:
 40 B/edge + 20 B/track + 72 B/pose) over the kernel's own duration measured with
-HIP events recorded by the launch on its stream (bt_ba_step_timed).
+HIP events recorded by the launch on its stream (bt_ba_step_timed); `cold_kernel_us` / `cold_frac` the
+same behind a 512 MB sweep (L2 and Infinity Cache hold nothing of the graph); `roofline.large` the same
+two numbers for the 8.4M-edge graph of the same generator, where the kernel (k_edge2) streams.
+`ms_per_step_blocks`: the K steps timed five more times (min / median / max); `value_large`: the 2.1M-edge
+graph's iterations/s (the workload that shards).
 `cpu_baseline` = `oracle.refseq`, the torch-CPU restatement that keeps the reference's
 operator sequence, timed on this host at 8 threads and at the
 container's CPU quota (rank 0, N = 1 only); the scalar C port of the checker is reported beside it.

@@ -44,7 +44,7 @@ late = np.argsort(end)[-16:]
 print("the 16 last waves: index, start, end: " + " ".join(f"{i}:{start[i]:.0f}-{end[i]:.0f}" for i in late))
 tp = tiles_end - start
 wpf = max(1, n // 64)                                   # waves per source frame (the generator's tiles are frame-major)
-print("tiles phase by source frame: " + " ".join(f"{tp[f * wpf:(f + 1) * wpf].mean():.0f}" for f in range(min(64, n // wpf))))
+print("tiles phase by 64th of the launch (consecutive waves, us): " + " ".join(f"{tp[f * wpf:(f + 1) * wpf].mean():.0f}" for f in range(min(64, n // wpf))))
 print("tiles phase by wave of the workgroup (index mod 2): " + " ".join(f"{tp[k::2].mean():.1f}" for k in range(2)))
 print("tiles phase by workgroup mod 8 (XCD): " + " ".join(f"{tp[(np.arange(n) // 2) % 8 == k].mean():.1f}" for k in range(8)))
 print("tiles phase by workgroup mod 32 : " + " ".join(f"{tp[(np.arange(n) // 2) % 32 == k].mean():.0f}" for k in range(32)))

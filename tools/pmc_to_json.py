@@ -17,15 +17,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from batrack_amd import _lib  # noqa: E402
 
-JACOBIAN = ("k_tile", "k_etile", "k_stream", "k_edge")
 
 
 def kernel_avg(db, counter):
     """(kernel name, launches, average value per launch) of the Jacobian kernel with the most launches in this pass."""
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
-    # (mode 2 of k_tile / k_etile / k_stream / k_edge is the step's last kernel; k_edge2's first template argument is a tile count)
-    rows = [r for r in rows if any(k in r[0] for k in JACOBIAN) and "upd" not in r[0].lower() and not re.search(r"k_(tile|etile|stream|edge)<2", r[0])]
+    # the step's kernels by their template names (a planner kernel like k_edge_tables is none of them); mode 2 of k_tile / k_etile /
+    # k_stream / k_edge is the step's last kernel, k_edge2's first template argument is a tile count
+    rows = [r for r in rows if re.search(r"\bk_(tile|etile|stream|edge|edge2)<", r[0]) and "upd" not in r[0].lower()
+            and not re.search(r"\bk_(tile|etile|stream|edge)<2", r[0])]
     if not rows:
         raise SystemExit(f"{db}: no Jacobian kernel with counter {counter}")
     # the pose+structure instantiation: the one with the largest average (the structure-only / update modes move less)
