@@ -12,10 +12,15 @@
 //     walks 8+ tiles of one source frame — and go to the float64 accumulators in global memory every kPaFlushTiles tiles;
 //   * a step holds ALL S slots of its 2G tracks, so their rows of E, their C and w are complete when the step's edges are
 //     done: Q and w' are formed right there by the tracks' first lanes, and E Q E^T of those tracks goes onto the matrix pipe
-//     in the same step (v_mfma_f32_16x16x4_f32, K = the step's tracks, the float32 accumulators running across steps and
-//     tiles of one camera set, kSchurFlushTiles at most).  The local E is [rows][16 tracks] (3.8 KB instead of 13), there is no
-//     per-tile phase — no merge barrier, no pass over the tile's tracks, no clearing of E (every element of a step's E is
-//     stored by exactly one lane, zeros where an edge is missing, unless the plan marks a repeated observation);
+//     in the same step (v_mfma_f32_16x16x4_f32, K = the step's 16 tracks, from ZERO accumulators: float32 chains longer than
+//     that cost the update its fifth digit — DESIGN.md §4), the step's products added to float64 sums in LDS that run across
+//     the steps and tiles of one camera set (kSchurFlushTiles at most).  The local E is [rows][16 tracks] (3.8 KB instead of
+//     13), there is no per-tile phase — no merge barrier, no pass over the tile's tracks, no clearing of E (every element of a
+//     step's E is stored by exactly one lane, zeros where an edge is missing; repeated observations of a (track, camera) are
+//     added up across their lanes first);
+//   * the kernel is as long as its slowest wave (tools/gpu_wave_times.py): the two waves of a SIMD take turns at the higher
+//     issue priority (the arbiter's default serves the older one first: 83-96 against 110-120 us for the same 8 tiles), the
+//     launch's first waves take the last tiles, workgroups of 4 waves add their sums up before the atomics;
 //   * the gathered operands of a step live in one of two register sets by the step's parity and are re-loaded in place two
 //     steps ahead, the edge ids likewise: no register is moved, no load is waited for before its use.
 // Reference: ba.py:228-337, projective_ops.py:54-100.
@@ -312,7 +317,8 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
     }
     // The launch's first waves take the LAST tiles: they are the first on their SIMDs and stay a few per cent ahead even with the
     // priorities taking turns, and the tile list of a growing map ends with its newest frames — the ones whose windows are clipped
-    // (repeated and self observations: the tiles that take longest; 143 -> @@ us at 8.4M edges of the benchmark generator).
+    // (repeated and self observations: the tiles that take longest; 132 -> 129 us at 8.4M edges of the benchmark generator,
+    // profiles/r05_edge2_wave_times.txt).
 #ifdef BT_E2_FORWARD      /* measurement */
     const int gwt = gw;
 #else
