@@ -968,10 +968,6 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         pl->fz_ok = (pl->fz_lazy.size() / 3 < 65536 && pl->row_idx.size() < 32768 && pend_ok) ? 1 : 0;
         pl->fzp_ok = pl->fz_ok;                          // additionally: every column's panel rows (+ y) fit one wave
         for (int64_t j = 0; j < n; ++j) if (6 * (pl->col_ptr[(size_t)j + 1] - pl->col_ptr[(size_t)j] - 1) + 1 > 64) pl->fzp_ok = 0;
-        if (pl->fzp_ok) {                               // 2: the diagonal block's rows fit the same wave as well (k_solve_chain)
-            pl->fzp_ok = 2;
-            for (int64_t j = 0; j < n; ++j) if (6 * (pl->col_ptr[(size_t)j + 1] - pl->col_ptr[(size_t)j]) + 1 > 64) pl->fzp_ok = 1;
-        }
         for (int32_t l = 0; l < nlev; ++l) {
             if (pl->lvl_ptr[(size_t)l + 1] - pl->lvl_ptr[(size_t)l] > 2) { pl->fz_ok = 0; pl->fzp_ok = 0; }
             int32_t w0 = 0;

@@ -97,7 +97,7 @@ struct PlanDev {
     // fused schedule (k_solve_fused): pending updates per destination block, lazy triples per column
     const int32_t *fz_pend_ptr, *fz_pend, *fz_lazy_ptr, *fz_lazy, *fz_yurg, *fz_meta, *fz_pmeta, *bs_sync, *fz_rowinfo, *fz_pfirst, *fz_psecond;
     int fz_npend, fz_nlazy, fz_ok;      // fz_ok: no level has more than two columns
-    int fzp_ok;                         // and every column's panel fits one wave (k_solve_pipe); 2: with the diagonal block's rows too (k_solve_chain)
+    int fzp_ok;                         // and every column's panel fits one wave (k_solve_pipe)
     const int32_t *lvl_meta;   // [nlev][kMaxLevelCols][8]: col, diag pos, #sub-blocks, first rest triple, #rest triples, dp first, #dp, 0  (col = -1: unused)
 };
 
