@@ -79,6 +79,12 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? BT_
     const int nthr = blockDim.x, kTileWaves = nthr >> 6;          // 8 or 16 waves per tile (launch parameter)
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); tn = clock64(); pf[i] += tn - tc; tc = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#ifdef BT_TILE_TIMES      /* measurement (tools/gpu_wave_times_tile.py): a wave's 100 MHz clock at its start, after the prologue, its slots, the merge + Q, the Schur product, its end */
+    long long wt[6] = {(long long)wall_clock64(), 0, 0, 0, 0, 0};
+#define BT_WT(i) wt[i] = (long long)wall_clock64()
+#else
+#define BT_WT(i) do { } while (0)
+#endif
     // LDS carve-up for the largest tile of the plan (fixed offsets: tiles of one workgroup differ in size)
     const int R16max = SO ? 0 : pd.max_rows16;
     R *Eh = lds, *stg = Eh + R16max * kLdsRowStride;
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? BT_
         }
         __syncthreads();
         BT_PF(0);
+        BT_WT(1);
 
         R Cacc = 0, wacc = 0, Ei[6] = {0, 0, 0, 0, 0, 0};
         unsigned la_cur = 0xffu;
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? BT_
             }
             BT_PF(3);
         }
+        BT_WT(2);
         if (!SO) flush_ej(lb_acc);
 
         // per-wave partials -> LDS
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? BT_
         }
         __syncthreads();
         BT_PF(4);
+        BT_WT(3);
         if (SO) continue;
 
         BT_PF(5);
@@ -392,11 +401,21 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? BT_
             }
         }
         BT_PF(6);
+        BT_WT(4);
     }
     if (!SO) {
         flush_pair();
         BT_PF(7);
     }
+#ifdef BT_TILE_TIMES
+    if (!SO && !FUSE && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BT_WT(5);
+        long long *o = reinterpret_cast<long long *>(a.patches_out) + 8 * ((size_t)blockIdx.x * kTileWaves + wave);
+        for (int i = 0; i < 6; ++i) o[i] = wt[i];
+    }
+#endif
+#undef BT_WT
     if (PROF && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BT_PF(8);
