@@ -2450,8 +2450,7 @@ static bool use_pipe_solver(const PlanDev &pd) {
 static int solver_threads() {
     // 12 waves: enough helper threads for one round of update rows on banded systems, and a
     // 170-register budget per thread so that a whole 6x6 operand block can be in flight from LDS
-    static const int t = std::getenv("BT_SOLVER_THREADS") ? std::atoi(std::getenv("BT_SOLVER_THREADS")) : 768;   // measurement only
-    return t >= 256 && t <= 768 ? (t / 64) * 64 : 768;
+    return 768;
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is one value per kernel for the whole process, while up to eight cached
@@ -2596,8 +2595,7 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int mode = solver_mode(pd);
         const bool prof = (a.dbg & 16) != 0;
         const int nthr = solver_threads();
-        static const int refine_env = std::getenv("BT_SOLVER_REFINE") ? std::atoi(std::getenv("BT_SOLVER_REFINE")) : 1;   // measurement only
-        const int passes = (mode >= 1 && refine_env) ? 2 : 1;        // float32 factor: one step of iterative refinement
+        const int passes = mode >= 1 ? 2 : 1;                        // float32 factor: one step of iterative refinement
         for (int pass = 0; pass < passes; ++pass) {
             if (pass == 1) hipLaunchKernelGGL(k_refine_residual, dim3((pd.D + 3) / 4), dim3(256), 0, st, pd, a);
             hipEvent_t *evp = pass == 0 ? ev : nullptr;                // (the event pair of kernel 3 times the first pass)

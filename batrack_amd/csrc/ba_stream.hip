@@ -569,8 +569,6 @@ static int launch_stream_t(const PlanDev &pd, const StepArgs &a, hipStream_t st,
             return BT_EHIP;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_stream<MODE, NT, PROF>, 128, lds) != hipSuccess || nb < 1) nb = 1;
-        static const int cap = std::getenv("BT_STREAM_WGS_PER_CU") ? std::atoi(std::getenv("BT_STREAM_WGS_PER_CU")) : 0;   // measurement only
-        if (cap > 0 && nb > cap) nb = cap;
         per_cu[slot] = nb; per_cu_lds[slot] = lds;
     }
     const int max_waves = n_cu * per_cu[slot];
