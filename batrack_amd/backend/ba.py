@@ -145,6 +145,20 @@ def _discard(stepper):
     _LAST_SHIFT[0] = None
 
 
+def _confirm(stepper):
+    """Settle a speculative plan.  True: it is the list's plan.  False: the guess was wrong — the plan is out of every cache.
+    An error of the confirmation itself (an index out of range in the new list) also takes the plan out of the caches before
+    it is raised again: a caller that catches it and calls once more must not step on the unconfirmed clone."""
+    try:
+        ok = stepper.plan.confirm()
+    except Exception:
+        _discard(stepper)
+        raise
+    if not ok:
+        _discard(stepper)
+    return ok
+
+
 def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True):
     """Build the plan of an edge list ahead of the BA calls that will use it.
 
@@ -248,10 +262,18 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     if targets_2d.shape[-1] != 2 or targets_2d.numel() != 2 * E:
         raise ValueError("targets_2d must be [1, E, 2]")
     stepper = _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, dev)
+    lmbda_in = lmbda                             # (what a repeated call after a failed speculation must be given again)
     lm_trk = None
     if isinstance(lmbda, torch.Tensor):
         if lmbda.numel() == 1:
             lmbda = float(lmbda)
+        else:
+            # a per-track tensor is checked against the plan's track count: a speculative clone carries its SOURCE's count, so
+            # the speculation is settled first (a wrong guess is rebuilt here, before anything is enqueued)
+            if stepper.plan.__dict__.get("speculative") and not _confirm(stepper):
+                stepper = _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, dev)
+        if isinstance(lmbda, float):
+            pass
         elif lmbda.numel() == stepper.plan.m:           # ba.py:299-300: lmbda.reshape(*C.shape), one value per distinct track
             lm_trk = _f32c(lmbda, "lmbda").reshape(-1).contiguous()
             lmbda = 0.0
@@ -266,10 +288,9 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
                                                        float(alpha), _lib.LOSS[loss], so, lm_trk)
         if PRINT:
             print("BA_rgbd_droid: PRINT is not implemented in batrack_amd (debug only, ba.py:244-245)")
-        if stepper.plan.__dict__.get("speculative") and not stepper.plan.confirm():
+        if stepper.plan.__dict__.get("speculative") and not _confirm(stepper):
             # the list was no shifted copy after all: what was just enqueued is void (the inputs are untouched) — once more, properly
-            _discard(stepper)
-            return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda, ii, jj, kk, bounds,
+            return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda_in, ii, jj, kk, bounds,
                                  ep=ep, PRINT=False, fixedp=fixedp, structure_only=structure_only, loss=loss, alpha=alpha)
         return (poses, out_patches) if so else (SE3(poses_out), out_patches)
     Pc = P.contiguous()
@@ -297,9 +318,8 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
                  bounds, lmbda, ep, alpha, loss, so, lmbda_per_track=lm_trk)
     if PRINT:
         print("BA_rgbd_droid: PRINT is not implemented in batrack_amd (debug only, ba.py:244-245)")
-    if stepper.plan.__dict__.get("speculative") and not stepper.plan.confirm():
-        _discard(stepper)
-        return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda, ii, jj, kk, bounds,
+    if stepper.plan.__dict__.get("speculative") and not _confirm(stepper):
+        return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda_in, ii, jj, kk, bounds,
                              ep=ep, PRINT=False, fixedp=fixedp, structure_only=structure_only, loss=loss, alpha=alpha)
     out_patches = patches_out.view(1, p_tot, 3, 1, 1)
     if so:

@@ -33,6 +33,7 @@
 
 #include "ba_edge.hpp"
 #include "ba_kernels.hpp"
+#include "dev_cache.hpp"
 
 namespace bt {
 namespace e2 {
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
                 for (int c = 0; c < kGeoD / 2; ++c) { const double2 t2 = g2[c]; gd[2 * c] = t2.x; gd[2 * c + 1] = t2.y; }
             }
             const Proj pA = project(gd, xyA.x, xyA.y, d.x, tu.x, tv.x, (fl & 1) != 0, b0, b1, b2, b3);
-            const Proj pB = project(gd, xyB.x, xyB.y, d.y, tu.y, tv.y, (fl & 2) != 0, b0, b1, b2, b3);
+            const Proj pB = project(gd, xyB.x, xyB.y, d.y, tu.y, tv.y, hasB && (fl & 2) != 0, b0, b1, b2, b3);
             BT_E2_PF(1);
             float gf[kGeoF];
             {
@@ -916,15 +917,10 @@ static size_t lds_bytes(const PlanDev &pd, int lgs, bool with_lmbda_trk) {
 template <int NT, int LGS, int LOSS>
 static int launch_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const size_t lds_w = (lds_bytes(pd, LGS, a.lmbda_trk != nullptr) + 255) & ~(size_t)255;     // one wave's slice
-    static int n_cu = 0;
-    static size_t lds_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return BT_EHIP;
-        n_cu = prop.multiProcessorCount;
-        lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
-    }
+    DevProps dp;
+    if (!device_props(&dp)) return BT_EHIP;
+    const int n_cu = dp.n_cu;
+    const size_t lds_cu = dp.lds_cu;
     // waves per workgroup = per CU: two per SIMD (the kernel's 256 registers) unless their LDS slices do not fit
     int W = (int)std::min<size_t>(8, lds_cu / lds_w);
     if (W < 1) return BT_EUNSUPPORTED;
@@ -937,12 +933,8 @@ static int launch_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEve
     const int wg = wg_env > 0 ? wg_env : 4;
     if (wg < W) W = wg;
     const size_t lds = lds_w * (size_t)W;
-    static size_t lds_set = 0;
-    if (lds_set != lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_edge2<NT, LGS, LOSS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return BT_EHIP;
-        lds_set = lds;
-    }
+    static LdsLimit lds_limit;
+    if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_edge2<NT, LGS, LOSS>), lds)) return BT_EHIP;
     if (a.dbg & 128) {                                                  // measurement: what the runtime says fits a CU
         static bool said = false;
         if (!said) {

@@ -25,6 +25,7 @@
 
 #include "ba_edge.hpp"
 #include "ba_kernels.hpp"
+#include "dev_cache.hpp"
 #include "ba_update.hpp"
 
 namespace bt {
@@ -650,11 +651,8 @@ int etile_precision_bytes(const PlanDev &pd) {
 template <int MODE, typename R, bool PROF = false, bool TWO = false>
 static int launch_etile_t(const PlanDev &pd, const StepArgs &a, int do_poses, int extra_blocks, int zero_blocks, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const size_t lds = etile_lds_bytes(pd, MODE, sizeof(R));
-    static size_t raised = 0;                      // per instantiation; only ever raised (several plans coexist)
-    if (lds > 48 * 1024 && lds > raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_etile<MODE, R, PROF, TWO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BT_EHIP;
-        raised = lds;
-    }
+    static LdsLimit lds_limit;                     // per instantiation and device; only ever raised (several plans coexist)
+    if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_etile<MODE, R, PROF, TWO>), lds)) return BT_EHIP;
     const dim3 grid((unsigned)(pd.T + extra_blocks + zero_blocks)), blk(kEtThreads);
     if (ev0) hipExtLaunchKernelGGL((k_etile<MODE, R, PROF, TWO>), grid, blk, lds, st, ev0, ev1, 0, pd, a, do_poses, pd.T, pd.T + extra_blocks);
     else hipLaunchKernelGGL((k_etile<MODE, R, PROF, TWO>), grid, blk, lds, st, pd, a, do_poses, pd.T, pd.T + extra_blocks);

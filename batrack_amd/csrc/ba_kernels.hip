@@ -2457,19 +2457,22 @@ static int solver_threads() {
 // plans (and the prefetch thread building the next one) coexist: the limit is only ever RAISED, under a lock, so a
 // small plan uploaded later cannot pull it below what an earlier plan launches with.
 static int raise_lds_limit(const void *fn, size_t need) {
+    struct Entry { const void *fn; int dev; size_t bytes; };
     static std::mutex mu;
-    static std::vector<std::pair<const void *, size_t>> *set = new std::vector<std::pair<const void *, size_t>>();
+    static std::vector<Entry> *set = new std::vector<Entry>();
     if (need <= 48 * 1024) return BT_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return BT_EHIP;             // (the attribute is per device as well)
     std::lock_guard<std::mutex> lk(mu);
     for (auto &e : *set)
-        if (e.first == fn) {
-            if (e.second >= need) return BT_OK;
+        if (e.fn == fn && e.dev == dev) {
+            if (e.bytes >= need) return BT_OK;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return BT_EHIP;
-            e.second = need;
+            e.bytes = need;
             return BT_OK;
         }
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) return BT_EHIP;
-    set->emplace_back(fn, need);
+    set->push_back(Entry{fn, dev, need});
     return BT_OK;
 }
 

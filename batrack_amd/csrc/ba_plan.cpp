@@ -105,10 +105,11 @@ int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int
 
 // Iterations of an edge-major tile (64 / S tracks each): an EVEN number (the last one empty where the tile's tracks end in an
 // odd one), so that the flat iteration stream of a wave pairs up (2J, 2J + 1) inside every tile — k_edge2 (ba_edge2.hip) takes
-// two iterations per step, one edge of each per lane.  (S = 1: one iteration is the whole tile; no second half to pair.)
+// two iterations per step, one edge of each per lane.  Also for S = 1, where one iteration is the whole tile: its second
+// iteration is a row of -1 (k_edge2 reads rows 2J and 2J + 1 whatever S is; an odd count would hand it the next tile's row).
 static inline int32_t em_iterations(int32_t ntrk, int32_t G) {
     const int32_t nit = (ntrk + G - 1) / G;
-    return G < kLanes ? (nit + 1) & ~1 : nit;
+    return (nit + 1) & ~1;
 }
 
 int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk64, int64_t E,

@@ -25,6 +25,7 @@
 
 #include "ba_edge.hpp"
 #include "ba_kernels.hpp"
+#include "dev_cache.hpp"
 
 namespace bt {
 
@@ -553,25 +554,22 @@ bool stream_applies(const PlanDev &pd) {
 template <int MODE, int NT, bool PROF = false>
 static int launch_stream_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const size_t lds = stream_lds_bytes(pd, MODE);
-    static int per_cu[4] = {0, 0, 0, 0};
-    static size_t per_cu_lds[4] = {0, 0, 0, 0};
-    static int n_cu = 0;
-    const int slot = MODE == kModeFull ? (NT == 3 ? 0 : 1) : MODE + 1;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return BT_EHIP;
-        n_cu = prop.multiProcessorCount;
-    }
-    if (!per_cu[slot] || per_cu_lds[slot] != lds) {
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stream<MODE, NT, PROF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return BT_EHIP;
+    // (per device: the LDS limit of a kernel and what fits a CU are properties of the device the launch goes to)
+    static LdsLimit lds_limit;
+    static std::atomic<int> per_cu_c[kMaxDevices];
+    static std::atomic<size_t> per_cu_lds[kMaxDevices];
+    DevProps dp;
+    if (!device_props(&dp)) return BT_EHIP;
+    const int n_cu = dp.n_cu, dslot = dp.dev >= 0 && dp.dev < kMaxDevices ? dp.dev : 0;
+    int per_cu = per_cu_lds[dslot].load(std::memory_order_acquire) == lds ? per_cu_c[dslot].load(std::memory_order_relaxed) : 0;
+    if (!per_cu) {
+        if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_stream<MODE, NT, PROF>), lds)) return BT_EHIP;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_stream<MODE, NT, PROF>, 128, lds) != hipSuccess || nb < 1) nb = 1;
-        per_cu[slot] = nb; per_cu_lds[slot] = lds;
+        per_cu = nb;
+        per_cu_c[dslot].store(nb, std::memory_order_relaxed); per_cu_lds[dslot].store(lds, std::memory_order_release);
     }
-    const int max_waves = n_cu * per_cu[slot];
+    const int max_waves = n_cu * per_cu;
     const int tpw = (pd.T + max_waves - 1) / max_waves, nw = (pd.T + tpw - 1) / tpw;
     if (ev0) hipExtLaunchKernelGGL((k_stream<MODE, NT, PROF>), dim3(nw), dim3(128), lds, st, ev0, ev1, 0, pd, a, tpw);
     else hipLaunchKernelGGL((k_stream<MODE, NT, PROF>), dim3(nw), dim3(128), lds, st, pd, a, tpw);

@@ -13,6 +13,7 @@
 
 #include "../../include/batrack_ba.h"
 #include "../../include/batrack_ga.h"
+#include "dev_cache.hpp"
 
 namespace bt {
 
@@ -643,11 +644,8 @@ extern "C" int bt_ga_backward_total(const bt_ga_args *a, const float *mono_scale
     if (w->rigid != 0.0f) {
         const size_t M = (size_t)(a->N + 1) / 2, Mb = (M + 63) / 64, lds = Mb * 64 * bt::kGaRec * sizeof(float4);
         if (lds > 160 * 1024) return BT_EUNSUPPORTED;             // N <= 4096 tracks per frame
-        static size_t raised = 0;
-        if (lds > 48 * 1024 && lds > raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&bt::k_ga_bwd_pairwise), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BT_EHIP;
-            raised = lds;
-        }
+        static bt::LdsLimit lds_limit;
+        if (!lds_limit.ensure(reinterpret_cast<const void *>(&bt::k_ga_bwd_pairwise), lds)) return BT_EHIP;
         hipLaunchKernelGGL(bt::k_ga_bwd_pairwise, dim3((unsigned)(a->Q * a->S), (unsigned)((Mb + bt::kGaStrip / 64 - 1) / (bt::kGaStrip / 64))), dim3(bt::kGaStrip),
                            lds, st, *a, mono_scaled, w->rigid, g_mono_scaled, grad_intrinsics);
     }
@@ -740,11 +738,8 @@ extern "C" int bt_ga_forward(const bt_ga_args *a, float *mono_scaled_out, double
     if (which & 2) {
         const size_t M = (size_t)(a->N + 1) / 2, lds = M * bt::kGaRec * sizeof(float4);
         if ((M + 63) / 64 * 64 * bt::kGaRec * sizeof(float4) > 160 * 1024) return BT_EUNSUPPORTED;      // N <= 4096 tracks per frame (the backward's staging: blocks of 64 track pairs)
-        static size_t raised = 0;
-        if (lds > 48 * 1024 && lds > raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&bt::k_ga_pairwise), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BT_EHIP;
-            raised = lds;
-        }
+        static bt::LdsLimit lds_limit;
+        if (!lds_limit.ensure(reinterpret_cast<const void *>(&bt::k_ga_pairwise), lds)) return BT_EHIP;
         hipLaunchKernelGGL(bt::k_ga_pairwise, dim3((unsigned)(a->Q * a->S), (unsigned)((M + bt::kGaStrip - 1) / bt::kGaStrip)), dim3(bt::kGaStrip),
                            lds, st, *a, mono_scaled_out, losses);
     }

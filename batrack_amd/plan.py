@@ -151,12 +151,18 @@ class Plan:
         """True: the plan is the list's plan (always, unless it came from `shifted_spec`).  False: the speculation failed."""
         if not self.__dict__.get("speculative"):
             return True
-        rc = self._lib.bt_plan_spec_confirm(self._h)
-        self.speculative = False
-        self._keep = None
-        if rc > 0:
+        if self.__dict__.get("invalid"):
             return False
-        _lib.check(rc, "bt_plan_spec_confirm")
+        rc = self._lib.bt_plan_spec_confirm(self._h)
+        self._keep = None
+        if rc != 0:
+            # wrong guess (rc > 0) or an invalid list (rc < 0): either way this object is no plan of the caller's list — it stays
+            # marked speculative and `invalid`, so that nobody who still holds it steps on it as a confirmed plan
+            self.invalid = True
+            if rc > 0:
+                return False
+            _lib.check(rc, "bt_plan_spec_confirm")
+        self.speculative = False
         return True
 
     def __getattr__(self, name):

@@ -107,6 +107,8 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
  * match costs a round trip of its own through bt_plan_create_shifted.  *which (optional) = index of the source that matched.
  * The clone's tables are copied on the library's plan stream without a host wait; the plan's first launches are ordered
  * behind them whatever stream they are given. */
+int bt_plan_create_shifted_any(const bt_plan *const *srcs, int nsrc, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
+                               int64_t n_buf, int64_t p_tot, int64_t fixedp, int *which, bt_plan **out);
 /* The same, SPECULATIVELY, with no host wait at all.  The caller's sliding window shifts its edge list by a whole number of
  * frames and fixedp moves along (batrack.py:189-212, :858): the shift is df = fixedp - src.fixedp frames and dk = df * (p_tot /
  * n_buf) patches.  The clone is made for THAT shift — copies and shift kernels enqueued on the plan stream behind an event
@@ -121,8 +123,6 @@ int bt_plan_create_shifted_spec(const bt_plan *src, const int64_t *ii, const int
 /* BT_OK: the plan is what bt_plan_create would have built (or was not speculative); BT_NO_MATCH: it is not — destroy it; BT_EINVAL:
  * the new list holds an index outside [0, n_buf) / [0, p_tot).  Waits for the verdict if it has not arrived. */
 int bt_plan_spec_confirm(bt_plan *plan);
-int bt_plan_create_shifted_any(const bt_plan *const *srcs, int nsrc, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
-                               int64_t n_buf, int64_t p_tot, int64_t fixedp, int *which, bt_plan **out);
 
 /* The device buffer and the host arrays of a destroyed plan are kept (up to eight of each) for the next
  * bt_plan_create: the caller replaces its edge list every frame (batrack.py:189-212), and a

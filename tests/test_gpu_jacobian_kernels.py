@@ -39,6 +39,8 @@ def ragged(g, drop=0.15):
                                                   (64, 2048, "k_stream", False, True), (64, 2048, "k_stream", True, True),
                                                   (64, 2048, "k_edge", False, True), (64, 4096, "k_edge", False, True),
                                                   (64, 6144, "k_edge", False, True), (64, 6144, "k_edge", True, True),
+                                                  # the size the roofline figures are quoted at: 8.4M edges, 16384 tiles, 8 tiles per wave
+                                                  (64, 16384, "k_edge", False, True), (64, 16384, "k_edge", True, True),
                                                   # ... or, switched off by the caller, the float64 tile kernel at every size
                                                   (64, 2048, "k_tile", False, False), (64, 2048, "k_tile", True, False), (64, 6144, "k_tile", False, False)])
 def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, wpt):
@@ -125,3 +127,37 @@ def test_uploaded_plan_of_many_one_track_tiles_steps_like_the_oracle():
     assert o["status"] == 0
     assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 5e-6 and rel(o["y"], ref["y"]) < 5e-6
     assert rel(o["poses_out"], ref["poses_out"]) < 5e-6 and rel(o["patches_out"], ref["patches_out"]) < 5e-6
+
+
+_ONE_OBS = r"""
+import numpy as np, sys
+sys.path.insert(0, "tests")
+import oracle
+from edge_problems import problem
+from gpu_util import HipProblem, rel
+# tracks with ONE observation each (S = 1 slot per track: an iteration is a whole 64-track tile), tiles of 64 / 64 / 37 tracks per source
+# frame over several frames: the advisor's round-5 case — an odd iteration count per tile used to shift every later tile by a row
+rng = np.random.default_rng(4)
+n_buf, per = 6, 165
+ii = np.repeat(np.arange(n_buf), per)
+jj = (ii + 1 + rng.integers(0, 2, ii.size) * 0) % n_buf           # every track of a frame sees the next frame: slot-uniform tiles
+kk = np.arange(ii.size)
+d = problem(ii, jj, kk, n_buf, ii.size, seed=9)
+ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"], d["ii"], d["jj"], d["kk"],
+                     d["bounds"], fixedp=1, want_system=True)
+o = HipProblem(d).raw_step("weights_pose", 1)
+assert o["plan"].jacobian_kernel == "k_edge", o["plan"].jacobian_kernel
+assert o["status"] == 0
+es, ey = rel(np.tril(o["S_lower"]), np.tril(ref["S"])), rel(o["y"], ref["y"])
+ep, ed = rel(o["poses_out"], ref["poses_out"]), rel(o["patches_out"], ref["patches_out"])
+print("one observation per track:", o["plan"].tiles, "tiles", es, ey, ep, ed)
+assert es < 5e-6 and ey < 5e-6 and ep < 5e-6 and ed < 5e-6, (es, ey, ep, ed)
+"""
+
+
+def test_one_observation_per_track_through_the_two_edge_kernel():
+    """S = 1 tiles (one observation per track) forced onto k_edge2: every tile's iteration count is padded to even (ba_plan.cpp
+    em_iterations), the second row of a step is empty and masked."""
+    env = dict(os.environ, **FORCED["k_edge"])
+    r = subprocess.run([sys.executable, "-c", _ONE_OBS], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
