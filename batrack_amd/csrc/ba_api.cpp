@@ -770,7 +770,7 @@ int bt_ba_step_timed(const bt_plan *pl, const bt_ba_args *a, void *ws, void *str
     if (!so && (!a->poses_out || a->poses_out == a->poses)) return BT_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     mark_launch(pl, stream);
-    hipEvent_t ev[10];
+    hipEvent_t ev[12];
     for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return BT_EHIP;
     const StepArgs s = make_args(pl, a, ws);
     const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
@@ -778,7 +778,7 @@ int bt_ba_step_timed(const bt_plan *pl, const bt_ba_args *a, void *ws, void *str
     int r = launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), so, st, ev, &ran);
     if (r == BT_OK) r = launch_solve_update(pl->dev, s, so, copy_poses, st, ev, &ran);
     if (r == BT_OK && hipStreamSynchronize(st) != hipSuccess) r = BT_EHIP;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
         ms[k] = 0.0f;                                  // a kernel that was not launched (structure-only steps skip two) reads 0
         if (r == BT_OK && (ran >> k & 1u) && hipEventElapsedTime(&ms[k], ev[2 * k], ev[2 * k + 1]) != hipSuccess) ms[k] = -1.0f;
     }

@@ -2513,7 +2513,7 @@ int configure_kernels(const PlanDev &pd) {
 
 // ev == nullptr: plain launches.  ev != nullptr: hipExtLaunchKernelGGL with a
 // (start, stop) event pair per kernel — ev[2*k], ev[2*k+1], k = 0 prep, 1 tile,
-// 2 pair_finalize, 3 solve, 4 update — so bench.py can read each kernel's own
+// 2 pair_finalize, 3 solve, 4 update, 5 the depth walk of the wave-per-tile plans — so bench.py can read each kernel's own
 // duration on the stream it ran on.
 #define BT_LAUNCH(K, kern, grid, block, lds, ...)                                                        \
     do {                                                                                                 \
@@ -2630,13 +2630,15 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
     const size_t upd_lds = ((size_t)pd.max_tile_pairs * kUpdGeo + kUpdThreads) * sizeof(float);
     if (so) BT_LAUNCH(4, k_update<true>, dim3(nb), dim3(kUpdThreads), 0, pd, a, do_poses, 0, nb);
     else if (pd.T > 0 && edge_applies(pd)) {
-        const int rc = launch_edge(pd, a, 2, st, nullptr, nullptr);
+        if (ran) *ran |= 1u << 5;
+        const int rc = launch_edge(pd, a, 2, st, ev ? ev[10] : nullptr, ev ? ev[11] : nullptr);
         if (rc != BT_OK) return rc;
         BT_LAUNCH(4, k_update<false>, dim3(nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, 0, nb);
     }
     else if (pd.T > 0 && stream_applies(pd)) {
-        // the tracks' depths by the wave-per-tile walk (its duration is not in the event pair of kernel 4), then the rest
-        const int rc = launch_stream(pd, a, 2, st, nullptr, nullptr);
+        // the tracks' depths by the wave-per-tile walk (event pair 5), then the rest
+        if (ran) *ran |= 1u << 5;
+        const int rc = launch_stream(pd, a, 2, st, ev ? ev[10] : nullptr, ev ? ev[11] : nullptr);
         if (rc != BT_OK) return rc;
         BT_LAUNCH(4, k_update<false>, dim3(nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, 0, nb);
     }

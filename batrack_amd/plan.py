@@ -177,8 +177,9 @@ class Plan:
 
     @property
     def jacobian_kernel(self):
-        """'k_tile' | 'k_stream' | 'k_edge' | 'k_etile': what the steps of this plan launch (bt_plan_jacobian_kernel)."""
-        return {0: "k_tile", 1: "k_stream", 2: "k_edge", 3: "k_etile"}.get(self._lib.bt_plan_jacobian_kernel(self._h), "host-only")
+        """'k_tile' | 'k_stream' | 'k_edge2' | 'k_etile': what the steps of this plan launch (bt_plan_jacobian_kernel; 'k_edge2': k_edge2 for the
+        pose+structure reduce, k_edge2u for structure-only steps and the depth back-substitution)."""
+        return {0: "k_tile", 1: "k_stream", 2: "k_edge2", 3: "k_etile"}.get(self._lib.bt_plan_jacobian_kernel(self._h), "host-only")
 
     @property
     def edge_precision(self):
@@ -315,10 +316,11 @@ class Stepper:
         import torch
         a = self._fill(*args)
         st = _raw_stream(self.device) if stream is None else stream
-        ms = (ctypes.c_float * 5)()
+        ms = (ctypes.c_float * 6)()
         _lib.check(self._lib.bt_ba_step_timed(self.plan.handle, ctypes.byref(a), self.ws.data_ptr(), st, ms),
                    "bt_ba_step_timed")
-        return dict(zip(("prep", "tile", "pair_finalize", "solve", "update"), [float(v) for v in ms]))
+        # "depth": the walk over the edges that back-substitutes the depths where it is a kernel of its own (k_edge2u / k_stream)
+        return dict(zip(("prep", "tile", "pair_finalize", "solve", "update", "depth"), [float(v) for v in ms]))
 
     def status(self):
         import torch

@@ -169,9 +169,11 @@ int bt_ba_workspace_init(const bt_plan *plan, void *workspace, void *stream);
 int bt_ba_step(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream);
 
 /* bt_ba_step with a (start, stop) HIP event pair around every kernel, recorded on
- * `stream` by the launch itself; synchronises, then ms[k] = duration of kernel k:
- * 0 (unused, 0), 1 k_tile (residual + Jacobian + assembly + Schur), 2 k_pair_finalize,
- * 3 k_solve, 4 k_update; 0 for a kernel the call did not launch.  Measurement only. */
+ * `stream` by the launch itself; synchronises, then ms[k] = duration of kernel k (SIX floats):
+ * 0 (unused, 0), 1 the Jacobian kernel (residual + Jacobian + assembly + Schur), 2 k_pair_finalize,
+ * 3 k_solve, 4 k_update (k_etile_upd), 5 the walk over the edges that back-substitutes the depths where
+ * that is a kernel of its own (k_edge2u / k_stream: plans of many tiles; elsewhere it is part of 4);
+ * 0 for a kernel the call did not launch.  Measurement only. */
 int bt_ba_step_timed(const bt_plan *plan, const bt_ba_args *args, void *workspace, void *stream, float *ms);
 
 /* The same call split at the multi-GPU exchange point:

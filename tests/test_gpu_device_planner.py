@@ -63,7 +63,7 @@ def test_lists_outside_the_device_path_are_planned_by_the_host():
     g = graphgen.make_graph(64, 2048, 8, seed=0)
     idx = [torch.as_tensor(a, device=DEV) for a in (g.ii, g.jj, g.kk)]
     p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
-    assert p.built_on_device and p.jacobian_kernel == "k_edge" and p.tiles == 2048      # (slot-uniform tiles: k_edge2; ragged ones: k_stream, below)
+    assert p.built_on_device and p.jacobian_kernel == "k_edge2" and p.tiles == 2048      # (slot-uniform tiles: k_edge2; ragged ones: k_stream, below)
     prev = wave_per_tile_kernels(False)
     try:
         p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
@@ -254,7 +254,7 @@ def test_device_planned_tables_of_the_wave_per_tile_kernels_equal_the_hosts(vari
     dev = Plan(*(torch.as_tensor(a, device=DEV) for a in (ii, jj, kk)), n_buf, p_tot, fixedp, own=own)
     host = Plan(ii, jj, kk, n_buf, p_tot, fixedp, own=own)
     assert dev.built_on_device and not host.built_on_device and host.tiles >= 2048
-    assert dev.jacobian_kernel == host.jacobian_kernel and host.jacobian_kernel in ("k_stream", "k_edge")
+    assert dev.jacobian_kernel == host.jacobian_kernel and host.jacobian_kernel in ("k_stream", "k_edge2")
     if variant.startswith("k_"):
         assert host.jacobian_kernel == variant[:variant.index("_", 2)]
     if variant == "ragged":
@@ -312,7 +312,7 @@ def test_random_many_tile_lists_plan_alike_on_device_and_host(seed):
         a, b = dev.array(name), host.array(name)
         assert a.shape == b.shape and (a == b).all(), name
     compare_wave_per_tile_tables(dev, host)            # (the tables exist whichever kernel the tiles' camera counts admit)
-    assert seed != 0 or host.jacobian_kernel == "k_edge", (host.jacobian_kernel, host.tiles)
+    assert seed != 0 or host.jacobian_kernel == "k_edge2", (host.jacobian_kernel, host.tiles)
 
 
 @pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")

@@ -35,6 +35,12 @@ for M in [int(x) for x in (sys.argv[1:] or ["256", "1024", "4096", "16384"])]:
         st.step(poses, patches, mono, intr, t3, 3, w, Po, Xo, *scal, False)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / 100 * 1e6
+    so = []
+    for k in range(8):                                         # the structure-only step's pass over the edges (k_edge2u / k_stream / k_tile SO)
+        ms = st.step_timed(poses, patches, mono, intr, t3, 3, w, Po, Xo, *scal, True)
+        if k >= 3:
+            so.append(ms["tile"] * 1e3)
+    med["so_tile"] = float(np.median(so))
     alg = 40 * plan.E + 20 * plan.m + 72 * plan.n_all
     print(f"E={plan.E:9d} tracks={plan.m:8d} tiles={plan.tiles:6d} plan={plan_ms:8.1f}ms | " +
           " ".join(f"{n}={v:9.2f}us" for n, v in med.items()) + f" step={wall:8.1f}us {plan.jacobian_kernel}" +
