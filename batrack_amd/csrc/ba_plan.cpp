@@ -147,9 +147,10 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // ---- ONE pass over the edges: n_all (ba.py:219), the window of patches and frames they name, edges per track and per
     // target frame, the camera pairs in use, and per track its source frame and the set of its target frames (a 64-bit mask
     // around the first target seen: a track's observations span a window of frames, batrack.py:399-410)
-    // (mask, mask2: target frames base + b and base + 64 + b; the host's own pass fills 64 bits around the first target it sees,
-    //  the device's table 128 around the source frame)
-    struct PerPatch { int32_t cnt, src, base, last_j; uint64_t mask, mask2; };
+    // (mask, mask2: target frames base + b and base + 64 + b, base = the source frame - 64: 128 bits around the source frame, in the
+    //  host's own pass as in the device's table)
+    // (rmask, rmask2: the targets the track observes more than once — the aligned slot layout below)
+    struct PerPatch { int32_t cnt, src, base, last_j; uint64_t mask, mask2, rmask, rmask2; };
 #define BT_FOR_TARGETS(T_, fr_, ...)                                                                                            \
     do {                                                                                                                        \
         for (uint64_t mk_ = (T_).mask; mk_; mk_ &= mk_ - 1) { const int32_t fr_ = (T_).base + __builtin_ctzll(mk_); __VA_ARGS__ }        \
@@ -157,7 +158,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     } while (0)
     static thread_local std::vector<PerPatch> pp_tab;            // indexed by patch; only [kmin, kmax] of the previous plan is dirty
     static thread_local int64_t pp_lo = 0, pp_hi = -1;
-    if ((int64_t)pp_tab.size() < p_tot) { pp_tab.assign((size_t)p_tot, PerPatch{0, 0, 0, 0, 0, 0}); pp_lo = 0; pp_hi = -1; }
+    if ((int64_t)pp_tab.size() < p_tot) { pp_tab.assign((size_t)p_tot, PerPatch{0, 0, 0, 0, 0, 0, 0, 0}); pp_lo = 0; pp_hi = -1; }
     for (int64_t p = pp_lo; p <= pp_hi; ++p) pp_tab[(size_t)p].cnt = 0;
     PerPatch *pp = pp_tab.data();
     int64_t n_all = n_all_min, kmin = p_tot, kmax = -1;       // [kmin, kmax]: patches the edges name (a window of the buffer)
@@ -178,6 +179,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             const PatchStat &d = dstats->tab[(size_t)(k - kmin)];
             PerPatch &t = pp[k];
             t.src = d.src; t.base = d.src - 64; t.last_j = 0; t.mask = d.mask; t.mask2 = d.mask2;
+            t.rmask = dstats->rtab ? dstats->rtab[(size_t)(k - kmin)].rmask & d.mask : 0; t.rmask2 = dstats->rtab ? dstats->rtab[(size_t)(k - kmin)].rmask2 & d.mask2 : 0;
             if (k >= own_lo && k < own_hi) { t.cnt = d.cnt; E_own += d.cnt; }
             else { t.cnt = 0; if (k < own_lo) pl->dev_q0 += d.cnt; }
         }
@@ -195,11 +197,16 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         ++E_own;
         ++cj[(size_t)j + 1];
         PerPatch &t = pp[k];
-        if (t.cnt++ == 0) { t.src = (int32_t)i; t.base = (int32_t)j - 32; t.mask = 0; t.mask2 = 0; }
+        // (128 bits around the SOURCE frame, as the device's table has them: a list is laid out the same way wherever its indices live)
+        if (t.cnt++ == 0) { t.src = (int32_t)i; t.base = (int32_t)i - 64; t.mask = 0; t.mask2 = 0; t.rmask = 0; t.rmask2 = 0; }
         else { if (t.src != (int32_t)i) src_ok = false; if ((int32_t)j < t.last_j) mono_j = false; }
         t.last_j = (int32_t)j;          // one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)
         const int64_t bit = j - t.base;
-        if (bit < 0 || bit >= 64) masks_ok = false; else t.mask |= 1ull << bit;
+        if (bit < 0 || bit >= 128) masks_ok = false;
+        else {
+            uint64_t &mw = bit < 64 ? t.mask : t.mask2, &rw = bit < 64 ? t.rmask : t.rmask2;
+            rw |= mw & (1ull << (bit & 63)); mw |= 1ull << (bit & 63);
+        }
     }
     pp_lo = kmin; pp_hi = kmax;
     // sharded plan: the number of distinct tracks in front of this rank's range — a per-track lmbda tensor (ba.py:299-300) is
@@ -255,12 +262,16 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     if (masks_ok) {
         // from the tracks' (source frame, target mask): a few thousand tracks instead of every edge
         // (neighbouring tracks mostly share their source frame and targets — the tracks of one frame: such a track adds nothing)
-        int32_t src_b = -1, base_b = 0; uint64_t mask_b = 0, mask2_b = 0;
+        // (the masks of a source frame's tracks are bits around the same base, src - 64: their union per frame, two words a track —
+        //  a graph whose tracks all differ, observations missing at random, walked every target of a million tracks here)
+        std::vector<uint64_t> fm((size_t)nw * 2, 0);
         for (int32_t k = 0; k < m; ++k) {
             const PerPatch &t = pp[pl->kx[(size_t)k]];
-            if (t.src == src_b && t.base == base_b && t.mask == mask_b && t.mask2 == mask2_b) continue;
-            src_b = t.src; base_b = t.base; mask_b = t.mask; mask2_b = t.mask2;
-            int32_t *row = pair_of.data() + (size_t)(t.src - f_lo) * nw - f_lo;
+            fm[(size_t)(t.src - f_lo) * 2] |= t.mask; fm[(size_t)(t.src - f_lo) * 2 + 1] |= t.mask2;
+        }
+        for (int64_t f = 0; f < nw; ++f) {
+            const PerPatch t{0, (int32_t)(f + f_lo), (int32_t)(f + f_lo) - 64, 0, fm[(size_t)f * 2], fm[(size_t)f * 2 + 1], 0, 0};
+            int32_t *row = pair_of.data() + (size_t)f * nw - f_lo;
             BT_FOR_TARGETS(t, fr, row[fr] = 0;);
         }
     } else {
@@ -364,8 +375,57 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         static const int pm_env2 = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;
         if (pm_env2 == 2) return BT_NEED_EDGES;                    // (pair-major tables of 64-track tiles are made from the host's slot arrays)
     }
+    // ALIGNED SLOTS (round 6) for the plans the wave-per-tile kernels take.  k_edge2 / k_edge2u need every tile SLOT-UNIFORM — all
+    // tracks of a tile with the same camera pair (or no edge) in slot s.  With slot s = a track's s-th edge that holds only where
+    // all tracks of a tile have the same observations: one missing observation shifts the rest of its track (a graph with a random
+    // 15 % of its observations dropped fell to k_stream: three times the time per edge).  So a tile's slots are laid out per PAIR:
+    // local pair p gets mult[p] consecutive slots from pbase[p], mult[p] = the largest number of edges a track of the tile has (or,
+    // from the tracks' figures alone, can have) with that pair; a track's r-th edge with pair p sits in slot pbase[p] + r, the
+    // slots it does not fill are null (edge -1: zero weight in every kernel).  Every tile is then slot-uniform by construction at
+    // sum(mult) slots instead of the longest track's count — 1 / (1 - drop) of the uniform cost.  Tiles do not run across two
+    // source frames (the pairs of one are no pairs of the other; the kernels also take a tile's source camera from its first track).
+    // Where it does not fit (more than 64 slots in some tile) the plan is laid out again the old way.
+    static thread_local int align_retry = 0;
+    const bool aligned = !align_retry && masks_ok && tcap == kLanes && m > 0 && ((int64_t)m + kLanes - 1) / kLanes >= em_min_p &&
+                         (!dstats || dstats->rep_known);
+    pl->dev_pbase.clear();
+    std::vector<uint64_t> tile_tmask;                                                         // aligned: per tile the union of its tracks' target masks (2 words)
+    if (aligned) {
+        // the same greedy rule on bit masks (a tile has one source frame, so its tracks' masks share their base): cameras = the
+        // free frames among the targets and the source frame (bit 64), in ascending order as the bits are
+        int32_t cur_src = -1;
+        uint64_t free_lo = 0, free_hi = 0, tm_lo = 0, tm_hi = 0, tg_lo = 0, tg_hi = 0;
+        auto flush = [&](int32_t k_end) {
+            if (k_end == trk0) return;
+            tile_set.clear();
+            const int64_t base = (int64_t)cur_src - 64;
+            for (uint64_t mk = tm_lo; mk; mk &= mk - 1) tile_set.push_back((int32_t)(base + __builtin_ctzll(mk) - fixedp));
+            for (uint64_t mk = tm_hi; mk; mk &= mk - 1) tile_set.push_back((int32_t)(base + 64 + __builtin_ctzll(mk) - fixedp));
+            tile_tmask.push_back(tg_lo); tile_tmask.push_back(tg_hi);
+            close_tile(k_end);
+            tm_lo = tm_hi = tg_lo = tg_hi = 0;
+        };
+        for (int32_t k = 0; k < m; ++k) {
+            const PerPatch &t = pp[pl->kx[(size_t)k]];
+            if (t.src != cur_src) {
+                flush(k);
+                cur_src = t.src;
+                const int64_t first_free = fixedp - ((int64_t)t.src - 64);          // bits >= this are free frames
+                free_lo = first_free <= 0 ? ~0ull : first_free >= 64 ? 0ull : ~0ull << first_free;
+                free_hi = first_free <= 64 ? ~0ull : first_free >= 128 ? 0ull : ~0ull << (first_free - 64);
+            }
+            const uint64_t c_lo = t.mask & free_lo, c_hi = (t.mask2 & free_hi) | (t.src >= fixedp ? 1ull : 0ull);
+            const int nk = __builtin_popcountll(c_lo) + __builtin_popcountll(c_hi);
+            if (nk > kTileCamHard) return BT_EUNSUPPORTED;
+            const int add = __builtin_popcountll(c_lo & ~tm_lo) + __builtin_popcountll(c_hi & ~tm_hi);
+            const int have = __builtin_popcountll(tm_lo) + __builtin_popcountll(tm_hi);
+            if (k - trk0 >= tcap || (k > trk0 && have + add > std::max<int>(kTileCamSoft, nk))) flush(k);
+            tm_lo |= c_lo; tm_hi |= c_hi; tg_lo |= t.mask; tg_hi |= t.mask2;
+        }
+        flush(m);
+    }
     int32_t src_p = -1, base_p = 0, set_epoch = -1; uint64_t mask_p = 0, mask2_p = 0;         // the previous track's figures: the same again = the same cameras
-    for (int32_t k = 0; k < m; ++k) {
+    for (int32_t k = 0; k < m && !aligned; ++k) {
         if (masks_ok && k > 0 && pp[pl->kx[(size_t)k]].src == src_p && pp[pl->kx[(size_t)k]].base == base_p && pp[pl->kx[(size_t)k]].mask == mask_p &&
             pp[pl->kx[(size_t)k]].mask2 == mask2_p) {
             // (trk_set is the previous track's and still right; in the tile it went into, it adds nothing)
@@ -397,7 +457,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) { stamp[(size_t)c] = epoch; tile_set.push_back(c); }
         set_epoch = epoch;
     }
-    close_tile(m);
+    if (!aligned) close_tile(m);
     const int32_t T = (int32_t)pl->tile_trk0.size();
     I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
     pl->max_rows16 = (int)((6 * max_cams + 15) / 16 * 16);
@@ -430,10 +490,11 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         pl->pm_edge.clear();
         pl->pm_edge.reserve((size_t)E_own * 2 + (size_t)T * kLanes * 4);      // (one allocation: the table grows tile by tile)
     }
-    pl->slot_edge.assign(want_slots ? (size_t)slots * kLanes : 0, -1);
-    pl->slot_pair.assign(want_slots ? (size_t)slots * kLanes : 0, 0);
-    pl->slot_lab.assign(want_slots ? (size_t)slots * kLanes : 0, 0xffff);
-    pl->slot_lp.assign(want_slots ? (size_t)slots * kLanes : 0, 0);
+    const size_t slot_elems = want_slots && !aligned ? (size_t)slots * kLanes : 0;      // (aligned: the arrays grow tile by tile below)
+    pl->slot_edge.assign(slot_elems, -1);
+    pl->slot_pair.assign(slot_elems, 0);
+    pl->slot_lab.assign(slot_elems, 0xffff);
+    pl->slot_lp.assign(slot_elems, 0);
     pl->tile_pair0.assign((size_t)T, 0); pl->tile_npair.assign((size_t)T, 0);
     pl->tile_pairs.clear();
     pl->max_tile_pairs = 0;
@@ -445,16 +506,24 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     pl->tile_cut8.assign((size_t)T * 9, 0);
     pl->tile_cut16.assign((size_t)T * 17, 0);
     {
-        std::vector<int32_t> local((size_t)n + 1, -1), lp_of(pl->pair_i.size(), -1), mine;
+        std::vector<int32_t> local((size_t)n + 1, -1), lp_of(pl->pair_i.size(), -1), mine, mult, pbase;
         std::vector<uint8_t> crossed;                              // crossed[s]: some track's run spans slots s - 1 and s
+        int64_t slots_al = 0;                                      // aligned layout: the slots of the tiles so far
         for (int32_t t = 0; t < T; ++t) {
             const int32_t c0 = pl->tile_cam0[(size_t)t], nc = pl->tile_ncam[(size_t)t], t0 = pl->tile_trk0[(size_t)t], nt = pl->tile_ntrk[(size_t)t];
-            const int32_t ns_t = pl->tile_nslot[(size_t)t];
+            int32_t ns_t = pl->tile_nslot[(size_t)t];
             if (ns_t > 0xffff) return BT_EUNSUPPORTED;           // (a track with more than 65535 observations)
-            crossed.assign((size_t)ns_t + 1, 0);
+            if (!aligned) crossed.assign((size_t)ns_t + 1, 0);
             for (int32_t c = 0; c < nc; ++c) local[(size_t)pl->tile_cams[(size_t)(c0 + c)]] = c;
             mine.clear();
-            if (masks_ok) {
+            if (aligned) {
+                // (one source frame per tile: its pairs are (source, target) over the union of the tracks' target masks, ascending)
+                const int32_t src_t = pp[pl->kx[(size_t)t0]].src;
+                const PerPatch tu{0, src_t, src_t - 64, 0, tile_tmask[(size_t)t * 2], tile_tmask[(size_t)t * 2 + 1], 0, 0};
+                const int32_t *row = pair_of.data() + (size_t)(src_t - f_lo) * nw - f_lo;
+                BT_FOR_TARGETS(tu, fr, mine.push_back(row[fr]););
+                for (int32_t gp : mine) lp_of[(size_t)gp] = 0;
+            } else if (masks_ok) {
                 int32_t src_b = -1, base_b = 0; uint64_t mask_b = 0, mask2_b = 0;
                 for (int32_t l = 0; l < nt; ++l) {
                     const PerPatch &tp = pp[pl->kx[(size_t)(t0 + l)]];
@@ -474,6 +543,42 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             std::sort(mine.begin(), mine.end());
             if ((int)mine.size() > kMaxTilePairs) return BT_EUNSUPPORTED;
             for (size_t q = 0; q < mine.size(); ++q) lp_of[(size_t)mine[q]] = (int32_t)q;
+            if (aligned) {
+                // slots per pair from the tracks' figures (no edge is read): a target outside the track's repeat mask has one
+                // edge; the repeated ones share the track's surplus, cnt - (distinct targets), each holding at least one of it
+                // (every pair of the tile has a slot; only the tracks that repeat a target are looked at bit by bit)
+                mult.assign(mine.size(), 1);
+                for (int32_t l = 0; l < nt; ++l) {
+                    const PerPatch &tp = pp[pl->kx[(size_t)(t0 + l)]];
+                    if (!(tp.rmask | tp.rmask2)) continue;
+                    const int32_t distinct = __builtin_popcountll(tp.mask) + __builtin_popcountll(tp.mask2);
+                    const int32_t nrep = __builtin_popcountll(tp.rmask) + __builtin_popcountll(tp.rmask2);
+                    const int32_t mrep = 1 + (tp.cnt - distinct) - (nrep - 1);
+                    const int32_t *row = pair_of.data() + (size_t)(tp.src - f_lo) * nw - f_lo;
+                    for (int half = 0; half < 2; ++half)
+                        for (uint64_t mk = half ? tp.rmask2 : tp.rmask; mk; mk &= mk - 1) {
+                            int32_t &mu = mult[(size_t)lp_of[(size_t)row[tp.base + 64 * half + __builtin_ctzll(mk)]]];
+                            mu = std::max(mu, mrep);
+                        }
+                }
+                pbase.assign(mine.size(), 0);
+                int32_t acc = 0;
+                for (size_t q = 0; q < mine.size(); ++q) { pbase[q] = acc; acc += mult[q]; }
+                if (acc > kLanes) {
+                    // (more (pair, repeat) slots than an iteration has lanes: the edge-major layout does not hold this tile)
+                    RetryScope guard(align_retry);
+                    return build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots, dstats);
+                }
+                ns_t = acc;
+                pl->tile_slot0[(size_t)t] = (int32_t)slots_al; pl->tile_nslot[(size_t)t] = ns_t;
+                slots_al += ns_t;
+                pl->dev_pbase.insert(pl->dev_pbase.end(), pbase.begin(), pbase.end());
+                crossed.assign((size_t)ns_t + 1, 0);
+                if (want_slots) {
+                    pl->slot_edge.resize((size_t)slots_al * kLanes, -1); pl->slot_pair.resize((size_t)slots_al * kLanes, 0);
+                    pl->slot_lab.resize((size_t)slots_al * kLanes, 0xffff); pl->slot_lp.resize((size_t)slots_al * kLanes, 0);
+                }
+            }
             if (pm_direct && !pm_fail) {
                 // pair-major tables of this tile (layout: the block further down that builds them from the slot arrays)
                 const int32_t np = (int32_t)mine.size();
@@ -535,19 +640,23 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             for (int32_t l = 0; l < nt && want_slots; ++l) {
                 const int32_t k = t0 + l;
                 uint16_t lb_before = 0xff;
+                int32_t gp_before = -1, rank = 0;                  // aligned layout: the edge's rank among the track's edges with its pair
                 for (int32_t sidx = off[(size_t)k]; sidx < off[(size_t)k + 1]; ++sidx) {
                     const int32_t e = ord[(size_t)sidx];
-                    const size_t idx = ((size_t)pl->tile_slot0[(size_t)t] + (size_t)(sidx - off[(size_t)k])) * kLanes + (size_t)l;
                     const int64_t i = IQ(sidx), j = JQ(sidx);
                     const int64_t a = i - fixedp, b = j - fixedp;
                     const uint16_t la = a >= 0 ? (uint16_t)local[(size_t)a] : 0xff;
                     const uint16_t lb = b >= 0 ? (uint16_t)local[(size_t)b] : 0xff;
                     const int32_t gp = pair_of[(size_t)((i - f_lo) * nw + (j - f_lo))];
+                    rank = gp == gp_before ? rank + 1 : 0;
+                    gp_before = gp;
+                    const int32_t sl = aligned ? pbase[(size_t)lp_of[(size_t)gp]] + rank : sidx - off[(size_t)k];
+                    const size_t idx = ((size_t)pl->tile_slot0[(size_t)t] + (size_t)sl) * kLanes + (size_t)l;
                     pl->slot_edge[idx] = e;
                     pl->slot_pair[idx] = gp;
                     pl->slot_lab[idx] = (uint16_t)(la | (lb << 8));
                     pl->slot_lp[idx] = (uint8_t)lp_of[(size_t)gp];
-                    if (lb != 0xff && lb == lb_before) crossed[(size_t)(sidx - off[(size_t)k])] = 1;
+                    if (lb != 0xff && lb == lb_before) crossed[(size_t)sl] = 1;
                     lb_before = lb;
                 }
             }
@@ -579,6 +688,11 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         }
     }
 
+    if (aligned) {
+        int64_t tot = 0;
+        for (int32_t t = 0; t < T; ++t) tot += pl->tile_nslot[(size_t)t];
+        slots = tot; I.slots = tot;
+    }
     // consecutive tiles with identical camera / pair lists: a persistent workgroup keeps its
     // accumulators across them
     pl->tile_flags.assign((size_t)T, 0);
@@ -622,7 +736,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             src_b = d.src; mask_b = d.mask; mask2_b = d.mask2;
             cset.clear();
             if (d.src >= fixedp) cset.push_back((int32_t)(d.src - fixedp));
-            const PerPatch dt{d.cnt, d.src, d.src - 64, 0, d.mask, d.mask2};
+            const PerPatch dt{d.cnt, d.src, d.src - 64, 0, d.mask, d.mask2, 0, 0};
             BT_FOR_TARGETS(dt, fr,
                 const int64_t c = (int64_t)fr - fixedp;
                 if (c >= 0) cset.push_back((int32_t)c););
@@ -1055,7 +1169,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         }
     }
 
-    // ---- edge-major layout of the same tiles (k_edge, ba_stream3.hip): the slots of a track padded to S = the next
+    // ---- edge-major layout of the same tiles (k_edge2 / k_edge2u, ba_edge2.hip / ba_edge2u.hip): the slots of a track padded to S = the next
     // power of two, an ITERATION = 64 lanes = 64 / S consecutive tracks x S slots (lane = track_in_iteration * S + slot),
     // so that on the caller's track-major edge lists a wave reads 64 consecutive edges, a track's sums are reductions over
     // S adjacent lanes, and a lane meets the same camera pair in every iteration of a tile (per-lane pair sums, no

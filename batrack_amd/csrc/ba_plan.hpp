@@ -146,6 +146,7 @@ struct bt_plan {
     int dev_slots = 0;                                        // likewise the [slots][64] arrays and the wave cuts of a 64-track layout
     int dev_wpt = 0;                                          // ... and with them the tables of the wave-per-tile kernels (slot_code, tile_la, it_edge, tile_sinfo)
     std::vector<int32_t> dev_off;                             // [m + 1]: first position of every track's edges in the grouped order
+    std::vector<int32_t> dev_pbase;                           // aligned slot layout (ba_plan.cpp): first slot of every (tile, local pair), as tile_pairs; empty: a track's s-th edge is its slot s
     mutable std::vector<int32_t> dev_readback;                // bt_plan_array(pm_edge / pm_rec) of such a plan
     std::vector<int32_t> dev_pair_of;                         // [nw * nw]: pair index of (i - f_lo, j - f_lo) or -1
     int64_t dev_f_lo = 0, dev_nw = 0;
@@ -188,6 +189,7 @@ struct bt_plan {
             v->clear();
         tile_cut8.clear(); tile_cut16.clear();
         pm_edge.clear(); pm_rec.clear(); pm_lb.clear(); pm_la.clear(); pp_ptr.clear(); pp_idx.clear(); sg_ptr.clear(); pm_ok = 0; sp_ok = 0; pm_rounds = 0;
+        dev_pbase.clear();
         slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); it_edge.clear(); tile_sinfo.clear(); em_ok = 0; st_ok = 0; em_its = 0; em_lgs = -1; act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;
         fz_ok = fzp_ok = 0;
@@ -213,10 +215,15 @@ int config_wave_per_tile_kernels(int enable);
 // leaves the one edge-sized table of a window plan (pm_edge) and the tiles' round counts to the device
 // (bt_plan::dev_pm).  Returns BT_NEED_EDGES where that does not apply (the caller then runs the analysis on the edges).
 struct PatchStat { int32_t cnt, src, src_min, pad; unsigned long long mask, mask2; };      // bit b of (mask | mask2 << 64): an edge into frame src - 64 + b
+// the target frames a track observes MORE THAN ONCE (same bit numbering as PatchStat's masks): gathered for lists large enough
+// for the wave-per-tile kernels, whose aligned slot layout needs to know where a track's extra edges can be
+struct RepStat { unsigned long long rmask, rmask2; };
 struct DevPlanStats {
     const PatchStat *tab;          // [kmax - kmin + 1], the patches kmin .. kmax
     int64_t kmin, kmax, n_all, f_lo;
     int any_self;
+    int rep_known;                 // the repeated targets were looked for (rtab null then means: there are none)
+    const RepStat *rtab;           // [kmax - kmin + 1] or null
 };
 enum { BT_NEED_EDGES = 2 };
 int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,

@@ -33,7 +33,10 @@ namespace bt {
 //  figures leave a workgroup as ONE record of partials, reduced by k_plan_count: four atomics per workgroup on the same four words
 //  — 131k of them for 8.4M edges — are served one after the other, 25 ns each: 3.3 ms of such a plan)
 constexpr int kStatBlocks = 1024;                 // workgroups of k_plan_stats (grid-stride), = records of partials
-__global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *words, long long E, PatchStat *stat, int *part, int *vals) {
+// REP: also the targets a track observes more than once (RepStat; flag bit 8: there are some) — the one place where an atomic
+// returns its old value, for the lists large enough for the wave-per-tile kernels only (their aligned slot layout, ba_plan.cpp)
+template <bool REP>
+__global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *words, long long E, PatchStat *stat, int *part, int *vals, RepStat *rstat) {
     __shared__ int s_max_f, s_min_f, s_kmin, s_kmax, s_flags;
     if (threadIdx.x == 0) { s_max_f = 0; s_min_f = 0x7fffffff; s_kmin = 0x7fffffff; s_kmax = -1; s_flags = 0; }
     __syncthreads();
@@ -49,6 +52,10 @@ __global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *wo
         atomicMin(&t->src_min, i);
         const int bit = j - (i - 64);
         if (bit < 0 || bit >= 128) fl |= 4;
+        else if (REP) {
+            const unsigned long long bm = 1ull << (bit & 63);
+            if (atomicOr(bit < 64 ? &t->mask : &t->mask2, bm) & bm) { atomicOr(bit < 64 ? &rstat[k].rmask : &rstat[k].rmask2, bm); fl |= 8; }
+        }
         else atomicOr(bit < 64 ? &t->mask : &t->mask2, 1ull << (bit & 63));
         max_f = max(max_f, max(i, j) + 1); min_f = min(min_f, min(i, j));
         kmin = min(kmin, k); kmax = max(kmax, k);
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(256) void k_plan_count(const PatchStat *stat, const
         glob[0] = max_f; glob[1] = min_f; glob[2] = kmin; glob[3] = kmax;
         if (fl & 1) glob[4] = 1;
         if (fl & 4) glob[6] = 1;
+        if (fl & 8) glob[8] = 1;
     }
     int n = 0, bad = 0;
     for (int p = kmin + (int)(blockIdx.x * blockDim.x + threadIdx.x); p <= kmax; p += (int)(gridDim.x * blockDim.x)) {
@@ -103,9 +111,12 @@ __global__ __launch_bounds__(256) void k_plan_count(const PatchStat *stat, const
     if ((threadIdx.x & 63) == 0) { if (n) atomicAdd(&glob[7], n); if (bad) glob[5] = 1; }
 }
 
-__global__ __launch_bounds__(256) void k_plan_stat_clear(PatchStat *stat, long long lo, long long hi) {
+__global__ __launch_bounds__(256) void k_plan_stat_clear(PatchStat *stat, RepStat *rstat, long long rstat_n, long long lo, long long hi) {
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p <= hi) { stat[p].cnt = 0; stat[p].src = -1; stat[p].src_min = 0x7fffffff; stat[p].mask = 0ull; stat[p].mask2 = 0ull; }
+    if (p <= hi) {
+        stat[p].cnt = 0; stat[p].src = -1; stat[p].src_min = 0x7fffffff; stat[p].mask = 0ull; stat[p].mask2 = 0ull;
+        if (p < rstat_n) { rstat[p].rmask = 0ull; rstat[p].rmask2 = 0ull; }      // (the two tables are dirty over the same range)
+    }
 }
 
 // The sort key of an edge: (patch - kmin) << jbits | (target frame - f_lo) — some 18 bits for a window instead of the 50 of
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(256) void k_plan_fill(PlanFillArgs a) {
 struct PlanSlotArgs {
     const unsigned *keys; const int *vals; const unsigned long long *words; int jbits; long long E;
     const int *trk_win, *trk_loc, *pair_of, *off; int f_lo, nw, fixedp;
+    const int *pbase;                       // aligned slot layout (ba_plan.cpp): first slot of every (tile, local pair), as tile_pairs; null: slot = the edge's position in its track
     const int *tile_slot0, *tile_cam0, *tile_ncam, *tile_cams, *tile_pair0, *tile_npair, *tile_pairs, *tile_nslot;
     int *slot_edge, *slot_pair; unsigned short *slot_lab; unsigned char *slot_lp;
     unsigned char *crossed;                 // [slots + 1], by global slot: some track's run of one target camera spans slots s - 1 and s
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(256) void k_plan_slots(PlanSlotArgs a) {
     const unsigned long long w = a.words[e];
     const int i = (int)((w >> 16) & 0xffff), j = (int)(w & 0xffff);
     const int trk = a.trk_win[key >> a.jbits], loc = a.trk_loc[trk], t = loc >> 6, l = loc & 63;
-    const int s = (int)(q - a.off[trk]);
+    const bool first = q == a.off[trk];                         // the track's first edge
     const int *cams = a.tile_cams + a.tile_cam0[t];
     const int nc = a.tile_ncam[t];
     const int la = local_cam(cams, nc, i - a.fixedp), lb = local_cam(cams, nc, j - a.fixedp);
@@ -233,14 +245,21 @@ __global__ __launch_bounds__(256) void k_plan_slots(PlanSlotArgs a) {
     const int *tp = a.tile_pairs + a.tile_pair0[t];
     int lo = 0, hi = a.tile_npair[t] - 1;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (tp[mid] < gp) lo = mid + 1; else hi = mid; }
+    int s = (int)(q - a.off[trk]);
+    if (a.pbase) {
+        // aligned: the pair's first slot + the edge's rank among the track's edges with that pair (equal keys are neighbours)
+        int r = 0;
+        while (r < 64 && q - r - 1 >= 0 && a.keys[q - r - 1] == key) ++r;
+        s = a.pbase[a.tile_pair0[t] + lo] + r;
+    }
     const size_t idx = ((size_t)a.tile_slot0[t] + (size_t)s) * 64 + (size_t)l;
     a.slot_edge[idx] = e; a.slot_pair[idx] = gp; a.slot_lab[idx] = (unsigned short)(la | (lb << 8)); a.slot_lp[idx] = (unsigned char)lo;
     // the previous edge of the track has the same target frame (its key is the same): a run that continues into this slot
-    const bool run = s > 0 && lb != 0xff && a.keys[q - 1] == key;
+    const bool run = !first && lb != 0xff && a.keys[q - 1] == key;
     if (run) a.crossed[a.tile_slot0[t] + s] = 1;
     if (a.slot_code) {
         a.slot_code[idx] = (unsigned short)(lb | (lo << 8));
-        if (s == 0) a.tile_la[(size_t)t * 64 + (size_t)l] = (unsigned char)la;
+        if (first) a.tile_la[(size_t)t * 64 + (size_t)l] = (unsigned char)la;
         // (flag bit 2 of the tile's record: a run spans the boundary of the two half-chunks of slots of k_stream's two waves)
         const int ns = a.tile_nslot[t], ch = (ns + 1) >> 1;
         if (run && s == ch && ch < ns) atomicOr(&a.tile_rec[(size_t)t * 8], 4 << 24);
@@ -307,6 +326,7 @@ __global__ __launch_bounds__(256) void k_plan_cuts(PlanSlotArgs a) {
 namespace {
 struct DevPlanBuffers {
     PatchStat *stat = nullptr; size_t stat_cap = 0; long long dirty_lo = 0, dirty_hi = -1;
+    RepStat *rstat = nullptr; size_t rstat_cap = 0; RepStat *h_rtab = nullptr; size_t rtab_cap = 0;   // the tracks' repeated targets (large lists only)
     int *glob = nullptr, *h_glob = nullptr;                       // 8 + 2 ints (device, pinned host)
     int *part = nullptr;                                          // [kStatBlocks][8]: the workgroups' partials of k_plan_stats
     unsigned *keys_in = nullptr, *keys = nullptr; int *vals_in = nullptr, *vals = nullptr; unsigned char *dcode = nullptr; size_t e_cap = 0;
@@ -345,16 +365,26 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
         b.stat_cap = (size_t)p_tot; b.dirty_lo = 0; b.dirty_hi = p_tot - 1;
     }
     if (!b.grow_edges((size_t)E)) return BT_ENOMEM;
+    // lists that can reach the tile count of the wave-per-tile kernels (64 tracks a tile): the repeated targets as well
+    const bool rep = E >= (int64_t)edge_min_tiles() * kLanes && edge_min_tiles() < (1 << 29);
+    if (rep && (size_t)p_tot > b.rstat_cap) {
+        (void)hipFree(b.rstat);
+        if (hipMalloc(reinterpret_cast<void **>(&b.rstat), (size_t)p_tot * sizeof(RepStat)) != hipSuccess) { b.rstat_cap = 0; return BT_ENOMEM; }
+        b.rstat_cap = (size_t)p_tot; b.dirty_lo = 0; b.dirty_hi = p_tot - 1;
+    }
     if (b.dirty_hi >= b.dirty_lo)
-        hipLaunchKernelGGL(k_plan_stat_clear, dim3((unsigned)((b.dirty_hi - b.dirty_lo + 256) / 256)), dim3(256), 0, cs, b.stat, b.dirty_lo, b.dirty_hi);
+        hipLaunchKernelGGL(k_plan_stat_clear, dim3((unsigned)((b.dirty_hi - b.dirty_lo + 256) / 256)), dim3(256), 0, cs, b.stat,
+                           b.rstat, (long long)b.rstat_cap, b.dirty_lo, b.dirty_hi);
     b.h_glob[0] = 0; b.h_glob[1] = 0x7fffffff; b.h_glob[2] = 0x7fffffff; b.h_glob[3] = -1;
     for (int c = 4; c < 10; ++c) b.h_glob[c] = 0;
     if (hipMemcpyAsync(b.glob, b.h_glob, 10 * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess) return BT_EHIP;
     const int nblk = (int)std::min<int64_t>(kStatBlocks, (E + 255) / 256);
-    hipLaunchKernelGGL(k_plan_stats, dim3((unsigned)nblk), dim3(256), 0, cs, reinterpret_cast<const unsigned long long *>(d_words),
-                       (long long)E, b.stat, b.part, b.vals_in);
+    if (rep) hipLaunchKernelGGL(k_plan_stats<true>, dim3((unsigned)nblk), dim3(256), 0, cs, reinterpret_cast<const unsigned long long *>(d_words),
+                                (long long)E, b.stat, b.part, b.vals_in, b.rstat);
+    else hipLaunchKernelGGL(k_plan_stats<false>, dim3((unsigned)nblk), dim3(256), 0, cs, reinterpret_cast<const unsigned long long *>(d_words),
+                            (long long)E, b.stat, b.part, b.vals_in, static_cast<RepStat *>(nullptr));
     hipLaunchKernelGGL(k_plan_count, dim3(64), dim3(256), 0, cs, b.stat, b.part, nblk, b.glob);
-    if (hipMemcpyAsync(b.h_glob, b.glob, 8 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
+    if (hipMemcpyAsync(b.h_glob, b.glob, 9 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
     const int *g = b.h_glob;
     b.dirty_lo = g[2]; b.dirty_hi = g[3];
     *tracks = g[7];
@@ -368,8 +398,15 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
         if (hipHostMalloc(reinterpret_cast<void **>(&b.h_tab), (nt + nt / 4 + 1024) * sizeof(PatchStat), hipHostMallocDefault) != hipSuccess) { b.tab_cap = 0; return BT_ENOMEM; }
         b.tab_cap = nt + nt / 4 + 1024;
     }
+    const bool any_rep = rep && g[8] != 0;
+    if (any_rep && nt > b.rtab_cap) {
+        (void)hipHostFree(b.h_rtab);
+        if (hipHostMalloc(reinterpret_cast<void **>(&b.h_rtab), (nt + nt / 4 + 1024) * sizeof(RepStat), hipHostMallocDefault) != hipSuccess) { b.rtab_cap = 0; return BT_ENOMEM; }
+        b.rtab_cap = nt + nt / 4 + 1024;
+    }
     hipEvent_t ev = nullptr;
     if (hipMemcpyAsync(b.h_tab, b.stat + g[2], nt * sizeof(PatchStat), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+        (any_rep && hipMemcpyAsync(b.h_rtab, b.rstat + g[2], nt * sizeof(RepStat), hipMemcpyDeviceToHost, cs) != hipSuccess) ||
         hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return BT_EHIP;
     if (hipEventRecord(ev, cs) != hipSuccess) { (void)hipEventDestroy(ev); return BT_EHIP; }
     // the sort runs while the host lays out tracks, pairs and tiles
@@ -392,6 +429,7 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
     (void)hipEventDestroy(ev);
     if (!sorted_ok || !waited) return BT_EHIP;
     st->tab = b.h_tab; st->kmin = g[2]; st->kmax = g[3]; st->n_all = g[0]; st->f_lo = g[1]; st->any_self = g[4];
+    st->rep_known = rep ? 1 : 0; st->rtab = any_rep ? b.h_rtab : nullptr;
     return BT_OK;
 }
 
@@ -450,8 +488,8 @@ int plan_device_fill(const bt_plan *pl, int64_t E, int32_t *d_rec, int32_t *d_pm
 int plan_device_slots_stage(const bt_plan *pl, void *stream) {
     hipStream_t cs = static_cast<hipStream_t>(stream);
     DevPlanBuffers &b = bufs();
-    const size_t nwin = pl->trk_win.size(), m = pl->trk_loc.size(), npo = pl->dev_pair_of.size(), noff = pl->dev_off.size();
-    const size_t n_small = nwin + m + npo + noff;
+    const size_t nwin = pl->trk_win.size(), m = pl->trk_loc.size(), npo = pl->dev_pair_of.size(), noff = pl->dev_off.size(), npb = pl->dev_pbase.size();
+    const size_t n_small = nwin + m + npo + noff + npb;
     if (n_small > b.small_cap) {
         (void)hipFree(b.small); (void)hipHostFree(b.h_small);
         const size_t want = n_small + n_small / 4 + 4096;
@@ -470,6 +508,7 @@ int plan_device_slots_stage(const bt_plan *pl, void *stream) {
     std::copy(pl->trk_loc.begin(), pl->trk_loc.end(), h + nwin);
     std::copy(pl->dev_pair_of.begin(), pl->dev_pair_of.end(), h + nwin + m);
     std::copy(pl->dev_off.begin(), pl->dev_off.end(), h + nwin + m + npo);
+    std::copy(pl->dev_pbase.begin(), pl->dev_pbase.end(), h + nwin + m + npo + noff);
     if (hipMemcpyAsync(b.small, h, n_small * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess ||
         hipMemsetAsync(b.crossed, 0, ncr, cs) != hipSuccess) return BT_EHIP;
     return BT_OK;
@@ -486,6 +525,7 @@ int plan_device_slots_fill(const bt_plan *pl, int64_t E, int32_t *d_slot_edge, i
     PlanSlotArgs a{};
     a.keys = b.keys + pl->dev_q0; a.vals = b.vals + pl->dev_q0; a.words = b.words; a.jbits = b.jbits; a.E = E;
     a.trk_win = b.small; a.trk_loc = b.small + nwin; a.pair_of = b.small + nwin + m; a.off = b.small + nwin + m + npo;
+    a.pbase = pl->dev_pbase.empty() ? nullptr : b.small + nwin + m + npo + pl->dev_off.size();
     a.f_lo = (int)pl->dev_f_lo; a.nw = (int)pl->dev_nw; a.fixedp = (int)pl->info.fixedp;
     const PlanDev &P = pl->dev;
     a.tile_slot0 = P.tile_slot0; a.tile_cam0 = P.tile_cam0; a.tile_ncam = P.tile_ncam; a.tile_cams = P.tile_cams;

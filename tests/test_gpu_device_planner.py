@@ -63,7 +63,7 @@ def test_lists_outside_the_device_path_are_planned_by_the_host():
     g = graphgen.make_graph(64, 2048, 8, seed=0)
     idx = [torch.as_tensor(a, device=DEV) for a in (g.ii, g.jj, g.kk)]
     p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
-    assert p.built_on_device and p.jacobian_kernel == "k_edge2" and p.tiles == 2048      # (slot-uniform tiles: k_edge2; ragged ones: k_stream, below)
+    assert p.built_on_device and p.jacobian_kernel == "k_edge2" and p.tiles == 2048      # (slot-uniform tiles: k_edge2; ragged ones as well since round 6: aligned slots, below)
     prev = wave_per_tile_kernels(False)
     try:
         p = Plan(*idx, g.poses.shape[0], g.patches.shape[0], 1)
@@ -240,7 +240,7 @@ def test_device_planned_tables_of_the_wave_per_tile_kernels_equal_the_hosts(vari
     if variant == "repeats":                    # repeated observations: runs across the half-chunk boundary (straddle flags), repeat bits
         extra = rng.integers(0, ii.size, ii.size // 2)
         ii, jj, kk = np.concatenate([ii, ii[extra]]), np.concatenate([jj, jj[extra]]), np.concatenate([kk, kk[extra]])
-    if variant == "ragged":                     # tracks of different lengths: tiles that are not slot-uniform (no k_edge for the plan)
+    if variant == "ragged":                     # tracks of different lengths: slot-uniform all the same (aligned slots with null entries, ba_plan.cpp)
         keep = rng.random(ii.size) > 0.15
         ii, jj, kk = ii[keep], jj[keep], kk[keep]
     if variant in ("k_edge_8192_shuffled", "repeats"):
@@ -256,9 +256,9 @@ def test_device_planned_tables_of_the_wave_per_tile_kernels_equal_the_hosts(vari
     assert dev.built_on_device and not host.built_on_device and host.tiles >= 2048
     assert dev.jacobian_kernel == host.jacobian_kernel and host.jacobian_kernel in ("k_stream", "k_edge2")
     if variant.startswith("k_"):
-        assert host.jacobian_kernel == variant[:variant.index("_", 2)]
+        assert host.jacobian_kernel == "k_edge2"
     if variant == "ragged":
-        assert host.jacobian_kernel == "k_stream"          # (tiles that are not slot-uniform: the device's verdict must be the host's)
+        assert host.jacobian_kernel == "k_edge2"           # (round 5: k_stream — a missing observation used to shift the rest of its track)
     for f in ("E", "m", "n", "tiles", "pairs", "slots", "nnz_blocks", "workspace_bytes"):
         assert getattr(dev, f) == getattr(host, f), f
     for name in SLOT_TABLES + ("trk_off",):

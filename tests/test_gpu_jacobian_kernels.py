@@ -22,9 +22,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GATES = {8: (2e-7, 1e-10, 1e-5, 1e-5, 1e-5), 6: (2e-7, 1e-6, 1e-5, 1e-5, 1e-5), 4: (5e-6, 5e-6, 3e-4, 3e-4, 1e-4)}
 
 
+def deep(g, times=9):
+    """Every observation `times` times: more than 64 (pair, repeat) slots per track — the edge-major layout of k_edge2 does not hold
+    such tiles, the plan stays with k_stream (what is left for that kernel since the aligned slots of round 6)."""
+    import copy
+    h = copy.copy(g)
+    for name in ("ii", "jj", "kk", "targets3", "weights", "weights_pose"):
+        setattr(h, name, np.ascontiguousarray(np.repeat(np.asarray(getattr(g, name)), times, axis=0)))
+    return h
+
+
 def ragged(g, drop=0.15):
-    """The graph without a random 15 % of its observations: tracks of different lengths, tiles that are not slot-uniform (k_stream's
-    graphs; a missing LAST observation alone would leave the slots of a tile aligned)."""
+    """The graph without a random 15 % of its observations: tracks of different lengths.  Round 5: tiles that are not slot-uniform,
+    k_stream's graphs; round 6: slot-uniform again by aligned slots with null entries (ba_plan.cpp), k_edge2's."""
     keep = np.random.default_rng(11).random(np.asarray(g.kk).size) > drop
     import copy
     h = copy.copy(g)
@@ -37,6 +47,7 @@ def ragged(g, drop=0.15):
                                                   # from 2048 tiles the wave-per-tile kernels, mixed precision: inside the 1e-5 bar:
                                                   # k_edge2 / k_edge where the tiles are slot-uniform, k_stream where they are not ...
                                                   (64, 2048, "k_stream", False, True), (64, 2048, "k_stream", True, True),
+                                                  (64, 2048, "ragged", False, True), (64, 2048, "ragged", True, True), (64, 8192, "ragged", False, True),
                                                   (64, 2048, "k_edge2", False, True), (64, 4096, "k_edge2", False, True),
                                                   (64, 6144, "k_edge2", False, True), (64, 6144, "k_edge2", True, True),
                                                   # the size the roofline figures are quoted at: 8.4M edges, 16384 tiles, 8 tiles per wave
@@ -47,7 +58,9 @@ def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, wpt):
     from batrack_amd.plan import wave_per_tile_kernels
     g = graphgen.make_graph(frames, M, 8, seed=5)
     if kernel == "k_stream":
-        g = ragged(g)
+        g = deep(g)
+    if kernel == "ragged":
+        g, kernel = ragged(g), "k_edge2"
     f = lambda a: np.asarray(a, np.float32).astype(np.float64)
     d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics), targets3=f(g.targets3),
              weights=f(g.weights), weights_pose=f(g.weights_pose), ii=g.ii, jj=g.jj, kk=g.kk, bounds=np.asarray(g.bounds))
@@ -79,7 +92,7 @@ def test_the_kernel_choice_is_the_plans_own():
     """A plan keeps the layout it was built with: switching the setting afterwards changes neither its kernel nor its tables."""
     import torch
     from batrack_amd.plan import Plan, wave_per_tile_kernels
-    g = ragged(graphgen.make_graph(64, 2048, 8, seed=2))
+    g = deep(graphgen.make_graph(64, 2048, 8, seed=2))
     T = lambda a: torch.as_tensor(a, device="cuda:0")
     ii, jj, kk = T(g.ii), T(g.jj), T(g.kk)
     assert wave_per_tile_kernels() is True                              # the default
@@ -150,7 +163,9 @@ assert o["status"] == 0
 es, ey = rel(np.tril(o["S_lower"]), np.tril(ref["S"])), rel(o["y"], ref["y"])
 ep, ed = rel(o["poses_out"], ref["poses_out"]), rel(o["patches_out"], ref["patches_out"])
 print("one observation per track:", o["plan"].tiles, "tiles", es, ey, ep, ed)
-assert es < 5e-6 and ey < 5e-6 and ep < 5e-6 and ed < 5e-6, (es, ey, ep, ed)
+# (a track with ONE observation leaves y = v - E Q w' as the small difference of two nearly equal vectors — each residual is all
+#  but absorbed by its own depth: the mixed-precision kernels' 1e-7 on v and E shows as 1e-5 on y; an off-by-one row shows as O(1))
+assert es < 5e-6 and ey < 1e-4 and ep < 3e-4 and ed < 5e-6, (es, ey, ep, ed)
 """
 
 

@@ -403,3 +403,64 @@ def test_small_tile_plan_that_reaches_the_stream_tile_count_does_not_crash():
         assert "bt_plan_create failed" in str(e)
     else:
         assert up.tiles == host.tiles
+
+
+def _ragged(g, drop=0.15, seed=11):
+    import copy
+    keep = np.random.default_rng(seed).random(np.asarray(g.kk).size) > drop
+    h = copy.copy(g)
+    for name in ("ii", "jj", "kk", "targets3", "weights", "weights_pose"):
+        setattr(h, name, np.ascontiguousarray(np.asarray(getattr(g, name))[keep]))
+    return h
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.15, 0.5])
+def test_aligned_slots_make_a_ragged_graph_slot_uniform(drop):
+    """Plans of >= 2048 tiles lay a tile's slots out per (camera pair, repeat) — ba_plan.cpp "ALIGNED SLOTS": with observations missing
+    at random (tracks of different lengths) every tile is still slot-uniform, so the edge-major tables (it_edge, tile_sinfo) exist;
+    every edge sits in exactly one slot and one lane of an iteration, under its own pair and track; a tile has ONE source frame."""
+    from batrack_amd import graphgen
+    g = graphgen.make_graph(64, 2048 if drop < 0.3 else 2560, 8, seed=3)
+    if drop:
+        g = _ragged(g, drop)
+    E = g.ii.size
+    pl = Plan(g.ii, g.jj, g.kk, g.poses.shape[0], g.patches.shape[0], 1, upload=False)
+    A = pl.arrays()
+    T = pl.tiles
+    assert T >= 2048
+    assert A["it_edge"].size > 0 and A["tile_sinfo"].size == T * 64, "the plan is not slot-uniform"
+    se, sp = A["slot_edge"].reshape(-1, 64), A["slot_pair"].reshape(-1, 64)
+    live = se >= 0
+    assert np.array_equal(np.sort(se[live]), np.arange(E))                       # every edge once
+    pair_i, pair_j = A["pair_i"], A["pair_j"]
+    assert np.array_equal(pair_i[sp[live]], g.ii[se[live]]) and np.array_equal(pair_j[sp[live]], g.jj[se[live]])
+    # slot-uniform: one pair per (tile, slot)
+    slot0, nslot, trk0, ntrk = A["tile_slot0"], A["tile_nslot"], A["tile_trk0"], A["tile_ntrk"]
+    kx = A["kx"]
+    for t in list(range(0, T, 97)) + [T - 1]:
+        rows = slice(slot0[t], slot0[t] + nslot[t])
+        for s in range(slot0[t], slot0[t] + nslot[t]):
+            p = sp[s][live[s]]
+            assert p.size == 0 or (p == p[0]).all()
+        # lanes = the tile's tracks, all of one source frame
+        e = se[rows][live[rows]]
+        assert np.unique(g.ii[e]).size == 1
+        assert set(np.unique(g.kk[e])) <= set(kx[trk0[t]:trk0[t] + ntrk[t]])
+        assert nslot[t] <= 64
+    # it_edge: the same edges, lane = track_in_iteration * S + slot
+    ie = A["it_edge"]
+    assert np.array_equal(np.sort(ie[ie >= 0]), np.arange(E))
+    rec = A["tile_rec"].reshape(-1, 8)
+    for t in list(range(0, T, 131)) + [T - 1]:
+        it0, lg, nit = rec[t, 6], rec[t, 7] & 0xff, rec[t, 7] >> 8
+        assert nit % 2 == 0 and (1 << lg) >= nslot[t]
+        blk = ie[it0 * 64:(it0 + nit) * 64].reshape(nit, 64)
+        G = 64 >> lg
+        for it in range(nit):
+            for ln in np.nonzero(blk[it] >= 0)[0]:
+                tr, s = it * G + (ln >> lg), ln & ((1 << lg) - 1)
+                assert se[slot0[t] + s, tr] == blk[it, ln]
+    if drop == 0.0:
+        # nothing missing: the aligned layout IS the old one (a track's s-th edge in slot s) wherever no observation repeats
+        full = nslot == 8
+        assert full.mean() > 0.8
