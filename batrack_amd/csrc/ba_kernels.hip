@@ -2252,9 +2252,30 @@ __global__ __launch_bounds__(THREADS) void k_update(PlanDev pd, StepArgs a, int 
 // ------------------------------------------------------------------ k_pack_system
 // Dense [S | y] (caller order, lower triangle) <-> the plan's non-zero blocks in factor order followed by
 // y in factor order: the multi-GPU exchange buffer (include/batrack_ba.h: bt_ba_pack).  One thread per element.
+// block b of a WIDE plan's packed form (ba_plan.cpp: no symbolic factorisation, every lower block): b = rn (rn + 1) / 2 + cn
+__device__ __forceinline__ void wide_block(int b, int &rn, int &cn) {
+    rn = (int)((sqrtf(8.0f * (float)b + 1.0f) - 1.0f) * 0.5f);
+    while ((rn + 1) * (rn + 2) / 2 <= b) ++rn;
+    while (rn * (rn + 1) / 2 > b) --rn;
+    cn = b - rn * (rn + 1) / 2;
+}
+
 template <bool UNPACK>
 __global__ __launch_bounds__(256) void k_pack_system(PlanDev pd, StepArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, nb = pd.nnzb * 36;
+    if (pd.wide) {
+        if (i < nb) {
+            const int b = i / 36, e = i - 36 * b, r = e / 6, c = e - 6 * r;
+            int rn, cn;
+            wide_block(b, rn, cn);
+            if (rn == cn && c > r) { if (!UNPACK) a.packed[i] = 0.0; return; }
+            double *p = a.S + (size_t)(6 * rn + r) * pd.D + 6 * cn + c;
+            if (UNPACK) *p = a.packed[i]; else a.packed[i] = *p;
+        } else if (i < nb + pd.D) {
+            if (UNPACK) a.y[i - nb] = a.packed[i]; else a.packed[i] = a.y[i - nb];
+        }
+        return;
+    }
     if (i < nb) {
         const int b = i / 36, e = i - 36 * b, r = e / 6, c = e - 6 * r, src = pd.blk_src[b];
         const int rn = src >> 9, cn = (src >> 1) & 255;
@@ -2281,6 +2302,14 @@ __global__ __launch_bounds__(256) void k_pack_system(PlanDev pd, StepArgs a) {
 __device__ __forceinline__ double *packed_elem(const PlanDev &pd, const StepArgs &a, int i, bool &zero) {
     const int nb = pd.nnzb * 36;
     zero = false;
+    if (pd.wide) {
+        if (i >= nb) return a.y + (i - nb);
+        const int b = i / 36, e = i - 36 * b, r = e / 6, c = e - 6 * r;
+        int rn, cn;
+        wide_block(b, rn, cn);
+        if (rn == cn && c > r) { zero = true; return nullptr; }
+        return a.S + (size_t)(6 * rn + r) * pd.D + 6 * cn + c;
+    }
     if (i < nb) {
         const int b = i / 36, e = i - 36 * b, r = e / 6, c = e - 6 * r, src = pd.blk_src[b];
         const int rn = src >> 9, cn = (src >> 1) & 255;
@@ -2424,8 +2453,9 @@ static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
     return tile_lds_bytes_r(pd, so, edge_precision(pd) ? sizeof(double) : sizeof(float), (size_t)tile_threads(pd) / 64);
 }
 
-// 0: factor in LDS as double, 1: in LDS as float, 2: in the global workspace (float)
+// 0: factor in LDS as double, 1: in LDS as float, 2: in the global workspace (float), 3: dense in the global workspace (double; wide plans)
 int solver_mode(const PlanDev &pd) {
+    if (pd.wide) return 3;                           // more than 255 free poses: dense, in the global workspace (ba_dense.hip)
     static const int force = std::getenv("BT_SOLVER_MODE") ? std::atoi(std::getenv("BT_SOLVER_MODE")) : -1;   // measurement only
     if (force == 2) return 2;
     if (force == 1 && solve_lds_bytes(pd, sizeof(float)) <= kLdsBudget) return 1;
@@ -2493,6 +2523,7 @@ int configure_kernels(const PlanDev &pd) {
             raise_lds_limit(reinterpret_cast<const void *>(&k_tile<true, false, false, false, double>), tile_lds_bytes(pd, true)) != BT_OK) return BT_EHIP;
     }
     const int mode = solver_mode(pd);
+    if (mode == 3) return BT_OK;                     // (the dense solver raises its own limit at launch)
     const void *fns[4] = { reinterpret_cast<const void *>(&k_solve_lds<double, false>),
                            reinterpret_cast<const void *>(&k_solve_lds<double, true>),
                            reinterpret_cast<const void *>(&k_solve_lds<float, false>),
@@ -2598,7 +2629,12 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         const int mode = solver_mode(pd);
         const bool prof = (a.dbg & 16) != 0;
         const int nthr = solver_threads();
-        const int passes = mode >= 1 ? 2 : 1;                        // float32 factor: one step of iterative refinement
+        const int passes = mode == 3 ? 0 : mode >= 1 ? 2 : 1;        // float32 factor: one step of iterative refinement
+        if (mode == 3) {
+            if (ran) *ran |= 1u << 3;
+            const int rc = launch_solve_dense(pd, a, st, ev ? ev[6] : nullptr, ev ? ev[7] : nullptr);
+            if (rc != BT_OK) return rc;
+        }
         for (int pass = 0; pass < passes; ++pass) {
             if (pass == 1) hipLaunchKernelGGL(k_refine_residual, dim3((pd.D + 3) / 4), dim3(256), 0, st, pd, a);
             hipEvent_t *evp = pass == 0 ? ev : nullptr;                // (the event pair of kernel 3 times the first pass)

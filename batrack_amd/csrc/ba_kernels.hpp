@@ -58,5 +58,7 @@ size_t xchg_bytes(const PlanDev &pd, int world);
 int launch_xchg_push(const PlanDev &pd, const StepArgs &a, void *const *bufs, int world, int rank, long long epoch, hipStream_t st);
 int launch_xchg_pull(const PlanDev &pd, const StepArgs &a, void *own, int world, long long epoch, hipStream_t st);
 int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
+// the dense solver of plans with more than 255 free poses (ba_dense.hip)
+int launch_solve_dense(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 
 }  // namespace bt

@@ -76,7 +76,8 @@ static void layout_workspace(bt_plan *pl) {
     w.packed = off;   off = align_up(off + ((size_t)I.nnz_blocks * 36 + D) * sizeof(double), 256);   // exchange form of [S | y]
     w.pairgeo = off;  off = align_up(off + (size_t)I.pairs * kPairGeomFloats * sizeof(double), 256);         // k_tile -> k_pair_finalize (float or double)
     w.qw = off;       off = align_up(off + (size_t)I.m * 2 * sizeof(double), 256);                           // (Q, w') per track (float2 or double2)
-    w.lfac = off;     off = align_up(off + (size_t)I.nnz_blocks * 36 * sizeof(float), 256);
+    // (a wide plan's dense factor: D x D doubles and the right-hand side behind it)
+    w.lfac = off;     off = align_up(off + (pl->wide ? (D * D + D) * sizeof(double) : (size_t)I.nnz_blocks * 36 * sizeof(float)), 256);
     w.linv = off;     off = align_up(off + (size_t)I.n * 36 * sizeof(float), 256);
     w.zvec = off;     off = align_up(off + D * sizeof(float), 256);
     w.dx = off;       off = align_up(off + D * sizeof(float) + 64, 256);
@@ -224,7 +225,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     I.sorted_input = sorted ? 1 : 0;
     const int64_t n = std::max<int64_t>(n_all - fixedp, 0);
     I.n = n;
-    if (n > kMaxFree) return BT_EUNSUPPORTED;
+    if (n > kMaxFreeWide) return BT_EUNSUPPORTED;          // (beyond kMaxFree: the dense solver, ba_dense.hip)
     if (!src_ok) return BT_EUNSUPPORTED;
     I.E = E_own;
     // Tile counts from which the wave-per-tile kernels take THIS plan.  A rank's plan of a sharded solve (own_lo / own_hi) holds
@@ -709,6 +710,19 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     }
 
     BT_TICK("8");
+    // More than kMaxFree (255) free poses: the block-sparse solvers' tables hold pose numbers in 8 bits and block numbers in 15.
+    // Such a system (a global / loop-closing adjustment; the reference's dense solve has no size clause, ba.py:60-70) is solved
+    // DENSE in the global workspace (ba_dense.hip): no symbolic factorisation here, the natural order, every lower block "non-zero".
+    pl->wide = n > kMaxFree ? 1 : 0;
+    if (pl->wide) {
+        pl->perm.resize((size_t)n);
+        std::iota(pl->perm.begin(), pl->perm.end(), 0);
+        pl->col_ptr.assign((size_t)n + 1, 0); pl->upd_ptr.assign((size_t)n + 1, 0); pl->upd_next.assign((size_t)n + 1, 0);
+        pl->lvl_ptr.assign(1, 0); pl->dp_ptr.assign((size_t)n + 1, 0);
+        pl->fz_ok = 0; pl->fzp_ok = 0;
+        I.nnz_blocks = n * (n + 1) / 2; I.updates = 0;
+    }
+    const auto symbolic = [&]() -> int {
     // ---- block structure of S (lower) and symbolic Cholesky ----------------
     // S[u][v] (u >= v) may be non-zero if u and v share a tile (Schur term,
     // ba.py:321) or form a camera pair with both ends free (B, ba.py:279-282).
@@ -1098,6 +1112,10 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             }
         }
     }
+
+    return BT_OK;
+    };
+    if (!pl->wide) { const int src_rc = symbolic(); if (src_rc != BT_OK) return src_rc; }
 
     BT_TICK("13");
     // ---- k_tile's first loads, indexed by the tile alone (no dependent index chain in its prologue):

@@ -14,7 +14,8 @@ namespace bt {
 constexpr int kLanes = 64;          // tracks per wave tile (one lane = one track)
 constexpr int kTileCamSoft = 16;    // close a tile when its camera union would exceed this
 constexpr int kTileCamHard = 64;    // a single track may not see more free cameras than this
-constexpr int kMaxFree = 255;       // free poses supported by the reduced solver
+constexpr int kMaxFree = 255;       // free poses the block-sparse solvers take (8-bit pose numbers in their tables)
+constexpr int kMaxFreeWide = 2048;  // ... and the dense solver of larger systems (ba_dense.hip: the right-hand side lives in LDS)
 constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj + 6 gj)
 // Private copies of y and of the per-pair sums for k_edge2 (ba_edge2.hip): thousands of waves end with atomics on the SAME few
 // cache lines (y is 6n doubles in all; a pair's 27 sums are hit by every wave of its source frame) and atomics on one line are
@@ -85,6 +86,7 @@ struct PlanDev {
     int et_lgts;                                             // sp_ok: log2 of the track stride of StepArgs::esave (>= the largest tile's tracks)
     int sp_ok;                                               // k_etile leaves per-tile Schur products and pair sums (StepArgs::spart) instead of atomics
     int pm_ok;                                               // the pair-major tables exist (every tile has at most 64 camera pairs)
+    int wide;                                                // more than kMaxFree free poses: the dense solver (ba_dense.hip); perm is the identity, the packed form is the lower triangle by blocks
     int trk_off;                                             // sharded plan: distinct tracks of the full edge list in front of this rank's first
     int em_self;                                             // some edge has ii == jj (its source-camera E lands on a target row)
     int em_ok, em_its, em_lgs;                               // every tile slot-uniform; total iterations; log2 S if the same for all tiles, else -1
@@ -141,6 +143,7 @@ struct bt_plan {
     std::vector<uint8_t> pm_lb, pm_la;
     std::vector<int32_t> pp_ptr, pp_idx, sg_ptr;
     int pm_ok = 0, sp_ok = 0, sg_n = 0, et_lgts = 0, trk_off = 0;
+    int wide = 0;                                             // more than kMaxFree free poses: dense solve, no symbolic factorisation
     // plans whose pm_edge is written on the device (plan_device.hip): the table's rounds, and what the kernels need of the host's analysis
     int dev_pm = 0;
     int dev_slots = 0;                                        // likewise the [slots][64] arrays and the wave cuts of a 64-track layout
@@ -188,7 +191,7 @@ struct bt_plan {
                         &bs_sync, &fz_rowinfo, &fz_pfirst, &fz_psecond})
             v->clear();
         tile_cut8.clear(); tile_cut16.clear();
-        pm_edge.clear(); pm_rec.clear(); pm_lb.clear(); pm_la.clear(); pp_ptr.clear(); pp_idx.clear(); sg_ptr.clear(); pm_ok = 0; sp_ok = 0; pm_rounds = 0;
+        pm_edge.clear(); pm_rec.clear(); pm_lb.clear(); pm_la.clear(); pp_ptr.clear(); pp_idx.clear(); sg_ptr.clear(); pm_ok = 0; sp_ok = 0; pm_rounds = 0; wide = 0;
         dev_pbase.clear();
         slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); it_edge.clear(); tile_sinfo.clear(); em_ok = 0; st_ok = 0; em_its = 0; em_lgs = -1; act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;

@@ -381,6 +381,52 @@ def test_largest_supported_system_vs_oracle():
     assert rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
 
 
+@pytest.mark.parametrize("frames", [300, 700])
+def test_more_than_255_free_poses_vs_oracle(frames):
+    """A band of 300 / 700 keyframes (299 / 699 free poses; ba.py:60-70 has no size clause): beyond the 255 poses the block-sparse
+    solvers' tables hold, the plan is `wide` — a dense blocked Cholesky in double in the global workspace (ba_dense.hip).  Float64
+    gates, through the C ABI and through BA_rgbd_droid; the packed exchange form (every lower block) round-trips."""
+    g = graphgen.make_graph(frames, 16, 6, seed=21)
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics),
+             targets3=f(g.targets3), weights=f(g.weights), weights_pose=f(g.weights_pose),
+             ii=g.ii, jj=g.jj, kk=g.kk, bounds=np.asarray(g.bounds))
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"],
+                         d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, want_system=True)
+    hp = HipProblem(d)
+    o = hp.raw_step("weights_pose", 1)
+    n = frames - 1
+    assert o["plan"].n == n and o["plan"].nnz_blocks == n * (n + 1) // 2 and o["status"] == 0
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-5) and rel(o["y"], ref["y"]) < tol(1e-10, 2e-5)
+    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < DX_TOL
+    assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(1, frames)) < 1e-5
+    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], np.unique(g.kk)) < 1e-5
+    assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL and rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
+    # the reference's entry point, two chained dual iterations (batrack.py:869-875) against the oracle's
+    P, X = hp.api_step("weights_pose", 1, False)
+    assert rel(P.data[0].cpu().numpy().astype(np.float64), ref["poses_out"]) < STATE_TOL
+    assert rel(X[0, :, :, 0, 0].cpu().numpy().astype(np.float64), ref["patches_out"]) < STATE_TOL
+    # pack -> clear -> unpack restores the dense system exactly (the multi-GPU exchange form of a wide plan)
+    st = o["stepper"]
+    Pg = hp.poses[0].contiguous(); pat = hp.patches.reshape(-1, 3).contiguous()
+    Pout, pout = torch.empty_like(Pg), torch.empty_like(pat)
+    tg = hp.t3[0]
+    args = (Pg, pat, hp.mono.reshape(-1), hp.intr[0], tg, tg.stride(0), hp.w["weights_pose"][0].contiguous(),
+            Pout, pout, hp.bounds, 1e-4, 10.0, 0.05, "huber", False)
+    st.step(*args, phase="reduce")
+    dense = st.system.clone()
+    st.step(*args, phase="pack")
+    st.system.zero_()
+    st.step(*args, phase="unpack")
+    D = 6 * n
+    low = np.tril(np.ones((D, D), bool))
+    a, b = st.system[: D * D].reshape(D, D).cpu().numpy(), dense[: D * D].reshape(D, D).cpu().numpy()
+    assert np.array_equal(a[low], b[low]) and torch.equal(st.system[D * D:D * D + D], dense[D * D:D * D + D])
+    st.step(*args, phase="solve_update")
+    torch.cuda.synchronize()
+    assert rel(Pout.cpu().numpy().astype(np.float64), ref["poses_out"]) < STATE_TOL
+
+
 def test_packed_exchange_form_roundtrip():
     """bt_ba_pack / bt_ba_unpack (the multi-GPU exchange form of [S | y]): packing, clearing the dense system and
     unpacking restores it exactly; the packed buffer is the plan's non-zero blocks in factor order; the

@@ -174,15 +174,20 @@ def _chain_edges(N, K=3):
 
 
 def test_plan_limits():
-    """The documented limits (include/batrack_ba.h): 255 free poses, 64 free cameras per track, one source
-    frame per track.  At the limit the plan builds; one past it the call is refused (BT_EUNSUPPORTED), never
-    a silent wrong answer."""
+    """The documented limits (include/batrack_ba.h): 2048 free poses (beyond 255 the dense solver: no symbolic factorisation, every
+    lower block in the packed form), 64 free cameras per track, one source frame per track.  At the limit the plan builds; one past
+    it the call is refused (BT_EUNSUPPORTED), never a silent wrong answer."""
     ii, jj, kk = _chain_edges(256)
     pl = Plan(ii, jj, kk, 256, 256, 1, upload=False)
-    assert pl.n == 255
+    assert pl.n == 255 and pl.nnz_blocks < 255 * 256 // 2
     ii, jj, kk = _chain_edges(257)
+    pl = Plan(ii, jj, kk, 257, 257, 1, upload=False)
+    assert pl.n == 256 and pl.nnz_blocks == 256 * 257 // 2 and np.array_equal(pl.array("perm"), np.arange(256))
+    ii, jj, kk = _chain_edges(2049)
+    assert Plan(ii, jj, kk, 2049, 2049, 1, upload=False).n == 2048
+    ii, jj, kk = _chain_edges(2050)
     with pytest.raises(RuntimeError, match="unsupported"):
-        Plan(ii, jj, kk, 257, 257, 1, upload=False)
+        Plan(ii, jj, kk, 2050, 2050, 1, upload=False)
     # one track of frame 0 seen by 64 / 65 free cameras
     for ncam, ok in ((64, True), (65, False)):
         N = ncam + 1
