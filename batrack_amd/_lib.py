@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(_HERE, "lib", "libbatrack_ba.so")   # BT_LIB_PATH: measurement builds only
-SOURCES = ["ba_kernels.hip", "ba_etile.hip", "ba_stream.hip", "ba_edge2.hip", "ba_edge2u.hip", "ba_dense.hip", "plan_pack.hip", "plan_device.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip", "ga_kernels.hip"]
+SOURCES = ["ba_kernels.hip", "ba_etile.hip", "ba_stream.hip", "ba_edge2.hip", "ba_edge2u.hip", "ba_dense.hip", "ba_loose.hip", "plan_pack.hip", "plan_device.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip", "ga_kernels.hip"]
 HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", "ba_edge.hpp", "ba_update.hpp", "dev_cache.hpp", "ba_edge2.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
            os.path.join("..", "..", "include", "batrack_se3.h"), os.path.join("..", "..", "include", "batrack_patchify.h"),
            os.path.join("..", "..", "include", "batrack_projective.h"), os.path.join("..", "..", "include", "batrack_ga.h")]
@@ -17,7 +17,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 BT_OK, BT_EINVAL, BT_ENOMEM, BT_EHIP, BT_EUNSUPPORTED = 0, -1, -2, -3, -4
 ERRORS = {BT_EINVAL: "invalid argument", BT_ENOMEM: "out of memory", BT_EHIP: "HIP runtime error",
-          BT_EUNSUPPORTED: "unsupported graph (n > 2048 free poses, a track seen by > 64 free cameras, or a track "
+          BT_EUNSUPPORTED: "unsupported graph (n > 2048 free poses, or a track "
                            "whose edges name more than one source frame: ii must equal ix[kk])"}
 LOSS = {"trivial": 0, "huber": 1, "cauchy": 2}
 

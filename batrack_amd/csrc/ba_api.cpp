@@ -215,6 +215,7 @@ static void bind_pointers(bt_plan *pl, const void *d) {
     P.slot_lp = reinterpret_cast<const uint8_t *>(b + O.slp); P.max_tile_pairs = pl->max_tile_pairs; P.max_tile_slots = pl->max_tile_slots; P.max_cams = (int)I.max_tile_cams; P.e_all = pl->e_all;
     P.slot_code = reinterpret_cast<const uint16_t *>(b + O.sc); P.tile_la = reinterpret_cast<const uint8_t *>(b + O.tla); P.tile_rec = BT_I32(O.trec); P.it_edge = BT_I32(O.ite); P.tile_sinfo = reinterpret_cast<const uint32_t *>(b + O.tsi); P.em_ok = pl->em_ok; P.st_ok = pl->st_ok; P.st_min = pl->st_min; P.em_min = pl->em_min; P.em_its = (int)pl->em_its; P.em_lgs = pl->em_lgs; P.em_self = pl->em_self;
     P.pm_edge = BT_I32(O.pme); P.pm_rec = BT_I32(O.pmr); P.pm_lb = reinterpret_cast<const uint8_t *>(b + O.pmb); P.pm_la = reinterpret_cast<const uint8_t *>(b + O.pml); P.pm_ok = pl->pm_ok; P.sp_ok = pl->sp_ok; P.wide = pl->wide; P.trk_off = pl->trk_off; P.pp_ptr = BT_I32(O.ppp); P.pp_idx = BT_I32(O.ppi); P.sg_ptr = BT_I32(O.sgp); P.sg_n = pl->sg_n; P.et_lgts = pl->et_lgts;
+    P.lz_trk = BT_I32(O.lzt); P.lz_ptr = BT_I32(O.lzp); P.lz_edge = BT_I32(O.lze); P.lz_pair = BT_I32(O.lzq); P.nlz = pl->nlz;
 #undef BT_I32
 }
 
@@ -245,6 +246,8 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
     O.sc = put(buf, pl->slot_code), O.tla = put(buf, pl->tile_la), O.trec = put(buf, pl->tile_rec), O.ite = put(buf, pl->it_edge), O.tsi = put(buf, pl->tile_sinfo);
     O.pme = put(buf, pl->pm_edge), O.pmr = put(buf, pl->pm_rec), O.pmb = put(buf, pl->pm_lb), O.pml = put(buf, pl->pm_la);
     O.ppp = put(buf, pl->pp_ptr), O.ppi = put(buf, pl->pp_idx), O.sgp = put(buf, pl->sg_ptr);
+    O.lzt = put(buf, pl->lz_trk), O.lzp = put(buf, pl->lz_ptr), O.lze = put(buf, pl->lz_edge), O.lzq = put(buf, pl->lz_pair);
+    pl->nlz = (int)pl->lz_trk.size();
     pl->sg_n = pl->sg_ptr.empty() ? 0 : (int)pl->sg_ptr.size() - 1;
     tick("pack arrays");
     size_t cap = 0;
@@ -463,7 +466,7 @@ static int clone_shifted(const bt_plan *src, const uint64_t *d_words, int64_t E,
     pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
     pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
     pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->st_ok = src->st_ok; pl->st_min = src->st_min; pl->em_min = src->em_min; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
-    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->wide = src->wide; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->dev_slots = 0; pl->dev_wpt = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds; pl->k_hi = src->k_hi >= 0 ? src->k_hi + dk : -1;
+    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->wide = src->wide; pl->nlz = src->nlz; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->dev_slots = 0; pl->dev_wpt = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds; pl->k_hi = src->k_hi >= 0 ? src->k_hi + dk : -1;
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
     void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);

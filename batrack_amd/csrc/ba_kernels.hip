@@ -2568,7 +2568,7 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
     } else if (pd.T > 0 && etile_applies(pd)) {
         if (ran) *ran |= 1u << 1;
         int rc;
-        if (so && fuse_so_poses >= 0 && fused) {
+        if (so && fuse_so_poses >= 0 && fused && pd.nlz == 0) {
             const int total = pd.p_tot + (fuse_so_poses ? pd.n_buf : 0), nbr = (total + 511) / 512;
             rc = launch_etile(pd, a, 1, fuse_so_poses, nbr, 0, st, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr);
             *fused = true;
@@ -2584,7 +2584,7 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         const bool wide = tile_wide(pd);
         const dim3 blk(tile_threads(pd)), grid(pd.T);
         if (a.prec) {                      // float64 per-edge path (8 waves per tile)
-            if (so && fuse_so_poses >= 0 && fused) {
+            if (so && fuse_so_poses >= 0 && fused && pd.nlz == 0) {
                 const int total = pd.p_tot + (fuse_so_poses ? pd.n_buf : 0), nbr = (total + (int)blk.x - 1) / (int)blk.x;
                 BT_LAUNCH(1, (k_tile<true, false, false, true, double>), dim3(pd.T + nbr), blk, tile_lds_bytes(pd, true), pd, a, fuse_so_poses);
                 *fused = true;
@@ -2593,7 +2593,7 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
             else if (a.dbg & 32) BT_LAUNCH(1, (k_tile<false, true, false, false, double>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
             else                 BT_LAUNCH(1, (k_tile<false, false, false, false, double>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
         }
-        else if (so && fuse_so_poses >= 0 && fused) {
+        else if (so && fuse_so_poses >= 0 && fused && pd.nlz == 0) {
             // the whole structure-only step in this launch: tile workgroups, then the rest of the patch buffer and the poses
             const int total = pd.p_tot + (fuse_so_poses ? pd.n_buf : 0), nbr = (total + (int)blk.x - 1) / (int)blk.x;
             const dim3 gridf(pd.T + nbr);
@@ -2607,6 +2607,10 @@ int launch_reduce(const PlanDev &pd, const StepArgs &a, size_t zero_doubles, boo
         else if (a.dbg & 32)   BT_LAUNCH(1, (k_tile<false, true>), grid, dim3(512), tile_lds_bytes(pd, false), pd, a, 0);
         else if (wide)         BT_LAUNCH(1, (k_tile<false, false, true>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
         else                   BT_LAUNCH(1, (k_tile<false, false>), grid, blk, tile_lds_bytes(pd, false), pd, a, 0);
+    }
+    {   // the tracks that sit in no tile (more than 64 free cameras): their edges, their Schur terms (ba_loose.hip)
+        const int rc = launch_loose_reduce(pd, a, so, st);
+        if (rc != BT_OK) return rc;
     }
     if (!so && pd.P > 0) {
         const int pb = (pd.P + 3) / 4, nt16 = pd.max_rows16 >> 4;
@@ -2692,6 +2696,7 @@ int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy
         BT_LAUNCH(4, (k_update<false, W>), dim3(pd.T + nbw + zbw), dim3(W), ((size_t)pd.max_tile_pairs * kUpdGeo + W) * sizeof(float), pd, a, do_poses, pd.T, pd.T + nbw);
     }
     else    BT_LAUNCH(4, k_update<false>, dim3(pd.T + nb + zb), dim3(kUpdThreads), upd_lds, pd, a, do_poses, pd.T, pd.T + nb);
+    if (!so) { const int rc = launch_loose_update(pd, a, st); if (rc != BT_OK) return rc; }
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 #undef BT_LAUNCH

@@ -58,6 +58,9 @@ size_t xchg_bytes(const PlanDev &pd, int world);
 int launch_xchg_push(const PlanDev &pd, const StepArgs &a, void *const *bufs, int world, int rank, long long epoch, hipStream_t st);
 int launch_xchg_pull(const PlanDev &pd, const StepArgs &a, void *own, int world, long long epoch, hipStream_t st);
 int launch_solve_update(const PlanDev &pd, const StepArgs &a, bool so, bool copy_poses, hipStream_t st, hipEvent_t *ev = nullptr, unsigned *ran = nullptr);
+// tracks seen by more than 64 free cameras sit in no tile (ba_loose.hip): their part of the reduce phase / of the last kernel
+int launch_loose_reduce(const PlanDev &pd, const StepArgs &a, bool so, hipStream_t st);
+int launch_loose_update(const PlanDev &pd, const StepArgs &a, hipStream_t st);
 // the dense solver of plans with more than 255 free poses (ba_dense.hip)
 int launch_solve_dense(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 

@@ -390,6 +390,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     const bool aligned = !align_retry && masks_ok && tcap == kLanes && m > 0 && ((int64_t)m + kLanes - 1) / kLanes >= em_min_p &&
                          (!dstats || dstats->rep_known);
     pl->dev_pbase.clear();
+    std::vector<int32_t> loose;                                                               // tracks seen by more than kTileCamHard free cameras
     std::vector<uint64_t> tile_tmask;                                                         // aligned: per tile the union of its tracks' target masks (2 words)
     if (aligned) {
         // the same greedy rule on bit masks (a tile has one source frame, so its tracks' masks share their base): cameras = the
@@ -417,7 +418,14 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             }
             const uint64_t c_lo = t.mask & free_lo, c_hi = (t.mask2 & free_hi) | (t.src >= fixedp ? 1ull : 0ull);
             const int nk = __builtin_popcountll(c_lo) + __builtin_popcountll(c_hi);
-            if (nk > kTileCamHard) return BT_EUNSUPPORTED;
+            if (nk > kTileCamHard) {                               // a loose track (see the general loop below)
+                if (dstats) return BT_NEED_EDGES;
+                flush(k);
+                loose.push_back(k);
+                pl->trk_loc[(size_t)k] = -1;
+                trk0 = k + 1;
+                continue;
+            }
             const int add = __builtin_popcountll(c_lo & ~tm_lo) + __builtin_popcountll(c_hi & ~tm_hi);
             const int have = __builtin_popcountll(tm_lo) + __builtin_popcountll(tm_hi);
             if (k - trk0 >= tcap || (k > trk0 && have + add > std::max<int>(kTileCamSoft, nk))) flush(k);
@@ -450,7 +458,21 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             }
         }
         }
-        if ((int)trk_set.size() > kTileCamHard) return BT_EUNSUPPORTED;
+        if ((int)trk_set.size() > kTileCamHard) {
+            // a LOOSE track: in no tile (its E does not fit a tile's camera budget); ba_loose.hip walks its edges
+            if (dstats) return BT_NEED_EDGES;                      // (their edge lists come from the host's grouped order)
+            if (tcap < kLanes) {                                   // (k_etile's stored per-tile sums have no place for them: 64-track tiles, atomics)
+                if (tcap_retry) return BT_EUNSUPPORTED;
+                RetryScope guard(tcap_retry);
+                return build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots, dstats);
+            }
+            close_tile(k);
+            loose.push_back(k);
+            pl->trk_loc[(size_t)k] = -1;
+            trk0 = k + 1;
+            src_p = -1;                                            // (the next track starts a tile: its cameras are looked at afresh)
+            continue;
+        }
         int add = 0;
         for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) ++add;
         const int limit = std::max<int>(kTileCamSoft, (int)trk_set.size());
@@ -694,6 +716,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         for (int32_t t = 0; t < T; ++t) tot += pl->tile_nslot[(size_t)t];
         slots = tot; I.slots = tot;
     }
+    // the loose tracks' edge lists (grouped order: by pair, then by the caller's index) with their camera pairs
+    pl->lz_trk.clear(); pl->lz_ptr.assign(1, 0); pl->lz_edge.clear(); pl->lz_pair.clear();
+    for (int32_t k : loose) {
+        pl->lz_trk.push_back(k);
+        for (int32_t q = off[(size_t)k]; q < off[(size_t)k + 1]; ++q) { pl->lz_edge.push_back(ord[(size_t)q]); pl->lz_pair.push_back(pair_q(q)); }
+        pl->lz_ptr.push_back((int32_t)pl->lz_edge.size());
+    }
     // consecutive tiles with identical camera / pair lists: a persistent workgroup keeps its
     // accumulators across them
     pl->tile_flags.assign((size_t)T, 0);
@@ -737,6 +766,21 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     for (size_t p = 0; p < pl->pair_i.size(); ++p) {
         const int64_t a = pl->pair_i[p] - fixedp, b = pl->pair_j[p] - fixedp;
         if (a >= 0 && b >= 0) nz[(size_t)std::max(a, b)][(size_t)std::min(a, b)] = 1;
+    }
+    {   // a loose track couples all its free cameras (its Schur term, ba.py:321)
+        std::vector<int32_t> cset;
+        for (size_t l = 0; l < pl->lz_trk.size(); ++l) {
+            cset.clear();
+            for (int32_t q = pl->lz_ptr[l]; q < pl->lz_ptr[l + 1]; ++q) {
+                const int64_t a = pl->pair_i[(size_t)pl->lz_pair[(size_t)q]] - fixedp, b = pl->pair_j[(size_t)pl->lz_pair[(size_t)q]] - fixedp;
+                if (a >= 0) cset.push_back((int32_t)a);
+                if (b >= 0) cset.push_back((int32_t)b);
+            }
+            std::sort(cset.begin(), cset.end());
+            cset.erase(std::unique(cset.begin(), cset.end()), cset.end());
+            for (size_t u = 0; u < cset.size(); ++u)
+                for (size_t v = 0; v <= u; ++v) nz[(size_t)cset[u]][(size_t)cset[v]] = 1;
+        }
     }
     if (E_own != E && dstats) {
         // (the same from the device's table: a track's cameras are its source frame and the frames of its mask)

@@ -13,7 +13,7 @@ namespace bt {
 
 constexpr int kLanes = 64;          // tracks per wave tile (one lane = one track)
 constexpr int kTileCamSoft = 16;    // close a tile when its camera union would exceed this
-constexpr int kTileCamHard = 64;    // a single track may not see more free cameras than this
+constexpr int kTileCamHard = 64;    // a track that sees more free cameras than this sits in no tile: a LOOSE track (ba_loose.hip)
 constexpr int kMaxFree = 255;       // free poses the block-sparse solvers take (8-bit pose numbers in their tables)
 constexpr int kMaxFreeWide = 2048;  // ... and the dense solver of larger systems (ba_dense.hip: the right-hand side lives in LDS)
 constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj + 6 gj)
@@ -86,6 +86,10 @@ struct PlanDev {
     int et_lgts;                                             // sp_ok: log2 of the track stride of StepArgs::esave (>= the largest tile's tracks)
     int sp_ok;                                               // k_etile leaves per-tile Schur products and pair sums (StepArgs::spart) instead of atomics
     int pm_ok;                                               // the pair-major tables exist (every tile has at most 64 camera pairs)
+    // LOOSE tracks (ba_plan.cpp): tracks seen by more than kTileCamHard free cameras sit in no tile; their edges are walked by
+    // k_loose_reduce / k_loose_update (ba_loose.hip), a workgroup per track, the track's E in LDS over ALL free cameras
+    const int32_t *lz_trk, *lz_ptr, *lz_edge, *lz_pair;      // track of loose track l; its edges [lz_ptr[l], lz_ptr[l + 1]): edge id, camera pair
+    int nlz;
     int wide;                                                // more than kMaxFree free poses: the dense solver (ba_dense.hip); perm is the identity, the packed form is the lower triangle by blocks
     int trk_off;                                             // sharded plan: distinct tracks of the full edge list in front of this rank's first
     int em_self;                                             // some edge has ii == jj (its source-camera E lands on a target row)
@@ -112,7 +116,7 @@ struct WsLayout {
 
 }  // namespace bt
 
-namespace bt { struct PlanOffsets { size_t ab, ar, bc, pme, pmr, pmb, pml, ppp, ppi, sgp, bs, bss, c0, cams, cl, cp, dp, dpp, e0, fl, flp, fm, fp, fpf, fpm, fpp, fps, fri, fy, ite, kx, lc, lm, lp, pi, pj, pm, ri, s0, sc, se, sl, slp, sn, sp, t0, tc, tc16, tc8, tf, tij, tkx, tla, tn, tnp, tp0, tps, trec, tsi, u, un, up; }; }
+namespace bt { struct PlanOffsets { size_t ab, ar, bc, pme, pmr, pmb, pml, ppp, ppi, sgp, bs, bss, c0, cams, cl, cp, dp, dpp, e0, fl, flp, fm, fp, fpf, fpm, fpp, fps, fri, fy, ite, kx, lc, lm, lp, lzt, lzp, lze, lzq, pi, pj, pm, ri, s0, sc, se, sl, slp, sn, sp, t0, tc, tc16, tc8, tf, tij, tkx, tla, tn, tnp, tp0, tps, trec, tsi, u, un, up; }; }
 
 struct bt_plan {
     bt_plan_info info{};
@@ -142,8 +146,10 @@ struct bt_plan {
     std::vector<int32_t> pm_edge, pm_rec;
     std::vector<uint8_t> pm_lb, pm_la;
     std::vector<int32_t> pp_ptr, pp_idx, sg_ptr;
+    std::vector<int32_t> lz_trk, lz_ptr, lz_edge, lz_pair;   // loose tracks (more than kTileCamHard free cameras)
     int pm_ok = 0, sp_ok = 0, sg_n = 0, et_lgts = 0, trk_off = 0;
     int wide = 0;                                             // more than kMaxFree free poses: dense solve, no symbolic factorisation
+    int nlz = 0;                                              // loose tracks (set at upload; clones copy it)
     // plans whose pm_edge is written on the device (plan_device.hip): the table's rounds, and what the kernels need of the host's analysis
     int dev_pm = 0;
     int dev_slots = 0;                                        // likewise the [slots][64] arrays and the wave cuts of a 64-track layout
@@ -191,8 +197,8 @@ struct bt_plan {
                         &bs_sync, &fz_rowinfo, &fz_pfirst, &fz_psecond})
             v->clear();
         tile_cut8.clear(); tile_cut16.clear();
-        pm_edge.clear(); pm_rec.clear(); pm_lb.clear(); pm_la.clear(); pp_ptr.clear(); pp_idx.clear(); sg_ptr.clear(); pm_ok = 0; sp_ok = 0; pm_rounds = 0; wide = 0;
-        dev_pbase.clear();
+        pm_edge.clear(); pm_rec.clear(); pm_lb.clear(); pm_la.clear(); pp_ptr.clear(); pp_idx.clear(); sg_ptr.clear(); pm_ok = 0; sp_ok = 0; pm_rounds = 0; wide = 0; nlz = 0;
+        dev_pbase.clear(); lz_trk.clear(); lz_ptr.clear(); lz_edge.clear(); lz_pair.clear();
         slot_lab.clear(); slot_lp.clear(); tile_la.clear(); slot_code.clear(); tile_rec.clear(); it_edge.clear(); tile_sinfo.clear(); em_ok = 0; st_ok = 0; em_its = 0; em_lgs = -1; act_bits.clear(); act_rank.clear(); stage.clear();
         max_tile_pairs = max_tile_slots = 0;
         fz_ok = fzp_ok = 0;

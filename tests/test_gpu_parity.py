@@ -425,6 +425,25 @@ def test_more_than_255_free_poses_vs_oracle(frames):
     st.step(*args, phase="solve_update")
     torch.cuda.synchronize()
     assert rel(Pout.cpu().numpy().astype(np.float64), ref["poses_out"]) < STATE_TOL
+    if frames > 300:
+        return
+    # the solver's failure semantics on the dense path (ba.py:9-13, :324-325), as the block-sparse solvers' tests have them
+    good = dense                                               # ([S | y] as the reduce phase left it: a solve clears it for the next step)
+    st.system.copy_(good)
+    st.system[D * D + 3] = float("nan")                        # a NaN in y: the factorisation succeeds, dX is NaN, one retry
+    st.step(*args, phase="solve_update")
+    torch.cuda.synchronize()
+    assert st.status() == 2 and bool(torch.isnan(st.dx).any())
+    st.system.copy_(good)
+    st.system[0] = -1e9                                        # a negative pivot (beyond the damping): failed factorisation, dX = 0
+    st.step(*args, phase="solve_update")
+    torch.cuda.synchronize()
+    assert st.status() == 1 and bool((st.dx == 0).all())
+    assert rel(Pout.cpu().numpy().astype(np.float64), d["poses"]) < 1e-6       # Exp(0) * G
+    st.system.copy_(good)
+    st.step(*args, phase="solve_update")
+    torch.cuda.synchronize()
+    assert st.status() == 0 and rel(Pout.cpu().numpy().astype(np.float64), ref["poses_out"]) < STATE_TOL
 
 
 def test_packed_exchange_form_roundtrip():
@@ -524,6 +543,59 @@ def test_track_seen_by_many_cameras_vs_oracle():
     assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 2e-5
     assert rel(o["poses_out"], ref["poses_out"]) < 5e-6             # a 47-pose dense system: float32 factor + one refinement step
     assert rel(o["patches_out"], ref["patches_out"]) < 5e-6
+
+
+@pytest.mark.parametrize("frames,hubs", [(128, 100), (320, 150)])
+def test_hub_tracks_seen_by_a_hundred_cameras_vs_oracle(frames, hubs):
+    """Tracks observed from 100 / 150 frames (a landmark of a global adjustment; the reference's dense E [n, m, 6] has no camera
+    limit, ba.py:268-292) next to an ordinary banded graph: more than 64 free cameras fit no tile — LOOSE tracks (ba_plan.cpp),
+    stepped by ba_loose.hip; the second case also has more than 255 free poses (the dense solver).  Float64 gates on the system,
+    dX and the state, both step kinds, through the C ABI and through BA_rgbd_droid; repeated observations and a self edge among
+    the hub's edges."""
+    g = graphgen.make_graph(frames, 8, 4, seed=21)
+    rng = np.random.default_rng(5)
+    ii, jj, kk = [g.ii], [g.jj], [g.kk]
+    hub_tracks = (3, 100, 8 * (frames // 2) + 1)
+    for k in hub_tracks:                                      # hub tracks: their source frame to `hubs` other frames
+        src = k // 8
+        tgt = rng.choice(frames, size=hubs, replace=False)
+        tgt = np.concatenate([tgt, tgt[:5], [src]])           # five targets twice, the source frame itself once more
+        ii.append(np.full(tgt.size, src)); jj.append(tgt); kk.append(np.full(tgt.size, k))
+    ii, jj, kk = (np.concatenate(a).astype(np.int64) for a in (ii, jj, kk))
+    p = rng.permutation(ii.size)                              # (the caller's order is not the planner's)
+    ii, jj, kk = ii[p], jj[p], kk[p]
+    gt = g.patches.copy(); gt[:, 2] = g.disp_gt
+    u, v, _ = graphgen.reproject(g.poses_gt, gt, g.intrinsics, ii, jj, kk)
+    E = len(kk)
+    t3 = np.stack([u + rng.normal(0, 0.5, E), v + rng.normal(0, 0.5, E), g.disp_gt[kk]], 1)
+    w = rng.uniform(0.3, 1.0, (E, 2))
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    d = dict(poses=f(g.poses), patches=f(g.patches), mono=f(g.mono_disp), intrinsics=f(g.intrinsics),
+             targets3=f(t3), weights=f(w), weights_pose=f(w), ii=ii, jj=jj, kk=kk, bounds=np.asarray(g.bounds))
+    ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights_pose"],
+                         d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, want_system=True)
+    hp = HipProblem(d)
+    o = hp.raw_step("weights_pose", 1)
+    assert o["status"] == 0 and o["plan"].n == frames - 1
+    loc = o["plan"].array("trk_loc")
+    kx = o["plan"].array("kx")
+    assert sorted(kx[loc < 0]) == sorted(hub_tracks)          # the hubs sit in no tile
+    assert o["plan"].edge_precision == 8
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 1e-10 and rel(o["y"], ref["y"]) < 1e-10
+    assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < DX_TOL
+    assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(1, frames)) < 1e-5
+    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], np.unique(kk)) < 1e-5
+    assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL and rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
+    # structure-only, and both through the reference's entry point
+    ref_so = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights"],
+                            d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, structure_only=True)
+    o_so = hp.raw_step("weights", 1, True)
+    assert update_err(o_so["patches_out"][:, 2], ref_so["patches_out"][:, 2], d["patches"][:, 2], np.unique(kk)) < 1e-5
+    P, X = hp.api_step("weights_pose", 1, False)
+    assert rel(P.data[0].cpu().numpy().astype(np.float64), ref["poses_out"]) < STATE_TOL
+    assert rel(X[0, :, :, 0, 0].cpu().numpy().astype(np.float64), ref["patches_out"]) < STATE_TOL
+    P2, X2 = hp.api_step("weights", 1, True)
+    assert rel(X2[0, :, :, 0, 0].cpu().numpy().astype(np.float64), ref_so["patches_out"]) < STATE_TOL
 
 
 def test_nan_in_solution_retries_with_larger_damping():

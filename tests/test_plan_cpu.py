@@ -188,15 +188,15 @@ def test_plan_limits():
     ii, jj, kk = _chain_edges(2050)
     with pytest.raises(RuntimeError, match="unsupported"):
         Plan(ii, jj, kk, 2050, 2050, 1, upload=False)
-    # one track of frame 0 seen by 64 / 65 free cameras
-    for ncam, ok in ((64, True), (65, False)):
+    # one track of frame 0 seen by 64 / 65 free cameras: the largest tile / a LOOSE track in no tile (ba_loose.hip), coupling all its cameras
+    for ncam in (64, 65):
         N = ncam + 1
         jj = np.arange(1, N, dtype=np.int64); ii = np.zeros_like(jj); kk = np.zeros_like(jj)
-        if ok:
-            assert Plan(ii, jj, kk, N, 4, 1, upload=False).max_tile_cams == 64
+        pl = Plan(ii, jj, kk, N, 4, 1, upload=False)
+        if ncam == 64:
+            assert pl.max_tile_cams == 64 and pl.tiles == 1 and pl.array("trk_loc")[0] == 0
         else:
-            with pytest.raises(RuntimeError, match="unsupported"):
-                Plan(ii, jj, kk, N, 4, 1, upload=False)
+            assert pl.tiles == 0 and pl.array("trk_loc")[0] == -1 and pl.nnz_blocks == ncam * (ncam + 1) // 2
     # a track whose edges name two source frames (the caller's invariant ii = ix[kk], batrack.py:199)
     with pytest.raises(RuntimeError, match="unsupported"):
         Plan(np.array([0, 1], np.int64), np.array([2, 3], np.int64), np.array([5, 5], np.int64), 4, 8, 1, upload=False)
