@@ -173,7 +173,7 @@ struct PackBuffers {
 
 static PackBuffers &pack_buffers() { static thread_local PackBuffers pb; return pb; }
 
-static bool api_prof() { static const bool p = std::getenv("BT_PLAN_PROF") != nullptr; return p; }
+static bool api_prof() { return plan_prof(); }
 struct ApiTick {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void operator()(const char *what) {
@@ -401,7 +401,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
             launch_pack_edges(ii, jj, kk, E, n_buf, p_tot, pb.d_words, pb.d_bad, cs) != BT_OK)
             return BT_EHIP;
         // window plans: the passes over the edges stay on the device (plan_device.hip), the host lays out what is small
-        static const bool dev_planner = !(std::getenv("BT_PLAN_DEVICE") && std::atoi(std::getenv("BT_PLAN_DEVICE")) == 0);
+        const bool dev_planner = !force().host_plan;
         if (dev_planner && upload && E >= 4096) {
             if (hipMemcpyAsync(pb.h_bad, pb.d_bad, sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess) return BT_EHIP;
             DevPlanStats st{};

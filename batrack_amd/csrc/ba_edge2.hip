@@ -806,8 +806,7 @@ static int launch_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEve
     // again but wait for more partners.  Measured with the waves' priorities taking turns (profiles/r05_edge2_workgroup.txt; us at
     // 8192 / 16384 / 32768 tiles): 2 waves 87 / 139 / 245, 4 waves 77 / 130 / 240, 8 waves (the whole CU) 76 / 133 / 248; at one tile
     // per wave (2048 tiles) 48 / 36 / 43.
-    static const int wg_env = std::getenv("BT_EDGE2_WG_WAVES") ? std::atoi(std::getenv("BT_EDGE2_WG_WAVES")) : 0;      // (measurement)
-    const int wg = wg_env > 0 ? wg_env : 4;
+    const int wg = 4;
     if (wg < W) W = wg;
     const size_t lds = lds_w * (size_t)W;
     static LdsLimit lds_limit;

@@ -302,8 +302,6 @@ static int launch_u(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEve
         if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_edge2u<MODE, LGS, LOSS>), lds)) return BT_EHIP;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_edge2u<MODE, LGS, LOSS>, 64, lds) != hipSuccess || nb < 1) nb = 1;
-        static const int cap = std::getenv("BT_EDGE2U_WAVES_PER_CU") ? std::atoi(std::getenv("BT_EDGE2U_WAVES_PER_CU")) : 0;     // (measurement)
-        if (cap > 0 && nb > cap) nb = cap;
         per_cu = nb;
         per_cu_c[dslot].store(nb, std::memory_order_relaxed); per_cu_lds[dslot].store(lds, std::memory_order_release);
     }
@@ -320,13 +318,9 @@ static int launch_u(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEve
 // tiles of the Schur product) and 64 camera pairs (one lane per pair in the prologue).
 // Measured on the benchmark generator (whole-step times; profiles/r02_kernel_choice.txt, r05_edge2_vs_edge.txt): k_tile is
 // fastest up to ~1500 tiles; from 2048 tiles k_edge2 where the tiles are slot-uniform (whole step 122 against k_stream's 130 us at
-// 2048 tiles, 151 against 160 at 4096), k_stream otherwise (BT_EDGE_PREF_TILES: k_stream keeps the graphs below it where both apply).
+// 2048 tiles, 151 against 160 at 4096), k_stream otherwise (tiles of more than 64 slots: the edge-major layout does not hold them).
 bool edge_applies(const PlanDev &pd) {
-    static const int off = std::getenv("BT_EDGE_OFF") ? std::atoi(std::getenv("BT_EDGE_OFF")) : 0;   // measurement only
-    static const int pref = std::getenv("BT_EDGE_PREF_TILES") ? std::atoi(std::getenv("BT_EDGE_PREF_TILES")) : 0;
-    if (off || !pd.em_ok || pd.T < pd.em_min || pd.max_cams > 10 || pd.max_cams <= 0 || pd.max_tile_pairs > 64 || pd.max_tile_pairs <= 0)
-        return false;
-    return pd.T >= pref || !stream_applies(pd);
+    return pd.em_ok && pd.T >= pd.em_min && pd.max_cams <= 10 && pd.max_cams > 0 && pd.max_tile_pairs <= 64 && pd.max_tile_pairs > 0;
 }
 
 // mode 0: the pose+structure reduce (k_edge2), 1: structure-only, 2: a pose+structure step's depth back-substitution (k_edge2u)

@@ -673,8 +673,8 @@ int launch_etile(const PlanDev &pd, const StepArgs &a, int mode, int do_poses, i
     }
     if (mode == kEtSO) return dbl ? launch_etile_t<kEtSO, double>(pd, a, do_poses, extra_blocks, 0, st, ev0, ev1) : launch_etile_t<kEtSO, float>(pd, a, do_poses, extra_blocks, 0, st, ev0, ev1);
     if (mode == kEtUpd) return dbl ? launch_etile_t<kEtUpd, double>(pd, a, do_poses, extra_blocks, zero_blocks, st, ev0, ev1) : launch_etile_t<kEtUpd, float>(pd, a, do_poses, extra_blocks, zero_blocks, st, ev0, ev1);
-    // float64: two rounds per trip (both variants need more than 128 registers: one workgroup per CU either way); BT_ETILE_TWO=0 for measurements
-    static const bool two = [] { const char *e = getenv("BT_ETILE_TWO"); return e ? atoi(e) != 0 : true; }();
+    // float64: two rounds per trip (both variants need more than 128 registers: one workgroup per CU either way)
+    constexpr bool two = true;
     if ((a.dbg & 32) && dbl && two) return launch_etile_t<kEtFull, double, true, true>(pd, a, 0, 0, 0, st, ev0, ev1);
     if (a.dbg & 32) return dbl ? launch_etile_t<kEtFull, double, true>(pd, a, 0, 0, 0, st, ev0, ev1) : launch_etile_t<kEtFull, float, true>(pd, a, 0, 0, 0, st, ev0, ev1);
     if (dbl && two) return launch_etile_t<kEtFull, double, false, true>(pd, a, 0, 0, 0, st, ev0, ev1);

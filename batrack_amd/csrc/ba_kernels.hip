@@ -2417,11 +2417,11 @@ int launch_xchg_pull(const PlanDev &pd, const StepArgs &a, void *own, int world,
 }
 
 // ------------------------------------------------------------------ launchers
-// 8 waves per tile; 16 for graphs of few tiles with deep slot loops (BT_TILE_WIDE = 0 / 1 forces: measurement only)
+// 8 waves per tile; 16 for graphs of few tiles with deep slot loops (BT_FORCE wide=0 / wide=1 forces: measurement only)
 int edge_precision(const PlanDev &pd);
 static bool tile_wide(const PlanDev &pd) {
     if (edge_precision(pd)) return false;
-    static const int env = std::getenv("BT_TILE_WIDE") ? std::atoi(std::getenv("BT_TILE_WIDE")) : -1;
+    const int env = force().tile_wide;
     if (env >= 0) return env != 0;
     return pd.T <= 128 && pd.max_tile_slots >= 24;
 }
@@ -2439,8 +2439,7 @@ static inline size_t tile_lds_bytes_r(const PlanDev &pd, bool so, size_t rsz, si
 }
 
 int edge_precision(const PlanDev &pd) {
-    static const int env = std::getenv("BT_EDGE_PREC") ? std::atoi(std::getenv("BT_EDGE_PREC")) : 1;   // 0: measurement only
-    if (env == 0 || pd.T <= 0 || edge_applies(pd) || stream_applies(pd)) return 0;
+    if (force().f32_edges || pd.T <= 0 || edge_applies(pd) || stream_applies(pd)) return 0;
     const int eb = etile_precision_bytes(pd);
     if (eb) return eb == 8 ? 1 : 0;
     return tile_lds_bytes_r(pd, false, sizeof(double), 8) <= kLdsBudget ? 1 : 0;
@@ -2456,25 +2455,25 @@ static inline size_t tile_lds_bytes(const PlanDev &pd, bool so) {
 // 0: factor in LDS as double, 1: in LDS as float, 2: in the global workspace (float), 3: dense in the global workspace (double; wide plans)
 int solver_mode(const PlanDev &pd) {
     if (pd.wide) return 3;                           // more than 255 free poses: dense, in the global workspace (ba_dense.hip)
-    static const int force = std::getenv("BT_SOLVER_MODE") ? std::atoi(std::getenv("BT_SOLVER_MODE")) : -1;   // measurement only
-    if (force == 2) return 2;
-    if (force == 1 && solve_lds_bytes(pd, sizeof(float)) <= kLdsBudget) return 1;
+    const int fs = force().solver;                   // (tests, measurement)
+    if (fs == 3) return 2;
+    if (fs == 2 && solve_lds_bytes(pd, sizeof(float)) <= kLdsBudget) return 1;
     if (solve_lds_bytes(pd, sizeof(double)) <= kLdsBudget) return 0;
     if (solve_lds_bytes(pd, sizeof(float)) <= kLdsBudget) return 1;
     return 2;
 }
 
 static int solver_threads();
-// one-phase-per-level variant of the double LDS solver; BT_SOLVER_FUSED=0: the two-phase k_solve_lds
+// one-phase-per-level variant of the double LDS solver; BT_FORCE solver=lds: the two-phase k_solve_lds
 static bool use_fused_solver(const PlanDev &pd) {
-    static const int on = std::getenv("BT_SOLVER_FUSED") ? std::atoi(std::getenv("BT_SOLVER_FUSED")) : 1;   // measurement only
-    return on != 0 && pd.fz_ok != 0 && solve_fused_lds_bytes(pd, solver_threads()) <= kLdsBudget;
+    const int fs = force().solver;
+    return fs != 1 && pd.fz_ok != 0 && solve_fused_lds_bytes(pd, solver_threads()) <= kLdsBudget;
 }
 
-// barrier-free variant of k_solve_fused; BT_SOLVER_PIPE=0: one workgroup barrier per level
+// barrier-free variant of k_solve_fused; BT_FORCE solver=fused: one workgroup barrier per level
 static bool use_pipe_solver(const PlanDev &pd) {
-    static const int on = std::getenv("BT_SOLVER_PIPE") ? std::atoi(std::getenv("BT_SOLVER_PIPE")) : 1;   // measurement only
-    return on != 0 && pd.fzp_ok != 0 && pd.fz_ok != 0 && solve_pipe_lds_bytes(pd) <= kLdsBudget;
+    const int fs = force().solver;
+    return fs < 0 && pd.fzp_ok != 0 && pd.fz_ok != 0 && solve_pipe_lds_bytes(pd) <= kLdsBudget;
 }
 
 static int solver_threads() {

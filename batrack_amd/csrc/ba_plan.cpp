@@ -29,15 +29,38 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // Those kernels evaluate an edge in MIXED precision since round 4 (reprojection and residual in float64, Jacobians and their
 // products in float32: ba_edge.hpp edge_eval_mixed) and keep the update within north_star's 1e-5 of the reference's float64
 // run (measured 1e-6 .. 5e-6 on the benchmark graphs; S and y 1e-7).  A caller who wants the reduced system itself to 1e-10
-// at every size switches them off — bt_config_wave_per_tile_kernels(0), or BT_WPT_KERNELS=0 in the environment — and every
-// plan then takes the float64-per-edge tile kernels (a third of the throughput from 2048 tiles on).  BT_EDGE_MIN_TILES /
-// BT_STREAM_MIN_TILES set the thresholds outright (tests, measurement).  A plan records what it was laid out for (st_ok,
+// at every size switches them off — bt_config_wave_per_tile_kernels(0) — and every plan then takes the float64-per-edge tile
+// kernels (a third of the throughput from 2048 tiles on).  BT_FORCE (ba_plan.hpp) forces one kernel for every plan (tests,
+// measurement).  A plan records what it was laid out for (st_ok,
 // em_ok, st_min, em_min): the launch-time choice never depends on a later change of this setting.
-static std::atomic<int> g_wpt_kernels{-1};           // -1: not set by the caller -> the environment decides (default on)
-static int wpt_env() {
-    static const int env = std::getenv("BT_WPT_KERNELS") ? std::atoi(std::getenv("BT_WPT_KERNELS")) : 1;
-    return env ? 1 : 0;
+const Force &force() {
+    static const Force f = [] {
+        Force r;
+        const char *e = std::getenv("BT_FORCE");
+        if (!e) return r;
+        std::string s(e);
+        size_t pos = 0;
+        while (pos <= s.size()) {
+            const size_t end = std::min(s.find(',', pos), s.size());
+            const std::string tok = s.substr(pos, end - pos);
+            pos = end + 1;
+            if (tok == "kernel=k_tile") r.kernel = 0; else if (tok == "kernel=k_stream") r.kernel = 1;
+            else if (tok == "kernel=k_edge2") r.kernel = 2; else if (tok == "kernel=k_etile") r.kernel = 3;
+            else if (tok == "solver=fused") r.solver = 0; else if (tok == "solver=lds") r.solver = 1;
+            else if (tok == "solver=lds32") r.solver = 2; else if (tok == "solver=global") r.solver = 3;
+            else if (tok == "order=natural") r.natural_order = 1; else if (tok == "prec=f32") r.f32_edges = 1;
+            else if (tok == "wide=0") r.tile_wide = 0; else if (tok == "wide=1") r.tile_wide = 1;
+            else if (tok == "plan=host") r.host_plan = 1; else if (tok == "wpt=0") r.wpt_off = 1;
+            else if (!tok.empty()) std::fprintf(stderr, "batrack: unknown BT_FORCE token '%s'\n", tok.c_str());
+        }
+        return r;
+    }();
+    return f;
 }
+bool plan_prof() { static const bool p = std::getenv("BT_PLAN_PROF") != nullptr; return p; }
+
+static std::atomic<int> g_wpt_kernels{-1};           // -1: not set by the caller -> BT_FORCE decides (default on)
+static int wpt_env() { return force().wpt_off ? 0 : 1; }
 int config_wave_per_tile_kernels(int enable) {
     const int prev = g_wpt_kernels.load();
     if (enable >= 0) g_wpt_kernels.store(enable ? 1 : 0);
@@ -49,13 +72,15 @@ static int wpt_kernels_on() {
 }
 constexpr int kNever = 1 << 30;
 int edge_min_tiles() {
-    static const int t = std::getenv("BT_EDGE_MIN_TILES") ? std::atoi(std::getenv("BT_EDGE_MIN_TILES")) : -1;
-    return t >= 0 ? t : (wpt_kernels_on() ? 2048 : kNever);
+    const int k = force().kernel;
+    return k == 2 ? 1 : k >= 0 ? kNever : (wpt_kernels_on() ? 2048 : kNever);
 }
 int stream_min_tiles() {
-    static const int t = std::getenv("BT_STREAM_MIN_TILES") ? std::atoi(std::getenv("BT_STREAM_MIN_TILES")) : -1;
-    return t >= 0 ? t : (wpt_kernels_on() ? 2048 : kNever);
+    const int k = force().kernel;
+    return (k == 1 || k == 2) ? 1 : k >= 0 ? kNever : (wpt_kernels_on() ? 2048 : kNever);
 }
+// the pair-major layout (k_etile): 1 = for the plans it was measured on (few tiles, deep tracks), 0 = never, 2 = every plan
+static int etile_mode() { const int k = force().kernel; return k == 3 ? 2 : k >= 0 ? 0 : 1; }
 
 static void layout_workspace(bt_plan *pl) {
     const bt_plan_info &I = pl->info;
@@ -125,7 +150,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     pl->e_all = E;
     if (own_hi <= 0) { own_lo = 0; own_hi = p_tot; }
     if (own_lo < 0 || own_hi > p_tot || own_lo > own_hi) return BT_EINVAL;
-    static const bool plan_prof = std::getenv("BT_PLAN_PROF") != nullptr;          // measurement only: time per phase on stderr
+    const bool plan_prof = bt::plan_prof();                                        // measurement only: time per phase on stderr
     auto t_prev = std::chrono::steady_clock::now();
 #define BT_TICK(name) do { if (plan_prof) { const auto t_now = std::chrono::steady_clock::now(); std::fprintf(stderr, "plan phase before %s: %.3f ms\n", name, std::chrono::duration<double, std::milli>(t_now - t_prev).count()); t_prev = t_now; } } while (0)
 
@@ -366,15 +391,12 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     };
     int tcap = kLanes;
     {
-        static const int env = std::getenv("BT_TILE_TRACKS") ? std::atoi(std::getenv("BT_TILE_TRACKS")) : 0;     // measurement only
-        static const int pm_env = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;
+        const int pm_env = etile_mode();
         const int64_t t64 = (m + kLanes - 1) / kLanes;
-        if (env > 0) tcap = std::min<int>(kLanes, env);
-        else if (pm_env && !tcap_retry && t64 > 0 && t64 <= 96 && E_own >= 24 * (int64_t)m && t64 < std::min(em_min_p, st_min_p) / 4) tcap = 16;
+        if (pm_env && !tcap_retry && t64 > 0 && t64 <= 96 && E_own >= 24 * (int64_t)m && t64 < std::min(em_min_p, st_min_p) / 4) tcap = 16;
     }
     if (dstats && tcap == kLanes) {                                // the device then writes the [slots][64] arrays and the wave cuts
-        static const int pm_env2 = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;
-        if (pm_env2 == 2) return BT_NEED_EDGES;                    // (pair-major tables of 64-track tiles are made from the host's slot arrays)
+        if (etile_mode() == 2) return BT_NEED_EDGES;                    // (pair-major tables of 64-track tiles are made from the host's slot arrays)
     }
     // ALIGNED SLOTS (round 6) for the plans the wave-per-tile kernels take.  k_edge2 / k_edge2u need every tile SLOT-UNIFORM — all
     // tracks of a tile with the same camera pair (or no edge) in slot s.  With slot s = a track's s-th edge that holds only where
@@ -836,7 +858,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     std::vector<int32_t> perm((size_t)n);
     std::iota(perm.begin(), perm.end(), 0);
     {
-        static const int nd = std::getenv("BT_SOLVER_ORDER") ? std::atoi(std::getenv("BT_SOLVER_ORDER")) : 1;   // 0 = natural
+        const int nd = force().natural_order ? 0 : 1;
         int best_k = -1, best_score = (int)n;        // natural chain length = n
         std::vector<uint8_t> in_s((size_t)n);
         for (int64_t k = 1; k < n && nd; ++k) {
@@ -1360,7 +1382,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         pl->pm_edge.clear(); pl->pm_rec.clear(); pl->pm_lb.clear(); pl->pm_la.clear();
     }
     if (!pm_direct) {
-        static const int pm_env = std::getenv("BT_ETILE") ? std::atoi(std::getenv("BT_ETILE")) : 1;     // 0: measurement / tests (forces k_tile)
+        const int pm_env = etile_mode();                            // 0: k_tile forced
         if (!pm_env || (pm_env != 2 && tcap == kLanes)) pl->pm_ok = 0;      // (tables only for the plans that will use them)
         for (int64_t t = 0; t < I.tiles && pl->pm_ok; ++t) if (pl->tile_npair[(size_t)t] > kLanes) pl->pm_ok = 0;
         if (pl->pm_ok) {

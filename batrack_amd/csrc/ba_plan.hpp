@@ -211,6 +211,23 @@ struct bt_plan {
 };
 
 namespace bt {
+// BT_FORCE — the ONE environment switch of the kernel / solver / planner choices (tests and measurement; production leaves it
+// unset).  Comma-separated tokens, parsed once per process:
+//   kernel=k_tile | k_stream | k_edge2 | k_etile   the Jacobian kernel every plan whose layout admits it takes
+//   solver=fused | lds | lds32 | global            the reduced solver (default: k_solve_pipe where the plan allows it)
+//   order=natural                                  no twisted elimination order
+//   prec=f32                                       float32 per-edge maths on the k_tile path (round 2's numerics)
+//   wide=0 | wide=1                                k_tile's 8 / 16 waves per tile
+//   plan=host                                      no device-side planner
+//   wpt=0                                          no wave-per-tile kernels (= bt_config_wave_per_tile_kernels(0))
+struct Force {
+    int kernel = -1;        // -1 the plan's own choice, 0 k_tile, 1 k_stream, 2 k_edge2, 3 k_etile
+    int solver = -1;        // -1 default, 0 k_solve_fused (barrier per level), 1 k_solve_lds<double>, 2 k_solve_lds<float>, 3 k_solve_global
+    int natural_order = 0, f32_edges = 0, tile_wide = -1, host_plan = 0, wpt_off = 0;
+};
+const Force &force();
+// BT_PLAN_PROF: time per planner phase on stderr (measurement)
+bool plan_prof();
 // Tile counts from which the wave-per-tile kernels take a graph (k_edge, k_stream; the environment overrides are for
 // measurement and tests).  The planner lays out their tables only for plans that will use them.
 int edge_min_tiles();

@@ -16,7 +16,7 @@ from batrack_amd.plan import Plan  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-FORCED = any(v in os.environ for v in ("BT_ETILE", "BT_EDGE_MIN_TILES", "BT_STREAM_MIN_TILES", "BT_EDGE_OFF", "BT_TILE_TRACKS", "BT_PLAN_DEVICE", "BT_WPT_KERNELS"))
+FORCED = bool(os.environ.get("BT_FORCE"))         # (kernel / planner selection forced: the suites of test_gpu_jacobian_kernels.py)
 TABLES = ("pm_edge", "pm_rec", "pm_lb", "pm_la", "kx", "pair_i", "pair_j", "tile_trk0", "tile_ntrk", "tile_ncam", "tile_cams", "tile_pair0",
           "tile_npair", "tile_pairs", "tile_flags", "tile_ij", "tile_kx", "pp_ptr", "pp_idx", "sg_ptr", "col_ptr", "row_idx", "perm", "act_bits", "act_rank")
 

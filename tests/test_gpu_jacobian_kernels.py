@@ -11,6 +11,7 @@ import pytest
 
 import oracle
 from batrack_amd import graphgen
+import force
 from gpu_util import HipProblem, rel, update_err
 
 pytestmark = pytest.mark.gpu
@@ -18,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # gates (state, S and y, dX, update poses, update disparities) by the plan's precision of the per-edge maths: 8 float64, 6 mixed
-# (k_stream / k_edge: float64 reprojection and residual, float32 Jacobians), 4 float32 (BT_EDGE_PREC=0: measurement)
+# (k_stream / k_edge2: float64 reprojection and residual, float32 Jacobians), 4 float32 (BT_FORCE prec=f32: measurement)
 GATES = {8: (2e-7, 1e-10, 1e-5, 1e-5, 1e-5), 6: (2e-7, 1e-6, 1e-5, 1e-5, 1e-5), 4: (5e-6, 5e-6, 3e-4, 3e-4, 1e-4)}
 
 
@@ -74,7 +75,7 @@ def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, wpt):
         wave_per_tile_kernels(prev)
     assert o["plan"].jacobian_kernel == kernel, (o["plan"].jacobian_kernel, o["plan"].tiles)
     prec = o["plan"].edge_precision
-    assert prec == (4 if os.environ.get("BT_EDGE_PREC") == "0" and kernel == "k_tile" else 6 if kernel in ("k_stream", "k_edge2") else 8)
+    assert prec == (4 if force.tokens().get("prec") == "f32" and kernel == "k_tile" else 6 if kernel in ("k_stream", "k_edge2") else 8)
     act = np.unique(g.kk)
     t_state, t_sys, t_dx, t_upd_p, t_upd_d = GATES[prec]
     assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], act) < t_upd_d
@@ -87,7 +88,7 @@ def test_plan_selected_kernel_vs_oracle(frames, M, kernel, so, wpt):
         assert rel(o["poses_out"], ref["poses_out"]) < t_state
 
 
-@pytest.mark.skipif("BT_WPT_KERNELS" in os.environ, reason="the default of the setting is what the test starts from")
+@pytest.mark.skipif("wpt" in force.tokens(), reason="the default of the setting is what the test starts from")
 def test_the_kernel_choice_is_the_plans_own():
     """A plan keeps the layout it was built with: switching the setting afterwards changes neither its kernel nor its tables."""
     import torch
@@ -107,10 +108,8 @@ def test_the_kernel_choice_is_the_plans_own():
     assert wave_per_tile_kernels() is True
 
 
-FORCED = {"k_edge2": dict(BT_EDGE_MIN_TILES="1", BT_EDGE_PREF_TILES="1", BT_STREAM_MIN_TILES="1"),      # wherever the tiles are slot-uniform
-          "k_stream": dict(BT_EDGE_OFF="1", BT_STREAM_MIN_TILES="1"),
-          "k_tile": dict(BT_EDGE_OFF="1", BT_STREAM_MIN_TILES="100000000", BT_ETILE="0"),
-          "k_etile": dict(BT_EDGE_OFF="1", BT_STREAM_MIN_TILES="100000000", BT_ETILE="2")}       # the pair-major tile kernel for every plan
+# BT_FORCE kernel=...: k_edge2 wherever the tiles are slot-uniform (else k_stream), k_etile = the pair-major tile kernel for every plan
+FORCED = {k: dict(BT_FORCE=f"kernel={k}") for k in ("k_edge2", "k_stream", "k_tile", "k_etile")}
 
 
 @pytest.mark.parametrize("kernel", ["k_edge2", "k_stream", "k_tile", "k_etile"])

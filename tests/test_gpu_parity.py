@@ -10,7 +10,7 @@ inputs, so against the reference's float64 result
       poses' - poses over the free poses                <= 1e-5           (measured <= 1.3e-6; reference float32 8e-5 .. 6e-3)
       disparities' - disparities over the active tracks <= 1e-5           (measured <= 2.8e-7; reference float32 3e-6 .. 1.9e-3)
   state (poses', disparities')   <= 2e-7                                  (measured <= 2e-8: float32 rounding of the output)
-With the float32 per-edge kernels forced (k_stream / k_edge, or BT_EDGE_PREC=0) the round-2 gates apply (5e-6 state,
+With the float32 / mixed per-edge kernels forced (BT_FORCE kernel=k_stream / k_edge2, or prec=f32) the round-2 gates apply (5e-6 state,
 4e-6 system, 3e-4 / 1e-4 update)."""
 import os
 
@@ -697,12 +697,15 @@ def test_device_planned_window_plan_equals_the_host_planned_one():
     f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
     poses, patches, mono, intr, t3, w = f32(g.poses), f32(g.patches), f32(g.mono_disp), f32(g.intrinsics), f32(g.targets3), f32(g.weights_pose)
     outs = []
-    forced = any(v in os.environ for v in ("BT_ETILE", "BT_EDGE_MIN_TILES", "BT_STREAM_MIN_TILES", "BT_EDGE_OFF", "BT_TILE_TRACKS"))   # (the suites of test_gpu_jacobian_kernels.py)
+    import force as force_env
+    ft = force_env.tokens()
+    forced = "kernel" in ft                       # (the suites of test_gpu_jacobian_kernels.py)
+    host_plan = ft.get("plan") == "host"
     for on_dev in (True, False):
         idx = [torch.as_tensor(a, device=dev) for a in (g.ii, g.jj, g.kk)] if on_dev else [np.asarray(a) for a in (g.ii, g.jj, g.kk)]
         plan = Plan(*idx, poses.shape[0], patches.shape[0], fixedp)
         if not forced:
-            assert plan.jacobian_kernel == "k_etile" and plan.built_on_device == (on_dev and os.environ.get("BT_PLAN_DEVICE", "1") != "0")
+            assert plan.jacobian_kernel == "k_etile" and plan.built_on_device == (on_dev and not host_plan)
         st = Stepper(plan, dev)
         Po, Xo = torch.empty_like(poses), torch.empty_like(patches)
         st.step(poses, patches, mono, intr, t3, 3, w, Po, Xo, list(g.bounds), 1e-4, 10.0, 0.05, "huber", False)
@@ -716,4 +719,4 @@ def test_device_planned_window_plan_equals_the_host_planned_one():
     idx = [torch.as_tensor(a, device=dev) for a in (g2.ii, g2.jj, g2.kk)]
     p2 = Plan(*idx, g2.poses.shape[0], g2.patches.shape[0], fp2)
     ref = Plan(np.asarray(g2.ii), np.asarray(g2.jj), np.asarray(g2.kk), g2.poses.shape[0], g2.patches.shape[0], fp2, upload=False)
-    assert (forced or os.environ.get("BT_PLAN_DEVICE", "1") == "0" or p2.built_on_device) and (p2.tiles, p2.m, p2.pairs, p2.n) == (ref.tiles, ref.m, ref.pairs, ref.n)
+    assert (forced or host_plan or p2.built_on_device) and (p2.tiles, p2.m, p2.pairs, p2.n) == (ref.tiles, ref.m, ref.pairs, ref.n)

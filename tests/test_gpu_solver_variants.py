@@ -45,25 +45,26 @@ print("RESULT " + json.dumps(out))
 
 # (environment, tolerance on dX, tolerance on the new poses).  Float64 per-edge maths and a float64 factor in LDS: dX is
 # inside north_star's 1e-5 (measured 2.6e-8 — it is stored as float32).  The float variants of the solver factor in
-# float32 and refine once; BT_EDGE_PREC=0 is the float32 per-edge path of round 2 (the reference's own precision: its
+# float32 and refine once; BT_FORCE prec=f32 is the float32 per-edge path of round 2 (the reference's own precision: its
 # float32 run is 5e-3 off in dX on these fixtures).
 VARIANTS = [
-    ({}, 1e-5, 2e-7),
-    ({"BT_SOLVER_PIPE": "0"}, 1e-5, 2e-7),
-    ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0"}, 1e-5, 2e-7),
-    ({"BT_SOLVER_PIPE": "0", "BT_SOLVER_FUSED": "0", "BT_SOLVER_ORDER": "0"}, 1e-5, 2e-7),
-    ({"BT_EDGE_PREC": "0"}, 2e-3, 1e-5),                          # float32 per edge, 8 / 16 waves per tile as the plan picks
-    ({"BT_EDGE_PREC": "0", "BT_TILE_WIDE": "1"}, 2e-3, 1e-5),     # 16-wave float32 k_tile forced
-    ({"BT_EDGE_PREC": "0", "BT_TILE_WIDE": "0"}, 2e-3, 1e-5),
-    ({"BT_SOLVER_MODE": "1"}, 5e-5, 1e-6),
-    ({"BT_SOLVER_MODE": "2"}, 5e-5, 1e-6),
+    ((), 1e-5, 2e-7),
+    (("solver=fused",), 1e-5, 2e-7),                              # one workgroup barrier per level instead of flags
+    (("solver=lds",), 1e-5, 2e-7),                                # the two-phase k_solve_lds<double>
+    (("solver=lds", "order=natural"), 1e-5, 2e-7),
+    (("prec=f32",), 2e-3, 1e-5),                                  # float32 per edge, 8 / 16 waves per tile as the plan picks
+    (("prec=f32", "wide=1"), 2e-3, 1e-5),                         # 16-wave float32 k_tile forced
+    (("prec=f32", "wide=0"), 2e-3, 1e-5),
+    (("solver=lds32",), 5e-5, 1e-6),
+    (("solver=global",), 5e-5, 1e-6),
 ]
 
 
-@pytest.mark.parametrize("env,tol_dx,tol_pose", VARIANTS, ids=lambda v: "-".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else None)
+@pytest.mark.parametrize("env,tol_dx,tol_pose", VARIANTS, ids=lambda v: (",".join(v) or "default") if isinstance(v, tuple) else None)
 def test_solver_variant(env, tol_dx, tol_pose):
-    e = dict(os.environ, **env)
-    if e.get("BT_EDGE_PREC") == "0" or e.get("BT_STREAM_MIN_TILES") == "1" or e.get("BT_EDGE_MIN_TILES") == "1":
+    import force
+    e = force.env_with(*env)                      # (BT_FORCE tokens on top of whatever the suite already runs under)
+    if force.f32_edges(e):
         tol_dx, tol_pose = max(tol_dx, 2e-3), max(tol_pose, 1e-5)         # float32 per-edge maths (forced by the environment)
     r = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + SCRIPT], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

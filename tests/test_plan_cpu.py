@@ -344,14 +344,14 @@ print("PM_OK", pl.tiles)
 
 @pytest.mark.parametrize("kind", ["c1", "window", "random", "c3"])
 def test_pair_major_tables_cover_every_edge_once(kind):
-    """The pair-major layout of k_etile (ba_plan.cpp; BT_ETILE=2 builds it for every plan, read once per process): every edge
+    """The pair-major layout of k_etile (ba_plan.cpp; BT_FORCE kernel=k_etile builds it for every plan, read once per process): every edge
     of the list sits in exactly one (tile, iteration, round, lane); the lane's local pair is the edge's pair, its track the
     edge's track; pm_lb / pm_la are the local target / source cameras the track-major tables give the same edge; the number
     of rounds is the largest multiplicity of a (track, pair)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", PM_SCRIPT, kind], cwd=root, env=dict(os.environ, BT_ETILE="2", PYTHONPATH=root),
+    r = subprocess.run([sys.executable, "-c", PM_SCRIPT, kind], cwd=root, env=dict(os.environ, BT_FORCE="kernel=k_etile", PYTHONPATH=root),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PM_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

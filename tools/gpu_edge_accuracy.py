@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HIP step against the float64 oracle on generated graphs of the benchmark shape (slot-uniform tiles), through whichever
-Jacobian kernel the environment selects (BT_EDGE_MIN_TILES=1 forces k_edge, BT_EDGE_OFF=1 / BT_STREAM_MIN_TILES pick the
+Jacobian kernel the environment selects (BT_FORCE=kernel=k_edge2 forces k_edge2, kernel=k_stream / k_tile pick the
 others): reduced system, camera update and the state update.  GPU box:  python tools/gpu_edge_accuracy.py [M ...]"""
 import os, sys
 import numpy as np

@@ -24,7 +24,7 @@ pmc() {     # counter, tag, M  (environment of the caller selects the kernels)
 # sources: the JSON carries their hash)
 if [ "${1:-all}" = "pmc" ]; then
     : > $OUT/pmc_fetch_write.txt
-    for C in FETCH_SIZE WRITE_SIZE; do pmc $C c3 256; pmc $C e8m 16384; BT_WPT_KERNELS=0 pmc $C e8mf64 16384; done
+    for C in FETCH_SIZE WRITE_SIZE; do pmc $C c3 256; pmc $C e8m 16384; BT_FORCE=wpt=0 pmc $C e8mf64 16384; done
     python $R/tools/pmc_to_json.py $OUT/pmc_k_tile.json \
         C3:131072:16384:64:/tmp/pmc_FETCH_SIZE_c3.db:/tmp/pmc_WRITE_SIZE_c3.db \
         E8M:8388608:1048576:64:/tmp/pmc_FETCH_SIZE_e8m.db:/tmp/pmc_WRITE_SIZE_e8m.db \
@@ -37,12 +37,12 @@ trace c3 python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-large
 trace window python $R/tools/gpu_timing.py --workload window
 trace e2m python $R/tools/gpu_pmc_run.py 4096 6
 trace e8m python $R/tools/gpu_pmc_run.py 16384 6
-BT_WPT_KERNELS=0 trace e8m_f64tile python $R/tools/gpu_pmc_run.py 16384 6
+BT_FORCE=wpt=0 trace e8m_f64tile python $R/tools/gpu_pmc_run.py 16384 6
 trace ga python $R/tools/gpu_ga_bench.py
 # ---- HBM traffic of the Jacobian kernel: C3 (k_tile, float64) and 8.4M edges (k_edge2, mixed precision: the default there; and the
 # float64 tile kernel the caller can have instead)
 : > $OUT/pmc_fetch_write.txt
-for C in FETCH_SIZE WRITE_SIZE; do pmc $C c3 256; pmc $C e8m 16384; BT_WPT_KERNELS=0 pmc $C e8mf64 16384; done
+for C in FETCH_SIZE WRITE_SIZE; do pmc $C c3 256; pmc $C e8m 16384; BT_FORCE=wpt=0 pmc $C e8mf64 16384; done
 # the same counters with L2 and MALL flushed between the steps (a 512 MB sweep: BT_PMC_COLD=1), and the kernel times warm / cold
 echo "# ---- cold: a 512 MB sweep between the steps (BT_PMC_COLD=1)" >> $OUT/pmc_fetch_write.txt
 for C in FETCH_SIZE WRITE_SIZE; do BT_PMC_COLD=1 pmc $C c3cold 256; BT_PMC_COLD=1 pmc $C e8mcold 16384; done
@@ -66,16 +66,16 @@ $R/tools/gpu_pmc_sq.sh 16384 $OUT/pmc_sq_e8m.txt > /dev/null 2>&1
 cd $R
 # ---- the edge sweep in both precisions (the roofline table of DESIGN.md §6)
 (echo "# default: k_tile (float64 per edge) below 2048 tiles, k_stream / k_edge (mixed precision) from there: every row inside the 1e-5 bar on the update"; python tools/gpu_sweep.py 256 1024 4096 16384 32768;
- echo "# BT_WPT_KERNELS=0: the float64 tile kernel at every size"; BT_WPT_KERNELS=0 python tools/gpu_sweep.py 4096 16384 32768) > $OUT/edge_sweep.txt 2>&1
+ echo "# BT_FORCE=wpt=0: the float64 tile kernel at every size"; BT_FORCE=wpt=0 python tools/gpu_sweep.py 4096 16384 32768) > $OUT/edge_sweep.txt 2>&1
 # ---- solver: k_solve_pipe with its in-kernel cycle counters (k_solve_chain, round 4's equal-time alternative, is deleted)
 (for w in C3 window; do python tools/gpu_timing.py --workload $w; done;
- BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver"; BT_SOLVER_PIPE=0 BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver";
+ BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver"; BT_FORCE=solver=fused BT_DEBUG_MODE=16 python tools/gpu_timing.py | grep -A2 "solver";
  BT_DEBUG_MODE=16 python tools/gpu_timing.py --workload window | grep -A2 "solver") > $OUT/solver_variants.txt 2>&1
 # ---- k_edge2 forced from 2048 tiles on (default: from 4096), and the window kernel with one / two rounds per trip
 # (profiles/r05_edge2_vs_edge.txt also holds round 4's k_edge on the same graphs: measured before its pose+structure
 #  instantiation was removed, at the commit named in the file)
-(echo "# k_edge2 forced from 2048 tiles on (BT_EDGE_PREF_TILES=1 BT_EDGE_MIN_TILES=1)"; BT_EDGE_PREF_TILES=1 BT_EDGE_MIN_TILES=1 python tools/gpu_sweep.py 2048 4096 8192 16384 32768) 2>&1 | cut -c1-330 > $OUT/edge2_forced.txt
-(python tools/gpu_timing.py --workload window; BT_ETILE_TWO=0 python tools/gpu_timing.py --workload window) > $OUT/window_rounds_per_trip.txt 2>&1
+(echo "# k_edge2 forced from 2048 tiles on (BT_FORCE=kernel=k_edge2)"; BT_FORCE=kernel=k_edge2 python tools/gpu_sweep.py 2048 4096 8192 16384 32768) 2>&1 | cut -c1-330 > $OUT/edge2_forced.txt
+(python tools/gpu_timing.py --workload window) > $OUT/window_rounds_per_trip.txt 2>&1
 python tools/gpu_spec_time.py > $OUT/plan_call_host_time.txt 2>&1
 python tests/sequence_report.py > $OUT/sequence_ate.txt 2>&1
 (echo "# 200 frames, steady state of the window"; python tests/sequence_report.py --frames 200 --skip-oracle) >> $OUT/sequence_ate.txt 2>&1
@@ -84,8 +84,8 @@ python tools/gpu_check.py > $OUT/parity_numbers.txt 2>&1
 python tools/gpu_refine_check.py >> $OUT/parity_numbers.txt 2>&1
 python tools/gpu_edge_accuracy.py 64 256 >> $OUT/parity_numbers.txt 2>&1
 (echo "# graphs of 2048 .. 8192 tiles, default (k_stream / k_edge, mixed precision)"; python tools/gpu_edge_accuracy.py 2048 8192;
- echo "# the same with the float64 tile kernel (BT_WPT_KERNELS=0)"; BT_WPT_KERNELS=0 python tools/gpu_edge_accuracy.py 2048 8192) >> $OUT/parity_numbers.txt 2>&1
-(for w in C3 window; do python tools/gpu_timing.py --workload $w; BT_EDGE_PREC=0 BT_ETILE=0 python tools/gpu_timing.py --workload $w; BT_ETILE=0 python tools/gpu_timing.py --workload $w; done) > $OUT/timing_variants.txt 2>&1
+ echo "# the same with the float64 tile kernel (BT_FORCE=wpt=0)"; BT_FORCE=wpt=0 python tools/gpu_edge_accuracy.py 2048 8192) >> $OUT/parity_numbers.txt 2>&1
+(for w in C3 window; do python tools/gpu_timing.py --workload $w; BT_FORCE=kernel=k_tile,prec=f32 python tools/gpu_timing.py --workload $w; BT_FORCE=kernel=k_tile python tools/gpu_timing.py --workload $w; done) > $OUT/timing_variants.txt 2>&1
 python tools/gpu_ga_bench.py > $OUT/global_refine_losses.txt 2>&1
 # ---- N > 1 plumbing on the one GPU (ranks share it; gloo rendezvous): not a scaling measurement
 for n in 2 4 8; do

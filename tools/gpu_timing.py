@@ -57,11 +57,12 @@ if int(os.environ.get("BT_DEBUG_MODE", "0")) & 16:
     names = ["load", "updates", "chol", "trsm", "store", "barrier", "Mprep", "backsub", "tail", "-"]
     ph = np.frombuffer(raw[stat_off + 16 + 320: stat_off + 16 + 320 + 16 * 12].tobytes(), dtype=np.int64).reshape(12, 2)
     print("  solver per-wave busy cycles (phase1, phase2): " + " ".join(f"w{w}:{a}/{b}" for w, (a, b) in enumerate(ph)))
-    if os.environ.get("BT_SOLVER_PIPE", "1") != "0":
+    forced_solver = dict(t.partition("=")[::2] for t in os.environ.get("BT_FORCE", "").split(",") if t).get("solver")
+    if forced_solver is None:
         g = pf.reshape(-1)
         print("  pipe solver per-wave (waiting, working) cycles: " + " ".join(f"w{w}:{a}/{b}" for w, (a, b) in enumerate(ph)))
         print(f"  pipe solver: load={g[0]} sweep_end={g[1]} total={g[2]} | row wave 2: row_update={g[13]} wait_diag={g[14]} chol+trsm={g[15]} waits_at_level_start={g[16]} (for a column {g[17]}, for the helpers {g[18]}) | diagonal wave 0: waits for a column {g[7]}, for the helpers {g[8]}")
-    elif os.environ.get("BT_SOLVER_FUSED", "1") != "0":
+    elif forced_solver == "fused":
         g = pf.reshape(-1)
         print(f"  fused solver: load={g[0]} sweep_end={g[1]} total={g[2]} | tail: Linv_end={g[3]} Mform_end={g[4]} backsub_end={g[5]} | row wave: row_update={g[16]} wait+load+chol={g[17]} trsm+store={g[18]}")
     for w in range(2):
