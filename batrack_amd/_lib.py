@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("BT_LIB_PATH") or os.path.join(_HERE, "lib", "libbatrack_ba.so")   # BT_LIB_PATH: measurement builds only
 SOURCES = ["ba_kernels.hip", "ba_etile.hip", "ba_stream.hip", "ba_edge2.hip", "ba_edge2u.hip", "ba_dense.hip", "ba_loose.hip", "plan_pack.hip", "plan_device.hip", "ba_plan.cpp", "ba_api.cpp", "se3_kernels.hip", "patchify_kernels.hip", "projective_kernels.hip", "ga_kernels.hip"]
-HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", "ba_edge.hpp", "ba_update.hpp", "dev_cache.hpp", "ba_edge2.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
+HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", "ba_edge.hpp", "ba_update.hpp", "dev_cache.hpp", "ba_edge2.hpp", "probe.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
            os.path.join("..", "..", "include", "batrack_se3.h"), os.path.join("..", "..", "include", "batrack_patchify.h"),
            os.path.join("..", "..", "include", "batrack_projective.h"), os.path.join("..", "..", "include", "batrack_ga.h")]
 # -fno-slp-vectorize: packed f32 pairs cost more register moves than the packed instructions save (measured on k_edge)

@@ -33,6 +33,7 @@
 
 #include "ba_edge2.hpp"
 #include "dev_cache.hpp"
+#include "probe.hpp"
 
 namespace bt {
 namespace e2 {
@@ -132,13 +133,7 @@ __device__ __forceinline__ void schur_rows(const float *Eh, const float *Qs, con
     }
 }
 
-// -DBT_E2_PROF (measurement builds, tools/build_variant.sh): cycle counters between the phases of a step, written behind the
-// status words for tools/gpu_sweep.py (BT_DEBUG_MODE=64 prints them); every probe waits for the LDS and fences the scheduler
-#ifdef BT_E2_PROF
-#define BT_E2_PF(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pf_n = clock64(); pf[i] += pf_n - pf_c; pf_c = pf_n; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define BT_E2_PF(i) do { } while (0)
-#endif
+// (BT_E2_PF(i), BT_PROBE_E2_*: measurement hooks, empty in the product build — probe.hpp)
 
 
 // LGS: log2 of the slots per track when every tile of the plan has the same (straight-line lane-group reductions, E rows of
@@ -204,13 +199,7 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
 #endif
     const bool has_work = gwt * tiles_per_wave < pd.T;
     const int t_begin = has_work ? gwt * tiles_per_wave : 0, t_end = has_work ? min(pd.T, t_begin + tiles_per_wave) : 0;
-#ifdef BT_E2_PROF
-    long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_c = clock64(), pf_n;
-#endif
-#ifdef BT_E2_TIMES        /* measurement (tools/gpu_wave_times.py): every wave's start, end of its tiles and end, 100 MHz clock, into patches_out */
-    const long long wt0 = wall_clock64();
-    long long wt1 = 0;
-#endif
+    BT_PROBE_E2_DECL();
 
     // E Q E^T since the last flush lives in LDS, as float64 (schur_rows); E (Q w') of the current tile in float32 registers,
     // added to float64 sums in LDS at the tile's end
@@ -696,9 +685,7 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
             px = px_n; py = py_n; pdisp = pd_n; mono_v = mono_n; lm_v = lm_n;
         }
     }
-#ifdef BT_E2_TIMES
-    wt1 = wall_clock64();
-#endif
+    BT_PROBE_E2_TILES_DONE();
     // ---- the end: the workgroup's waves add up what they hold, then the roots of the tree issue the atomics (see the top)
     {
         const int S_p = 1 << pa_lgS;
@@ -761,24 +748,7 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
             }
         }
     }
-#ifdef BT_E2_TIMES
-    if (lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long *o = reinterpret_cast<long long *>(a.patches_out) + 4 * (size_t)gw;
-        o[0] = wt0; o[1] = wt1; o[2] = wall_clock64(); o[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) /* HW_ID */ | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) /* XCC_ID */ << 32);
-    }
-#endif
-#ifdef BT_E2_PROF
-    BT_E2_PF(8);
-    if (lane == 0 && (gw == 0 || gw == (int)(gridDim.x * nwv) / 2)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        BT_E2_PF(9);
-        long long *o = reinterpret_cast<long long *>(a.status + 4) + (gw == 0 ? 20 : 40);
-        for (int i = 0; i < 10; ++i) o[i] = pf[i];
-        o[10] = t_end - t_begin;
-        o[11] = pf[10]; o[12] = pf[11]; o[13] = pf[12];
-    }
-#endif
+    BT_PROBE_E2_END(gw, (int)(gridDim.x * nwv));
 }
 #undef BT_DPPF
 

@@ -26,6 +26,7 @@
 #include "ba_edge.hpp"
 #include "ba_kernels.hpp"
 #include "dev_cache.hpp"
+#include "probe.hpp"
 #include "ba_update.hpp"
 
 namespace bt {
@@ -123,9 +124,7 @@ __global__ __launch_bounds__(kEtThreads, TWO ? 1 : 2) void k_etile(PlanDev pd, S
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     typedef typename Vec2<R>::type R2;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-#ifdef BT_ET_TIMES        /* measurement (tools/gpu_wave_times_window.py): a wave's 100 MHz clock at its start, after the prologue, its rounds, the merge, its end */
-    long long wt[5] = {(long long)wall_clock64(), 0, 0, 0, 0};
-#endif
+    BT_PROBE_ET_DECL();           // (measurement hooks: probe.hpp, tools/probes/wave_times.hpp)
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); tn = clock64(); pf[i] += tn - tc; tc = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
     constexpr int GS = MODE == kEtUpd ? kEtGeoUpd : kPairGeomFloats;
@@ -239,9 +238,7 @@ __global__ __launch_bounds__(kEtThreads, TWO ? 1 : 2) void k_etile(PlanDev pd, S
     gather(e_cur, tu_c, tv_c, w0_c, w1_c);
     __syncthreads();
     BT_PF(0);
-#ifdef BT_ET_TIMES
-    wt[1] = (long long)wall_clock64();
-#endif
+    BT_PROBE_ET_MARK(1);
 
     // this lane's pair: the same for the whole tile
     R g[GS];
@@ -435,9 +432,7 @@ __global__ __launch_bounds__(kEtThreads, TWO ? 1 : 2) void k_etile(PlanDev pd, S
         }
     }
     BT_PF(1);
-#ifdef BT_ET_TIMES
-    wt[2] = (long long)wall_clock64();
-#endif
+    BT_PROBE_ET_MARK(2);
     if (MODE != kEtFull) return;
 
     // ---- the lanes' pair sums: over the lanes with the same pair, then lane s (< S) adds them to the workgroup's float64 sums
@@ -458,9 +453,7 @@ __global__ __launch_bounds__(kEtThreads, TWO ? 1 : 2) void k_etile(PlanDev pd, S
     }
     __syncthreads();
     BT_PF(2);
-#ifdef BT_ET_TIMES
-    wt[3] = (long long)wall_clock64();
-#endif
+    BT_PROBE_ET_MARK(3);
 
     // per-pair sums of the tile -> the workspace (k_pair_finalize turns them into B and v): atomics, or — sp_ok, where many
     // tiles share each pair — stored per tile for k_pair_finalize to add up
@@ -557,15 +550,7 @@ __global__ __launch_bounds__(kEtThreads, TWO ? 1 : 2) void k_etile(PlanDev pd, S
         }
     }
     BT_PF(3);
-#ifdef BT_ET_TIMES
-    if (MODE == kEtFull && lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wt[4] = (long long)wall_clock64();
-        long long *o = reinterpret_cast<long long *>(a.patches_out) + 8 * ((size_t)blockIdx.x * kEtWaves + wave);
-        for (int i = 0; i < 5; ++i) o[i] = wt[i];
-        o[5] = ((long long)ntrk << 32) | (long long)(D << 8 | nit);
-    }
-#endif
+    BT_PROBE_ET_END(MODE == kEtFull, lane, wave, ((long long)ntrk << 32) | (long long)(D << 8 | nit));
     if (PROF && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BT_PF(4);

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "ba_kernels.hpp"
+#include "probe.hpp"
 #include "ba_edge.hpp"
 #include "ba_update.hpp"
 
@@ -79,12 +80,8 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? BT_
     const int nthr = blockDim.x, kTileWaves = nthr >> 6;          // 8 or 16 waves per tile (launch parameter)
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = PROF ? clock64() : 0, tn;
 #define BT_PF(i) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); tn = clock64(); pf[i] += tn - tc; tc = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
-#ifdef BT_TILE_TIMES      /* measurement (tools/gpu_wave_times_tile.py): a wave's 100 MHz clock at its start, after the prologue, its slots, the merge + Q, the Schur product, its end */
-    long long wt[6] = {(long long)wall_clock64(), 0, 0, 0, 0, 0};
-#define BT_WT(i) wt[i] = (long long)wall_clock64()
-#else
-#define BT_WT(i) do { } while (0)
-#endif
+    BT_PROBE_TILE_DECL();         // (measurement hooks: probe.hpp, tools/probes/wave_times.hpp)
+#define BT_WT(i) BT_PROBE_TILE_MARK(i)
     // LDS carve-up for the largest tile of the plan (fixed offsets: tiles of one workgroup differ in size)
     const int R16max = SO ? 0 : pd.max_rows16;
     R *Eh = lds, *stg = Eh + R16max * kLdsRowStride;
@@ -407,14 +404,7 @@ __global__ __launch_bounds__(WIDE ? 1024 : 512, WIDE ? 2 : (sizeof(R) == 8 ? BT_
         flush_pair();
         BT_PF(7);
     }
-#ifdef BT_TILE_TIMES
-    if (!SO && !FUSE && lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        BT_WT(5);
-        long long *o = reinterpret_cast<long long *>(a.patches_out) + 8 * ((size_t)blockIdx.x * kTileWaves + wave);
-        for (int i = 0; i < 6; ++i) o[i] = wt[i];
-    }
-#endif
+    BT_PROBE_TILE_END(!SO && !FUSE, lane, wave, kTileWaves);
 #undef BT_WT
     if (PROF && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -45,7 +45,7 @@ for M in [int(x) for x in (sys.argv[1:] or ["256", "1024", "4096", "16384"])]:
     print(f"E={plan.E:9d} tracks={plan.m:8d} tiles={plan.tiles:6d} plan={plan_ms:8.1f}ms | " +
           " ".join(f"{n}={v:9.2f}us" for n, v in med.items()) + f" step={wall:8.1f}us {plan.jacobian_kernel}" +
           f" | k_tile: {alg/1e6:8.2f} MB algorithmic -> {alg/med['tile']/1e3:8.1f} GB/s = {alg/med['tile']/1e3/8000*100:5.2f}% of 8 TB/s, {plan.E/med['tile']:.0f} edges/us", flush=True)
-    if int(os.environ.get("BT_DEBUG_MODE", "0")) & 64:          # a -DBT_E2_PROF build of k_edge2 (tools/build_variant.sh)
+    if int(os.environ.get("BT_DEBUG_MODE", "0")) & 64:          # an edge2_phases build of k_edge2 (tools/probes/edge2_phases.hpp, tools/build_variant.sh)
         torch.cuda.synchronize()
         off = (st._lib.bt_ba_dx(plan.handle, st.ws.data_ptr()) - st.ws.data_ptr())
         raw = st.ws.cpu().numpy()

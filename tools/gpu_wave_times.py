@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""When do the waves of k_edge2 start and end?  A -DBT_E2_TIMES build (tools/build_variant.sh, BT_LIB_PATH) makes every wave write
+"""When do the waves of k_edge2 start and end?  A wave-times build (tools/build_variant.sh times ba_edge2.hip -DBT_PROBE_HEADER='"../../tools/probes/wave_times.hpp"', BT_LIB_PATH) makes every wave write
 its start, the end of its tiles and its end (100 MHz clock) into patches_out; this runs the reduce phase of a step on the
 benchmark generator's graph (M tracks per frame) and prints the distribution relative to the first start."""
 import os, sys

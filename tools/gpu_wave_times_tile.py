@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""When do the waves of k_tile reach its phases (C3: 256 tiles, one per CU)?  A -DBT_TILE_TIMES build of ba_kernels.hip
+"""When do the waves of k_tile reach its phases (C3: 256 tiles, one per CU)?  A wave-times build (-DBT_PROBE_HEADER='"../../tools/probes/wave_times.hpp"') of ba_kernels.hip
 (tools/build_variant.sh, BT_LIB_PATH) makes every wave write its 100 MHz clock at its start, after the prologue, after its slots,
 after the merge + Q, after the Schur product and at its end into patches_out; this runs the reduce phase of a C3 step."""
 import os, sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""When do the waves of k_etile (the sliding window's Jacobian kernel) start and end?  A -DBT_ET_TIMES build (tools/build_variant.sh,
+"""When do the waves of k_etile (the sliding window's Jacobian kernel) start and end?  A wave-times build (-DBT_PROBE_HEADER='"../../tools/probes/wave_times.hpp"'; tools/build_variant.sh,
 BT_LIB_PATH) makes every wave write its 100 MHz clock at its start, after the prologue, after its rounds, after the pair-sum merge
 and at its end into patches_out; this runs the reduce phase of a step on the real-shape window graph."""
 import os, sys
