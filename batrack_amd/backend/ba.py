@@ -159,6 +159,21 @@ def _confirm(stepper):
     return ok
 
 
+def _print_residual(poses, patches, intrinsics, targets_2d, ii, jj, kk, bounds):
+    """What the reference prints under PRINT=True (ba.py:244-245): the mean over the edges of |v * r|, r = target - reprojection,
+    v = Z > 0.2 and |r| < 250 and inside the bounds (ba.py:228-242) — a debugging aid, computed beside the step (the fused
+    reprojection kernel, include/batrack_projective.h) and synchronising like the reference's .item()."""
+    from . import projective_ops as pops
+    coords, v = pops.transform(poses, patches, intrinsics, ii, jj, kk, valid=True)
+    p = coords.shape[3]
+    c = coords[..., p // 2, p // 2, :]
+    r = targets_2d - c
+    v = (v[..., p // 2, p // 2] if v.dim() == 4 else v).reshape(r.shape[:-1]).float()
+    v = v * (r.norm(dim=-1) < 250).float()
+    v = v * ((c[..., 0] > bounds[0]) & (c[..., 1] > bounds[1]) & (c[..., 0] < bounds[2]) & (c[..., 1] < bounds[3])).float()
+    print((r * v[..., None]).norm(dim=-1).mean().item())
+
+
 def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True):
     """Build the plan of an edge list ahead of the BA calls that will use it.
 
@@ -287,7 +302,7 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
                                                        targets_2d, weights, [float(b) for b in bounds], float(lmbda), float(ep),
                                                        float(alpha), _lib.LOSS[loss], so, lm_trk)
         if PRINT:
-            print("BA_rgbd_droid: PRINT is not implemented in batrack_amd (debug only, ba.py:244-245)")
+            _print_residual(poses, patches, intrinsics, targets_2d, ii, jj, kk, bounds)
         if stepper.plan.__dict__.get("speculative") and not _confirm(stepper):
             # the list was no shifted copy after all: what was just enqueued is void (the inputs are untouched) — once more, properly
             return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda_in, ii, jj, kk, bounds,
@@ -317,7 +332,7 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     stepper.step(Pc, pat, mono, intr, tg, tg.stride(0), w, poses_out, patches_out,
                  bounds, lmbda, ep, alpha, loss, so, lmbda_per_track=lm_trk)
     if PRINT:
-        print("BA_rgbd_droid: PRINT is not implemented in batrack_amd (debug only, ba.py:244-245)")
+        _print_residual(poses, patches, intrinsics, targets_2d, ii, jj, kk, bounds)
     if stepper.plan.__dict__.get("speculative") and not _confirm(stepper):
         return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda_in, ii, jj, kk, bounds,
                              ep=ep, PRINT=False, fixedp=fixedp, structure_only=structure_only, loss=loss, alpha=alpha)

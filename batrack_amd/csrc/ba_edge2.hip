@@ -456,7 +456,11 @@ __global__ __launch_bounds__(512, 1) void k_edge2(PlanDev pd, StepArgs a, int ti
             constexpr int P = decltype(pc)::value;
 #ifndef BT_E2_NO_PRIO
             // (see "wave priority" at the top; slices of the CU's clock, so that exactly one of a SIMD's two waves is raised at any time)
-            if ((((unsigned)clock64() >> BT_E2_PRIO_SHIFT) & 1u) ^ (unsigned)rank_s) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            // (BT_E2_PRIO_YOUNG eighths of the time to the wave that arrived second on its SIMD, the rest to the first)
+            {
+                const unsigned ph = ((unsigned)clock64() >> (BT_E2_PRIO_SHIFT - 2)) & 7u;
+                if (rank_s ? ph < BT_E2_PRIO_YOUNG : ph >= BT_E2_PRIO_YOUNG) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
 #endif
             const f2 tu = tu_q[P], tv = tv_q[P];
             const int fl = fl_q[P];

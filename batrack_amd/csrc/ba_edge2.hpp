@@ -14,6 +14,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef BT_E2_PRIO_SHIFT
 #define BT_E2_PRIO_SHIFT 13        // log2 of the priority slice in shader clocks
 #endif
+#ifndef BT_E2_PRIO_YOUNG
+#define BT_E2_PRIO_YOUNG 4         // eighths of a priority period in which the SIMD's SECOND wave is the raised one
+#endif
 #ifndef BT_E2_SB
 #define BT_E2_SB __builtin_amdgcn_sched_barrier(0)
 #endif

@@ -1384,6 +1384,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     if (!pm_direct) {
         const int pm_env = etile_mode();                            // 0: k_tile forced
         if (!pm_env || (pm_env != 2 && tcap == kLanes)) pl->pm_ok = 0;      // (tables only for the plans that will use them)
+        if (!loose.empty()) pl->pm_ok = 0;                                   // (k_etile's stored per-tile sums bypass the accumulators the loose tracks add to)
         for (int64_t t = 0; t < I.tiles && pl->pm_ok; ++t) if (pl->tile_npair[(size_t)t] > kLanes) pl->pm_ok = 0;
         if (pl->pm_ok) {
             pl->pm_rec.assign((size_t)I.tiles * 4, 0);

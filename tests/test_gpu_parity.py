@@ -399,8 +399,8 @@ def test_more_than_255_free_poses_vs_oracle(frames):
     assert o["plan"].n == n and o["plan"].nnz_blocks == n * (n + 1) // 2 and o["status"] == 0
     assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-5) and rel(o["y"], ref["y"]) < tol(1e-10, 2e-5)
     assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < DX_TOL
-    assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(1, frames)) < 1e-5
-    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], np.unique(g.kk)) < 1e-5
+    assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(1, frames)) < UPD_POSE_TOL
+    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], np.unique(g.kk)) < UPD_DISP_TOL
     assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL and rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
     # the reference's entry point, two chained dual iterations (batrack.py:869-875) against the oracle's
     P, X = hp.api_step("weights_pose", 1, False)
@@ -580,22 +580,39 @@ def test_hub_tracks_seen_by_a_hundred_cameras_vs_oracle(frames, hubs):
     loc = o["plan"].array("trk_loc")
     kx = o["plan"].array("kx")
     assert sorted(kx[loc < 0]) == sorted(hub_tracks)          # the hubs sit in no tile
-    assert o["plan"].edge_precision == 8
-    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < 1e-10 and rel(o["y"], ref["y"]) < 1e-10
+    assert F32_EDGE or o["plan"].edge_precision == 8
+    assert rel(np.tril(o["S_lower"]), np.tril(ref["S"])) < tol(1e-10, 2e-5) and rel(o["y"], ref["y"]) < tol(1e-10, 2e-5)
     assert rel(o["dX"].reshape(-1), ref["dX"].reshape(-1)) < DX_TOL
-    assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(1, frames)) < 1e-5
-    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], np.unique(kk)) < 1e-5
+    assert update_err(o["poses_out"], ref["poses_out"], d["poses"], np.arange(1, frames)) < UPD_POSE_TOL
+    assert update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2], np.unique(kk)) < UPD_DISP_TOL
     assert rel(o["poses_out"], ref["poses_out"]) < STATE_TOL and rel(o["patches_out"], ref["patches_out"]) < STATE_TOL
     # structure-only, and both through the reference's entry point
     ref_so = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d["weights"],
                             d["ii"], d["jj"], d["kk"], d["bounds"], fixedp=1, structure_only=True)
     o_so = hp.raw_step("weights", 1, True)
-    assert update_err(o_so["patches_out"][:, 2], ref_so["patches_out"][:, 2], d["patches"][:, 2], np.unique(kk)) < 1e-5
+    assert update_err(o_so["patches_out"][:, 2], ref_so["patches_out"][:, 2], d["patches"][:, 2], np.unique(kk)) < UPD_DISP_TOL
     P, X = hp.api_step("weights_pose", 1, False)
     assert rel(P.data[0].cpu().numpy().astype(np.float64), ref["poses_out"]) < STATE_TOL
     assert rel(X[0, :, :, 0, 0].cpu().numpy().astype(np.float64), ref["patches_out"]) < STATE_TOL
     P2, X2 = hp.api_step("weights", 1, True)
     assert rel(X2[0, :, :, 0, 0].cpu().numpy().astype(np.float64), ref_so["patches_out"]) < STATE_TOL
+
+
+def test_print_reports_the_mean_masked_residual(capsys):
+    """PRINT=True (ba.py:244-245) prints the mean over the edges of |v r| — r masked by Z > 0.2, |r| < 250 and the bounds — before the
+    robust weights; the oracle's per-edge residual is that masked r."""
+    d = load("c1_rough")
+    hp = HipProblem(d)
+    from batrack_amd.backend.ba import BA_rgbd_droid
+    from batrack_amd.backend.lietorch import SE3
+    capsys.readouterr()
+    BA_rgbd_droid(SE3(hp.poses), hp.patches, hp.mono, hp.intr, hp.t3[..., :2], hp.t3[..., 2:], hp.w["weights_pose"], 1e-4,
+                  hp.ii, hp.jj, hp.kk, hp.bounds, ep=10.0, PRINT=True, fixedp=1, loss="huber", alpha=0.05)
+    torch.cuda.synchronize()
+    out = capsys.readouterr().out.strip().splitlines()
+    e = oracle.edges(d["poses"], d["patches"], d["intrinsics"], d["targets3"], d["weights_pose"], d["ii"], d["jj"], d["kk"], d["bounds"])
+    want = float(np.linalg.norm(e["r"], axis=1).mean())
+    assert len(out) == 1 and abs(float(out[0]) - want) < 1e-4 * max(want, 1.0), (out, want)
 
 
 def test_nan_in_solution_retries_with_larger_damping():
