@@ -1,11 +1,11 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): rocprofv3 kernel traces and PMC passes of the round, summaries under gpurun_out/prof_r05/
-# (copied into profiles/r05_* afterwards).  PMC passes are their own runs with --kernel-trace only (no other trace domain
+# Runs on the GPU box (gpurun): rocprofv3 kernel traces and PMC passes of the round, summaries under gpurun_out/prof_r06/
+# (copied into profiles/r06_* afterwards).  PMC passes are their own runs with --kernel-trace only (no other trace domain
 # beside --pmc).  profiles/pmc_k_tile.json is rewritten from the FETCH_SIZE / WRITE_SIZE passes of THIS build
 # (tools/pmc_to_json.py: it carries the hash of the kernel sources; bench.py refuses it when the sources change).
 set -u
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r05
+OUT=$R/gpurun_out/prof_r06
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 trace() {   # name, command...
@@ -34,6 +34,15 @@ fi
 # ---- headline bench first (fresh clocks), then the traces
 python $R/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.stderr
 trace c3 python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-large
+# `tools/gpu_profile_round.sh quick`: the bench line, the two traces the roofline figures rest on, the edge and ragged sweeps
+if [ "${1:-all}" = "quick" ]; then
+    trace e8m python $R/tools/gpu_pmc_run.py 16384 6
+    cd $R
+    python tools/gpu_sweep.py 256 4096 16384 32768 > $OUT/edge_sweep.txt 2>&1
+    python tools/gpu_ragged_sweep.py > $OUT/ragged_graphs.txt 2>&1
+    ls -la $OUT
+    exit 0
+fi
 trace window python $R/tools/gpu_timing.py --workload window
 trace e2m python $R/tools/gpu_pmc_run.py 4096 6
 trace e8m python $R/tools/gpu_pmc_run.py 16384 6
@@ -87,6 +96,7 @@ python tools/gpu_edge_accuracy.py 64 256 >> $OUT/parity_numbers.txt 2>&1
  echo "# the same with the float64 tile kernel (BT_FORCE=wpt=0)"; BT_FORCE=wpt=0 python tools/gpu_edge_accuracy.py 2048 8192) >> $OUT/parity_numbers.txt 2>&1
 (for w in C3 window; do python tools/gpu_timing.py --workload $w; BT_FORCE=kernel=k_tile,prec=f32 python tools/gpu_timing.py --workload $w; BT_FORCE=kernel=k_tile python tools/gpu_timing.py --workload $w; done) > $OUT/timing_variants.txt 2>&1
 python tools/gpu_ga_bench.py > $OUT/global_refine_losses.txt 2>&1
+python tools/gpu_ragged_sweep.py > $OUT/ragged_graphs.txt 2>&1
 # ---- N > 1 plumbing on the one GPU (ranks share it; gloo rendezvous): not a scaling measurement
 for n in 2 4 8; do
   BT_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29820 + n)) bench.py --gpus $n --steps 50 --warmup 5 2> $OUT/bench_plumbing_n$n.stderr | tail -1 > $OUT/bench_plumbing_n$n.json
