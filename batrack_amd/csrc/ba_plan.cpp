@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <unordered_map>
 
 namespace bt {
 
@@ -175,8 +176,12 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // around the first target seen: a track's observations span a window of frames, batrack.py:399-410)
     // (mask, mask2: target frames base + b and base + 64 + b, base = the source frame - 64: 128 bits around the source frame, in the
     //  host's own pass as in the device's table)
-    // (rmask, rmask2: the targets the track observes more than once — the aligned slot layout below)
-    struct PerPatch { int32_t cnt, src, base, last_j; uint64_t mask, mask2, rmask, rmask2; };
+    // (32 bytes a patch: the passes below stream a million of these.  The targets a track observes MORE THAN ONCE — the aligned
+    //  slot layout's multiplicities — are kept aside, looked up only for the tracks whose count exceeds their distinct targets:
+    //  the device's table where it gathered them, a map filled by the host's own pass)
+    struct PerPatch { int32_t cnt, src, base, last_j; uint64_t mask, mask2; };
+    static thread_local std::unordered_map<int64_t, RepStat> rep_host;
+    rep_host.clear();
 #define BT_FOR_TARGETS(T_, fr_, ...)                                                                                            \
     do {                                                                                                                        \
         for (uint64_t mk_ = (T_).mask; mk_; mk_ &= mk_ - 1) { const int32_t fr_ = (T_).base + __builtin_ctzll(mk_); __VA_ARGS__ }        \
@@ -184,7 +189,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     } while (0)
     static thread_local std::vector<PerPatch> pp_tab;            // indexed by patch; only [kmin, kmax] of the previous plan is dirty
     static thread_local int64_t pp_lo = 0, pp_hi = -1;
-    if ((int64_t)pp_tab.size() < p_tot) { pp_tab.assign((size_t)p_tot, PerPatch{0, 0, 0, 0, 0, 0, 0, 0}); pp_lo = 0; pp_hi = -1; }
+    if ((int64_t)pp_tab.size() < p_tot) { pp_tab.assign((size_t)p_tot, PerPatch{0, 0, 0, 0, 0, 0}); pp_lo = 0; pp_hi = -1; }
     for (int64_t p = pp_lo; p <= pp_hi; ++p) pp_tab[(size_t)p].cnt = 0;
     PerPatch *pp = pp_tab.data();
     int64_t n_all = n_all_min, kmin = p_tot, kmax = -1;       // [kmin, kmax]: patches the edges name (a window of the buffer)
@@ -205,7 +210,6 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             const PatchStat &d = dstats->tab[(size_t)(k - kmin)];
             PerPatch &t = pp[k];
             t.src = d.src; t.base = d.src - 64; t.last_j = 0; t.mask = d.mask; t.mask2 = d.mask2;
-            t.rmask = dstats->rtab ? dstats->rtab[(size_t)(k - kmin)].rmask & d.mask : 0; t.rmask2 = dstats->rtab ? dstats->rtab[(size_t)(k - kmin)].rmask2 & d.mask2 : 0;
             if (k >= own_lo && k < own_hi) { t.cnt = d.cnt; E_own += d.cnt; }
             else { t.cnt = 0; if (k < own_lo) pl->dev_q0 += d.cnt; }
         }
@@ -224,14 +228,15 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         ++cj[(size_t)j + 1];
         PerPatch &t = pp[k];
         // (128 bits around the SOURCE frame, as the device's table has them: a list is laid out the same way wherever its indices live)
-        if (t.cnt++ == 0) { t.src = (int32_t)i; t.base = (int32_t)i - 64; t.mask = 0; t.mask2 = 0; t.rmask = 0; t.rmask2 = 0; }
+        if (t.cnt++ == 0) { t.src = (int32_t)i; t.base = (int32_t)i - 64; t.mask = 0; t.mask2 = 0; }
         else { if (t.src != (int32_t)i) src_ok = false; if ((int32_t)j < t.last_j) mono_j = false; }
         t.last_j = (int32_t)j;          // one source frame per track: the caller builds ii = ix[kk] (batrack.py:199)
         const int64_t bit = j - t.base;
         if (bit < 0 || bit >= 128) masks_ok = false;
         else {
-            uint64_t &mw = bit < 64 ? t.mask : t.mask2, &rw = bit < 64 ? t.rmask : t.rmask2;
-            rw |= mw & (1ull << (bit & 63)); mw |= 1ull << (bit & 63);
+            uint64_t &mw = bit < 64 ? t.mask : t.mask2;
+            if (mw & (1ull << (bit & 63))) { RepStat &r = rep_host[k]; (bit < 64 ? r.rmask : r.rmask2) |= 1ull << (bit & 63); }
+            mw |= 1ull << (bit & 63);
         }
     }
     pp_lo = kmin; pp_hi = kmax;
@@ -296,7 +301,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             fm[(size_t)(t.src - f_lo) * 2] |= t.mask; fm[(size_t)(t.src - f_lo) * 2 + 1] |= t.mask2;
         }
         for (int64_t f = 0; f < nw; ++f) {
-            const PerPatch t{0, (int32_t)(f + f_lo), (int32_t)(f + f_lo) - 64, 0, fm[(size_t)f * 2], fm[(size_t)f * 2 + 1], 0, 0};
+            const PerPatch t{0, (int32_t)(f + f_lo), (int32_t)(f + f_lo) - 64, 0, fm[(size_t)f * 2], fm[(size_t)f * 2 + 1]};
             int32_t *row = pair_of.data() + (size_t)f * nw - f_lo;
             BT_FOR_TARGETS(t, fr, row[fr] = 0;);
         }
@@ -418,7 +423,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         // the same greedy rule on bit masks (a tile has one source frame, so its tracks' masks share their base): cameras = the
         // free frames among the targets and the source frame (bit 64), in ascending order as the bits are
         int32_t cur_src = -1;
-        uint64_t free_lo = 0, free_hi = 0, tm_lo = 0, tm_hi = 0, tg_lo = 0, tg_hi = 0;
+        uint64_t free_lo = 0, free_hi = 0, tm_lo = 0, tm_hi = 0, tg_lo = 0, tg_hi = 0, pm_lo = ~0ull, pm_hi = ~0ull;
         auto flush = [&](int32_t k_end) {
             if (k_end == trk0) return;
             tile_set.clear();
@@ -433,11 +438,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             const PerPatch &t = pp[pl->kx[(size_t)k]];
             if (t.src != cur_src) {
                 flush(k);
-                cur_src = t.src;
+                cur_src = t.src; pm_lo = pm_hi = ~0ull;
                 const int64_t first_free = fixedp - ((int64_t)t.src - 64);          // bits >= this are free frames
                 free_lo = first_free <= 0 ? ~0ull : first_free >= 64 ? 0ull : ~0ull << first_free;
                 free_hi = first_free <= 64 ? ~0ull : first_free >= 128 ? 0ull : ~0ull << (first_free - 64);
             }
+            if (k > trk0 && k - trk0 < tcap && t.mask == pm_lo && t.mask2 == pm_hi) continue;      // (the same targets as the track before: nothing new)
+            pm_lo = t.mask; pm_hi = t.mask2;
             const uint64_t c_lo = t.mask & free_lo, c_hi = (t.mask2 & free_hi) | (t.src >= fixedp ? 1ull : 0ull);
             const int nk = __builtin_popcountll(c_lo) + __builtin_popcountll(c_hi);
             if (nk > kTileCamHard) {                               // a loose track (see the general loop below)
@@ -564,7 +571,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             if (aligned) {
                 // (one source frame per tile: its pairs are (source, target) over the union of the tracks' target masks, ascending)
                 const int32_t src_t = pp[pl->kx[(size_t)t0]].src;
-                const PerPatch tu{0, src_t, src_t - 64, 0, tile_tmask[(size_t)t * 2], tile_tmask[(size_t)t * 2 + 1], 0, 0};
+                const PerPatch tu{0, src_t, src_t - 64, 0, tile_tmask[(size_t)t * 2], tile_tmask[(size_t)t * 2 + 1]};
                 const int32_t *row = pair_of.data() + (size_t)(src_t - f_lo) * nw - f_lo;
                 BT_FOR_TARGETS(tu, fr, mine.push_back(row[fr]););
                 for (int32_t gp : mine) lp_of[(size_t)gp] = 0;
@@ -595,13 +602,19 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                 mult.assign(mine.size(), 1);
                 for (int32_t l = 0; l < nt; ++l) {
                     const PerPatch &tp = pp[pl->kx[(size_t)(t0 + l)]];
-                    if (!(tp.rmask | tp.rmask2)) continue;
                     const int32_t distinct = __builtin_popcountll(tp.mask) + __builtin_popcountll(tp.mask2);
-                    const int32_t nrep = __builtin_popcountll(tp.rmask) + __builtin_popcountll(tp.rmask2);
+                    if (tp.cnt <= distinct) continue;
+                    RepStat rs{0, 0};
+                    const int64_t patch = pl->kx[(size_t)(t0 + l)];
+                    if (dstats) { if (dstats->rtab) rs = dstats->rtab[(size_t)(patch - kmin)]; }
+                    else { const auto it = rep_host.find(patch); if (it != rep_host.end()) rs = it->second; }
+                    rs.rmask &= tp.mask; rs.rmask2 &= tp.mask2;
+                    const int32_t nrep = __builtin_popcountll(rs.rmask) + __builtin_popcountll(rs.rmask2);
+                    if (nrep == 0) { pl->dev_pbase.clear(); return BT_EINVAL; }      // (cannot happen: a surplus edge repeats some target)
                     const int32_t mrep = 1 + (tp.cnt - distinct) - (nrep - 1);
                     const int32_t *row = pair_of.data() + (size_t)(tp.src - f_lo) * nw - f_lo;
                     for (int half = 0; half < 2; ++half)
-                        for (uint64_t mk = half ? tp.rmask2 : tp.rmask; mk; mk &= mk - 1) {
+                        for (uint64_t mk = half ? rs.rmask2 : rs.rmask; mk; mk &= mk - 1) {
                             int32_t &mu = mult[(size_t)lp_of[(size_t)row[tp.base + 64 * half + __builtin_ctzll(mk)]]];
                             mu = std::max(mu, mrep);
                         }
@@ -816,7 +829,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             src_b = d.src; mask_b = d.mask; mask2_b = d.mask2;
             cset.clear();
             if (d.src >= fixedp) cset.push_back((int32_t)(d.src - fixedp));
-            const PerPatch dt{d.cnt, d.src, d.src - 64, 0, d.mask, d.mask2, 0, 0};
+            const PerPatch dt{d.cnt, d.src, d.src - 64, 0, d.mask, d.mask2};
             BT_FOR_TARGETS(dt, fr,
                 const int64_t c = (int64_t)fr - fixedp;
                 if (c >= 0) cset.push_back((int32_t)c););
