@@ -406,7 +406,7 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
             if (hipMemcpyAsync(pb.h_bad, pb.d_bad, sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess) return BT_EHIP;
             DevPlanStats st{};
             int64_t tracks = 0;
-            int rc = plan_device_stats(pb.d_words, E, p_tot, cs, &st, &tracks);       // (rc == BT_OK: it synchronised, h_bad is in as well)
+            int rc = plan_device_stats(pb.d_words, E, p_tot, fixedp, own_lo, own_hi, cs, &st, &tracks);       // (rc == BT_OK: it synchronised, h_bad is in as well)
             if (rc != BT_OK && rc != BT_NEED_EDGES) return rc;
             // (BT_NEED_EDGES can come back before anything was waited for — p_tot or E beyond the device path — and h_bad may
             //  then still hold an earlier list's verdict: it is read only behind a synchronisation; the host path below does its own)

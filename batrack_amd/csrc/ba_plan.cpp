@@ -205,9 +205,11 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         // a sharded plan lays out the tracks of [own_lo, own_hi) only: the device's sort keeps a patch's edges together in
         // patch order, so the rank's edges are ONE segment of the sorted list — it starts behind the edges of the patches in
         // front of the range (dev_q0).  The other ranks' tracks keep their (source frame, mask) for the pattern of S below.
-        pl->dev_q0 = 0;
-        for (int64_t k = kmin; k <= kmax; ++k) {
-            const PatchStat &d = dstats->tab[(size_t)(k - kmin)];
+        // (round 6: the table of such a plan holds the rank's own patches only — dstats->sliced —, the edges in front of them, the
+        //  tracks in front of them and the coupling pattern of the whole list come reduced from the device)
+        pl->dev_q0 = dstats->sliced ? dstats->edges_before : 0;
+        for (int64_t k = dstats->tab_lo; k < dstats->tab_lo + dstats->tab_n; ++k) {
+            const PatchStat &d = dstats->tab[(size_t)(k - dstats->tab_lo)];
             PerPatch &t = pp[k];
             t.src = d.src; t.base = d.src - 64; t.last_j = 0; t.mask = d.mask; t.mask2 = d.mask2;
             if (k >= own_lo && k < own_hi) { t.cnt = d.cnt; E_own += d.cnt; }
@@ -244,7 +246,8 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // indexed by the GLOBAL track number, the kernels count from the rank's first track
     pl->trk_off = 0;
     if (dstats) {
-        for (int64_t k = kmin; k < std::min(own_lo, kmax + 1); ++k) pl->trk_off += dstats->tab[(size_t)(k - kmin)].cnt > 0 ? 1 : 0;
+        if (dstats->sliced) pl->trk_off = (int)dstats->trk_before;
+        else for (int64_t k = kmin; k < std::min(own_lo, kmax + 1); ++k) pl->trk_off += dstats->tab[(size_t)(k - dstats->tab_lo)].cnt > 0 ? 1 : 0;
     } else if (E_own != E && own_lo > 0) {
         std::vector<uint8_t> seen((size_t)own_lo, 0);
         for (int64_t e = 0; e < E; ++e) { const int64_t k = KK(e); if (k < own_lo && !seen[(size_t)k]) { seen[(size_t)k] = 1; ++pl->trk_off; } }
@@ -278,7 +281,9 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     static thread_local std::vector<int32_t> off_scratch;        // (a million tracks: no fresh pages per plan)
     std::vector<int32_t> &off = off_scratch;
     off.assign(1, 0);
-    for (int64_t p = kmin; p <= kmax; ++p) {
+    // (a rank's sliced table: only its own patches can carry a track of this plan)
+    const int64_t p_first = dstats && dstats->sliced ? dstats->tab_lo : kmin, p_last = dstats && dstats->sliced ? dstats->tab_lo + dstats->tab_n - 1 : kmax;
+    for (int64_t p = p_first; p <= p_last; ++p) {
         const int32_t c = pp[p].cnt;
         if (c > 0) { pl->kx.push_back((int32_t)p); off.push_back(off.back() + c); pl->trk_win[(size_t)(p - kmin)] = m++; }
     }
@@ -606,7 +611,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                     if (tp.cnt <= distinct) continue;
                     RepStat rs{0, 0};
                     const int64_t patch = pl->kx[(size_t)(t0 + l)];
-                    if (dstats) { if (dstats->rtab) rs = dstats->rtab[(size_t)(patch - kmin)]; }
+                    if (dstats) { if (dstats->rtab) rs = dstats->rtab[(size_t)(patch - dstats->tab_lo)]; }
                     else { const auto it = rep_host.find(patch); if (it != rep_host.end()) rs = it->second; }
                     rs.rmask &= tp.mask; rs.rmask2 &= tp.mask2;
                     const int32_t nrep = __builtin_popcountll(rs.rmask) + __builtin_popcountll(rs.rmask2);
@@ -817,13 +822,19 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                 for (size_t v = 0; v <= u; ++v) nz[(size_t)cset[u]][(size_t)cset[v]] = 1;
         }
     }
-    if (E_own != E && dstats) {
+    if (E_own != E && dstats && dstats->sliced) {
+        // (the other ranks' tracks: the pattern of the whole list, reduced on the device — k_plan_pattern)
+        if (!dstats->pattern) return BT_NEED_EDGES;
+        for (int64_t u = 0; u < n; ++u)
+            for (int64_t v = 0; v <= u; ++v)
+                if ((dstats->pattern[(size_t)u * dstats->pattern_words + (size_t)(v >> 5)] >> (v & 31)) & 1u) nz[(size_t)u][(size_t)v] = 1;
+    } else if (E_own != E && dstats) {
         // (the same from the device's table: a track's cameras are its source frame and the frames of its mask)
         std::vector<int32_t> cset;
         int32_t src_b = -1; uint64_t mask_b = 0, mask2_b = 0;
         for (int64_t p = kmin; p <= kmax; ++p) {
             if (p >= own_lo && p < own_hi) continue;
-            const PatchStat &d = dstats->tab[(size_t)(p - kmin)];
+            const PatchStat &d = dstats->tab[(size_t)(p - dstats->tab_lo)];
             if (d.cnt <= 0) continue;
             if (d.src == src_b && d.mask == mask_b && d.mask2 == mask2_b) continue;          // (the same cameras as the track before: nothing new)
             src_b = d.src; mask_b = d.mask; mask2_b = d.mask2;

@@ -245,11 +245,17 @@ struct PatchStat { int32_t cnt, src, src_min, pad; unsigned long long mask, mask
 // for the wave-per-tile kernels, whose aligned slot layout needs to know where a track's extra edges can be
 struct RepStat { unsigned long long rmask, rmask2; };
 struct DevPlanStats {
-    const PatchStat *tab;          // [kmax - kmin + 1], the patches kmin .. kmax
+    const PatchStat *tab;          // the patches tab_lo .. tab_lo + tab_n - 1: all the list names (kmin .. kmax), or — a rank's plan of a
+    int64_t tab_lo, tab_n;         // sharded solve — only those of its own range: the rank's host share is then ~ its share of the tracks
     int64_t kmin, kmax, n_all, f_lo;
     int any_self;
     int rep_known;                 // the repeated targets were looked for (rtab null then means: there are none)
-    const RepStat *rtab;           // [kmax - kmin + 1] or null
+    const RepStat *rtab;           // as tab, or null
+    // a rank's plan: what it needs to know of the OTHER ranks' tracks, reduced on the device from the full table
+    int sliced;                    // tab holds the own range only
+    int64_t trk_before, edges_before;      // distinct tracks / edges of the patches in front of the range
+    const uint32_t *pattern;       // [n][pattern_words] bits: free cameras u >= v that some track of the list couples (null: n = 0 or a wide plan)
+    int pattern_words;
 };
 enum { BT_NEED_EDGES = 2 };
 int build_plan_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
@@ -268,7 +274,7 @@ int launch_pack_edges(const int64_t *ii, const int64_t *jj, const int64_t *kk, i
                       uint64_t *out, int *bad, void *stream);
 int pack_edges_host(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot, uint64_t *out);
 // the passes over the edges on the device (plan_device.hip; bt_plan_create)
-int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *stream, DevPlanStats *st, int64_t *tracks);
+int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, int64_t fixedp, int64_t own_lo, int64_t own_hi, void *stream, DevPlanStats *st, int64_t *tracks);
 int plan_device_rounds(const bt_plan *pl, int64_t E, void *stream, int64_t *rounds);
 int plan_device_fill(const bt_plan *pl, int64_t E, int32_t *d_rec, int32_t *d_pm_edge, int64_t rounds, void *stream);
 int plan_device_slots_stage(const bt_plan *pl, void *stream);

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void k_plan_stats(const unsigned long long *wo
 // tracks (patches with an edge) and the one-source-frame check over the window's slice of the table.  Every workgroup first
 // reduces the partials k_plan_stats left (shuffles, no atomics: a kernel of its own for that was another launch and ~2k
 // same-address LDS atomics); workgroup 0 writes the list's figures to glob[0..6].
-__global__ __launch_bounds__(256) void k_plan_count(const PatchStat *stat, const int *part, int nblk, int *glob) {
+// (own_lo: a rank's plan also counts the tracks and edges of the patches in front of its range — glob[13], glob[14])
+__global__ __launch_bounds__(256) void k_plan_count(const PatchStat *stat, const int *part, int nblk, int *glob, int own_lo) {
     __shared__ int red[4][5];
     int max_f = 0, min_f = 0x7fffffff, kmin = 0x7fffffff, kmax = -1, fl = 0;
     for (int r = threadIdx.x; r < nblk; r += blockDim.x) {
@@ -93,14 +94,47 @@ __global__ __launch_bounds__(256) void k_plan_count(const PatchStat *stat, const
         if (fl & 1) glob[4] = 1;
         if (fl & 4) glob[6] = 1;
     }
-    int n = 0, bad = 0;
+    int n = 0, bad = 0, nb = 0, eb = 0;
     for (int p = kmin + (int)(blockIdx.x * blockDim.x + threadIdx.x); p <= kmax; p += (int)(gridDim.x * blockDim.x)) {
         const PatchStat t = stat[p];
-        if (t.cnt > 0) { ++n; bad |= t.src != t.src_min; }
+        if (t.cnt > 0) { ++n; bad |= t.src != t.src_min; if (p < own_lo) { ++nb; eb += t.cnt; } }
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { n += __shfl_xor(n, m); bad |= __shfl_xor(bad, m); }
-    if ((threadIdx.x & 63) == 0) { if (n) atomicAdd(&glob[7], n); if (bad) glob[5] = 1; }
+    for (int m = 32; m >= 1; m >>= 1) { n += __shfl_xor(n, m); bad |= __shfl_xor(bad, m); nb += __shfl_xor(nb, m); eb += __shfl_xor(eb, m); }
+    if ((threadIdx.x & 63) == 0) { if (n) atomicAdd(&glob[7], n); if (bad) glob[5] = 1; if (nb) { atomicAdd(&glob[13], nb); atomicAdd(&glob[14], eb); } }
+}
+
+// The block pattern of the reduced system over ALL tracks of the list, for a rank's plan of a sharded solve: the free cameras of a
+// track (its source frame and its targets) couple pairwise (the track's Schur term, ba.py:321; the pairs' B blocks are among them).
+// bits [u][v], v <= u, n x W words; every workgroup ORs into a bitmap in LDS first.
+__global__ __launch_bounds__(256) void k_plan_pattern(const PatchStat *stat, int kmin, int kmax, int fixedp, int n, int W, unsigned *out) {
+    extern __shared__ unsigned bm[];
+    for (int i = threadIdx.x; i < n * W; i += blockDim.x) bm[i] = 0u;
+    __syncthreads();
+    for (int p = kmin + (int)(blockIdx.x * blockDim.x + threadIdx.x); p <= kmax; p += (int)(gridDim.x * blockDim.x)) {
+        const PatchStat t = stat[p];
+        if (t.cnt <= 0) continue;
+        if (p > kmin) { const PatchStat q = stat[p - 1]; if (q.cnt > 0 && q.src == t.src && q.mask == t.mask && q.mask2 == t.mask2) continue; }   // (as the patch before)
+        // the track's cameras as bits of camera numbers: camera of mask bit b = off + b, off = src - 64 - fixedp; the source is bit 64
+        const int off = t.src - 64 - fixedp;
+        unsigned long long m0 = t.mask, m1 = t.mask2 | 1ull;
+        unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};                       // n <= 255: eight words
+        for (int half = 0; half < 2; ++half)
+            for (unsigned long long mk = half ? m1 : m0; mk; mk &= mk - 1) {
+                const int c = off + 64 * half + __builtin_ctzll(mk);
+                if (c >= 0 && c < n) cw[c >> 5] |= 1u << (c & 31);
+            }
+        for (int w = 0; w < W; ++w)
+            for (unsigned um = cw[w]; um; um &= um - 1) {
+                const int u = 32 * w + __builtin_ctz(um);
+                for (int v = 0; v <= w; ++v) {
+                    const unsigned val = v < w ? cw[v] : (cw[v] & (0xffffffffu >> (31 - (u & 31))));       // columns <= u
+                    if (val && (bm[u * W + v] & val) != val) atomicOr(&bm[u * W + v], val);
+                }
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n * W; i += blockDim.x) if (bm[i]) atomicOr(&out[i], bm[i]);
 }
 
 __global__ __launch_bounds__(256) void k_plan_stat_clear(PatchStat *stat, RepStat *rstat, long long rstat_n, long long lo, long long hi) {
@@ -334,6 +368,7 @@ namespace {
 struct DevPlanBuffers {
     PatchStat *stat = nullptr; size_t stat_cap = 0; long long dirty_lo = 0, dirty_hi = -1;
     RepStat *rstat = nullptr; size_t rstat_cap = 0; RepStat *h_rtab = nullptr; size_t rtab_cap = 0;   // the tracks' repeated targets (large lists only)
+    unsigned *pat = nullptr, *h_pat = nullptr;                    // the coupling pattern of a sharded solve: 255 x 8 words (device, pinned host)
     int *glob = nullptr, *h_glob = nullptr;                       // 8 + 2 ints (device, pinned host)
     int *part = nullptr;                                          // [kStatBlocks][8]: the workgroups' partials of k_plan_stats
     unsigned *keys_in = nullptr, *keys = nullptr; int *vals_in = nullptr, *vals = nullptr; unsigned char *dcode = nullptr; size_t e_cap = 0;
@@ -358,7 +393,7 @@ DevPlanBuffers &bufs() { static thread_local DevPlanBuffers b; return b; }
 // Pass 1: the per-patch table and the list's figures.  On BT_OK *st describes the table slice (pinned host memory, valid until
 // the thread's next call) and the sort of the words has been queued behind it on `stream`.  BT_NEED_EDGES: not a list this
 // path takes.
-int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *stream, DevPlanStats *st, int64_t *tracks) {
+int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, int64_t fixedp, int64_t own_lo, int64_t own_hi, void *stream, DevPlanStats *st, int64_t *tracks) {
     hipStream_t cs = static_cast<hipStream_t>(stream);
     DevPlanBuffers &b = bufs();
     if (!b.glob) {
@@ -383,28 +418,43 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
         hipLaunchKernelGGL(k_plan_stat_clear, dim3((unsigned)((b.dirty_hi - b.dirty_lo + 256) / 256)), dim3(256), 0, cs, b.stat,
                            b.rstat, (long long)b.rstat_cap, b.dirty_lo, b.dirty_hi);
     b.h_glob[0] = 0; b.h_glob[1] = 0x7fffffff; b.h_glob[2] = 0x7fffffff; b.h_glob[3] = -1;
-    for (int c = 4; c < 10; ++c) b.h_glob[c] = 0;
-    if (hipMemcpyAsync(b.glob, b.h_glob, 10 * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess) return BT_EHIP;
+    for (int c = 4; c < 16; ++c) b.h_glob[c] = 0;
+    if (hipMemcpyAsync(b.glob, b.h_glob, 16 * sizeof(int), hipMemcpyHostToDevice, cs) != hipSuccess) return BT_EHIP;
     const int nblk = (int)std::min<int64_t>(kStatBlocks, (E + 255) / 256);
     hipLaunchKernelGGL(k_plan_stats, dim3((unsigned)nblk), dim3(256), 0, cs, reinterpret_cast<const unsigned long long *>(d_words),
                        (long long)E, b.stat, b.part, b.vals_in);
-    hipLaunchKernelGGL(k_plan_count, dim3(64), dim3(256), 0, cs, b.stat, b.part, nblk, b.glob);
-    if (hipMemcpyAsync(b.h_glob, b.glob, 8 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
+    const bool ranked = own_hi > 0 && !(own_lo <= 0 && own_hi >= p_tot);      // a rank's plan of a sharded solve
+    hipLaunchKernelGGL(k_plan_count, dim3(64), dim3(256), 0, cs, b.stat, b.part, nblk, b.glob, ranked ? (int)std::min<int64_t>(own_lo, 0x7fffffff) : 0);
+    if (hipMemcpyAsync(b.h_glob, b.glob, 8 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+        hipMemcpyAsync(b.h_glob + 13, b.glob + 13, 2 * sizeof(int), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) return BT_EHIP;
     const int *g = b.h_glob;
     b.dirty_lo = g[2]; b.dirty_hi = g[3];
     *tracks = g[7];
     if (g[5] || g[6] || g[3] < g[2]) return BT_NEED_EDGES;
     // (not a patch range mostly empty: the table's slice would be a larger copy than the edges)
     const int64_t t64 = ((int64_t)g[7] + kLanes - 1) / kLanes;
-    const size_t nt = (size_t)(g[3] - g[2] + 1);
-    if (t64 <= 0 || nt > 4 * (size_t)g[7] + 65536) return BT_NEED_EDGES;
+    if (t64 <= 0 || (size_t)(g[3] - g[2] + 1) > 4 * (size_t)g[7] + 65536) return BT_NEED_EDGES;
+    // the slice of the table the host reads: all the patches the list names, or the rank's own
+    const int64_t t_lo = ranked ? std::max<int64_t>(g[2], own_lo) : g[2], t_hi = ranked ? std::min<int64_t>(g[3], own_hi - 1) : g[3];
+    const size_t nt = t_hi >= t_lo ? (size_t)(t_hi - t_lo + 1) : 0;
+    if (nt == 0) return BT_NEED_EDGES;                             // (a rank without tracks: the host's analysis, as before)
     if (nt > b.tab_cap) {
         (void)hipHostFree(b.h_tab);
         if (hipHostMalloc(reinterpret_cast<void **>(&b.h_tab), (nt + nt / 4 + 1024) * sizeof(PatchStat), hipHostMallocDefault) != hipSuccess) { b.tab_cap = 0; return BT_ENOMEM; }
         b.tab_cap = nt + nt / 4 + 1024;
     }
+    // a rank's plan: the coupling pattern of the whole list, reduced here instead of read record by record on the host
+    const int n_free = (int)std::max<int64_t>(0, (int64_t)g[0] - fixedp), pat_w = (n_free + 31) / 32;
+    const bool want_pat = ranked && n_free > 0 && n_free <= kMaxFree;
+    if (want_pat) {
+        if (!b.pat && (hipMalloc(reinterpret_cast<void **>(&b.pat), 256 * 8 * sizeof(unsigned)) != hipSuccess ||
+                       hipHostMalloc(reinterpret_cast<void **>(&b.h_pat), 256 * 8 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess)) return BT_ENOMEM;
+        if (hipMemsetAsync(b.pat, 0, (size_t)n_free * pat_w * sizeof(unsigned), cs) != hipSuccess) return BT_EHIP;
+        hipLaunchKernelGGL(k_plan_pattern, dim3(64), dim3(256), (size_t)n_free * pat_w * sizeof(unsigned), cs, b.stat, g[2], g[3], (int)fixedp, n_free, pat_w, b.pat);
+        if (hipMemcpyAsync(b.h_pat, b.pat, (size_t)n_free * pat_w * sizeof(unsigned), hipMemcpyDeviceToHost, cs) != hipSuccess) return BT_EHIP;
+    }
     hipEvent_t ev = nullptr;
-    if (hipMemcpyAsync(b.h_tab, b.stat + g[2], nt * sizeof(PatchStat), hipMemcpyDeviceToHost, cs) != hipSuccess ||
+    if (hipMemcpyAsync(b.h_tab, b.stat + t_lo, nt * sizeof(PatchStat), hipMemcpyDeviceToHost, cs) != hipSuccess ||
         hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return BT_EHIP;
     if (hipEventRecord(ev, cs) != hipSuccess) { (void)hipEventDestroy(ev); return BT_EHIP; }
     // the sort runs while the host lays out tracks, pairs and tiles
@@ -435,13 +485,15 @@ int plan_device_stats(const uint64_t *d_words, int64_t E, int64_t p_tot, void *s
                 if (hipHostMalloc(reinterpret_cast<void **>(&b.h_rtab), (nt + nt / 4 + 1024) * sizeof(RepStat), hipHostMallocDefault) != hipSuccess) { b.rtab_cap = 0; (void)hipEventDestroy(ev); return BT_ENOMEM; }
                 b.rtab_cap = nt + nt / 4 + 1024;
             }
-            if (hipMemcpyAsync(b.h_rtab, b.rstat + g[2], nt * sizeof(RepStat), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) { (void)hipEventDestroy(ev); return BT_EHIP; }
+            if (hipMemcpyAsync(b.h_rtab, b.rstat + t_lo, nt * sizeof(RepStat), hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) { (void)hipEventDestroy(ev); return BT_EHIP; }
         }
     }
     const bool waited = hipEventSynchronize(ev) == hipSuccess;
     (void)hipEventDestroy(ev);
     if (!sorted_ok || !waited) return BT_EHIP;
-    st->tab = b.h_tab; st->kmin = g[2]; st->kmax = g[3]; st->n_all = g[0]; st->f_lo = g[1]; st->any_self = g[4];
+    st->tab = b.h_tab; st->tab_lo = t_lo; st->tab_n = (int64_t)nt; st->kmin = g[2]; st->kmax = g[3]; st->n_all = g[0]; st->f_lo = g[1]; st->any_self = g[4];
+    st->sliced = ranked ? 1 : 0; st->trk_before = g[13]; st->edges_before = g[14];
+    st->pattern = want_pat ? b.h_pat : nullptr; st->pattern_words = pat_w;
     st->rep_known = rep ? 1 : 0; st->rtab = any_rep ? b.h_rtab : nullptr;
     return BT_OK;
 }

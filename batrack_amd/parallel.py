@@ -28,6 +28,20 @@ import torch.distributed as dist
 def partition_tracks(kk, world):
     """Split the sorted distinct tracks of `kk` into `world` contiguous ranges with
     near-equal edge counts.  Returns the list of (lo, hi) patch-id bounds, hi exclusive."""
+    if isinstance(kk, torch.Tensor) and kk.is_cuda and kk.numel() > 0:
+        # on the device (a host np.unique of 8.4M indices is 0.3 s, on every rank): the same bounds, `world` numbers come back
+        ids, counts = torch.unique(kk, return_counts=True)
+        csum = counts.cumsum(0).to(torch.float64)
+        total, n_ids = float(csum[-1]), ids.numel()
+        targets = torch.tensor([total * (r + 1) / world - 1e-9 for r in range(world - 1)], dtype=torch.float64, device=kk.device)
+        cut = [min(int(c) + 1, n_ids) for c in torch.searchsorted(csum, targets, right=False).cpu().tolist()] + [n_ids]
+        for r in range(1, world):
+            cut[r] = max(cut[r], cut[r - 1])
+        edges_idx = [0] + cut                                         # first track of rank r = edges_idx[r], one past its last = edges_idx[r + 1]
+        got = ids[torch.tensor([min(i, n_ids - 1) for i in edges_idx], device=kk.device)].cpu().tolist()
+        last = int(ids[-1]) + 1
+        val = [int(v) if i < n_ids else last for i, v in zip(edges_idx, got)]
+        return [(val[r], val[r + 1]) for r in range(world)]
     kk = np.asarray(kk.cpu() if isinstance(kk, torch.Tensor) else kk)
     if kk.size == 0:
         return [(0, 0)] * world

@@ -380,3 +380,18 @@ def test_targets_far_from_their_source_frame(reach):
     for name in names:
         a, b = dev.array(name), host.array(name)
         assert a.shape == b.shape and (a == b).all(), name
+
+
+def test_track_partition_on_the_device_equals_the_hosts():
+    """partition_tracks of a device tensor (torch.unique / cumsum / searchsorted there, `world` numbers back) gives the bounds the
+    numpy statement gives — every rank derives every rank's range from them."""
+    from batrack_amd.parallel import partition_tracks
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        m = int(rng.integers(1, 5000))
+        kk = rng.choice(np.arange(0, 20000, 3), size=m, replace=True)
+        kk = np.repeat(kk, rng.integers(1, 12, kk.size)).astype(np.int64)
+        rng.shuffle(kk)
+        for world in (1, 2, 3, 8, 16):
+            assert partition_tracks(torch.as_tensor(kk, device=DEV), world) == partition_tracks(kk, world), (trial, world)
+    assert partition_tracks(torch.as_tensor(np.array([5, 5, 5], np.int64), device=DEV), 4) == partition_tracks(np.array([5, 5, 5], np.int64), 4)
