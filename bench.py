@@ -521,7 +521,10 @@ def main():
                                                                          ("one-shot peer writes over hipIpc-mapped buffers" if exchange == "ipc" else "RCCL all-reduce")),
                        "plan_build_ms": round(plan_ms_steady if plan_ms_steady is not None else plan_ms, 2),
                        "plan_build_ms_cold": round(plan_ms, 2), "edge_precision": "float64 per edge" if plan.edge_precision == 8 else "float32 per edge",
-                       "solver_status": status, **extra},
+                       "solver_status": status,
+                       # what the process group itself reports (WORLD_SIZE is what the launcher said)
+                       "ranks_reported_by_process_group": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1),
+                       **extra},
         }
         if large is not None:
             out["config"]["sharded_large" if world > 1 else "large_graph"] = large
