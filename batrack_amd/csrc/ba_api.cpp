@@ -193,7 +193,7 @@ static void bind_pointers(bt_plan *pl, const void *d) {
     P.E = (int)I.E; P.n_buf = (int)I.n_buf; P.p_tot = (int)I.p_tot; P.fixedp = (int)I.fixedp;
     P.n_all = (int)I.n_all; P.n = (int)I.n; P.D = (int)(6 * I.n); P.m = (int)I.m; P.P = (int)I.pairs;
     P.T = (int)I.tiles; P.slots = (int)I.slots; P.erows = (int)I.erows; P.nnzb = (int)I.nnz_blocks;
-    P.nupd = (int)I.updates; P.max_rows16 = pl->max_rows16;
+    P.nupd = (int)I.updates; P.max_rows16 = pl->max_rows16; P.dev_id = pl->dev_id;
 #define BT_I32(off) reinterpret_cast<const int32_t *>(b + (off))
     P.kx = BT_I32(O.kx);
     P.act_bits = reinterpret_cast<const uint32_t *>(b + O.ab); P.act_rank = BT_I32(O.ar);
@@ -268,6 +268,7 @@ int upload_plan(bt_plan *pl, const uint64_t *d_packed = nullptr) {
     const size_t pk_off = (tables_end + 255) / 256 * 256, total = keep_pk ? pk_off + (size_t)pl->e_all * sizeof(uint64_t) : tables_end;
     void *d = dev_pool().acquire(total + 256, &cap, &reuse_after);
     if (!d) return BT_ENOMEM;
+    if (hipGetDevice(&pl->dev_id) != hipSuccess) pl->dev_id = 0;      // (once per plan: its launches take their per-device figures from it)
     tick("device buffer");
     hipStream_t cs = copy_stream();
     // a recycled buffer may still be read by kernels of the destroyed plan queued on the caller's stream: the upload
@@ -466,7 +467,7 @@ static int clone_shifted(const bt_plan *src, const uint64_t *d_words, int64_t E,
     pl->cnt_nlev = src->cnt_nlev; pl->cnt_ndp = src->cnt_ndp; pl->cnt_npend = src->cnt_npend; pl->cnt_nlazy = src->cnt_nlazy;
     pl->max_rows16 = src->max_rows16; pl->max_tile_pairs = src->max_tile_pairs; pl->max_tile_slots = src->max_tile_slots;
     pl->fz_ok = src->fz_ok; pl->fzp_ok = src->fzp_ok; pl->em_ok = src->em_ok; pl->st_ok = src->st_ok; pl->st_min = src->st_min; pl->em_min = src->em_min; pl->em_its = src->em_its; pl->em_lgs = src->em_lgs;
-    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->wide = src->wide; pl->nlz = src->nlz; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->dev_slots = 0; pl->dev_wpt = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds; pl->k_hi = src->k_hi >= 0 ? src->k_hi + dk : -1;
+    pl->em_self = src->em_self; pl->e_all = src->e_all; pl->pm_ok = src->pm_ok; pl->sp_ok = src->sp_ok; pl->wide = src->wide; pl->nlz = src->nlz; pl->dev_id = src->dev_id; pl->sg_n = src->sg_n; pl->et_lgts = src->et_lgts; pl->dev_pm = 0; pl->dev_slots = 0; pl->dev_wpt = 0; pl->trk_off = src->trk_off; pl->pm_rounds = src->pm_rounds; pl->k_hi = src->k_hi >= 0 ? src->k_hi + dk : -1;
     size_t cap = 0;
     hipEvent_t reuse_after = nullptr;
     void *d = dev_pool().acquire(pl->dev_bytes + 256, &cap, &reuse_after);

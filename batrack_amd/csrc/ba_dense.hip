@@ -232,7 +232,7 @@ int launch_solve_dense(const PlanDev &pd, const StepArgs &a, hipStream_t st, hip
     const int D = pd.D;
     const size_t lds = dense_solve_lds_bytes(pd);
     static LdsLimit lds_limit;
-    if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_dn_solve), lds + 24 * 1024)) return BT_EHIP;     // (+ the kernel's static arrays)
+    if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_dn_solve), lds + 24 * 1024, pd.dev_id)) return BT_EHIP;     // (+ the kernel's static arrays)
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int nload = (int)std::min<size_t>(4096, ((size_t)D * D + 255) / 256);
         if (attempt == 0 && ev0) hipExtLaunchKernelGGL(k_dn_load, dim3(nload), dim3(256), 0, st, ev0, nullptr, 0, d, a.S, a.y, a.ep, attempt);

@@ -769,7 +769,7 @@ template <int NT, int LGS, int LOSS>
 static int launch_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const size_t lds_w = (lds_bytes(pd, LGS, a.lmbda_trk != nullptr) + 255) & ~(size_t)255;     // one wave's slice
     DevProps dp;
-    if (!device_props(&dp)) return BT_EHIP;
+    if (!device_props(&dp, pd.dev_id)) return BT_EHIP;
     const int n_cu = dp.n_cu;
     const size_t lds_cu = dp.lds_cu;
     // waves per workgroup = per CU: two per SIMD (the kernel's 256 registers) unless their LDS slices do not fit
@@ -784,7 +784,7 @@ static int launch_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEve
     if (wg < W) W = wg;
     const size_t lds = lds_w * (size_t)W;
     static LdsLimit lds_limit;
-    if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_edge2<NT, LGS, LOSS>), lds)) return BT_EHIP;
+    if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_edge2<NT, LGS, LOSS>), lds, pd.dev_id)) return BT_EHIP;
     if (a.dbg & 128) {                                                  // measurement: what the runtime says fits a CU
         static bool said = false;
         if (!said) {

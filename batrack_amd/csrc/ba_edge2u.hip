@@ -295,11 +295,11 @@ static int launch_u(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEve
     static std::atomic<int> per_cu_c[kMaxDevices];
     static std::atomic<size_t> per_cu_lds[kMaxDevices];
     DevProps dp;
-    if (!device_props(&dp)) return BT_EHIP;
+    if (!device_props(&dp, pd.dev_id)) return BT_EHIP;
     const int dslot = dp.dev >= 0 && dp.dev < kMaxDevices ? dp.dev : 0;
     int per_cu = per_cu_lds[dslot].load(std::memory_order_acquire) == lds ? per_cu_c[dslot].load(std::memory_order_relaxed) : 0;
     if (!per_cu) {
-        if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_edge2u<MODE, LGS, LOSS>), lds)) return BT_EHIP;
+        if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_edge2u<MODE, LGS, LOSS>), lds, pd.dev_id)) return BT_EHIP;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_edge2u<MODE, LGS, LOSS>, 64, lds) != hipSuccess || nb < 1) nb = 1;
         per_cu = nb;

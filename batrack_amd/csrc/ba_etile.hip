@@ -637,7 +637,7 @@ template <int MODE, typename R, bool PROF = false, bool TWO = false>
 static int launch_etile_t(const PlanDev &pd, const StepArgs &a, int do_poses, int extra_blocks, int zero_blocks, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     const size_t lds = etile_lds_bytes(pd, MODE, sizeof(R));
     static LdsLimit lds_limit;                     // per instantiation and device; only ever raised (several plans coexist)
-    if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_etile<MODE, R, PROF, TWO>), lds)) return BT_EHIP;
+    if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_etile<MODE, R, PROF, TWO>), lds, pd.dev_id)) return BT_EHIP;
     const dim3 grid((unsigned)(pd.T + extra_blocks + zero_blocks)), blk(kEtThreads);
     if (ev0) hipExtLaunchKernelGGL((k_etile<MODE, R, PROF, TWO>), grid, blk, lds, st, ev0, ev1, 0, pd, a, do_poses, pd.T, pd.T + extra_blocks);
     else hipLaunchKernelGGL((k_etile<MODE, R, PROF, TWO>), grid, blk, lds, st, pd, a, do_poses, pd.T, pd.T + extra_blocks);

@@ -2475,13 +2475,11 @@ static int solver_threads() {
 // hipFuncAttributeMaxDynamicSharedMemorySize is one value per kernel for the whole process, while up to eight cached
 // plans (and the prefetch thread building the next one) coexist: the limit is only ever RAISED, under a lock, so a
 // small plan uploaded later cannot pull it below what an earlier plan launches with.
-static int raise_lds_limit(const void *fn, size_t need) {
+static int raise_lds_limit(const void *fn, size_t need, int dev) {
     struct Entry { const void *fn; int dev; size_t bytes; };
     static std::mutex mu;
     static std::vector<Entry> *set = new std::vector<Entry>();
-    if (need <= 48 * 1024) return BT_OK;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return BT_EHIP;             // (the attribute is per device as well)
+    if (need <= 48 * 1024) return BT_OK;                              // (the attribute is per device as well: `dev` = the plan's)
     std::lock_guard<std::mutex> lk(mu);
     for (auto &e : *set)
         if (e.fn == fn && e.dev == dev) {
@@ -2503,13 +2501,13 @@ int configure_kernels(const PlanDev &pd) {
                              reinterpret_cast<const void *>(&k_tile<false, false, false, false, double>),
                              reinterpret_cast<const void *>(&k_tile<false, true, false, false, double>) };
     const bool dbl = edge_precision(pd) != 0;
-    for (int i = dbl ? 4 : 0; i < (dbl ? 6 : 4); ++i) if (raise_lds_limit(tiles[i], need) != BT_OK) return BT_EHIP;
+    for (int i = dbl ? 4 : 0; i < (dbl ? 6 : 4); ++i) if (raise_lds_limit(tiles[i], need, pd.dev_id) != BT_OK) return BT_EHIP;
     if (dbl && !etile_applies(pd)) {
         const size_t nu = ((size_t)pd.max_tile_pairs * kUpdGeo + kUpdThreads) * sizeof(double);
         if (nu > kLdsBudget) return BT_EUNSUPPORTED;
-        if (raise_lds_limit(reinterpret_cast<const void *>(&k_update<false, kUpdThreads, double>), nu) != BT_OK) return BT_EHIP;
-        if (raise_lds_limit(reinterpret_cast<const void *>(&k_tile<true, false, false, true, double>), tile_lds_bytes(pd, true)) != BT_OK ||
-            raise_lds_limit(reinterpret_cast<const void *>(&k_tile<true, false, false, false, double>), tile_lds_bytes(pd, true)) != BT_OK) return BT_EHIP;
+        if (raise_lds_limit(reinterpret_cast<const void *>(&k_update<false, kUpdThreads, double>), nu, pd.dev_id) != BT_OK) return BT_EHIP;
+        if (raise_lds_limit(reinterpret_cast<const void *>(&k_tile<true, false, false, true, double>), tile_lds_bytes(pd, true), pd.dev_id) != BT_OK ||
+            raise_lds_limit(reinterpret_cast<const void *>(&k_tile<true, false, false, false, double>), tile_lds_bytes(pd, true), pd.dev_id) != BT_OK) return BT_EHIP;
     }
     const int mode = solver_mode(pd);
     if (mode == 3) return BT_OK;                     // (the dense solver raises its own limit at launch)
@@ -2519,14 +2517,14 @@ int configure_kernels(const PlanDev &pd) {
                            reinterpret_cast<const void *>(&k_solve_lds<float, true>) };
     if (mode < 2)
         for (int v = 0; v < 2; ++v)
-            if (raise_lds_limit(fns[2 * mode + v], solve_lds_bytes(pd, mode == 0 ? 8 : 4)) != BT_OK) return BT_EHIP;
+            if (raise_lds_limit(fns[2 * mode + v], solve_lds_bytes(pd, mode == 0 ? 8 : 4), pd.dev_id) != BT_OK) return BT_EHIP;
     if (mode == 0 && use_pipe_solver(pd))
-        if (raise_lds_limit(reinterpret_cast<const void *>(&k_solve_pipe<false>), solve_pipe_lds_bytes(pd)) != BT_OK ||
-            raise_lds_limit(reinterpret_cast<const void *>(&k_solve_pipe<true>), solve_pipe_lds_bytes(pd)) != BT_OK)
+        if (raise_lds_limit(reinterpret_cast<const void *>(&k_solve_pipe<false>), solve_pipe_lds_bytes(pd), pd.dev_id) != BT_OK ||
+            raise_lds_limit(reinterpret_cast<const void *>(&k_solve_pipe<true>), solve_pipe_lds_bytes(pd), pd.dev_id) != BT_OK)
             return BT_EHIP;
     if (mode == 0 && use_fused_solver(pd))
-        if (raise_lds_limit(reinterpret_cast<const void *>(&k_solve_fused<false>), solve_fused_lds_bytes(pd, solver_threads())) != BT_OK ||
-            raise_lds_limit(reinterpret_cast<const void *>(&k_solve_fused<true>), solve_fused_lds_bytes(pd, solver_threads())) != BT_OK)
+        if (raise_lds_limit(reinterpret_cast<const void *>(&k_solve_fused<false>), solve_fused_lds_bytes(pd, solver_threads()), pd.dev_id) != BT_OK ||
+            raise_lds_limit(reinterpret_cast<const void *>(&k_solve_fused<true>), solve_fused_lds_bytes(pd, solver_threads()), pd.dev_id) != BT_OK)
             return BT_EHIP;
     return BT_OK;
 }

@@ -212,7 +212,7 @@ int launch_loose_reduce(const PlanDev &pd, const StepArgs &a, bool so, hipStream
     if (so) hipLaunchKernelGGL(lz::k_loose_reduce<true>, dim3(pd.nlz), dim3(lz::kThreads), 0, st, pd, a, rawk);
     else {
         static LdsLimit lds_limit;
-        if (!lds_limit.ensure(reinterpret_cast<const void *>(&lz::k_loose_reduce<false>), lds)) return BT_EHIP;
+        if (!lds_limit.ensure(reinterpret_cast<const void *>(&lz::k_loose_reduce<false>), lds, pd.dev_id)) return BT_EHIP;
         hipLaunchKernelGGL(lz::k_loose_reduce<false>, dim3(pd.nlz), dim3(lz::kThreads), lds, st, pd, a, rawk);
     }
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;

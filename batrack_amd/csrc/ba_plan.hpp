@@ -90,6 +90,7 @@ struct PlanDev {
     // k_loose_reduce / k_loose_update (ba_loose.hip), a workgroup per track, the track's E in LDS over ALL free cameras
     const int32_t *lz_trk, *lz_ptr, *lz_edge, *lz_pair;      // track of loose track l; its edges [lz_ptr[l], lz_ptr[l + 1]): edge id, camera pair
     int nlz;
+    int dev_id;                                              // the device the plan's tables live on (the launchers' per-device caches: no hipGetDevice per launch)
     int wide;                                                // more than kMaxFree free poses: the dense solver (ba_dense.hip); perm is the identity, the packed form is the lower triangle by blocks
     int trk_off;                                             // sharded plan: distinct tracks of the full edge list in front of this rank's first
     int em_self;                                             // some edge has ii == jj (its source-camera E lands on a target row)
@@ -150,6 +151,7 @@ struct bt_plan {
     int pm_ok = 0, sp_ok = 0, sg_n = 0, et_lgts = 0, trk_off = 0;
     int wide = 0;                                             // more than kMaxFree free poses: dense solve, no symbolic factorisation
     int nlz = 0;                                              // loose tracks (set at upload; clones copy it)
+    int dev_id = 0;                                           // the device the tables were uploaded to
     // plans whose pm_edge is written on the device (plan_device.hip): the table's rounds, and what the kernels need of the host's analysis
     int dev_pm = 0;
     int dev_slots = 0;                                        // likewise the [slots][64] arrays and the wave cuts of a 64-track layout

@@ -559,11 +559,11 @@ static int launch_stream_t(const PlanDev &pd, const StepArgs &a, hipStream_t st,
     static std::atomic<int> per_cu_c[kMaxDevices];
     static std::atomic<size_t> per_cu_lds[kMaxDevices];
     DevProps dp;
-    if (!device_props(&dp)) return BT_EHIP;
+    if (!device_props(&dp, pd.dev_id)) return BT_EHIP;
     const int n_cu = dp.n_cu, dslot = dp.dev >= 0 && dp.dev < kMaxDevices ? dp.dev : 0;
     int per_cu = per_cu_lds[dslot].load(std::memory_order_acquire) == lds ? per_cu_c[dslot].load(std::memory_order_relaxed) : 0;
     if (!per_cu) {
-        if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_stream<MODE, NT, PROF>), lds)) return BT_EHIP;
+        if (!lds_limit.ensure(reinterpret_cast<const void *>(&k_stream<MODE, NT, PROF>), lds, pd.dev_id)) return BT_EHIP;
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_stream<MODE, NT, PROF>, 128, lds) != hipSuccess || nb < 1) nb = 1;
         per_cu = nb;

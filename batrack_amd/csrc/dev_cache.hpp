@@ -13,12 +13,11 @@ constexpr int kMaxDevices = 64;
 
 struct DevProps { int dev, n_cu; size_t lds_cu; };
 
-// properties of the CURRENT device (hipGetDevice), read once per device
-inline bool device_props(DevProps *out) {
+// properties of device `dev` (the plan's: PlanDev::dev_id — no runtime call on the launch path; -1: the current device), read once per device
+inline bool device_props(DevProps *out, int dev = -1) {
     static std::atomic<int> n_cu[kMaxDevices];
     static std::atomic<size_t> lds_cu[kMaxDevices];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return false;
     const int slot = dev >= 0 && dev < kMaxDevices ? dev : -1;
     int n = slot >= 0 ? n_cu[slot].load(std::memory_order_acquire) : 0;
     size_t l = slot >= 0 ? lds_cu[slot].load(std::memory_order_relaxed) : 0;
@@ -36,11 +35,10 @@ inline bool device_props(DevProps *out) {
 // one per kernel instantiation (a function-local static of its launcher)
 struct LdsLimit {
     std::atomic<size_t> raised[kMaxDevices];
-    // make `bytes` of dynamic LDS launchable for `func` on the current device
-    bool ensure(const void *func, size_t bytes) {
+    // make `bytes` of dynamic LDS launchable for `func` on device `dev` (-1: the current device; the attribute is set on the current one)
+    bool ensure(const void *func, size_t bytes, int dev = -1) {
         if (bytes <= 48 * 1024) return true;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return false;
         const int slot = dev >= 0 && dev < kMaxDevices ? dev : -1;
         if (slot >= 0 && raised[slot].load(std::memory_order_acquire) >= bytes) return true;
         if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;

@@ -219,6 +219,9 @@ class Plan:
             pass
 
 
+_WS_STREAM = {}            # workspace address -> raw stream it was last handed to a Stepper under
+
+
 def _raw_stream(device):
     """hipStream_t of PyTorch's current stream on `device` (without building a Stream object per call)."""
     import torch
@@ -240,10 +243,17 @@ class Stepper:
         # zero-filled: the accumulators must start clear (bt_ba_workspace_init); every step leaves them clear.  `ws`: the
         # workspace of another stepper whose plan has the same workspace layout (a shifted clone and its source), used on the
         # same stream: every step leaves it as it found it, so the two can take turns
-        if ws is not None and ws.numel() >= max(plan.workspace_bytes, 256) and ws.device == self.device:
+        # (... on the SAME stream: the stream a workspace was last handed out under is remembered, and a stepper created under
+        #  another one gets a workspace of its own instead of racing the queued steps of the first — ADVICE round 5)
+        cur = _raw_stream(self.device)
+        if (ws is not None and ws.numel() >= max(plan.workspace_bytes, 256) and ws.device == self.device
+                and _WS_STREAM.get(ws.data_ptr(), cur) == cur):
             self.ws = ws
         else:
             self.ws = torch.zeros(max(plan.workspace_bytes, 256), dtype=torch.uint8, device=self.device)
+        if len(_WS_STREAM) > 64:
+            _WS_STREAM.clear()
+        _WS_STREAM[self.ws.data_ptr()] = cur
         self._args = _lib.BaArgs()
         self._lib = _lib.lib()
         self._ops = None if _USE_CTYPES else _lib.torch_ops()
