@@ -493,13 +493,17 @@ def main():
             bcall = lambda _=None: bst.step_timed(Bp, Bx, Bm, Bi, Bt, 3, Bw, Bo, Bxo, *bscal, False)
             for _ in range(3):
                 bcall()
-            warm = float(np.median([1e3 * bcall()["tile"] for _ in range(12)]))
+            runs = [bcall() for _ in range(12)]
+            warm = float(np.median([1e3 * r_["tile"] for r_ in runs]))
+            # every kernel of that step ("depth": the back-substitution's pass over the edges, k_edge2u)
+            step_kernels = {k_: round(float(np.median([1e3 * r_[k_] for r_ in runs])), 2) for k_ in runs[0] if np.median([r_[k_] for r_ in runs]) > 0}
             cold = cold_tile_us(None, bcall)
             balg = 40 * bplan.E + 20 * bplan.m + 72 * bplan.n_all
             roofline["large"] = {"workload": f"64 keyframes, {bplan.E} edges, {bplan.m} tracks (make_graph(64, 16384, 8), seed {args.seed})",
                                  "kernel": bplan.jacobian_kernel, "edge_precision": bplan.edge_precision, "algorithmic_bytes": balg,
                                  "kernel_us": round(warm, 2), "achieved": round(balg / (warm * 1e-6) / 1e9, 1), "frac": round(balg / (warm * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "cold_kernel_us": round(cold, 2), "cold_frac": round(balg / (cold * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                                 "cold_kernel_us": round(cold, 2), "cold_frac": round(balg / (cold * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "step_kernel_us": step_kernels}
             del bst, bplan, Bp, Bx, Bt, Bw
         except Exception as e:                                   # (a record beside the headline number: never its failure)
             roofline["large"] = {"error": repr(e)}
