@@ -149,6 +149,9 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     I = bt_plan_info{};
     I.n_buf = n_buf; I.p_tot = p_tot; I.fixedp = fixedp;
     pl->e_all = E;
+    // A plan of a SHARDED solve (the caller named a track range, whatever it covers): the ranks exchange [S | y] block by block of the
+    // factor's pattern, so every rank must arrive at the same pattern — from what all of them can see, the tracks of the whole list.
+    const bool sharded = own_hi > 0;
     if (own_hi <= 0) { own_lo = 0; own_hi = p_tot; }
     if (own_lo < 0 || own_hi > p_tot || own_lo > own_hi) return BT_EINVAL;
     const bool plan_prof = bt::plan_prof();                                        // measurement only: time per phase on stderr
@@ -468,6 +471,27 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         flush(m);
     }
     int32_t src_p = -1, base_p = 0, set_epoch = -1; uint64_t mask_p = 0, mask2_p = 0;         // the previous track's figures: the same again = the same cameras
+    // A tile's camera PAIRS (source frame -> target frame, the fixed frames too: every pair's geometry sits in the tile's LDS table)
+    // are bounded as well: kMaxTilePairs.  The cameras bound them only among the FREE frames — with most of a long trajectory fixed,
+    // 64 tracks of few free cameras each name hundreds of pairs.  Counted per run of tracks with one source frame (tracks come
+    // sorted by patch and a frame's patches are neighbours; a source frame that comes back counts again: the bound may close a
+    // tile early, never late).
+    std::vector<int32_t> pair_stamp(aligned ? (size_t)0 : (size_t)n_buf, -1);
+    int32_t pair_run = 0, run_src = -1;
+    int tile_pairs = 0;
+    auto mark_targets = [&](int32_t k) -> int {                    // the track's targets not yet seen in this run (and now seen)
+        int cnt = 0;
+        if (masks_ok) {
+            const PerPatch &t = pp[pl->kx[(size_t)k]];
+            BT_FOR_TARGETS(t, fr, if (pair_stamp[(size_t)fr] != pair_run) { pair_stamp[(size_t)fr] = pair_run; ++cnt; });
+        } else {
+            for (int32_t sidx = off[(size_t)k]; sidx < off[(size_t)k + 1]; ++sidx) {
+                const int64_t fr = JQ(sidx);
+                if (pair_stamp[(size_t)fr] != pair_run) { pair_stamp[(size_t)fr] = pair_run; ++cnt; }
+            }
+        }
+        return cnt;
+    };
     for (int32_t k = 0; k < m && !aligned; ++k) {
         if (masks_ok && k > 0 && pp[pl->kx[(size_t)k]].src == src_p && pp[pl->kx[(size_t)k]].base == base_p && pp[pl->kx[(size_t)k]].mask == mask_p &&
             pp[pl->kx[(size_t)k]].mask2 == mask2_p) {
@@ -492,8 +516,13 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             }
         }
         }
-        if ((int)trk_set.size() > kTileCamHard) {
-            // a LOOSE track: in no tile (its E does not fit a tile's camera budget); ba_loose.hip walks its edges
+        const int32_t src_k = masks_ok ? pp[pl->kx[(size_t)k]].src : (int32_t)IQ(off[(size_t)k]);
+        if (src_k != run_src) { run_src = src_k; ++pair_run; }
+        int np_new = mark_targets(k);
+        bool too_many_pairs = false;                               // (the track alone: possible only without masks — they hold 128 targets)
+        if (!masks_ok && off[(size_t)k + 1] - off[(size_t)k] > kMaxTilePairs) { ++pair_run; too_many_pairs = mark_targets(k) > kMaxTilePairs; }
+        if ((int)trk_set.size() > kTileCamHard || too_many_pairs) {
+            // a LOOSE track: in no tile (its E does not fit a tile's camera budget, or its pairs a tile's table); ba_loose.hip walks its edges
             if (dstats) return BT_NEED_EDGES;                      // (their edge lists come from the host's grouped order)
             if (tcap < kLanes) {                                   // (k_etile's stored per-tile sums have no place for them: 64-track tiles, atomics)
                 if (tcap_retry) return BT_EUNSUPPORTED;
@@ -505,12 +534,18 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             pl->trk_loc[(size_t)k] = -1;
             trk0 = k + 1;
             src_p = -1;                                            // (the next track starts a tile: its cameras are looked at afresh)
+            tile_pairs = 0; ++pair_run;
             continue;
         }
         int add = 0;
         for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) ++add;
         const int limit = std::max<int>(kTileCamSoft, (int)trk_set.size());
-        if (k - trk0 >= tcap || (k > trk0 && (int)tile_set.size() + add > limit)) close_tile(k);
+        if (k - trk0 >= tcap || (k > trk0 && ((int)tile_set.size() + add > limit || tile_pairs + np_new > kMaxTilePairs))) {
+            close_tile(k);
+            tile_pairs = 0; ++pair_run;
+            np_new = mark_targets(k);                              // (all of the track's pairs are new to the tile it opens)
+        }
+        tile_pairs += np_new;
         for (int32_t c : trk_set) if (stamp[(size_t)c] != epoch) { stamp[(size_t)c] = epoch; tile_set.push_back(c); }
         set_epoch = epoch;
     }
@@ -797,7 +832,11 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // ba.py:321) or form a camera pair with both ends free (B, ba.py:279-282).
     std::vector<std::vector<uint8_t>> nz((size_t)n, std::vector<uint8_t>((size_t)n, 0));
     for (int64_t c = 0; c < n; ++c) nz[(size_t)c][(size_t)c] = 1;
-    for (int32_t t = 0; t < T; ++t) {
+    // One plan for the whole list: a TILE's cameras couple pairwise — more than its tracks' own couplings where the tracks of a tile
+    // see different cameras, and free to have (the tile's product is formed over all of them).  A sharded plan must not: the tiles
+    // are this rank's, the pattern is everybody's — there the tracks' own couplings only, of this rank's tracks as of the others'
+    // (what a tile adds outside them is a sum of exact zeros: an E row of a camera a track does not see is zero).
+    for (int32_t t = 0; t < T && !sharded; ++t) {
         const int32_t c0 = pl->tile_cam0[(size_t)t], nc = pl->tile_ncam[(size_t)t];
         for (int32_t u = 0; u < nc; ++u)
             for (int32_t v = 0; v <= u; ++v)
@@ -822,18 +861,17 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
                 for (size_t v = 0; v <= u; ++v) nz[(size_t)cset[u]][(size_t)cset[v]] = 1;
         }
     }
-    if (E_own != E && dstats && dstats->sliced) {
-        // (the other ranks' tracks: the pattern of the whole list, reduced on the device — k_plan_pattern)
+    if (sharded && dstats && dstats->sliced) {
+        // (the pattern of the whole list, reduced on the device — k_plan_pattern)
         if (!dstats->pattern) return BT_NEED_EDGES;
         for (int64_t u = 0; u < n; ++u)
             for (int64_t v = 0; v <= u; ++v)
                 if ((dstats->pattern[(size_t)u * dstats->pattern_words + (size_t)(v >> 5)] >> (v & 31)) & 1u) nz[(size_t)u][(size_t)v] = 1;
-    } else if (E_own != E && dstats) {
+    } else if (sharded && dstats) {
         // (the same from the device's table: a track's cameras are its source frame and the frames of its mask)
         std::vector<int32_t> cset;
         int32_t src_b = -1; uint64_t mask_b = 0, mask2_b = 0;
         for (int64_t p = kmin; p <= kmax; ++p) {
-            if (p >= own_lo && p < own_hi) continue;
             const PatchStat &d = dstats->tab[(size_t)(p - dstats->tab_lo)];
             if (d.cnt <= 0) continue;
             if (d.src == src_b && d.mask == mask_b && d.mask2 == mask2_b) continue;          // (the same cameras as the track before: nothing new)
@@ -849,14 +887,14 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             for (size_t u = 0; u < cset.size(); ++u)
                 for (size_t v = 0; v <= u; ++v) nz[(size_t)cset[u]][(size_t)cset[v]] = 1;
         }
-    } else if (E_own != E) {
-        // sharded: tracks owned by other ranks contribute blocks to the all-reduced system too.
-        // Their pattern: every camera pair of an edge, and all pairs among the free cameras of a track.
+    } else if (sharded) {
+        // from the edges: all pairs among the free cameras of a track (the camera pair of an edge is among them), every track
+        // of the list
         std::vector<int32_t> toff((size_t)p_tot + 1, 0);
-        for (int64_t e = 0; e < E; ++e) if (!owned(e)) toff[(size_t)KK(e) + 1]++;
+        for (int64_t e = 0; e < E; ++e) toff[(size_t)KK(e) + 1]++;
         for (int64_t p = 0; p < p_tot; ++p) toff[(size_t)p + 1] += toff[(size_t)p];
-        std::vector<int32_t> tord((size_t)(E - E_own) + 1), tcur(toff.begin(), toff.end() - 1);
-        for (int64_t e = 0; e < E; ++e) if (!owned(e)) tord[(size_t)tcur[(size_t)KK(e)]++] = (int32_t)e;
+        std::vector<int32_t> tord((size_t)E + 1), tcur(toff.begin(), toff.end() - 1);
+        for (int64_t e = 0; e < E; ++e) tord[(size_t)tcur[(size_t)KK(e)]++] = (int32_t)e;
         std::vector<int32_t> cset;
         for (int64_t p = 0; p < p_tot; ++p) {
             if (toff[(size_t)p] == toff[(size_t)p + 1]) continue;

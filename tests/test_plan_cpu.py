@@ -469,3 +469,46 @@ def test_aligned_slots_make_a_ragged_graph_slot_uniform(drop):
         # nothing missing: the aligned layout IS the old one (a track's s-th edge in slot s) wherever no observation repeats
         full = nslot == 8
         assert full.mean() > 0.8
+
+
+def test_a_mostly_fixed_trajectory_stays_inside_the_pair_table_of_a_tile():
+    """With most of a long trajectory fixed, the free cameras of a track are few and 64 tracks fill a tile long before its camera budget
+    — but every (source, target) pair of the tile, fixed frames included, has its geometry in the tile's table (kMaxTilePairs = 192).
+    The planner closes tiles on the pairs too; such lists used to be BT_EUNSUPPORTED (found by tests/test_gpu_fuzz.py)."""
+    rng = np.random.default_rng(3)
+    N, M = 100, 3
+    kk = np.repeat(np.arange(N * M, dtype=np.int64), 9)
+    ii = kk // M
+    jj = np.clip(ii + rng.integers(-6, 7, kk.size), 0, N - 1).astype(np.int64)
+    for fixedp in (99, 97, 50, 1):
+        pl = Plan(ii, jj, kk, N, N * M, fixedp, upload=False)
+        assert pl.n == N - fixedp
+        tp0, tnp = pl.array("tile_pair0"), pl.array("tile_npair")
+        assert tnp.max() <= 192 and tnp.sum() >= len(set(zip(ii.tolist(), jj.tolist())))
+        assert tp0[-1] + tnp[-1] == tnp.sum()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_ranks_of_a_sharded_solve_agree_on_the_pattern_of_an_irregular_graph(world):
+    """The ranks exchange [S | y] block by block of the factor's pattern (bt_ba_reduce_pack / _push), so the plans of all ranks —
+    each laying out only its own tracks — must hold the same pattern, order and factor structure.  On a banded graph the cameras of a
+    tile are the cameras of each of its tracks and anything agrees; on an irregular one a tile couples more than its tracks do, and a
+    rank's own tiles used to leak into its pattern (found by tests/test_gpu_fuzz_sharded.py: the all-reduce sizes differed)."""
+    from batrack_amd.parallel import partition_tracks, plan_range
+    rng = np.random.default_rng(17)
+    N, M = 40, 5
+    kk = np.repeat(np.arange(N * M, dtype=np.int64), rng.integers(1, 9, N * M))
+    ii = kk // M
+    near = np.clip(ii + rng.integers(-4, 5, kk.size), 0, N - 1)
+    jj = np.where(rng.random(kk.size) < 0.2, rng.integers(0, N, kk.size), near).astype(np.int64)
+    ranges = partition_tracks(kk, world)
+    plans = [Plan(ii, jj, kk, N, N * M, 2, upload=False, own=plan_range(r, N * M)) for r in ranges]
+    assert sum(p.E for p in plans) == kk.size
+    ref = plans[0]
+    for p in plans[1:]:
+        assert p.n == ref.n and p.nnz_blocks == ref.nnz_blocks
+        for name in ("perm", "col_ptr", "row_idx"):
+            assert np.array_equal(p.array(name), ref.array(name)), name
+    # one plan for the whole list may couple more (its tiles' cameras pairwise), never less
+    full = Plan(ii, jj, kk, N, N * M, 2, upload=False)
+    assert full.nnz_blocks >= ref.nnz_blocks
