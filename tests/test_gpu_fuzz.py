@@ -103,7 +103,8 @@ def check(seed, big=False):
     d, fixedp, so, loss, wkey, desc = draw(seed, big)
     ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"],
                          d["bounds"], fixedp=fixedp, structure_only=so, loss=loss, want_system=True)
-    o = HipProblem(d).raw_step(wkey, fixedp, so=so, loss=loss)
+    hp = HipProblem(d)
+    o = hp.raw_step(wkey, fixedp, so=so, loss=loss)
     plan = o["plan"]
     f32 = plan.edge_precision != 8
     desc += f" | n={plan.n} tiles={plan.tiles} kernel {plan.jacobian_kernel} f{'32' if f32 else '64'}"
@@ -123,7 +124,8 @@ def check(seed, big=False):
         # (a float32 edge pass FORCED onto graphs of a few tiles — BT_FORCE, measurement only — sums in other orders than the oracle's
         #  float32 run: up to three times its error on systems of a handful of edges)
         k32 = 10.0 if FORCED_F32 else 2.0
-        ok_S = max(2e-5 if FORCED_F32 else 4e-6, k32 * errs["ref32_S"]) if f32 else max(1e-9, 1e-3 * errs["ref32_S"])
+        # (2e-5: the gate of the hub-track case of tests/test_gpu_parity.py — tiles of 40 cameras sum their float32 rows in long chains)
+        ok_S = max(2e-5, k32 * errs["ref32_S"]) if f32 else max(1e-9, 1e-3 * errs["ref32_S"])
         ok_y = max(2e-5, k32 * errs["ref32_y"]) if f32 else max(5e-9, 1e-3 * errs["ref32_y"])
         assert errs["S"] < ok_S and errs["y"] < ok_y, (desc, errs)
         assert (o["status"] != 0) == ref["failed"] or o["status"] in (0, 1), (desc, o["status"], ref["failed"])
@@ -137,6 +139,27 @@ def check(seed, big=False):
     if solved and not ref["failed"]:
         errs["upd_pose"] = update_err(o["poses_out"], ref["poses_out"], d["poses"])
         errs["upd_disp"] = update_err(o["patches_out"][:, 2], ref["patches_out"][:, 2], d["patches"][:, 2])
+    # The same plan and workspace again: the OTHER step kind, then the first kind once more — every step must leave the workspace as
+    # it found it (accumulators, counters, per-tile records), whatever ran before.
+    import torch
+    st = o["stepper"]
+    P = hp.poses[0].contiguous(); pat = hp.patches.reshape(-1, 3).contiguous(); tg = hp.t3[0]
+    for so2 in ((not so) or plan.n == 0, so or plan.n == 0):
+        pout = torch.empty_like(pat)
+        Pout = P if so2 else torch.empty_like(P)
+        st.step(P, pat, hp.mono.reshape(-1), hp.intr[0], tg, tg.stride(0), hp.w[wkey][0].contiguous(), Pout, pout, hp.bounds,
+                1e-4, 10.0, 0.05, loss, so2)
+        torch.cuda.synchronize()
+        r2 = ref if so2 == (so or plan.n == 0) else oracle.ba_step(
+            d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"], d["bounds"],
+            fixedp=fixedp, structure_only=so2, loss=loss)
+        r32 = ref32 if so2 == (so or plan.n == 0) else oracle.ba_step(
+            d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"], d["bounds"],
+            fixedp=fixedp, structure_only=so2, loss=loss, dtype=np.float32)
+        hp2, hd2 = rel(r32["poses_out"], r2["poses_out"]), rel(r32["patches_out"], r2["patches_out"])
+        ep2, ed2 = rel(Pout.cpu().numpy(), r2["poses_out"]), rel(pout.cpu().numpy(), r2["patches_out"])
+        assert ep2 < max(floor, k32 * hp2) and ed2 < max(floor, k32 * hd2), (desc, "again, structure-only" if so2 else "again, poses", ep2, ed2, hp2, hd2)
+        assert st.system.numel() == 0 or float(st.system.abs().max()) == 0.0, (desc, "accumulators not clear")
     return desc, errs
 
 

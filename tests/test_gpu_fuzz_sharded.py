@@ -2,7 +2,7 @@
 range of the list (the device planner's sliced analysis where it applies, the host's otherwise), reduces its tracks, exchanges the
 packed system (both exchange paths, alternating by seed) and solves; the disparities are gathered.  Rank 0 compares with the oracle.
 
-As a script: python tests/test_gpu_fuzz_sharded.py [first_seed] [count] [world]"""
+As a script: python tests/test_gpu_fuzz_sharded.py [first_seed] [count] [world] [big]"""
 import os
 import sys
 
@@ -18,7 +18,7 @@ sys.path[:0] = [os.path.dirname(HERE), HERE]
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, seeds, out):
+def _worker(rank, world, port, seeds, out, big=False):
     sys.path[:0] = [os.path.dirname(HERE), HERE]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,7 +31,7 @@ def _worker(rank, world, port, seeds, out):
         dev = torch.device("cuda:0")
         lines = []
         for seed in seeds:
-            d, fixedp, so, loss, wkey, desc = F.draw(seed)
+            d, fixedp, so, loss, wkey, desc = F.draw(seed, big)
             T = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
             poses, patches, mono, intr, t3, w = (T(d[k]) for k in ("poses", "patches", "mono", "intrinsics", "targets3", wkey))
             ii, jj, kk = (torch.as_tensor(d[k], device=dev) for k in ("ii", "jj", "kk"))
@@ -67,11 +67,11 @@ def _worker(rank, world, port, seeds, out):
         dist.destroy_process_group()
 
 
-def run(seeds, world):
+def run(seeds, world, big=False):
     port = 29900 + (os.getpid() % 1000)
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, list(seeds), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, list(seeds), out, big), nprocs=world, join=True)
     lines = [l for r in range(world) for l in out.get(r, [])]
     return lines
 
@@ -87,7 +87,7 @@ if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     world = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-    lines = run(range(first, first + count), world)
+    lines = run(range(first, first + count), world, big=len(sys.argv) > 4 and sys.argv[4] == "big")
     bad = [l for l in lines if not l.startswith("ok")]
     for l in lines:
         print(l)
