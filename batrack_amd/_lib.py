@@ -188,6 +188,10 @@ def lib():
     L.bt_plan_create_shifted_any.argtypes = [ctypes.POINTER(vp), i32, vp, vp, vp, i64, i64, i64, i64, ctypes.POINTER(i32), ctypes.POINTER(vp)]
     L.bt_plan_create_shifted_spec.restype = i32
     L.bt_plan_create_shifted_spec.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, vp, ctypes.POINTER(vp)]
+    L.bt_plan_preshift.restype = i32
+    L.bt_plan_preshift.argtypes = [vp, i64, ctypes.POINTER(vp)]
+    L.bt_plan_spec_bind.restype = i32
+    L.bt_plan_spec_bind.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, vp]
     L.bt_plan_spec_confirm.restype = i32
     L.bt_plan_spec_confirm.argtypes = [vp]
     L.bt_plan_destroy.restype = None

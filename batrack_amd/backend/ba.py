@@ -32,6 +32,7 @@ _CACHE = {}          # key -> (stepper, (weakref ii, jj, kk))
 _CACHE_MAX = 8
 _PENDING = {}        # key -> (future, result box, (ii, jj, kk)): plans being built by prefetch_plan
 _LAST_SHIFT = [None]  # frame shift of the last plan that was made as a shifted copy
+_PRE = {}            # id(source stepper) -> (source stepper, its clone for the NEXT list, made ahead: Plan.preshift) — a handful at most
 _WORKER = None       # one long-lived host thread (the planner keeps edge-sized scratch per thread)
 
 
@@ -42,10 +43,12 @@ def _key(ii, jj, kk, n_buf, p_tot, fixedp, device):
 
 def _store(key, stepper, ii, jj, kk):
     if len(_CACHE) >= _CACHE_MAX:
-        _CACHE.pop(next(iter(_CACHE)))
+        old = _CACHE.pop(next(iter(_CACHE)))
+        _PRE.pop(id(old[0]), None)                # (a clone made ahead from a plan that has left the cache is of no use either)
     _CACHE[key] = (stepper, tuple(weakref.ref(t) for t in (ii, jj, kk)))
 
 
+_REPEAT = [False]    # the call in progress found the plan of the call before it in place (not the first call of an update())
 _LAST = [None]       # (ii, jj, kk, versions, fixedp, n_buf, p_tot, device, stepper) of the last call: an update() makes 2*ITER calls on one list
 
 
@@ -56,7 +59,9 @@ def _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, device):
     last = _LAST[0]
     if (last is not None and last[0] is ii and last[1] is jj and last[2] is kk and last[3] == (ii._version, jj._version, kk._version, ii.data_ptr(), jj.data_ptr(), kk.data_ptr())
             and last[4] == fixedp and last[5] == n_buf and last[6] == p_tot and last[7] == device):
+        _REPEAT[0] = True
         return last[8]
+    _REPEAT[0] = False
     stepper = _plan_lookup(ii, jj, kk, n_buf, p_tot, fixedp, device)
     _LAST[0] = (ii, jj, kk, (ii._version, jj._version, kk._version, ii.data_ptr(), jj.data_ptr(), kk.data_ptr()), fixedp, n_buf, p_tot, device, stepper)
     return stepper
@@ -80,9 +85,36 @@ def _plan_lookup(ii, jj, kk, n_buf, p_tot, fixedp, device):
         if "error" in box and not isinstance(box["error"], Exception):
             raise box["error"]                    # KeyboardInterrupt and the like; ordinary errors are re-raised by the build below
     pl, ws = _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, True)
-    stepper = Stepper(pl, device, ws)
+    stepper = pl if isinstance(pl, Stepper) else Stepper(pl, device, ws)
     _store(key, stepper, ii, jj, kk)
     return stepper
+
+
+def _speculate(ii, jj, kk, n_buf, p_tot, fixedp, made_ahead_only=False):
+    """The plan of a list ASSUMED to be an earlier one moved up by the shift that was right last time — no synchronisation, no host
+    wait, `confirm()` after the first step: a clone made ahead (Plan.preshift, with its stepper) bound to the list by one comparison
+    kernel, else a clone made here (Plan.shifted_spec).  (plan or stepper, workspace to share) or None."""
+    if _LAST_SHIFT[0] is None or os.environ.get("BT_PLAN_SHIFT", "1") == "0" or os.environ.get("BT_PLAN_SPECULATE", "1") == "0":
+        return None
+    E, nb, pt, fp = ii.numel(), int(n_buf), int(p_tot), int(fixedp)
+    try:
+        cached = list(_CACHE.values())
+    except RuntimeError:
+        return None
+    for st, _ in reversed(cached):
+        inf = st.plan.info
+        if (inf["E"] == E and inf["n_buf"] == nb and inf["p_tot"] == pt and fp - inf["fixedp"] == _LAST_SHIFT[0]
+                and not st.plan.__dict__.get("speculative")):
+            pre = _PRE.pop(id(st), None)
+            if pre is not None and pre[0] is st and pre[1].plan.info["fixedp"] == fp and pre[1].plan.bind(ii, jj, kk, n_buf, p_tot, fixedp):
+                return pre[1], st.ws          # made (stepper and all) while the previous update()'s steps ran: only the comparison is left
+            if made_ahead_only:
+                return None
+            pl = Plan.shifted_spec(st.plan, ii, jj, kk, n_buf, p_tot, fixedp)
+            if pl is not None:
+                return pl, st.ws
+            return None
+    return None
 
 
 def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync, speculate=True):
@@ -95,20 +127,10 @@ def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync, speculate=True):
     last time (Plan.shifted_spec: the clone is enqueued with no synchronisation and no host wait, the comparison that proves the
     assumption runs on the GPU beside it); BA_rgbd_droid confirms after it has enqueued the call's step and repeats the call on a
     properly built plan where the assumption was wrong."""
-    if speculate and _LAST_SHIFT[0] is not None and os.environ.get("BT_PLAN_SHIFT", "1") != "0" and os.environ.get("BT_PLAN_SPECULATE", "1") != "0":
-        E, nb, pt, fp = ii.numel(), int(n_buf), int(p_tot), int(fixedp)
-        try:
-            cached = list(_CACHE.values())
-        except RuntimeError:
-            cached = []
-        for st, _ in reversed(cached):
-            inf = st.plan.info
-            if (inf["E"] == E and inf["n_buf"] == nb and inf["p_tot"] == pt and fp - inf["fixedp"] == _LAST_SHIFT[0]
-                    and not st.plan.__dict__.get("speculative")):
-                pl = Plan.shifted_spec(st.plan, ii, jj, kk, n_buf, p_tot, fixedp)
-                if pl is not None:
-                    return pl, st.ws
-                break
+    if speculate:
+        got = _speculate(ii, jj, kk, n_buf, p_tot, fixedp)
+        if got is not None:
+            return got
     if sync:
         # once, here: the index tensors must be complete before any of the builds below reads them on the plan stream
         # (Plan.shifted may return before it gets to synchronise, so nothing below relies on it having done so)
@@ -136,6 +158,32 @@ def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync, speculate=True):
     return Plan(ii, jj, kk, n_buf, p_tot, fixedp, sync=False), None
 
 
+def _preshift(stepper):
+    """Make the clone for the list the NEXT update() will most likely bring — this plan's, moved up by the shift that was right last
+    time — now, while this update()'s steps run: called after a step of a confirmed plan has been enqueued on a call that found its
+    plan in place (the second call of an update(): the host is ahead of the GPU there, and the first call of the next update(),
+    which has the GPU idle behind it, is left with one comparison kernel).  Once per plan."""
+    if stepper.__dict__.get("_pre_tried"):
+        return
+    df = _LAST_SHIFT[0]
+    if df is None or stepper.plan.__dict__.get("speculative"):
+        return
+    stepper._pre_tried = True
+    if os.environ.get("BT_PLAN_SHIFT", "1") == "0" or os.environ.get("BT_PLAN_SPECULATE", "1") == "0" or os.environ.get("BT_PLAN_PRESHIFT", "1") == "0":
+        return
+    pl = Plan.preshift(stepper.plan, df)
+    if pl is not None:
+        while len(_PRE) >= 3:
+            _PRE.pop(next(iter(_PRE)))
+        # (the clone shares its source's workspace, as a clone made in the call does: same layout, same stream, taking turns)
+        _PRE[id(stepper)] = (stepper, Stepper(pl, stepper.device, stepper.ws))
+        # ... and the room the next update()'s plan will need in the cache is made now (destroying a plan is not free either)
+        if len(_CACHE) >= _CACHE_MAX:
+            old = next(iter(_CACHE))
+            if _CACHE[old][0] is not stepper:
+                _PRE.pop(id(_CACHE.pop(old)[0]), None)
+
+
 def _discard(stepper):
     """A plan whose speculation failed: out of every cache (and the shift that was assumed with it)."""
     for k in [k for k, (st, _) in list(_CACHE.items()) if st is stepper]:
@@ -143,6 +191,7 @@ def _discard(stepper):
     if _LAST[0] is not None and _LAST[0][8] is stepper:
         _LAST[0] = None
     _LAST_SHIFT[0] = None
+    _PRE.clear()                                 # (clones made ahead under the shift that just proved wrong)
 
 
 def _confirm(stepper):
@@ -193,6 +242,13 @@ def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True
     if key in _CACHE or key in _PENDING:
         return
     _lib.lib()
+    # A clone made ahead for exactly this list (Plan.preshift, during the previous update()): bound here and now, on the caller's
+    # thread — one comparison kernel on the stream that made the list — and the first BA call finds its plan in the cache (it
+    # confirms after its first step like any speculative plan; by then the verdict has long arrived).
+    got = _speculate(ii, jj, kk, n_buf, p_tot, fixedp, made_ahead_only=True)
+    if got is not None:
+        _store(key, got[0], ii, jj, kk)
+        return
     ready = torch.cuda.Event()
     caller_stream = torch.cuda.current_stream(dev)
     ready.record(caller_stream)                                # the indices are complete once this has passed
@@ -226,6 +282,7 @@ def clear_plan_cache():
     for fut, _, _ in list(_PENDING.values()):
         fut.result()
     _PENDING.clear()
+    _PRE.clear()
     _CACHE.clear()
     _LAST[0] = None
 
@@ -307,6 +364,8 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
             # the list was no shifted copy after all: what was just enqueued is void (the inputs are untouched) — once more, properly
             return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda_in, ii, jj, kk, bounds,
                                  ep=ep, PRINT=False, fixedp=fixedp, structure_only=structure_only, loss=loss, alpha=alpha)
+        if _REPEAT[0]:
+            _preshift(stepper)                   # (behind this call's launches: the clone for the next update()'s list)
         return (poses, out_patches) if so else (SE3(poses_out), out_patches)
     Pc = P.contiguous()
     pat = patches.reshape(p_tot, 3).contiguous()
@@ -336,6 +395,8 @@ def BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targ
     if stepper.plan.__dict__.get("speculative") and not _confirm(stepper):
         return BA_rgbd_droid(poses, patches, patches_monodisp, intrinsics, targets_2d, targets_disp, weights, lmbda_in, ii, jj, kk, bounds,
                              ep=ep, PRINT=False, fixedp=fixedp, structure_only=structure_only, loss=loss, alpha=alpha)
+    if _REPEAT[0]:
+        _preshift(stepper)
     out_patches = patches_out.view(1, p_tot, 3, 1, 1)
     if so:
         return poses, out_patches

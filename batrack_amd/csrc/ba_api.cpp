@@ -355,6 +355,7 @@ static void mark_launch(const bt_plan *pl, void *stream) {
 
 static int check(const bt_plan *pl, const bt_ba_args *a, const void *ws) {
     if (!pl || !a || !ws || !pl->dev_base) return BT_EINVAL;
+    if (pl->spec_unbound) return BT_EINVAL;                    // (a clone made ahead of its list, never given it: bt_plan_spec_bind)
     if (!a->poses || !a->patches || !a->mono_disp || !a->intrinsics || !a->patches_out) return BT_EINVAL;
     if (pl->info.E > 0 && (!a->targets || !a->weights || a->target_stride < 2)) return BT_EINVAL;
     if (a->loss < BT_LOSS_TRIVIAL || a->loss > BT_LOSS_CAUCHY) return BT_EINVAL;
@@ -481,9 +482,11 @@ static int clone_shifted(const bt_plan *src, const uint64_t *d_words, int64_t E,
     auto I32 = [&](size_t off) { return reinterpret_cast<int32_t *>(nb + off); };
     int rc = BT_OK;
     // the tables as they are, the new packed edge list behind them, then the ones that hold absolute frame / patch numbers
-    if (hipMemcpyAsync(nb, ob, src->pk_off, hipMemcpyDeviceToDevice, cs) != hipSuccess ||
-        hipMemcpyAsync(nb + pl->pk_off, d_words, (size_t)E * sizeof(uint64_t), hipMemcpyDeviceToDevice, cs) != hipSuccess)
-        rc = BT_EHIP;
+    // (d_words null — a clone made ahead of its list, bt_plan_preshift: the list it expects, the source's words moved by the shift)
+    if (hipMemcpyAsync(nb, ob, src->pk_off, hipMemcpyDeviceToDevice, cs) != hipSuccess) rc = BT_EHIP;
+    else if (d_words) { if (hipMemcpyAsync(nb + pl->pk_off, d_words, (size_t)E * sizeof(uint64_t), hipMemcpyDeviceToDevice, cs) != hipSuccess) rc = BT_EHIP; }
+    else rc = launch_words_add(reinterpret_cast<const uint64_t *>(ob + src->pk_off), ((uint64_t)dk << 32) | ((uint64_t)di << 16) | (uint64_t)di,
+                               reinterpret_cast<uint64_t *>(nb + pl->pk_off), E, cs);
     if (rc == BT_OK)
         rc = launch_plan_shift(I32(O.kx), (int)pl->info.m, I32(O.tkx), (int)pl->info.tiles * kLanes, I32(O.tij), pl->n_tile_ij, I32(O.pi), I32(O.pj),
                                (int)pl->info.pairs, reinterpret_cast<const uint32_t *>(ob + O.ab), reinterpret_cast<uint32_t *>(nb + O.ab), I32(O.ar),
@@ -511,13 +514,16 @@ static int clone_shifted(const bt_plan *src, const uint64_t *d_words, int64_t E,
 // bt_plan_spec_confirm right after its first step; sixteen unconfirmed speculative plans at a time are sixteen more than the
 // caller has)
 struct SpecSlots {
-    int *h = nullptr;                                                        // pinned, mapped: the comparison kernel writes its verdict there
+    int *h = nullptr;                                                        // pinned, mapped: the comparison kernel writes its verdict there (4 ints a slot)
+    unsigned *tickets = nullptr;                                             // device: one counter a slot (k_match_done's last-workgroup ticket)
     hipEvent_t ev_in = nullptr;                                              // orders the plan stream behind the caller's stream
     unsigned next = 0;
     bool ensure() {
-        if (h && ev_in) return true;
-        return (h || hipHostMalloc(reinterpret_cast<void **>(&h), 16 * 2 * sizeof(int), hipHostMallocMapped) == hipSuccess) &&
-               (ev_in || hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess);
+        if (h && ev_in && tickets) return true;
+        if (!h) { if (hipHostMalloc(reinterpret_cast<void **>(&h), 16 * 4 * sizeof(int), hipHostMallocMapped) != hipSuccess) return false; std::memset(h, 0, 16 * 4 * sizeof(int)); }
+        if (!tickets && (hipMalloc(reinterpret_cast<void **>(&tickets), 16 * sizeof(unsigned)) != hipSuccess ||
+                         hipMemset(tickets, 0, 16 * sizeof(unsigned)) != hipSuccess)) return false;
+        return ev_in || hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess;
     }
 };
 static SpecSlots &spec_slots() { static SpecSlots s; return s; }
@@ -530,7 +536,7 @@ int bt_plan_create_shifted_spec(const bt_plan *src, const int64_t *ii, const int
     if (!src || !ii || !jj || !kk || E <= 0) return BT_EINVAL;
     if (n_buf > 32768 || p_tot > (int64_t)0x7fffffff || n_buf <= 0 || p_tot % n_buf != 0) return BT_NO_MATCH;
     if (!src->dev_base || !src->pk_off || src->e_all != E || src->info.E != E || src->info.n_buf != n_buf || src->info.p_tot != p_tot) return BT_NO_MATCH;
-    if (src->spec_ev) return BT_NO_MATCH;                                        // (an unconfirmed speculation is no source)
+    if (src->spec_ev || src->spec_epoch || src->spec_unbound) return BT_NO_MATCH;   // (an unconfirmed speculation is no source)
     const int64_t di = fixedp - src->info.fixedp, dk = di * (p_tot / n_buf);
     // every number the clone's tables will hold stays inside the caller's buffers, whatever the new list turns out to be
     if (di <= 0 || di >= 32768 || src->info.n_all + di > n_buf || src->k_hi < 0 || src->k_hi + dk >= p_tot) return BT_NO_MATCH;
@@ -543,7 +549,7 @@ int bt_plan_create_shifted_spec(const bt_plan *src, const int64_t *ii, const int
         std::lock_guard<std::mutex> g(spec_mutex());
         SpecSlots &ss = spec_slots();
         if (!ss.ensure()) return BT_ENOMEM;
-        h_flag = ss.h + 2 * (ss.next++ % 16);
+        h_flag = ss.h + 4 * (ss.next++ % 16);
         // the index tensors are complete when `in_stream` gets here: the plan stream waits for that, the host does not
         if (hipEventRecord(ss.ev_in, static_cast<hipStream_t>(in_stream)) != hipSuccess || hipStreamWaitEvent(cs, ss.ev_in, 0) != hipSuccess) {
             if (hipStreamSynchronize(static_cast<hipStream_t>(in_stream)) != hipSuccess) return BT_EHIP;
@@ -566,8 +572,74 @@ int bt_plan_create_shifted_spec(const bt_plan *src, const int64_t *ii, const int
     return BT_OK;
 }
 
+// The two halves of bt_plan_create_shifted_spec apart.  The caller's window moves by the same number of frames update() after
+// update(): the clone for the NEXT list can be made while the steps of the current one run (its tables depend on the source and
+// the shift only), and what is left for the call that brings the list — the first of an update(), with the GPU idle behind it — is
+// the comparison kernel.
+int bt_plan_preshift(const bt_plan *src, int64_t df, bt_plan **out) {
+    if (!out) return BT_EINVAL;
+    *out = nullptr;
+    if (!src) return BT_EINVAL;
+    const int64_t n_buf = src->info.n_buf, p_tot = src->info.p_tot, E = src->e_all;
+    if (!src->dev_base || !src->pk_off || E <= 0 || src->info.E != E || src->spec_ev || src->spec_epoch || src->spec_unbound) return BT_NO_MATCH;
+    if (n_buf <= 0 || n_buf > 32768 || p_tot > (int64_t)0x7fffffff || p_tot % n_buf != 0) return BT_NO_MATCH;
+    const int64_t dk = df * (p_tot / n_buf);
+    if (df <= 0 || df >= 32768 || src->info.n_all + df > n_buf || src->k_hi < 0 || src->k_hi + dk >= p_tot) return BT_NO_MATCH;
+    bt_plan *pl = nullptr;
+    const int rc = clone_shifted(src, nullptr, E, src->info.fixedp + df, df, dk, copy_stream(), &pl);
+    if (rc != BT_OK) return rc;
+    pl->spec_unbound = 1;
+    *out = pl;
+    return BT_OK;
+}
+
+int bt_plan_spec_bind(bt_plan *pl, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
+                      int64_t fixedp, void *in_stream) {
+    if (!pl || !ii || !jj || !kk) return BT_EINVAL;
+    if (!pl->spec_unbound || !pl->dev_base) return BT_EINVAL;
+    if (pl->e_all != E || pl->info.n_buf != n_buf || pl->info.p_tot != p_tot || pl->info.fixedp != fixedp) return BT_NO_MATCH;
+    ApiTick tick;
+    int *h_flag;
+    unsigned *ticket;
+    int epoch;
+    {
+        std::lock_guard<std::mutex> g(spec_mutex());
+        SpecSlots &ss = spec_slots();
+        if (!ss.ensure()) return BT_ENOMEM;
+        const unsigned slot = ss.next++ % 16;
+        h_flag = ss.h + 4 * slot; ticket = ss.tickets + slot;
+        epoch = (int)((ss.next & 0x3fffffffu) | 0x40000000u);          // (never 0, never the slot's previous one)
+    }
+    h_flag[0] = 0; h_flag[1] = 0; h_flag[2] = 0;
+    // the list against the one the clone was made for (its own packed words): ONE launch, on the stream that made the index tensors
+    // and will run the step — no cross-stream order to set up, no event to record (the verdict is polled: bt_plan_spec_confirm)
+    const uint64_t *own = reinterpret_cast<const uint64_t *>(static_cast<const char *>(pl->dev_base) + pl->pk_off);
+    if (launch_match_done(ii, jj, kk, E, n_buf, p_tot, own, h_flag, ticket, epoch, in_stream) != BT_OK) return BT_EHIP;
+    tick("bind: comparison launched");
+    pl->spec_flag = h_flag; pl->spec_epoch = epoch; pl->spec_stream = in_stream; pl->spec_unbound = 0;
+    return BT_OK;
+}
+
 int bt_plan_spec_confirm(bt_plan *pl) {
     if (!pl) return BT_EINVAL;
+    if (pl->spec_unbound) return BT_NO_MATCH;                    // (never given its list)
+    if (pl->spec_epoch) {
+        // (bt_plan_spec_bind: the comparison ran in front of the step that was just enqueued; its last workgroup wrote the epoch)
+        volatile int *f = pl->spec_flag;
+        const int want = pl->spec_epoch;
+        bool done = false;
+        for (int spins = 0; spins < (1 << 22) && !done; ++spins) done = f[2] == want;
+        if (!done) {                                              // (a GPU far behind: wait for the stream instead of spinning on)
+            if (hipStreamSynchronize(static_cast<hipStream_t>(pl->spec_stream)) != hipSuccess) return BT_EHIP;
+            done = f[2] == want;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const int differs = f[0], bad = f[1];
+        pl->spec_epoch = 0; pl->spec_flag = nullptr; pl->spec_stream = nullptr;
+        if (!done) return BT_EHIP;
+        if (bad) return BT_EINVAL;
+        return differs ? BT_NO_MATCH : BT_OK;
+    }
     if (!pl->spec_ev) return BT_OK;
     hipEvent_t ev = static_cast<hipEvent_t>(pl->spec_ev);
     const bool waited = hipEventSynchronize(ev) == hipSuccess;
@@ -599,6 +671,7 @@ int bt_plan_create_shifted_any(const bt_plan *const *srcs, int nsrc, const int64
         const bt_plan *src = srcs[q];
         if (!src) return BT_EINVAL;
         if (!src->dev_base || !src->pk_off || src->e_all != E || src->info.E != E || src->info.n_buf != n_buf || src->info.p_tot != p_tot) continue;
+        if (src->spec_ev || src->spec_epoch || src->spec_unbound) continue;
         cand[nc] = src; idx[nc++] = q;
     }
     if (nc == 0) return BT_NO_MATCH;
@@ -650,6 +723,7 @@ int bt_plan_create_shifted(const bt_plan *src, const int64_t *ii, const int64_t 
 void bt_plan_destroy(bt_plan *pl) {
     if (!pl) return;
     if (pl->spec_ev) { (void)hipEventSynchronize(static_cast<hipEvent_t>(pl->spec_ev)); dev_pool().give_event(static_cast<hipEvent_t>(pl->spec_ev)); pl->spec_ev = nullptr; pl->spec_flag = nullptr; }
+    if (pl->spec_epoch) { (void)hipStreamSynchronize(static_cast<hipStream_t>(pl->spec_stream)); pl->spec_epoch = 0; pl->spec_flag = nullptr; pl->spec_stream = nullptr; }   // (a comparison that reads this plan's words may still be queued)
     if (void *r = pl->ready.exchange(nullptr, std::memory_order_acq_rel)) {
         // (copies of a clone that was never launched may still be queued on the plan stream: the buffer's next owner writes it
         //  on that same stream, behind them)
@@ -758,12 +832,16 @@ int bt_ba_step(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
     const bool so = is_so(pl, a);
     if (!so && (!a->poses_out || a->poses_out == a->poses)) return BT_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    ApiTick tick;
     mark_launch(pl, stream);
+    tick("step: mark_launch");
     const StepArgs s = make_args(pl, a, ws);
     const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
     bool fused = false;              // (structure-only steps on the k_tile path are one launch)
     int r = launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), so, st, nullptr, nullptr, so ? (copy_poses ? 1 : 0) : -1, &fused);
+    tick("step: reduce launched");
     if (r == BT_OK && !fused) r = launch_solve_update(pl->dev, s, so, copy_poses, st);
+    tick("step: solve + update launched");
     return r;
 }
 

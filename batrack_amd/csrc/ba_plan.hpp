@@ -185,6 +185,9 @@ struct bt_plan {
     int64_t k_hi = -1;                                        // largest patch index the plan's tables hold (bt_plan_create_shifted_spec checks k_hi + dk < p_tot)
     void *spec_ev = nullptr;                                  // hipEvent_t behind the verdict of a speculative clone (bt_plan_spec_confirm), else null
     int *spec_flag = nullptr;                                 // its two pinned ints: list differs / index out of range
+    int spec_epoch = 0;                                       // > 0: no event — the verdict is complete when spec_flag[2] holds this (bt_plan_spec_bind)
+    void *spec_stream = nullptr;                              //   (the stream the comparison was launched on: what a poll that runs out of patience waits for)
+    int spec_unbound = 0;                                     // made AHEAD of its list (bt_plan_preshift): no step before bt_plan_spec_bind
     bt::PlanDev dev{};
 
     // Back to the state of a new object, but with the vectors' capacity kept: destroyed plans are recycled
@@ -207,7 +210,7 @@ struct bt_plan {
         max_rows16 = 16;
         ws = bt::WsLayout{};
         dev_base = nullptr; dev_cap = 0;
-        last_stream = nullptr; launched = false; ready = nullptr; k_hi = -1; spec_ev = nullptr; spec_flag = nullptr;
+        last_stream = nullptr; launched = false; ready = nullptr; k_hi = -1; spec_ev = nullptr; spec_flag = nullptr; spec_unbound = 0; spec_epoch = 0; spec_stream = nullptr;
         dev = bt::PlanDev{};
     }
 };
@@ -270,6 +273,10 @@ int launch_shift_match(const uint64_t *nw, const uint64_t *ow, int64_t E, int *o
 // range (bt_plan_create_shifted_spec; host_flags: device-visible pinned memory, cleared by the caller)
 int launch_pack_match_expect(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
                              const uint64_t *ow, uint64_t delta, uint64_t *out, int *host_flags, void *stream);
+// the list against `ow` word for word; host_flags (pinned): [0] differs, [1] index out of range, [2] = epoch once every workgroup is through
+int launch_match_done(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
+                      const uint64_t *ow, int *host_flags, unsigned *ticket, int epoch, void *stream);
+int launch_words_add(const uint64_t *ow, uint64_t delta, uint64_t *out, int64_t E, void *stream);
 int launch_plan_shift(int32_t *kx, int m, int32_t *tile_kx, int nkx, int32_t *tile_ij, int nij, int32_t *pair_i, int32_t *pair_j, int P,
                       const uint32_t *old_bits, uint32_t *new_bits, int32_t *new_rank, int nwords, int df, int dk, void *stream);
 int launch_pack_edges(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,

@@ -90,12 +90,60 @@ __global__ __launch_bounds__(256) void k_pack_match_expect(const long long *ii, 
     if (w - ow[e] != delta) flags[0] = 1;
 }
 
+// The same comparison for a clone that was made AHEAD of its list (bt_plan_spec_bind), launched on the caller's own stream in
+// front of its first step: no packed copy, and no event either — the last workgroup to finish (a ticket) writes `epoch` behind the
+// verdict, and the host polls that word.  In the first call of an update() every HIP call costs 10-25 us of host time (idle
+// queues): this is the only one the new list needs before its step.
+__global__ __launch_bounds__(256) void k_match_done(const long long *ii, const long long *jj, const long long *kk, long long E, long long n_buf, long long p_tot,
+                                                    const unsigned long long *ow, int *flags, unsigned *ticket, int epoch) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) {
+        const long long i = ii[e], j = jj[e], k = kk[e];
+        const bool bad = i < 0 || j < 0 || i >= n_buf || j >= n_buf || k < 0 || k >= p_tot;
+        const unsigned long long w = ((unsigned long long)k << 32) | ((unsigned long long)i << 16) | (unsigned long long)j;
+        if (bad || w != ow[e]) {
+            if (bad) flags[1] = 1;
+            flags[0] = 1;
+            __threadfence_system();                 // (in host memory before this workgroup takes its ticket)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *ticket = 0u;                           // (for the slot's next use)
+            __threadfence_system();
+            __hip_atomic_store(flags + 2, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+int launch_match_done(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
+                      const uint64_t *ow, int *host_flags, unsigned *ticket, int epoch, void *stream) {
+    hipLaunchKernelGGL(k_match_done, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long *>(ii), reinterpret_cast<const long long *>(jj), reinterpret_cast<const long long *>(kk),
+                       (long long)E, (long long)n_buf, (long long)p_tot, reinterpret_cast<const unsigned long long *>(ow), host_flags, ticket, epoch);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
 int launch_pack_match_expect(const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
                              const uint64_t *ow, uint64_t delta, uint64_t *out, int *host_flags, void *stream) {
     hipLaunchKernelGGL(k_pack_match_expect, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const long long *>(ii), reinterpret_cast<const long long *>(jj), reinterpret_cast<const long long *>(kk),
                        (long long)E, (long long)n_buf, (long long)p_tot, reinterpret_cast<const unsigned long long *>(ow), (unsigned long long)delta,
                        reinterpret_cast<unsigned long long *>(out), host_flags);
+    return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
+}
+
+// the packed list a shifted clone EXPECTS: the source's words moved by `delta` (bt_plan_preshift: the new list is not there yet)
+__global__ __launch_bounds__(256) void k_words_add(const unsigned long long *ow, unsigned long long delta, unsigned long long *out, long long E) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) out[e] = ow[e] + delta;
+}
+
+int launch_words_add(const uint64_t *ow, uint64_t delta, uint64_t *out, int64_t E, void *stream) {
+    hipLaunchKernelGGL(k_words_add, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned long long *>(ow), (unsigned long long)delta, reinterpret_cast<unsigned long long *>(out), (long long)E);
     return hipGetLastError() == hipSuccess ? BT_OK : BT_EHIP;
 }
 

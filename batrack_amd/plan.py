@@ -147,6 +147,45 @@ class Plan:
         self.speculative = True
         return self
 
+    @classmethod
+    def preshift(cls, src, df):
+        """The clone of `src` for a list that does not exist yet: src's moved up by `df` frames (bt_plan_preshift) — enqueued now, on
+        the library's plan stream, so that the call that brings the list only has to `bind` it.  None where no such shift fits the
+        buffers.  The plan cannot be stepped before `bind`."""
+        if not src.uploaded or src.__dict__.get("speculative"):
+            return None
+        h = ctypes.c_void_p()
+        rc = src._lib.bt_plan_preshift(src._h, int(df), ctypes.byref(h))
+        if rc > 0:
+            return None
+        _lib.check(rc, "bt_plan_preshift")
+        self = cls.__new__(cls)
+        self._lib, self._h, self._keep = src._lib, h, None
+        s = src.info
+        self.info = dict(s, fixedp=s["fixedp"] + int(df), n_all=s["n_all"] + int(df))
+        self.uploaded = True
+        self.speculative = True
+        self.unbound = True
+        return self
+
+    def bind(self, ii, jj, kk, n_buf, p_tot, fixedp):
+        """Give a pre-shifted clone its list (bt_plan_spec_bind: one comparison kernel, no host wait).  True: step it, then `confirm()`
+        as after `shifted_spec`.  False: the list cannot be the one the clone was made for (size, buffers or fixedp differ)."""
+        import torch
+        if not self.__dict__.get("unbound"):
+            return False
+        if not (ii.is_cuda and jj.is_cuda and kk.is_cuda and ii.dtype == jj.dtype == kk.dtype == torch.int64
+                and ii.is_contiguous() and jj.is_contiguous() and kk.is_contiguous()):
+            return False
+        stream = torch._C._cuda_getCurrentRawStream(ii.device.index if ii.device.index is not None else torch.cuda.current_device())
+        rc = self._lib.bt_plan_spec_bind(self._h, ii.data_ptr(), jj.data_ptr(), kk.data_ptr(), ii.numel(), int(n_buf), int(p_tot), int(fixedp), stream)
+        if rc > 0:
+            return False
+        _lib.check(rc, "bt_plan_spec_bind")
+        self._keep = (ii, jj, kk)                                    # (the index tensors are read by a kernel still queued)
+        self.unbound = False
+        return True
+
     def confirm(self):
         """True: the plan is the list's plan (always, unless it came from `shifted_spec`).  False: the speculation failed."""
         if not self.__dict__.get("speculative"):

@@ -120,6 +120,16 @@ int bt_plan_create_shifted_any(const bt_plan *const *srcs, int nsrc, const int64
  * BT_NO_MATCH from the create call itself: the shift is not of that form (no speculation possible).  src as for the above. */
 int bt_plan_create_shifted_spec(const bt_plan *src, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E,
                                 int64_t n_buf, int64_t p_tot, int64_t fixedp, void *in_stream, bt_plan **out);
+/* The two halves of bt_plan_create_shifted_spec apart (round 6): the window moves by the same number of frames update() after
+ * update(), so the clone for the NEXT list — its tables depend on the source and the shift only — can be enqueued while the steps of
+ * the current list run (bt_plan_preshift: `df` frames, fixedp = src.fixedp + df; BT_NO_MATCH where no such shift fits the buffers),
+ * and the call that brings the list pays for one comparison kernel (bt_plan_spec_bind: the list against the one the clone was made
+ * for, verdict as above; BT_NO_MATCH, without a kernel, if the list's size / buffers / fixedp are not the clone's).  A clone that
+ * was never bound cannot be stepped (BT_EINVAL) and confirms as BT_NO_MATCH; after a successful bind it is the plan
+ * bt_plan_create_shifted_spec would have returned: step, then bt_plan_spec_confirm. */
+int bt_plan_preshift(const bt_plan *src, int64_t df, bt_plan **out);
+int bt_plan_spec_bind(bt_plan *plan, const int64_t *ii, const int64_t *jj, const int64_t *kk, int64_t E, int64_t n_buf, int64_t p_tot,
+                      int64_t fixedp, void *in_stream);
 /* BT_OK: the plan is what bt_plan_create would have built (or was not speculative); BT_NO_MATCH: it is not — destroy it; BT_EINVAL:
  * the new list holds an index outside [0, n_buf) / [0, p_tot).  Waits for the verdict if it has not arrived. */
 int bt_plan_spec_confirm(bt_plan *plan);

@@ -218,6 +218,14 @@ def test_sequence_replay_uses_shifted_plans_and_gives_the_same_trajectory(monkey
             made["shifted"] += r is not None
             return r
         monkeypatch.setattr(Plan, "shifted_spec", classmethod(spec))
+        real_bind = Plan.bind
+
+        def bind(self, *a, **k):                                   # (... or was made AHEAD, during the update() before, and only meets its list here)
+            r = real_bind(self, *a, **k)
+            made["shifted"] += bool(r)
+            made["bound"] = made.get("bound", 0) + bool(r)
+            return r
+        monkeypatch.setattr(Plan, "bind", bind)
 
         def init(self, *a, **k):
             made["built"] += 1
@@ -231,4 +239,52 @@ def test_sequence_replay_uses_shifted_plans_and_gives_the_same_trajectory(monkey
     hip_ba.clear_plan_cache()
     assert runs["0"][1]["shifted"] == 0
     assert runs["1"][1]["shifted"] >= 20 and runs["1"][1]["built"] <= runs["0"][1]["built"] - 20     # the steady state (from frame ~34) is served by shifts
+    assert runs["1"][1].get("bound", 0) >= 15                      # most of them made ahead (Plan.preshift), bound by one comparison kernel
     assert np.abs(runs["1"][0] - runs["0"][0]).max() < 2e-5
+
+
+def test_a_clone_made_ahead_of_its_list():
+    """bt_plan_preshift / bt_plan_spec_bind: the clone for the next window is enqueued before its list exists; it cannot be stepped
+    unbound, binds to the list it was made for (verdict good: same result as a plan built from scratch), says BT_NO_MATCH — through
+    `confirm()` — for a list that is not the shifted one, and refuses a list of another size or fixedp without a kernel."""
+    from batrack_amd import graphgen
+    g = graphgen.make_graph(12, 64, 6, seed=4, n_buf=24)
+    dev = DEV
+    T = lambda a: torch.as_tensor(a, device=dev)
+    n_buf, p_tot, fixedp = 24, 24 * 64, 2
+    ii0, jj0, kk0 = T(g.ii), T(g.jj), T(g.kk)
+    src = Plan(ii0, jj0, kk0, n_buf, p_tot, fixedp)
+    pre = Plan.preshift(src, 3)
+    assert pre is not None and pre.info["fixedp"] == fixedp + 3
+    st = Stepper(pre, dev)
+    poses = torch.zeros(n_buf, 7, device=dev); poses[:, 6] = 1
+    f = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=dev)
+    poses[3:15] = f(g.poses[:12])
+    pat = torch.zeros(p_tot, 3, device=dev); pat[3 * 64:15 * 64] = f(g.patches[:12 * 64]); pat[:, 2].clamp_(min=0.1)
+    mono = pat[:, 2].clone()
+    intr = f(g.intrinsics[:1]).repeat(n_buf, 1)
+    t3, w = f(g.targets3), f(g.weights_pose)
+    args = lambda P, X: (poses, pat, mono, intr, t3, 3, w, P, X, list(g.bounds), 1e-4, 10.0, 0.05, "huber", False)
+    with pytest.raises(RuntimeError):
+        st.step(*args(torch.empty_like(poses), torch.empty_like(pat)))          # unbound: BT_EINVAL
+    ii1, jj1, kk1 = ii0 + 3, jj0 + 3, kk0 + 3 * 64
+    assert not pre.bind(ii1[:-1].contiguous(), jj1[:-1].contiguous(), kk1[:-1].contiguous(), n_buf, p_tot, fixedp + 3)   # another size
+    assert not pre.bind(ii1, jj1, kk1, n_buf, p_tot, fixedp + 2)                                                        # another fixedp
+    assert pre.bind(ii1, jj1, kk1, n_buf, p_tot, fixedp + 3)
+    P1, X1 = torch.empty_like(poses), torch.empty_like(pat)
+    st.step(*args(P1, X1))
+    assert pre.confirm()
+    ref = Stepper(Plan(ii1, jj1, kk1, n_buf, p_tot, fixedp + 3), dev)
+    P2, X2 = torch.empty_like(poses), torch.empty_like(pat)
+    ref.step(*args(P2, X2))
+    torch.cuda.synchronize()
+    assert (P1 - P2).abs().max() < 1e-6 and (X1 - X2).abs().max() < 1e-6
+    # a list that is NOT the shifted one (one edge points elsewhere): bound, stepped, and then told so
+    pre2 = Plan.preshift(src, 3)
+    jj_bad = jj1.clone(); jj_bad[5] = jj_bad[5] + 1
+    assert pre2.bind(ii1, jj_bad, kk1, n_buf, p_tot, fixedp + 3)
+    assert pre2.confirm() is False
+    # never bound: no plan of anything
+    pre3 = Plan.preshift(src, 3)
+    assert pre3.confirm() is False
+    assert Plan.preshift(src, 30) is None                                        # the shift does not fit the buffers

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""What an update() of the replay costs beyond its GPU work: in the steady state every update()'s 2 x ITER BA calls are timed as the
+caller times them (sync, calls, sync), then the SAME calls are repeated on the same list (every plan cached: nothing but argument
+handling and launches on the host) and timed again.  The difference is what the new plan of the first call costs on the critical
+path.  GPU box:  python tools/gpu_update_floor.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from batrack_amd.backend import ba as hip_ba
+from batrack_amd.sequence import SlamConfig, SyntheticObservations, WindowedBA
+
+rec = dict(first=[], again=[], calls=[], bound=[])
+from batrack_amd import plan as plan_mod
+_bind = plan_mod.Plan.bind
+state = dict(bound=False, k=0)
+
+
+def counting_bind(self, *a, **k):
+    r = _bind(self, *a, **k)
+    state["bound"] = state["bound"] or bool(r)
+    return r
+
+
+plan_mod.Plan.bind = counting_bind
+AB = os.environ.get("AB", "0") == "1"          # alternate: clones made ahead (Plan.preshift) on / off, update() by update()
+pf = hip_ba.prefetch_plan if os.environ.get("PREFETCH", "0") == "1" else None
+obs = SyntheticObservations(n_frames=int(os.environ.get("FRAMES", 200)), M=256, seed=0)
+trk = WindowedBA(obs, hip_ba.BA_rgbd_droid, SlamConfig(PATCHES_PER_FRAME=256, BUFFER_SIZE=1024), device="cuda:0", prefetch=pf)
+orig_ba = trk.ba
+log = []
+
+
+def recording_ba(*a, **k):
+    log.append((a, k))
+    return orig_ba(*a, **k)
+
+
+orig_update = trk.update
+
+
+def update():
+    log.clear()
+    trk.ba = recording_ba
+    t0 = trk.stats["ba_seconds"]
+    if AB:
+        state["k"] += 1
+        os.environ["BT_PLAN_PRESHIFT"] = "1" if (state["k"] // 2) % 2 else "0"       # (two updates each: the clone serves the update AFTER it was made)
+    orig_update()
+    rec["first"].append(trk.stats["ba_seconds"] - t0)
+    rec["bound"].append(state["bound"])
+    state["bound"] = False                  # (with prefetch the clone is bound BEFORE update(), where the caller hands over the list)
+    trk.ba = orig_ba
+    calls = list(log)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for a, k in calls:                       # (results discarded: the state of the replay is the first pass's)
+        orig_ba(*a, **k)
+    torch.cuda.synchronize()
+    rec["again"].append(time.perf_counter() - t)
+    per = []
+    for a, k in calls[:2]:                   # one pose+structure and one structure-only call on their own
+        torch.cuda.synchronize(); t = time.perf_counter(); orig_ba(*a, **k); torch.cuda.synchronize(); per.append(time.perf_counter() - t)
+    rec["calls"].append(per)
+
+
+trk.update = update
+trk.run()
+if AB:
+    f, b = np.array(rec["first"][-160:]) * 1e3, np.array(rec["bound"][-160:])
+    print(f"update() as the caller times it, median over the last 160 updates by how its first call got its plan: a clone made ahead, bound by one kernel "
+          f"{np.median(f[b]):.3f} ms (n = {int(b.sum())}); a clone made in the call (shifted_spec) {np.median(f[~b]):.3f} ms (n = {int((~b).sum())})")
+f, a = np.array(rec["first"][-100:]) * 1e3, np.array(rec["again"][-100:]) * 1e3
+c = np.array(rec["calls"][-100:]) * 1e6
+print(f"prefetch {'on' if pf else 'off'}: update() as the caller times it {np.median(f):.3f} ms; the same {len(log)} calls again, plans cached {np.median(a):.3f} ms; "
+      f"difference {1e3 * (np.median(f) - np.median(a)):.0f} us")
+print(f"one call alone, synchronised: pose+structure {np.median(c[:, 0]):.1f} us, structure-only {np.median(c[:, 1]):.1f} us")
