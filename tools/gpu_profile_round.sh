@@ -86,6 +86,7 @@ cd $R
 (echo "# k_edge2 forced from 2048 tiles on (BT_FORCE=kernel=k_edge2)"; BT_FORCE=kernel=k_edge2 python tools/gpu_sweep.py 2048 4096 8192 16384 32768) 2>&1 | cut -c1-330 > $OUT/edge2_forced.txt
 (python tools/gpu_timing.py --workload window) > $OUT/window_rounds_per_trip.txt 2>&1
 python tools/gpu_spec_time.py > $OUT/plan_call_host_time.txt 2>&1
+(for i in 1 2 3; do AB=1 FRAMES=400 python tools/gpu_update_floor.py; done; BT_PLAN_PRESHIFT=0 python tools/gpu_update_floor.py | tail -2; PREFETCH=1 python tools/gpu_update_floor.py | tail -2) 2>&1 | grep -v amdgpu.ids > $OUT/update_floor.txt
 python tests/sequence_report.py > $OUT/sequence_ate.txt 2>&1
 (echo "# 200 frames, steady state of the window"; python tests/sequence_report.py --frames 200 --skip-oracle) >> $OUT/sequence_ate.txt 2>&1
 (python tools/gpu_plan_time.py; python tools/gpu_plan_time.py window; python tools/gpu_plan_time.py large) > $OUT/plan_time.txt 2>&1

@@ -70,6 +70,11 @@ if AB:
     f, b = np.array(rec["first"][-160:]) * 1e3, np.array(rec["bound"][-160:])
     print(f"update() as the caller times it, median over the last 160 updates by how its first call got its plan: a clone made ahead, bound by one kernel "
           f"{np.median(f[b]):.3f} ms (n = {int(b.sum())}); a clone made in the call (shifted_spec) {np.median(f[~b]):.3f} ms (n = {int((~b).sum())})")
+    allf = np.array(rec["first"]) * 1e3
+    top = np.argsort(allf)[-8:][::-1]
+    print("  slowest updates (index of update, ms, first call bound a clone made ahead): " + ", ".join(f"#{i} {allf[i]:.2f} {rec['bound'][i]}" for i in top))
+    q = lambda v: " ".join(f"{x:.3f}" for x in np.percentile(v, [10, 50, 90, 99])) + f" mean {v.mean():.3f}"
+    print(f"  percentiles 10 / 50 / 90 / 99 and mean: made ahead {q(f[b])}; made in the call {q(f[~b])}")
 f, a = np.array(rec["first"][-100:]) * 1e3, np.array(rec["again"][-100:]) * 1e3
 c = np.array(rec["calls"][-100:]) * 1e6
 print(f"prefetch {'on' if pf else 'off'}: update() as the caller times it {np.median(f):.3f} ms; the same {len(log)} calls again, plans cached {np.median(a):.3f} ms; "
