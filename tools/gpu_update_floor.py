@@ -23,6 +23,30 @@ def counting_bind(self, *a, **k):
 
 
 plan_mod.Plan.bind = counting_bind
+import torch
+slow = []                                   # (what, update index, ms) of any wrapped call that took more than 2 ms
+
+
+def timed(obj, name, what):
+    f = getattr(obj, name)
+
+    def w(*a, **k):
+        t = time.perf_counter(); r = f(*a, **k); dt = (time.perf_counter() - t) * 1e3
+        if dt > 2.0:
+            slow.append((what, len(rec["first"]), round(dt, 2)))
+        return r
+    setattr(obj, name, w)
+
+
+timed(plan_mod.Plan, "confirm", "Plan.confirm")
+timed(plan_mod.Plan, "shifted_spec", "Plan.shifted_spec")
+timed(plan_mod.Plan, "shifted_any", "Plan.shifted_any")
+timed(plan_mod.Plan, "__init__", "Plan.__init__")
+timed(plan_mod.Stepper, "__init__", "Stepper.__init__")
+timed(torch.cuda, "synchronize", "synchronize")
+timed(hip_ba, "_preshift", "_preshift")
+timed(hip_ba, "_plan_lookup", "_plan_lookup")
+timed(hip_ba, "_store", "_store")
 AB = os.environ.get("AB", "0") == "1"          # alternate: clones made ahead (Plan.preshift) on / off, update() by update()
 pf = hip_ba.prefetch_plan if os.environ.get("PREFETCH", "0") == "1" else None
 obs = SyntheticObservations(n_frames=int(os.environ.get("FRAMES", 200)), M=256, seed=0)
@@ -73,8 +97,12 @@ if AB:
     allf = np.array(rec["first"]) * 1e3
     top = np.argsort(allf)[-8:][::-1]
     print("  slowest updates (index of update, ms, first call bound a clone made ahead): " + ", ".join(f"#{i} {allf[i]:.2f} {rec['bound'][i]}" for i in top))
+    print("  calls over 2 ms (what, update, ms): " + ", ".join(f"{w} #{i} {d}" for w, i, d in slow[:24]))
     q = lambda v: " ".join(f"{x:.3f}" for x in np.percentile(v, [10, 50, 90, 99])) + f" mean {v.mean():.3f}"
     print(f"  percentiles 10 / 50 / 90 / 99 and mean: made ahead {q(f[b])}; made in the call {q(f[~b])}")
+allf = np.array(rec["first"]) * 1e3
+top = np.argsort(allf)[-6:][::-1]
+print("slowest updates (#, ms): " + ", ".join(f"#{i} {allf[i]:.2f}" for i in top) + " | calls over 2 ms: " + ", ".join(f"{w} #{i} {d}" for w, i, d in slow[:12]))
 f, a = np.array(rec["first"][-100:]) * 1e3, np.array(rec["again"][-100:]) * 1e3
 c = np.array(rec["calls"][-100:]) * 1e6
 print(f"prefetch {'on' if pf else 'off'}: update() as the caller times it {np.median(f):.3f} ms; the same {len(log)} calls again, plans cached {np.median(a):.3f} ms; "
