@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "ba_kernels.hpp"
+#include "dev_cache.hpp"
 
 #define BT_VERSION 204
 
@@ -515,15 +516,20 @@ static int clone_shifted(const bt_plan *src, const uint64_t *d_words, int64_t E,
 // caller has)
 struct SpecSlots {
     int *h = nullptr;                                                        // pinned, mapped: the comparison kernel writes its verdict there (4 ints a slot)
-    unsigned *tickets = nullptr;                                             // device: one counter a slot (k_match_done's last-workgroup ticket)
+    unsigned *tickets[kMaxDevices] = {};                                     // device memory, per device: one counter a slot (k_match_done's last-workgroup ticket)
     hipEvent_t ev_in = nullptr;                                              // orders the plan stream behind the caller's stream
     unsigned next = 0;
     bool ensure() {
-        if (h && ev_in && tickets) return true;
-        if (!h) { if (hipHostMalloc(reinterpret_cast<void **>(&h), 16 * 4 * sizeof(int), hipHostMallocMapped) != hipSuccess) return false; std::memset(h, 0, 16 * 4 * sizeof(int)); }
-        if (!tickets && (hipMalloc(reinterpret_cast<void **>(&tickets), 16 * sizeof(unsigned)) != hipSuccess ||
-                         hipMemset(tickets, 0, 16 * sizeof(unsigned)) != hipSuccess)) return false;
+        if (h && ev_in) return true;
+        if (!h) { if (hipHostMalloc(reinterpret_cast<void **>(&h), 16 * 4 * sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return false; std::memset(h, 0, 16 * 4 * sizeof(int)); }
         return ev_in || hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess;
+    }
+    // the tickets of the device a plan lives on (allocated on first use, with that device current — as it is for every launch of the plan)
+    unsigned *tickets_of(int dev) {
+        if (dev < 0 || dev >= kMaxDevices) return nullptr;
+        if (!tickets[dev] && (hipMalloc(reinterpret_cast<void **>(&tickets[dev]), 16 * sizeof(unsigned)) != hipSuccess ||
+                              hipMemset(tickets[dev], 0, 16 * sizeof(unsigned)) != hipSuccess)) { tickets[dev] = nullptr; return nullptr; }
+        return tickets[dev];
     }
 };
 static SpecSlots &spec_slots() { static SpecSlots s; return s; }
@@ -606,8 +612,10 @@ int bt_plan_spec_bind(bt_plan *pl, const int64_t *ii, const int64_t *jj, const i
         std::lock_guard<std::mutex> g(spec_mutex());
         SpecSlots &ss = spec_slots();
         if (!ss.ensure()) return BT_ENOMEM;
+        unsigned *tk = ss.tickets_of(pl->dev_id);
+        if (!tk) return BT_ENOMEM;
         const unsigned slot = ss.next++ % 16;
-        h_flag = ss.h + 4 * slot; ticket = ss.tickets + slot;
+        h_flag = ss.h + 4 * slot; ticket = tk + slot;
         epoch = (int)((ss.next & 0x3fffffffu) | 0x40000000u);          // (never 0, never the slot's previous one)
     }
     h_flag[0] = 0; h_flag[1] = 0; h_flag[2] = 0;
