@@ -48,6 +48,7 @@ def _store(key, stepper, ii, jj, kk):
     _CACHE[key] = (stepper, tuple(weakref.ref(t) for t in (ii, jj, kk)))
 
 
+_CALLS_BEFORE = [0]  # how many calls the previous edge list got (an update() makes 2 x ITER): decides when the next clone is made
 _REPEAT = [False]    # the call in progress found the plan of the call before it in place (not the first call of an update())
 _LAST = [None]       # (ii, jj, kk, versions, fixedp, n_buf, p_tot, device, stepper) of the last call: an update() makes 2*ITER calls on one list
 
@@ -62,6 +63,8 @@ def _plan_for(ii, jj, kk, n_buf, p_tot, fixedp, device):
         _REPEAT[0] = True
         return last[8]
     _REPEAT[0] = False
+    if last is not None:
+        _CALLS_BEFORE[0] = last[8].__dict__.get("_repeats", 0) + 1
     stepper = _plan_lookup(ii, jj, kk, n_buf, p_tot, fixedp, device)
     _LAST[0] = (ii, jj, kk, (ii._version, jj._version, kk._version, ii.data_ptr(), jj.data_ptr(), kk.data_ptr()), fixedp, n_buf, p_tot, device, stepper)
     return stepper
@@ -160,10 +163,20 @@ def _build_plan(ii, jj, kk, n_buf, p_tot, fixedp, sync, speculate=True):
 
 def _preshift(stepper):
     """Make the clone for the list the NEXT update() will most likely bring — this plan's, moved up by the shift that was right last
-    time — now, while this update()'s steps run: called after a step of a confirmed plan has been enqueued on a call that found its
-    plan in place (the second call of an update(): the host is ahead of the GPU there, and the first call of the next update(),
-    which has the GPU idle behind it, is left with one comparison kernel).  Once per plan."""
+    time — now, while this update()'s steps run: called after the step of every call that found its plan in place has been enqueued, it
+    picks ONE of them (below) to spend its ~45 us behind; the first call of the next update(), which has the GPU idle behind it, is
+    left with one comparison kernel.  Once per plan."""
+    stepper._repeats = stepper.__dict__.get("_repeats", 0) + 1          # this is call number _repeats + 1 on the plan
     if stepper.__dict__.get("_pre_tried"):
+        return
+    # WHEN: behind a call that leaves the host ~45 us it can spend unnoticed, i.e. with that much GPU work queued in front of it.  The
+    # first call of an update() is late by its plan; the host catches up by ~10-25 us a call (a structure-only step is 19 us of
+    # kernels, a pose+structure one 61): behind call 2 the clone cost the update() 16-37 us (the GPU ran dry before call 3 arrived),
+    # behind call 5 or 7 nothing (tools/gpu_update_floor.py, AB_AT).  So: call 5 where the update()s have that many calls (how many the
+    # previous list got), else call 3, else 2.  BT_PLAN_PRESHIFT_AT: the measurement's override.
+    at = os.environ.get("BT_PLAN_PRESHIFT_AT")
+    at = int(at) if at else (5 if _CALLS_BEFORE[0] >= 6 else 3 if _CALLS_BEFORE[0] >= 4 else 2)
+    if stepper._repeats + 1 < at:
         return
     df = _LAST_SHIFT[0]
     if df is None or stepper.plan.__dict__.get("speculative"):

@@ -69,7 +69,12 @@ def update():
     t0 = trk.stats["ba_seconds"]
     if AB:
         state["k"] += 1
-        os.environ["BT_PLAN_PRESHIFT"] = "1" if (state["k"] // 2) % 2 else "0"       # (two updates each: the clone serves the update AFTER it was made)
+        if os.environ.get("AB_AT"):                # instead: the call of the update() behind which the clone is made, two settings alternating
+            a0, a1 = os.environ["AB_AT"].split(",")
+            os.environ["BT_PLAN_PRESHIFT_AT"] = a1 if (state["k"] // 2) % 2 else a0
+            rec.setdefault("at", []).append(os.environ["BT_PLAN_PRESHIFT_AT"])
+        else:
+            os.environ["BT_PLAN_PRESHIFT"] = "1" if (state["k"] // 2) % 2 else "0"       # (two updates each: the clone serves the update AFTER it was made)
     orig_update()
     rec["first"].append(trk.stats["ba_seconds"] - t0)
     rec["bound"].append(state["bound"])
@@ -90,7 +95,13 @@ def update():
 
 trk.update = update
 trk.run()
-if AB:
+if AB and "at" in rec:
+    f, at = np.array(rec["first"][-160:]) * 1e3, np.array(rec["at"][-160:])
+    # (the setting of update k decides where the clone for update k + 1 is made: it costs update k its host time, and update k + 1 is
+    #  served the same either way — so update k's own time is what differs)
+    for v in sorted(set(at)):
+        print(f"clone made behind call {v} of the update(): update() median {np.median(f[at == v]):.3f} ms, p10 {np.percentile(f[at == v], 10):.3f}, p90 {np.percentile(f[at == v], 90):.3f} (n = {int((at == v).sum())})")
+elif AB:
     f, b = np.array(rec["first"][-160:]) * 1e3, np.array(rec["bound"][-160:])
     print(f"update() as the caller times it, median over the last 160 updates by how its first call got its plan: a clone made ahead, bound by one kernel "
           f"{np.median(f[b]):.3f} ms (n = {int(b.sum())}); a clone made in the call (shifted_spec) {np.median(f[~b]):.3f} ms (n = {int((~b).sum())})")
