@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -521,7 +522,7 @@ struct SpecSlots {
     unsigned next = 0;
     bool ensure() {
         if (h && ev_in) return true;
-        if (!h) { if (hipHostMalloc(reinterpret_cast<void **>(&h), 16 * 4 * sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return false; std::memset(h, 0, 16 * 4 * sizeof(int)); }
+        if (!h) { if (hipHostMalloc(reinterpret_cast<void **>(&h), 16 * 4 * sizeof(int), hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) return false; std::memset(h, 0, 16 * 4 * sizeof(int)); }
         return ev_in || hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess;
     }
     // the tickets of the device a plan lives on (allocated on first use, with that device current — as it is for every launch of the plan)
@@ -636,10 +637,17 @@ int bt_plan_spec_confirm(bt_plan *pl) {
         volatile int *f = pl->spec_flag;
         const int want = pl->spec_epoch;
         bool done = false;
-        for (int spins = 0; spins < (1 << 22) && !done; ++spins) done = f[2] == want;
-        if (!done) {                                              // (a GPU far behind: wait for the stream instead of spinning on)
-            if (hipStreamSynchronize(static_cast<hipStream_t>(pl->spec_stream)) != hipSuccess) return BT_EHIP;
-            done = f[2] == want;
+        for (int spins = 0; spins < (1 << 17) && !done; ++spins) done = f[2] == want;      // (~ 2 ms)
+        if (!done) {
+            // a GPU far behind — the caller's earlier work sits in front of the comparison: keep looking, but let the core go in
+            // between (returning when the VERDICT is there, not when the step behind it is done, keeps the next call's launches
+            // under that step); after seconds of that, the stream itself
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!(done = f[2] == want) && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) std::this_thread::yield();
+            if (!done) {
+                if (hipStreamSynchronize(static_cast<hipStream_t>(pl->spec_stream)) != hipSuccess) return BT_EHIP;
+                done = f[2] == want;
+            }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         const int differs = f[0], bad = f[1];

@@ -279,6 +279,19 @@ def test_a_clone_made_ahead_of_its_list():
     ref.step(*args(P2, X2))
     torch.cuda.synchronize()
     assert (P1 - P2).abs().max() < 1e-6 and (X1 - X2).abs().max() < 1e-6
+    # the same with the GPU far behind — tens of milliseconds of the caller's earlier work in front of the comparison (in the pipeline:
+    # the tracker pass): the verdict is waited for (a spin, then a yielding poll), not guessed
+    pre_b = Plan.preshift(src, 3)
+    st_b = Stepper(pre_b, dev)
+    big = torch.randn(4096, 4096, device=dev)
+    for _ in range(40):
+        big = (big @ big).clamp_(-1, 1)
+    assert pre_b.bind(ii1, jj1, kk1, n_buf, p_tot, fixedp + 3)
+    P3, X3 = torch.empty_like(poses), torch.empty_like(pat)
+    st_b.step(*args(P3, X3))
+    assert pre_b.confirm()
+    torch.cuda.synchronize()
+    assert (P3 - P2).abs().max() < 1e-6 and (X3 - X2).abs().max() < 1e-6
     # a list that is NOT the shifted one (one edge points elsewhere): bound, stepped, and then told so
     pre2 = Plan.preshift(src, 3)
     jj_bad = jj1.clone(); jj_bad[5] = jj_bad[5] + 1
