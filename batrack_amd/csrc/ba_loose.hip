@@ -1,4 +1,4 @@
-// ba_loose.hip — LOOSE tracks: tracks seen by more than 64 free cameras (kTileCamHard).  A tile keeps its E as [6 x cameras][tracks] in
+// ba_loose.hip — LOOSE tracks: tracks seen by more than 64 free cameras (kTileCamHard; more than 32 where a plan has only a few such: ba_plan.cpp).  A tile keeps its E as [6 x cameras][tracks] in
 // LDS with at most 64 cameras; a hub track — a landmark of a global / loop-closing adjustment seen from a hundred keyframes — has
 // no place in one.  The reference's dense E [n, m, 6] (ba.py:268-292) has no such clause, so these tracks take a slow-but-correct
 // path of their own, a workgroup per track, everything in double:

@@ -425,7 +425,15 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     const bool aligned = !align_retry && masks_ok && tcap == kLanes && m > 0 && ((int64_t)m + kLanes - 1) / kLanes >= em_min_p &&
                          (!dstats || dstats->rep_known);
     pl->dev_pbase.clear();
-    std::vector<int32_t> loose;                                                               // tracks seen by more than kTileCamHard free cameras
+    // LOOSE tracks: seen by more free cameras than a tile takes.  64 is what the kernels' tables take (kTileCamHard) — but a tile of
+    // more than 32 cameras no longer holds its E in LDS as double, and ONE such tile turns the whole plan's per-edge maths to float32
+    // (bt_plan_edge_precision).  A landmark seen from 40 or 60 frames next to ordinary tracks — a handful per plan — is therefore
+    // loose as well (ba_loose.hip walks it in double; the plan stays float64: update errors 1e-6 instead of 1e-4 .. 1e-3 on such
+    // graphs, tests/test_gpu_fuzz.py); a plan with MANY tracks that long (more than kFewHubs) keeps them in tiles — there the loose
+    // path's atomics would cost more than float32 does — and is laid out again with the threshold at 64.
+    static thread_local int hub_retry = 0;
+    const int cam_hard = hub_retry ? kTileCamHard : kTileCamF64;
+    std::vector<int32_t> loose;                                                               // tracks seen by more than cam_hard free cameras
     std::vector<uint64_t> tile_tmask;                                                         // aligned: per tile the union of its tracks' target masks (2 words)
     if (aligned) {
         // the same greedy rule on bit masks (a tile has one source frame, so its tracks' masks share their base): cameras = the
@@ -455,7 +463,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
             pm_lo = t.mask; pm_hi = t.mask2;
             const uint64_t c_lo = t.mask & free_lo, c_hi = (t.mask2 & free_hi) | (t.src >= fixedp ? 1ull : 0ull);
             const int nk = __builtin_popcountll(c_lo) + __builtin_popcountll(c_hi);
-            if (nk > kTileCamHard) {                               // a loose track (see the general loop below)
+            if (nk > cam_hard) {                                   // a loose track (see the general loop below)
                 if (dstats) return BT_NEED_EDGES;
                 flush(k);
                 loose.push_back(k);
@@ -521,7 +529,7 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         int np_new = mark_targets(k);
         bool too_many_pairs = false;                               // (the track alone: possible only without masks — they hold 128 targets)
         if (!masks_ok && off[(size_t)k + 1] - off[(size_t)k] > kMaxTilePairs) { ++pair_run; too_many_pairs = mark_targets(k) > kMaxTilePairs; }
-        if ((int)trk_set.size() > kTileCamHard || too_many_pairs) {
+        if ((int)trk_set.size() > cam_hard || too_many_pairs) {
             // a LOOSE track: in no tile (its E does not fit a tile's camera budget, or its pairs a tile's table); ba_loose.hip walks its edges
             if (dstats) return BT_NEED_EDGES;                      // (their edge lists come from the host's grouped order)
             if (tcap < kLanes) {                                   // (k_etile's stored per-tile sums have no place for them: 64-track tiles, atomics)
@@ -550,6 +558,10 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
         set_epoch = epoch;
     }
     if (!aligned) close_tile(m);
+    if (!hub_retry && (int)loose.size() > kFewHubs) {              // (many long tracks: tiles of up to 64 cameras, float32 per edge)
+        RetryScope guard(hub_retry);
+        return build_plan_host(ii64, jj64, kk64, E, n_buf, p_tot, fixedp, n_all_min, own_lo, own_hi, pl, packed, keep_slots, dstats);
+    }
     const int32_t T = (int32_t)pl->tile_trk0.size();
     I.tiles = T; I.slots = slots; I.erows = erows; I.max_tile_cams = max_cams;
     pl->max_rows16 = (int)((6 * max_cams + 15) / 16 * 16);

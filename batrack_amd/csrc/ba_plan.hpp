@@ -14,6 +14,8 @@ namespace bt {
 constexpr int kLanes = 64;          // tracks per wave tile (one lane = one track)
 constexpr int kTileCamSoft = 16;    // close a tile when its camera union would exceed this
 constexpr int kTileCamHard = 64;    // a track that sees more free cameras than this sits in no tile: a LOOSE track (ba_loose.hip)
+constexpr int kTileCamF64 = 32;     // ... and so does one that sees more than THIS, where a plan has only a few of them (kFewHubs): a tile of 32
+constexpr int kFewHubs = 64;        //     cameras keeps its E in LDS as double, one of 33 .. 64 would turn the whole plan's per-edge maths to float32
 constexpr int kMaxFree = 255;       // free poses the block-sparse solvers take (8-bit pose numbers in their tables)
 constexpr int kMaxFreeWide = 2048;  // ... and the dense solver of larger systems (ba_dense.hip: the right-hand side lives in LDS)
 constexpr int kPairAccStride = 32;  // doubles per camera pair (27 used: 21 Bjj + 6 gj)

@@ -188,15 +188,26 @@ def test_plan_limits():
     ii, jj, kk = _chain_edges(2050)
     with pytest.raises(RuntimeError, match="unsupported"):
         Plan(ii, jj, kk, 2050, 2050, 1, upload=False)
-    # one track of frame 0 seen by 64 / 65 free cameras: the largest tile / a LOOSE track in no tile (ba_loose.hip), coupling all its cameras
-    for ncam in (64, 65):
+    # one track of frame 0 seen by 32 / 33 / 65 free cameras: the largest tile that keeps its E as double / a LOOSE track in no tile
+    # (ba_loose.hip: a plan with a few such landmarks stays float64 per edge) / loose whatever the plan, coupling all its cameras
+    for ncam in (32, 33, 65):
         N = ncam + 1
         jj = np.arange(1, N, dtype=np.int64); ii = np.zeros_like(jj); kk = np.zeros_like(jj)
         pl = Plan(ii, jj, kk, N, 4, 1, upload=False)
-        if ncam == 64:
-            assert pl.max_tile_cams == 64 and pl.tiles == 1 and pl.array("trk_loc")[0] == 0
+        if ncam == 32:
+            assert pl.max_tile_cams == 32 and pl.tiles == 1 and pl.array("trk_loc")[0] == 0
         else:
             assert pl.tiles == 0 and pl.array("trk_loc")[0] == -1 and pl.nnz_blocks == ncam * (ncam + 1) // 2
+    # MANY tracks that long (more than 64 of them): tiles of up to 64 cameras again (float32 per edge), 65 still loose
+    for ncam in (64, 65):
+        N = ncam + 1
+        jj = np.tile(np.arange(1, N, dtype=np.int64), 70); kk = np.repeat(np.arange(70, dtype=np.int64), ncam); ii = np.zeros_like(jj)
+        pl = Plan(ii, jj, kk, N, 128, 1, upload=False)
+        loc = pl.array("trk_loc")
+        if ncam == 64:
+            assert pl.max_tile_cams == 64 and (loc >= 0).all()
+        else:
+            assert pl.tiles == 0 and (loc == -1).all()
     # a track whose edges name two source frames (the caller's invariant ii = ix[kk], batrack.py:199)
     with pytest.raises(RuntimeError, match="unsupported"):
         Plan(np.array([0, 1], np.int64), np.array([2, 3], np.int64), np.array([5, 5], np.int64), 4, 8, 1, upload=False)
