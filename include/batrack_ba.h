@@ -27,8 +27,8 @@
  * Jacobians, robust weights, ba.py:228-266 / projective_ops.py:54-100) is float64 on those inputs for every plan of fewer than
  * 2048 tiles (bt_plan_edge_precision() == 8: every window of the real pipeline); beyond, the wave-per-tile kernels keep the
  * reprojection and the residual in float64 and do the Jacobians and their products in float32 (== 6; switched off by
- * bt_config_wave_per_tile_kernels(0)); float32 throughout (== 4) only where a tile's E does not fit LDS as double (a track
- * seen by more than about 30 free cameras);
+ * bt_config_wave_per_tile_kernels(0)); float32 throughout (== 4) only where a tile's E does not fit LDS as double: plans with
+ * MORE THAN 64 tracks seen by 33 .. 64 free cameras each (a few such landmarks are stepped on a float64 path of their own);
  * sums across edges, the reduced system, its factorisation and the retraction are float64 always.  The update agrees with
  * the reference's float64 run to ~1e-6 (north_star: 1e-5).
  */
@@ -78,9 +78,11 @@ typedef struct {
  * produced them; the call may then come from any host thread while other streams
  * are busy) or on the host (on_device=0).  upload=0 keeps the plan
  * host-only (no HIP call is made: CPU tests).  Errors: BT_EINVAL for indices
- * out of range, BT_EUNSUPPORTED if a single track is seen by more than 64 free
- * cameras, n > 255, or the edges of one track name different source frames (the
- * caller's invariant ii = ix[kk], batrack.py:199, is relied upon).
+ * out of range, BT_EUNSUPPORTED for more than 2048 free poses (beyond 255 the step uses a
+ * dense solver in the global workspace), more than 32768 pose slots, or the edges of one
+ * track naming different source frames (the caller's invariant ii = ix[kk], batrack.py:199,
+ * is relied upon).  No limit on the cameras a track is seen by: beyond 64 free ones (32 where
+ * a plan has few such tracks) it is stepped on a per-track path of its own, slower per edge.
  * n_all_min: lower bound for n_all (0 = derive from the edges).
  * own_lo, own_hi: multi-GPU sharding.  Every rank passes the FULL edge
  * list; the plan assembles only the tracks with own_lo <= kk < own_hi (own_hi = 0: all),
@@ -251,8 +253,8 @@ int bt_ba_status(const bt_plan *plan, void *workspace, void *stream, int32_t *st
 int bt_plan_jacobian_kernel(const bt_plan *plan);
 /* Precision of the per-edge maths (reprojection, Jacobians, robust weights, the products they enter, E) of this plan's
  * steps: 8 = float64 on the float32 inputs — every plan that takes k_tile and whose tiles' E fits LDS as double (up to
- * about 30 free cameras per tile: every window of the real pipeline, which has 15) — 4 = float32 like the reference's
- * own run (hub tracks seen by more than about 30 free cameras; BT_EDGE_PREC=0), 6 = mixed: float64 reprojection and residual,
+ * 32 free cameras per tile: every window of the real pipeline, which has 15) — 4 = float32 like the reference's
+ * own run (plans with more than 64 tracks seen by 33 .. 64 free cameras each; BT_FORCE prec=f32), 6 = mixed: float64 reprojection and residual,
  * float32 Jacobians and products (k_stream / k_edge, graphs of >= 2048 tiles; update within 1e-5 like 8, S and y 1e-7).  Sums across edges, the reduced system and its factorisation are float64 either way. */
 int bt_plan_edge_precision(const bt_plan *plan);
 /* The wave-per-tile kernels for graphs of >= 2048 tiles (k_stream, k_edge: about three times the float64 tile kernels'
