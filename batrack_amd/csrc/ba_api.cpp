@@ -461,7 +461,6 @@ int bt_plan_create(const int64_t *ii, const int64_t *jj, const int64_t *kk, int6
 // packed words, d_words, behind them), no host wait — the plan carries the event its first launches are ordered behind.
 static int clone_shifted(const bt_plan *src, const uint64_t *d_words, int64_t E, int64_t fixedp, int64_t di, int64_t dk, hipStream_t cs, bt_plan **out) {
     ApiTick tick;
-    const PackBuffers &pb_unused = pack_buffers(); (void)pb_unused;
     bt_plan *pl = plan_pool().take();
     if (!pl) return BT_ENOMEM;
     pl->info = src->info; pl->info.fixedp = fixedp; pl->info.n_all = src->info.n_all + di;
@@ -848,16 +847,12 @@ int bt_ba_step(const bt_plan *pl, const bt_ba_args *a, void *ws, void *stream) {
     const bool so = is_so(pl, a);
     if (!so && (!a->poses_out || a->poses_out == a->poses)) return BT_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ApiTick tick;
     mark_launch(pl, stream);
-    tick("step: mark_launch");
     const StepArgs s = make_args(pl, a, ws);
     const bool copy_poses = so && a->poses_out && a->poses_out != a->poses;
     bool fused = false;              // (structure-only steps on the k_tile path are one launch)
     int r = launch_reduce(pl->dev, s, pl->ws.zero_bytes / sizeof(double), so, st, nullptr, nullptr, so ? (copy_poses ? 1 : 0) : -1, &fused);
-    tick("step: reduce launched");
     if (r == BT_OK && !fused) r = launch_solve_update(pl->dev, s, so, copy_poses, st);
-    tick("step: solve + update launched");
     return r;
 }
 

@@ -11,7 +11,7 @@
 //   * the per-wave partials of (E source row, C, w), their barrier and the owner threads' merge: a track lives in one wave,
 //     its Q = 1 / (C + prior + lambda) and w' (ba.py:296-311) are formed by the track's first lane right there.
 // One barrier, then the tile's Schur product E Q E^T on v_mfma_f64_16x16x4_f64 exactly as in k_tile.  The per-edge maths is
-// float64 on the float32 inputs by default (StepArgs::prec), float32 with BT_EDGE_PREC=0.
+// float64 on the float32 inputs by default (StepArgs::prec), float32 with BT_FORCE prec=f32.
 // MODE kEtSO: structure-only steps, the whole step in this launch (the tracks' first lanes write the new disparities, the
 // workgroups behind the tile workgroups do the rest of the buffer and the poses).  MODE kEtUpd: a step's last kernel — the
 // depth back-substitution dZ = Q (w' - sum E^T dX) re-evaluated per edge (see k_update in ba_kernels.hip), the rest of the
