@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Non-finite INPUTS (a NaN / inf target, weight, disparity or pose in one to three places of a random graph): what the HIP step and the
 oracle make of them.  Not a parity test — the reference pins one such case (tests/golden/c1_nan.npz: a NaN target; both follow it) and
-nothing else about garbage in: an inf target leaves 0 * inf = NaN in y and the reference's poses NaN, where the HIP solver reports a
-failed factorisation and leaves the poses unmoved.  What this checks is that nothing crashes or hangs, and it counts the cases whose
+nothing else about garbage in: an inf target leaves 0 * inf = NaN in y only and the reference's poses NaN, where in the HIP
+kernels the NaN reaches S too, the factorisation fails and the poses stay unmoved.  What this checks is that nothing crashes or hangs, and it counts the cases whose
 finite entries or non-finite patterns differ (profiles/r06_fuzz.txt).  GPU box:  python tests/gpu_nan_fuzz.py [first_seed] [count]"""
 import os, sys
 import numpy as np
