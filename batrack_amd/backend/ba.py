@@ -93,10 +93,11 @@ def _plan_lookup(ii, jj, kk, n_buf, p_tot, fixedp, device):
     return stepper
 
 
-def _speculate(ii, jj, kk, n_buf, p_tot, fixedp, made_ahead_only=False):
+def _speculate(ii, jj, kk, n_buf, p_tot, fixedp, probe=False):
     """The plan of a list ASSUMED to be an earlier one moved up by the shift that was right last time — no synchronisation, no host
     wait, `confirm()` after the first step: a clone made ahead (Plan.preshift, with its stepper) bound to the list by one comparison
-    kernel, else a clone made here (Plan.shifted_spec).  (plan or stepper, workspace to share) or None."""
+    kernel, else a clone made here (Plan.shifted_spec).  (plan or stepper, workspace to share) or None.  `probe`: only say whether a
+    clone made ahead is there (its stepper), touching nothing."""
     if _LAST_SHIFT[0] is None or os.environ.get("BT_PLAN_SHIFT", "1") == "0" or os.environ.get("BT_PLAN_SPECULATE", "1") == "0":
         return None
     E, nb, pt, fp = ii.numel(), int(n_buf), int(p_tot), int(fixedp)
@@ -108,11 +109,12 @@ def _speculate(ii, jj, kk, n_buf, p_tot, fixedp, made_ahead_only=False):
         inf = st.plan.info
         if (inf["E"] == E and inf["n_buf"] == nb and inf["p_tot"] == pt and fp - inf["fixedp"] == _LAST_SHIFT[0]
                 and not st.plan.__dict__.get("speculative")):
+            if probe:                         # (prefetch_plan asking: is there a clone made ahead for this list?  Nothing is touched)
+                pre = _PRE.get(id(st))
+                return (pre[1], st.ws) if pre is not None and pre[0] is st and pre[1].plan.info["fixedp"] == fp else None
             pre = _PRE.pop(id(st), None)
             if pre is not None and pre[0] is st and pre[1].plan.info["fixedp"] == fp and pre[1].plan.bind(ii, jj, kk, n_buf, p_tot, fixedp):
                 return pre[1], st.ws          # made (stepper and all) while the previous update()'s steps ran: only the comparison is left
-            if made_ahead_only:
-                return None
             pl = Plan.shifted_spec(st.plan, ii, jj, kk, n_buf, p_tot, fixedp)
             if pl is not None:
                 return pl, st.ws
@@ -255,12 +257,11 @@ def prefetch_plan(ii, jj, kk, n_buf, p_tot, fixedp, device=None, background=True
     if key in _CACHE or key in _PENDING:
         return
     _lib.lib()
-    # A clone made ahead for exactly this list (Plan.preshift, during the previous update()): bound here and now, on the caller's
-    # thread — one comparison kernel on the stream that made the list — and the first BA call finds its plan in the cache (it
-    # confirms after its first step like any speculative plan; by then the verdict has long arrived).
-    got = _speculate(ii, jj, kk, n_buf, p_tot, fixedp, made_ahead_only=True)
-    if got is not None:
-        _store(key, got[0], ii, jj, kk)
+    # A clone made ahead for this list (Plan.preshift, during the previous update()) waits for it: nothing to build.  It is NOT bound
+    # here — measured (tools/gpu_update_floor.py, PREFETCH=1 AB=1): with the comparison launched at prefetch time the update() took
+    # 0.412 ms against 0.38-0.39 with the first BA call launching it — in front of the step the comparison also wakes the idle GPU
+    # while the host is still preparing the step's launches.
+    if _speculate(ii, jj, kk, n_buf, p_tot, fixedp, probe=True) is not None:
         return
     ready = torch.cuda.Event()
     caller_stream = torch.cuda.current_stream(dev)
