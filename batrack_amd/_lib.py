@@ -12,7 +12,7 @@ SOURCES = ["ba_kernels.hip", "ba_etile.hip", "ba_stream.hip", "ba_edge2.hip", "b
 HEADERS = ["ba_kernels.hpp", "ba_plan.hpp", "ba_edge.hpp", "ba_update.hpp", "dev_cache.hpp", "ba_edge2.hpp", "probe.hpp", os.path.join("..", "..", "include", "batrack_ba.h"),
            os.path.join("..", "..", "include", "batrack_se3.h"), os.path.join("..", "..", "include", "batrack_patchify.h"),
            os.path.join("..", "..", "include", "batrack_projective.h"), os.path.join("..", "..", "include", "batrack_ga.h")]
-# -fno-slp-vectorize: packed f32 pairs cost more register moves than the packed instructions save (measured on k_edge)
+# -fno-slp-vectorize: packed f32 pairs cost more register moves than the packed instructions save (measured on k_edge, round 4's kernel; k_edge2 writes its packed pairs out by hand)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
 
 BT_OK, BT_EINVAL, BT_ENOMEM, BT_EHIP, BT_EUNSUPPORTED = 0, -1, -2, -3, -4

@@ -36,7 +36,7 @@ __device__ inline void quat_to_rot(const double *q, double R[9]) {
 // Relative pose of camera pair (i, j) and the intrinsics the edge maths needs, 20 numbers:
 // R_ij (9, row-major), t_ij (3), (1/fx_i, 1/fy_i, cx_i, cy_i), (fx_j, fy_j, cx_j, cy_j).
 // Gij = Gj * Gi^-1 (projective_ops.py:61) in double; a self edge is exactly the identity.
-// T = float: rounded to float32 (the float32 per-edge path, k_stream / k_edge); T = double: kept (the float64 per-edge path).
+// T = float: rounded to float32 (the float32 per-edge path, k_stream / k_edge2); T = double: kept (the float64 per-edge path).
 // RAWK: g[12], g[13] hold fx_i, fy_i themselves instead of their reciprocals (edge_eval_mixed divides in double: a float32
 // reciprocal of the one focal length every camera shares is the SAME 6e-8 off for every edge of the graph — a bias along the
 // weakly constrained directions of the reduced system, which it took to find: dX 3e-5 with it, 2e-6 without).
@@ -173,7 +173,7 @@ __device__ __forceinline__ void edge_eval_mixed(const float *g, float x, float y
     o.r0 = vld * r0; o.r1 = vld * r1;
 }
 
-// what the wave-per-tile kernels (k_stream, k_edge) evaluate an edge with; -DBT_WPT_MIXED=0: plain float32 (measurement builds)
+// what the wave-per-tile kernels (k_stream, k_edge2, k_edge2u) evaluate an edge with; -DBT_WPT_MIXED=0: plain float32 (measurement builds)
 #ifndef BT_WPT_MIXED
 #define BT_WPT_MIXED 1
 #endif

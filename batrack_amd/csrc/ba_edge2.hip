@@ -1,5 +1,5 @@
 // ba_edge2.hip — k_edge2: the pose+structure Jacobian kernel for graphs of many SLOT-UNIFORM tiles, TWO EDGES PER LANE
-// (gfx950, wave64).  Round 5: what bounds k_edge (ba_stream3.hip) is the number of vector instructions a wave has to issue
+// (gfx950, wave64).  Round 5: what bounded round 4's one-edge-per-lane k_edge (deleted) was the number of vector instructions a wave has to issue
 // (~430 per edge-lane, profiles/r04_pmc_sq_e8m.txt), not bytes.  Same edge-major tables (it_edge, tile_sinfo, tile_rec), but
 //   * a STEP is two iterations of the table: a lane handles the same slot of TWO tracks (track t and t + G of the step's 2G
 //     tracks).  Both edges meet the same camera pair, so they share the pair's geometry (one set of LDS reads) and the 26
@@ -806,7 +806,7 @@ static int launch_t(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEve
 
 }  // namespace e2
 
-// pose+structure reduce of a plan k_edge applies to (edge_applies, ba_stream3.hip)
+// pose+structure reduce of a plan the edge-major layout applies to (edge_applies, ba_plan.hpp)
 int launch_edge2(const PlanDev &pd, const StepArgs &a, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     if ((unsigned long long)pd.e_all * (unsigned long long)a.tstride * 4ull >= (1ull << 32)) return BT_EUNSUPPORTED;   // 32-bit byte offsets into the targets
     if ((unsigned long long)pd.p_tot * (unsigned long long)a.mstride * 4ull >= (1ull << 32)) return BT_EUNSUPPORTED;

@@ -29,7 +29,7 @@ struct StepArgs {
 
 int configure_kernels(const PlanDev &pd);
 // precision of the per-edge maths for this plan: 1 = float64 (graphs that take k_tile, unless BT_FORCE prec=f32 or the
-// tile's E would not fit LDS as double), 0 = float32 (k_stream / k_edge: graphs of >= 2048 tiles)
+// tile's E would not fit LDS as double), 0 = float32 (k_stream / k_edge2: graphs of >= 2048 tiles)
 int edge_precision(const PlanDev &pd);
 // wave-per-tile streaming kernels (ba_stream.hip) for graphs of many tiles; mode 0 = pose+structure, 1 = structure-only,
 // 2 = depth back-substitution

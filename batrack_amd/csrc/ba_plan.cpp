@@ -26,7 +26,7 @@ namespace bt {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Tile counts from which a plan is laid out for the wave-per-tile kernels k_stream / k_edge (2048: profiles/r02_kernel_choice.txt).
+// Tile counts from which a plan is laid out for the wave-per-tile kernels k_stream / k_edge2 (2048: profiles/r02_kernel_choice.txt).
 // Those kernels evaluate an edge in MIXED precision since round 4 (reprojection and residual in float64, Jacobians and their
 // products in float32: ba_edge.hpp edge_eval_mixed) and keep the update within north_star's 1e-5 of the reference's float64
 // run (measured 1e-6 .. 5e-6 on the benchmark graphs; S and y 1e-7).  A caller who wants the reduced system itself to 1e-10
@@ -829,15 +829,25 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     // More than kMaxFree (255) free poses: the block-sparse solvers' tables hold pose numbers in 8 bits and block numbers in 15.
     // Such a system (a global / loop-closing adjustment; the reference's dense solve has no size clause, ba.py:60-70) is solved
     // DENSE in the global workspace (ba_dense.hip): no symbolic factorisation here, the natural order, every lower block "non-zero".
-    pl->wide = n > kMaxFree ? 1 : 0;
-    if (pl->wide) {
+    // The same solver takes the systems of FEWER poses whose block-sparse factor does not fit LDS as double (decided below, once
+    // the symbolic factorisation has counted its blocks): a hundred poses tied by long-range edges fill in to a nearly dense factor,
+    // which the block-sparse solvers can only hold as float32 (or in global memory) — 24 ms a solve at 179 poses and a float32
+    // factor's precision, against the dense solver's 3 ms in double.
+    const auto go_wide = [&]() {
+        pl->wide = 1;
         pl->perm.resize((size_t)n);
         std::iota(pl->perm.begin(), pl->perm.end(), 0);
         pl->col_ptr.assign((size_t)n + 1, 0); pl->upd_ptr.assign((size_t)n + 1, 0); pl->upd_next.assign((size_t)n + 1, 0);
         pl->lvl_ptr.assign(1, 0); pl->dp_ptr.assign((size_t)n + 1, 0);
+        for (auto *v : {&pl->row_idx, &pl->upd, &pl->blk_col, &pl->blk_src, &pl->lvl_cols, &pl->col_lvl, &pl->dp, &pl->lvl_meta, &pl->fz_pend_ptr,
+                        &pl->fz_pend, &pl->fz_lazy_ptr, &pl->fz_lazy, &pl->fz_yurg, &pl->fz_meta, &pl->fz_pmeta, &pl->bs_sync, &pl->fz_rowinfo,
+                        &pl->fz_pfirst, &pl->fz_psecond})
+            v->clear();
         pl->fz_ok = 0; pl->fzp_ok = 0;
         I.nnz_blocks = n * (n + 1) / 2; I.updates = 0;
-    }
+    };
+    pl->wide = 0;
+    if (n > kMaxFree) go_wide();
     const auto symbolic = [&]() -> int {
     // ---- block structure of S (lower) and symbolic Cholesky ----------------
     // S[u][v] (u >= v) may be non-zero if u and v share a tile (Schur term,
@@ -1255,7 +1265,22 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
 
     return BT_OK;
     };
-    if (!pl->wide) { const int src_rc = symbolic(); if (src_rc != BT_OK) return src_rc; }
+    if (!pl->wide) {
+        const int src_rc = symbolic();
+        if (src_rc != BT_OK) return src_rc;
+        // The factor does not fit LDS as double: float32 with refinement (three solves), or the dense solver — whichever is priced
+        // lower.  Measured (tools/gpu_solver_choice.py, profiles/r06_solver_choice.txt): a block-sparse solve outside LDS-as-double
+        // costs ~8 us a level + 26 ns a block update (a 255-pose band of half-width 7: 131 levels, 7k updates, 1.2 ms; 255 poses
+        // tied by long-range edges: 2.8M updates, 70 ms), the dense solver ~19 us a pose whatever the pattern (launch-bound: 3
+        // launches per 48 columns, 255 poses 4.9 ms).  Long bands stay block-sparse, filled-in systems go dense (95 poses: 12.4 ->
+        // 1.6 ms a step, 255: 210 -> 5.3 ms) and get a float64 factor with it.
+        // (a forced solver — tests, measurement — keeps the block-sparse tables whatever their size)
+        const size_t nlev = pl->lvl_ptr.size() - 1;
+        if (force().solver < 0 &&
+            solve_lds_bytes_raw((size_t)I.nnz_blocks, (size_t)(6 * n), (size_t)I.updates, (size_t)n, nlev, pl->dp.size(), sizeof(double)) > kLdsBudget &&
+            3.0 * (8.0 * (double)nlev + 0.026 * (double)I.updates) > 19.0 * (double)n)
+            go_wide();
+    }
 
     BT_TICK("13");
     // ---- k_tile's first loads, indexed by the tile alone (no dependent index chain in its prologue):

@@ -29,6 +29,19 @@ constexpr int kPrivArrive = 8192;   // ints: xcc (3 bits) | se (3) | sh (1) | cu
 constexpr int kPairGeomFloats = 20; // R(9) t(3) Ki(4) Kj(4)
 constexpr int kLdsRowStride = 66;
 constexpr int kMaxLevelCols = 4;
+// LDS a solver workgroup may ask for (160 KB a CU), and what the block-sparse factor with its tables takes there at `elem` bytes
+// per number: the planner sends systems whose factor does not fit as double to the dense solver (ba_plan.cpp: `wide`).
+constexpr size_t kLdsBudget = 160 * 1024 - 512;
+inline size_t solve_lds_bytes_raw(size_t nnzb, size_t D, size_t nupd, size_t n, size_t nlev, size_t ndp, size_t elem) {
+    size_t b = (nnzb * 36 + 2 * D) * elem;                                 // Lw, z, zt
+    b = (b + 15) / 16 * 16;
+    b += nupd * 3 * sizeof(unsigned short);                                // update triples
+    b = (b + 15) / 16 * 16;
+    // row_idx, col_ptr, upd_ptr, upd_next, dp_ptr, lvl_ptr, lvl_cols, dp
+    b += (nnzb + 4 * (n + 1) + nlev + 1 + n + ndp) * sizeof(int);
+    b = (b + 15) / 16 * 16 + nlev * kMaxLevelCols * 8 * sizeof(int);       // lvl_meta
+    return b + 64;
+}
 constexpr int kSpGroupMax = 32;     // tiles per group of k_pair_finalize's positional sums of the tiles' Schur products
 constexpr int kMaxTilePairs = 192;  // distinct camera pairs per tile whose geometry is kept in LDS    // columns of the reduced system factored concurrently (one critical wave each)   // floats per local E row (bank-conflict-free)
 
@@ -93,7 +106,7 @@ struct PlanDev {
     const int32_t *lz_trk, *lz_ptr, *lz_edge, *lz_pair;      // track of loose track l; its edges [lz_ptr[l], lz_ptr[l + 1]): edge id, camera pair
     int nlz;
     int dev_id;                                              // the device the plan's tables live on (the launchers' per-device caches: no hipGetDevice per launch)
-    int wide;                                                // more than kMaxFree free poses: the dense solver (ba_dense.hip); perm is the identity, the packed form is the lower triangle by blocks
+    int wide;                                                // more than kMaxFree free poses, or a factor too large for LDS as double: the dense solver (ba_dense.hip); perm is the identity, the packed form is the lower triangle by blocks
     int trk_off;                                             // sharded plan: distinct tracks of the full edge list in front of this rank's first
     int em_self;                                             // some edge has ii == jj (its source-camera E lands on a target row)
     int em_ok, em_its, em_lgs;                               // every tile slot-uniform; total iterations; log2 S if the same for all tiles, else -1
@@ -151,7 +164,7 @@ struct bt_plan {
     std::vector<int32_t> pp_ptr, pp_idx, sg_ptr;
     std::vector<int32_t> lz_trk, lz_ptr, lz_edge, lz_pair;   // loose tracks (more than kTileCamHard free cameras)
     int pm_ok = 0, sp_ok = 0, sg_n = 0, et_lgts = 0, trk_off = 0;
-    int wide = 0;                                             // more than kMaxFree free poses: dense solve, no symbolic factorisation
+    int wide = 0;                                             // more than kMaxFree free poses, or a factor too large for LDS as double: dense solve, no symbolic tables
     int nlz = 0;                                              // loose tracks (set at upload; clones copy it)
     int dev_id = 0;                                           // the device the tables were uploaded to
     // plans whose pm_edge is written on the device (plan_device.hip): the table's rounds, and what the kernels need of the host's analysis
@@ -235,7 +248,7 @@ struct Force {
 const Force &force();
 // BT_PLAN_PROF: time per planner phase on stderr (measurement)
 bool plan_prof();
-// Tile counts from which the wave-per-tile kernels take a graph (k_edge, k_stream; the environment overrides are for
+// Tile counts from which the wave-per-tile kernels take a graph (k_edge2, k_stream; the environment overrides are for
 // measurement and tests).  The planner lays out their tables only for plans that will use them.
 int edge_min_tiles();
 int stream_min_tiles();
@@ -290,11 +303,11 @@ int plan_device_rounds(const bt_plan *pl, int64_t E, void *stream, int64_t *roun
 int plan_device_fill(const bt_plan *pl, int64_t E, int32_t *d_rec, int32_t *d_pm_edge, int64_t rounds, void *stream);
 int plan_device_slots_stage(const bt_plan *pl, void *stream);
 // the tables of the wave-per-tile kernels, written by the same passes (device pointers into the plan's buffer; tile_rec is the
-// host's upload, the passes add the straddle flag; it_edge / tile_sinfo null: the layout of k_edge does not apply)
+// host's upload, the passes add the straddle flag; it_edge / tile_sinfo null: the layout of k_edge2 does not apply)
 struct DevWptOut { uint16_t *slot_code; uint8_t *tile_la; int32_t *tile_rec; int32_t *it_edge; uint32_t *tile_sinfo; int64_t its; };
 int plan_device_slots_fill(const bt_plan *pl, int64_t E, int32_t *d_slot_edge, int32_t *d_slot_pair, uint16_t *d_slot_lab, uint8_t *d_slot_lp,
                            uint16_t *d_cut8, uint16_t *d_cut16, void *stream, const DevWptOut *wpt = nullptr);
-// after the stream of plan_device_slots_fill has been waited for: 1 = some tile is not slot-uniform (no k_edge for this plan)
+// after the stream of plan_device_slots_fill has been waited for: 1 = some tile is not slot-uniform (no k_edge2 for this plan)
 int plan_device_em_verdict();
 // Copies the arrays to the device and fills plan->dev (ba_api.cpp).
 int upload_plan(bt_plan *plan);

@@ -16,7 +16,7 @@
 // The host keeps what is small: tracks, pairs, tiles, the reduced system's symbolic factorisation (ba_plan.cpp reads the
 // per-patch table instead of the edges).  64-track layouts: k_plan_slots / k_plan_cuts instead of the last three — and, for the
 // graphs of the wave-per-tile kernels (2048 tiles and more), k_plan_slots writes their compact tables as well and k_plan_sinfo
-// decides whether the edge-major layout of k_edge applies (every tile slot-uniform).  A sharded plan runs the passes on the
+// decides whether the edge-major layout of k_edge2 applies (every tile slot-uniform).  A sharded plan runs the passes on the
 // rank's segment of the sorted list.  Anything that does not fit — a track whose target frames are not within 64 of its source
 // frame, two source frames for one track — falls back to the analysis on the edges.
 #include <hip/hip_runtime.h>

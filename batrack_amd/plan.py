@@ -23,7 +23,7 @@ PLAN_ARRAYS = ("kx", "trk_of_patch", "trk_loc", "pair_i", "pair_j", "tile_trk0",
 
 
 def wave_per_tile_kernels(enable=None):
-    """The wave-per-tile kernels (k_stream, k_edge) for graphs of >= 2048 tiles, on by default: mixed precision (float64
+    """The wave-per-tile kernels (k_stream, k_edge2 / k_edge2u) for graphs of >= 2048 tiles, on by default: mixed precision (float64
     reprojection and residual, float32 Jacobians), update within 1e-5 of the reference's float64 run, about three times the
     float64 tile kernels' throughput.  `wave_per_tile_kernels(False)` lays the plans created afterwards out for the float64
     tile kernels whatever their size (include/batrack_ba.h: bt_config_wave_per_tile_kernels).  Returns the previous setting; no
@@ -222,7 +222,7 @@ class Plan:
 
     @property
     def edge_precision(self):
-        """8 | 6 | 4: float64 per edge, mixed (float64 reprojection and residual, float32 Jacobians: k_stream / k_edge), float32
+        """8 | 6 | 4: float64 per edge, mixed (float64 reprojection and residual, float32 Jacobians: k_stream / k_edge2), float32
         (bt_plan_edge_precision)."""
         return self._lib.bt_plan_edge_precision(self._h)
 

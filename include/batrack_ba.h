@@ -29,8 +29,11 @@
  * reprojection and the residual in float64 and do the Jacobians and their products in float32 (== 6; switched off by
  * bt_config_wave_per_tile_kernels(0)); float32 throughout (== 4) only where a tile's E does not fit LDS as double: plans with
  * MORE THAN 64 tracks seen by 33 .. 64 free cameras each (a few such landmarks are stepped on a float64 path of their own);
- * sums across edges, the reduced system, its factorisation and the retraction are float64 always.  The update agrees with
- * the reference's float64 run to ~1e-6 (north_star: 1e-5).
+ * sums across edges, the reduced system and the retraction are float64 always.  The factorisation is float64 wherever the
+ * block-sparse factor fits LDS as double (every window of the real pipeline, the 64-keyframe benchmark graph) and wherever the
+ * system is solved dense (more than 255 free poses; fewer poses whose factor fills in beyond LDS and is cheaper dense); long thin
+ * bands beyond LDS are factored in float32 and refined twice against the float64 system, which leaves dX at the float32 rounding
+ * it is stored in.  The update agrees with the reference's float64 run to ~1e-6 (north_star: 1e-5).
  */
 #ifndef BATRACK_BA_H
 #define BATRACK_BA_H
@@ -78,8 +81,9 @@ typedef struct {
  * produced them; the call may then come from any host thread while other streams
  * are busy) or on the host (on_device=0).  upload=0 keeps the plan
  * host-only (no HIP call is made: CPU tests).  Errors: BT_EINVAL for indices
- * out of range, BT_EUNSUPPORTED for more than 2048 free poses (beyond 255 the step uses a
- * dense solver in the global workspace), more than 32768 pose slots, or the edges of one
+ * out of range, BT_EUNSUPPORTED for more than 2048 free poses (beyond 255 — and for fewer poses
+ * with a filled-in factor that outgrows LDS — the step uses a dense solver in the global
+ * workspace), more than 32768 pose slots, or the edges of one
  * track naming different source frames (the caller's invariant ii = ix[kk], batrack.py:199,
  * is relied upon).  No limit on the cameras a track is seen by: beyond 64 free ones (32 where
  * a plan has few such tracks) it is stepped on a per-track path of its own, slower per edge.
@@ -247,7 +251,7 @@ float *bt_ba_dx(const bt_plan *plan, void *workspace);
 int bt_ba_status(const bt_plan *plan, void *workspace, void *stream, int32_t *status);
 
 /* Which Jacobian kernel the steps of this (uploaded) plan launch: 0 = k_tile (one tile per workgroup), 1 = k_stream (two
- * waves per tile, tiles streamed), 2 = k_edge (edge-major, one wave per tile), 3 = k_etile (pair-major lanes, one tile of 16
+ * waves per tile, tiles streamed), 2 = k_edge2 (edge-major, one wave per tile, two edges per lane), 3 = k_etile (pair-major lanes, one tile of 16
  * tracks per workgroup: sliding-window graphs) — chosen from the plan's size and shape; -1 for a host-only
  * plan.  For tests and tooling. */
 int bt_plan_jacobian_kernel(const bt_plan *plan);
@@ -255,9 +259,9 @@ int bt_plan_jacobian_kernel(const bt_plan *plan);
  * steps: 8 = float64 on the float32 inputs — every plan that takes k_tile and whose tiles' E fits LDS as double (up to
  * 32 free cameras per tile: every window of the real pipeline, which has 15) — 4 = float32 like the reference's
  * own run (plans with more than 64 tracks seen by 33 .. 64 free cameras each; BT_FORCE prec=f32), 6 = mixed: float64 reprojection and residual,
- * float32 Jacobians and products (k_stream / k_edge, graphs of >= 2048 tiles; update within 1e-5 like 8, S and y 1e-7).  Sums across edges, the reduced system and its factorisation are float64 either way. */
+ * float32 Jacobians and products (k_stream / k_edge2, graphs of >= 2048 tiles; update within 1e-5 like 8, S and y 1e-7).  Sums across edges, the reduced system and its factorisation are float64 either way. */
 int bt_plan_edge_precision(const bt_plan *plan);
-/* The wave-per-tile kernels for graphs of >= 2048 tiles (k_stream, k_edge: about three times the float64 tile kernels'
+/* The wave-per-tile kernels for graphs of >= 2048 tiles (k_stream, k_edge2: about three times the float64 tile kernels'
  * throughput there).  They evaluate an edge in MIXED precision — reprojection and residual in float64 on the float32 inputs,
  * Jacobians and their products in float32 — which keeps the pose / depth update within the 1e-5 of the reference's float64
  * run this library promises (measured 1e-6 .. 5e-6 on the benchmark graphs; S and y themselves 1e-7 instead of the tile

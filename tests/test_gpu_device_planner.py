@@ -92,7 +92,7 @@ WPT_TABLES = ("slot_code", "tile_la", "tile_rec", "it_edge", "tile_sinfo")
 
 
 def compare_wave_per_tile_tables(dev, host):
-    """slot_code, tile_la, tile_rec always; the edge-major tables of k_edge where the host found every tile slot-uniform (and
+    """slot_code, tile_la, tile_rec always; the edge-major tables of k_edge2 where the host found every tile slot-uniform (and
     the device must have reached the same verdict: the two plans launch the same kernel)."""
     assert dev.jacobian_kernel == host.jacobian_kernel
     uniform = host.array("it_edge").size > 0
@@ -232,7 +232,7 @@ def test_sharded_plans_are_laid_out_on_the_device_too(graph, world):
 @pytest.mark.skipif(FORCED, reason="kernel / planner selection forced by the environment")
 @pytest.mark.parametrize("variant", ["k_edge_2048", "k_edge_8192", "k_edge_8192_shuffled", "repeats", "ragged", "sharded"])
 def test_device_planned_tables_of_the_wave_per_tile_kernels_equal_the_hosts(variant):
-    """Graphs of 2048 tiles and more (k_stream, k_edge): slot_code, tile_la, the tile records with their straddle flag, and — where
+    """Graphs of 2048 tiles and more (k_stream, k_edge2): slot_code, tile_la, the tile records with their straddle flag, and — where
     every tile is slot-uniform — it_edge and tile_sinfo come from kernels (plan_device.hip) and equal the host's."""
     rng = np.random.default_rng(23)
     g, fixedp = graphgen.make_graph(64, 2048 if variant == "k_edge_2048" else 8192 if "8192" in variant else 4096, 8, seed=6), 1
@@ -274,14 +274,14 @@ def test_random_many_tile_lists_plan_alike_on_device_and_host(seed):
     in every second list, shuffled, any fixedp; odd seeds: a rank's range of a sharded solve): whichever wave-per-tile kernel the
     planner picks, every table of the device-planned plan is the host's."""
     rng = np.random.default_rng(900 + seed)
-    n_frames, M = int(rng.integers(28, 40)), int(rng.choice([6144, 8192])) * (2 if seed % 2 or seed == 0 else 1)     # (a rank of two keeps 2048 tiles; seed 0: 4096 for k_edge)
+    n_frames, M = int(rng.integers(28, 40)), int(rng.choice([6144, 8192])) * (2 if seed % 2 or seed == 0 else 1)     # (a rank of two keeps 2048 tiles; seed 0: 4096 for k_edge2)
     n_buf, p_tot = n_frames + 2, (n_frames + 1) * M
     src = np.repeat(np.arange(n_frames), M)
     pat = src * M + np.tile(np.arange(M), n_frames)
-    alive = rng.random(pat.size) < (2.0 if seed == 0 else 0.97)          # (seed 0: no gaps, tiles inside a frame: slot-uniform, k_edge)
+    alive = rng.random(pat.size) < (2.0 if seed == 0 else 0.97)          # (seed 0: no gaps, tiles inside a frame: slot-uniform, k_edge2)
     src, pat = src[alive], pat[alive]
     # per track: a window of targets around the source frame, the same for the tracks of a frame in even seeds (slot-uniform
-    # tiles: k_edge), thinned per track in odd ones (k_stream)
+    # tiles: k_edge2), thinned per track in odd ones (k_stream)
     span = int(rng.integers(2, 5))                                       # (at most 10 cameras per tile: the wave-per-tile kernels' limit)
     off = np.arange(-span, span + 1)
     off = off[off != 0]

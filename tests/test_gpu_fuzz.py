@@ -21,6 +21,11 @@ import force as _force  # noqa: E402  (tests/force.py)
 
 pytestmark = pytest.mark.gpu
 FORCED_F32 = _force.f32_edges()
+# lmbda and alpha as the step receives them: float32 (include/batrack_ba.h: bt_ba_args; the reference adds its Python floats to float32
+# tensors, ba.py:302-303, i.e. rounds them the same way).  The float64 oracle is handed THESE values: with the doubles 1e-4 / 0.05 a
+# graph whose tracks lean on the depth prior shows alpha's rounding (1.5e-8) in [S | y] — 9.0e-9 / 6.4e-9 on seeds 30971 / 30470, to
+# six digits what the oracle itself gives between the two alphas — and that is not an error of the step.
+ABI_SCALARS = dict(lmbda=float(np.float32(1e-4)), alpha=float(np.float32(0.05)))
 
 
 def draw(seed, big=False):
@@ -102,7 +107,7 @@ def check(seed, big=False):
     from gpu_util import HipProblem, rel, update_err
     d, fixedp, so, loss, wkey, desc = draw(seed, big)
     ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"],
-                         d["bounds"], fixedp=fixedp, structure_only=so, loss=loss, want_system=True)
+                         d["bounds"], fixedp=fixedp, structure_only=so, loss=loss, want_system=True, **ABI_SCALARS)
     hp = HipProblem(d)
     o = hp.raw_step(wkey, fixedp, so=so, loss=loss)
     plan = o["plan"]
@@ -114,9 +119,16 @@ def check(seed, big=False):
     # gates of a float32 edge pass on [S | y], and of every path on the state — the update of an ill-conditioned random system amplifies
     # the float32 rounding of dX by its condition number.
     ref32 = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"],
-                           d["bounds"], fixedp=fixedp, structure_only=so, loss=loss, dtype=np.float32, want_system=True)
-    if solved and np.abs(ref["S"]).max() < 1e-20:
-        solved = False                                # (no valid edge reaches a free pose: two roundings of zero have no relative error)
+                           d["bounds"], fixedp=fixedp, structure_only=so, loss=loss, dtype=np.float32, want_system=True, **ABI_SCALARS)
+    if solved:
+        # No valid edge reaches a free pose, or only SELF edges do (ii == jj: Gij is the identity, Ji = -Jj, and the edge's blocks cancel
+        # to zero in exact arithmetic — seed 32333: the float64 oracle keeps 2.9e-11 of rounding there, its float32 run 2e-25, the HIP
+        # step, which knows a self edge's Ad to be exactly I, something else again): S is rounding noise against the size of the edges' own
+        # blocks, and two roundings of zero have no relative error.
+        eo = oracle.edges(d["poses"], d["patches"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"], d["bounds"], loss=loss)
+        blk = float((eo["W"][:, :, None] * np.maximum(eo["Ji"] ** 2, eo["Jj"] ** 2)).max()) if d["ii"].size else 0.0
+        if np.abs(ref["S"]).max() <= 1e-12 * blk or np.abs(ref["S"]).max() < 1e-20:
+            solved = False
     if solved:
         errs["S"] = rel(np.tril(o["S_lower"]), np.tril(ref["S"])); errs["y"] = rel(o["y"], ref["y"])
         errs["ref32_S"] = rel(np.tril(ref32["S"]), np.tril(ref["S"])); errs["ref32_y"] = rel(ref32["y"], ref["y"])
@@ -126,7 +138,7 @@ def check(seed, big=False):
         k32 = 10.0 if FORCED_F32 else 2.0
         # (2e-5: the gate of the hub-track case of tests/test_gpu_parity.py — tiles of 40 cameras sum their float32 rows in long chains)
         ok_S = max(2e-5, k32 * errs["ref32_S"]) if f32 else max(1e-9, 1e-3 * errs["ref32_S"])
-        ok_y = max(2e-5, k32 * errs["ref32_y"]) if f32 else max(5e-9, 1e-3 * errs["ref32_y"])
+        ok_y = max(2e-5, k32 * errs["ref32_y"]) if f32 else max(1e-9, 1e-3 * errs["ref32_y"])
         assert errs["S"] < ok_S and errs["y"] < ok_y, (desc, errs)
         assert (o["status"] != 0) == ref["failed"] or o["status"] in (0, 1), (desc, o["status"], ref["failed"])
     hard_p = rel(ref32["poses_out"], ref["poses_out"]); hard_d = rel(ref32["patches_out"], ref["patches_out"])
@@ -152,10 +164,10 @@ def check(seed, big=False):
         torch.cuda.synchronize()
         r2 = ref if so2 == (so or plan.n == 0) else oracle.ba_step(
             d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"], d["bounds"],
-            fixedp=fixedp, structure_only=so2, loss=loss)
+            fixedp=fixedp, structure_only=so2, loss=loss, **ABI_SCALARS)
         r32 = ref32 if so2 == (so or plan.n == 0) else oracle.ba_step(
             d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"], d["bounds"],
-            fixedp=fixedp, structure_only=so2, loss=loss, dtype=np.float32)
+            fixedp=fixedp, structure_only=so2, loss=loss, dtype=np.float32, **ABI_SCALARS)
         hp2, hd2 = rel(r32["poses_out"], r2["poses_out"]), rel(r32["patches_out"], r2["patches_out"])
         ep2, ed2 = rel(Pout.cpu().numpy(), r2["poses_out"]), rel(pout.cpu().numpy(), r2["patches_out"])
         assert ep2 < max(floor, k32 * hp2) and ed2 < max(floor, k32 * hd2), (desc, "again, structure-only" if so2 else "again, poses", ep2, ed2, hp2, hd2)

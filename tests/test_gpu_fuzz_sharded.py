@@ -52,9 +52,9 @@ def _worker(rank, world, port, seeds, out, big=False):
                 continue
             if rank == 0:
                 ref = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"],
-                                     d["bounds"], fixedp=fixedp, structure_only=so, loss=loss)
+                                     d["bounds"], fixedp=fixedp, structure_only=so, loss=loss, **F.ABI_SCALARS)
                 ref32 = oracle.ba_step(d["poses"], d["patches"], d["mono"], d["intrinsics"], d["targets3"], d[wkey], d["ii"], d["jj"], d["kk"],
-                                       d["bounds"], fixedp=fixedp, structure_only=so, loss=loss, dtype=np.float32)
+                                       d["bounds"], fixedp=fixedp, structure_only=so, loss=loss, dtype=np.float32, **F.ABI_SCALARS)
                 hp, hd = rel(ref32["poses_out"], ref["poses_out"]), rel(ref32["patches_out"], ref["patches_out"])
                 ep, ed = rel(Pn.cpu().numpy(), ref["poses_out"]), rel(full.cpu().numpy(), ref["patches_out"])
                 floor = 8e-6 if f32 else 3e-7

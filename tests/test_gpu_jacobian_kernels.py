@@ -1,6 +1,6 @@
-"""-m gpu: the Jacobian kernels.  A plan picks k_tile, k_stream or k_edge (k_edge2 + k_edge) from its size and shape; the
+"""-m gpu: the Jacobian kernels.  A plan picks k_tile, k_stream or k_edge2 (+ k_edge2u for the depth pass) from its size and shape; the
 fixtures are small and all take k_tile, so (a) graphs of the benchmark generator large enough for the plan to pick k_stream
-and k_edge BY ITSELF are compared with the float64 oracle, and (b) the whole parity suite is re-run in child processes with
+and k_edge2 BY ITSELF are compared with the float64 oracle, and (b) the whole parity suite is re-run in child processes with
 the selection forced (the thresholds are read once per process), so every fixture that fits a kernel's layout goes through it."""
 import os
 import subprocess
@@ -46,7 +46,7 @@ def ragged(g, drop=0.15):
 
 @pytest.mark.parametrize("frames,M,kernel,so,wpt", [(16, 16, "k_tile", False, True), (64, 1024, "k_tile", False, True),
                                                   # from 2048 tiles the wave-per-tile kernels, mixed precision: inside the 1e-5 bar:
-                                                  # k_edge2 / k_edge where the tiles are slot-uniform, k_stream where they are not ...
+                                                  # k_edge2 / k_edge2u where the tiles are slot-uniform, k_stream where they are not ...
                                                   (64, 2048, "k_stream", False, True), (64, 2048, "k_stream", True, True),
                                                   (64, 2048, "ragged", False, True), (64, 2048, "ragged", True, True), (64, 8192, "ragged", False, True),
                                                   (64, 2048, "k_edge2", False, True), (64, 4096, "k_edge2", False, True),

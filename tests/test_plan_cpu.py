@@ -185,6 +185,18 @@ def test_plan_limits():
     assert pl.n == 256 and pl.nnz_blocks == 256 * 257 // 2 and np.array_equal(pl.array("perm"), np.arange(256))
     ii, jj, kk = _chain_edges(2049)
     assert Plan(ii, jj, kk, 2049, 2049, 1, upload=False).n == 2048
+    # fewer than 256 poses whose factor does not fit LDS as double: a long thin band stays block-sparse (float32 factor, refined); a graph
+    # with long-range edges fills in and is priced cheaper DENSE (ba_plan.cpp, tools/gpu_solver_choice.py) — perm the identity, every block
+    rng = np.random.default_rng(5)
+    N, M, K = 120, 8, 8
+    kk = np.repeat(np.arange(N * M, dtype=np.int64), K); ii = kk // M
+    jb = np.clip(ii + np.tile(np.arange(K, dtype=np.int64) - 3, N * M), 0, N - 1)
+    band = Plan(ii, jb, kk, N, N * M, 1, upload=False)
+    assert band.n == N - 1 and band.nnz_blocks < (N - 1) * N // 2 // 4 and band.updates > 0
+    jf = np.where(rng.random(ii.size) < 0.3, rng.integers(0, N, ii.size), jb)
+    filled = Plan(ii, jf, kk, N, N * M, 1, upload=False)
+    assert filled.n == N - 1 and filled.nnz_blocks == (N - 1) * N // 2 and filled.updates == 0
+    assert np.array_equal(filled.array("perm"), np.arange(N - 1))
     ii, jj, kk = _chain_edges(2050)
     with pytest.raises(RuntimeError, match="unsupported"):
         Plan(ii, jj, kk, 2050, 2050, 1, upload=False)

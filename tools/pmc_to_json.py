@@ -24,7 +24,7 @@ def kernel_avg(db, counter):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
     # the step's kernels by their template names (a planner kernel like k_edge_tables is none of them); mode 2 of k_tile / k_etile /
-    # k_stream / k_edge is the step's last kernel, k_edge2's first template argument is a tile count
+    # k_stream / k_edge2u is the step's last kernel, k_edge2's first template argument is a tile count
     rows = [r for r in rows if re.search(r"\bk_(tile|etile|stream|edge|edge2)<", r[0]) and "upd" not in r[0].lower()
             and not re.search(r"\bk_(tile|etile|stream|edge)<2", r[0])]
     if not rows:
