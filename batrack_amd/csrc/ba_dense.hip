@@ -47,41 +47,78 @@ __global__ __launch_bounds__(256) void k_dn_load(Dense d, const double *S, const
     if (blockIdx.x == 0 && threadIdx.x == 0) d.ctl[kCtlFail] = 0;
 }
 
-// the diagonal block of panel p, factored in LDS
-__global__ __launch_bounds__(256) void k_dn_panel(Dense d, int p0, int attempt) {
+// the diagonal block of panel p, factored by ONE wave: lane r holds row r in registers, a pivot's scaled column reaches the other
+// lanes through LDS as broadcast reads (the loops are unrolled: every register index and LDS offset is a constant), no workgroup
+// barrier.  (The first version — 256 threads on the block in LDS, three barriers and an IEEE sqrt + divide per pivot — took 49 us a
+// panel, a third of the solver's time; the column by v_readlane instead of LDS 26 us: two readlanes and their hazard slots per product.)
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// 1 / sqrt(x) in double: the float32 seed and three Newton steps (the third is there for the seed's worst case; x > 0, and scaled so
+// that the float32 seed neither overflows nor flushes)
+__device__ __forceinline__ double rsqrt_d(double x) {
+    int e;
+    const double m = frexp(x, &e);                             // x = m 2^e, m in [0.5, 1)
+    const int h = e >> 1;                                       // x = (m 2^(e - 2h)) 4^h, the bracket in [0.5, 2)
+    const double xs = ldexp(m, e - 2 * h);
+    double y = (double)__builtin_amdgcn_rsqf((float)xs);
+    y = y * (1.5 - 0.5 * xs * y * y);
+    y = y * (1.5 - 0.5 * xs * y * y);
+    y = y * (1.5 - 0.5 * xs * y * y);
+    return ldexp(y, -h);
+}
+#define BT_DN_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+__global__ __launch_bounds__(64) void k_dn_panel(Dense d, int p0, int attempt) {
     if (skip(d, attempt) || d.ctl[kCtlFail]) return;
-    __shared__ double A[NB][NB + 1];
-    __shared__ int bad;
-    const int tid = threadIdx.x, nb = min(NB, d.D - p0);
-    if (tid == 0) bad = 0;
-    for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, c = i - r * nb; A[r][c] = c <= r ? d.L[(size_t)(p0 + r) * d.D + p0 + c] : 0.0; }
-    __syncthreads();
-    for (int k = 0; k < nb; ++k) {
-        const double piv = A[k][k];
-        if (!(piv > 0.0)) { if (tid == 0) bad = 1; break; }          // (every thread sees the same pivot: a uniform exit)
-        const double il = 1.0 / sqrt(piv);
-        __syncthreads();
-        if (tid == 0) A[k][k] = sqrt(piv);
-        for (int r = k + 1 + tid; r < nb; r += 256) A[r][k] *= il;
-        __syncthreads();
-        const int m = nb - k - 1;                                      // trailing block: rows, cols k+1 .. nb-1, lower part
-        for (int i = tid; i < m * m; i += 256) {
-            const int r = k + 1 + i / m, c = k + 1 + i % m;
-            if (c <= r) A[r][c] -= A[r][k] * A[c][k];
-        }
-        __syncthreads();
+    // a pivot's scaled column, for every lane to read (the same address in all lanes: a broadcast); two copies taking turns, so that
+    // a pivot's store never meets the reads of the pivot before it
+    __shared__ __attribute__((aligned(16))) double col[2][NB + 16];
+    const int lane = threadIdx.x, nb = min(NB, d.D - p0);
+    const bool act = lane < nb;
+    // (rows and columns beyond the block: the identity, so that their pivots are 1 and nothing of them reaches the block)
+    double row[NB];
+    const double *src = d.L + (size_t)(p0 + min(lane, nb - 1)) * d.D + p0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) row[c] = (act && c <= lane) ? src[c] : (c == lane ? 1.0 : 0.0);
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double akk = readlane_d(row[k], k);
+        if (!(akk > 0.0)) { bad = true; break; }                  // (the same value in every lane: a uniform exit)
+        const double il = rsqrt_d(akk);
+        const double lrk = lane > k ? row[k] * il : lane == k ? akk * il : 0.0;
+        row[k] = lrk;
+        double *ck = col[k & 1];
+        ck[lane] = lrk;                                           // (lanes 48 .. 63 store zeros behind the column)
+        BT_DN_WAVE_SYNC();
+#pragma unroll
+        for (int c = k + 1; c < NB; ++c) row[c] = fma(-lrk, ck[c], row[c]);      // (used for c <= lane only)
     }
-    __syncthreads();
-    if (bad) { if (tid == 0) d.ctl[kCtlFail] = 1; return; }
-    for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, c = i - r * nb; if (c <= r) d.L[(size_t)(p0 + r) * d.D + p0 + c] = A[r][c]; }
+    if (bad) { if (lane == 0) d.ctl[kCtlFail] = 1; return; }
+    if (act) {
+        double *dst = d.L + (size_t)(p0 + lane) * d.D + p0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) if (c <= lane) dst[c] = row[c];
+    }
 }
 
-// the rows below the panel: L[r, panel] = A[r, panel] L_pp^-T, one thread per row
+// the rows below the panel: L[r, panel] = A[r, panel] L_pp^-T, one thread per row (the diagonal's reciprocals once per workgroup).
+// 35 us a panel and now the solver's largest kernel: a wave's time is the LDS latency under each of its 1128 dependent
+// multiply-adds.  (Column by column with the finished x[c] taken out of the columns behind it at once — independent multiply-adds —
+// was written and not kept: the compiler hoists the 1128 LDS reads of the unrolled triangle to the top, 256 registers and 7.8 KB of
+// scratch a lane, memory clobbers or scheduling barriers between the columns notwithstanding.  The form that would pay is the
+// inverse of the diagonal block from the panel's wave and this kernel as a plain tile product.)
 __global__ __launch_bounds__(256) void k_dn_trsm(Dense d, int p0, int attempt) {
     if (skip(d, attempt) || d.ctl[kCtlFail]) return;
     __shared__ double Lp[NB][NB + 1];
+    __shared__ double inv[NB];
     const int tid = threadIdx.x, nb = min(NB, d.D - p0), p1 = p0 + nb;
     for (int i = tid; i < nb * nb; i += 256) { const int r = i / nb, c = i - r * nb; Lp[r][c] = c <= r ? d.L[(size_t)(p0 + r) * d.D + p0 + c] : 0.0; }
+    __syncthreads();
+    if (tid < NB) inv[tid] = tid < nb ? 1.0 / Lp[tid][tid] : 0.0;
     __syncthreads();
     const int r = p1 + blockIdx.x * 256 + tid;
     if (r >= d.D) return;
@@ -95,7 +132,7 @@ __global__ __launch_bounds__(256) void k_dn_trsm(Dense d, int p0, int attempt) {
             double t = x[c];
 #pragma unroll
             for (int k = 0; k < c; ++k) t -= x[k] * Lp[c][k];
-            x[c] = t / Lp[c][c];
+            x[c] = t * inv[c];
         }
     }
 #pragma unroll
@@ -122,6 +159,8 @@ __global__ __launch_bounds__(256) void k_dn_syrk(Dense d, int p0, int attempt) {
     __syncthreads();
     const int ty = tid >> 4, tx = tid & 15;                  // 16 x 16 threads, 3 x 3 outputs each
     double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    // (not unrolled all the way: 48 x 6 operands in flight took 256 registers and 388 bytes of scratch a lane — the largest launch 121 us)
+#pragma unroll 4
     for (int k = 0; k < NB; ++k) {
         double a[3], b[3];
 #pragma unroll
@@ -147,7 +186,6 @@ __global__ __launch_bounds__(1024) void k_dn_solve(Dense d, float *dx, int *stat
     const int tid = threadIdx.x, D = d.D;
     double *z = sm;                                          // [D]
     double *part = z + D;                                    // [NB][kSl]
-    double *t = part + NB * 21;                              // [NB]
     constexpr int kSl = 21;                                  // slices per panel row / column: 48 x 21 = 1008 threads
     __shared__ double Lp[NB][NB + 1];
     __shared__ int has_nan;
@@ -172,42 +210,45 @@ __global__ __launch_bounds__(1024) void k_dn_solve(Dense d, float *dx, int *stat
             part[q * kSl + sl] = acc;
         }
         __syncthreads();
-        if (tid < nb) { double acc = z[p0 + tid]; for (int s = 0; s < kSl; ++s) acc -= part[tid * kSl + s]; t[tid] = acc; }
-        __syncthreads();
-        if (tid < 64) {                                      // one wave: the panel's triangle, a lane per row
+        if (tid < 64) {                                      // one wave: the panel's triangle, a lane per row, its unknown in a register
+            double tv = 0.0, invd = 0.0;
+            if (tid < nb) { tv = z[p0 + tid]; for (int s = 0; s < kSl; ++s) tv -= part[tid * kSl + s]; invd = 1.0 / Lp[tid][tid]; }
+#pragma unroll 4
             for (int k = 0; k < nb; ++k) {
-                const double zk = t[k] / Lp[k][k];
-                if (tid == k) t[k] = zk;
-                if (tid > k && tid < nb) t[tid] -= Lp[tid][k] * zk;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double lk = Lp[min(tid, NB - 1)][k];
+                const double zk = readlane_d(tv, k) * readlane_d(invd, k);
+                if (tid == k) tv = zk;
+                else if (tid > k && tid < nb) tv = fma(-lk, zk, tv);
             }
+            if (tid < nb) z[p0 + tid] = tv;
         }
-        __syncthreads();
-        if (tid < nb) z[p0 + tid] = t[tid];
         __syncthreads();
     }
     // ---- L^T x = w
     for (int p0 = ((D - 1) / NB) * NB; p0 >= 0; p0 -= NB) {
         const int nb = min(NB, D - p0), p1 = p0 + nb;
         for (int i = tid; i < nb * nb; i += 1024) { const int r = i / nb, c = i - r * nb; Lp[r][c] = c <= r ? d.L[(size_t)(p0 + r) * D + p0 + c] : 0.0; }
-        if (q < nb) {
-            double acc = 0.0;
-            for (int r = p1 + sl; r < D; r += kSl) acc += d.L[(size_t)r * D + p0 + q] * z[r];
-            part[q * kSl + sl] = acc;
-        }
-        __syncthreads();
-        if (tid < nb) { double acc = z[p0 + tid]; for (int s = 0; s < kSl; ++s) acc -= part[tid * kSl + s]; t[tid] = acc; }
-        __syncthreads();
-        if (tid < 64) {
-            for (int k = nb - 1; k >= 0; --k) {
-                const double xk = t[k] / Lp[k][k];
-                if (tid == k) t[k] = xk;
-                if (tid < k) t[tid] -= Lp[k][tid] * xk;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {   // (a column per LANE here: the wave's loads of a row of L are then contiguous — with the forward sweep's mapping every lane
+            //  of a load sat in a row of its own, and this kernel took 1.2 ms of a 255-pose solve)
+            const int qb = tid % NB, sb = tid / NB;
+            if (sb < kSl && qb < nb) {
+                double acc = 0.0;
+                for (int r = p1 + sb; r < D; r += kSl) acc += d.L[(size_t)r * D + p0 + qb] * z[r];
+                part[qb * kSl + sb] = acc;
             }
         }
         __syncthreads();
-        if (tid < nb) z[p0 + tid] = t[tid];
+        if (tid < 64) {
+            double tv = 0.0, invd = 0.0;
+            if (tid < nb) { tv = z[p0 + tid]; for (int s = 0; s < kSl; ++s) tv -= part[tid * kSl + s]; invd = 1.0 / Lp[tid][tid]; }
+            for (int k = nb - 1; k >= 0; --k) {
+                const double lk = Lp[k][min(tid, NB - 1)];
+                const double xk = readlane_d(tv, k) * readlane_d(invd, k);
+                if (tid == k) tv = xk;
+                else if (tid < k) tv = fma(-lk, xk, tv);
+            }
+            if (tid < nb) z[p0 + tid] = tv;
+        }
         __syncthreads();
     }
     for (int i = tid; i < D; i += 1024) if (z[i] != z[i]) has_nan = 1;
@@ -239,7 +280,7 @@ int launch_solve_dense(const PlanDev &pd, const StepArgs &a, hipStream_t st, hip
         else hipLaunchKernelGGL(k_dn_load, dim3(nload), dim3(256), 0, st, d, a.S, a.y, a.ep, attempt);
         for (int p0 = 0; p0 < D; p0 += NB) {
             const int p1 = std::min(D, p0 + NB), below = D - p1;
-            hipLaunchKernelGGL(k_dn_panel, dim3(1), dim3(256), 0, st, d, p0, attempt);
+            hipLaunchKernelGGL(k_dn_panel, dim3(1), dim3(64), 0, st, d, p0, attempt);
             if (below > 0) {
                 hipLaunchKernelGGL(k_dn_trsm, dim3((below + 255) / 256), dim3(256), 0, st, d, p0, attempt);
                 const int nt = (below + NB - 1) / NB;

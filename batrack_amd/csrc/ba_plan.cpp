@@ -1268,17 +1268,18 @@ int build_plan_host(const int64_t *ii64, const int64_t *jj64, const int64_t *kk6
     if (!pl->wide) {
         const int src_rc = symbolic();
         if (src_rc != BT_OK) return src_rc;
-        // The factor does not fit LDS as double: float32 with refinement (three solves), or the dense solver — whichever is priced
-        // lower.  Measured (tools/gpu_solver_choice.py, profiles/r06_solver_choice.txt): a block-sparse solve outside LDS-as-double
-        // costs ~8 us a level + 26 ns a block update (a 255-pose band of half-width 7: 131 levels, 7k updates, 1.2 ms; 255 poses
-        // tied by long-range edges: 2.8M updates, 70 ms), the dense solver ~19 us a pose whatever the pattern (launch-bound: 3
-        // launches per 48 columns, 255 poses 4.9 ms).  Long bands stay block-sparse, filled-in systems go dense (95 poses: 12.4 ->
-        // 1.6 ms a step, 255: 210 -> 5.3 ms) and get a float64 factor with it.
+        // The factor does not fit LDS as double: float32 with refinement, or the dense solver — whichever is priced lower.  Measured
+        // (tools/gpu_solver_choice.py, profiles/r06_solver_choice.txt): a block-sparse solve costs ~2.5 us a level where the float32
+        // factor fits LDS, ~8 us from global memory, + 26 ns a block update, and a step takes two of them (three where the first
+        // refinement step has not converged) — a 255-pose band of half-width 7: 131 levels, 7k updates, 2.4 ms a step; 255 poses
+        // tied by long-range edges: 2.8M updates, 140 ms; the dense solver ~12 us a pose whatever the pattern (255 poses 3.1 ms).
+        // Long bands stay block-sparse, filled-in systems go dense (95 poses: 12.4 -> 1.0 ms a step, 255: 211 -> 3.5 ms) and get
+        // a float64 factor with it.
         // (a forced solver — tests, measurement — keeps the block-sparse tables whatever their size)
         const size_t nlev = pl->lvl_ptr.size() - 1;
-        if (force().solver < 0 &&
-            solve_lds_bytes_raw((size_t)I.nnz_blocks, (size_t)(6 * n), (size_t)I.updates, (size_t)n, nlev, pl->dp.size(), sizeof(double)) > kLdsBudget &&
-            3.0 * (8.0 * (double)nlev + 0.026 * (double)I.updates) > 19.0 * (double)n)
+        const auto lds_at = [&](size_t elem) { return solve_lds_bytes_raw((size_t)I.nnz_blocks, (size_t)(6 * n), (size_t)I.updates, (size_t)n, nlev, pl->dp.size(), elem); };
+        const double level_us = lds_at(sizeof(float)) <= kLdsBudget ? 2.5 : 8.0;
+        if (force().solver < 0 && lds_at(sizeof(double)) > kLdsBudget && 2.2 * (level_us * (double)nlev + 0.026 * (double)I.updates) > 12.0 * (double)n)
             go_wide();
     }
 

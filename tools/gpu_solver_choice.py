@@ -15,7 +15,10 @@ from batrack_amd.plan import Plan, Stepper
 
 dev = "cuda:0"
 print("BT_FORCE =", os.environ.get("BT_FORCE", ""))
-for N, far in ((64, 0.0), (96, 0.0), (128, 0.0), (192, 0.0), (256, 0.0), (48, 0.3), (96, 0.3), (160, 0.3), (256, 0.3)):
+CASES = ((64, 0.0), (96, 0.0), (128, 0.0), (192, 0.0), (256, 0.0), (48, 0.3), (96, 0.3), (160, 0.3), (256, 0.3))
+if len(sys.argv) > 1 and sys.argv[1] == "dense":                  # (for a kernel trace of the dense solver alone)
+    CASES = ((96, 0.3), (256, 0.3))
+for N, far in CASES:
     g = graphgen.make_graph(N, 64, 8, seed=N)
     ii, jj, kk = g.ii.copy(), g.jj.copy(), g.kk.copy()
     t3 = np.asarray(g.targets3, np.float64).copy()
