@@ -97,3 +97,27 @@ def test_partition_tracks_properties():
             assert h0 == l1 and l0 <= h0
         counts = [int(((kk >= lo) & (kk < hi)).sum()) for lo, hi in b]
         assert sum(counts) == len(kk)
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_ranks_agree_on_the_solver_of_a_mid_size_system(world):
+    """Late round 6: a plan whose block-sparse factor does not fit LDS as double is priced and may go to the dense solver
+    (ba_plan.cpp) — a decision every rank of a sharded solve must take alike, from the pattern of the WHOLE list, whatever its own
+    track range: the packed exchange form (every lower block / the factor's blocks) hangs on it."""
+    from batrack_amd.parallel import partition_tracks, plan_range
+    from batrack_amd.plan import Plan
+    rng = np.random.default_rng(11)
+    N, M, K = 110, 64, 8
+    kk = np.repeat(np.arange(N * M, dtype=np.int64), K); ii = kk // M
+    band = np.clip(ii + np.tile(np.arange(K, dtype=np.int64) - 3, N * M), 0, N - 1)
+    filled = np.where(rng.random(ii.size) < 0.3, rng.integers(0, N, ii.size), band)
+    for jj, dense in ((band, False), (filled, True)):
+        whole = Plan(ii, jj, kk, N, N * M, 1, upload=False)
+        n = whole.n
+        assert (whole.nnz_blocks == n * (n + 1) // 2) == dense
+        seen = set()
+        for rank, own in enumerate(partition_tracks(kk, world)):
+            pl = Plan(ii, jj, kk, N, N * M, 1, upload=False, own=plan_range(own, N * M))
+            seen.add((pl.n, pl.nnz_blocks, pl.updates, tuple(pl.array("perm")[:8])))
+        assert len(seen) == 1, seen
+        assert (next(iter(seen))[1] == n * (n + 1) // 2) == dense
